@@ -1,0 +1,446 @@
+"""ctypes view of include/gorder_hip.h plus a thin engine wrapper.
+
+Python is harness only (tests, bench, multi-GPU launcher): the product is the C-ABI library
+``gorder_amd/libgorder_hip.so`` built from ``gorder_amd/csrc`` (hand-written HIP for gfx950).
+There is NO CPU fallback here: if the library or a GPU is missing every call raises.
+
+The table classes mirror what gorder's ``SystemTopology`` holds for this path
+(/root/reference/src/analysis/topology/mod.rs:34-65, topology/bond.rs:220-246,
+leaflets.rs:575-590, 744-775).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgorder_hip.so")
+
+# ---- status codes (gorder_status_t) ---------------------------------------------------------
+OK = 0
+ERR_UNDEFINED_BOX = 1
+ERR_NOT_ORTHOGONAL_BOX = 2
+ERR_ZERO_BOX = 3
+ERR_UNDEFINED_POSITION = 4
+ERR_INVALID_GLOBAL_MEMBRANE_CENTER = 5
+ERR_INVALID_LOCAL_MEMBRANE_CENTER = 6
+ERR_INVALID_ARGUMENT = 100
+ERR_DEVICE = 101
+ERR_NO_DEVICE = 102
+ERR_BOX_RANGE = 103
+ERR_LEAFLETS_NOT_PRIMED = 104
+ERR_OVERFLOW = 105
+
+LEAFLETS_NONE, LEAFLETS_GLOBAL, LEAFLETS_LOCAL, LEAFLETS_INDIVIDUAL, LEAFLETS_MANUAL = range(5)
+UA_CH1_SAT, UA_CH2, UA_CH3, UA_CH1_UNSAT = 1, 2, 3, 4
+UA_N_H = {UA_CH1_SAT: 1, UA_CH2: 2, UA_CH3: 3, UA_CH1_UNSAT: 1}
+
+_u32p = C.POINTER(C.c_uint32)
+
+
+class CLeaflets(C.Structure):
+    _fields_ = [("method", C.c_uint32), ("normal_dim", C.c_uint32), ("frequency", C.c_uint32),
+                ("flip", C.c_uint32), ("radius", C.c_float), ("n_membrane", C.c_uint32),
+                ("membrane", _u32p)]
+
+
+class COrderMap(C.Structure):
+    _fields_ = [("enabled", C.c_uint32), ("plane", C.c_uint32), ("span_x", C.c_float * 2),
+                ("span_y", C.c_float * 2), ("bin", C.c_float * 2)]
+
+
+class CUaAtom(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("indices", _u32p)]
+
+
+class CMolType(C.Structure):
+    _fields_ = [("n_molecules", C.c_uint32), ("n_bond_types", C.c_uint32), ("bonds", _u32p),
+                ("n_ua_atoms", C.c_uint32), ("ua_atoms", C.POINTER(CUaAtom)), ("heads", _u32p),
+                ("n_methyls", C.c_uint32), ("methyls", _u32p)]
+
+
+class CTables(C.Structure):
+    _fields_ = [("n_atoms", C.c_uint32), ("n_molecule_types", C.c_uint32),
+                ("molecule_types", C.POINTER(CMolType)), ("handle_pbc", C.c_int32),
+                ("normal", C.c_float * 3), ("leaflets", CLeaflets), ("ordermap", COrderMap),
+                ("timewise", C.c_int32), ("device", C.c_int32)]
+
+
+class CPlan(C.Structure):
+    _fields_ = [("n_tiles", C.c_uint32), ("block_threads", C.c_uint32),
+                ("max_window_atoms", C.c_uint32), ("n_direct_items", C.c_uint32),
+                ("frames_per_stage", C.c_uint32), ("lds_bytes", C.c_uint32)]
+
+
+# ---- python-side description of the tables ----------------------------------------------------
+def _u32(a, shape=None) -> Optional[np.ndarray]:
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def _ptr(a: Optional[np.ndarray]):
+    if a is None or a.size == 0:
+        return _u32p()
+    return a.ctypes.data_as(_u32p)
+
+
+@dataclass
+class MolType:
+    """One molecule type (topology/molecule.rs:146-169) reduced to its index tables."""
+    n_molecules: int
+    bonds: Optional[np.ndarray] = None        # [n_bond_types, n_molecules, 2] uint32
+    ua_atoms: List[tuple] = field(default_factory=list)   # [(kind, indices[n_molecules, 4])]
+    heads: Optional[np.ndarray] = None        # [n_molecules]
+    methyls: Optional[np.ndarray] = None      # [n_molecules, n_methyls]
+    name: str = ""
+
+    @property
+    def n_bond_types(self) -> int:
+        return 0 if self.bonds is None else int(np.asarray(self.bonds).shape[0])
+
+    @property
+    def n_slots(self) -> int:
+        return self.n_bond_types + sum(UA_N_H[int(k)] for k, _ in self.ua_atoms)
+
+
+@dataclass
+class Leaflets:
+    method: int = LEAFLETS_NONE
+    normal_dim: int = 2
+    frequency: int = 1      # 0 = once; REAL frequency (input frequency * step)
+    flip: bool = False
+    radius: float = 0.0
+    membrane: Optional[np.ndarray] = None
+
+
+@dataclass
+class OrderMap:
+    enabled: bool = False
+    plane: int = 0
+    span_x: Sequence[float] = (0.0, 0.0)
+    span_y: Sequence[float] = (0.0, 0.0)
+    bin: Sequence[float] = (0.1, 0.1)
+
+
+@dataclass
+class Tables:
+    n_atoms: int
+    molecule_types: List[MolType]
+    handle_pbc: bool = True
+    normal: Sequence[float] = (0.0, 0.0, 1.0)
+    leaflets: Leaflets = field(default_factory=Leaflets)
+    ordermap: OrderMap = field(default_factory=OrderMap)
+    timewise: bool = False
+    device: int = 0
+
+    @property
+    def n_acc(self) -> int:
+        return sum(m.n_slots for m in self.molecule_types)
+
+    @property
+    def n_molecules_total(self) -> int:
+        return sum(m.n_molecules for m in self.molecule_types)
+
+    @property
+    def n_samples_per_frame(self) -> int:
+        return sum(m.n_slots * m.n_molecules for m in self.molecule_types)
+
+    def as_ctypes(self):
+        """-> (CTables, keepalive list).  The C side copies what it needs during create()."""
+        keep = []
+        mts = (CMolType * max(1, len(self.molecule_types)))()
+        for k, m in enumerate(self.molecule_types):
+            c = mts[k]
+            c.n_molecules = m.n_molecules
+            b = _u32(m.bonds, (-1, m.n_molecules, 2)) if m.bonds is not None else None
+            c.n_bond_types = 0 if b is None else b.shape[0]
+            c.bonds = _ptr(b)
+            ua = (CUaAtom * max(1, len(m.ua_atoms)))()
+            for q, (kind, idx) in enumerate(m.ua_atoms):
+                ia = _u32(idx, (m.n_molecules, 4))
+                ua[q].kind = int(kind)
+                ua[q].indices = _ptr(ia)
+                keep.append(ia)
+            c.n_ua_atoms = len(m.ua_atoms)
+            c.ua_atoms = C.cast(ua, C.POINTER(CUaAtom))
+            h = _u32(m.heads, (m.n_molecules,)) if m.heads is not None else None
+            c.heads = _ptr(h)
+            me = _u32(m.methyls, (m.n_molecules, -1)) if m.methyls is not None else None
+            c.n_methyls = 0 if me is None else me.shape[1]
+            c.methyls = _ptr(me)
+            keep += [b, ua, h, me]
+        t = CTables()
+        t.n_atoms = self.n_atoms
+        t.n_molecule_types = len(self.molecule_types)
+        t.molecule_types = C.cast(mts, C.POINTER(CMolType))
+        t.handle_pbc = 1 if self.handle_pbc else 0
+        t.normal[:] = [float(x) for x in self.normal]
+        lf = self.leaflets
+        mem = _u32(lf.membrane) if lf.membrane is not None else None
+        t.leaflets.method = lf.method
+        t.leaflets.normal_dim = lf.normal_dim
+        t.leaflets.frequency = lf.frequency
+        t.leaflets.flip = 1 if lf.flip else 0
+        t.leaflets.radius = lf.radius
+        t.leaflets.n_membrane = 0 if mem is None else mem.size
+        t.leaflets.membrane = _ptr(mem)
+        om = self.ordermap
+        t.ordermap.enabled = 1 if om.enabled else 0
+        t.ordermap.plane = om.plane
+        t.ordermap.span_x[:] = [float(x) for x in om.span_x]
+        t.ordermap.span_y[:] = [float(x) for x in om.span_y]
+        t.ordermap.bin[:] = [float(x) for x in om.bin]
+        t.timewise = 1 if self.timewise else 0
+        t.device = self.device
+        keep += [mts, mem]
+        return t, keep
+
+
+# ---- the library ------------------------------------------------------------------------------
+_EXPORTS = [
+    "gorder_hip_create", "gorder_hip_destroy", "gorder_hip_n_accumulators", "gorder_hip_ordermap_dims",
+    "gorder_hip_set_stream", "gorder_hip_submit_device", "gorder_hip_submit_host",
+    "gorder_hip_prime_leaflets", "gorder_hip_set_manual_leaflets", "gorder_hip_synchronize",
+    "gorder_hip_finish", "gorder_hip_timewise", "gorder_hip_leaflets", "gorder_hip_leaflet_distances",
+    "gorder_hip_accumulators_device", "gorder_hip_bind_accumulators", "gorder_hip_last_error_index",
+    "gorder_hip_last_error_message", "gorder_hip_strerror", "gorder_hip_kernel_time", "gorder_hip_plan",
+    "gorder_hip_plan_tables",
+]
+
+_lib = None
+
+
+class GorderHipError(RuntimeError):
+    def __init__(self, status: int, message: str = "", index: int = 0):
+        self.status = status
+        self.index = index
+        super().__init__(f"gorder_hip status {status}: {message}")
+
+
+def load_library() -> C.CDLL:
+    """Load libgorder_hip.so (built by __graft_entry__.build / make -C gorder_amd/csrc). Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GorderHipError(ERR_NO_DEVICE, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; "
+                                            "g.build()'` (there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+    lib.gorder_hip_create.argtypes = [C.POINTER(CTables), C.POINTER(vp)]
+    lib.gorder_hip_destroy.argtypes = [vp]
+    lib.gorder_hip_destroy.restype = None
+    lib.gorder_hip_n_accumulators.argtypes = [vp]
+    lib.gorder_hip_n_accumulators.restype = u32
+    lib.gorder_hip_ordermap_dims.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
+    lib.gorder_hip_ordermap_dims.restype = u32
+    lib.gorder_hip_set_stream.argtypes = [vp, vp]
+    lib.gorder_hip_submit_device.argtypes = [vp, vp, vp, vp, u32]
+    lib.gorder_hip_submit_host.argtypes = [vp, vp, vp, vp, u32]
+    lib.gorder_hip_prime_leaflets.argtypes = [vp, vp, vp, u64]
+    lib.gorder_hip_set_manual_leaflets.argtypes = [vp, vp, u64]
+    lib.gorder_hip_synchronize.argtypes = [vp]
+    lib.gorder_hip_finish.argtypes = [vp, vp, vp, vp, vp, C.POINTER(u64)]
+    lib.gorder_hip_timewise.argtypes = [vp, vp, vp, u64]
+    lib.gorder_hip_leaflets.argtypes = [vp, vp, C.POINTER(u64)]
+    lib.gorder_hip_leaflet_distances.argtypes = [vp, vp]
+    lib.gorder_hip_accumulators_device.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
+    lib.gorder_hip_bind_accumulators.argtypes = [vp, vp, u64]
+    lib.gorder_hip_last_error_index.argtypes = [vp]
+    lib.gorder_hip_last_error_index.restype = u64
+    lib.gorder_hip_last_error_message.argtypes = [vp]
+    lib.gorder_hip_last_error_message.restype = C.c_char_p
+    lib.gorder_hip_strerror.argtypes = [i32]
+    lib.gorder_hip_strerror.restype = C.c_char_p
+    lib.gorder_hip_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64), i32]
+    lib.gorder_hip_plan.argtypes = [vp, C.POINTER(CPlan)]
+    lib.gorder_hip_plan_tables.argtypes = [C.POINTER(CTables), C.POINTER(CPlan), C.POINTER(i32)]
+    _lib = lib
+    return lib
+
+
+def plan_tables(tables: Tables) -> dict:
+    """Host-only: how the library would tile these tables (no device needed)."""
+    lib = load_library()
+    ct, keep = tables.as_ctypes()
+    plan, check = CPlan(), C.c_int(-1)
+    st = lib.gorder_hip_plan_tables(C.byref(ct), C.byref(plan), C.byref(check))
+    if st != OK:
+        raise GorderHipError(st, lib.gorder_hip_strerror(st).decode())
+    d = {name: getattr(plan, name) for name, _ in CPlan._fields_}
+    d["selfcheck"] = check.value
+    return d
+
+
+@dataclass
+class Results:
+    sums: np.ndarray        # int64  [3, n_acc]   total / upper / lower
+    counts: np.ndarray      # uint64 [3, n_acc]
+    n_frames: int
+    map_sums: Optional[np.ndarray] = None
+    map_counts: Optional[np.ndarray] = None
+
+    def order(self, min_samples: int = 1) -> np.ndarray:
+        """AnalysisOrder::calc_order (order.rs:101-107): truncating i64 division, then /1e6 as f32."""
+        out = np.full(self.sums.shape, np.nan, dtype=np.float32)
+        n = self.counts.astype(np.int64)
+        ok = n >= max(1, min_samples)
+        # Rust i64 `/` truncates toward zero (numpy // floors)
+        q = (np.abs(self.sums[ok]) // n[ok]) * np.sign(self.sums[ok])
+        out[ok] = (q.astype(np.float64) / 1e6).astype(np.float32)
+        return out
+
+
+class HipEngine:
+    """One `SystemTopology` on one GPU (one handle per rank / stream)."""
+
+    def __init__(self, tables: Tables):
+        self.lib = load_library()
+        self.tables = tables
+        ct, keep = tables.as_ctypes()
+        self._h = C.c_void_p()
+        st = self.lib.gorder_hip_create(C.byref(ct), C.byref(self._h))
+        if st != OK:
+            msg = self.lib.gorder_hip_strerror(st).decode()
+            if self._h:
+                msg += ": " + self.lib.gorder_hip_last_error_message(self._h).decode()
+                self.lib.gorder_hip_destroy(self._h)
+                self._h = C.c_void_p()
+            raise GorderHipError(st, msg)
+        self.n_acc = self.lib.gorder_hip_n_accumulators(self._h)
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.gorder_hip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st: int):
+        if st != OK:
+            msg = self.lib.gorder_hip_strerror(st).decode() + ": " + \
+                self.lib.gorder_hip_last_error_message(self._h).decode()
+            raise GorderHipError(st, msg, self.lib.gorder_hip_last_error_index(self._h))
+
+    def set_stream(self, stream_ptr: int):
+        self._check(self.lib.gorder_hip_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def use_torch_stream(self):
+        import torch
+        self.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    @staticmethod
+    def _frame_index(frame_index, n_frames):
+        if frame_index is None:
+            frame_index = np.arange(n_frames, dtype=np.uint64)
+        fi = np.ascontiguousarray(frame_index, dtype=np.uint64)
+        assert fi.shape == (n_frames,)
+        return fi
+
+    def submit_device(self, xyz, box, frame_index=None):
+        """xyz: torch float32 CUDA tensor [F, N, 3]; box: [F, 3, 3] (or None when handle_pbc=False)."""
+        assert xyz.is_cuda and xyz.is_contiguous() and xyz.dtype.is_floating_point and xyz.element_size() == 4
+        n_frames = xyz.shape[0]
+        assert xyz.shape[1] == self.tables.n_atoms and xyz.shape[2] == 3
+        fi = self._frame_index(frame_index, n_frames)
+        bp = None
+        if box is not None:
+            assert box.is_cuda and box.is_contiguous() and box.numel() == 9 * n_frames
+            bp = C.c_void_p(box.data_ptr())
+        self._check(self.lib.gorder_hip_submit_device(self._h, C.c_void_p(xyz.data_ptr()), bp,
+                                                      fi.ctypes.data_as(C.c_void_p), n_frames))
+
+    def submit_host(self, xyz: np.ndarray, box: Optional[np.ndarray], frame_index=None):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        n_frames = xyz.shape[0]
+        assert xyz.shape[1:] == (self.tables.n_atoms, 3)
+        fi = self._frame_index(frame_index, n_frames)
+        bp = None
+        if box is not None:
+            box = np.ascontiguousarray(box, dtype=np.float32).reshape(n_frames, 9)
+            bp = box.ctypes.data_as(C.c_void_p)
+        self._check(self.lib.gorder_hip_submit_host(self._h, xyz.ctypes.data_as(C.c_void_p), bp,
+                                                    fi.ctypes.data_as(C.c_void_p), n_frames))
+
+    def prime_leaflets_device(self, xyz, box, frame_index: int):
+        bp = C.c_void_p(box.data_ptr()) if box is not None else None
+        self._check(self.lib.gorder_hip_prime_leaflets(self._h, C.c_void_p(xyz.data_ptr()), bp, frame_index))
+
+    def set_manual_leaflets(self, flags: np.ndarray, frame_index: int = 0):
+        flags = np.ascontiguousarray(flags, dtype=np.uint8)
+        assert flags.size == self.tables.n_molecules_total
+        self._check(self.lib.gorder_hip_set_manual_leaflets(self._h, flags.ctypes.data_as(C.c_void_p), frame_index))
+
+    def synchronize(self):
+        self._check(self.lib.gorder_hip_synchronize(self._h))
+
+    def finish(self) -> Results:
+        n = self.n_acc
+        sums = np.zeros((3, n), dtype=np.int64)
+        counts = np.zeros((3, n), dtype=np.uint64)
+        nx, ny = C.c_uint32(), C.c_uint32()
+        nt = self.lib.gorder_hip_ordermap_dims(self._h, C.byref(nx), C.byref(ny))
+        ms = mc = None
+        msp = mcp = None
+        if nt:
+            ms = np.zeros((3, n, nx.value, ny.value), dtype=np.int64)
+            mc = np.zeros((3, n, nx.value, ny.value), dtype=np.uint64)
+            msp, mcp = ms.ctypes.data_as(C.c_void_p), mc.ctypes.data_as(C.c_void_p)
+        nf = C.c_uint64()
+        self._check(self.lib.gorder_hip_finish(self._h, sums.ctypes.data_as(C.c_void_p),
+                                               counts.ctypes.data_as(C.c_void_p), msp, mcp, C.byref(nf)))
+        return Results(sums, counts, int(nf.value), ms, mc)
+
+    def timewise(self, n_frames: int):
+        n = self.n_acc
+        s = np.zeros((n_frames, 3, n), dtype=np.int64)
+        c = np.zeros((n_frames, 3, n), dtype=np.uint64)
+        self._check(self.lib.gorder_hip_timewise(self._h, s.ctypes.data_as(C.c_void_p),
+                                                 c.ctypes.data_as(C.c_void_p), n_frames))
+        return s, c
+
+    def leaflets(self):
+        flags = np.zeros(self.tables.n_molecules_total, dtype=np.uint8)
+        fr = C.c_uint64()
+        self._check(self.lib.gorder_hip_leaflets(self._h, flags.ctypes.data_as(C.c_void_p), C.byref(fr)))
+        return flags, int(fr.value)
+
+    def leaflet_distances(self) -> np.ndarray:
+        d = np.zeros(self.tables.n_molecules_total, dtype=np.float32)
+        self._check(self.lib.gorder_hip_leaflet_distances(self._h, d.ctypes.data_as(C.c_void_p)))
+        return d
+
+    def accumulator_words(self) -> int:
+        p, n = C.c_void_p(), C.c_uint64()
+        self._check(self.lib.gorder_hip_accumulators_device(self._h, C.byref(p), C.byref(n)))
+        return int(n.value)
+
+    def bind_accumulators(self, tensor):
+        """Accumulate into a caller-owned torch.int64 CUDA tensor (so that torch.distributed can
+        all-reduce it over RCCL)."""
+        assert tensor.is_cuda and tensor.is_contiguous() and tensor.element_size() == 8
+        self._keep.append(tensor)
+        self._check(self.lib.gorder_hip_bind_accumulators(self._h, C.c_void_p(tensor.data_ptr()), tensor.numel()))
+
+    def kernel_time(self, reset: bool = False):
+        ms, n = C.c_double(), C.c_uint64()
+        self._check(self.lib.gorder_hip_kernel_time(self._h, C.byref(ms), C.byref(n), 1 if reset else 0))
+        return ms.value, int(n.value)
+
+    def plan(self) -> dict:
+        p = CPlan()
+        self._check(self.lib.gorder_hip_plan(self._h, C.byref(p)))
+        return {name: getattr(p, name) for name, _ in CPlan._fields_}

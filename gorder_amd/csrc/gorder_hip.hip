@@ -1,0 +1,948 @@
+// gorder_hip.hip — MI355X (gfx950) kernels + C ABI of the lipid-order engine.
+//
+// Path accelerated (reference file:line under /root/reference/src/analysis):
+//   analyze_frame                      common.rs:201-235
+//   MoleculeTypes::analyze_frame       topology/molecule.rs:54-95
+//   BondType::analyze_frame            topology/bond.rs:396-446      -> k_bonds_tiled / k_bonds_direct
+//   BondLike::add_order                topology/bond.rs:184-215         (register accumulators)
+//   calc_sch / vector_to               mod.rs:78-82, pbc.rs:378-385     (gm_math.h)
+//   OrderValue / AnalysisOrder         order.rs:13-66, 178-188          (i64 ticks, u64 counts)
+//   check_box                          common.rs:186-198             -> k_check_box
+//   SystemLeafletClassification::run   leaflets.rs:171-205           -> k_leaflets_global
+//   common_identify_leaflet            leaflets.rs:711-732              (same kernel)
+//   IndividualClassification           leaflets.rs:777-801           -> k_leaflets_individual
+//   should_assign / get_assigned       leaflets.rs:435-441, 1437-1472   (host: assignment-row table)
+//   SystemTopology::add / reduce       topology/mod.rs:236-272          (integer sums: order-free)
+//
+// Built for gfx950 only.  No CPU fallback: without a device every entry point fails loudly.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/gorder_hip.h"
+#include "gm_math.h"
+#include "plan.h"
+
+#pragma clang fp contract(off)
+
+using gorder::DirectItem;
+using gorder::Item;
+using gorder::kBlock;
+using gorder::Plan;
+using gorder::Tile;
+
+namespace {
+
+constexpr int kFramesPerStage = 4;   // G: frames staged in LDS per barrier pair (= waves per block)
+constexpr uint32_t kErrWords = 4;    // device error record: code, payload, frame, spare
+
+struct FrameArgs {
+    const float *xyz;        // [n_frames][n_atoms][3]
+    const float *box9;       // [n_frames][9]
+    uint32_t n_atoms;
+    uint32_t n_frames;
+    uint32_t frames_per_chunk;
+    int pbc;
+    float nx, ny, nz, n2;    // static normal and its norm
+    int leaflets;            // 0/1
+    const uint8_t *aflags;   // [rows][n_mol_total]
+    const uint32_t *arow;    // [n_frames] assignment row of each frame
+    uint32_t n_mol_total;
+    unsigned long long *acc; // [4][n_acc]: sum_total, sum_upper, cnt_total, cnt_upper
+    uint32_t n_acc;
+    uint32_t *err;
+};
+
+__device__ __forceinline__ void raise_error(uint32_t *err, uint32_t code, uint32_t payload, uint32_t frame) {
+    if (atomicCAS(&err[0], 0u, code) == 0u) {
+        err[1] = payload;
+        err[2] = frame;
+    }
+}
+
+// ---- check_box (common.rs:186-198), one thread per frame -----------------------------------
+__global__ void k_check_box(const float *__restrict__ box9, uint32_t n_frames, uint32_t *err) {
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_frames) return;
+    const float *b = box9 + 9 * (size_t)f;
+    bool all_nan = true;
+    for (int i = 0; i < 9; i++) all_nan = all_nan && (b[i] != b[i]);
+    if (all_nan) { raise_error(err, GORDER_ERR_UNDEFINED_BOX, 0, f); return; }
+    if (b[1] != 0.0f || b[2] != 0.0f || b[3] != 0.0f || b[5] != 0.0f || b[6] != 0.0f || b[7] != 0.0f) {
+        raise_error(err, GORDER_ERR_NOT_ORTHOGONAL_BOX, 0, f);
+        return;
+    }
+    if (b[0] == 0.0f && b[4] == 0.0f && b[8] == 0.0f) { raise_error(err, GORDER_ERR_ZERO_BOX, 0, f); return; }
+    if (!(b[0] > 0.0f) || !(b[4] > 0.0f) || !(b[8] > 0.0f)) raise_error(err, GORDER_ERR_BOX_RANGE, 0, f);
+}
+
+// total_frames (topology/mod.rs:141-144) lives in the last word of the accumulator block so that a
+// multi-GPU all-reduce sums it together with the order sums (topology/mod.rs:243)
+__global__ void k_count_frames(unsigned long long *word, uint32_t n_frames) { atomicAdd(word, (unsigned long long)n_frames); }
+
+// ---- one bond sample (bond.rs:407-443) -----------------------------------------------------
+struct SampleAcc {
+    long long s_tot = 0, s_up = 0;
+    uint32_t n_tot = 0, n_up = 0;
+};
+
+__device__ __forceinline__ void bond_sample(const FrameArgs &a, uint32_t f, float p1x, float p1y, float p1z,
+                                            float p2x, float p2y, float p2z, uint32_t mol, SampleAcc &acc,
+                                            int &bad) {
+    float vx = p2x - p1x, vy = p2y - p1y, vz = p2z - p1z;
+    if (a.pbc) {
+        const float *b = a.box9 + 9 * (size_t)f;
+        vx = gm_min_image(vx, b[0], bad);
+        vy = gm_min_image(vy, b[4], bad);
+        vz = gm_min_image(vz, b[8], bad);
+    }
+    const float sch = gm_calc_sch(vx, vy, vz, a.nx, a.ny, a.nz, a.n2);
+    const long long tick = gm_tick(sch);
+    acc.s_tot += tick;
+    acc.n_tot += 1;
+    if (a.leaflets) {
+        const uint8_t fl = a.aflags[(size_t)a.arow[f] * a.n_mol_total + mol];
+        if (fl == 0) {   // Leaflet::Upper = 0 (lib.rs:416-422)
+            acc.s_up += tick;
+            acc.n_up += 1;
+        }
+    }
+}
+
+// ---- K1: tiled bonds ----------------------------------------------------------------------
+// grid.x = n_tiles * n_chunks; block = 256 = 4 waves; dynamic LDS = G * lw floats.
+// Each block owns one tile (<= 256 samples, one contiguous atom window) for frames_per_chunk frames.
+// Per stage it copies the window of G frames HBM -> LDS (wave w stages frame w, 16 B per lane,
+// fully coalesced, every byte read once) and every thread evaluates its sample for the G frames.
+template <int G>
+__global__ __launch_bounds__(256) void k_bonds_tiled(FrameArgs a, const Tile *__restrict__ tiles,
+                                                      const Item *__restrict__ items,
+                                                      const uint32_t *__restrict__ tile_slots,
+                                                      uint32_t n_tiles, uint32_t lw) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const uint32_t tile_id = blockIdx.x % n_tiles;
+    const uint32_t chunk = blockIdx.x / n_tiles;
+    const Tile t = tiles[tile_id];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    const bool active = tid < t.n_items;
+    Item it{0, 0, 0, 0, 0};
+    if (active) it = items[t.item0 + tid];
+
+    const uint32_t f_begin = chunk * a.frames_per_chunk;
+    const uint32_t f_end = min(a.n_frames, f_begin + a.frames_per_chunk);
+    const size_t total_floats = (size_t)a.n_frames * a.n_atoms * 3u;
+    const uint32_t win_floats = 3u * t.n_window;
+
+    SampleAcc acc;
+    int bad = 0;
+    uint32_t nan_atom = 0xffffffffu, nan_frame = 0;
+
+    for (uint32_t f0 = f_begin; f0 < f_end; f0 += G) {
+        // ---- stage: wave k copies the window of frame f0+k
+        for (uint32_t k = wave; k < (uint32_t)G; k += 4) {
+            const uint32_t f = f0 + k;
+            if (f < f_end) {
+                const size_t base = ((size_t)f * a.n_atoms + t.atom0) * 3u;
+                const size_t abase = base & ~(size_t)3;
+                const uint32_t n4 = ((uint32_t)(base & 3u) + win_floats + 3u) >> 2;
+                const float4 *src = reinterpret_cast<const float4 *>(a.xyz + abase);
+                float4 *dst = reinterpret_cast<float4 *>(lds + (size_t)k * lw);
+                for (uint32_t i = lane; i < n4; i += 64) {
+                    const size_t e = abase + 4u * (size_t)i;
+                    float4 v;
+                    if (e + 4 <= total_floats) {
+                        v = src[i];
+                    } else {   // last few floats of the whole buffer
+                        v.x = e + 0 < total_floats ? a.xyz[e + 0] : 0.0f;
+                        v.y = e + 1 < total_floats ? a.xyz[e + 1] : 0.0f;
+                        v.z = e + 2 < total_floats ? a.xyz[e + 2] : 0.0f;
+                        v.w = 0.0f;
+                    }
+                    dst[i] = v;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- compute: my sample in each staged frame
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < G; k++) {
+                const uint32_t f = f0 + k;
+                if (f < f_end) {
+                    const size_t base = ((size_t)f * a.n_atoms + t.atom0) * 3u;
+                    const float *w = lds + (size_t)k * lw + (uint32_t)(base & 3u);
+                    const float p1x = w[3u * it.li], p1y = w[3u * it.li + 1], p1z = w[3u * it.li + 2];
+                    const float p2x = w[3u * it.lj], p2y = w[3u * it.lj + 1], p2z = w[3u * it.lj + 2];
+                    if (p1x != p1x) { nan_atom = t.atom0 + it.li; nan_frame = f; }
+                    else if (p2x != p2x) { nan_atom = t.atom0 + it.lj; nan_frame = f; }
+                    bond_sample(a, f, p1x, p1y, p1z, p2x, p2y, p2z, it.mol, acc, bad);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    if (nan_atom != 0xffffffffu) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, nan_atom, nan_frame);
+    if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f_begin);
+
+    // ---- epilogue: fold the block's samples per accumulator slot in LDS, then one global atomic
+    // per (slot, field).  Integer sums: the result does not depend on the order (order.rs:44-60).
+    unsigned long long *l_s = reinterpret_cast<unsigned long long *>(lds);   // [2][256]
+    uint32_t *l_n = reinterpret_cast<uint32_t *>(l_s + 2 * kBlock);          // [2][256]
+    l_s[tid] = 0; l_s[kBlock + tid] = 0; l_n[tid] = 0; l_n[kBlock + tid] = 0;
+    __syncthreads();
+    if (active && acc.n_tot) {
+        atomicAdd(&l_s[it.lslot], (unsigned long long)acc.s_tot);
+        atomicAdd(&l_n[it.lslot], acc.n_tot);
+        if (acc.n_up) {
+            atomicAdd(&l_s[kBlock + it.lslot], (unsigned long long)acc.s_up);
+            atomicAdd(&l_n[kBlock + it.lslot], acc.n_up);
+        }
+    }
+    __syncthreads();
+    if (tid < t.n_slots && l_n[tid]) {
+        const uint32_t slot = tile_slots[t.slot0 + tid];
+        atomicAdd(&a.acc[slot], l_s[tid]);
+        atomicAdd(&a.acc[2u * a.n_acc + slot], (unsigned long long)l_n[tid]);
+        if (l_n[kBlock + tid]) {
+            atomicAdd(&a.acc[a.n_acc + slot], l_s[kBlock + tid]);
+            atomicAdd(&a.acc[3u * a.n_acc + slot], (unsigned long long)l_n[kBlock + tid]);
+        }
+    }
+}
+
+// ---- K1b: direct gather (samples whose atoms do not fit one LDS window; also the A/B baseline)
+__global__ __launch_bounds__(256) void k_bonds_direct(FrameArgs a, const DirectItem *__restrict__ items,
+                                                       uint32_t n_items, uint32_t blocks_per_chunk) {
+    const uint32_t chunk = blockIdx.x / blocks_per_chunk;
+    const uint32_t q = (blockIdx.x % blocks_per_chunk) * blockDim.x + threadIdx.x;
+    if (q >= n_items) return;
+    const DirectItem it = items[q];
+    const uint32_t f_begin = chunk * a.frames_per_chunk;
+    const uint32_t f_end = min(a.n_frames, f_begin + a.frames_per_chunk);
+    SampleAcc acc;
+    int bad = 0;
+    for (uint32_t f = f_begin; f < f_end; f++) {
+        const float *p1 = a.xyz + ((size_t)f * a.n_atoms + it.i) * 3u;
+        const float *p2 = a.xyz + ((size_t)f * a.n_atoms + it.j) * 3u;
+        const float p1x = p1[0], p1y = p1[1], p1z = p1[2];
+        const float p2x = p2[0], p2y = p2[1], p2z = p2[2];
+        if (p1x != p1x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, it.i, f);
+        else if (p2x != p2x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, it.j, f);
+        bond_sample(a, f, p1x, p1y, p1z, p2x, p2y, p2z, it.mol, acc, bad);
+    }
+    if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f_begin);
+    if (acc.n_tot) {
+        atomicAdd(&a.acc[it.slot], (unsigned long long)acc.s_tot);
+        atomicAdd(&a.acc[2u * a.n_acc + it.slot], (unsigned long long)acc.n_tot);
+        if (acc.n_up) {
+            atomicAdd(&a.acc[a.n_acc + it.slot], (unsigned long long)acc.s_up);
+            atomicAdd(&a.acc[3u * a.n_acc + it.slot], (unsigned long long)acc.n_up);
+        }
+    }
+}
+
+// ---- leaflets ------------------------------------------------------------------------------
+struct LeafletArgs {
+    const float *xyz;
+    const float *box9;
+    uint32_t n_atoms;
+    const uint32_t *aframes;   // [n_assign] local frame index of each assignment frame
+    uint32_t row0;             // first output row
+    uint8_t *aflags;           // [rows][n_mol_total]
+    float *adist;              // [n_mol_total] signed distance of the LAST assignment frame (debug/tests)
+    uint32_t n_mol_total;
+    const uint32_t *heads;     // [n_mol_total] head atom per molecule
+    const uint32_t *membrane;  // Global: membrane atom list
+    uint32_t n_membrane;
+    const uint32_t *methyl_begin;  // Individual: [n_mol_total+1] ranges into methyl_atoms
+    const uint32_t *methyl_atoms;
+    uint32_t dim;
+    int flip, pbc;
+    uint32_t *err;
+};
+
+__device__ __forceinline__ double block_sum(double v, double *scratch) {
+    // deterministic tree reduction over the block
+    const uint32_t tid = threadIdx.x;
+    scratch[tid] = v;
+    __syncthreads();
+    for (uint32_t s = blockDim.x >> 1; s > 0; s >>= 1) {
+        if (tid < s) scratch[tid] += scratch[tid + s];
+        __syncthreads();
+    }
+    const double r = scratch[0];
+    __syncthreads();
+    return r;
+}
+
+// One block per assignment frame: refined Bai-Breen centre of the membrane group
+// (leaflets.rs:186-197 -> groan_rs group_get_center) followed by common_identify_leaflet
+// (leaflets.rs:711-732) for every molecule.  Sums are accumulated in f64 (the reference sums f32
+// sequentially; only the sign of head - centre is consumed).
+__global__ __launch_bounds__(1024) void k_leaflets_global(LeafletArgs a) {
+    __shared__ double scratch[1024];
+    __shared__ float s_center[3];
+    const uint32_t f = a.aframes[blockIdx.x];
+    const float *x = a.xyz + (size_t)f * a.n_atoms * 3u;
+    float box[3] = {1.0f, 1.0f, 1.0f};
+    if (a.pbc) {
+        const float *b = a.box9 + 9 * (size_t)f;
+        box[0] = b[0]; box[1] = b[4]; box[2] = b[8];
+    }
+    int bad = 0;
+    float est[3];
+    if (a.pbc) {
+        double sc[3] = {0, 0, 0}, ss[3] = {0, 0, 0};
+        const float two_pi = 6.2831855f;
+        for (uint32_t i = threadIdx.x; i < a.n_membrane; i += blockDim.x) {
+            const float *p = x + 3u * (size_t)a.membrane[i];
+            for (int d = 0; d < 3; d++) {
+                const float c = gm_wrap(p[d], box[d], bad);
+                const float theta = c * (two_pi / box[d]);
+                float sn, cs;
+                sincosf(theta, &sn, &cs);
+                sc[d] += (double)cs;
+                ss[d] += (double)sn;
+            }
+        }
+        for (int d = 0; d < 3; d++) {
+            const double tc = block_sum(sc[d], scratch);
+            const double ts = block_sum(ss[d], scratch);
+            const float th = atan2f(-(float)ts, -(float)tc) + 3.1415927f;
+            est[d] = th / (two_pi / box[d]);
+        }
+    } else {
+        est[0] = est[1] = est[2] = 0.0f;
+    }
+    double acc[3] = {0, 0, 0};
+    for (uint32_t i = threadIdx.x; i < a.n_membrane; i += blockDim.x) {
+        const float *p = x + 3u * (size_t)a.membrane[i];
+        for (int d = 0; d < 3; d++) {
+            const float dx = p[d] - est[d];
+            acc[d] += (double)(a.pbc ? gm_min_image(dx, box[d], bad) : dx);
+        }
+    }
+    for (int d = 0; d < 3; d++) {
+        const double tot = block_sum(acc[d], scratch);
+        if (threadIdx.x == 0) {
+            float c = est[d] + (float)(tot / (double)a.n_membrane);
+            if (a.pbc) c = gm_wrap(c, box[d], bad);
+            s_center[d] = c;
+        }
+    }
+    __syncthreads();
+    const float cx = s_center[0], cy = s_center[1], cz = s_center[2];
+    if (threadIdx.x == 0 && (cx != cx || cy != cy || cz != cz || a.n_membrane == 0))
+        raise_error(a.err, GORDER_ERR_INVALID_GLOBAL_MEMBRANE_CENTER, 0, f);
+    const float cdim = a.dim == 0 ? cx : (a.dim == 1 ? cy : cz);
+    uint8_t *row = a.aflags + (size_t)(a.row0 + blockIdx.x) * a.n_mol_total;
+    const bool last = blockIdx.x + 1 == gridDim.x;
+    for (uint32_t m = threadIdx.x; m < a.n_mol_total; m += blockDim.x) {
+        const float hp = x[3u * (size_t)a.heads[m] + a.dim];
+        float d = hp - cdim;
+        if (a.pbc) d = gm_min_image(d, box[a.dim], bad);
+        row[m] = (uint8_t)((d >= 0.0f ? 0 : 1) ^ (a.flip ? 1 : 0));
+        if (last && a.adist) a.adist[m] = d;
+    }
+    if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f);
+}
+
+// grid = (ceil(n_mol/256), n_assign).  IndividualClassification::identify_leaflet, leaflets.rs:777-801:
+// sequential f32 sum of signed head-methyl distances along the normal.
+__global__ __launch_bounds__(256) void k_leaflets_individual(LeafletArgs a) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= a.n_mol_total) return;
+    const uint32_t f = a.aframes[blockIdx.y];
+    const float *x = a.xyz + (size_t)f * a.n_atoms * 3u;
+    float L = 1.0f;
+    if (a.pbc) L = a.box9[9 * (size_t)f + 4 * a.dim];
+    int bad = 0;
+    const float hp = x[3u * (size_t)a.heads[m] + a.dim];
+    float total = 0.0f;
+    for (uint32_t k = a.methyl_begin[m]; k < a.methyl_begin[m + 1]; k++) {
+        const float mp = x[3u * (size_t)a.methyl_atoms[k] + a.dim];
+        const float d = hp - mp;
+        total += a.pbc ? gm_min_image(d, L, bad) : d;
+    }
+    a.aflags[(size_t)(a.row0 + blockIdx.y) * a.n_mol_total + m] =
+        (uint8_t)((total >= 0.0f ? 0 : 1) ^ (a.flip ? 1 : 0));
+    if (blockIdx.y + 1 == gridDim.y && a.adist) a.adist[m] = total;
+    if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f);
+}
+
+}  // namespace
+
+// ============================================================================================
+// host side
+// ============================================================================================
+
+struct gorder_hip_handle {
+    Plan plan;
+    gorder_tables_t tables{};           // scalar copy (pointers inside are NOT kept)
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    // device tables
+    Tile *d_tiles = nullptr;
+    Item *d_items = nullptr;
+    uint32_t *d_tile_slots = nullptr;
+    DirectItem *d_direct = nullptr;
+    uint32_t *d_err = nullptr;
+    unsigned long long *d_acc = nullptr;   // [4][n_acc] + total_frames
+    bool acc_external = false;
+    size_t acc_words = 0;
+    // leaflets
+    uint32_t *d_heads = nullptr, *d_membrane = nullptr, *d_methyl_begin = nullptr, *d_methyl_atoms = nullptr;
+    uint8_t *d_aflags = nullptr;
+    size_t aflags_rows = 0;
+    float *d_adist = nullptr;
+    uint32_t *d_arow = nullptr, *d_aframes = nullptr;
+    size_t arow_cap = 0, aframes_cap = 0;
+    bool have_assignment = false;
+    uint64_t assignment_frame = 0;
+    // host staging for submit_host
+    float *d_stage_xyz = nullptr, *d_stage_box = nullptr;
+    size_t stage_xyz_cap = 0, stage_box_cap = 0;
+    float n2 = 1.0f;
+    uint32_t lw = 0;
+    size_t lds_bytes = 0;
+    uint64_t n_frames = 0;
+    uint64_t err_index = 0;
+    std::string err_msg;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timing;
+    double timing_ms = 0.0;
+    uint64_t timing_launches = 0;
+};
+
+namespace {
+
+int fail(gorder_hip_handle *h, int status, const std::string &msg) {
+    if (h) h->err_msg = msg;
+    return status;
+}
+
+#define HIP_TRY(h, expr)                                                                    \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(h, GORDER_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T>
+int upload(gorder_hip_handle *h, T **dst, const std::vector<T> &src) {
+    *dst = nullptr;
+    if (src.empty()) return GORDER_OK;
+    HIP_TRY(h, hipMalloc((void **)dst, src.size() * sizeof(T)));
+    HIP_TRY(h, hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return GORDER_OK;
+}
+
+template <typename T>
+int ensure(gorder_hip_handle *h, T **buf, size_t *cap, size_t need) {
+    if (need <= *cap) return GORDER_OK;
+    if (*buf) HIP_TRY(h, hipFree(*buf));
+    *buf = nullptr;
+    *cap = 0;
+    const size_t n = need + need / 2;
+    HIP_TRY(h, hipMalloc((void **)buf, n * sizeof(T)));
+    *cap = n;
+    return GORDER_OK;
+}
+
+bool should_assign(uint32_t frequency, uint64_t frame) {   // leaflets.rs:435-441
+    return frequency == 0 ? frame == 0 : (frame % frequency) == 0;
+}
+
+int check_device_error(gorder_hip_handle *h) {
+    uint32_t e[kErrWords];
+    HIP_TRY(h, hipMemcpy(e, h->d_err, sizeof(e), hipMemcpyDeviceToHost));
+    if (e[0] == 0) return GORDER_OK;
+    h->err_index = e[1];
+    char buf[160];
+    snprintf(buf, sizeof(buf), "device raised %s (payload %u) in batch frame %u", gorder_hip_strerror((int)e[0]),
+             e[1], e[2]);
+    h->err_msg = buf;
+    return (int)e[0];
+}
+
+bool env_flag(const char *name) {
+    const char *v = getenv(name);
+    return v && *v && strcmp(v, "0") != 0;
+}
+
+// Launch the order kernels of one batch (internal).
+int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
+    const Plan &p = h->plan;
+    const uint32_t n_tiles = (uint32_t)p.tiles.size();
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(h, hipEventCreate(&e0));
+    HIP_TRY(h, hipEventCreate(&e1));
+    HIP_TRY(h, hipEventRecord(e0, h->stream));
+    if (n_tiles) {
+        // enough workgroups to fill 256 CUs x 8 blocks, frames split into chunks of whole stages
+        const uint32_t target = 256u * 8u;
+        uint32_t n_chunks = std::max(1u, (target + n_tiles - 1) / n_tiles);
+        uint32_t fpc = (a.n_frames + n_chunks - 1) / n_chunks;
+        fpc = ((fpc + kFramesPerStage - 1) / kFramesPerStage) * kFramesPerStage;
+        n_chunks = (a.n_frames + fpc - 1) / fpc;
+        a.frames_per_chunk = fpc;
+        const uint64_t grid = (uint64_t)n_tiles * n_chunks;
+        if (grid > 0x7fffffffull) return fail(h, GORDER_ERR_INVALID_ARGUMENT, "batch too large");
+        hipLaunchKernelGGL((k_bonds_tiled<kFramesPerStage>), dim3((uint32_t)grid), dim3(kBlock), h->lds_bytes,
+                           h->stream, a, h->d_tiles, h->d_items, h->d_tile_slots, n_tiles, h->lw);
+        HIP_TRY(h, hipGetLastError());
+    }
+    if (!p.direct.empty()) {
+        const uint32_t n_items = (uint32_t)p.direct.size();
+        const uint32_t bpc = (n_items + kBlock - 1) / kBlock;
+        const uint32_t target = 256u * 8u;
+        uint32_t n_chunks = std::max(1u, (target + bpc - 1) / bpc);
+        n_chunks = std::min(n_chunks, a.n_frames);
+        const uint32_t fpc = (a.n_frames + n_chunks - 1) / n_chunks;
+        n_chunks = (a.n_frames + fpc - 1) / fpc;
+        FrameArgs b = a;
+        b.frames_per_chunk = fpc;
+        hipLaunchKernelGGL(k_bonds_direct, dim3(bpc * n_chunks), dim3(kBlock), 0, h->stream, b, h->d_direct, n_items,
+                           bpc);
+        HIP_TRY(h, hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_count_frames, dim3(1), dim3(1), 0, h->stream, a.acc + 4 * (size_t)a.n_acc, a.n_frames);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(e1, h->stream));
+    h->timing.emplace_back(e0, e1);
+    h->timing_launches += 1;
+    return GORDER_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *gorder_hip_strerror(int status) {
+    switch (status) {
+        case GORDER_OK: return "ok";
+        case GORDER_ERR_UNDEFINED_BOX: return "system has undefined simulation box";
+        case GORDER_ERR_NOT_ORTHOGONAL_BOX: return "the simulation box is not orthogonal";
+        case GORDER_ERR_ZERO_BOX: return "all dimensions of the simulation box are zero";
+        case GORDER_ERR_UNDEFINED_POSITION: return "atom has an undefined position";
+        case GORDER_ERR_INVALID_GLOBAL_MEMBRANE_CENTER: return "could not calculate global membrane center";
+        case GORDER_ERR_INVALID_LOCAL_MEMBRANE_CENTER: return "could not calculate local membrane center";
+        case GORDER_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case GORDER_ERR_DEVICE: return "HIP runtime error";
+        case GORDER_ERR_NO_DEVICE: return "no HIP device available (this library has no CPU fallback)";
+        case GORDER_ERR_BOX_RANGE: return "box edge <= 0 or coordinate too far outside the box";
+        case GORDER_ERR_LEAFLETS_NOT_PRIMED: return "leaflet assignment missing for the first frame";
+        case GORDER_ERR_OVERFLOW: return "order accumulator overflowed";
+        default: return "unknown status";
+    }
+}
+
+int gorder_hip_plan_tables(const gorder_tables_t *tables, gorder_hip_plan_t *out, int *selfcheck) {
+    if (!tables || !out) return GORDER_ERR_INVALID_ARGUMENT;
+    Plan p;
+    const int st = gorder::build_plan(*tables, env_flag("GORDER_HIP_FORCE_DIRECT"), p);
+    if (st != GORDER_OK) return st;
+    out->n_tiles = (uint32_t)p.tiles.size();
+    out->block_threads = kBlock;
+    out->max_window_atoms = p.max_window;
+    out->n_direct_items = (uint32_t)p.direct.size();
+    out->frames_per_stage = kFramesPerStage;
+    const uint32_t lw = ((3u * p.max_window + 3u + 3u) / 4u) * 4u;
+    size_t lds = (size_t)kFramesPerStage * lw * sizeof(float);
+    if (lds < (size_t)kBlock * 24) lds = (size_t)kBlock * 24;
+    out->lds_bytes = (uint32_t)lds;
+    if (selfcheck) *selfcheck = gorder::selfcheck_plan(*tables, p);
+    return GORDER_OK;
+}
+
+int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
+    if (!t || !out) return GORDER_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return GORDER_ERR_NO_DEVICE;
+    if (t->device < 0 || t->device >= n_dev) return GORDER_ERR_INVALID_ARGUMENT;
+    // features of the ABI that this build does not implement yet fail loudly, never silently
+    if (t->ordermap.enabled || t->timewise) return GORDER_ERR_INVALID_ARGUMENT;
+    for (uint32_t m = 0; m < t->n_molecule_types; m++)
+        if (t->molecule_types[m].n_ua_atoms) return GORDER_ERR_INVALID_ARGUMENT;
+    if (t->leaflets.method == GORDER_LEAFLETS_LOCAL) return GORDER_ERR_INVALID_ARGUMENT;
+
+    gorder_hip_handle *h = new (std::nothrow) gorder_hip_handle();
+    if (!h) return GORDER_ERR_DEVICE;
+    *out = h;   // returned even on failure so that the caller can read the message; destroy() is safe
+    h->tables = *t;
+    h->tables.molecule_types = nullptr;
+    h->tables.leaflets.membrane = nullptr;
+    h->device = t->device;
+    HIP_TRY(h, hipSetDevice(h->device));
+    int st = gorder::build_plan(*t, env_flag("GORDER_HIP_FORCE_DIRECT"), h->plan);
+    if (st != GORDER_OK) return fail(h, st, "invalid bond tables");
+    const Plan &p = h->plan;
+    HIP_TRY(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
+    if ((st = upload(h, &h->d_tiles, p.tiles)) != GORDER_OK) return st;
+    if ((st = upload(h, &h->d_items, p.items)) != GORDER_OK) return st;
+    if ((st = upload(h, &h->d_tile_slots, p.tile_slots)) != GORDER_OK) return st;
+    if ((st = upload(h, &h->d_direct, p.direct)) != GORDER_OK) return st;
+    HIP_TRY(h, hipMalloc((void **)&h->d_err, kErrWords * sizeof(uint32_t)));
+    HIP_TRY(h, hipMemset(h->d_err, 0, kErrWords * sizeof(uint32_t)));
+    h->acc_words = 4 * (size_t)p.n_acc + 1;
+    HIP_TRY(h, hipMalloc((void **)&h->d_acc, h->acc_words * sizeof(unsigned long long)));
+    HIP_TRY(h, hipMemset(h->d_acc, 0, h->acc_words * sizeof(unsigned long long)));
+    {   // |normal| with the f32 sequence of nalgebra's norm (oracle: norm3)
+        const float *n = t->normal;
+        h->n2 = sqrtf((n[0] * n[0] + n[1] * n[1]) + n[2] * n[2]);
+    }
+    h->lw = ((3u * p.max_window + 3u + 3u) / 4u) * 4u;
+    h->lds_bytes = (size_t)kFramesPerStage * h->lw * sizeof(float);
+    if (h->lds_bytes < (size_t)kBlock * 24) h->lds_bytes = (size_t)kBlock * 24;
+
+    const gorder_leaflets_t &lf = t->leaflets;
+    if (lf.method != GORDER_LEAFLETS_NONE) {
+        if (lf.normal_dim > 2) return fail(h, GORDER_ERR_INVALID_ARGUMENT, "leaflets.normal_dim");
+        std::vector<uint32_t> heads, mb(1, 0), ma;
+        for (uint32_t m = 0; m < t->n_molecule_types; m++) {
+            const gorder_moltype_t &mt = t->molecule_types[m];
+            if (lf.method != GORDER_LEAFLETS_MANUAL && !mt.heads)
+                return fail(h, GORDER_ERR_INVALID_ARGUMENT, "leaflets need heads[] per molecule type");
+            if (lf.method == GORDER_LEAFLETS_INDIVIDUAL && (!mt.methyls || mt.n_methyls == 0))
+                return fail(h, GORDER_ERR_INVALID_ARGUMENT, "individual leaflets need methyls[]");
+            for (uint32_t k = 0; k < mt.n_molecules; k++) {
+                const uint32_t hd = mt.heads ? mt.heads[k] : 0;
+                if (hd >= t->n_atoms) return fail(h, GORDER_ERR_INVALID_ARGUMENT, "head index out of range");
+                heads.push_back(hd);
+                if (lf.method == GORDER_LEAFLETS_INDIVIDUAL)
+                    for (uint32_t q = 0; q < mt.n_methyls; q++) {
+                        const uint32_t a = mt.methyls[(size_t)k * mt.n_methyls + q];
+                        if (a >= t->n_atoms) return fail(h, GORDER_ERR_INVALID_ARGUMENT, "methyl index out of range");
+                        ma.push_back(a);
+                    }
+                mb.push_back((uint32_t)ma.size());
+            }
+        }
+        if ((st = upload(h, &h->d_heads, heads)) != GORDER_OK) return st;
+        if ((st = upload(h, &h->d_methyl_begin, mb)) != GORDER_OK) return st;
+        if ((st = upload(h, &h->d_methyl_atoms, ma)) != GORDER_OK) return st;
+        if (lf.method == GORDER_LEAFLETS_GLOBAL) {
+            if (!lf.membrane || lf.n_membrane == 0)
+                return fail(h, GORDER_ERR_INVALID_ARGUMENT, "global leaflets need the membrane group");
+            std::vector<uint32_t> mem(lf.membrane, lf.membrane + lf.n_membrane);
+            for (uint32_t a : mem)
+                if (a >= t->n_atoms) return fail(h, GORDER_ERR_INVALID_ARGUMENT, "membrane index out of range");
+            if ((st = upload(h, &h->d_membrane, mem)) != GORDER_OK) return st;
+        }
+        HIP_TRY(h, hipMalloc((void **)&h->d_adist, sizeof(float) * (p.n_mol_total ? p.n_mol_total : 1)));
+    }
+    return GORDER_OK;
+}
+
+void gorder_hip_destroy(gorder_hip_handle *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto &ev : h->timing) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    (void)hipFree(h->d_tiles); (void)hipFree(h->d_items); (void)hipFree(h->d_tile_slots);
+    (void)hipFree(h->d_direct); (void)hipFree(h->d_err);
+    if (!h->acc_external) (void)hipFree(h->d_acc);
+    (void)hipFree(h->d_heads); (void)hipFree(h->d_membrane); (void)hipFree(h->d_methyl_begin);
+    (void)hipFree(h->d_methyl_atoms); (void)hipFree(h->d_aflags); (void)hipFree(h->d_adist);
+    (void)hipFree(h->d_arow); (void)hipFree(h->d_aframes);
+    (void)hipFree(h->d_stage_xyz); (void)hipFree(h->d_stage_box);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+uint32_t gorder_hip_n_accumulators(const gorder_hip_handle *h) { return h ? h->plan.n_acc : 0; }
+uint32_t gorder_hip_ordermap_dims(const gorder_hip_handle *, uint32_t *nx, uint32_t *ny) {
+    if (nx) *nx = 0;
+    if (ny) *ny = 0;
+    return 0;
+}
+
+int gorder_hip_set_stream(gorder_hip_handle *h, void *hip_stream) {
+    if (!h) return GORDER_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return GORDER_OK;
+}
+
+int gorder_hip_plan(const gorder_hip_handle *h, gorder_hip_plan_t *plan) {
+    if (!h || !plan) return GORDER_ERR_INVALID_ARGUMENT;
+    plan->n_tiles = (uint32_t)h->plan.tiles.size();
+    plan->block_threads = kBlock;
+    plan->max_window_atoms = h->plan.max_window;
+    plan->n_direct_items = (uint32_t)h->plan.direct.size();
+    plan->frames_per_stage = kFramesPerStage;
+    plan->lds_bytes = (uint32_t)h->lds_bytes;
+    return GORDER_OK;
+}
+
+// ---- leaflet assignment rows for a batch (host part of leaflets.rs:435-441, 1437-1472) --------
+static int run_leaflets(gorder_hip_handle *h, const float *d_xyz, const float *d_box,
+                        const std::vector<uint32_t> &aframes, uint32_t row0) {
+    if (aframes.empty()) return GORDER_OK;
+    int st;
+    if ((st = ensure(h, &h->d_aframes, &h->aframes_cap, aframes.size())) != GORDER_OK) return st;
+    HIP_TRY(h, hipMemcpyAsync(h->d_aframes, aframes.data(), aframes.size() * sizeof(uint32_t),
+                              hipMemcpyHostToDevice, h->stream));
+    const gorder_leaflets_t &lf = h->tables.leaflets;
+    LeafletArgs la{};
+    la.xyz = d_xyz; la.box9 = d_box; la.n_atoms = h->plan.n_atoms;
+    la.aframes = h->d_aframes; la.row0 = row0; la.aflags = h->d_aflags; la.adist = h->d_adist;
+    la.n_mol_total = h->plan.n_mol_total; la.heads = h->d_heads;
+    la.membrane = h->d_membrane; la.n_membrane = lf.n_membrane;
+    la.methyl_begin = h->d_methyl_begin; la.methyl_atoms = h->d_methyl_atoms;
+    la.dim = lf.normal_dim; la.flip = lf.flip ? 1 : 0; la.pbc = h->tables.handle_pbc ? 1 : 0;
+    la.err = h->d_err;
+    if (lf.method == GORDER_LEAFLETS_GLOBAL) {
+        hipLaunchKernelGGL(k_leaflets_global, dim3((uint32_t)aframes.size()), dim3(1024), 0, h->stream, la);
+    } else if (lf.method == GORDER_LEAFLETS_INDIVIDUAL) {
+        // gridDim.y <= 65535: launch in slabs
+        size_t done = 0;
+        while (done < aframes.size()) {
+            const uint32_t ny = (uint32_t)std::min<size_t>(aframes.size() - done, 65535);
+            LeafletArgs lb = la;
+            lb.aframes = h->d_aframes + done;
+            lb.row0 = row0 + (uint32_t)done;
+            // adist is only written by the last slab's last row
+            if (done + ny < aframes.size()) lb.adist = nullptr;
+            hipLaunchKernelGGL(k_leaflets_individual, dim3((la.n_mol_total + 255) / 256, ny), dim3(256), 0,
+                               h->stream, lb);
+            done += ny;
+        }
+    }
+    HIP_TRY(h, hipGetLastError());
+    return GORDER_OK;
+}
+
+int gorder_hip_submit_device(gorder_hip_handle *h, const float *d_xyz, const float *d_box,
+                             const uint64_t *frame_index, uint32_t n_frames) {
+    if (!h || !d_xyz || !frame_index) return GORDER_ERR_INVALID_ARGUMENT;
+    const bool pbc = h->tables.handle_pbc != 0;
+    if (pbc && !d_box) return fail(h, GORDER_ERR_INVALID_ARGUMENT, "box required when handle_pbc = 1");
+    if (((uintptr_t)d_xyz & 15u) != 0) return fail(h, GORDER_ERR_INVALID_ARGUMENT, "d_xyz must be 16-byte aligned");
+    if (n_frames == 0) return GORDER_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const Plan &p = h->plan;
+    const gorder_leaflets_t &lf = h->tables.leaflets;
+    int st;
+
+    // ---- leaflet assignment rows of this batch; row 0 = assignment carried over from earlier
+    // batches (AssignedLeaflets::local, leaflets.rs:1371-1380), rows 1.. = assignment frames here
+    const bool leaflets = lf.method != GORDER_LEAFLETS_NONE;
+    size_t n_new_rows = 0;
+    if (leaflets) {
+        std::vector<uint32_t> arow(n_frames), aframes;
+        uint32_t cur = 0;
+        bool have = h->have_assignment;
+        uint64_t last_assign_frame = h->assignment_frame;
+        for (uint32_t f = 0; f < n_frames; f++) {
+            if (lf.method != GORDER_LEAFLETS_MANUAL && should_assign(lf.frequency, frame_index[f])) {
+                aframes.push_back(f);
+                cur = (uint32_t)aframes.size();
+                have = true;
+                last_assign_frame = frame_index[f];
+            }
+            if (!have) return fail(h, GORDER_ERR_LEAFLETS_NOT_PRIMED, "no leaflet assignment for the first frame");
+            arow[f] = cur;
+        }
+        const size_t rows = aframes.size() + 1;
+        if (rows > h->aflags_rows) {
+            uint8_t *nb = nullptr;
+            const size_t nrows = rows + rows / 4;
+            HIP_TRY(h, hipMalloc((void **)&nb, nrows * (size_t)p.n_mol_total));
+            if (h->d_aflags) {
+                HIP_TRY(h, hipStreamSynchronize(h->stream));
+                HIP_TRY(h, hipMemcpy(nb, h->d_aflags, p.n_mol_total, hipMemcpyDeviceToDevice));
+                HIP_TRY(h, hipFree(h->d_aflags));
+            }
+            h->d_aflags = nb;
+            h->aflags_rows = nrows;
+        }
+        if ((st = ensure(h, &h->d_arow, &h->arow_cap, n_frames)) != GORDER_OK) return st;
+        HIP_TRY(h, hipMemcpyAsync(h->d_arow, arow.data(), n_frames * sizeof(uint32_t), hipMemcpyHostToDevice,
+                                  h->stream));
+        if ((st = run_leaflets(h, d_xyz, d_box, aframes, 1)) != GORDER_OK) return st;
+        h->have_assignment = true;
+        h->assignment_frame = last_assign_frame;
+        n_new_rows = aframes.size();
+    }
+    if (pbc) {
+        hipLaunchKernelGGL(k_check_box, dim3((n_frames + 255) / 256), dim3(256), 0, h->stream, d_box, n_frames,
+                           h->d_err);
+        HIP_TRY(h, hipGetLastError());
+    }
+    FrameArgs a{};
+    a.xyz = d_xyz; a.box9 = d_box; a.n_atoms = p.n_atoms; a.n_frames = n_frames;
+    a.pbc = pbc ? 1 : 0;
+    a.nx = h->tables.normal[0]; a.ny = h->tables.normal[1]; a.nz = h->tables.normal[2]; a.n2 = h->n2;
+    a.leaflets = leaflets ? 1 : 0; a.aflags = h->d_aflags; a.arow = h->d_arow; a.n_mol_total = p.n_mol_total;
+    a.acc = h->d_acc; a.n_acc = p.n_acc; a.err = h->d_err;
+    if ((st = launch_orders(h, a)) != GORDER_OK) return st;
+    if (n_new_rows) {   // newest assignment becomes the carry row of the next batch
+        HIP_TRY(h, hipMemcpyAsync(h->d_aflags, h->d_aflags + n_new_rows * (size_t)p.n_mol_total, p.n_mol_total,
+                                  hipMemcpyDeviceToDevice, h->stream));
+    }
+    h->n_frames += n_frames;
+    return GORDER_OK;
+}
+
+int gorder_hip_submit_host(gorder_hip_handle *h, const float *xyz, const float *box, const uint64_t *frame_index,
+                           uint32_t n_frames) {
+    if (!h || !xyz || !frame_index) return GORDER_ERR_INVALID_ARGUMENT;
+    if (n_frames == 0) return GORDER_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    int st;
+    const size_t nx = (size_t)n_frames * h->plan.n_atoms * 3u, nb = (size_t)n_frames * 9u;
+    // the staging buffer may still be read by kernels of the previous batch
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if ((st = ensure(h, &h->d_stage_xyz, &h->stage_xyz_cap, nx)) != GORDER_OK) return st;
+    HIP_TRY(h, hipMemcpyAsync(h->d_stage_xyz, xyz, nx * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (box) {
+        if ((st = ensure(h, &h->d_stage_box, &h->stage_box_cap, nb)) != GORDER_OK) return st;
+        HIP_TRY(h, hipMemcpyAsync(h->d_stage_box, box, nb * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    }
+    return gorder_hip_submit_device(h, h->d_stage_xyz, box ? h->d_stage_box : nullptr, frame_index, n_frames);
+}
+
+int gorder_hip_prime_leaflets(gorder_hip_handle *h, const float *d_xyz, const float *d_box, uint64_t frame_index) {
+    if (!h || !d_xyz) return GORDER_ERR_INVALID_ARGUMENT;
+    const gorder_leaflets_t &lf = h->tables.leaflets;
+    if (lf.method == GORDER_LEAFLETS_NONE || lf.method == GORDER_LEAFLETS_MANUAL) return GORDER_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (h->aflags_rows < 2) {
+        uint8_t *nb = nullptr;
+        HIP_TRY(h, hipMalloc((void **)&nb, 2 * (size_t)h->plan.n_mol_total));
+        if (h->d_aflags) HIP_TRY(h, hipFree(h->d_aflags));
+        h->d_aflags = nb;
+        h->aflags_rows = 2;
+    }
+    std::vector<uint32_t> aframes(1, 0);
+    const int st = run_leaflets(h, d_xyz, d_box, aframes, 0);
+    if (st != GORDER_OK) return st;
+    h->have_assignment = true;
+    h->assignment_frame = frame_index;
+    return GORDER_OK;
+}
+
+int gorder_hip_set_manual_leaflets(gorder_hip_handle *h, const uint8_t *flags, uint64_t frame_index) {
+    if (!h || !flags) return GORDER_ERR_INVALID_ARGUMENT;
+    if (h->tables.leaflets.method != GORDER_LEAFLETS_MANUAL) return GORDER_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const uint32_t n = h->plan.n_mol_total;
+    std::vector<uint8_t> tmp(n);
+    for (uint32_t i = 0; i < n; i++) tmp[i] = (uint8_t)((flags[i] & 1) ^ (h->tables.leaflets.flip ? 1 : 0));
+    if (h->aflags_rows < 1) {
+        HIP_TRY(h, hipMalloc((void **)&h->d_aflags, 2 * (size_t)n));
+        h->aflags_rows = 2;
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(h->d_aflags, tmp.data(), n, hipMemcpyHostToDevice));
+    h->have_assignment = true;
+    h->assignment_frame = frame_index;
+    return GORDER_OK;
+}
+
+int gorder_hip_synchronize(gorder_hip_handle *h) {
+    if (!h) return GORDER_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return check_device_error(h);
+}
+
+int gorder_hip_finish(gorder_hip_handle *h, int64_t *sums, uint64_t *counts, int64_t *map_sums,
+                      uint64_t *map_counts, uint64_t *n_frames_analyzed) {
+    if (!h) return GORDER_ERR_INVALID_ARGUMENT;
+    (void)map_sums; (void)map_counts;
+    const int st = gorder_hip_synchronize(h);
+    if (st != GORDER_OK) return st;
+    const uint32_t n = h->plan.n_acc;
+    std::vector<unsigned long long> raw(4 * (size_t)n + 1);
+    HIP_TRY(h, hipMemcpy(raw.data(), h->d_acc, raw.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    const bool lf = h->tables.leaflets.method != GORDER_LEAFLETS_NONE;
+    for (uint32_t s = 0; s < n; s++) {
+        const int64_t tot = (int64_t)raw[s], up = (int64_t)raw[n + s];
+        const uint64_t ctot = raw[2 * (size_t)n + s], cup = raw[3 * (size_t)n + s];
+        if (sums) {
+            sums[s] = tot;
+            sums[n + s] = lf ? up : 0;
+            sums[2 * (size_t)n + s] = lf ? tot - up : 0;   // every sample is upper or lower (bond.rs:199-213)
+        }
+        if (counts) {
+            counts[s] = ctot;
+            counts[n + s] = lf ? cup : 0;
+            counts[2 * (size_t)n + s] = lf ? ctot - cup : 0;
+        }
+    }
+    if (n_frames_analyzed) *n_frames_analyzed = raw[4 * (size_t)n];
+    return GORDER_OK;
+}
+
+int gorder_hip_timewise(gorder_hip_handle *, int64_t *, uint64_t *, uint64_t) { return GORDER_ERR_INVALID_ARGUMENT; }
+
+int gorder_hip_leaflets(gorder_hip_handle *h, uint8_t *flags, uint64_t *assignment_frame) {
+    if (!h) return GORDER_ERR_INVALID_ARGUMENT;
+    if (!h->have_assignment) return GORDER_ERR_LEAFLETS_NOT_PRIMED;
+    const int st = gorder_hip_synchronize(h);
+    if (st != GORDER_OK) return st;
+    if (flags) HIP_TRY(h, hipMemcpy(flags, h->d_aflags, h->plan.n_mol_total, hipMemcpyDeviceToHost));
+    if (assignment_frame) *assignment_frame = h->assignment_frame;
+    return GORDER_OK;
+}
+
+int gorder_hip_leaflet_distances(gorder_hip_handle *h, float *dist) {
+    if (!h || !dist || !h->d_adist) return GORDER_ERR_INVALID_ARGUMENT;
+    const int st = gorder_hip_synchronize(h);
+    if (st != GORDER_OK) return st;
+    HIP_TRY(h, hipMemcpy(dist, h->d_adist, sizeof(float) * h->plan.n_mol_total, hipMemcpyDeviceToHost));
+    return GORDER_OK;
+}
+
+int gorder_hip_accumulators_device(gorder_hip_handle *h, void **d_ptr, uint64_t *n_u64) {
+    if (!h || !d_ptr || !n_u64) return GORDER_ERR_INVALID_ARGUMENT;
+    *d_ptr = h->d_acc;
+    *n_u64 = h->acc_words;
+    return GORDER_OK;
+}
+
+int gorder_hip_bind_accumulators(gorder_hip_handle *h, void *d_ptr, uint64_t n_u64) {
+    if (!h || !d_ptr || n_u64 < h->acc_words || ((uintptr_t)d_ptr & 7u)) return GORDER_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(d_ptr, h->d_acc, h->acc_words * sizeof(unsigned long long), hipMemcpyDeviceToDevice));
+    if (!h->acc_external) HIP_TRY(h, hipFree(h->d_acc));
+    h->d_acc = (unsigned long long *)d_ptr;
+    h->acc_external = true;
+    return GORDER_OK;
+}
+
+uint64_t gorder_hip_last_error_index(const gorder_hip_handle *h) { return h ? h->err_index : 0; }
+const char *gorder_hip_last_error_message(const gorder_hip_handle *h) { return h ? h->err_msg.c_str() : ""; }
+
+int gorder_hip_kernel_time(gorder_hip_handle *h, double *ms, uint64_t *launches, int reset) {
+    if (!h) return GORDER_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (auto &ev : h->timing) {
+        float t = 0.0f;
+        HIP_TRY(h, hipEventElapsedTime(&t, ev.first, ev.second));
+        h->timing_ms += t;
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    h->timing.clear();
+    if (ms) *ms = h->timing_ms;
+    if (launches) *launches = h->timing_launches;
+    if (reset) { h->timing_ms = 0.0; h->timing_launches = 0; }
+    return GORDER_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,177 @@
+// plan.h — host-side work partitioning for the per-frame kernels (pure C++, no HIP).
+//
+// The reference walks `bond type -> molecule instance` (topology/bond.rs:396-446) once per frame.
+// On the GPU the same samples are re-grouped by WHERE THEIR ATOMS LIVE IN THE FRAME: a *tile* is a
+// set of up to `block` samples whose atoms all fall into one contiguous window of the AoS frame
+// [atom0, atom0 + n_window).  One workgroup owns one tile for a whole range of frames: it streams
+// the window of every frame through LDS with 16-byte coalesced loads (each coordinate byte is
+// fetched from HBM exactly once) and each thread keeps the running i64 sum of ITS sample in
+// registers, so no cross-lane reduction or atomic is needed inside the frame loop.
+// Samples whose own atoms span more than `max_window` atoms go to a direct-gather list.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <vector>
+
+#include "../../include/gorder_hip.h"
+
+namespace gorder {
+
+constexpr uint32_t kBlock = 256;        // threads per workgroup = samples per tile
+constexpr uint32_t kMaxWindow = 1024;   // atoms per LDS window (12 KiB per staged frame)
+
+struct Item {            // one AA/CG bond sample of a tile (12 bytes)
+    uint16_t li, lj;     // atom indices relative to the tile's atom0 (p1, p2 of bond.rs:407-418)
+    uint16_t lslot;      // index into the tile's slot list
+    uint16_t pad;
+    uint32_t mol;        // global molecule id (molecule type major) -> leaflet flag lookup
+};
+struct Tile {
+    uint32_t atom0, n_window;
+    uint32_t item0, n_items;
+    uint32_t slot0, n_slots;   // range in Plan::tile_slots
+};
+struct DirectItem {
+    uint32_t i, j, slot, mol;
+};
+
+struct Plan {
+    uint32_t n_atoms = 0, n_acc = 0, n_mol_total = 0;
+    uint32_t max_window = 0;
+    std::vector<Tile> tiles;
+    std::vector<Item> items;
+    std::vector<uint32_t> tile_slots;
+    std::vector<DirectItem> direct;
+    std::vector<uint32_t> mol0;    // first global molecule id per molecule type
+    std::vector<uint32_t> slot0;   // first accumulator slot per molecule type
+};
+
+struct Sample {
+    uint32_t i, j, slot, mol;
+};
+
+// Returns GORDER_OK or GORDER_ERR_INVALID_ARGUMENT (index out of range, self bond, ...).
+inline int build_plan(const gorder_tables_t &t, bool force_direct, Plan &p) {
+    p = Plan();
+    p.n_atoms = t.n_atoms;
+    if (t.n_atoms == 0 || (t.n_molecule_types && !t.molecule_types)) return GORDER_ERR_INVALID_ARGUMENT;
+    std::vector<Sample> samples;
+    uint32_t slot = 0, mol = 0;
+    for (uint32_t m = 0; m < t.n_molecule_types; m++) {
+        const gorder_moltype_t &mt = t.molecule_types[m];
+        p.mol0.push_back(mol);
+        p.slot0.push_back(slot);
+        if (mt.n_bond_types && !mt.bonds) return GORDER_ERR_INVALID_ARGUMENT;
+        for (uint32_t bt = 0; bt < mt.n_bond_types; bt++) {
+            for (uint32_t k = 0; k < mt.n_molecules; k++) {
+                const uint32_t *b = mt.bonds + 2 * ((size_t)bt * mt.n_molecules + k);
+                if (b[0] >= t.n_atoms || b[1] >= t.n_atoms || b[0] == b[1]) return GORDER_ERR_INVALID_ARGUMENT;
+                samples.push_back({b[0], b[1], slot + bt, mol + k});
+            }
+        }
+        slot += mt.n_bond_types;
+        for (uint32_t a = 0; a < mt.n_ua_atoms; a++) {
+            const uint32_t kind = mt.ua_atoms[a].kind;
+            slot += kind == GORDER_UA_CH3 ? 3 : kind == GORDER_UA_CH2 ? 2 : 1;
+        }
+        mol += mt.n_molecules;
+    }
+    p.n_acc = slot;
+    p.n_mol_total = mol;
+
+    auto lo = [](const Sample &s) { return std::min(s.i, s.j); };
+    auto hi = [](const Sample &s) { return std::max(s.i, s.j); };
+    std::stable_sort(samples.begin(), samples.end(), [&](const Sample &a, const Sample &b) {
+        if (lo(a) != lo(b)) return lo(a) < lo(b);
+        return hi(a) < hi(b);
+    });
+
+    size_t k = 0;
+    while (k < samples.size()) {
+        const Sample &first = samples[k];
+        if (force_direct || hi(first) - lo(first) + 1 > kMaxWindow) {
+            p.direct.push_back({first.i, first.j, first.slot, first.mol});
+            k++;
+            continue;
+        }
+        Tile tile{};
+        tile.atom0 = lo(first);
+        tile.item0 = (uint32_t)p.items.size();
+        tile.slot0 = (uint32_t)p.tile_slots.size();
+        uint32_t top = hi(first);
+        std::vector<uint32_t> slots;
+        while (k < samples.size() && tile.n_items < kBlock) {
+            const Sample &s = samples[k];
+            if (hi(s) - lo(s) + 1 > kMaxWindow) {   // oversized sample: direct list, keep packing
+                p.direct.push_back({s.i, s.j, s.slot, s.mol});
+                k++;
+                continue;
+            }
+            const uint32_t ntop = std::max(top, hi(s));
+            if (ntop - tile.atom0 + 1 > kMaxWindow) break;
+            top = ntop;
+            uint32_t ls = 0;
+            for (; ls < slots.size(); ls++)
+                if (slots[ls] == s.slot) break;
+            if (ls == slots.size()) slots.push_back(s.slot);
+            p.items.push_back({(uint16_t)(s.i - tile.atom0), (uint16_t)(s.j - tile.atom0), (uint16_t)ls, 0, s.mol});
+            tile.n_items++;
+            k++;
+        }
+        tile.n_window = top - tile.atom0 + 1;
+        tile.n_slots = (uint32_t)slots.size();
+        p.tile_slots.insert(p.tile_slots.end(), slots.begin(), slots.end());
+        p.max_window = std::max(p.max_window, tile.n_window);
+        p.tiles.push_back(tile);
+    }
+    return GORDER_OK;
+}
+
+// Every sample of the tables appears exactly once (tile item or direct item) with the right atoms,
+// slot and molecule; windows stay inside the frame.  Used by the CPU test-suite.
+inline int selfcheck_plan(const gorder_tables_t &t, const Plan &p) {
+    std::vector<Sample> want, got;
+    uint32_t slot = 0, mol = 0;
+    for (uint32_t m = 0; m < t.n_molecule_types; m++) {
+        const gorder_moltype_t &mt = t.molecule_types[m];
+        for (uint32_t bt = 0; bt < mt.n_bond_types; bt++)
+            for (uint32_t k = 0; k < mt.n_molecules; k++) {
+                const uint32_t *b = mt.bonds + 2 * ((size_t)bt * mt.n_molecules + k);
+                want.push_back({b[0], b[1], slot + bt, mol + k});
+            }
+        slot += mt.n_bond_types;
+        for (uint32_t a = 0; a < mt.n_ua_atoms; a++) {
+            const uint32_t kind = mt.ua_atoms[a].kind;
+            slot += kind == GORDER_UA_CH3 ? 3 : kind == GORDER_UA_CH2 ? 2 : 1;
+        }
+        mol += mt.n_molecules;
+    }
+    for (const Tile &tile : p.tiles) {
+        if (tile.n_items == 0 || tile.n_items > kBlock) return 1;
+        if (tile.n_window == 0 || tile.n_window > kMaxWindow) return 2;
+        if ((uint64_t)tile.atom0 + tile.n_window > t.n_atoms) return 3;
+        if (tile.n_slots == 0 || tile.n_slots > tile.n_items) return 4;
+        for (uint32_t q = 0; q < tile.n_items; q++) {
+            const Item &it = p.items[tile.item0 + q];
+            if (it.li >= tile.n_window || it.lj >= tile.n_window || it.lslot >= tile.n_slots) return 5;
+            got.push_back({tile.atom0 + it.li, tile.atom0 + it.lj, p.tile_slots[tile.slot0 + it.lslot], it.mol});
+        }
+    }
+    for (const DirectItem &d : p.direct) got.push_back({d.i, d.j, d.slot, d.mol});
+    auto cmp = [](const Sample &a, const Sample &b) {
+        if (a.slot != b.slot) return a.slot < b.slot;
+        if (a.mol != b.mol) return a.mol < b.mol;
+        if (a.i != b.i) return a.i < b.i;
+        return a.j < b.j;
+    };
+    std::sort(want.begin(), want.end(), cmp);
+    std::sort(got.begin(), got.end(), cmp);
+    if (want.size() != got.size()) return 6;
+    for (size_t q = 0; q < want.size(); q++)
+        if (want[q].i != got[q].i || want[q].j != got[q].j || want[q].slot != got[q].slot ||
+            want[q].mol != got[q].mol)
+            return 7;
+    return 0;
+}
+
+}  // namespace gorder

@@ -1,0 +1,230 @@
+/*
+ * gorder_hip.h — C ABI of the MI355X (gfx950) lipid-order engine.
+ *
+ * This is the drop-in boundary for ONE path of VachaLab/gorder: the per-frame
+ * order-parameter computation that gorder runs inside
+ *   groan_rs `System::traj_iter_map_reduce(.., body = analyze_frame, ..)`
+ *   (call sites  src/analysis/common.rs:283-339, body  src/analysis/common.rs:201-235,
+ *    data type  `SystemTopology`  src/analysis/topology/mod.rs:34-65,
+ *    map/reduce trait impl  src/analysis/topology/mod.rs:256-278).
+ *
+ * Mapping of the reference's interface onto this ABI
+ *   SystemTopology::new  (topology/mod.rs:70-118)        -> gorder_hip_create
+ *   ParallelTrajData::initialize (topology/mod.rs:274-277) -> one handle per GPU/rank; the caller
+ *                                                            passes GLOBAL frame indices to submit
+ *   analyze_frame (common.rs:201-235), called per frame   -> gorder_hip_submit_{device,host}, called
+ *                                                            per BATCH of frames (AoS xyz as decoded)
+ *   SystemTopology::add / reduce (topology/mod.rs:236-272) -> gorder_hip_finish returns raw i64 sums +
+ *                                                            u64 counts which add element-wise
+ *                                                            (order.rs:160-176, ordermap.rs:116-138);
+ *                                                            on a multi-GPU node one RCCL all-reduce
+ *                                                            over the packed buffer of
+ *                                                            gorder_hip_accumulators_device()
+ *   Result<(), AnalysisError> (errors.rs:121-168)          -> gorder_status_t + gorder_hip_last_error_index
+ *
+ * Plain pointers and sizes only.  No allocation ownership crosses the boundary: every input
+ * buffer stays owned by the caller, every output buffer is caller-allocated.
+ * A handle is thread-compatible (one handle per host thread / GPU / stream), exactly like one
+ * `SystemTopology` clone per thread in the reference.
+ */
+#ifndef GORDER_HIP_H
+#define GORDER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ---------------------------------------------------------------------------
+ * 1..6 mirror the AnalysisError variants the per-frame path can raise (src/errors.rs:121-141).
+ * >= 100 are errors of this library (no counterpart in the reference). */
+typedef enum {
+    GORDER_OK = 0,
+    GORDER_ERR_UNDEFINED_BOX = 1,                   /* AnalysisError::UndefinedBox            errors.rs:124 */
+    GORDER_ERR_NOT_ORTHOGONAL_BOX = 2,              /* AnalysisError::NotOrthogonalBox        errors.rs:128 */
+    GORDER_ERR_ZERO_BOX = 3,                        /* AnalysisError::ZeroBox                 errors.rs:132 */
+    GORDER_ERR_UNDEFINED_POSITION = 4,              /* AnalysisError::UndefinedPosition(idx)  errors.rs:136 */
+    GORDER_ERR_INVALID_GLOBAL_MEMBRANE_CENTER = 5,  /* ...::InvalidGlobalMembraneCenter       errors.rs:139 */
+    GORDER_ERR_INVALID_LOCAL_MEMBRANE_CENTER = 6,   /* ...::InvalidLocalMembraneCenter(idx)   errors.rs:143 */
+    GORDER_ERR_INVALID_ARGUMENT = 100,
+    GORDER_ERR_DEVICE = 101,          /* a HIP runtime call failed; see gorder_hip_last_error_message */
+    GORDER_ERR_NO_DEVICE = 102,       /* no gfx950 device visible: the product path has NO CPU fallback */
+    GORDER_ERR_BOX_RANGE = 103,       /* a box edge is <= 0 / NaN, or a coordinate lies so far outside
+                                         the box that the reference's `while` minimum-image loop would not
+                                         terminate in 8 iterations (the reference would spin) */
+    GORDER_ERR_LEAFLETS_NOT_PRIMED = 104, /* first submitted frame is not an assignment frame and no
+                                             earlier assignment is known: call gorder_hip_prime_leaflets */
+    GORDER_ERR_OVERFLOW = 105         /* i64 accumulator overflow (reference panics, order.rs:44-60) */
+} gorder_status_t;
+
+/* ---- leaflets -------------------------------------------------------------------------------- */
+typedef enum {
+    GORDER_LEAFLETS_NONE = 0,
+    GORDER_LEAFLETS_GLOBAL = 1,      /* leaflets.rs:171-205 + :711-732 */
+    GORDER_LEAFLETS_LOCAL = 2,       /* leaflets.rs:661-675 + pbc.rs:273-318 + :711-732 */
+    GORDER_LEAFLETS_INDIVIDUAL = 3,  /* leaflets.rs:777-801 */
+    GORDER_LEAFLETS_MANUAL = 4       /* host supplies flags per assignment frame (leaflets.rs:820-860);
+                                        Leaflet encoding Upper=0, Lower=1 (lib.rs:416-422) */
+} gorder_leaflet_method_t;
+
+typedef struct {
+    uint32_t method;        /* gorder_leaflet_method_t */
+    uint32_t normal_dim;    /* 0=x 1=y 2=z : `membrane_normal: Dimension` of the classifier */
+    uint32_t frequency;     /* 0 = Frequency::Once, n>=1 = Frequency::Every(n); this is the REAL
+                               frequency = input frequency * step (leaflets.rs:157-163) */
+    uint32_t flip;          /* leaflets.rs:68-73 */
+    float radius;           /* Local: cylinder radius in nm (leaflets.rs:389-418) */
+    uint32_t n_membrane;    /* Global/Local: size of group "Membrane" */
+    const uint32_t *membrane; /* atom indices (into the submitted coordinate frame) */
+} gorder_leaflets_t;
+
+/* ---- ordermaps (src/analysis/ordermap.rs:40-113, input/ordermap.rs:34-50) --------------------- */
+typedef struct {
+    uint32_t enabled;
+    uint32_t plane;         /* 0=xy, 1=xz, 2=yz (yz projects to (z, y), input/ordermap.rs:48) */
+    float span_x[2];        /* resolved span; GridSpan::Auto => (0, box) of the STRUCTURE file */
+    float span_y[2];
+    float bin[2];
+} gorder_ordermap_t;
+
+/* ---- molecule types ---------------------------------------------------------------------------
+ * United-atom carbon kinds (uaorder.rs:448-452). */
+typedef enum {
+    GORDER_UA_CH1_SAT = 1,   /* indices = helper1, helper2, helper3, target  (uaorder.rs:1050-1055) */
+    GORDER_UA_CH2 = 2,       /* indices = helper1, target, helper2, -        (uaorder.rs:911-915)  */
+    GORDER_UA_CH3 = 3,
+    GORDER_UA_CH1_UNSAT = 4
+} gorder_ua_kind_t;
+
+typedef struct {
+    uint32_t kind;             /* gorder_ua_kind_t; number of virtual C-H bonds = 1,2,3,1 */
+    const uint32_t *indices;   /* [n_molecules][4] */
+} gorder_ua_atom_t;
+
+typedef struct {
+    uint32_t n_molecules;
+    /* AA / CG (BondType, topology/bond.rs:220-246): */
+    uint32_t n_bond_types;
+    const uint32_t *bonds;     /* [n_bond_types][n_molecules][2] atom indices, first < second
+                                  (bond.rs:300-304, 338-344) */
+    /* UA (UAOrderAtoms, topology/uatom.rs): */
+    uint32_t n_ua_atoms;
+    const gorder_ua_atom_t *ua_atoms;
+    /* leaflet classifier inputs (leaflets.rs:575-590, 744-775): */
+    const uint32_t *heads;     /* [n_molecules] or NULL */
+    uint32_t n_methyls;        /* equal for all molecules of a type (leaflets.rs:760-770) */
+    const uint32_t *methyls;   /* [n_molecules][n_methyls] or NULL */
+} gorder_moltype_t;
+
+typedef struct {
+    uint32_t n_atoms;           /* atoms per submitted frame (the decoded "Master" group, common.rs:283-304) */
+    uint32_t n_molecule_types;
+    const gorder_moltype_t *molecule_types;
+    int32_t handle_pbc;         /* 1 = PBC3D (pbc.rs:257-460), 0 = NoPBC (pbc.rs:98-253) */
+    float normal[3];            /* static membrane normal (normal.rs:75-87, input/axis.rs:49-58) */
+    gorder_leaflets_t leaflets;
+    gorder_ordermap_t ordermap;
+    int32_t timewise;           /* 1 = keep per-frame partial sums (estimate_error; timewise.rs:130-186) */
+    int32_t device;             /* HIP device ordinal */
+} gorder_tables_t;
+
+/* Accumulator slots are numbered in reference iteration order: molecule type major, then bond
+ * type (AA/CG) or (united atom, hydrogen) (UA).  n_acc = number of slots.  All result arrays are
+ * laid out [3][n_acc] with the leading index 0=total, 1=upper, 2=lower (bond.rs:233-246). */
+
+typedef struct gorder_hip_handle gorder_hip_handle;
+
+int gorder_hip_create(const gorder_tables_t *tables, gorder_hip_handle **out);
+void gorder_hip_destroy(gorder_hip_handle *h);
+
+/* number of accumulator slots / ordermap tiles (0 if maps are off) */
+uint32_t gorder_hip_n_accumulators(const gorder_hip_handle *h);
+uint32_t gorder_hip_ordermap_dims(const gorder_hip_handle *h, uint32_t *nx, uint32_t *ny);
+
+/* Run the launches of this handle on a caller-owned hipStream_t (e.g. PyTorch's current stream).
+ * NULL selects the handle's own stream. */
+int gorder_hip_set_stream(gorder_hip_handle *h, void *hip_stream);
+
+/* Analyse a batch of frames whose coordinates are ALREADY in HBM.
+ *   d_xyz  [n_frames][n_atoms][3] f32 (AoS, exactly as an XTC decoder emits them), 16-byte aligned
+ *   d_box  [n_frames][3][3]       f32 box matrix rows (GROMACS/XTC order); must be diagonal
+ *   frame_index [n_frames] (HOST) global frame indices = `SystemTopology::frame` (topology/mod.rs:141-144)
+ * Asynchronous on the handle's stream; errors raised on the device surface at the next
+ * gorder_hip_synchronize / gorder_hip_finish. */
+int gorder_hip_submit_device(gorder_hip_handle *h, const float *d_xyz, const float *d_box,
+                             const uint64_t *frame_index, uint32_t n_frames);
+
+/* Same, from host memory (pinned or pageable); stages through an internal device buffer. */
+int gorder_hip_submit_host(gorder_hip_handle *h, const float *xyz, const float *box,
+                           const uint64_t *frame_index, uint32_t n_frames);
+
+/* Compute (only) the leaflet assignment of ONE frame that precedes a rank's frame range
+ * (replaces the cross-thread spin-wait of leaflets.rs:1529-1565). */
+int gorder_hip_prime_leaflets(gorder_hip_handle *h, const float *d_xyz, const float *d_box,
+                              uint64_t frame_index);
+
+/* Manual assignment (GORDER_LEAFLETS_MANUAL): flags[n_molecules_total] for the assignment frame
+ * that applies from `frame_index` on; molecules ordered molecule type major. */
+int gorder_hip_set_manual_leaflets(gorder_hip_handle *h, const uint8_t *flags, uint64_t frame_index);
+
+int gorder_hip_synchronize(gorder_hip_handle *h);
+
+/* Synchronise and copy the accumulators out.  Leaves them intact (callers may keep submitting).
+ *   sums   [3][n_acc] i64 : sum of round(f64(S) * 1e6)            (order.rs:13-26)
+ *   counts [3][n_acc] u64 : n_samples                              (order.rs:178-188)
+ * Optional (NULL to skip):
+ *   map_sums / map_counts [3][n_acc][nx*ny]  (x-major, y inner; ordermap.rs:100-113)
+ * n_frames_analyzed: `total_frames` (topology/mod.rs:141-144). */
+int gorder_hip_finish(gorder_hip_handle *h, int64_t *sums, uint64_t *counts, int64_t *map_sums,
+                      uint64_t *map_counts, uint64_t *n_frames_analyzed);
+
+/* Per-frame partial sums (timewise.rs:130-186) of the frames submitted so far, in submission order:
+ *   tw_sums / tw_counts [n_frames_analyzed][3][n_acc].  Requires tables.timewise = 1. */
+int gorder_hip_timewise(gorder_hip_handle *h, int64_t *tw_sums, uint64_t *tw_counts,
+                        uint64_t capacity_frames);
+
+/* Leaflet flags of the most recent assignment frame, [n_molecules_total] (Upper=0, Lower=1). */
+int gorder_hip_leaflets(gorder_hip_handle *h, uint8_t *flags, uint64_t *assignment_frame);
+/* Signed distances (nm) behind those flags, [n_molecules_total] (leaflets.rs:725, 796). */
+int gorder_hip_leaflet_distances(gorder_hip_handle *h, float *distances);
+
+/* Device pointer + element count of the packed u64 accumulator block
+ * {i64 sums[3][n_acc], u64 counts[3][n_acc], u64 total_frames, (maps...)} so that a host can issue
+ * ONE RCCL all-reduce (ncclUint64 / ncclSum) over it — the multi-GPU form of
+ * SystemTopology::reduce (topology/mod.rs:256-272). */
+int gorder_hip_accumulators_device(gorder_hip_handle *h, void **d_ptr, uint64_t *n_u64);
+
+/* Make the handle accumulate into caller-owned device memory (>= n_u64 words, 8-byte aligned; e.g.
+ * a torch.int64 tensor that the host then hands to torch.distributed.all_reduce = RCCL).  The
+ * current contents of the handle's accumulators are copied over. */
+int gorder_hip_bind_accumulators(gorder_hip_handle *h, void *d_ptr, uint64_t n_u64);
+
+/* Payload of the last UndefinedPosition / InvalidLocalMembraneCenter error (atom index). */
+uint64_t gorder_hip_last_error_index(const gorder_hip_handle *h);
+const char *gorder_hip_last_error_message(const gorder_hip_handle *h);
+const char *gorder_hip_strerror(int status);
+
+/* Device time (ms, HIP events on the launch stream) and launch count of the dominant per-frame
+ * kernel since the last call with reset != 0. */
+int gorder_hip_kernel_time(gorder_hip_handle *h, double *ms, uint64_t *launches, int reset);
+
+/* Introspection for tests / DESIGN.md: how the bond table was tiled. */
+typedef struct {
+    uint32_t n_tiles;
+    uint32_t block_threads;
+    uint32_t max_window_atoms;
+    uint32_t n_direct_items;     /* samples that did not fit an LDS window (direct-gather kernel) */
+    uint32_t frames_per_stage;
+    uint32_t lds_bytes;
+} gorder_hip_plan_t;
+int gorder_hip_plan(const gorder_hip_handle *h, gorder_hip_plan_t *plan);
+/* Same, without touching a device (host logic only); *selfcheck = 0 when every sample of the
+ * tables is covered exactly once by the plan. */
+int gorder_hip_plan_tables(const gorder_tables_t *tables, gorder_hip_plan_t *plan, int *selfcheck);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GORDER_HIP_H */

@@ -1,0 +1,890 @@
+/*
+ * gorder_oracle.c — CPU restatement (plain C99 + pthreads) of the per-frame order-parameter path of
+ * VachaLab/gorder v1.4.1.  Every function cites the reference file:line it follows.
+ *
+ * TEST INFRASTRUCTURE ONLY (see gorder_oracle.h).  Not part of the product path.
+ *
+ * Pinning status: see DESIGN.md §"Oracle".  The reference is Rust and cannot be built here (no
+ * cargo/rustc, un-vendored crates), so this restatement is pinned by the reference's own known-
+ * answer tests and golden output files (tests/golden/, tests/test_oracle_*.py).
+ * Arithmetic that lives in third-party crates absent from /root/reference (groan_rs 0.11.2,
+ * nalgebra 0.34.0, statistical 1.0.0) is restated from their documented behaviour; each such
+ * function is marked [3rd-party].
+ *
+ * All geometry is f32 with NO fused multiply-add (build with -ffp-contract=off): rustc never
+ * contracts a*b+c.  fmaf() appears only in MIRROR-mode trig, which restates the device kernels.
+ */
+#define _GNU_SOURCE
+#include "gorder_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ============================================================================================
+ * scalar building blocks
+ * ========================================================================================== */
+
+#define MI_MAX_ITER 8 /* see GORDER_ERR_BOX_RANGE in gorder_hip.h */
+
+/* [3rd-party] groan_rs minimum image of a 1-D displacement: shift by whole box lengths until the
+ * value lies in [-L/2, L/2].  Used by Vector3D::vector_to (pbc.rs:378-385) and ::distance
+ * (pbc.rs:354-356).  `*bad` is raised instead of spinning for ever on a degenerate input. */
+static inline float min_image(float dx, float L, int *bad) {
+    const float half = L / 2.0f;
+    int it = 0;
+    while (dx > half) {
+        dx -= L;
+        if (++it > MI_MAX_ITER) { *bad = 1; return dx; }
+    }
+    it = 0;
+    while (dx < -half) {
+        dx += L;
+        if (++it > MI_MAX_ITER) { *bad = 1; return dx; }
+    }
+    return dx;
+}
+
+/* [3rd-party] groan_rs Vector3D::wrap: into [0, L] per dimension (pbc.rs:388-390). */
+static inline float wrap1(float x, float L, int *bad) {
+    int it = 0;
+    while (x > L) {
+        x -= L;
+        if (++it > MI_MAX_ITER) { *bad = 1; return x; }
+    }
+    it = 0;
+    while (x < 0.0f) {
+        x += L;
+        if (++it > MI_MAX_ITER) { *bad = 1; return x; }
+    }
+    return x;
+}
+
+/* PBC3D::vector_to (pbc.rs:378-385) / NoPBC::vector_to (pbc.rs:188-190) */
+static inline int vector_to(const float *p1, const float *p2, const float *box, int pbc, float *out) {
+    int bad = 0;
+    for (int d = 0; d < 3; d++) {
+        float v = p2[d] - p1[d];
+        out[d] = pbc ? min_image(v, box[d], &bad) : v;
+    }
+    return bad;
+}
+
+int gorder_oracle_vector_to(const float p1[3], const float p2[3], const float box[3], int handle_pbc,
+                            float out[3]) {
+    return vector_to(p1, p2, box, handle_pbc, out);
+}
+
+/* [3rd-party] nalgebra dot / norm of a 3-vector: (a0*b0 + a1*b1) + a2*b2, sqrt of the same. */
+static inline float dot3(const float *a, const float *b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+static inline float norm3(const float *a) { return sqrtf(dot3(a, a)); }
+
+/* ---- MIRROR-mode trig: restatement of gorder_amd/csrc/gm_math.h (same operations, same order) */
+static const float M_PIO2_HI = 0x1.921fb6p+0f, M_PIO2_LO = -0x1.777a5cp-25f;
+static const float M_PI_HI = 0x1.921fb6p+1f, M_PI_LO = -0x1.777a5cp-24f;
+static const float M_PIO4 = 0x1.921fb6p-1f, M_3PIO4 = 0x1.2d97c8p+1f;
+
+static inline float m_asin_r(float z) {
+    float p = 0x1.15e1a4p-5f;
+    p = fmaf(p, z, 0x1.169f76p-6f);
+    p = fmaf(p, z, 0x1.fe10bap-6f);
+    p = fmaf(p, z, 0x1.6d55e6p-5f);
+    p = fmaf(p, z, 0x1.333448p-4f);
+    p = fmaf(p, z, 0x1.555554p-3f);
+    return p;
+}
+
+float gorder_oracle_mirror_acosf(float x) {
+    const float ax = fabsf(x);
+    if (!(ax <= 1.0f)) return NAN;
+    if (ax <= 0.5f) {
+        const float z = x * x;
+        const float r = z * m_asin_r(z);
+        return M_PIO2_HI - (x - (M_PIO2_LO - x * r));
+    }
+    const float z = (1.0f - ax) * 0.5f;
+    const float s = sqrtf(z);
+    const float r = z * m_asin_r(z);
+    const float c = (s > 0.0f) ? fmaf(-s, s, z) / (s + s) : 0.0f;
+    float w = fmaf(s, r, c);
+    if (x > 0.0f) return 2.0f * (s + w);
+    w = w - M_PIO2_LO;
+    return 2.0f * (M_PIO2_HI - (s + w));
+}
+
+static inline float m_kcos(float r) {
+    const float z = r * r;
+    const float zl = fmaf(r, r, -z);
+    const float c = fmaf(fmaf(0x1.9bd908p-16f, z, -0x1.6c12d4p-10f), z, 0x1.555554p-5f);
+    const float hz = 0.5f * z;
+    const float w = 1.0f - hz;
+    return w + ((((1.0f - w) - hz) - 0.5f * zl) + z * (z * c));
+}
+static inline float m_ksin(float r) {
+    const float z = r * r;
+    const float s =
+        fmaf(fmaf(fmaf(0x1.6dbf02p-19f, z, -0x1.a013acp-13f), z, 0x1.11110ep-7f), z, -0x1.555556p-3f);
+    return fmaf(r * z, s, r);
+}
+/* valid for t in [0, pi] (the range of acos); NaN propagates */
+float gorder_oracle_mirror_cosf(float t) {
+    if (t < M_PIO4) return m_kcos(t);
+    if (t <= M_3PIO4) return m_ksin((M_PIO2_HI - t) + M_PIO2_LO);
+    if (t != t) return t;
+    return -m_kcos((M_PI_HI - t) + M_PI_LO);
+}
+
+/* [3rd-party] nalgebra Matrix::angle, reached through groan_rs Vector3D::angle (mod.rs:79):
+ * 0 if either norm is 0, else acos(clamp(a.b / (|a||b|), -1, 1)); clamp lets NaN through. */
+static inline float angle3(const float *a, const float *b, int trig) {
+    const float prod = dot3(a, b);
+    const float n1 = norm3(a), n2 = norm3(b);
+    if (n1 == 0.0f || n2 == 0.0f) return 0.0f;
+    float c = prod / (n1 * n2);
+    if (c < -1.0f) c = -1.0f;
+    else if (c > 1.0f) c = 1.0f;
+    return trig == GORDER_ORACLE_TRIG_MIRROR ? gorder_oracle_mirror_acosf(c) : acosf(c);
+}
+
+/* calc_sch, src/analysis/mod.rs:78-82 */
+static inline float calc_sch(const float *v, const float *n, int trig) {
+    const float angle = angle3(v, n, trig);
+    const float co = trig == GORDER_ORACLE_TRIG_MIRROR ? gorder_oracle_mirror_cosf(angle) : cosf(angle);
+    return (1.5f * co * co) - 0.5f;
+}
+float gorder_oracle_calc_sch(const float v[3], const float n[3], int trig_mode) {
+    return calc_sch(v, n, trig_mode);
+}
+
+/* OrderValue::from(f32), order.rs:21-26: (value as f64 * 1e6).round() as i64.
+ * f64::round = half away from zero; `as i64` saturates and maps NaN to 0. */
+int64_t gorder_oracle_tick(float s) {
+    const double t = round((double)s * 1000000.0);
+    if (t != t) return 0;
+    if (t >= 9223372036854775807.0) return INT64_MAX;
+    if (t <= -9223372036854775808.0) return INT64_MIN;
+    return (int64_t)t;
+}
+
+/* AnalysisOrder::calc_order (order.rs:101-107) with OrderValue / usize (order.rs:34-42, truncating
+ * integer division) and f32::from(OrderValue) (order.rs:28-32). */
+float gorder_oracle_calc_order(int64_t sum, uint64_t n, uint64_t min_samples) {
+    if (n < min_samples || n == 0) return NAN;
+    const int64_t q = sum / (int64_t)n;
+    return (float)((double)q / 1000000.0);
+}
+
+/* ---- centre of geometry -------------------------------------------------------------------
+ * [3rd-party] groan_rs System::group_get_center (pbc.rs:269-271) / iterator get_center
+ * (pbc.rs:305-308): "Refined Bai-Breen" (CHANGELOG.md:46).  Restated as: wrap each position, map
+ * to an angle per dimension, average cos/sin, take the circular mean; then refine with the plain
+ * mean of the minimum-image displacements from that estimate and wrap.  NoPBC: arithmetic mean
+ * (group_get_center_naive, pbc.rs:103).  Summation in atom-index order, f32.
+ * Only the SIGN of (head - centre) along the normal feeds the results (leaflets.rs:725-731), so
+ * last-bit differences from the crate cannot change a flag except for a lipid sitting within
+ * ~1e-6 nm of the centre plane; pinned through the leaflet counts of aaorder.rs:268-350. */
+static int center_of(const float *xyz, const uint32_t *idx, uint32_t n, const float *box, int pbc,
+                     float *out) {
+    int bad = 0;
+    if (n == 0) { out[0] = out[1] = out[2] = NAN; return 0; }
+    if (!pbc) {
+        float s[3] = {0, 0, 0};
+        for (uint32_t i = 0; i < n; i++) {
+            const float *p = xyz + 3 * (size_t)idx[i];
+            s[0] += p[0]; s[1] += p[1]; s[2] += p[2];
+        }
+        for (int d = 0; d < 3; d++) out[d] = s[d] / (float)n;
+        return 0;
+    }
+    const float two_pi = 6.2831855f;
+    float est[3];
+    for (int d = 0; d < 3; d++) {
+        const float scaling = two_pi / box[d];
+        float sc = 0.0f, ss = 0.0f;
+        for (uint32_t i = 0; i < n; i++) {
+            float c = wrap1(xyz[3 * (size_t)idx[i] + d], box[d], &bad);
+            const float theta = c * scaling;
+            sc += cosf(theta);
+            ss += sinf(theta);
+        }
+        const float th = atan2f(-ss, -sc) + 3.1415927f;
+        est[d] = th / scaling;
+    }
+    for (int d = 0; d < 3; d++) {
+        float acc = 0.0f;
+        for (uint32_t i = 0; i < n; i++) {
+            const float dx = xyz[3 * (size_t)idx[i] + d] - est[d];
+            acc += min_image(dx, box[d], &bad);
+        }
+        out[d] = wrap1(est[d] + acc / (float)n, box[d], &bad);
+    }
+    return bad;
+}
+int gorder_oracle_center(const float *xyz, const uint32_t *idx, uint32_t n, const float box[3],
+                         int handle_pbc, float out[3]) {
+    return center_of(xyz, idx, n, box, handle_pbc, out);
+}
+
+/* ---- united-atom hydrogen construction, uaorder.rs:947-1104 ------------------------------- */
+static const float TETRAHEDRAL_ANGLE = 1.910633f;      /* uaorder.rs:35 */
+static const float TETRAHEDRAL_ANGLE_HALF = 0.9553165f; /* uaorder.rs:37 */
+static const float BOND_LENGTH = 0.109f;                /* uaorder.rs:39 */
+static const float CH3_ANGLE = 2.0943952f;              /* uaorder.rs:41 */
+
+static inline void cross3(const float *a, const float *b, float *o) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+/* [3rd-party] nalgebra Unit::new_normalize / groan_rs to_unit: component / norm */
+static inline void unit3(const float *a, float *o) {
+    const float n = norm3(a);
+    o[0] = a[0] / n; o[1] = a[1] / n; o[2] = a[2] / n;
+}
+/* [3rd-party] nalgebra Rotation3::from_axis_angle(unit axis, angle) applied to v
+ * (groan_rs Vector3D::rotate = matrix * vector, column-accumulated). */
+static void rotate_axis_angle(const float *u, float angle, const float *v, float *o) {
+    if (angle == 0.0f) { o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; return; }
+    const float ux = u[0], uy = u[1], uz = u[2];
+    const float sqx = ux * ux, sqy = uy * uy, sqz = uz * uz;
+    const float s = sinf(angle), c = cosf(angle);
+    const float omc = 1.0f - c;
+    const float m11 = sqx + (1.0f - sqx) * c;
+    const float m12 = ux * uy * omc - uz * s;
+    const float m13 = ux * uz * omc + uy * s;
+    const float m21 = ux * uy * omc + uz * s;
+    const float m22 = sqy + (1.0f - sqy) * c;
+    const float m23 = uy * uz * omc - ux * s;
+    const float m31 = ux * uz * omc - uy * s;
+    const float m32 = uy * uz * omc + ux * s;
+    const float m33 = sqz + (1.0f - sqz) * c;
+    o[0] = (m11 * v[0] + m12 * v[1]) + m13 * v[2];
+    o[1] = (m21 * v[0] + m22 * v[1]) + m23 * v[2];
+    o[2] = (m31 * v[0] + m32 * v[1]) + m33 * v[2];
+}
+/* [3rd-party] groan_rs Vector3D::shift(direction, distance): move along the normalised direction;
+ * then PBCHandler::wrap (pbc.rs:388-390; no-op for NoPBC, pbc.rs:193) */
+static int shift_wrap(const float *target, const float *dir, const float *box, int pbc, float *h) {
+    float u[3];
+    int bad = 0;
+    unit3(dir, u);
+    for (int d = 0; d < 3; d++) {
+        h[d] = target[d] + u[d] * BOND_LENGTH;
+        if (pbc) h[d] = wrap1(h[d], box[d], &bad);
+    }
+    return bad;
+}
+
+int gorder_oracle_predict_hydrogens(uint32_t kind, const float pos[4][3], const float box[3],
+                                    int pbc, float out[3][3]) {
+    int bad = 0;
+    if (kind == GORDER_UA_CH3) { /* uaorder.rs:947-981; indices helper1,target,helper2 */
+        const float *h1 = pos[0], *t = pos[1], *h2 = pos[2];
+        float th1[3], th2[3], axis[3], ua[3], hv1[3], nth1[3], hv[3];
+        bad |= vector_to(t, h1, box, pbc, th1);
+        bad |= vector_to(t, h2, box, pbc, th2);
+        cross3(th2, th1, axis);
+        unit3(axis, ua);
+        rotate_axis_angle(ua, TETRAHEDRAL_ANGLE, th1, hv1);
+        bad |= shift_wrap(t, hv1, box, pbc, out[0]);
+        unit3(th1, nth1);
+        rotate_axis_angle(nth1, CH3_ANGLE, hv1, hv);
+        bad |= shift_wrap(t, hv, box, pbc, out[1]);
+        rotate_axis_angle(nth1, -CH3_ANGLE, hv1, hv);
+        bad |= shift_wrap(t, hv, box, pbc, out[2]);
+        return bad ? -1 : 3;
+    }
+    if (kind == GORDER_UA_CH2) { /* uaorder.rs:985-1020 */
+        const float *h1 = pos[0], *t = pos[1], *h2 = pos[2];
+        float a[3], b[3], th1[3], th2[3], pn[3], diff[3], ra[3], rv[3], ura[3], hv[3];
+        bad |= vector_to(t, h1, box, pbc, a);
+        bad |= vector_to(t, h2, box, pbc, b);
+        unit3(a, th1);
+        unit3(b, th2);
+        cross3(th2, th1, pn);
+        for (int d = 0; d < 3; d++) diff[d] = th1[d] - th2[d];
+        unit3(diff, ra);
+        cross3(pn, ra, rv);
+        unit3(ra, ura); /* Unit::new_normalize(*rot_axis) normalises the already-unit axis again */
+        rotate_axis_angle(ura, TETRAHEDRAL_ANGLE_HALF, rv, hv);
+        bad |= shift_wrap(t, hv, box, pbc, out[0]);
+        rotate_axis_angle(ura, -TETRAHEDRAL_ANGLE_HALF, rv, hv);
+        bad |= shift_wrap(t, hv, box, pbc, out[1]);
+        return bad ? -1 : 2;
+    }
+    if (kind == GORDER_UA_CH1_UNSAT) { /* uaorder.rs:1024-1045 */
+        const float *h1 = pos[0], *t = pos[1], *h2 = pos[2];
+        float th1[3], th2[3], axis[3], ua[3], hv[3];
+        bad |= vector_to(t, h1, box, pbc, th1);
+        bad |= vector_to(t, h2, box, pbc, th2);
+        const float gamma = angle3(th1, th2, GORDER_ORACLE_TRIG_LIBM);
+        cross3(th1, th2, axis);
+        unit3(axis, ua);
+        rotate_axis_angle(ua, 3.14159265358979323846f - (gamma / 2.0f), th2, hv);
+        bad |= shift_wrap(t, hv, box, pbc, out[0]);
+        return bad ? -1 : 1;
+    }
+    if (kind == GORDER_UA_CH1_SAT) { /* uaorder.rs:1087-1104; indices h1,h2,h3,target */
+        const float *t = pos[3];
+        float a[3], th1[3], th2[3], th3[3], hv[3];
+        bad |= vector_to(t, pos[0], box, pbc, a); unit3(a, th1);
+        bad |= vector_to(t, pos[1], box, pbc, a); unit3(a, th2);
+        bad |= vector_to(t, pos[2], box, pbc, a); unit3(a, th3);
+        for (int d = 0; d < 3; d++) hv[d] = -((th1[d] + th2[d]) + th3[d]);
+        bad |= shift_wrap(t, hv, box, pbc, out[0]);
+        return bad ? -1 : 1;
+    }
+    return -2;
+}
+
+/* ---- timewise statistics ------------------------------------------------------------------ */
+/* TimeWiseData::estimate_error, timewise.rs:191-231; [3rd-party] statistical::standard_deviation
+ * = sqrt(sum((x-mean)^2)/(n-1)) in f32. */
+float gorder_oracle_estimate_error(const int64_t *sums, const uint64_t *counts, uint64_t n_frames,
+                                   uint64_t n_blocks) {
+    if (n_frames == 0 || n_blocks < 2) return NAN;
+    const uint64_t block_size = n_frames / n_blocks;
+    if (block_size == 0) return NAN;
+    int64_t *bs = (int64_t *)calloc(n_blocks, sizeof(int64_t));
+    uint64_t *bn = (uint64_t *)calloc(n_blocks, sizeof(uint64_t));
+    for (uint64_t i = 0; i < n_frames; i++) {
+        const uint64_t b = i / block_size;
+        if (b < n_blocks) { bs[b] += sums[i]; bn[b] += counts[i]; }
+    }
+    float *o = (float *)malloc(n_blocks * sizeof(float));
+    float result;
+    int nan = 0;
+    for (uint64_t b = 0; b < n_blocks; b++) {
+        if (bn[b] == 0) { nan = 1; break; }
+        o[b] = (float)((double)(bs[b] / (int64_t)bn[b]) / 1000000.0);
+    }
+    if (nan) result = NAN;
+    else {
+        float mean = 0.0f;
+        for (uint64_t b = 0; b < n_blocks; b++) mean += o[b];
+        mean = mean / (float)n_blocks;
+        float var = 0.0f;
+        for (uint64_t b = 0; b < n_blocks; b++) { const float d = mean - o[b]; var += d * d; }
+        result = sqrtf(var / (float)(n_blocks - 1));
+    }
+    free(bs); free(bn); free(o);
+    return result;
+}
+/* TimeWiseData::prefix_average, timewise.rs:259-274 */
+void gorder_oracle_prefix_average(const int64_t *sums, const uint64_t *counts, uint64_t n_frames,
+                                  float *out) {
+    int64_t s = 0;
+    uint64_t n = 0;
+    for (uint64_t i = 0; i < n_frames; i++) {
+        s += sums[i];
+        n += counts[i];
+        out[i] = n == 0 ? NAN : (float)((double)(s / (int64_t)n) / 1000000.0);
+    }
+}
+
+/* ============================================================================================
+ * the analysis state ("SystemTopology", topology/mod.rs:34-65)
+ * ========================================================================================== */
+
+typedef struct {
+    uint32_t n_molecules, n_bond_types, n_ua_atoms, n_methyls;
+    uint32_t *bonds;      /* [n_bond_types][n_molecules][2] */
+    uint32_t *ua_kind;    /* [n_ua_atoms] */
+    uint32_t **ua_idx;    /* [n_ua_atoms] -> [n_molecules][4] */
+    uint32_t *ua_slot0;   /* first accumulator slot of each ua atom */
+    uint32_t *heads;      /* [n_molecules] or NULL */
+    uint32_t *methyls;    /* [n_molecules][n_methyls] or NULL */
+    uint32_t slot0;       /* first accumulator slot of this molecule type */
+    uint32_t mol0;        /* index of first molecule in the global molecule numbering */
+} o_moltype;
+
+typedef struct {
+    int64_t *sums;     /* [3][n_acc] */
+    uint64_t *counts;  /* [3][n_acc] */
+    int64_t *map_sums; /* [3][n_acc][ntiles] or NULL */
+    uint64_t *map_counts;
+} o_acc;
+
+struct gorder_oracle_handle {
+    uint32_t n_atoms, n_mt, n_acc, n_mol_total;
+    o_moltype *mt;
+    int pbc, trig, n_threads, timewise;
+    float normal[3];
+    gorder_leaflets_t lf;
+    uint32_t *membrane;
+    gorder_ordermap_t om;
+    uint32_t nx, ny;
+    o_acc acc;
+    /* leaflets: flags of the most recent assignment (AssignedLeaflets::local, leaflets.rs:1371-1380) */
+    uint8_t *flags;
+    float *flag_dist;
+    int have_flags;
+    uint64_t flags_frame;
+    /* timewise: grows by one row [3][n_acc] per analysed frame */
+    int64_t *tw_sums;
+    uint64_t *tw_counts;
+    uint64_t tw_cap;
+    uint64_t n_frames;
+    uint64_t err_index;
+};
+
+static void acc_alloc(const gorder_oracle_handle *h, o_acc *a) {
+    a->sums = (int64_t *)calloc(3 * (size_t)h->n_acc, sizeof(int64_t));
+    a->counts = (uint64_t *)calloc(3 * (size_t)h->n_acc, sizeof(uint64_t));
+    a->map_sums = NULL;
+    a->map_counts = NULL;
+    if (h->om.enabled) {
+        const size_t n = 3 * (size_t)h->n_acc * h->nx * h->ny;
+        a->map_sums = (int64_t *)calloc(n, sizeof(int64_t));
+        a->map_counts = (uint64_t *)calloc(n, sizeof(uint64_t));
+    }
+}
+static void acc_free(o_acc *a) {
+    free(a->sums); free(a->counts); free(a->map_sums); free(a->map_counts);
+}
+
+/* [3rd-party] groan_rs GridMap::new: tiles centred at span_min + k*bin, n = round(span/bin) + 1
+ * (confirmed from fixture data). */
+static uint32_t gridmap_n(float lo, float hi, float bin) {
+    const float n = roundf((hi - lo) / bin);
+    return n < 0.0f ? 0u : (uint32_t)n + 1u;
+}
+/* [3rd-party] GridMap::get_mut_at: nearest tile centre; None outside the grid. */
+static inline int gridmap_index(float x, float lo, float bin, uint32_t n) {
+    const float k = roundf((x - lo) / bin);
+    if (!(k >= 0.0f) || !(k < (float)n)) return -1;
+    return (int)k;
+}
+
+uint32_t gorder_oracle_n_accumulators(const gorder_oracle_handle *h) { return h->n_acc; }
+uint32_t gorder_oracle_ordermap_dims(const gorder_oracle_handle *h, uint32_t *nx, uint32_t *ny) {
+    if (nx) *nx = h->nx;
+    if (ny) *ny = h->ny;
+    return h->om.enabled ? h->nx * h->ny : 0;
+}
+uint64_t gorder_oracle_last_error_index(const gorder_oracle_handle *h) { return h->err_index; }
+
+static void *dup_mem(const void *p, size_t n) {
+    if (!p || n == 0) return NULL;
+    void *q = malloc(n);
+    memcpy(q, p, n);
+    return q;
+}
+
+int gorder_oracle_create(const gorder_tables_t *t, int trig_mode, int n_threads,
+                         gorder_oracle_handle **out) {
+    if (!t || !out || t->n_atoms == 0) return GORDER_ERR_INVALID_ARGUMENT;
+    gorder_oracle_handle *h = (gorder_oracle_handle *)calloc(1, sizeof(*h));
+    h->n_atoms = t->n_atoms;
+    h->n_mt = t->n_molecule_types;
+    h->pbc = t->handle_pbc != 0;
+    h->trig = trig_mode;
+    h->n_threads = n_threads < 1 ? 1 : n_threads;
+    h->timewise = t->timewise != 0;
+    memcpy(h->normal, t->normal, sizeof(h->normal));
+    h->lf = t->leaflets;
+    h->membrane = (uint32_t *)dup_mem(t->leaflets.membrane, sizeof(uint32_t) * t->leaflets.n_membrane);
+    h->lf.membrane = h->membrane;
+    h->om = t->ordermap;
+    if (h->om.enabled) {
+        h->nx = gridmap_n(h->om.span_x[0], h->om.span_x[1], h->om.bin[0]);
+        h->ny = gridmap_n(h->om.span_y[0], h->om.span_y[1], h->om.bin[1]);
+    }
+    h->mt = (o_moltype *)calloc(h->n_mt ? h->n_mt : 1, sizeof(o_moltype));
+    uint32_t slot = 0, mol = 0;
+    for (uint32_t m = 0; m < h->n_mt; m++) {
+        const gorder_moltype_t *s = &t->molecule_types[m];
+        o_moltype *d = &h->mt[m];
+        d->n_molecules = s->n_molecules;
+        d->n_bond_types = s->n_bond_types;
+        d->n_ua_atoms = s->n_ua_atoms;
+        d->n_methyls = s->n_methyls;
+        d->slot0 = slot;
+        d->mol0 = mol;
+        d->bonds = (uint32_t *)dup_mem(s->bonds, sizeof(uint32_t) * 2 * (size_t)s->n_bond_types * s->n_molecules);
+        slot += s->n_bond_types;
+        if (s->n_ua_atoms) {
+            d->ua_kind = (uint32_t *)calloc(s->n_ua_atoms, sizeof(uint32_t));
+            d->ua_idx = (uint32_t **)calloc(s->n_ua_atoms, sizeof(uint32_t *));
+            d->ua_slot0 = (uint32_t *)calloc(s->n_ua_atoms, sizeof(uint32_t));
+            for (uint32_t a = 0; a < s->n_ua_atoms; a++) {
+                const uint32_t k = s->ua_atoms[a].kind;
+                d->ua_kind[a] = k;
+                d->ua_idx[a] = (uint32_t *)dup_mem(s->ua_atoms[a].indices, sizeof(uint32_t) * 4 * (size_t)s->n_molecules);
+                d->ua_slot0[a] = slot;
+                slot += (k == GORDER_UA_CH3) ? 3 : (k == GORDER_UA_CH2) ? 2 : 1;
+            }
+        }
+        d->heads = (uint32_t *)dup_mem(s->heads, sizeof(uint32_t) * s->n_molecules);
+        d->methyls = (uint32_t *)dup_mem(s->methyls, sizeof(uint32_t) * (size_t)s->n_molecules * s->n_methyls);
+        mol += s->n_molecules;
+    }
+    h->n_acc = slot;
+    h->n_mol_total = mol;
+    acc_alloc(h, &h->acc);
+    h->flags = (uint8_t *)calloc(mol ? mol : 1, 1);
+    h->flag_dist = (float *)calloc(mol ? mol : 1, sizeof(float));
+    *out = h;
+    return GORDER_OK;
+}
+
+void gorder_oracle_destroy(gorder_oracle_handle *h) {
+    if (!h) return;
+    for (uint32_t m = 0; m < h->n_mt; m++) {
+        o_moltype *d = &h->mt[m];
+        free(d->bonds);
+        for (uint32_t a = 0; a < d->n_ua_atoms; a++) free(d->ua_idx[a]);
+        free(d->ua_kind); free(d->ua_idx); free(d->ua_slot0); free(d->heads); free(d->methyls);
+    }
+    free(h->mt); free(h->membrane); acc_free(&h->acc);
+    free(h->flags); free(h->flag_dist); free(h->tw_sums); free(h->tw_counts);
+    free(h);
+}
+
+/* check_box, common.rs:186-198.  A frame's box arrives as a 3x3 matrix (XTC layout). */
+static int check_box(const float *b9, float *box3) {
+    int all_nan = 1;
+    for (int i = 0; i < 9; i++) if (b9[i] == b9[i]) all_nan = 0;
+    if (all_nan) return GORDER_ERR_UNDEFINED_BOX;
+    if (b9[1] != 0.0f || b9[2] != 0.0f || b9[3] != 0.0f || b9[5] != 0.0f || b9[6] != 0.0f || b9[7] != 0.0f)
+        return GORDER_ERR_NOT_ORTHOGONAL_BOX;
+    box3[0] = b9[0]; box3[1] = b9[4]; box3[2] = b9[8];
+    if (box3[0] == 0.0f && box3[1] == 0.0f && box3[2] == 0.0f) return GORDER_ERR_ZERO_BOX;
+    if (!(box3[0] > 0.0f) || !(box3[1] > 0.0f) || !(box3[2] > 0.0f)) return GORDER_ERR_BOX_RANGE;
+    return GORDER_OK;
+}
+
+/* should_assign, leaflets.rs:435-441 */
+static inline int should_assign(uint32_t frequency, uint64_t frame) {
+    return frequency == 0 ? frame == 0 : (frame % frequency) == 0;
+}
+
+/* ---- leaflet assignment of one frame (molecule.rs:61-70 + leaflets.rs:444-498, 1406-1435) ---- */
+typedef struct { uint32_t *cell_start; uint32_t *cell_atoms; uint32_t ncx, ncy; } o_grid;
+
+static int assign_leaflets(gorder_oracle_handle *h, const float *xyz, const float *box, uint8_t *flags,
+                           float *dist) {
+    const uint32_t dim = h->lf.normal_dim;
+    int bad = 0;
+    if (h->lf.method == GORDER_LEAFLETS_GLOBAL) {
+        /* SystemLeafletClassification::run, leaflets.rs:186-197 */
+        float center[3];
+        bad |= center_of(xyz, h->membrane, h->lf.n_membrane, box, h->pbc, center);
+        if (center[0] != center[0] || center[1] != center[1] || center[2] != center[2])
+            return GORDER_ERR_INVALID_GLOBAL_MEMBRANE_CENTER;
+        for (uint32_t m = 0; m < h->n_mt; m++) {
+            const o_moltype *mt = &h->mt[m];
+            for (uint32_t i = 0; i < mt->n_molecules; i++) {
+                /* common_identify_leaflet, leaflets.rs:711-732 */
+                const float hp = xyz[3 * (size_t)mt->heads[i] + dim];
+                const float d = h->pbc ? min_image(hp - center[dim], box[dim], &bad) : hp - center[dim];
+                dist[mt->mol0 + i] = d;
+                flags[mt->mol0 + i] = (uint8_t)((d >= 0.0f ? 0 : 1) ^ (h->lf.flip ? 1 : 0));
+            }
+        }
+    } else if (h->lf.method == GORDER_LEAFLETS_LOCAL) {
+        /* PBC3D::calc_local_membrane_centers, pbc.rs:273-318 (NoPBC: pbc.rs:107-139).
+         * Every membrane atom whose in-plane (PBC) distance from the head is < radius belongs to the
+         * cylinder; the CellGrid of the reference only prunes the search.  Brute force over a 2-D
+         * bucket grid here; members are visited in atom-index order. */
+        const int a = (dim + 1) % 3, b = (dim + 2) % 3;
+        const float r = h->lf.radius;
+        uint32_t *members = (uint32_t *)malloc(sizeof(uint32_t) * (h->lf.n_membrane ? h->lf.n_membrane : 1));
+        for (uint32_t m = 0; m < h->n_mt; m++) {
+            const o_moltype *mt = &h->mt[m];
+            for (uint32_t i = 0; i < mt->n_molecules; i++) {
+                const float *hp = xyz + 3 * (size_t)mt->heads[i];
+                uint32_t nm = 0;
+                for (uint32_t k = 0; k < h->lf.n_membrane; k++) {
+                    const float *p = xyz + 3 * (size_t)h->membrane[k];
+                    float da = p[a] - hp[a], db = p[b] - hp[b];
+                    if (h->pbc) { da = min_image(da, box[a], &bad); db = min_image(db, box[b], &bad); }
+                    if (sqrtf(da * da + db * db) < r) members[nm++] = h->membrane[k];
+                }
+                float center[3];
+                bad |= center_of(xyz, members, nm, box, h->pbc, center);
+                if (nm == 0 || center[0] != center[0] || center[1] != center[1] || center[2] != center[2]) {
+                    h->err_index = mt->heads[i];
+                    free(members);
+                    return GORDER_ERR_INVALID_LOCAL_MEMBRANE_CENTER;
+                }
+                const float d = h->pbc ? min_image(hp[dim] - center[dim], box[dim], &bad) : hp[dim] - center[dim];
+                dist[mt->mol0 + i] = d;
+                flags[mt->mol0 + i] = (uint8_t)((d >= 0.0f ? 0 : 1) ^ (h->lf.flip ? 1 : 0));
+            }
+        }
+        free(members);
+    } else if (h->lf.method == GORDER_LEAFLETS_INDIVIDUAL) {
+        /* IndividualClassification::identify_leaflet, leaflets.rs:777-801 */
+        for (uint32_t m = 0; m < h->n_mt; m++) {
+            const o_moltype *mt = &h->mt[m];
+            for (uint32_t i = 0; i < mt->n_molecules; i++) {
+                const float hp = xyz[3 * (size_t)mt->heads[i] + dim];
+                float total = 0.0f;
+                for (uint32_t k = 0; k < mt->n_methyls; k++) {
+                    const float mp = xyz[3 * (size_t)mt->methyls[(size_t)i * mt->n_methyls + k] + dim];
+                    total += h->pbc ? min_image(hp - mp, box[dim], &bad) : hp - mp;
+                }
+                dist[mt->mol0 + i] = total;
+                flags[mt->mol0 + i] = (uint8_t)((total >= 0.0f ? 0 : 1) ^ (h->lf.flip ? 1 : 0));
+            }
+        }
+    }
+    return bad ? GORDER_ERR_BOX_RANGE : GORDER_OK;
+}
+
+/* ---- one sample: BondLike::add_order, bond.rs:184-215 (+ Map::add_order, ordermap.rs:100-113) */
+static inline void add_order(const gorder_oracle_handle *h, o_acc *a, int64_t *tw_s, uint64_t *tw_n,
+                             uint32_t slot, float sch, const float *pos, int leaflet /* -1 none */) {
+    const int64_t tick = gorder_oracle_tick(sch);
+    const uint32_t n_acc = h->n_acc;
+    int tile = -1;
+    if (h->om.enabled) {
+        float x, y;
+        switch (h->om.plane) { /* Plane::projection2plane, input/ordermap.rs:44-50 */
+            case 0: x = pos[0]; y = pos[1]; break;
+            case 1: x = pos[0]; y = pos[2]; break;
+            default: x = pos[2]; y = pos[1]; break;
+        }
+        const int ix = gridmap_index(x, h->om.span_x[0], h->om.bin[0], h->nx);
+        const int iy = gridmap_index(y, h->om.span_y[0], h->om.bin[1], h->ny);
+        if (ix >= 0 && iy >= 0) tile = ix * (int)h->ny + iy;
+    }
+    for (int pass = 0; pass < 2; pass++) {
+        const int which = pass == 0 ? 0 : (leaflet < 0 ? -1 : 1 + leaflet);
+        if (which < 0) break;
+        const size_t k = (size_t)which * n_acc + slot;
+        a->sums[k] += tick;
+        a->counts[k] += 1;
+        if (tw_s) { tw_s[k] += tick; tw_n[k] += 1; }
+        if (tile >= 0) {
+            const size_t t = k * ((size_t)h->nx * h->ny) + (size_t)tile;
+            a->map_sums[t] += tick;
+            a->map_counts[t] += 1;
+        }
+    }
+}
+
+/* ---- one frame: analyze_frame (common.rs:201-235) -> MoleculeTypes::analyze_frame
+ * (molecule.rs:54-95) -> BondType::analyze_frame (bond.rs:396-446) / UAAtom::analyze_frame
+ * (uaorder.rs:400-437).  `flags` = leaflet assignment that applies to this frame. */
+static int analyze_frame_orders(const gorder_oracle_handle *h, o_acc *a, int64_t *tw_s, uint64_t *tw_n,
+                                const float *xyz, const float *box, const uint8_t *flags,
+                                uint64_t *err_index) {
+    int bad = 0;
+    const int lf = h->lf.method != GORDER_LEAFLETS_NONE;
+    for (uint32_t m = 0; m < h->n_mt; m++) {
+        const o_moltype *mt = &h->mt[m];
+        for (uint32_t bt = 0; bt < mt->n_bond_types; bt++) {
+            const uint32_t *bonds = mt->bonds + 2 * (size_t)bt * mt->n_molecules;
+            for (uint32_t i = 0; i < mt->n_molecules; i++) {
+                const float *p1 = xyz + 3 * (size_t)bonds[2 * i];
+                const float *p2 = xyz + 3 * (size_t)bonds[2 * i + 1];
+                if (p1[0] != p1[0]) { *err_index = bonds[2 * i]; return GORDER_ERR_UNDEFINED_POSITION; }
+                if (p2[0] != p2[0]) { *err_index = bonds[2 * i + 1]; return GORDER_ERR_UNDEFINED_POSITION; }
+                float v[3], mid[3];
+                bad |= vector_to(p1, p2, box, h->pbc, v);
+                for (int d = 0; d < 3; d++) mid[d] = p1[d] + v[d] / 2.0f; /* bond.rs:422 */
+                const float sch = calc_sch(v, h->normal, h->trig);
+                add_order(h, a, tw_s, tw_n, mt->slot0 + bt, sch, mid, lf ? flags[mt->mol0 + i] : -1);
+            }
+        }
+        for (uint32_t ua = 0; ua < mt->n_ua_atoms; ua++) {
+            const uint32_t kind = mt->ua_kind[ua];
+            const int ti = kind == GORDER_UA_CH1_SAT ? 3 : 1;
+            const int nidx = kind == GORDER_UA_CH1_SAT ? 4 : 3;
+            for (uint32_t i = 0; i < mt->n_molecules; i++) {
+                const uint32_t *ix = mt->ua_idx[ua] + 4 * (size_t)i;
+                float pos[4][3] = {{0}};
+                for (int k = 0; k < nidx; k++) {
+                    const float *p = xyz + 3 * (size_t)ix[k];
+                    if (p[0] != p[0]) { *err_index = ix[k]; return GORDER_ERR_UNDEFINED_POSITION; }
+                    pos[k][0] = p[0]; pos[k][1] = p[1]; pos[k][2] = p[2];
+                }
+                float hy[3][3];
+                const int nh = gorder_oracle_predict_hydrogens(kind, pos, box, h->pbc, hy);
+                if (nh < 0) { bad = 1; continue; }
+                for (int k = 0; k < nh; k++) {
+                    /* UAAtom::calculate_sch, uaorder.rs:375-397: vec = target->H, pos = H + vec/2 (sic) */
+                    float v[3], bp[3];
+                    bad |= vector_to(pos[ti], hy[k], box, h->pbc, v);
+                    for (int d = 0; d < 3; d++) bp[d] = hy[k][d] + v[d] / 2.0f;
+                    const float sch = calc_sch(v, h->normal, h->trig);
+                    add_order(h, a, tw_s, tw_n, mt->ua_slot0[ua] + (uint32_t)k, sch, bp,
+                              lf ? flags[mt->mol0 + i] : -1);
+                }
+            }
+        }
+    }
+    return bad ? GORDER_ERR_BOX_RANGE : GORDER_OK;
+}
+
+/* ---- batch driver: restates groan_rs traj_iter_map_reduce as used at common.rs:283-339:
+ * thread t analyses frames t, t+n, t+2n, ... with its own accumulator clone
+ * (ParallelTrajData::initialize, topology/mod.rs:274-277), the clones are folded in thread order
+ * (SystemTopology::reduce, topology/mod.rs:257-272).  Leaflet flags of assignment frames are
+ * resolved first, which is what the reference's shared map + spin-wait (leaflets.rs:1523-1577)
+ * achieves. */
+typedef struct {
+    gorder_oracle_handle *h;
+    const float *xyz, *box;
+    const uint8_t *frame_flags; /* [n_frames][n_mol_total] or NULL */
+    uint32_t n_frames, tid, nthr;
+    o_acc acc;
+    int64_t *tw_s; uint64_t *tw_n; /* batch timewise rows (shared, disjoint rows per thread) */
+    int status; uint64_t err_index;
+} o_job;
+
+static void *worker(void *arg) {
+    o_job *j = (o_job *)arg;
+    gorder_oracle_handle *h = j->h;
+    const size_t row = 3 * (size_t)h->n_acc;
+    for (uint32_t f = j->tid; f < j->n_frames; f += j->nthr) {
+        float box3[3] = {0, 0, 0};
+        if (h->pbc) {
+            const int st = check_box(j->box + 9 * (size_t)f, box3);
+            if (st != GORDER_OK) { j->status = st; return NULL; }
+        }
+        const int st = analyze_frame_orders(
+            h, &j->acc, j->tw_s ? j->tw_s + row * f : NULL, j->tw_n ? j->tw_n + row * f : NULL,
+            j->xyz + 3 * (size_t)h->n_atoms * f, box3,
+            j->frame_flags ? j->frame_flags + (size_t)h->n_mol_total * f : NULL, &j->err_index);
+        if (st != GORDER_OK) { j->status = st; return NULL; }
+    }
+    return NULL;
+}
+
+int gorder_oracle_submit(gorder_oracle_handle *h, const float *xyz, const float *box,
+                         const uint64_t *frame_index, uint32_t n_frames) {
+    if (!h || !xyz || (!box && h->pbc) || !frame_index) return GORDER_ERR_INVALID_ARGUMENT;
+    if (n_frames == 0) return GORDER_OK;
+    const size_t row = 3 * (size_t)h->n_acc;
+    uint8_t *frame_flags = NULL;
+    int status = GORDER_OK;
+    /* pass 1: leaflet flags per frame (sequential; molecule.rs:61-70) */
+    if (h->lf.method != GORDER_LEAFLETS_NONE) {
+        frame_flags = (uint8_t *)malloc((size_t)h->n_mol_total * n_frames);
+        for (uint32_t f = 0; f < n_frames; f++) {
+            const uint64_t g = frame_index[f];
+            if (h->lf.method != GORDER_LEAFLETS_MANUAL && should_assign(h->lf.frequency, g)) {
+                float box3[3] = {0, 0, 0};
+                if (h->pbc) {
+                    status = check_box(box + 9 * (size_t)f, box3);
+                    if (status != GORDER_OK) goto done;
+                }
+                status = assign_leaflets(h, xyz + 3 * (size_t)h->n_atoms * f, box3, h->flags, h->flag_dist);
+                if (status != GORDER_OK) goto done;
+                h->have_flags = 1;
+                h->flags_frame = g;
+            }
+            if (!h->have_flags) { status = GORDER_ERR_LEAFLETS_NOT_PRIMED; goto done; }
+            memcpy(frame_flags + (size_t)h->n_mol_total * f, h->flags, h->n_mol_total);
+        }
+    }
+    /* timewise rows for this batch */
+    int64_t *tw_s = NULL; uint64_t *tw_n = NULL;
+    if (h->timewise) {
+        if (h->n_frames + n_frames > h->tw_cap) {
+            h->tw_cap = (h->n_frames + n_frames) * 2;
+            h->tw_sums = (int64_t *)realloc(h->tw_sums, h->tw_cap * row * sizeof(int64_t));
+            h->tw_counts = (uint64_t *)realloc(h->tw_counts, h->tw_cap * row * sizeof(uint64_t));
+        }
+        tw_s = h->tw_sums + row * h->n_frames;
+        tw_n = h->tw_counts + row * h->n_frames;
+        memset(tw_s, 0, row * n_frames * sizeof(int64_t));
+        memset(tw_n, 0, row * n_frames * sizeof(uint64_t));
+    }
+    {
+        uint32_t nthr = (uint32_t)h->n_threads;
+        if (nthr > n_frames) nthr = n_frames;
+        o_job *jobs = (o_job *)calloc(nthr, sizeof(o_job));
+        pthread_t *th = (pthread_t *)calloc(nthr, sizeof(pthread_t));
+        for (uint32_t t = 0; t < nthr; t++) {
+            jobs[t].h = h; jobs[t].xyz = xyz; jobs[t].box = box; jobs[t].frame_flags = frame_flags;
+            jobs[t].n_frames = n_frames; jobs[t].tid = t; jobs[t].nthr = nthr;
+            jobs[t].tw_s = tw_s; jobs[t].tw_n = tw_n; jobs[t].status = GORDER_OK;
+            acc_alloc(h, &jobs[t].acc);
+            if (nthr > 1) pthread_create(&th[t], NULL, worker, &jobs[t]);
+            else worker(&jobs[t]);
+        }
+        const size_t ntile = (size_t)h->nx * h->ny;
+        for (uint32_t t = 0; t < nthr; t++) {
+            if (nthr > 1) pthread_join(th[t], NULL);
+            if (jobs[t].status != GORDER_OK && status == GORDER_OK) {
+                status = jobs[t].status;
+                h->err_index = jobs[t].err_index;
+            }
+            /* SystemTopology::add, topology/mod.rs:236-254 */
+            for (size_t k = 0; k < row; k++) {
+                if (__builtin_add_overflow(h->acc.sums[k], jobs[t].acc.sums[k], &h->acc.sums[k]))
+                    status = GORDER_ERR_OVERFLOW; /* order.rs:44-60 panics */
+                h->acc.counts[k] += jobs[t].acc.counts[k];
+            }
+            if (h->om.enabled)
+                for (size_t k = 0; k < row * ntile; k++) {
+                    h->acc.map_sums[k] += jobs[t].acc.map_sums[k];
+                    h->acc.map_counts[k] += jobs[t].acc.map_counts[k];
+                }
+            acc_free(&jobs[t].acc);
+        }
+        free(jobs); free(th);
+    }
+    if (status == GORDER_OK) h->n_frames += n_frames;
+done:
+    free(frame_flags);
+    return status;
+}
+
+int gorder_oracle_prime_leaflets(gorder_oracle_handle *h, const float *xyz, const float *box,
+                                 uint64_t frame_index) {
+    float box3[3] = {0, 0, 0};
+    if (h->pbc) {
+        const int st = check_box(box, box3);
+        if (st != GORDER_OK) return st;
+    }
+    const int st = assign_leaflets(h, xyz, box3, h->flags, h->flag_dist);
+    if (st == GORDER_OK) { h->have_flags = 1; h->flags_frame = frame_index; }
+    return st;
+}
+
+int gorder_oracle_set_manual_leaflets(gorder_oracle_handle *h, const uint8_t *flags, uint64_t frame_index) {
+    for (uint32_t i = 0; i < h->n_mol_total; i++) h->flags[i] = (uint8_t)((flags[i] & 1) ^ (h->lf.flip ? 1 : 0));
+    h->have_flags = 1;
+    h->flags_frame = frame_index;
+    return GORDER_OK;
+}
+
+int gorder_oracle_finish(gorder_oracle_handle *h, int64_t *sums, uint64_t *counts, int64_t *map_sums,
+                         uint64_t *map_counts, uint64_t *n_frames_analyzed) {
+    const size_t row = 3 * (size_t)h->n_acc;
+    if (sums) memcpy(sums, h->acc.sums, row * sizeof(int64_t));
+    if (counts) memcpy(counts, h->acc.counts, row * sizeof(uint64_t));
+    if (h->om.enabled) {
+        const size_t n = row * h->nx * h->ny;
+        if (map_sums) memcpy(map_sums, h->acc.map_sums, n * sizeof(int64_t));
+        if (map_counts) memcpy(map_counts, h->acc.map_counts, n * sizeof(uint64_t));
+    }
+    if (n_frames_analyzed) *n_frames_analyzed = h->n_frames;
+    return GORDER_OK;
+}
+
+int gorder_oracle_timewise(gorder_oracle_handle *h, int64_t *tw_sums, uint64_t *tw_counts,
+                           uint64_t capacity_frames) {
+    if (!h->timewise) return GORDER_ERR_INVALID_ARGUMENT;
+    if (capacity_frames < h->n_frames) return GORDER_ERR_INVALID_ARGUMENT;
+    const size_t row = 3 * (size_t)h->n_acc;
+    memcpy(tw_sums, h->tw_sums, row * h->n_frames * sizeof(int64_t));
+    memcpy(tw_counts, h->tw_counts, row * h->n_frames * sizeof(uint64_t));
+    return GORDER_OK;
+}
+
+int gorder_oracle_leaflets(gorder_oracle_handle *h, uint8_t *flags, float *distances,
+                           uint64_t *assignment_frame) {
+    if (!h->have_flags) return GORDER_ERR_LEAFLETS_NOT_PRIMED;
+    if (flags) memcpy(flags, h->flags, h->n_mol_total);
+    if (distances) memcpy(distances, h->flag_dist, sizeof(float) * h->n_mol_total);
+    if (assignment_frame) *assignment_frame = h->flags_frame;
+    return GORDER_OK;
+}

@@ -1,0 +1,301 @@
+"""GPU parity: the HIP path (through the C ABI) against the oracle on the same seeded inputs.
+
+Bar: sample counts and i64 order sums EQUAL to the oracle's MIRROR mode (same polynomial trig,
+restated in C); every order parameter within 1e-6 (north_star tolerance) of the oracle's LIBM mode,
+which evaluates acos/cos with the host libm exactly as the Rust reference does.
+"""
+import numpy as np
+import pytest
+
+from gorder_amd import HipEngine, abi, synthetic
+from gorder_amd.abi import (LEAFLETS_GLOBAL, LEAFLETS_INDIVIDUAL, LEAFLETS_MANUAL, LEAFLETS_NONE, MolType,
+                            Tables)
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6   # BASELINE.json north_star: "every per-bond order parameter within 1e-6 of the reference"
+
+
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def run_gpu(system, xyz, box, frame_index=None, host=False, batches=1):
+    torch = torch_cuda()
+    eng = HipEngine(system.tables)
+    eng.use_torch_stream()
+    n = xyz.shape[0]
+    edges = np.linspace(0, n, batches + 1).astype(int)
+    keep = []
+    for a, b in zip(edges[:-1], edges[1:]):
+        if a == b:
+            continue
+        fi = None if frame_index is None else frame_index[a:b]
+        if fi is None:
+            fi = np.arange(a, b)
+        if host:
+            eng.submit_host(xyz[a:b], None if box is None else box[a:b], fi)
+        else:
+            dx = torch.from_numpy(xyz[a:b]).cuda()
+            db = None if box is None else torch.from_numpy(box[a:b]).cuda()
+            keep += [dx, db]
+            eng.submit_device(dx, db, fi)
+    res = eng.finish()
+    return eng, res
+
+
+def run_oracle(system, xyz, box, frame_index=None, trig=oracle.TRIG_MIRROR, n_threads=1):
+    o = oracle.OracleEngine(system.tables, trig=trig, n_threads=n_threads)
+    o.submit(xyz, box, frame_index)
+    return o, o.finish()
+
+
+def assert_parity(system, xyz, box, frame_index=None, **kw):
+    eng, got = run_gpu(system, xyz, box, frame_index, **kw)
+    _, want = run_oracle(system, xyz, box, frame_index)
+    assert got.n_frames == want.n_frames == xyz.shape[0]
+    np.testing.assert_array_equal(got.counts, want.counts)
+    np.testing.assert_array_equal(got.sums, want.sums)
+    _, libm = run_oracle(system, xyz, box, frame_index, trig=oracle.TRIG_LIBM)
+    np.testing.assert_array_equal(got.counts, libm.counts)
+    a, b = got.order(), libm.order()
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    assert np.nanmax(np.abs(a - b)) <= TOL
+    return eng, got
+
+
+@pytest.mark.parametrize("n_lipids,n_frames", [(256, 12), (7, 9), (64, 1)])
+def test_aa_no_leaflets(built, n_lipids, n_frames):
+    system = synthetic.aa_membrane(n_lipids)
+    xyz = system.frames(n_frames, seed=11)
+    assert_parity(system, xyz, system.box9(n_frames))
+
+
+def test_cg_global_leaflets_mixed_types(built):
+    system = synthetic.cg_membrane(600, leaflets=LEAFLETS_GLOBAL, n_types=3)
+    n = 20
+    xyz = system.frames(n, seed=5)
+    eng, got = assert_parity(system, xyz, system.box9(n))
+    # both leaflets populated, and upper + lower == total
+    assert got.counts[1].sum() > 0 and got.counts[2].sum() > 0
+    np.testing.assert_array_equal(got.counts[1] + got.counts[2], got.counts[0])
+    np.testing.assert_array_equal(got.sums[1] + got.sums[2], got.sums[0])
+    o, _ = run_oracle(system, xyz, system.box9(n))
+    flags, fr = eng.leaflets()
+    oflags, odist, ofr = o.leaflets()
+    assert fr == ofr == n - 1
+    np.testing.assert_array_equal(flags, oflags)
+    np.testing.assert_allclose(eng.leaflet_distances(), odist, atol=2e-5)
+
+
+@pytest.mark.parametrize("frequency", [0, 1, 5])
+def test_leaflet_frequency_and_batching(built, frequency):
+    # Frequency::Once / Every(n): non-assignment frames reuse the assignment of floor(g/n)*n
+    # (leaflets.rs:1437-1472), also across submit() batches
+    system = synthetic.cg_membrane(128, leaflets=LEAFLETS_INDIVIDUAL, frequency=frequency)
+    n = 23
+    xyz = system.frames(n, seed=9)
+    # make lipids flip over time so that the assignment frame matters
+    xyz[7:, : 12 * 20, 2] = system.box[2] - xyz[7:, : 12 * 20, 2]
+    assert_parity(system, xyz, system.box9(n), batches=4)
+
+
+def test_flip_and_manual(built):
+    system = synthetic.cg_membrane(64, leaflets=LEAFLETS_GLOBAL, flip=True)
+    xyz = system.frames(6, seed=2)
+    _, flipped = assert_parity(system, xyz, system.box9(6))
+    system2 = synthetic.cg_membrane(64, leaflets=LEAFLETS_GLOBAL, flip=False)
+    _, plain = assert_parity(system2, xyz, system2.box9(6))
+    np.testing.assert_array_equal(flipped.sums[1], plain.sums[2])
+    np.testing.assert_array_equal(flipped.counts[2], plain.counts[1])
+    # manual flags reproduce the global assignment when fed the same flags
+    torch = torch_cuda()
+    system3 = synthetic.cg_membrane(64, leaflets=LEAFLETS_MANUAL)
+    system3.tables.molecule_types[0].heads = None
+    eng = HipEngine(system3.tables)
+    flags = (np.arange(64) % 2).astype(np.uint8)
+    eng.set_manual_leaflets(flags)
+    eng.submit_device(torch.from_numpy(xyz).cuda(), torch.from_numpy(system3.box9(6)).cuda())
+    got = eng.finish()
+    o = oracle.OracleEngine(system3.tables, trig=oracle.TRIG_MIRROR)
+    o.set_manual_leaflets(flags)
+    o.submit(xyz, system3.box9(6))
+    want = o.finish()
+    np.testing.assert_array_equal(got.sums, want.sums)
+    np.testing.assert_array_equal(got.counts, want.counts)
+
+
+def test_no_pbc_and_tilted_normal(built):
+    system = synthetic.cg_membrane(100, handle_pbc=False, normal=(0.3, -0.2, 0.9))
+    xyz = system.frames(5, seed=4)
+    assert_parity(system, xyz, None)
+    system = synthetic.cg_membrane(100, handle_pbc=True, normal=(1.0, 0.0, 0.0))
+    assert_parity(system, xyz, system.box9(5))
+
+
+def test_host_submit_matches_device_submit(built):
+    system = synthetic.aa_membrane(32)
+    xyz = system.frames(10, seed=8)
+    _, a = run_gpu(system, xyz, system.box9(10), host=True, batches=3)
+    _, b = run_gpu(system, xyz, system.box9(10), host=False)
+    np.testing.assert_array_equal(a.sums, b.sums)
+    np.testing.assert_array_equal(a.counts, b.counts)
+
+
+def test_direct_kernel_equals_tiled_kernel(built, monkeypatch):
+    system = synthetic.aa_membrane(40)
+    xyz = system.frames(9, seed=6)
+    _, tiled = run_gpu(system, xyz, system.box9(9))
+    monkeypatch.setenv("GORDER_HIP_FORCE_DIRECT", "1")
+    eng, direct = run_gpu(system, xyz, system.box9(9))
+    assert eng.plan()["n_tiles"] == 0
+    np.testing.assert_array_equal(tiled.sums, direct.sums)
+    np.testing.assert_array_equal(tiled.counts, direct.counts)
+
+
+def test_scattered_bonds(built):
+    # bonds that cannot share an LDS window take the direct-gather kernel; mixed with tiled ones
+    rng = np.random.default_rng(1)
+    n_atoms, n_mol = 30000, 50
+    far = np.stack([rng.integers(0, 1000, n_mol), rng.integers(20000, 30000, n_mol)], axis=1)
+    near = np.stack([np.arange(5000, 5000 + n_mol), np.arange(5001, 5001 + n_mol)], axis=1)
+    bonds = np.stack([np.sort(far, axis=1), near]).astype(np.uint32)
+    t = Tables(n_atoms=n_atoms, molecule_types=[MolType(n_molecules=n_mol, bonds=bonds)])
+    box = np.array([7.0, 8.0, 9.0], dtype=np.float32)
+    system = synthetic.System("scatter", t, (rng.random((n_atoms, 3)) * box).astype(np.float32), box, 0.05)
+    xyz = system.frames(6, seed=1)
+    eng, _ = assert_parity(system, xyz, system.box9(6))
+    assert eng.plan()["n_direct_items"] == n_mol
+
+
+def test_edge_cases(built):
+    torch = torch_cuda()
+    system = synthetic.cg_membrane(20)
+    # zero frames is a no-op
+    eng = HipEngine(system.tables)
+    eng.submit_host(np.zeros((0, system.n_atoms, 3), np.float32), np.zeros((0, 3, 3), np.float32))
+    r = eng.finish()
+    assert r.n_frames == 0 and r.counts.sum() == 0 and np.isnan(r.order()).all()
+    # zero-length bond: angle() returns 0 -> S = 1 (mod.rs:78-82 with nalgebra's zero-norm rule)
+    xyz = system.frames(2, seed=0)
+    xyz[:, 1] = xyz[:, 0]
+    assert_parity(system, xyz, system.box9(2))
+    # atoms exactly half a box apart, on the box faces, outside the box by one image
+    xyz = system.frames(3, seed=1)
+    xyz[0, 0] = [0.0, 0.0, 0.0]
+    xyz[0, 1] = [system.box[0] / 2, system.box[1] / 2, system.box[2] / 2]
+    xyz[1, :24] += system.box
+    xyz[2, :24] -= system.box
+    assert_parity(system, xyz, system.box9(3))
+
+
+def test_errors_mirror_the_reference(built):
+    torch = torch_cuda()
+    system = synthetic.cg_membrane(20)
+    xyz = system.frames(3, seed=0)
+
+    def status_of(xyz, box):
+        eng = HipEngine(system.tables)
+        eng.submit_host(xyz, box)
+        with pytest.raises(abi.GorderHipError) as e:
+            eng.finish()
+        return e.value
+
+    box = system.box9(3)
+    bad = box.copy(); bad[1, 0, 1] = 0.5
+    assert status_of(xyz, bad).status == abi.ERR_NOT_ORTHOGONAL_BOX         # common.rs:190-192
+    bad = box.copy(); bad[2] = 0.0
+    assert status_of(xyz, bad).status == abi.ERR_ZERO_BOX                   # common.rs:194-196
+    bad = box.copy(); bad[0] = np.nan
+    assert status_of(xyz, bad).status == abi.ERR_UNDEFINED_BOX              # common.rs:187
+    x2 = xyz.copy(); x2[1, 13, 0] = np.nan
+    e = status_of(x2, box)
+    assert e.status == abi.ERR_UNDEFINED_POSITION and e.index == 13         # bond.rs:411-417
+    x2 = xyz.copy(); x2[0, 5] = 1e9
+    assert status_of(x2, box).status == abi.ERR_BOX_RANGE
+    # the oracle agrees on the codes
+    for arr, bx, code in ((xyz, bad, abi.ERR_UNDEFINED_BOX),):
+        o = oracle.OracleEngine(system.tables)
+        with pytest.raises(oracle.OracleError) as oe:
+            o.submit(arr, bx)
+        assert oe.value.status == code
+    # leaflets whose first frame is not an assignment frame need priming
+    s2 = synthetic.cg_membrane(20, leaflets=LEAFLETS_GLOBAL, frequency=5)
+    eng = HipEngine(s2.tables)
+    with pytest.raises(abi.GorderHipError) as e:
+        eng.submit_host(xyz, box, np.array([6, 7, 8]))
+    assert e.value.status == abi.ERR_LEAFLETS_NOT_PRIMED
+
+
+def test_priming_replaces_cross_thread_wait(built):
+    # rank r starts at frame 6 with Every(5): it needs the assignment of frame 5 (leaflets.rs:1437-1472)
+    torch = torch_cuda()
+    system = synthetic.cg_membrane(64, leaflets=LEAFLETS_GLOBAL, frequency=5)
+    xyz = system.frames(12, seed=3)
+    xyz[6:, : 12 * 10, 2] = system.box[2] - xyz[6:, : 12 * 10, 2]
+    box = system.box9(12)
+    whole, ref = run_oracle(system, xyz, box)
+    # shard: frames 6..11 only, primed with frame 5
+    eng = HipEngine(system.tables)
+    eng.prime_leaflets_device(torch.from_numpy(xyz[5]).cuda(), torch.from_numpy(box[5]).cuda(), 5)
+    eng.submit_host(xyz[6:], box[6:], np.arange(6, 12))
+    tail = eng.finish()
+    eng0 = HipEngine(system.tables)
+    eng0.submit_host(xyz[:6], box[:6], np.arange(0, 6))
+    head = eng0.finish()
+    np.testing.assert_array_equal(head.sums + tail.sums, ref.sums)      # SystemTopology::add
+    np.testing.assert_array_equal(head.counts + tail.counts, ref.counts)
+
+
+def test_launch_geometry_invariance(built):
+    # integer accumulation => identical results however the frames are batched (tests_aa.rs:320-368)
+    system = synthetic.aa_membrane(24)
+    xyz = system.frames(37, seed=12)
+    box = system.box9(37)
+    _, a = run_gpu(system, xyz, box, batches=1)
+    _, b = run_gpu(system, xyz, box, batches=5)
+    _, c = run_gpu(system, xyz, box, batches=37)
+    for r in (b, c):
+        np.testing.assert_array_equal(a.sums, r.sums)
+        np.testing.assert_array_equal(a.counts, r.counts)
+    _, threaded = run_oracle(system, xyz, box, n_threads=3)
+    np.testing.assert_array_equal(a.sums, threaded.sums)
+
+
+def test_full_size_properties(built):
+    """BASELINE config 2 at full width (256 lipids, 25 088 atoms, 16 384 bonds/frame), more frames than
+    the oracle is asked to chew: size-independent properties + an oracle check on a frame subset."""
+    torch = torch_cuda()
+    system = synthetic.aa_membrane(256)
+    n = 2000
+    d_xyz, d_box = system.frames_device(n, seed=1)
+    eng = HipEngine(system.tables)
+    eng.use_torch_stream()
+    eng.submit_device(d_xyz, d_box)
+    full = eng.finish()
+    assert full.n_frames == n
+    assert (full.counts[0] == n * 256).all()
+    # linearity over frame subsets: sum(parts) == whole
+    parts = None
+    for a, b in ((0, 700), (700, 701), (701, 2000)):
+        e = HipEngine(system.tables)
+        e.use_torch_stream()
+        e.submit_device(d_xyz[a:b].contiguous(), d_box[a:b].contiguous(), np.arange(a, b))
+        r = e.finish()
+        parts = r.sums.copy() if parts is None else parts + r.sums
+    np.testing.assert_array_equal(parts, full.sums)
+    # oracle on a strided subset of the very same device frames
+    sel = np.arange(0, n, 97)
+    sub = d_xyz[torch.from_numpy(sel).cuda()].contiguous()
+    e = HipEngine(system.tables)
+    e.use_torch_stream()
+    e.submit_device(sub, d_box[: len(sel)].contiguous())
+    got = e.finish()
+    _, want = run_oracle(system, sub.cpu().numpy(), system.box9(len(sel)))
+    np.testing.assert_array_equal(got.sums, want.sums)
+    np.testing.assert_array_equal(got.counts, want.counts)
+    # order parameters are physical
+    s = full.order()[0]
+    assert np.all(s >= -0.5 - 1e-6) and np.all(s <= 1.0 + 1e-6)
