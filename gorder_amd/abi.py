@@ -233,6 +233,16 @@ def load_library() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise GorderHipError(ERR_NO_DEVICE, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; "
                                             "g.build()'` (there is no CPU fallback)")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so (SONAME
+    # libamdhip64.so.7, same as /opt/rocm's).  Import torch FIRST so that our DT_NEEDED entry binds to
+    # the runtime torch already initialised; two runtimes in one process cannot both own the device.
+    try:
+        import torch  # noqa: F401
+        _rt = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(_rt):
+            C.CDLL(_rt, mode=C.RTLD_GLOBAL)
+    except ImportError:      # plain C/C++ hosts link against /opt/rocm directly
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
     lib.gorder_hip_create.argtypes = [C.POINTER(CTables), C.POINTER(vp)]
@@ -287,6 +297,15 @@ class Results:
     n_frames: int
     map_sums: Optional[np.ndarray] = None
     map_counts: Optional[np.ndarray] = None
+
+    def order_ticks(self, min_samples: int = 1) -> np.ndarray:
+        """Mean order parameter in integer ticks of 1e-6 (`OrderValue / usize`, order.rs:34-42);
+        INT64_MIN marks "fewer than min_samples" (NaN in `order`)."""
+        n = self.counts.astype(np.int64)
+        ok = n >= max(1, min_samples)
+        q = np.full(self.sums.shape, np.iinfo(np.int64).min, dtype=np.int64)
+        q[ok] = (np.abs(self.sums[ok]) // n[ok]) * np.sign(self.sums[ok])
+        return q
 
     def order(self, min_samples: int = 1) -> np.ndarray:
         """AnalysisOrder::calc_order (order.rs:101-107): truncating i64 division, then /1e6 as f32."""
