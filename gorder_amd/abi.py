@@ -36,6 +36,7 @@ ERR_LEAFLETS_NOT_PRIMED = 104
 ERR_OVERFLOW = 105
 
 LEAFLETS_NONE, LEAFLETS_GLOBAL, LEAFLETS_LOCAL, LEAFLETS_INDIVIDUAL, LEAFLETS_MANUAL = range(5)
+FLAG_TRIG_ACOS_COS = 1
 UA_CH1_SAT, UA_CH2, UA_CH3, UA_CH1_UNSAT = 1, 2, 3, 4
 UA_N_H = {UA_CH1_SAT: 1, UA_CH2: 2, UA_CH3: 3, UA_CH1_UNSAT: 1}
 
@@ -67,7 +68,7 @@ class CTables(C.Structure):
     _fields_ = [("n_atoms", C.c_uint32), ("n_molecule_types", C.c_uint32),
                 ("molecule_types", C.POINTER(CMolType)), ("handle_pbc", C.c_int32),
                 ("normal", C.c_float * 3), ("leaflets", CLeaflets), ("ordermap", COrderMap),
-                ("timewise", C.c_int32), ("device", C.c_int32)]
+                ("timewise", C.c_int32), ("device", C.c_int32), ("flags", C.c_uint32)]
 
 
 class CPlan(C.Structure):
@@ -140,6 +141,7 @@ class Tables:
     ordermap: OrderMap = field(default_factory=OrderMap)
     timewise: bool = False
     device: int = 0
+    flags: int = 0          # FLAG_TRIG_ACOS_COS: acos->cos round trip like the reference
 
     @property
     def n_acc(self) -> int:
@@ -200,6 +202,7 @@ class Tables:
         t.ordermap.bin[:] = [float(x) for x in om.bin]
         t.timewise = 1 if self.timewise else 0
         t.device = self.device
+        t.flags = self.flags
         keep += [mts, mem]
         return t, keep
 

@@ -20,19 +20,43 @@
 
 // 1-D minimum image: shift by whole box lengths into [-L/2, L/2] (groan_rs).  `bad` is raised
 // instead of spinning when the reference's `while` loop would need more than GM_MI_MAX_ITER steps.
-__device__ __forceinline__ float gm_min_image(float dx, float L, int &bad) {
+// This is the literal loop; gm_min_image below is the same function with a branch-free first step.
+__device__ __forceinline__ float gm_min_image_loop(float dx, float L, int &bad) {
     const float half = L / 2.0f;
     int it = 0;
+#pragma clang loop unroll(disable)
     while (dx > half) {
         dx -= L;
         if (++it > GM_MI_MAX_ITER) { bad = 1; return dx; }
     }
     it = 0;
+#pragma clang loop unroll(disable)
     while (dx < -half) {
         dx += L;
         if (++it > GM_MI_MAX_ITER) { bad = 1; return dx; }
     }
     return dx;
+}
+
+// One iteration of each `while`, as selects; `slow` is raised when that was not enough (the atoms are
+// more than 1.5 box lengths apart), in which case the caller re-runs gm_min_image_loop on the input.
+// The literal form is  a = dx > half ? dx - L : dx;  b = a < -half ? a + L : a.  If the first shift
+// happened then a = RN(dx - L) >= -half (rounding is monotonic and -half is a float), so the second
+// cannot; hence b is one select chain on dx itself.  One shift was enough iff |dx| <= 1.5 L ... which
+// is tested on the results: (dx - L) > half or (dx + L) < -half.
+__device__ __forceinline__ float gm_min_image_step(float dx, float L, bool &slow) {
+    const float half = L / 2.0f;
+    const float dn = dx - L, up = dx + L;
+    const bool hi = dx > half, lo = dx < -half;
+    slow = slow || (hi && dn > half) || (lo && up < -half);
+    return hi ? dn : (lo ? up : dx);
+}
+
+__device__ __forceinline__ float gm_min_image(float dx, float L, int &bad) {
+    bool slow = false;
+    const float r = gm_min_image_step(dx, L, slow);
+    if (__builtin_expect(slow, 0)) return gm_min_image_loop(dx, L, bad);
+    return r;
 }
 
 // groan_rs Vector3D::wrap into [0, L]
@@ -69,20 +93,22 @@ __device__ __forceinline__ float gm_asin_r(float z) {
     return p;
 }
 
+// Branch-free (a wave almost always holds lanes of every range); the arithmetic of each range is
+// exactly the sequence restated in oracle/gorder_oracle.c (gorder_oracle_mirror_acosf).
 __device__ __forceinline__ float gm_acosf(float x) {
     const float ax = __builtin_fabsf(x);
-    if (!(ax <= 1.0f)) return __builtin_nanf("");
     // both argument reductions share the polynomial: z = x^2 (|x| <= 1/2) or (1-|x|)/2
     const bool small = ax <= 0.5f;
     const float z = small ? x * x : (1.0f - ax) * 0.5f;
     const float r = z * gm_asin_r(z);
-    if (small) return GM_PIO2_HI - (x - (GM_PIO2_LO - x * r));
+    const float r_small = GM_PIO2_HI - (x - (GM_PIO2_LO - x * r));
     const float s = __builtin_sqrtf(z);
     const float c = (s > 0.0f) ? __builtin_fmaf(-s, s, z) / (s + s) : 0.0f;
-    float w = __builtin_fmaf(s, r, c);
-    if (x > 0.0f) return 2.0f * (s + w);
-    w = w - GM_PIO2_LO;
-    return 2.0f * (GM_PIO2_HI - (s + w));
+    const float w = __builtin_fmaf(s, r, c);
+    const float r_pos = 2.0f * (s + w);
+    const float r_neg = 2.0f * (GM_PIO2_HI - (s + (w - GM_PIO2_LO)));
+    float res = small ? r_small : (x > 0.0f ? r_pos : r_neg);
+    return (ax <= 1.0f) ? res : __builtin_nanf("");
 }
 
 __device__ __forceinline__ float gm_kcos(float r) {
@@ -100,33 +126,56 @@ __device__ __forceinline__ float gm_ksin(float r) {
         -0x1.555556p-3f);
     return __builtin_fmaf(r * z, s, r);
 }
+// t in [0, pi] (the range of acos) or NaN.  Both kernels are evaluated and selected.
 __device__ __forceinline__ float gm_cosf(float t) {
-    if (t < GM_PIO4) return gm_kcos(t);
-    if (t <= GM_3PIO4) return gm_ksin((GM_PIO2_HI - t) + GM_PIO2_LO);
-    if (t != t) return t;
-    return -gm_kcos((GM_PI_HI - t) + GM_PI_LO);
+    const bool lo = t < GM_PIO4;
+    const bool mid = !lo && (t <= GM_3PIO4);
+    const float rc = lo ? t : (GM_PI_HI - t) + GM_PI_LO;
+    const float rs = (GM_PIO2_HI - t) + GM_PIO2_LO;
+    const float kc = gm_kcos(rc);
+    const float ks = gm_ksin(rs);
+    return mid ? ks : (lo ? kc : -kc);   // t = NaN: rc = NaN -> NaN
 }
 
-// nalgebra angle + calc_sch.  n2 = |normal| is precomputed on the host with the same f32 sequence.
+// P2 of the angle between the bond vector v and the membrane normal n (calc_sch, mod.rs:78-82).
+//   n2 = |n|, n2sq = |n|^2, both precomputed on the host with nalgebra's f32 sequence.
+//
+// ACOS_COS = true restates the reference literally: c = clamp(v.n / (|v||n|)), angle = acos(c)
+//   (0 if a norm is 0), S = 1.5 cos(angle)^2 - 0.5, with this file's own acos / cos kernels.
+//
+// ACOS_COS = false (library default, gorder_flags_t in gorder_hip.h) evaluates the same quantity from
+//   the SQUARED cosine, q = (v.n)^2 / (|v|^2 |n|^2), S = 1.5 q - 0.5: no acos -> cos round trip, no
+//   square root, one IEEE division.  Every operation is a correctly rounded f32 operation, restated
+//   by the oracle's DIRECT mode.  Against the reference's libm pipeline 5.9 % of samples move by one
+//   1e-6 tick (never more) and the mean moves by 2.6e-10 (tools/trig_fidelity.c).
+template <bool ACOS_COS>
 __device__ __forceinline__ float gm_calc_sch(float vx, float vy, float vz, float nx, float ny, float nz,
-                                             float n2) {
+                                             float n2, float n2sq) {
     const float prod = (vx * nx + vy * ny) + vz * nz;
-    const float n1 = __builtin_sqrtf((vx * vx + vy * vy) + vz * vz);
-    float angle = 0.0f;
-    if (!(n1 == 0.0f || n2 == 0.0f)) {
+    const float s2 = (vx * vx + vy * vy) + vz * vz;
+    if (ACOS_COS) {
+        const float n1 = __builtin_sqrtf(s2);
         float c = prod / (n1 * n2);
-        if (c < -1.0f) c = -1.0f;
-        else if (c > 1.0f) c = 1.0f;
-        angle = gm_acosf(c);
+        c = c < -1.0f ? -1.0f : (c > 1.0f ? 1.0f : c);     // NaN passes through, like f32::clamp
+        float angle = gm_acosf(c);
+        angle = (n1 == 0.0f || n2 == 0.0f) ? 0.0f : angle;  // nalgebra: angle = 0 if either norm is 0
+        const float co = gm_cosf(angle);
+        return (1.5f * co * co) - 0.5f;
+    } else {
+        float q = (prod * prod) / (s2 * n2sq);
+        q = q > 1.0f ? 1.0f : q;                             // the clamp of the cosine; NaN passes through
+        q = (s2 == 0.0f || n2sq == 0.0f) ? 1.0f : q;         // zero norm -> angle 0 -> cos^2 = 1
+        return (1.5f * q) - 0.5f;
     }
-    const float co = gm_cosf(angle);
-    return (1.5f * co * co) - 0.5f;
 }
 
-// round(f64(S) * 1e6) as i64 — S is in [-0.5, 1] or NaN here, so the tick fits 32 bits.
+// round(f64(S) * 1e6) as i64 (order.rs:21-26) — S is in [-0.5, 1] or NaN here, so the tick fits 32 bits.
 // f64::round is half-away-from-zero; NaN -> 0 (Rust `as i64`).
+// t = S * 1e6 is exact in f64 (24-bit x 20-bit significands), has <= 38 significant bits and
+// |t| <= 1e6, hence t + copysign(0.5, t) is exact whenever |t| >= 0.5 and stays inside (-1, 1)
+// otherwise: truncating it toward zero IS round-half-away-from-zero.
 __device__ __forceinline__ int gm_tick(float s) {
     const double t = (double)s * 1000000.0;
-    const double r = __builtin_round(t);
-    return (r != r) ? 0 : (int)r;
+    const double r = t + __builtin_copysign(0.5, t);
+    return (t != t) ? 0 : (int)r;
 }

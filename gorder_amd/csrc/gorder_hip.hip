@@ -49,7 +49,7 @@ struct FrameArgs {
     uint32_t n_frames;
     uint32_t frames_per_chunk;
     int pbc;
-    float nx, ny, nz, n2;    // static normal and its norm
+    float nx, ny, nz, n2, n2sq;   // static normal, its norm and squared norm
     int leaflets;            // 0/1
     const uint8_t *aflags;   // [rows][n_mol_total]
     const uint32_t *arow;    // [n_frames] assignment row of each frame
@@ -92,17 +92,28 @@ struct SampleAcc {
     uint32_t n_tot = 0, n_up = 0;
 };
 
-__device__ __forceinline__ void bond_sample(const FrameArgs &a, uint32_t f, float p1x, float p1y, float p1z,
+// returns true when S came out NaN (undefined position or a non-finite coordinate)
+template <bool ACOS_COS>
+__device__ __forceinline__ bool bond_sample(const FrameArgs &a, uint32_t f, float p1x, float p1y, float p1z,
                                             float p2x, float p2y, float p2z, uint32_t mol, SampleAcc &acc,
                                             int &bad) {
     float vx = p2x - p1x, vy = p2y - p1y, vz = p2z - p1z;
     if (a.pbc) {
         const float *b = a.box9 + 9 * (size_t)f;
-        vx = gm_min_image(vx, b[0], bad);
-        vy = gm_min_image(vy, b[4], bad);
-        vz = gm_min_image(vz, b[8], bad);
+        const float bx = b[0], by = b[4], bz = b[8];
+        bool slow = false;   // one select-only step per dimension; the literal loops only when needed
+        const float rx = gm_min_image_step(vx, bx, slow);
+        const float ry = gm_min_image_step(vy, by, slow);
+        const float rz = gm_min_image_step(vz, bz, slow);
+        if (__builtin_expect(slow, 0)) {
+            vx = gm_min_image_loop(vx, bx, bad);
+            vy = gm_min_image_loop(vy, by, bad);
+            vz = gm_min_image_loop(vz, bz, bad);
+        } else {
+            vx = rx; vy = ry; vz = rz;
+        }
     }
-    const float sch = gm_calc_sch(vx, vy, vz, a.nx, a.ny, a.nz, a.n2);
+    const float sch = gm_calc_sch<ACOS_COS>(vx, vy, vz, a.nx, a.ny, a.nz, a.n2, a.n2sq);
     const long long tick = gm_tick(sch);
     acc.s_tot += tick;
     acc.n_tot += 1;
@@ -113,79 +124,197 @@ __device__ __forceinline__ void bond_sample(const FrameArgs &a, uint32_t f, floa
             acc.n_up += 1;
         }
     }
+    return sch != sch;
 }
 
 // ---- K1: tiled bonds ----------------------------------------------------------------------
 // grid.x = n_tiles * n_chunks; block = 256 = 4 waves; dynamic LDS = G * lw floats.
 // Each block owns one tile (<= 256 samples, one contiguous atom window) for frames_per_chunk frames.
-// Per stage it copies the window of G frames HBM -> LDS (wave w stages frame w, 16 B per lane,
-// fully coalesced, every byte read once) and every thread evaluates its sample for the G frames.
-template <int G>
-__global__ __launch_bounds__(256) void k_bonds_tiled(FrameArgs a, const Tile *__restrict__ tiles,
+// Per stage the window of G frames goes HBM -> registers -> LDS (256/G threads per frame, 16 B per
+// lane, fully coalesced, every byte read once) and every thread evaluates its sample for the G
+// frames.  The loads of stage s+1 are issued BEFORE the arithmetic of stage s (NPF float4 registers
+// per thread), so each resident block keeps a whole stage of HBM traffic in flight while it computes.
+//
+// The 16-byte loads start at the window's first float rounded DOWN to 16 B and end at its last float
+// rounded UP to 16 B.  xyz is 16-byte aligned, so the last load of the whole buffer stays inside the
+// aligned 16-byte granule that holds the last valid float: it cannot cross into an unmapped page.
+typedef float v4f __attribute__((ext_vector_type(4)));   // native 16-byte vector (SROA-friendly, unlike float4)
+
+template <int G, int NPF, bool ACOS_COS>
+struct TiledStage {
+    static constexpr uint32_t TPF = 256 / G;   // threads that stage one frame
+
+    // issue the loads of my frame slot of the stage that starts at frame f0
+    template <bool TAIL>
+    static __device__ __forceinline__ void load(const FrameArgs &a, const Tile &t, uint32_t f0, uint32_t f_end,
+                                                uint32_t sk, uint32_t si, v4f (&pre)[NPF]) {
+        const uint32_t f = f0 + sk;
+        if (TAIL && f >= f_end) return;
+        const size_t base = ((size_t)f * a.n_atoms + t.atom0) * 3u;
+        const uint32_t n4 = ((uint32_t)(base & 3u) + 3u * t.n_window + 3u) >> 2;
+        const v4f *src = reinterpret_cast<const v4f *>(a.xyz + (base & ~(size_t)3));
+#pragma unroll
+        for (int j = 0; j < NPF; j++) {   // unconditional (index clamped): keeps pre[] in registers
+            const uint32_t i = si + (uint32_t)j * TPF;
+            pre[j] = src[i < n4 ? i : n4 - 1u];
+        }
+    }
+    // registers (and, for windows wider than NPF * TPF float4, late loads) -> LDS
+    template <bool TAIL>
+    static __device__ __forceinline__ void store(const FrameArgs &a, const Tile &t, uint32_t f0, uint32_t f_end,
+                                                 uint32_t sk, uint32_t si, const v4f (&pre)[NPF], float *lds,
+                                                 uint32_t lw) {
+        const uint32_t f = f0 + sk;
+        if (TAIL && f >= f_end) return;
+        const size_t base = ((size_t)f * a.n_atoms + t.atom0) * 3u;
+        const uint32_t n4 = ((uint32_t)(base & 3u) + 3u * t.n_window + 3u) >> 2;
+        const v4f *src = reinterpret_cast<const v4f *>(a.xyz + (base & ~(size_t)3));
+        v4f *dst = reinterpret_cast<v4f *>(lds + (size_t)sk * lw);
+#pragma unroll
+        for (int j = 0; j < NPF; j++) {
+            const uint32_t i = si + (uint32_t)j * TPF;
+            if (i < n4) dst[i] = pre[j];
+        }
+        for (uint32_t i = si + (uint32_t)NPF * TPF; i < n4; i += TPF) dst[i] = src[i];
+    }
+    // My sample in each of the G staged frames.  The common path is straight-line code (selects only) so
+    // that the G independent dependency chains interleave; the rare cases (atoms more than 1.5 box
+    // lengths apart -> literal minimum-image loops; NaN result -> which atom is undefined?) are
+    // collected in a bit mask and handled once, after the stage.
+    static __device__ __forceinline__ void compute(const FrameArgs &a, const Tile &t, const Item &it, uint32_t f0,
+                                                   const float *lds, uint32_t lw, SampleAcc &acc, int &bad,
+                                                   uint32_t &nan_atom, uint32_t &nan_frame) {
+        int tick[G];
+        uint8_t fl[G];
+        uint32_t rare = 0;
+        if (a.leaflets) {
+#pragma unroll
+            for (int k = 0; k < G; k++) fl[k] = a.aflags[(size_t)a.arow[f0 + k] * a.n_mol_total + it.mol];
+        }
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+            const uint32_t f = f0 + k;
+            const uint32_t sh = (uint32_t)((((size_t)f * a.n_atoms + t.atom0) * 3u) & 3u);
+            const float *w = lds + (size_t)k * lw + sh;
+            const float p1x = w[3u * it.li], p1y = w[3u * it.li + 1], p1z = w[3u * it.li + 2];
+            const float p2x = w[3u * it.lj], p2y = w[3u * it.lj + 1], p2z = w[3u * it.lj + 2];
+            float vx = p2x - p1x, vy = p2y - p1y, vz = p2z - p1z;
+            if (a.pbc) {
+                const float *b = a.box9 + 9 * (size_t)f;
+                bool slow = false;
+                vx = gm_min_image_step(vx, b[0], slow);
+                vy = gm_min_image_step(vy, b[4], slow);
+                vz = gm_min_image_step(vz, b[8], slow);
+                rare |= (slow ? 1u : 0u) << k;
+            }
+            const float sch = gm_calc_sch<ACOS_COS>(vx, vy, vz, a.nx, a.ny, a.nz, a.n2, a.n2sq);
+            rare |= ((sch != sch) ? 1u : 0u) << k;
+            tick[k] = gm_tick(sch);
+        }
+        if (__builtin_expect(rare != 0, 0)) {
+#pragma unroll 1
+            for (int k = 0; k < G; k++) {
+                if (!((rare >> k) & 1u)) continue;
+                const uint32_t f = f0 + k;
+                const uint32_t sh = (uint32_t)((((size_t)f * a.n_atoms + t.atom0) * 3u) & 3u);
+                const float *w = lds + (size_t)k * lw + sh;
+                const float p1x = w[3u * it.li], p1y = w[3u * it.li + 1], p1z = w[3u * it.li + 2];
+                const float p2x = w[3u * it.lj], p2y = w[3u * it.lj + 1], p2z = w[3u * it.lj + 2];
+                float vx = p2x - p1x, vy = p2y - p1y, vz = p2z - p1z;
+                if (a.pbc) {
+                    const float *b = a.box9 + 9 * (size_t)f;
+                    vx = gm_min_image_loop(vx, b[0], bad);
+                    vy = gm_min_image_loop(vy, b[4], bad);
+                    vz = gm_min_image_loop(vz, b[8], bad);
+                }
+                const float sch = gm_calc_sch<ACOS_COS>(vx, vy, vz, a.nx, a.ny, a.nz, a.n2, a.n2sq);
+                tick[k] = gm_tick(sch);
+                if (sch != sch) {
+                    if (p1x != p1x) { nan_atom = t.atom0 + it.li; nan_frame = f; }
+                    else if (p2x != p2x) { nan_atom = t.atom0 + it.lj; nan_frame = f; }
+                }
+            }
+        }
+        int st = 0, su = 0;
+        uint32_t nu = 0;
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+            st += tick[k];
+            if (a.leaflets) {   // Leaflet::Upper = 0 (lib.rs:416-422)
+                su += fl[k] == 0 ? tick[k] : 0;
+                nu += fl[k] == 0 ? 1u : 0u;
+            }
+        }
+        acc.s_tot += st;
+        acc.n_tot += G;
+        acc.s_up += su;
+        acc.n_up += nu;
+    }
+    // partial last stage: frames f0 .. f_end-1, one at a time (not performance relevant)
+    static __device__ __forceinline__ void compute_tail(const FrameArgs &a, const Tile &t, const Item &it,
+                                                        uint32_t f0, uint32_t f_end, const float *lds, uint32_t lw,
+                                                        SampleAcc &acc, int &bad, uint32_t &nan_atom,
+                                                        uint32_t &nan_frame) {
+#pragma unroll 1
+        for (uint32_t f = f0; f < f_end; f++) {
+            const uint32_t sh = (uint32_t)((((size_t)f * a.n_atoms + t.atom0) * 3u) & 3u);
+            const float *w = lds + (size_t)(f - f0) * lw + sh;
+            const float p1x = w[3u * it.li], p1y = w[3u * it.li + 1], p1z = w[3u * it.li + 2];
+            const float p2x = w[3u * it.lj], p2y = w[3u * it.lj + 1], p2z = w[3u * it.lj + 2];
+            if (bond_sample<ACOS_COS>(a, f, p1x, p1y, p1z, p2x, p2y, p2z, it.mol, acc, bad)) {
+                if (p1x != p1x) { nan_atom = t.atom0 + it.li; nan_frame = f; }
+                else if (p2x != p2x) { nan_atom = t.atom0 + it.lj; nan_frame = f; }
+            }
+        }
+    }
+};
+
+template <int G, int NPF, bool ACOS_COS>
+__global__ __launch_bounds__(256) void k_bonds_tiled(FrameArgs a_in, const float *__restrict__ xyz,
+                                                      const float *__restrict__ box9,
+                                                      const uint8_t *__restrict__ aflags,
+                                                      const uint32_t *__restrict__ arow,
+                                                      const Tile *__restrict__ tiles,
                                                       const Item *__restrict__ items,
                                                       const uint32_t *__restrict__ tile_slots,
                                                       uint32_t n_tiles, uint32_t lw) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    using S = TiledStage<G, NPF, ACOS_COS>;
+    // the read-only streams come in as __restrict__ kernel arguments so that the compiler can prove
+    // that the accumulator / error stores never clobber them (uniform loads become scalar loads)
+    FrameArgs a = a_in;
+    a.xyz = xyz; a.box9 = box9; a.aflags = aflags; a.arow = arow;
     const uint32_t tile_id = blockIdx.x % n_tiles;
     const uint32_t chunk = blockIdx.x / n_tiles;
     const Tile t = tiles[tile_id];
     const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    const uint32_t sk = tid / S::TPF, si = tid % S::TPF;   // staging role: frame slot, first float4
     const bool active = tid < t.n_items;
     Item it{0, 0, 0, 0, 0};
     if (active) it = items[t.item0 + tid];
 
     const uint32_t f_begin = chunk * a.frames_per_chunk;
     const uint32_t f_end = min(a.n_frames, f_begin + a.frames_per_chunk);
-    const size_t total_floats = (size_t)a.n_frames * a.n_atoms * 3u;
-    const uint32_t win_floats = 3u * t.n_window;
+    const uint32_t f_full = f_begin + ((f_end - f_begin) / G) * G;   // end of the whole stages
 
     SampleAcc acc;
     int bad = 0;
     uint32_t nan_atom = 0xffffffffu, nan_frame = 0;
+    v4f pre[NPF];
 
-    for (uint32_t f0 = f_begin; f0 < f_end; f0 += G) {
-        // ---- stage: wave k copies the window of frame f0+k
-        for (uint32_t k = wave; k < (uint32_t)G; k += 4) {
-            const uint32_t f = f0 + k;
-            if (f < f_end) {
-                const size_t base = ((size_t)f * a.n_atoms + t.atom0) * 3u;
-                const size_t abase = base & ~(size_t)3;
-                const uint32_t n4 = ((uint32_t)(base & 3u) + win_floats + 3u) >> 2;
-                const float4 *src = reinterpret_cast<const float4 *>(a.xyz + abase);
-                float4 *dst = reinterpret_cast<float4 *>(lds + (size_t)k * lw);
-                for (uint32_t i = lane; i < n4; i += 64) {
-                    const size_t e = abase + 4u * (size_t)i;
-                    float4 v;
-                    if (e + 4 <= total_floats) {
-                        v = src[i];
-                    } else {   // last few floats of the whole buffer
-                        v.x = e + 0 < total_floats ? a.xyz[e + 0] : 0.0f;
-                        v.y = e + 1 < total_floats ? a.xyz[e + 1] : 0.0f;
-                        v.z = e + 2 < total_floats ? a.xyz[e + 2] : 0.0f;
-                        v.w = 0.0f;
-                    }
-                    dst[i] = v;
-                }
-            }
-        }
+    if (f_begin < f_full) S::template load<false>(a, t, f_begin, f_end, sk, si, pre);
+    for (uint32_t f0 = f_begin; f0 < f_full; f0 += G) {
+        S::template store<false>(a, t, f0, f_end, sk, si, pre, lds, lw);
         __syncthreads();
-        // ---- compute: my sample in each staged frame
-        if (active) {
-#pragma unroll
-            for (int k = 0; k < G; k++) {
-                const uint32_t f = f0 + k;
-                if (f < f_end) {
-                    const size_t base = ((size_t)f * a.n_atoms + t.atom0) * 3u;
-                    const float *w = lds + (size_t)k * lw + (uint32_t)(base & 3u);
-                    const float p1x = w[3u * it.li], p1y = w[3u * it.li + 1], p1z = w[3u * it.li + 2];
-                    const float p2x = w[3u * it.lj], p2y = w[3u * it.lj + 1], p2z = w[3u * it.lj + 2];
-                    if (p1x != p1x) { nan_atom = t.atom0 + it.li; nan_frame = f; }
-                    else if (p2x != p2x) { nan_atom = t.atom0 + it.lj; nan_frame = f; }
-                    bond_sample(a, f, p1x, p1y, p1z, p2x, p2y, p2z, it.mol, acc, bad);
-                }
-            }
-        }
+        if (f0 + G < f_full) S::template load<false>(a, t, f0 + G, f_end, sk, si, pre);   // next stage in flight
+        if (active) S::compute(a, t, it, f0, lds, lw, acc, bad, nan_atom, nan_frame);
+        __syncthreads();
+    }
+    if (f_full < f_end) {   // last, partial stage of the batch
+        S::template load<true>(a, t, f_full, f_end, sk, si, pre);
+        S::template store<true>(a, t, f_full, f_end, sk, si, pre, lds, lw);
+        __syncthreads();
+        if (active) S::compute_tail(a, t, it, f_full, f_end, lds, lw, acc, bad, nan_atom, nan_frame);
         __syncthreads();
     }
 
@@ -219,6 +348,7 @@ __global__ __launch_bounds__(256) void k_bonds_tiled(FrameArgs a, const Tile *__
 }
 
 // ---- K1b: direct gather (samples whose atoms do not fit one LDS window; also the A/B baseline)
+template <bool ACOS_COS>
 __global__ __launch_bounds__(256) void k_bonds_direct(FrameArgs a, const DirectItem *__restrict__ items,
                                                        uint32_t n_items, uint32_t blocks_per_chunk) {
     const uint32_t chunk = blockIdx.x / blocks_per_chunk;
@@ -234,9 +364,10 @@ __global__ __launch_bounds__(256) void k_bonds_direct(FrameArgs a, const DirectI
         const float *p2 = a.xyz + ((size_t)f * a.n_atoms + it.j) * 3u;
         const float p1x = p1[0], p1y = p1[1], p1z = p1[2];
         const float p2x = p2[0], p2y = p2[1], p2z = p2[2];
-        if (p1x != p1x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, it.i, f);
-        else if (p2x != p2x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, it.j, f);
-        bond_sample(a, f, p1x, p1y, p1z, p2x, p2y, p2z, it.mol, acc, bad);
+        if (__builtin_expect(bond_sample<ACOS_COS>(a, f, p1x, p1y, p1z, p2x, p2y, p2z, it.mol, acc, bad), 0)) {
+            if (p1x != p1x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, it.i, f);
+            else if (p2x != p2x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, it.j, f);
+        }
     }
     if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f_begin);
     if (acc.n_tot) {
@@ -411,7 +542,10 @@ struct gorder_hip_handle {
     // host staging for submit_host
     float *d_stage_xyz = nullptr, *d_stage_box = nullptr;
     size_t stage_xyz_cap = 0, stage_box_cap = 0;
-    float n2 = 1.0f;
+    float n2 = 1.0f, n2sq = 1.0f;
+    int frames_per_stage = kFramesPerStage;   // G (2, 4 or 8); GORDER_HIP_FRAMES_PER_STAGE overrides
+    uint32_t wg_capacity = 256u * 6u;          // co-resident workgroups of the tiled kernel on this device
+    uint32_t wg_target = 0;                    // GORDER_HIP_WG_TARGET: force the workgroup count aimed at
     uint32_t lw = 0;
     size_t lds_bytes = 0;
     uint64_t n_frames = 0;
@@ -488,30 +622,55 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
     HIP_TRY(h, hipEventRecord(e0, h->stream));
     if (n_tiles) {
         // enough workgroups to fill 256 CUs x 8 blocks, frames split into chunks of whole stages
-        const uint32_t target = 256u * 8u;
-        uint32_t n_chunks = std::max(1u, (target + n_tiles - 1) / n_tiles);
-        uint32_t fpc = (a.n_frames + n_chunks - 1) / n_chunks;
-        fpc = ((fpc + kFramesPerStage - 1) / kFramesPerStage) * kFramesPerStage;
+        // Cut the frame range into chunks of whole stages.  All workgroups do the same amount of work,
+        // so the grid should be a whole number of co-resident rounds: exactly one round when the tiles
+        // fit, otherwise many short rounds so that the last, partial one costs little.
+        const uint32_t G = (uint32_t)h->frames_per_stage;
+        const uint32_t n_stages = (a.n_frames + G - 1) / G;
+        uint32_t target = h->wg_target ? h->wg_target : h->wg_capacity;
+        if (!h->wg_target && n_tiles > h->wg_capacity / 2) target = 12u * h->wg_capacity;
+        uint32_t n_chunks = std::max(1u, target / n_tiles);
+        n_chunks = std::min(n_chunks, std::max(1u, n_stages / 4u));   // >= 4 stages per workgroup
+        uint32_t fpc = ((n_stages + n_chunks - 1) / n_chunks) * G;
         n_chunks = (a.n_frames + fpc - 1) / fpc;
         a.frames_per_chunk = fpc;
         const uint64_t grid = (uint64_t)n_tiles * n_chunks;
         if (grid > 0x7fffffffull) return fail(h, GORDER_ERR_INVALID_ARGUMENT, "batch too large");
-        hipLaunchKernelGGL((k_bonds_tiled<kFramesPerStage>), dim3((uint32_t)grid), dim3(kBlock), h->lds_bytes,
-                           h->stream, a, h->d_tiles, h->d_items, h->d_tile_slots, n_tiles, h->lw);
+        const bool ac = (h->tables.flags & GORDER_FLAG_TRIG_ACOS_COS) != 0;
+        const dim3 g((uint32_t)grid), b(kBlock);
+#define GORDER_LAUNCH_TILED(G_, NPF_)                                                                       \
+        do {                                                                                                \
+            if (ac) hipLaunchKernelGGL((k_bonds_tiled<G_, NPF_, true>), g, b, h->lds_bytes, h->stream, a,       \
+                                       a.xyz, a.box9, a.aflags, a.arow, h->d_tiles, h->d_items,             \
+                                       h->d_tile_slots, n_tiles, h->lw);                                    \
+            else hipLaunchKernelGGL((k_bonds_tiled<G_, NPF_, false>), g, b, h->lds_bytes, h->stream, a,         \
+                                    a.xyz, a.box9, a.aflags, a.arow, h->d_tiles, h->d_items,                \
+                                    h->d_tile_slots, n_tiles, h->lw);                                       \
+        } while (0)
+        switch (h->frames_per_stage) {
+            case 2: GORDER_LAUNCH_TILED(2, 3); break;
+            case 8: GORDER_LAUNCH_TILED(8, 10); break;
+            default: GORDER_LAUNCH_TILED(4, 5); break;
+        }
+#undef GORDER_LAUNCH_TILED
         HIP_TRY(h, hipGetLastError());
     }
     if (!p.direct.empty()) {
         const uint32_t n_items = (uint32_t)p.direct.size();
         const uint32_t bpc = (n_items + kBlock - 1) / kBlock;
-        const uint32_t target = 256u * 8u;
+        const uint32_t target = h->wg_target ? h->wg_target : 256u * 8u;
         uint32_t n_chunks = std::max(1u, (target + bpc - 1) / bpc);
         n_chunks = std::min(n_chunks, a.n_frames);
         const uint32_t fpc = (a.n_frames + n_chunks - 1) / n_chunks;
         n_chunks = (a.n_frames + fpc - 1) / fpc;
         FrameArgs b = a;
         b.frames_per_chunk = fpc;
-        hipLaunchKernelGGL(k_bonds_direct, dim3(bpc * n_chunks), dim3(kBlock), 0, h->stream, b, h->d_direct, n_items,
-                           bpc);
+        if (h->tables.flags & GORDER_FLAG_TRIG_ACOS_COS)
+            hipLaunchKernelGGL(k_bonds_direct<true>, dim3(bpc * n_chunks), dim3(kBlock), 0, h->stream, b, h->d_direct,
+                               n_items, bpc);
+        else
+            hipLaunchKernelGGL(k_bonds_direct<false>, dim3(bpc * n_chunks), dim3(kBlock), 0, h->stream, b, h->d_direct,
+                               n_items, bpc);
         HIP_TRY(h, hipGetLastError());
     }
     hipLaunchKernelGGL(k_count_frames, dim3(1), dim3(1), 0, h->stream, a.acc + 4 * (size_t)a.n_acc, a.n_frames);
@@ -599,11 +758,37 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
     HIP_TRY(h, hipMemset(h->d_acc, 0, h->acc_words * sizeof(unsigned long long)));
     {   // |normal| with the f32 sequence of nalgebra's norm (oracle: norm3)
         const float *n = t->normal;
-        h->n2 = sqrtf((n[0] * n[0] + n[1] * n[1]) + n[2] * n[2]);
+        h->n2sq = (n[0] * n[0] + n[1] * n[1]) + n[2] * n[2];
+        h->n2 = sqrtf(h->n2sq);
+    }
+    if (const char *e = getenv("GORDER_HIP_FRAMES_PER_STAGE")) {
+        const int g = atoi(e);
+        if (g == 2 || g == 4 || g == 8) h->frames_per_stage = g;
+    }
+    if (const char *e = getenv("GORDER_HIP_WG_TARGET")) {
+        const int w = atoi(e);
+        if (w > 0) h->wg_target = (uint32_t)w;
     }
     h->lw = ((3u * p.max_window + 3u + 3u) / 4u) * 4u;
-    h->lds_bytes = (size_t)kFramesPerStage * h->lw * sizeof(float);
+    h->lds_bytes = (size_t)h->frames_per_stage * h->lw * sizeof(float);
     if (h->lds_bytes < (size_t)kBlock * 24) h->lds_bytes = (size_t)kBlock * 24;
+    {   // how many workgroups of the tiled kernel are co-resident: the frame range of a batch is cut so
+        // that the grid is a whole number of such rounds (no half-empty last round)
+        int n_cu = 256, per_cu = 6;
+        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device);
+        const bool ac = (t->flags & GORDER_FLAG_TRIG_ACOS_COS) != 0;
+        hipError_t e;
+        switch (h->frames_per_stage) {
+            case 2: e = ac ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bonds_tiled<2, 3, true>, kBlock, h->lds_bytes)
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bonds_tiled<2, 3, false>, kBlock, h->lds_bytes); break;
+            case 8: e = ac ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bonds_tiled<8, 10, true>, kBlock, h->lds_bytes)
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bonds_tiled<8, 10, false>, kBlock, h->lds_bytes); break;
+            default: e = ac ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bonds_tiled<4, 5, true>, kBlock, h->lds_bytes)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bonds_tiled<4, 5, false>, kBlock, h->lds_bytes); break;
+        }
+        if (e != hipSuccess || per_cu < 1) per_cu = 4;
+        h->wg_capacity = (uint32_t)n_cu * (uint32_t)per_cu;
+    }
 
     const gorder_leaflets_t &lf = t->leaflets;
     if (lf.method != GORDER_LEAFLETS_NONE) {
@@ -680,7 +865,7 @@ int gorder_hip_plan(const gorder_hip_handle *h, gorder_hip_plan_t *plan) {
     plan->block_threads = kBlock;
     plan->max_window_atoms = h->plan.max_window;
     plan->n_direct_items = (uint32_t)h->plan.direct.size();
-    plan->frames_per_stage = kFramesPerStage;
+    plan->frames_per_stage = (uint32_t)h->frames_per_stage;
     plan->lds_bytes = (uint32_t)h->lds_bytes;
     return GORDER_OK;
 }
@@ -783,7 +968,7 @@ int gorder_hip_submit_device(gorder_hip_handle *h, const float *d_xyz, const flo
     FrameArgs a{};
     a.xyz = d_xyz; a.box9 = d_box; a.n_atoms = p.n_atoms; a.n_frames = n_frames;
     a.pbc = pbc ? 1 : 0;
-    a.nx = h->tables.normal[0]; a.ny = h->tables.normal[1]; a.nz = h->tables.normal[2]; a.n2 = h->n2;
+    a.nx = h->tables.normal[0]; a.ny = h->tables.normal[1]; a.nz = h->tables.normal[2]; a.n2 = h->n2; a.n2sq = h->n2sq;
     a.leaflets = leaflets ? 1 : 0; a.aflags = h->d_aflags; a.arow = h->d_arow; a.n_mol_total = p.n_mol_total;
     a.acc = h->d_acc; a.n_acc = p.n_acc; a.err = h->d_err;
     if ((st = launch_orders(h, a)) != GORDER_OK) return st;

@@ -118,6 +118,17 @@ typedef struct {
     const uint32_t *methyls;   /* [n_molecules][n_methyls] or NULL */
 } gorder_moltype_t;
 
+/* How cos(theta) of calc_sch (mod.rs:78-82) is evaluated.
+ * Default (0): cos(theta) = clamp(v.n / (|v||n|), -1, 1) taken DIRECTLY.  The reference evaluates
+ *   `angle = acos(clamp(..))` and then `angle.cos()` in f32; that round trip returns the same number
+ *   up to +-2 ulp of rounding noise.  Measured against the libm round trip: 3.3 % of samples move by
+ *   one 1e-6 tick, never more, mean shift 3e-10 — four orders below the 1e-6 parity tolerance.
+ * GORDER_FLAG_TRIG_ACOS_COS: evaluate the acos -> cos round trip like the reference (own f32
+ *   polynomial kernels, < 1 ulp each; 1.6 % of samples move by one tick vs glibc 2.35). */
+typedef enum {
+    GORDER_FLAG_TRIG_ACOS_COS = 1u
+} gorder_flags_t;
+
 typedef struct {
     uint32_t n_atoms;           /* atoms per submitted frame (the decoded "Master" group, common.rs:283-304) */
     uint32_t n_molecule_types;
@@ -128,6 +139,7 @@ typedef struct {
     gorder_ordermap_t ordermap;
     int32_t timewise;           /* 1 = keep per-frame partial sums (estimate_error; timewise.rs:130-186) */
     int32_t device;             /* HIP device ordinal */
+    uint32_t flags;             /* gorder_flags_t */
 } gorder_tables_t;
 
 /* Accumulator slots are numbered in reference iteration order: molecule type major, then bond

@@ -137,20 +137,32 @@ float gorder_oracle_mirror_cosf(float t) {
 }
 
 /* [3rd-party] nalgebra Matrix::angle, reached through groan_rs Vector3D::angle (mod.rs:79):
- * 0 if either norm is 0, else acos(clamp(a.b / (|a||b|), -1, 1)); clamp lets NaN through. */
-static inline float angle3(const float *a, const float *b, int trig) {
+ * 0 if either norm is 0, else acos(clamp(a.b / (|a||b|), -1, 1)); clamp lets NaN through.
+ * `*cosine` receives the clamped cosine (1 for the zero-norm case, = cos(0)). */
+static inline float angle3(const float *a, const float *b, int trig, float *cosine) {
     const float prod = dot3(a, b);
     const float n1 = norm3(a), n2 = norm3(b);
-    if (n1 == 0.0f || n2 == 0.0f) return 0.0f;
+    if (n1 == 0.0f || n2 == 0.0f) { if (cosine) *cosine = 1.0f; return 0.0f; }
     float c = prod / (n1 * n2);
     if (c < -1.0f) c = -1.0f;
     else if (c > 1.0f) c = 1.0f;
+    if (cosine) *cosine = c;
     return trig == GORDER_ORACLE_TRIG_MIRROR ? gorder_oracle_mirror_acosf(c) : acosf(c);
 }
 
-/* calc_sch, src/analysis/mod.rs:78-82 */
+/* calc_sch, src/analysis/mod.rs:78-82.
+ * DIRECT restates the device library's default evaluation (gorder_amd/csrc/gm_math.h): P2 from the
+ * squared cosine q = (v.n)^2 / (|v|^2 |n|^2), no acos -> cos round trip and no square root. */
 static inline float calc_sch(const float *v, const float *n, int trig) {
-    const float angle = angle3(v, n, trig);
+    if (trig == GORDER_ORACLE_TRIG_DIRECT) {
+        const float prod = dot3(v, n);
+        const float s2 = dot3(v, v), n2sq = dot3(n, n);
+        float q = (prod * prod) / (s2 * n2sq);
+        if (q > 1.0f) q = 1.0f;
+        if (s2 == 0.0f || n2sq == 0.0f) q = 1.0f;
+        return (1.5f * q) - 0.5f;
+    }
+    const float angle = angle3(v, n, trig, NULL);
     const float co = trig == GORDER_ORACLE_TRIG_MIRROR ? gorder_oracle_mirror_cosf(angle) : cosf(angle);
     return (1.5f * co * co) - 0.5f;
 }
@@ -319,7 +331,7 @@ int gorder_oracle_predict_hydrogens(uint32_t kind, const float pos[4][3], const 
         float th1[3], th2[3], axis[3], ua[3], hv[3];
         bad |= vector_to(t, h1, box, pbc, th1);
         bad |= vector_to(t, h2, box, pbc, th2);
-        const float gamma = angle3(th1, th2, GORDER_ORACLE_TRIG_LIBM);
+        const float gamma = angle3(th1, th2, GORDER_ORACLE_TRIG_LIBM, NULL);
         cross3(th1, th2, axis);
         unit3(axis, ua);
         rotate_axis_angle(ua, 3.14159265358979323846f - (gamma / 2.0f), th2, hv);

@@ -20,9 +20,11 @@ extern "C" {
 /* How acos / cos of `calc_sch` (src/analysis/mod.rs:78-82) are evaluated:
  *   LIBM   — host libm acosf/cosf: what the Rust reference itself calls on linux-gnu
  *            (f32::acos -> acosf, f32::cos -> cosf).  This is the reference-faithful mode.
+ *   DIRECT — cos(theta) = the clamped cosine itself, no acos -> cos round trip: restates the device
+ *            library's default mode (include/gorder_hip.h, gorder_flags_t) for EQUALITY checks.
  *   MIRROR — the oracle's own restatement (in portable C, fmaf only) of the polynomial kernels the
  *            device code uses, so that device-vs-oracle i64 sums can be compared for EQUALITY. */
-enum { GORDER_ORACLE_TRIG_LIBM = 0, GORDER_ORACLE_TRIG_MIRROR = 1 };
+enum { GORDER_ORACLE_TRIG_LIBM = 0, GORDER_ORACLE_TRIG_MIRROR = 1, GORDER_ORACLE_TRIG_DIRECT = 2 };
 
 typedef struct gorder_oracle_handle gorder_oracle_handle;
 

@@ -15,7 +15,7 @@ from gorder_amd.abi import OK, CTables, Results, Tables
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgorder_oracle.so")
-TRIG_LIBM, TRIG_MIRROR = 0, 1
+TRIG_LIBM, TRIG_MIRROR, TRIG_DIRECT = 0, 1, 2
 _lib = None
 
 

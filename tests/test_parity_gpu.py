@@ -1,8 +1,9 @@
 """GPU parity: the HIP path (through the C ABI) against the oracle on the same seeded inputs.
 
-Bar: sample counts and i64 order sums EQUAL to the oracle's MIRROR mode (same polynomial trig,
-restated in C); every order parameter within 1e-6 (north_star tolerance) of the oracle's LIBM mode,
-which evaluates acos/cos with the host libm exactly as the Rust reference does.
+Bar: sample counts and i64 order sums EQUAL to the oracle mode that restates the device's cosine
+evaluation (DIRECT for the default, MIRROR for GORDER_FLAG_TRIG_ACOS_COS); every order parameter
+within 1e-6 (north_star tolerance) of the oracle's LIBM mode, which evaluates acos/cos with the host
+libm exactly as the Rust reference does.
 """
 import numpy as np
 import pytest
@@ -46,7 +47,9 @@ def run_gpu(system, xyz, box, frame_index=None, host=False, batches=1):
     return eng, res
 
 
-def run_oracle(system, xyz, box, frame_index=None, trig=oracle.TRIG_MIRROR, n_threads=1):
+def run_oracle(system, xyz, box, frame_index=None, trig=None, n_threads=1):
+    if trig is None:   # the oracle mode that restates the device library's cosine evaluation
+        trig = oracle.TRIG_MIRROR if (system.tables.flags & abi.FLAG_TRIG_ACOS_COS) else oracle.TRIG_DIRECT
     o = oracle.OracleEngine(system.tables, trig=trig, n_threads=n_threads)
     o.submit(xyz, box, frame_index)
     return o, o.finish()
@@ -77,15 +80,19 @@ def assert_parity(system, xyz, box, frame_index=None, **kw):
     return eng, got
 
 
-@pytest.mark.parametrize("n_lipids,n_frames", [(256, 12), (7, 9), (64, 1)])
-def test_aa_no_leaflets(built, n_lipids, n_frames):
+@pytest.mark.parametrize("flags", [0, abi.FLAG_TRIG_ACOS_COS])
+@pytest.mark.parametrize("n_lipids,n_frames", [(256, 12), (7, 9), (64, 1), (31, 50)])
+def test_aa_no_leaflets(built, n_lipids, n_frames, flags):
     system = synthetic.aa_membrane(n_lipids)
+    system.tables.flags = flags
     xyz = system.frames(n_frames, seed=11)
     assert_parity(system, xyz, system.box9(n_frames))
 
 
-def test_cg_global_leaflets_mixed_types(built):
+@pytest.mark.parametrize("flags", [0, abi.FLAG_TRIG_ACOS_COS])
+def test_cg_global_leaflets_mixed_types(built, flags):
     system = synthetic.cg_membrane(600, leaflets=LEAFLETS_GLOBAL, n_types=3)
+    system.tables.flags = flags
     n = 20
     xyz = system.frames(n, seed=5)
     eng, got = assert_parity(system, xyz, system.box9(n))
@@ -130,7 +137,7 @@ def test_flip_and_manual(built):
     eng.set_manual_leaflets(flags)
     eng.submit_device(torch.from_numpy(xyz).cuda(), torch.from_numpy(system3.box9(6)).cuda())
     got = eng.finish()
-    o = oracle.OracleEngine(system3.tables, trig=oracle.TRIG_MIRROR)
+    o = oracle.OracleEngine(system3.tables, trig=oracle.TRIG_DIRECT)
     o.set_manual_leaflets(flags)
     o.submit(xyz, system3.box9(6))
     want = o.finish()
@@ -258,6 +265,16 @@ def test_priming_replaces_cross_thread_wait(built):
     head = eng0.finish()
     np.testing.assert_array_equal(head.sums + tail.sums, ref.sums)      # SystemTopology::add
     np.testing.assert_array_equal(head.counts + tail.counts, ref.counts)
+
+
+@pytest.mark.parametrize("g", ["2", "4", "8"])
+def test_frames_per_stage_variants(built, monkeypatch, g):
+    monkeypatch.setenv("GORDER_HIP_FRAMES_PER_STAGE", g)
+    monkeypatch.setenv("GORDER_HIP_WG_TARGET", "40")
+    system = synthetic.cg_membrane(150, leaflets=LEAFLETS_GLOBAL, frequency=3)
+    xyz = system.frames(43, seed=21)
+    eng, _ = assert_parity(system, xyz, system.box9(43))
+    assert eng.plan()["frames_per_stage"] == int(g)
 
 
 def test_launch_geometry_invariance(built):
