@@ -18,7 +18,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgorder_hip.so")
+LIB_PATH = os.environ.get("GORDER_HIP_LIB") or os.path.join(_HERE, "libgorder_hip.so")   # env: A/B builds
 
 # ---- status codes (gorder_status_t) ---------------------------------------------------------
 OK = 0

@@ -42,14 +42,13 @@ __device__ __forceinline__ float gm_min_image_loop(float dx, float L, int &bad) 
 // more than 1.5 box lengths apart), in which case the caller re-runs gm_min_image_loop on the input.
 // The literal form is  a = dx > half ? dx - L : dx;  b = a < -half ? a + L : a.  If the first shift
 // happened then a = RN(dx - L) >= -half (rounding is monotonic and -half is a float), so the second
-// cannot; hence b is one select chain on dx itself.  One shift was enough iff |dx| <= 1.5 L ... which
-// is tested on the results: (dx - L) > half or (dx + L) < -half.
+// cannot; hence b is one select chain on dx itself.
 __device__ __forceinline__ float gm_min_image_step(float dx, float L, bool &slow) {
     const float half = L / 2.0f;
-    const float dn = dx - L, up = dx + L;
-    const bool hi = dx > half, lo = dx < -half;
-    slow = slow || (hi && dn > half) || (lo && up < -half);
-    return hi ? dn : (lo ? up : dx);
+    const float r = dx > half ? dx - L : (dx < -half ? dx + L : dx);
+    // one shift was enough iff the result lies in [-half, half] (NaN: loops would not iterate either)
+    slow = slow || (__builtin_fabsf(r) > half);
+    return r;
 }
 
 __device__ __forceinline__ float gm_min_image(float dx, float L, int &bad) {
@@ -151,6 +150,9 @@ __device__ __forceinline__ float gm_cosf(float t) {
 template <bool ACOS_COS>
 __device__ __forceinline__ float gm_calc_sch(float vx, float vy, float vz, float nx, float ny, float nz,
                                              float n2, float n2sq) {
+#ifdef GORDER_DEBUG_NOMATH   // timing experiment only: how fast does the data path alone stream?
+    return (vx + vy) + vz;
+#endif
     const float prod = (vx * nx + vy * ny) + vz * nz;
     const float s2 = (vx * vx + vy * vy) + vz * vz;
     if (ACOS_COS) {

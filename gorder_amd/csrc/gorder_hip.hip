@@ -140,7 +140,7 @@ __device__ __forceinline__ bool bond_sample(const FrameArgs &a, uint32_t f, floa
 // aligned 16-byte granule that holds the last valid float: it cannot cross into an unmapped page.
 typedef float v4f __attribute__((ext_vector_type(4)));   // native 16-byte vector (SROA-friendly, unlike float4)
 
-template <int G, int NPF, bool ACOS_COS>
+template <int G, int NPF, bool ACOS_COS, bool PBC, bool LEAF>
 struct TiledStage {
     static constexpr uint32_t TPF = 256 / G;   // threads that stage one frame
 
@@ -156,7 +156,7 @@ struct TiledStage {
 #pragma unroll
         for (int j = 0; j < NPF; j++) {   // unconditional (index clamped): keeps pre[] in registers
             const uint32_t i = si + (uint32_t)j * TPF;
-            pre[j] = src[i < n4 ? i : n4 - 1u];
+            pre[j] = __builtin_nontemporal_load(src + (i < n4 ? i : n4 - 1u));   // streamed once: nt
         }
     }
     // registers (and, for windows wider than NPF * TPF float4, late loads) -> LDS
@@ -175,63 +175,56 @@ struct TiledStage {
             const uint32_t i = si + (uint32_t)j * TPF;
             if (i < n4) dst[i] = pre[j];
         }
-        for (uint32_t i = si + (uint32_t)NPF * TPF; i < n4; i += TPF) dst[i] = src[i];
+        for (uint32_t i = si + (uint32_t)NPF * TPF; i < n4; i += TPF) dst[i] = __builtin_nontemporal_load(src + i);
     }
-    // My sample in each of the G staged frames.  The common path is straight-line code (selects only) so
-    // that the G independent dependency chains interleave; the rare cases (atoms more than 1.5 box
-    // lengths apart -> literal minimum-image loops; NaN result -> which atom is undefined?) are
-    // collected in a bit mask and handled once, after the stage.
-    static __device__ __forceinline__ void compute(const FrameArgs &a, const Tile &t, const Item &it, uint32_t f0,
-                                                   const float *lds, uint32_t lw, SampleAcc &acc, int &bad,
-                                                   uint32_t &nan_atom, uint32_t &nan_frame) {
+    // My sample in each of the G frames of a stage; P[k] = {p1x,p1y,p1z,p2x,p2y,p2z} of frame f0 + k.
+    // The common path is straight-line code (selects only) so that the G independent dependency chains
+    // interleave; the rare cases (atoms more than 1.5 box lengths apart -> literal minimum-image loops;
+    // NaN result -> which atom is undefined?) are collected in a bit mask and handled after the stage.
+    static __device__ __forceinline__ void compute_core(const FrameArgs &a, const Tile &t, const Item &it,
+                                                        uint32_t f0, const float (&P)[G][6], SampleAcc &acc,
+                                                        int &bad, uint32_t &nan_atom, uint32_t &nan_frame) {
         int tick[G];
         uint8_t fl[G];
+        float bx[G], by[G], bz[G];
         uint32_t rare = 0;
-        if (a.leaflets) {
+        // uniform per-frame inputs of the whole stage first (scalar loads, issued back to back)
 #pragma unroll
-            for (int k = 0; k < G; k++) fl[k] = a.aflags[(size_t)a.arow[f0 + k] * a.n_mol_total + it.mol];
+        for (int k = 0; k < G; k++) {
+            if (PBC) {
+                const float *b = a.box9 + 9 * (size_t)(f0 + k);
+                bx[k] = b[0]; by[k] = b[4]; bz[k] = b[8];
+            }
+            if (LEAF) fl[k] = a.aflags[(size_t)a.arow[f0 + k] * a.n_mol_total + it.mol];
         }
 #pragma unroll
         for (int k = 0; k < G; k++) {
-            const uint32_t f = f0 + k;
-            const uint32_t sh = (uint32_t)((((size_t)f * a.n_atoms + t.atom0) * 3u) & 3u);
-            const float *w = lds + (size_t)k * lw + sh;
-            const float p1x = w[3u * it.li], p1y = w[3u * it.li + 1], p1z = w[3u * it.li + 2];
-            const float p2x = w[3u * it.lj], p2y = w[3u * it.lj + 1], p2z = w[3u * it.lj + 2];
-            float vx = p2x - p1x, vy = p2y - p1y, vz = p2z - p1z;
-            if (a.pbc) {
-                const float *b = a.box9 + 9 * (size_t)f;
-                bool slow = false;
-                vx = gm_min_image_step(vx, b[0], slow);
-                vy = gm_min_image_step(vy, b[4], slow);
-                vz = gm_min_image_step(vz, b[8], slow);
-                rare |= (slow ? 1u : 0u) << k;
+            float vx = P[k][3] - P[k][0], vy = P[k][4] - P[k][1], vz = P[k][5] - P[k][2];
+            bool slow = false;
+            if (PBC) {
+                vx = gm_min_image_step(vx, bx[k], slow);
+                vy = gm_min_image_step(vy, by[k], slow);
+                vz = gm_min_image_step(vz, bz[k], slow);
             }
             const float sch = gm_calc_sch<ACOS_COS>(vx, vy, vz, a.nx, a.ny, a.nz, a.n2, a.n2sq);
-            rare |= ((sch != sch) ? 1u : 0u) << k;
+            rare |= ((slow || sch != sch) ? 1u : 0u) << k;
             tick[k] = gm_tick(sch);
         }
         if (__builtin_expect(rare != 0, 0)) {
-#pragma unroll 1
+#pragma unroll
             for (int k = 0; k < G; k++) {
                 if (!((rare >> k) & 1u)) continue;
-                const uint32_t f = f0 + k;
-                const uint32_t sh = (uint32_t)((((size_t)f * a.n_atoms + t.atom0) * 3u) & 3u);
-                const float *w = lds + (size_t)k * lw + sh;
-                const float p1x = w[3u * it.li], p1y = w[3u * it.li + 1], p1z = w[3u * it.li + 2];
-                const float p2x = w[3u * it.lj], p2y = w[3u * it.lj + 1], p2z = w[3u * it.lj + 2];
-                float vx = p2x - p1x, vy = p2y - p1y, vz = p2z - p1z;
-                if (a.pbc) {
-                    const float *b = a.box9 + 9 * (size_t)f;
-                    vx = gm_min_image_loop(vx, b[0], bad);
-                    vy = gm_min_image_loop(vy, b[4], bad);
-                    vz = gm_min_image_loop(vz, b[8], bad);
+                float vx = P[k][3] - P[k][0], vy = P[k][4] - P[k][1], vz = P[k][5] - P[k][2];
+                if (PBC) {
+                    vx = gm_min_image_loop(vx, bx[k], bad);
+                    vy = gm_min_image_loop(vy, by[k], bad);
+                    vz = gm_min_image_loop(vz, bz[k], bad);
                 }
                 const float sch = gm_calc_sch<ACOS_COS>(vx, vy, vz, a.nx, a.ny, a.nz, a.n2, a.n2sq);
                 tick[k] = gm_tick(sch);
                 if (sch != sch) {
-                    if (p1x != p1x) { nan_atom = t.atom0 + it.li; nan_frame = f; }
-                    else if (p2x != p2x) { nan_atom = t.atom0 + it.lj; nan_frame = f; }
+                    if (P[k][0] != P[k][0]) { nan_atom = t.atom0 + it.li; nan_frame = f0 + k; }
+                    else if (P[k][3] != P[k][3]) { nan_atom = t.atom0 + it.lj; nan_frame = f0 + k; }
                 }
             }
         }
@@ -240,7 +233,7 @@ struct TiledStage {
 #pragma unroll
         for (int k = 0; k < G; k++) {
             st += tick[k];
-            if (a.leaflets) {   // Leaflet::Upper = 0 (lib.rs:416-422)
+            if (LEAF) {   // Leaflet::Upper = 0 (lib.rs:416-422)
                 su += fl[k] == 0 ? tick[k] : 0;
                 nu += fl[k] == 0 ? 1u : 0u;
             }
@@ -249,6 +242,20 @@ struct TiledStage {
         acc.n_tot += G;
         acc.s_up += su;
         acc.n_up += nu;
+    }
+    // LDS-staged variant: pick my two atoms out of the staged windows
+    static __device__ __forceinline__ void compute(const FrameArgs &a, const Tile &t, const Item &it, uint32_t f0,
+                                                   const float *lds, uint32_t lw, SampleAcc &acc, int &bad,
+                                                   uint32_t &nan_atom, uint32_t &nan_frame) {
+        float P[G][6];
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+            const uint32_t sh = (uint32_t)((((size_t)(f0 + k) * a.n_atoms + t.atom0) * 3u) & 3u);
+            const float *w = lds + (size_t)k * lw + sh;
+            P[k][0] = w[3u * it.li]; P[k][1] = w[3u * it.li + 1]; P[k][2] = w[3u * it.li + 2];
+            P[k][3] = w[3u * it.lj]; P[k][4] = w[3u * it.lj + 1]; P[k][5] = w[3u * it.lj + 2];
+        }
+        compute_core(a, t, it, f0, P, acc, bad, nan_atom, nan_frame);
     }
     // partial last stage: frames f0 .. f_end-1, one at a time (not performance relevant)
     static __device__ __forceinline__ void compute_tail(const FrameArgs &a, const Tile &t, const Item &it,
@@ -269,8 +276,11 @@ struct TiledStage {
     }
 };
 
-template <int G, int NPF, bool ACOS_COS>
-__global__ __launch_bounds__(256) void k_bonds_tiled(FrameArgs a_in, const float *__restrict__ xyz,
+#ifndef GORDER_TILED_MIN_WAVES
+#define GORDER_TILED_MIN_WAVES 4   // waves per SIMD the register allocation must allow (8 => <= 64 VGPRs)
+#endif
+template <int G, int NPF, bool ACOS_COS, bool PBC, bool LEAF>
+__global__ __launch_bounds__(256, GORDER_TILED_MIN_WAVES) void k_bonds_tiled(FrameArgs a_in, const float *__restrict__ xyz,
                                                       const float *__restrict__ box9,
                                                       const uint8_t *__restrict__ aflags,
                                                       const uint32_t *__restrict__ arow,
@@ -279,7 +289,7 @@ __global__ __launch_bounds__(256) void k_bonds_tiled(FrameArgs a_in, const float
                                                       const uint32_t *__restrict__ tile_slots,
                                                       uint32_t n_tiles, uint32_t lw) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    using S = TiledStage<G, NPF, ACOS_COS>;
+    using S = TiledStage<G, NPF, ACOS_COS, PBC, LEAF>;
     // the read-only streams come in as __restrict__ kernel arguments so that the compiler can prove
     // that the accumulator / error stores never clobber them (uniform loads become scalar loads)
     FrameArgs a = a_in;
@@ -325,6 +335,97 @@ __global__ __launch_bounds__(256) void k_bonds_tiled(FrameArgs a_in, const float
     // per (slot, field).  Integer sums: the result does not depend on the order (order.rs:44-60).
     unsigned long long *l_s = reinterpret_cast<unsigned long long *>(lds);   // [2][256]
     uint32_t *l_n = reinterpret_cast<uint32_t *>(l_s + 2 * kBlock);          // [2][256]
+    l_s[tid] = 0; l_s[kBlock + tid] = 0; l_n[tid] = 0; l_n[kBlock + tid] = 0;
+    __syncthreads();
+    if (active && acc.n_tot) {
+        atomicAdd(&l_s[it.lslot], (unsigned long long)acc.s_tot);
+        atomicAdd(&l_n[it.lslot], acc.n_tot);
+        if (acc.n_up) {
+            atomicAdd(&l_s[kBlock + it.lslot], (unsigned long long)acc.s_up);
+            atomicAdd(&l_n[kBlock + it.lslot], acc.n_up);
+        }
+    }
+    __syncthreads();
+    if (tid < t.n_slots && l_n[tid]) {
+        const uint32_t slot = tile_slots[t.slot0 + tid];
+        atomicAdd(&a.acc[slot], l_s[tid]);
+        atomicAdd(&a.acc[2u * a.n_acc + slot], (unsigned long long)l_n[tid]);
+        if (l_n[kBlock + tid]) {
+            atomicAdd(&a.acc[a.n_acc + slot], l_s[kBlock + tid]);
+            atomicAdd(&a.acc[3u * a.n_acc + slot], (unsigned long long)l_n[kBlock + tid]);
+        }
+    }
+}
+
+// ---- K1g: same tiles, but every lane gathers its two atoms straight from global memory (through the
+// per-CU vector L1) instead of going through an LDS-staged window: no LDS traffic and no barriers in
+// the frame loop, waves run fully decoupled.  Each HBM byte is still fetched about once: the lanes
+// of a wave touch one contiguous ~1 KiB run of the frame and neighbouring waves share only its ends.
+// The loads of stage s+1 are issued before the arithmetic of stage s (2 x G x 6 registers).
+template <int G, bool ACOS_COS, bool PBC, bool LEAF>
+__global__ __launch_bounds__(256) void k_bonds_gather(FrameArgs a_in, const float *__restrict__ xyz,
+                                                       const float *__restrict__ box9,
+                                                       const uint8_t *__restrict__ aflags,
+                                                       const uint32_t *__restrict__ arow,
+                                                       const Tile *__restrict__ tiles,
+                                                       const Item *__restrict__ items,
+                                                       const uint32_t *__restrict__ tile_slots, uint32_t n_tiles) {
+    __shared__ unsigned long long l_s[2 * kBlock];
+    __shared__ uint32_t l_n[2 * kBlock];
+    using S = TiledStage<G, 1, ACOS_COS, PBC, LEAF>;
+    FrameArgs a = a_in;
+    a.xyz = xyz; a.box9 = box9; a.aflags = aflags; a.arow = arow;
+    const uint32_t tile_id = blockIdx.x % n_tiles;
+    const uint32_t chunk = blockIdx.x / n_tiles;
+    const Tile t = tiles[tile_id];
+    const uint32_t tid = threadIdx.x;
+    const bool active = tid < t.n_items;
+    Item it{0, 0, 0, 0, 0};
+    if (active) it = items[t.item0 + tid];
+    const uint32_t f_begin = chunk * a.frames_per_chunk;
+    const uint32_t f_end = min(a.n_frames, f_begin + a.frames_per_chunk);
+    const uint32_t f_full = f_begin + ((f_end - f_begin) / G) * G;
+    const size_t fstride = (size_t)a.n_atoms * 3u;
+    const float *pi = xyz + ((size_t)t.atom0 + it.li) * 3u;
+    const float *pj = xyz + ((size_t)t.atom0 + it.lj) * 3u;
+
+    SampleAcc acc;
+    int bad = 0;
+    uint32_t nan_atom = 0xffffffffu, nan_frame = 0;
+    float cur[G][6], nxt[G][6];
+    auto fetch = [&](float (&P)[G][6], uint32_t f0) {
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+            const float *q1 = pi + (size_t)(f0 + k) * fstride, *q2 = pj + (size_t)(f0 + k) * fstride;
+            P[k][0] = q1[0]; P[k][1] = q1[1]; P[k][2] = q1[2];
+            P[k][3] = q2[0]; P[k][4] = q2[1]; P[k][5] = q2[2];
+        }
+    };
+    if (active) {
+        if (f_begin < f_full) fetch(cur, f_begin);
+        for (uint32_t f0 = f_begin; f0 < f_full; f0 += G) {
+            const bool more = f0 + G < f_full;
+            if (more) fetch(nxt, f0 + G);
+            S::compute_core(a, t, it, f0, cur, acc, bad, nan_atom, nan_frame);
+            if (more) {
+#pragma unroll
+                for (int k = 0; k < G; k++)
+#pragma unroll
+                    for (int c = 0; c < 6; c++) cur[k][c] = nxt[k][c];
+            }
+        }
+        for (uint32_t f = f_full; f < f_end; f++) {
+            const float *q1 = pi + (size_t)f * fstride, *q2 = pj + (size_t)f * fstride;
+            const float p1x = q1[0], p1y = q1[1], p1z = q1[2], p2x = q2[0], p2y = q2[1], p2z = q2[2];
+            if (bond_sample<ACOS_COS>(a, f, p1x, p1y, p1z, p2x, p2y, p2z, it.mol, acc, bad)) {
+                if (p1x != p1x) { nan_atom = t.atom0 + it.li; nan_frame = f; }
+                else if (p2x != p2x) { nan_atom = t.atom0 + it.lj; nan_frame = f; }
+            }
+        }
+    }
+    if (nan_atom != 0xffffffffu) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, nan_atom, nan_frame);
+    if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f_begin);
+
     l_s[tid] = 0; l_s[kBlock + tid] = 0; l_n[tid] = 0; l_n[kBlock + tid] = 0;
     __syncthreads();
     if (active && acc.n_tot) {
@@ -544,6 +645,7 @@ struct gorder_hip_handle {
     size_t stage_xyz_cap = 0, stage_box_cap = 0;
     float n2 = 1.0f, n2sq = 1.0f;
     int frames_per_stage = kFramesPerStage;   // G (2, 4 or 8); GORDER_HIP_FRAMES_PER_STAGE overrides
+    bool use_gather = false;                   // GORDER_HIP_KERNEL=gather: L1-gather kernel instead of LDS staging
     uint32_t wg_capacity = 256u * 6u;          // co-resident workgroups of the tiled kernel on this device
     uint32_t wg_target = 0;                    // GORDER_HIP_WG_TARGET: force the workgroup count aimed at
     uint32_t lw = 0;
@@ -628,7 +730,7 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
         const uint32_t G = (uint32_t)h->frames_per_stage;
         const uint32_t n_stages = (a.n_frames + G - 1) / G;
         uint32_t target = h->wg_target ? h->wg_target : h->wg_capacity;
-        if (!h->wg_target && n_tiles > h->wg_capacity / 2) target = 12u * h->wg_capacity;
+        if (!h->wg_target) target = 12u * h->wg_capacity;   // measured: ~8-12 short rounds beat one long round
         uint32_t n_chunks = std::max(1u, target / n_tiles);
         n_chunks = std::min(n_chunks, std::max(1u, n_stages / 4u));   // >= 4 stages per workgroup
         uint32_t fpc = ((n_stages + n_chunks - 1) / n_chunks) * G;
@@ -638,20 +740,55 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
         if (grid > 0x7fffffffull) return fail(h, GORDER_ERR_INVALID_ARGUMENT, "batch too large");
         const bool ac = (h->tables.flags & GORDER_FLAG_TRIG_ACOS_COS) != 0;
         const dim3 g((uint32_t)grid), b(kBlock);
+#define GORDER_LAUNCH_TILED_V(G_, NPF_, AC_, PBC_, LF_)                                                    \
+        hipLaunchKernelGGL((k_bonds_tiled<G_, NPF_, AC_, PBC_, LF_>), g, b, h->lds_bytes, h->stream, a, a.xyz,   \
+                           a.box9, a.aflags, a.arow, h->d_tiles, h->d_items, h->d_tile_slots, n_tiles, h->lw)
 #define GORDER_LAUNCH_TILED(G_, NPF_)                                                                       \
         do {                                                                                                \
-            if (ac) hipLaunchKernelGGL((k_bonds_tiled<G_, NPF_, true>), g, b, h->lds_bytes, h->stream, a,       \
-                                       a.xyz, a.box9, a.aflags, a.arow, h->d_tiles, h->d_items,             \
-                                       h->d_tile_slots, n_tiles, h->lw);                                    \
-            else hipLaunchKernelGGL((k_bonds_tiled<G_, NPF_, false>), g, b, h->lds_bytes, h->stream, a,         \
-                                    a.xyz, a.box9, a.aflags, a.arow, h->d_tiles, h->d_items,                \
-                                    h->d_tile_slots, n_tiles, h->lw);                                       \
+            const int v_ = (ac ? 4 : 0) | (a.pbc ? 2 : 0) | (a.leaflets ? 1 : 0);                           \
+            switch (v_) {                                                                                   \
+                case 0: GORDER_LAUNCH_TILED_V(G_, NPF_, false, false, false); break;                        \
+                case 1: GORDER_LAUNCH_TILED_V(G_, NPF_, false, false, true); break;                         \
+                case 2: GORDER_LAUNCH_TILED_V(G_, NPF_, false, true, false); break;                         \
+                case 3: GORDER_LAUNCH_TILED_V(G_, NPF_, false, true, true); break;                          \
+                case 4: GORDER_LAUNCH_TILED_V(G_, NPF_, true, false, false); break;                         \
+                case 5: GORDER_LAUNCH_TILED_V(G_, NPF_, true, false, true); break;                          \
+                case 6: GORDER_LAUNCH_TILED_V(G_, NPF_, true, true, false); break;                          \
+                default: GORDER_LAUNCH_TILED_V(G_, NPF_, true, true, true); break;                          \
+            }                                                                                               \
         } while (0)
-        switch (h->frames_per_stage) {
-            case 2: GORDER_LAUNCH_TILED(2, 3); break;
-            case 8: GORDER_LAUNCH_TILED(8, 10); break;
-            default: GORDER_LAUNCH_TILED(4, 5); break;
+#define GORDER_LAUNCH_GATHER_V(G_, AC_, PBC_, LF_)                                                         \
+        hipLaunchKernelGGL((k_bonds_gather<G_, AC_, PBC_, LF_>), g, b, 0, h->stream, a, a.xyz, a.box9, a.aflags, \
+                           a.arow, h->d_tiles, h->d_items, h->d_tile_slots, n_tiles)
+#define GORDER_LAUNCH_GATHER(G_)                                                                            \
+        do {                                                                                                \
+            const int v_ = (ac ? 4 : 0) | (a.pbc ? 2 : 0) | (a.leaflets ? 1 : 0);                           \
+            switch (v_) {                                                                                   \
+                case 0: GORDER_LAUNCH_GATHER_V(G_, false, false, false); break;                             \
+                case 1: GORDER_LAUNCH_GATHER_V(G_, false, false, true); break;                              \
+                case 2: GORDER_LAUNCH_GATHER_V(G_, false, true, false); break;                              \
+                case 3: GORDER_LAUNCH_GATHER_V(G_, false, true, true); break;                               \
+                case 4: GORDER_LAUNCH_GATHER_V(G_, true, false, false); break;                              \
+                case 5: GORDER_LAUNCH_GATHER_V(G_, true, false, true); break;                               \
+                case 6: GORDER_LAUNCH_GATHER_V(G_, true, true, false); break;                               \
+                default: GORDER_LAUNCH_GATHER_V(G_, true, true, true); break;                               \
+            }                                                                                               \
+        } while (0)
+        if (h->use_gather) {
+            switch (h->frames_per_stage) {
+                case 2: GORDER_LAUNCH_GATHER(2); break;
+                default: GORDER_LAUNCH_GATHER(4); break;
+            }
+        } else {
+            switch (h->frames_per_stage) {
+                case 2: GORDER_LAUNCH_TILED(2, 3); break;
+                case 8: GORDER_LAUNCH_TILED(8, 10); break;
+                default: GORDER_LAUNCH_TILED(4, 5); break;
+            }
         }
+#undef GORDER_LAUNCH_GATHER
+#undef GORDER_LAUNCH_GATHER_V
+#undef GORDER_LAUNCH_TILED_V
 #undef GORDER_LAUNCH_TILED
         HIP_TRY(h, hipGetLastError());
     }
@@ -765,6 +902,7 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
         const int g = atoi(e);
         if (g == 2 || g == 4 || g == 8) h->frames_per_stage = g;
     }
+    if (const char *e = getenv("GORDER_HIP_KERNEL")) h->use_gather = strcmp(e, "gather") == 0;
     if (const char *e = getenv("GORDER_HIP_WG_TARGET")) {
         const int w = atoi(e);
         if (w > 0) h->wg_target = (uint32_t)w;
@@ -779,12 +917,12 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
         const bool ac = (t->flags & GORDER_FLAG_TRIG_ACOS_COS) != 0;
         hipError_t e;
         switch (h->frames_per_stage) {
-            case 2: e = ac ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bonds_tiled<2, 3, true>, kBlock, h->lds_bytes)
-                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bonds_tiled<2, 3, false>, kBlock, h->lds_bytes); break;
-            case 8: e = ac ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bonds_tiled<8, 10, true>, kBlock, h->lds_bytes)
-                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bonds_tiled<8, 10, false>, kBlock, h->lds_bytes); break;
-            default: e = ac ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bonds_tiled<4, 5, true>, kBlock, h->lds_bytes)
-                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bonds_tiled<4, 5, false>, kBlock, h->lds_bytes); break;
+            case 2: e = ac ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bonds_tiled<2, 3, true, true, false>, kBlock, h->lds_bytes)
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bonds_tiled<2, 3, false, true, false>, kBlock, h->lds_bytes); break;
+            case 8: e = ac ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bonds_tiled<8, 10, true, true, false>, kBlock, h->lds_bytes)
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bonds_tiled<8, 10, false, true, false>, kBlock, h->lds_bytes); break;
+            default: e = ac ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bonds_tiled<4, 5, true, true, false>, kBlock, h->lds_bytes)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bonds_tiled<4, 5, false, true, false>, kBlock, h->lds_bytes); break;
         }
         if (e != hipSuccess || per_cu < 1) per_cu = 4;
         h->wg_capacity = (uint32_t)n_cu * (uint32_t)per_cu;
