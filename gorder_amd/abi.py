@@ -450,6 +450,10 @@ class HipEngine:
         self._check(self.lib.gorder_hip_accumulators_device(self._h, C.byref(p), C.byref(n)))
         return int(n.value)
 
+    def flush(self):
+        """Make the packed accumulator block complete (stream-ordered) — call before a collective on it."""
+        self.accumulator_words()
+
     def bind_accumulators(self, tensor):
         """Accumulate into a caller-owned torch.int64 CUDA tensor (so that torch.distributed can
         all-reduce it over RCCL)."""

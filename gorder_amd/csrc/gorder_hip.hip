@@ -55,6 +55,8 @@ struct FrameArgs {
     const uint32_t *arow;    // [n_frames] assignment row of each frame
     uint32_t n_mol_total;
     unsigned long long *acc; // [4][n_acc]: sum_total, sum_upper, cnt_total, cnt_upper
+    unsigned long long *rep; // [n_rep][4][n_acc] replicas the tiled kernels add into (folded into acc later)
+    uint32_t n_rep;
     uint32_t n_acc;
     uint32_t *err;
 };
@@ -85,6 +87,18 @@ __global__ void k_check_box(const float *__restrict__ box9, uint32_t n_frames, u
 // total_frames (topology/mod.rs:141-144) lives in the last word of the accumulator block so that a
 // multi-GPU all-reduce sums it together with the order sums (topology/mod.rs:243)
 __global__ void k_count_frames(unsigned long long *word, uint32_t n_frames) { atomicAdd(word, (unsigned long long)n_frames); }
+
+// acc[i] += sum_r rep[r][i]; rep := 0   (i < 4 * n_acc)
+__global__ void k_fold_replicas(unsigned long long *acc, unsigned long long *rep, uint32_t n_rep, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long s = 0;
+    for (uint32_t r = 0; r < n_rep; r++) {
+        s += rep[(size_t)r * n + i];
+        rep[(size_t)r * n + i] = 0;
+    }
+    acc[i] += s;
+}
 
 // ---- one bond sample (bond.rs:407-443) -----------------------------------------------------
 struct SampleAcc {
@@ -142,7 +156,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));   // native 16-byte vecto
 
 template <int G, int NPF, bool ACOS_COS, bool PBC, bool LEAF>
 struct TiledStage {
-    static constexpr uint32_t TPF = 256 / G;   // threads that stage one frame
+    static constexpr uint32_t TPF = kBlock / G;   // threads that stage one frame
 
     // issue the loads of my frame slot of the stage that starts at frame f0
     template <bool TAIL>
@@ -280,7 +294,7 @@ struct TiledStage {
 #define GORDER_TILED_MIN_WAVES 4   // waves per SIMD the register allocation must allow (8 => <= 64 VGPRs)
 #endif
 template <int G, int NPF, bool ACOS_COS, bool PBC, bool LEAF>
-__global__ __launch_bounds__(256, GORDER_TILED_MIN_WAVES) void k_bonds_tiled(FrameArgs a_in, const float *__restrict__ xyz,
+__global__ __launch_bounds__(kBlock, GORDER_TILED_MIN_WAVES) void k_bonds_tiled(FrameArgs a_in, const float *__restrict__ xyz,
                                                       const float *__restrict__ box9,
                                                       const uint8_t *__restrict__ aflags,
                                                       const uint32_t *__restrict__ arow,
@@ -346,13 +360,19 @@ __global__ __launch_bounds__(256, GORDER_TILED_MIN_WAVES) void k_bonds_tiled(Fra
         }
     }
     __syncthreads();
+#ifdef GORDER_DEBUG_NOEPILOGUE   // timing experiment only
+    if (a.n_frames == 0xffffffffu)
+#endif
     if (tid < t.n_slots && l_n[tid]) {
+        // spread the blocks over n_rep replicas of the accumulator block: same-address atomics of
+        // thousands of blocks would otherwise serialise in L2
+        unsigned long long *acc = a.rep + (size_t)(blockIdx.x % a.n_rep) * 4u * a.n_acc;
         const uint32_t slot = tile_slots[t.slot0 + tid];
-        atomicAdd(&a.acc[slot], l_s[tid]);
-        atomicAdd(&a.acc[2u * a.n_acc + slot], (unsigned long long)l_n[tid]);
+        atomicAdd(&acc[slot], l_s[tid]);
+        atomicAdd(&acc[2u * a.n_acc + slot], (unsigned long long)l_n[tid]);
         if (l_n[kBlock + tid]) {
-            atomicAdd(&a.acc[a.n_acc + slot], l_s[kBlock + tid]);
-            atomicAdd(&a.acc[3u * a.n_acc + slot], (unsigned long long)l_n[kBlock + tid]);
+            atomicAdd(&acc[a.n_acc + slot], l_s[kBlock + tid]);
+            atomicAdd(&acc[3u * a.n_acc + slot], (unsigned long long)l_n[kBlock + tid]);
         }
     }
 }
@@ -363,7 +383,7 @@ __global__ __launch_bounds__(256, GORDER_TILED_MIN_WAVES) void k_bonds_tiled(Fra
 // of a wave touch one contiguous ~1 KiB run of the frame and neighbouring waves share only its ends.
 // The loads of stage s+1 are issued before the arithmetic of stage s (2 x G x 6 registers).
 template <int G, bool ACOS_COS, bool PBC, bool LEAF>
-__global__ __launch_bounds__(256) void k_bonds_gather(FrameArgs a_in, const float *__restrict__ xyz,
+__global__ __launch_bounds__(kBlock) void k_bonds_gather(FrameArgs a_in, const float *__restrict__ xyz,
                                                        const float *__restrict__ box9,
                                                        const uint8_t *__restrict__ aflags,
                                                        const uint32_t *__restrict__ arow,
@@ -437,13 +457,19 @@ __global__ __launch_bounds__(256) void k_bonds_gather(FrameArgs a_in, const floa
         }
     }
     __syncthreads();
+#ifdef GORDER_DEBUG_NOEPILOGUE   // timing experiment only
+    if (a.n_frames == 0xffffffffu)
+#endif
     if (tid < t.n_slots && l_n[tid]) {
+        // spread the blocks over n_rep replicas of the accumulator block: same-address atomics of
+        // thousands of blocks would otherwise serialise in L2
+        unsigned long long *acc = a.rep + (size_t)(blockIdx.x % a.n_rep) * 4u * a.n_acc;
         const uint32_t slot = tile_slots[t.slot0 + tid];
-        atomicAdd(&a.acc[slot], l_s[tid]);
-        atomicAdd(&a.acc[2u * a.n_acc + slot], (unsigned long long)l_n[tid]);
+        atomicAdd(&acc[slot], l_s[tid]);
+        atomicAdd(&acc[2u * a.n_acc + slot], (unsigned long long)l_n[tid]);
         if (l_n[kBlock + tid]) {
-            atomicAdd(&a.acc[a.n_acc + slot], l_s[kBlock + tid]);
-            atomicAdd(&a.acc[3u * a.n_acc + slot], (unsigned long long)l_n[kBlock + tid]);
+            atomicAdd(&acc[a.n_acc + slot], l_s[kBlock + tid]);
+            atomicAdd(&acc[3u * a.n_acc + slot], (unsigned long long)l_n[kBlock + tid]);
         }
     }
 }
@@ -629,6 +655,9 @@ struct gorder_hip_handle {
     DirectItem *d_direct = nullptr;
     uint32_t *d_err = nullptr;
     unsigned long long *d_acc = nullptr;   // [4][n_acc] + total_frames
+    unsigned long long *d_rep = nullptr;   // [n_rep][4][n_acc] (see k_fold_replicas)
+    uint32_t n_rep = 32;
+    bool rep_dirty = false;
     bool acc_external = false;
     size_t acc_words = 0;
     // leaflets
@@ -715,6 +744,16 @@ bool env_flag(const char *name) {
 }
 
 // Launch the order kernels of one batch (internal).
+// fold the replicas into the accumulator block (stream-ordered; cheap: 4 * n_acc threads)
+int fold_replicas(gorder_hip_handle *h) {
+    if (!h->rep_dirty || !h->d_rep) return GORDER_OK;
+    const uint32_t n = 4u * h->plan.n_acc;
+    hipLaunchKernelGGL(k_fold_replicas, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_acc, h->d_rep, h->n_rep, n);
+    HIP_TRY(h, hipGetLastError());
+    h->rep_dirty = false;
+    return GORDER_OK;
+}
+
 int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
     const Plan &p = h->plan;
     const uint32_t n_tiles = (uint32_t)p.tiles.size();
@@ -893,6 +932,15 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
     h->acc_words = 4 * (size_t)p.n_acc + 1;
     HIP_TRY(h, hipMalloc((void **)&h->d_acc, h->acc_words * sizeof(unsigned long long)));
     HIP_TRY(h, hipMemset(h->d_acc, 0, h->acc_words * sizeof(unsigned long long)));
+    if (const char *e = getenv("GORDER_HIP_REPLICAS")) {
+        const int r = atoi(e);
+        if (r >= 1 && r <= 1024) h->n_rep = (uint32_t)r;
+    }
+    if (p.n_acc) {
+        const size_t rep_bytes = (size_t)h->n_rep * 4u * p.n_acc * sizeof(unsigned long long);
+        HIP_TRY(h, hipMalloc((void **)&h->d_rep, rep_bytes));
+        HIP_TRY(h, hipMemset(h->d_rep, 0, rep_bytes));
+    }
     {   // |normal| with the f32 sequence of nalgebra's norm (oracle: norm3)
         const float *n = t->normal;
         h->n2sq = (n[0] * n[0] + n[1] * n[1]) + n[2] * n[2];
@@ -975,6 +1023,7 @@ void gorder_hip_destroy(gorder_hip_handle *h) {
     (void)hipFree(h->d_tiles); (void)hipFree(h->d_items); (void)hipFree(h->d_tile_slots);
     (void)hipFree(h->d_direct); (void)hipFree(h->d_err);
     if (!h->acc_external) (void)hipFree(h->d_acc);
+    (void)hipFree(h->d_rep);
     (void)hipFree(h->d_heads); (void)hipFree(h->d_membrane); (void)hipFree(h->d_methyl_begin);
     (void)hipFree(h->d_methyl_atoms); (void)hipFree(h->d_aflags); (void)hipFree(h->d_adist);
     (void)hipFree(h->d_arow); (void)hipFree(h->d_aframes);
@@ -1108,8 +1157,9 @@ int gorder_hip_submit_device(gorder_hip_handle *h, const float *d_xyz, const flo
     a.pbc = pbc ? 1 : 0;
     a.nx = h->tables.normal[0]; a.ny = h->tables.normal[1]; a.nz = h->tables.normal[2]; a.n2 = h->n2; a.n2sq = h->n2sq;
     a.leaflets = leaflets ? 1 : 0; a.aflags = h->d_aflags; a.arow = h->d_arow; a.n_mol_total = p.n_mol_total;
-    a.acc = h->d_acc; a.n_acc = p.n_acc; a.err = h->d_err;
+    a.acc = h->d_acc; a.rep = h->d_rep; a.n_rep = h->n_rep; a.n_acc = p.n_acc; a.err = h->d_err;
     if ((st = launch_orders(h, a)) != GORDER_OK) return st;
+    h->rep_dirty = true;
     if (n_new_rows) {   // newest assignment becomes the carry row of the next batch
         HIP_TRY(h, hipMemcpyAsync(h->d_aflags, h->d_aflags + n_new_rows * (size_t)p.n_mol_total, p.n_mol_total,
                                   hipMemcpyDeviceToDevice, h->stream));
@@ -1185,7 +1235,9 @@ int gorder_hip_finish(gorder_hip_handle *h, int64_t *sums, uint64_t *counts, int
                       uint64_t *map_counts, uint64_t *n_frames_analyzed) {
     if (!h) return GORDER_ERR_INVALID_ARGUMENT;
     (void)map_sums; (void)map_counts;
-    const int st = gorder_hip_synchronize(h);
+    int st = fold_replicas(h);
+    if (st != GORDER_OK) return st;
+    st = gorder_hip_synchronize(h);
     if (st != GORDER_OK) return st;
     const uint32_t n = h->plan.n_acc;
     std::vector<unsigned long long> raw(4 * (size_t)n + 1);
@@ -1231,6 +1283,10 @@ int gorder_hip_leaflet_distances(gorder_hip_handle *h, float *dist) {
 
 int gorder_hip_accumulators_device(gorder_hip_handle *h, void **d_ptr, uint64_t *n_u64) {
     if (!h || !d_ptr || !n_u64) return GORDER_ERR_INVALID_ARGUMENT;
+    {   // the packed block must be complete before a collective reads it (stream-ordered)
+        const int st = fold_replicas(h);
+        if (st != GORDER_OK) return st;
+    }
     *d_ptr = h->d_acc;
     *n_u64 = h->acc_words;
     return GORDER_OK;
@@ -1239,6 +1295,10 @@ int gorder_hip_accumulators_device(gorder_hip_handle *h, void **d_ptr, uint64_t 
 int gorder_hip_bind_accumulators(gorder_hip_handle *h, void *d_ptr, uint64_t n_u64) {
     if (!h || !d_ptr || n_u64 < h->acc_words || ((uintptr_t)d_ptr & 7u)) return GORDER_ERR_INVALID_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->device));
+    {
+        const int st = fold_replicas(h);
+        if (st != GORDER_OK) return st;
+    }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipMemcpy(d_ptr, h->d_acc, h->acc_words * sizeof(unsigned long long), hipMemcpyDeviceToDevice));
     if (!h->acc_external) HIP_TRY(h, hipFree(h->d_acc));

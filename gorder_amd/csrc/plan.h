@@ -17,7 +17,10 @@
 
 namespace gorder {
 
-constexpr uint32_t kBlock = 256;        // threads per workgroup = samples per tile
+#ifndef GORDER_BLOCK
+#define GORDER_BLOCK 256
+#endif
+constexpr uint32_t kBlock = GORDER_BLOCK;   // threads per workgroup = samples per tile (64 or 256)
 constexpr uint32_t kMaxWindow = 1024;   // atoms per LDS window (12 KiB per staged frame)
 
 struct Item {            // one AA/CG bond sample of a tile (12 bytes)

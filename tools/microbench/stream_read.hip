@@ -72,5 +72,30 @@ int main() {
         snprintf(nm, 96, "tiles G=1, %u WGs", n_tiles * nch);
         time(nm, [&] { hipLaunchKernelGGL((k_tiles<1, false>), dim3(n_tiles * nch), dim3(256), 0, 0, d, n_tiles, win4, frame_floats / 4, (uint32_t)n_frames, fpc, out); });
     }
+    {   // CG-1M shape: 1 000 008 atoms/frame (12 MB), 3581 tiles of ~3.4 KB, 250 frames
+        const size_t ff = 1000008ull * 3; const uint32_t nf = 250, nt = 3581, w4 = (uint32_t)(ff / 4 / nt);
+        const size_t by = ff * 4 * nf;
+        printf("CG-1M shape: %u tiles x %u float4, frame stride %.1f MB, %.2f GB\n", nt, w4, ff * 4 / 1e6, by / 1e9);
+        for (uint32_t chunks : {1u, 3u, 10u}) {
+            uint32_t fpc = (nf + chunks - 1) / chunks; fpc = (fpc + 3) / 4 * 4; uint32_t nch = (nf + fpc - 1) / fpc;
+            hipLaunchKernelGGL((k_tiles<4, true>), dim3(nt * nch), dim3(256), 0, 0, d, nt, w4, ff / 4, nf, fpc, out); CK(hipDeviceSynchronize());
+            float best = 1e9;
+            for (int r = 0; r < 5; r++) { CK(hipEventRecord(e0));
+                hipLaunchKernelGGL((k_tiles<4, true>), dim3(nt * nch), dim3(256), 0, 0, d, nt, w4, ff / 4, nf, fpc, out);
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms; }
+            printf("  tiles G=4 nt, %u WGs: %.4f ms %.0f GB/s\n", nt * nch, best, (double)nt * w4 * 16 * nf / (best * 1e-3) / 1e9);
+        }
+        // wider tiles: 4 adjacent tiles per WG pass (13.6 KB contiguous per frame)
+        for (uint32_t chunks : {3u, 10u}) {
+            const uint32_t nt4 = nt / 4, w44 = w4 * 4;
+            uint32_t fpc = (nf + chunks - 1) / chunks; fpc = (fpc + 3) / 4 * 4; uint32_t nch = (nf + fpc - 1) / fpc;
+            hipLaunchKernelGGL((k_tiles<4, true>), dim3(nt4 * nch), dim3(256), 0, 0, d, nt4, w44, ff / 4, nf, fpc, out); CK(hipDeviceSynchronize());
+            float best = 1e9;
+            for (int r = 0; r < 5; r++) { CK(hipEventRecord(e0));
+                hipLaunchKernelGGL((k_tiles<4, true>), dim3(nt4 * nch), dim3(256), 0, 0, d, nt4, w44, ff / 4, nf, fpc, out);
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms; }
+            printf("  4x wider tiles, %u WGs: %.4f ms %.0f GB/s\n", nt4 * nch, best, (double)nt4 * w44 * 16 * nf / (best * 1e-3) / 1e9);
+        }
+    }
     return 0;
 }

@@ -12,11 +12,15 @@ system, name = bench.make_system(wl)
 system.tables.flags = 1 if os.environ.get("QB_ACOS") else 0
 d_xyz, d_box = system.frames_device(frames, seed=1)
 eng = HipEngine(system.tables); eng.use_torch_stream()
-for _ in range(2): eng.submit_device(d_xyz, d_box)
+for _ in range(3): eng.submit_device(d_xyz, d_box)
 eng.synchronize(); eng.kernel_time(reset=True)
-for _ in range(reps): eng.submit_device(d_xyz, d_box)
-eng.synchronize()
-ms, n = eng.kernel_time()
-b = system.bytes_per_frame * frames
-print(f"{wl} frames={frames} plan={eng.plan()} env={ {k:v for k,v in os.environ.items() if k.startswith('GORDER')} }")
-print(f"  avg launch {ms/n:.4f} ms  -> {b/(ms/n*1e-3)/1e9:.1f} GB/s  ({b/(ms/n*1e-3)/8e12*100:.1f}% of 8 TB/s)  {frames/(ms/n*1e-3)/1e6:.2f} Mframes/s")
+ts = []
+for _ in range(reps):
+    eng.submit_device(d_xyz, d_box); eng.synchronize()
+    ms, n = eng.kernel_time(reset=True); ts.append(ms)
+ts = np.array(ts); b = system.bytes_per_frame * frames
+env = {k: v for k, v in os.environ.items() if k.startswith('GORDER') or k.startswith('QB')}
+print(f"{wl} frames={frames} plan={eng.plan()} env={env}")
+f = lambda ms: f"{ms:.4f} ms {b/(ms*1e-3)/1e9:.0f} GB/s {b/(ms*1e-3)/8e12*100:.1f}%"
+print("  per-launch ms:", " ".join(f"{t:.3f}" for t in ts))
+print(f"  min {f(ts.min())} | median {f(np.median(ts))} | max {f(ts.max())}  ({frames/(np.median(ts)*1e-3)/1e6:.2f} Mframes/s)")
