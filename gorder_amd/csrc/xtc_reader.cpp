@@ -1,0 +1,363 @@
+// xtc_reader.cpp — host-side GROMACS XTC reader (include/gorder_xtc.h).  Pure C++17, no HIP.
+//
+// Wire format (published GROMACS "xtc" / xdr3dcoord): big-endian XDR.  Per frame:
+//   int32 magic = 1995, int32 natoms, int32 step, float32 time, float32 box[3][3],
+//   int32 natoms; if natoms <= 9: natoms*3 raw float32.  Otherwise:
+//   float32 precision, int32 minint[3], int32 maxint[3], int32 smallidx, int32 nbytes,
+//   nbytes of bit stream (padded to a multiple of 4).
+// The bit stream packs each atom's three integers (coordinate * precision, offset by minint) either
+// in full width or, for runs of neighbouring atoms, as small differences in a mixed-radix number
+// whose radix comes from the `magicints` table.
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/gorder_xtc.h"
+
+namespace {
+
+const int kMagicInts[] = {
+    0,       0,       0,       0,       0,       0,       0,       0,       0,       8,        10,       12,
+    16,      20,      25,      32,      40,      50,      64,      80,      101,     128,      161,      203,
+    256,     322,     406,     512,     645,     812,     1024,    1290,    1625,    2048,     2580,     3250,
+    4096,    5060,    6501,    8192,    10321,   13003,   16384,   20642,   26007,   32768,    41285,    52015,
+    65536,   82570,   104031,  131072,  165140,  208063,  262144,  330280,  416127,  524287,   660561,   832255,
+    1048576, 1321122, 1664510, 2097152, 2642245, 3329021, 4194304, 5284491, 6658042, 8388607,  10568983, 13316085,
+    16777216};
+constexpr int kFirstIdx = 9;
+constexpr int kLastIdx = (int)(sizeof(kMagicInts) / sizeof(kMagicInts[0]));
+
+struct BitReader {
+    const uint8_t *p;
+    size_t n, pos = 0;        // byte position
+    uint32_t lastbits = 0;    // bits left over in lastbyte
+    uint32_t lastbyte = 0;
+    bool overrun = false;
+
+    uint32_t bits(int nbits) {
+        const uint32_t mask = nbits >= 32 ? 0xffffffffu : ((1u << nbits) - 1u);
+        uint32_t num = 0;
+        while (nbits >= 8) {
+            lastbyte = (lastbyte << 8) | next();
+            num |= (lastbyte >> lastbits) << (nbits - 8);
+            nbits -= 8;
+        }
+        if (nbits > 0) {
+            if ((int)lastbits < nbits) {
+                lastbits += 8;
+                lastbyte = (lastbyte << 8) | next();
+            }
+            lastbits -= (uint32_t)nbits;
+            num |= (lastbyte >> lastbits) & ((1u << nbits) - 1u);
+        }
+        return num & mask;
+    }
+    uint32_t next() {
+        if (pos >= n) { overrun = true; return 0; }
+        return p[pos++];
+    }
+    // three integers packed as one mixed-radix number of `nbits` bits with radices sizes[0..2]
+    void ints(int nbits, const uint32_t sizes[3], int out[3]) {
+        uint32_t bytes[32];
+        bytes[1] = bytes[2] = bytes[3] = 0;
+        int nbytes = 0;
+        while (nbits > 8) {
+            bytes[nbytes++] = bits(8);
+            nbits -= 8;
+        }
+        if (nbits > 0) bytes[nbytes++] = bits(nbits);
+        for (int i = 2; i > 0; i--) {
+            uint32_t num = 0;
+            for (int j = nbytes - 1; j >= 0; j--) {
+                num = (num << 8) | bytes[j];
+                const uint32_t q = num / sizes[i];
+                bytes[j] = q;
+                num -= q * sizes[i];
+            }
+            out[i] = (int)num;
+        }
+        out[0] = (int)(bytes[0] | (bytes[1] << 8) | (bytes[2] << 16) | (bytes[3] << 24));
+    }
+};
+
+int size_of_int(uint32_t size) {
+    uint32_t num = 1;
+    int nbits = 0;
+    while (size >= num && nbits < 32) {
+        nbits++;
+        num <<= 1;
+    }
+    return nbits;
+}
+
+int size_of_ints(const uint32_t sizes[3]) {
+    uint32_t bytes[32];
+    int nbytes = 1;
+    bytes[0] = 1;
+    for (int i = 0; i < 3; i++) {
+        uint32_t tmp = 0;
+        int b = 0;
+        for (; b < nbytes; b++) {
+            tmp = bytes[b] * sizes[i] + tmp;
+            bytes[b] = tmp & 0xff;
+            tmp >>= 8;
+        }
+        while (tmp != 0) {
+            bytes[b++] = tmp & 0xff;
+            tmp >>= 8;
+        }
+        nbytes = b;
+    }
+    uint32_t num = 1;
+    nbytes--;
+    int nbits = 0;
+    while (bytes[nbytes] >= num) {
+        nbits++;
+        num *= 2;
+    }
+    return nbits + nbytes * 8;
+}
+
+uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+float bef(const uint8_t *p) {
+    const uint32_t u = be32(p);
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+}  // namespace
+
+struct gorder_xtc_reader {
+    FILE *fp = nullptr;
+    uint32_t natoms = 0;
+    std::vector<uint32_t> group;      // atoms to convert (empty = all)
+    std::vector<int32_t> slot_of;     // atom -> output slot or -1 (only when group given)
+    std::vector<uint8_t> buf;
+    std::vector<int> ints;            // decoded integer coordinates of one frame
+};
+
+namespace {
+
+bool read_exact(FILE *fp, void *dst, size_t n) { return fread(dst, 1, n, fp) == n; }
+
+// Decode the compressed block into integer coordinates for all atoms.
+int decode_ints(gorder_xtc_reader *r, const int minint[3], const int maxint[3], int smallidx, const uint8_t *data,
+                size_t nbytes) {
+    const uint32_t natoms = r->natoms;
+    r->ints.resize((size_t)natoms * 3);
+    uint32_t sizeint[3];
+    int bitsizeint[3] = {0, 0, 0};
+    for (int k = 0; k < 3; k++) {
+        const int64_t s = (int64_t)maxint[k] - (int64_t)minint[k] + 1;
+        if (s <= 0 || s > 0xffffffffll) return GORDER_XTC_ERR_FORMAT;
+        sizeint[k] = (uint32_t)s;
+    }
+    int bitsize;
+    if ((sizeint[0] | sizeint[1] | sizeint[2]) > 0xffffff) {
+        for (int k = 0; k < 3; k++) bitsizeint[k] = size_of_int(sizeint[k]);
+        bitsize = 0;
+    } else {
+        bitsize = size_of_ints(sizeint);
+    }
+    if (smallidx < kFirstIdx || smallidx >= kLastIdx) return GORDER_XTC_ERR_FORMAT;
+    int smaller = kMagicInts[smallidx > kFirstIdx ? smallidx - 1 : kFirstIdx] / 2;
+    int smallnum = kMagicInts[smallidx] / 2;
+    uint32_t sizesmall[3] = {(uint32_t)kMagicInts[smallidx], (uint32_t)kMagicInts[smallidx], (uint32_t)kMagicInts[smallidx]};
+
+    BitReader br{data, nbytes};
+    int *out = r->ints.data();
+    uint32_t i = 0;
+    int run = 0;
+    while (i < natoms) {
+        int cur[3];
+        if (bitsize == 0) {
+            for (int k = 0; k < 3; k++) cur[k] = (int)br.bits(bitsizeint[k]);
+        } else {
+            br.ints(bitsize, sizeint, cur);
+        }
+        i++;
+        for (int k = 0; k < 3; k++) cur[k] += minint[k];
+        int prev[3] = {cur[0], cur[1], cur[2]};
+        const uint32_t flag = br.bits(1);
+        int is_smaller = 0;
+        if (flag == 1) {
+            run = (int)br.bits(5);
+            is_smaller = run % 3;
+            run -= is_smaller;
+            is_smaller--;
+        }
+        if (run > 0) {
+            if (i + (uint32_t)(run / 3) > natoms) return GORDER_XTC_ERR_FORMAT;
+            for (int k = 0; k < run; k += 3) {
+                int d[3];
+                br.ints(smallidx, sizesmall, d);
+                i++;
+                for (int c = 0; c < 3; c++) cur[c] = d[c] + prev[c] - smallnum;
+                if (k == 0) {
+                    // the first atom of a run is stored AFTER the second one (water: O after H)
+                    for (int c = 0; c < 3; c++) { const int t = cur[c]; cur[c] = prev[c]; prev[c] = t; }
+                    out[0] = prev[0]; out[1] = prev[1]; out[2] = prev[2];
+                    out += 3;
+                } else {
+                    prev[0] = cur[0]; prev[1] = cur[1]; prev[2] = cur[2];
+                }
+                out[0] = cur[0]; out[1] = cur[1]; out[2] = cur[2];
+                out += 3;
+            }
+        } else {
+            out[0] = cur[0]; out[1] = cur[1]; out[2] = cur[2];
+            out += 3;
+        }
+        smallidx += is_smaller;
+        if (smallidx < kFirstIdx || smallidx >= kLastIdx) return GORDER_XTC_ERR_FORMAT;
+        if (is_smaller < 0) {
+            smallnum = smaller;
+            smaller = smallidx > kFirstIdx ? kMagicInts[smallidx - 1] / 2 : 0;
+        } else if (is_smaller > 0) {
+            smaller = smallnum;
+            smallnum = kMagicInts[smallidx] / 2;
+        }
+        sizesmall[0] = sizesmall[1] = sizesmall[2] = (uint32_t)kMagicInts[smallidx];
+        if (br.overrun) return GORDER_XTC_ERR_FORMAT;
+    }
+    return GORDER_XTC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gorder_xtc_open(const char *path, const uint32_t *group, uint32_t n_group, gorder_xtc_reader **out) {
+    if (!path || !out) return GORDER_XTC_ERR_ARGUMENT;
+    *out = nullptr;
+    FILE *fp = fopen(path, "rb");
+    if (!fp) return GORDER_XTC_ERR_OPEN;
+    uint8_t head[8];
+    if (!read_exact(fp, head, 8) || be32(head) != 1995u) {
+        fclose(fp);
+        return GORDER_XTC_ERR_FORMAT;
+    }
+    gorder_xtc_reader *r = new gorder_xtc_reader();
+    r->fp = fp;
+    r->natoms = be32(head + 4);
+    fseek(fp, 0, SEEK_SET);
+    if (group && n_group) {
+        r->group.assign(group, group + n_group);
+        r->slot_of.assign(r->natoms, -1);
+        for (uint32_t k = 0; k < n_group; k++) {
+            if (group[k] >= r->natoms) {
+                gorder_xtc_close(r);
+                return GORDER_XTC_ERR_ARGUMENT;
+            }
+            r->slot_of[group[k]] = (int32_t)k;
+        }
+    }
+    *out = r;
+    return GORDER_XTC_OK;
+}
+
+void gorder_xtc_close(gorder_xtc_reader *r) {
+    if (!r) return;
+    if (r->fp) fclose(r->fp);
+    delete r;
+}
+
+uint32_t gorder_xtc_n_atoms_file(const gorder_xtc_reader *r) { return r ? r->natoms : 0; }
+uint32_t gorder_xtc_n_atoms_out(const gorder_xtc_reader *r) {
+    return r ? (r->group.empty() ? r->natoms : (uint32_t)r->group.size()) : 0;
+}
+
+int gorder_xtc_next(gorder_xtc_reader *r, float *xyz, float *box9, int64_t *step, float *time_ps,
+                    float *precision) {
+    if (!r || !r->fp) return GORDER_XTC_ERR_ARGUMENT;
+    uint8_t head[16 + 36 + 4];
+    const size_t got = fread(head, 1, sizeof(head), r->fp);
+    if (got == 0) return GORDER_XTC_EOF;
+    if (got != sizeof(head) || be32(head) != 1995u) return GORDER_XTC_ERR_FORMAT;
+    const uint32_t natoms = be32(head + 4);
+    if (natoms != r->natoms || be32(head + 52) != natoms) return GORDER_XTC_ERR_FORMAT;
+    if (step) *step = (int32_t)be32(head + 8);
+    if (time_ps) *time_ps = bef(head + 12);
+    if (box9) for (int k = 0; k < 9; k++) box9[k] = bef(head + 16 + 4 * k);
+    const bool all = r->group.empty();
+    if (natoms <= 9) {   // uncompressed small systems
+        r->buf.resize((size_t)natoms * 12);
+        if (!read_exact(r->fp, r->buf.data(), r->buf.size())) return GORDER_XTC_ERR_FORMAT;
+        if (precision) *precision = 0.0f;
+        if (xyz) {
+            for (uint32_t a = 0; a < natoms; a++) {
+                const int32_t s = all ? (int32_t)a : r->slot_of[a];
+                if (s < 0) continue;
+                for (int c = 0; c < 3; c++) xyz[3 * (size_t)s + c] = bef(r->buf.data() + 12 * (size_t)a + 4 * c);
+            }
+        }
+        return GORDER_XTC_OK;
+    }
+    uint8_t h2[4 + 24 + 4 + 4];
+    if (!read_exact(r->fp, h2, sizeof(h2))) return GORDER_XTC_ERR_FORMAT;
+    const float prec = bef(h2);
+    int minint[3], maxint[3];
+    for (int k = 0; k < 3; k++) {
+        minint[k] = (int32_t)be32(h2 + 4 + 4 * k);
+        maxint[k] = (int32_t)be32(h2 + 16 + 4 * k);
+    }
+    const int smallidx = (int32_t)be32(h2 + 28);
+    const uint32_t nbytes = be32(h2 + 32);
+    const size_t padded = ((size_t)nbytes + 3) & ~(size_t)3;
+    if (precision) *precision = prec;
+    if (!xyz) {
+        if (fseek(r->fp, (long)padded, SEEK_CUR) != 0) return GORDER_XTC_ERR_FORMAT;
+        return GORDER_XTC_OK;
+    }
+    r->buf.resize(padded + 8);
+    if (!read_exact(r->fp, r->buf.data(), padded)) return GORDER_XTC_ERR_FORMAT;
+    memset(r->buf.data() + padded, 0, 8);
+    const int st = decode_ints(r, minint, maxint, smallidx, r->buf.data(), padded);
+    if (st != GORDER_XTC_OK) return st;
+    const float inv_precision = 1.0f / prec;   // GROMACS xdrfile: coordinate = int * (1 / precision)
+    const int *q = r->ints.data();
+    if (all) {
+        for (size_t k = 0; k < (size_t)natoms * 3; k++) xyz[k] = (float)q[k] * inv_precision;
+    } else {
+        for (size_t k = 0; k < r->group.size(); k++) {
+            const size_t a = r->group[k];
+            xyz[3 * k + 0] = (float)q[3 * a + 0] * inv_precision;
+            xyz[3 * k + 1] = (float)q[3 * a + 1] * inv_precision;
+            xyz[3 * k + 2] = (float)q[3 * a + 2] * inv_precision;
+        }
+    }
+    return GORDER_XTC_OK;
+}
+
+int64_t gorder_xtc_read_window(gorder_xtc_reader *r, float begin_ps, float end_ps, uint32_t step, uint64_t *state,
+                               double *last_time, float *xyz, float *box9, float *time_ps, uint64_t capacity) {
+    if (!r || !state || !last_time || !xyz || !box9 || step == 0) return GORDER_XTC_ERR_ARGUMENT;
+    const size_t nout = gorder_xtc_n_atoms_out(r);
+    uint64_t written = 0;
+    while (written < capacity) {
+        // peek the header to decide whether the coordinates are needed at all
+        const long pos = ftell(r->fp);
+        float t = 0.0f;
+        int st = gorder_xtc_next(r, nullptr, nullptr, nullptr, &t, nullptr);
+        if (st == GORDER_XTC_EOF) break;
+        if (st != GORDER_XTC_OK) return st;
+        if ((double)t == *last_time) continue;             // duplicate frame at a file boundary
+        *last_time = (double)t;
+        if (t < begin_ps) continue;
+        if (end_ps >= 0.0f && t > end_ps) break;
+        const uint64_t k = (*state)++;
+        if (k % step != 0) continue;
+        if (fseek(r->fp, pos, SEEK_SET) != 0) return GORDER_XTC_ERR_FORMAT;
+        st = gorder_xtc_next(r, xyz + written * nout * 3, box9 + written * 9, nullptr, &t, nullptr);
+        if (st != GORDER_XTC_OK) return st;
+        if (time_ps) time_ps[written] = t;
+        written++;
+    }
+    return (int64_t)written;
+}
+
+}  // extern "C"

@@ -1,0 +1,79 @@
+"""ctypes binding of the host-side XTC reader (include/gorder_xtc.h, gorder_amd/csrc/xtc_reader.cpp)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from .abi import load_library
+
+_bound = False
+
+
+def _lib():
+    global _bound
+    lib = load_library()
+    if not _bound:
+        vp = C.c_void_p
+        lib.gorder_xtc_open.argtypes = [C.c_char_p, vp, C.c_uint32, C.POINTER(vp)]
+        lib.gorder_xtc_close.argtypes = [vp]
+        lib.gorder_xtc_close.restype = None
+        lib.gorder_xtc_n_atoms_file.argtypes = [vp]
+        lib.gorder_xtc_n_atoms_file.restype = C.c_uint32
+        lib.gorder_xtc_n_atoms_out.argtypes = [vp]
+        lib.gorder_xtc_n_atoms_out.restype = C.c_uint32
+        lib.gorder_xtc_next.argtypes = [vp, vp, vp, C.POINTER(C.c_int64), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        lib.gorder_xtc_read_window.argtypes = [vp, C.c_float, C.c_float, C.c_uint32, C.POINTER(C.c_uint64),
+                                               C.POINTER(C.c_double), vp, vp, vp, C.c_uint64]
+        lib.gorder_xtc_read_window.restype = C.c_int64
+        _bound = True
+    return lib
+
+
+def read_trajectory(paths: Sequence[str], group: Optional[np.ndarray] = None, begin: float = 0.0, end: float = -1.0,
+                    step: int = 1, chunk: int = 64, return_precision: bool = False):
+    """Read (and concatenate) XTC files like gorder's `read_trajectory`
+    (/root/reference/src/analysis/common.rs:239-342): time window in ps, every `step`-th frame,
+    duplicate boundary frames of consecutive files dropped.
+    -> xyz [F, n_out, 3] f32, box [F, 3, 3] f32, time [F] f32."""
+    lib = _lib()
+    grp = None if group is None else np.ascontiguousarray(group, dtype=np.uint32)
+    state, last = C.c_uint64(0), C.c_double(float("-inf"))
+    xs, bs, ts = [], [], []
+    prec = 0.0
+    for path in paths:
+        r = C.c_void_p()
+        st = lib.gorder_xtc_open(path.encode(), None if grp is None else grp.ctypes.data, 0 if grp is None else grp.size,
+                                 C.byref(r))
+        if st != 0:
+            raise IOError(f"cannot open {path}: status {st}")
+        try:
+            n = lib.gorder_xtc_n_atoms_out(r)
+            if return_precision and prec == 0.0:
+                p, t = C.c_float(), C.c_float()
+                lib.gorder_xtc_next(r, None, None, None, C.byref(t), C.byref(p))
+                prec = p.value
+                lib.gorder_xtc_close(r)
+                r = C.c_void_p()
+                lib.gorder_xtc_open(path.encode(), None if grp is None else grp.ctypes.data,
+                                    0 if grp is None else grp.size, C.byref(r))
+            while True:
+                x = np.empty((chunk, n, 3), dtype=np.float32)
+                b = np.empty((chunk, 3, 3), dtype=np.float32)
+                t = np.empty(chunk, dtype=np.float32)
+                got = lib.gorder_xtc_read_window(r, begin, end, step, C.byref(state), C.byref(last), x.ctypes.data,
+                                                 b.ctypes.data, t.ctypes.data, chunk)
+                if got < 0:
+                    raise IOError(f"{path}: XTC read error {got}")
+                if got == 0:
+                    break
+                xs.append(x[:got]); bs.append(b[:got]); ts.append(t[:got])
+        finally:
+            lib.gorder_xtc_close(r)
+    if not xs:
+        n = 0 if grp is None else grp.size
+        out = (np.zeros((0, n, 3), np.float32), np.zeros((0, 3, 3), np.float32), np.zeros(0, np.float32))
+    else:
+        out = (np.concatenate(xs), np.concatenate(bs), np.concatenate(ts))
+    return out + (prec,) if return_precision else out

@@ -1,0 +1,60 @@
+/*
+ * gorder_xtc.h — C ABI of the host-side XTC trajectory reader.
+ *
+ * Replaces, for the drop-in path, what gorder reaches through groan_rs' `GroupXtcReader`
+ * (call sites /root/reference/src/analysis/common.rs:281-304): sequential decode of GROMACS
+ * xdr3dcoord-compressed frames, conversion of only the atoms of the "Master" group, the time window
+ * `begin/end/step` (common.rs:239-246) and concatenation of several files with the duplicate
+ * boundary frame dropped (CHANGELOG.md:64).
+ *
+ * The third-party decoder (molly 0.5.0 via groan_rs 0.11.2) is not in /root/reference; the wire
+ * format restated here is the published GROMACS XTC format (magic 1995, "magic ints" mixed-radix
+ * packing).  int -> f32 conversion: coordinate = int * (1 / precision) as in GROMACS' xdrfile.
+ */
+#ifndef GORDER_XTC_H
+#define GORDER_XTC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gorder_xtc_reader gorder_xtc_reader;
+
+typedef enum {
+    GORDER_XTC_OK = 0,
+    GORDER_XTC_EOF = 1,            /* clean end of file */
+    GORDER_XTC_ERR_OPEN = -1,
+    GORDER_XTC_ERR_FORMAT = -2,    /* bad magic / truncated frame / corrupt bit stream */
+    GORDER_XTC_ERR_ARGUMENT = -3
+} gorder_xtc_status_t;
+
+/* Open one file.  `group` (may be NULL = all atoms) lists the n_group atom indices to convert;
+ * decoded frames hold exactly those atoms, in that order (the "Master" group of common.rs:283-304). */
+int gorder_xtc_open(const char *path, const uint32_t *group, uint32_t n_group, gorder_xtc_reader **out);
+void gorder_xtc_close(gorder_xtc_reader *r);
+uint32_t gorder_xtc_n_atoms_file(const gorder_xtc_reader *r);   /* atoms per frame in the file */
+uint32_t gorder_xtc_n_atoms_out(const gorder_xtc_reader *r);    /* atoms per decoded frame */
+
+/* Decode the next frame: xyz [n_atoms_out][3] nm, box [3][3], step, time (ps), precision.
+ * Pass xyz = NULL to skip the coordinate block (header only; cheap). */
+int gorder_xtc_next(gorder_xtc_reader *r, float *xyz, float *box9, int64_t *step, float *time_ps,
+                    float *precision);
+
+/* Decode up to `capacity` frames selected by the time window into caller buffers
+ * xyz [capacity][n_atoms_out][3], box [capacity][3][3], time [capacity]:
+ *   begin/end in ps (negative end = no limit), every `step`-th frame of the window.
+ * `*state` (init 0) carries the frame counter across calls/files; `*last_time` (init -inf) the time of
+ * the previous analysed-or-skipped frame so that a frame whose time equals the last frame of the
+ * previous file is dropped when reading concatenated trajectories.
+ * Returns the number of frames written (0 at end of file) or a negative gorder_xtc_status_t. */
+int64_t gorder_xtc_read_window(gorder_xtc_reader *r, float begin_ps, float end_ps, uint32_t step,
+                               uint64_t *state, double *last_time, float *xyz, float *box9, float *time_ps,
+                               uint64_t capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures from the reference's own test DATA files.
+
+    python tests/golden/make_fixtures.py        (needs /root/reference; run once, output is committed)
+
+Only data travels: lipid-only subsets of the reference's structure / bond / trajectory fixtures
+(re-packed as integer coordinates exactly as stored in the XTC files) and the expected-output
+text files of its integration tests.  No reference source code is read or copied.
+
+  pcpepg  tests/files/pcpepg.gro + pcpepg.bnd + split/pcpepg{1..5}.xtc   (tests_aa.rs:47-77)
+  cg      tests/files/cg.gro + cg.bnd + split/cg{1..5}.xtc               (tests_cg.rs:46-66)
+"""
+import ctypes as C
+import os
+import shutil
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference/tests/files"
+
+from gorder_amd import structure as st   # noqa: E402
+from gorder_amd import xtc              # noqa: E402
+
+LIPIDS = {"POPC", "POPE", "POPG", "POPS"}
+
+
+def pack(name, gro, bnd, xtcs):
+    s = st.read_gro(os.path.join(REF, gro))
+    adj = st.read_bnd(os.path.join(REF, bnd), s.n_atoms)
+    keep = np.array([r in LIPIDS for r in s.resnames])
+    idx = np.flatnonzero(keep)
+    remap = -np.ones(s.n_atoms, dtype=np.int64)
+    remap[idx] = np.arange(len(idx))
+    pairs = sorted({(int(remap[a]), int(remap[b])) for a in idx for b in adj[a] if keep[b] and a < b})
+    frames, boxes, times, prec = xtc.read_trajectory([os.path.join(REF, x) for x in xtcs], group=idx.astype(np.uint32),
+                                                     return_precision=True)
+    ints = np.rint(frames.astype(np.float64) * prec).astype(np.int32)
+    back = (ints.astype(np.float32) * np.float32(1.0 / np.float32(prec))).astype(np.float32)
+    assert np.array_equal(back, frames), "integer round trip must reproduce the decoder's floats exactly"
+    assert np.abs(ints).max() < 32768
+    out = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(out, resids=s.resids[idx].astype(np.int32), resnames=np.array([s.resnames[i] for i in idx]),
+                        names=np.array([s.names[i] for i in idx]), bonds=np.array(pairs, dtype=np.int32),
+                        structure_box=s.box, ints=ints.astype(np.int16), precision=np.float32(prec),
+                        boxes=boxes.astype(np.float32), times=times.astype(np.float32))
+    print(name, "atoms", len(idx), "bonds", len(pairs), "frames", len(times), "t", times[0], times[-1],
+          "->", os.path.getsize(out) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    pack("pcpepg", "pcpepg.gro", "pcpepg.bnd", [f"split/pcpepg{i}.xtc" for i in range(1, 6)])
+    pack("cg", "cg.gro", "cg.bnd", [f"split/cg{i}.xtc" for i in range(1, 6)])
+    for f in ("aa_order_basic.yaml", "aa_order_begin_end_step.yaml", "aa_order_leaflets.yaml",
+              "cg_order_basic.yaml", "cg_order_begin_end_step.yaml", "cg_order_leaflets.yaml"):
+        src = os.path.join(REF, f)
+        if os.path.exists(src):
+            shutil.copy(src, os.path.join(HERE, "expected", f))

@@ -1,0 +1,75 @@
+"""Shared helpers for the golden-fixture tests (data under tests/golden/, made by make_fixtures.py)."""
+import os
+
+import numpy as np
+import yaml
+
+from gorder_amd import structure as st
+from gorder_amd.abi import LEAFLETS_GLOBAL, LEAFLETS_INDIVIDUAL, LEAFLETS_LOCAL
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+class Fixture:
+    def __init__(self, name):
+        z = np.load(os.path.join(GOLDEN, name + ".npz"))
+        self.structure = st.Structure(z["resids"], [str(x) for x in z["resnames"]], [str(x) for x in z["names"]],
+                                      z["structure_box"])
+        n = self.structure.n_atoms
+        adj = [[] for _ in range(n)]
+        for a, b in z["bonds"]:
+            adj[a].append(int(b)); adj[b].append(int(a))
+        self.structure.bonds = [sorted(x) for x in adj]
+        prec = np.float32(z["precision"])
+        # exactly the decoder's arithmetic: int * (1 / precision) in f32
+        self.xyz = (z["ints"].astype(np.float32) * np.float32(np.float32(1.0) / prec)).astype(np.float32)
+        self.boxes = z["boxes"].astype(np.float32)
+        self.times = z["times"]
+        self.names = np.array(self.structure.names)
+
+    def window(self, begin=None, end=None, step=1):
+        """groan_rs time window (common.rs:239-246): frames with begin <= t <= end, every step-th."""
+        sel = np.ones(len(self.times), dtype=bool)
+        if begin is not None:
+            sel &= self.times >= begin
+        if end is not None:
+            sel &= self.times <= end
+        idx = np.flatnonzero(sel)[::step]
+        return idx
+
+    def element(self, el):
+        s = self.structure
+        return np.array([st.guess_element(n, r) == el for n, r in zip(s.names, s.resnames)])
+
+    def name_in(self, *names):
+        return np.isin(self.names, names)
+
+
+def expected(name):
+    with open(os.path.join(GOLDEN, "expected", name)) as f:
+        return yaml.safe_load(f)
+
+
+def aa_setup(fx, leaflets=None, frequency=1, **kw):
+    """AAOrder '@membrane and element name carbon' / '... hydrogen' (tests_aa.rs:63-66); the fixture
+    holds exactly the @membrane lipids."""
+    heavy, hyd = fx.element("carbon"), fx.element("hydrogen")
+    lf = None
+    if leaflets is not None:
+        allm = np.ones(fx.structure.n_atoms, dtype=bool)
+        lf = {"method": leaflets, "membrane": allm, "heads": fx.name_in("P"),
+              "methyls": fx.name_in("C218", "C316"), "frequency": frequency, "radius": 2.5}
+    return st.build_tables(fx.structure, "aa", heavy, hyd, leaflets=lf, **kw)
+
+
+def cg_setup(fx, leaflets=None, frequency=1, **kw):
+    """CGOrder '@membrane' (tests_cg.rs:194)."""
+    beads = np.ones(fx.structure.n_atoms, dtype=bool)
+    lf = None
+    if leaflets is not None:
+        lf = {"method": leaflets, "membrane": beads, "heads": fx.name_in("PO4"),
+              "methyls": fx.name_in("C4A", "C4B"), "frequency": frequency, "radius": 2.5}
+    return st.build_tables(fx.structure, "cg", beads, leaflets=lf, **kw)
+
+
+METHODS = {"global": LEAFLETS_GLOBAL, "local": LEAFLETS_LOCAL, "individual": LEAFLETS_INDIVIDUAL}

@@ -1,0 +1,108 @@
+"""The HIP path against the reference's own golden outputs (same fixtures as test_golden_oracle.py)
+and, frame for frame, against the oracle on the real membrane data."""
+import numpy as np
+import pytest
+
+from gorder_amd import HipEngine, abi
+from gorder_amd import structure as st
+from oracle import oracle
+from golden_util import METHODS, Fixture, aa_setup, cg_setup, expected
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pcpepg(built):
+    return Fixture("pcpepg")
+
+
+@pytest.fixture(scope="module")
+def cg(built):
+    return Fixture("cg")
+
+
+def gpu_run(tables, fx, midx, frames, frame_index=None, batches=3):
+    eng = HipEngine(tables)
+    xyz = np.ascontiguousarray(fx.xyz[frames][:, midx, :])
+    box = fx.boxes[frames]
+    fi = np.asarray(frames if frame_index is None else frame_index)
+    edges = np.linspace(0, len(frames), batches + 1).astype(int)
+    for a, b in zip(edges[:-1], edges[1:]):
+        if b > a:
+            eng.submit_host(xyz[a:b], box[a:b], fi[a:b])
+    return eng, eng.finish(), xyz, box, fi
+
+
+def oracle_run(tables, xyz, box, fi, trig):
+    o = oracle.OracleEngine(tables, trig=trig, n_threads=4)
+    o.submit(xyz, box, fi)
+    return o, o.finish()
+
+
+@pytest.mark.parametrize("flags", [0, abi.FLAG_TRIG_ACOS_COS])
+def test_aa_order_basic(pcpepg, flags):
+    tables, labels, midx = aa_setup(pcpepg, flags=flags)
+    frames = pcpepg.window()
+    eng, res, xyz, box, fi = gpu_run(tables, pcpepg, midx, frames)
+    assert res.n_frames == 51
+    bad = st.compare_trees(st.results_tree(res, labels, "aa", leaflets=False), expected("aa_order_basic.yaml"))
+    assert not bad, bad[:10]
+    # and bit-exact against the oracle mode that restates the device arithmetic
+    _, want = oracle_run(tables, xyz, box, fi, oracle.TRIG_MIRROR if flags else oracle.TRIG_DIRECT)
+    np.testing.assert_array_equal(res.sums, want.sums)
+    np.testing.assert_array_equal(res.counts, want.counts)
+    # within 1e-6 of the reference-faithful (libm) oracle
+    _, libm = oracle_run(tables, xyz, box, fi, oracle.TRIG_LIBM)
+    assert np.abs(res.order_ticks() - libm.order_ticks()).max() <= 1
+
+
+@pytest.mark.parametrize("method", ["global", "local", "individual"])
+def test_aa_order_leaflets(pcpepg, method):
+    tables, labels, midx = aa_setup(pcpepg, leaflets=METHODS[method])
+    frames = pcpepg.window()
+    eng, res, xyz, box, fi = gpu_run(tables, pcpepg, midx, frames)
+    bad = st.compare_trees(st.results_tree(res, labels, "aa", leaflets=True), expected("aa_order_leaflets.yaml"))
+    assert not bad, bad[:10]
+    o, want = oracle_run(tables, xyz, box, fi, oracle.TRIG_DIRECT)
+    flags, _ = eng.leaflets()
+    oflags, odist, _ = o.leaflets()
+    diff = flags != oflags
+    assert not diff.any() or np.abs(odist[diff]).max() < 1e-4   # only a lipid ON the mid-plane may differ
+    if not diff.any():
+        np.testing.assert_array_equal(res.sums, want.sums)
+        np.testing.assert_array_equal(res.counts, want.counts)
+
+
+def test_aa_begin_end_step(pcpepg):
+    tables, labels, midx = aa_setup(pcpepg, leaflets=METHODS["global"], frequency=3)
+    frames = pcpepg.window(450_200.0, 450_400.0, 3)
+    eng, res, *_ = gpu_run(tables, pcpepg, midx, frames, frame_index=np.arange(4) * 3, batches=2)
+    bad = st.compare_trees(st.results_tree(res, labels, "aa", leaflets=True), expected("aa_order_begin_end_step.yaml"))
+    assert not bad, bad[:10]
+
+
+def test_cg_order_basic(cg):
+    tables, labels, midx = cg_setup(cg)
+    frames = cg.window()
+    eng, res, xyz, box, fi = gpu_run(tables, cg, midx, frames)
+    bad = st.compare_trees(st.results_tree(res, labels, "cg", leaflets=False), expected("cg_order_basic.yaml"))
+    assert not bad, bad[:10]
+    _, want = oracle_run(tables, xyz, box, fi, oracle.TRIG_DIRECT)
+    np.testing.assert_array_equal(res.sums, want.sums)
+
+
+@pytest.mark.parametrize("method", ["global", "local", "individual"])
+def test_cg_order_leaflets(cg, method):
+    tables, labels, midx = cg_setup(cg, leaflets=METHODS[method])
+    frames = cg.window()
+    eng, res, xyz, box, fi = gpu_run(tables, cg, midx, frames)
+    bad = st.compare_trees(st.results_tree(res, labels, "cg", leaflets=True), expected("cg_order_leaflets.yaml"))
+    assert not bad, bad[:10]
+
+
+def test_cg_begin_end_step(cg):
+    tables, labels, midx = cg_setup(cg, leaflets=METHODS["global"], frequency=5)
+    frames = cg.window(352_000.0, 358_000.0, 5)
+    eng, res, *_ = gpu_run(tables, cg, midx, frames, frame_index=np.arange(13) * 5)
+    bad = st.compare_trees(st.results_tree(res, labels, "cg", leaflets=True), expected("cg_order_begin_end_step.yaml"))
+    assert not bad, bad[:10]

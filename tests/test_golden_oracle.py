@@ -1,0 +1,116 @@
+"""Pin the oracle with the reference's own golden outputs.
+
+Inputs: the reference's test structures / bond files / split XTC trajectories (tests/golden/*.npz, the
+lipid-only subset, integer coordinates as stored in the XTC files).  Expected: the YAML files the
+reference's integration tests compare against, with the reference's own tolerance (floats within 2e-4,
+/root/reference/tests/common/mod.rs:139-150).  Every trig mode of the oracle must reproduce them.
+"""
+import numpy as np
+import pytest
+
+from gorder_amd import structure as st
+from oracle import oracle
+from golden_util import METHODS, Fixture, aa_setup, cg_setup, expected
+
+
+@pytest.fixture(scope="module")
+def pcpepg(built):
+    return Fixture("pcpepg")
+
+
+@pytest.fixture(scope="module")
+def cg(built):
+    return Fixture("cg")
+
+
+def run(tables, fx, frames, trig, n_threads=1):
+    eng = oracle.OracleEngine(tables, trig=trig, n_threads=n_threads)
+    xyz = fx.xyz[frames][:, :, :]
+    eng.submit(np.ascontiguousarray(xyz[:, : tables.n_atoms] if xyz.shape[1] == tables.n_atoms else xyz),
+               fx.boxes[frames], frames)
+    return eng.finish()
+
+
+def master_frames(fx, midx, frames):
+    return np.ascontiguousarray(fx.xyz[frames][:, midx, :])
+
+
+@pytest.mark.parametrize("trig", [oracle.TRIG_LIBM, oracle.TRIG_MIRROR, oracle.TRIG_DIRECT])
+def test_aa_order_basic(pcpepg, trig):
+    # tests_aa.rs:47-77: 51 frames (5 concatenated files), no leaflets
+    tables, labels, midx = aa_setup(pcpepg)
+    assert [m.name for m in labels] == ["POPE", "POPC", "POPG"]
+    assert [m.n_molecules for m in labels] == [131, 128, 15]           # aaorder.rs:413
+    assert [len(m.bonds) for m in labels] == [73, 82, 74]               # molecule.rs:525
+    frames = pcpepg.window()
+    assert len(frames) == 51                                            # tests_aa.rs:5455
+    eng = oracle.OracleEngine(tables, trig=trig, n_threads=3)
+    eng.submit(master_frames(pcpepg, midx, frames), pcpepg.boxes[frames], frames)
+    res = eng.finish()
+    assert res.n_frames == 51
+    tree = st.results_tree(res, labels, "aa", leaflets=False)
+    bad = st.compare_trees(tree, expected("aa_order_basic.yaml"))
+    assert not bad, bad[:10]
+
+
+@pytest.mark.parametrize("method", ["global", "local", "individual"])
+def test_aa_order_leaflets(pcpepg, method):
+    # tests_aa.rs:289-317: global / local(2.5 nm) / individual all reproduce aa_order_leaflets.yaml
+    tables, labels, midx = aa_setup(pcpepg, leaflets=METHODS[method])
+    frames = pcpepg.window()
+    eng = oracle.OracleEngine(tables, trig=oracle.TRIG_LIBM, n_threads=4)
+    eng.submit(master_frames(pcpepg, midx, frames), pcpepg.boxes[frames], frames)
+    tree = st.results_tree(eng.finish(), labels, "aa", leaflets=True)
+    bad = st.compare_trees(tree, expected("aa_order_leaflets.yaml"))
+    assert not bad, bad[:10]
+
+
+def test_aa_begin_end_step_leaflets(pcpepg):
+    # tests_aa.rs:1271-1304: begin 450200 ps, end 450400 ps, step 3, global leaflets -> 4 frames
+    tables, labels, midx = aa_setup(pcpepg, leaflets=METHODS["global"], frequency=3)   # real frequency = 1 * step
+    frames = pcpepg.window(450_200.0, 450_400.0, 3)
+    assert len(frames) == 4
+    eng = oracle.OracleEngine(tables, trig=oracle.TRIG_LIBM)
+    # SystemTopology::frame advances by step (topology/mod.rs:141-144): 0, 3, 6, 9
+    eng.submit(master_frames(pcpepg, midx, frames), pcpepg.boxes[frames], np.arange(4) * 3)
+    tree = st.results_tree(eng.finish(), labels, "aa", leaflets=True)
+    bad = st.compare_trees(tree, expected("aa_order_begin_end_step.yaml"))
+    assert not bad, bad[:10]
+
+
+@pytest.mark.parametrize("trig", [oracle.TRIG_LIBM, oracle.TRIG_DIRECT])
+def test_cg_order_basic(cg, trig):
+    tables, labels, midx = cg_setup(cg)
+    assert [m.name for m in labels] == ["POPC", "POPE", "POPG"]
+    assert [m.n_molecules for m in labels] == [242, 242, 24]            # cgorder.rs counts
+    assert [len(m.bonds) for m in labels] == [11, 11, 11]
+    frames = cg.window()
+    eng = oracle.OracleEngine(tables, trig=trig, n_threads=2)
+    eng.submit(master_frames(cg, midx, frames), cg.boxes[frames], frames)
+    tree = st.results_tree(eng.finish(), labels, "cg", leaflets=False)
+    bad = st.compare_trees(tree, expected("cg_order_basic.yaml"))
+    assert not bad, bad[:10]
+
+
+@pytest.mark.parametrize("method", ["global", "local", "individual"])
+def test_cg_order_leaflets(cg, method):
+    # tests_cg.rs:180-205
+    tables, labels, midx = cg_setup(cg, leaflets=METHODS[method])
+    frames = cg.window()
+    eng = oracle.OracleEngine(tables, trig=oracle.TRIG_LIBM, n_threads=4)
+    eng.submit(master_frames(cg, midx, frames), cg.boxes[frames], frames)
+    tree = st.results_tree(eng.finish(), labels, "cg", leaflets=True)
+    bad = st.compare_trees(tree, expected("cg_order_leaflets.yaml"))
+    assert not bad, bad[:10]
+
+
+def test_cg_begin_end_step(cg):
+    # tests_cg.rs:808-845: 352-358 ns, step 5, global leaflets -> 13 frames
+    tables, labels, midx = cg_setup(cg, leaflets=METHODS["global"], frequency=5)
+    frames = cg.window(352_000.0, 358_000.0, 5)
+    assert len(frames) == 13
+    eng = oracle.OracleEngine(tables, trig=oracle.TRIG_LIBM)
+    eng.submit(master_frames(cg, midx, frames), cg.boxes[frames], np.arange(13) * 5)
+    tree = st.results_tree(eng.finish(), labels, "cg", leaflets=True)
+    bad = st.compare_trees(tree, expected("cg_order_begin_end_step.yaml"))
+    assert not bad, bad[:10]
