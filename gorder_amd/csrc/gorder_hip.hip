@@ -11,6 +11,7 @@
 //   SystemLeafletClassification::run   leaflets.rs:171-205           -> k_leaflets_global
 //   common_identify_leaflet            leaflets.rs:711-732              (same kernel)
 //   IndividualClassification           leaflets.rs:777-801           -> k_leaflets_individual
+//   LocalClassification + local centres leaflets.rs:661-675, pbc.rs:273-318 -> k_local_{bin,scan,scatter,flags}
 //   should_assign / get_assigned       leaflets.rs:435-441, 1437-1472   (host: assignment-row table)
 //   SystemTopology::add / reduce       topology/mod.rs:236-272          (integer sums: order-free)
 //
@@ -636,6 +637,243 @@ __global__ __launch_bounds__(256) void k_leaflets_individual(LeafletArgs a) {
     if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f);
 }
 
+// ---- Local leaflets (LocalClassification, leaflets.rs:661-675 -> PBC3D::calc_local_membrane_centers,
+// pbc.rs:273-318; NoPBC: pbc.rs:107-139) ---------------------------------------------------------
+// For every lipid head: centre of geometry (refined Bai-Breen, like the global centre) of the membrane
+// atoms whose in-plane minimum-image distance from the head is < radius (an infinite cylinder along the
+// normal), then common_identify_leaflet (leaflets.rs:711-732).  The reference prunes the search with a
+// CellGrid of cell edge = radius (neighbours +-1 in-plane, all cells along the normal, pbc.rs:287-292);
+// here: a 2-D in-plane cell list per assignment frame, cell edge >= radius, built on the device.
+//   k_local_bin     : per (slab frame, membrane atom): cell id, per-atom cos/sin of the 3 angles, count
+//   k_local_scan    : per slab frame: exclusive scan of the cell counts (one block)
+//   k_local_scatter : per (slab frame, membrane atom): place the atom in its cell's list
+//   k_local_flags   : one wave per (slab frame, head): two passes over the 3x3 neighbour cells
+constexpr uint32_t kLocalMaxCells1D = 128;
+constexpr uint32_t kLocalSlab = 32;   // assignment frames processed per launch group
+
+struct LocalArgs {
+    const float *xyz;
+    const float *box9;
+    uint32_t n_atoms;
+    const uint32_t *aframes;    // [n_slab] local frame index of each assignment frame of this slab
+    uint32_t n_slab;
+    uint32_t row0;
+    uint8_t *aflags;
+    float *adist;               // written for the last frame of the whole batch only (may be null)
+    int write_dist_frame;       // slab-local index whose distances go to adist (-1: none)
+    uint32_t n_mol_total;
+    const uint32_t *heads;
+    const uint32_t *membrane;
+    uint32_t n_membrane;
+    uint32_t dim;               // normal
+    int flip, pbc;
+    float radius;
+    // scratch, per slab frame
+    uint32_t *cell_of;          // [n_slab][n_membrane]
+    float *trig;                // [n_slab][n_membrane][6]: cos x,y,z then sin x,y,z of 2 pi wrap(c)/L
+    uint32_t *cell_count;       // [n_slab][kLocalMaxCells1D^2 + 1] counts -> starts
+    uint32_t *cell_fill;        // [n_slab][kLocalMaxCells1D^2]
+    uint32_t *cell_atoms;       // [n_slab][n_membrane] positions in the membrane list, grouped by cell
+    uint32_t *err;
+};
+
+__device__ __forceinline__ void local_grid(const LocalArgs &a, const float *box, uint32_t &nca, uint32_t &ncb,
+                                           int &da, int &db) {
+    da = (int)((a.dim + 1u) % 3u);
+    db = (int)((a.dim + 2u) % 3u);
+    if (a.pbc) {
+        const float fa = floorf(box[da] / a.radius), fb = floorf(box[db] / a.radius);
+        nca = (uint32_t)fminf(fmaxf(fa, 1.0f), (float)kLocalMaxCells1D);
+        ncb = (uint32_t)fminf(fmaxf(fb, 1.0f), (float)kLocalMaxCells1D);
+    } else {
+        nca = ncb = 1;   // no periodic images to prune with: one cell holds every atom
+    }
+}
+
+__device__ __forceinline__ void frame_box(const LocalArgs &a, uint32_t f, float *box) {
+    box[0] = box[1] = box[2] = 1.0f;
+    if (a.pbc) {
+        const float *b = a.box9 + 9 * (size_t)f;
+        box[0] = b[0]; box[1] = b[4]; box[2] = b[8];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_local_bin(LocalArgs a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t s = blockIdx.y;
+    if (i >= a.n_membrane) return;
+    const uint32_t f = a.aframes[s];
+    float box[3];
+    frame_box(a, f, box);
+    uint32_t nca, ncb;
+    int da, db;
+    local_grid(a, box, nca, ncb, da, db);
+    const float *p = a.xyz + ((size_t)f * a.n_atoms + a.membrane[i]) * 3u;
+    int bad = 0;
+    float w[3];
+    float *tr = a.trig + ((size_t)s * a.n_membrane + i) * 6u;
+    for (int d = 0; d < 3; d++) {
+        w[d] = a.pbc ? gm_wrap(p[d], box[d], bad) : p[d];
+        if (a.pbc) {
+            float sn, cs;
+            sincosf(w[d] * (6.2831855f / box[d]), &sn, &cs);
+            tr[d] = cs;
+            tr[3 + d] = sn;
+        }
+    }
+    uint32_t ca = 0, cb = 0;
+    if (a.pbc) {
+        ca = (uint32_t)fminf(fmaxf(floorf(w[da] / box[da] * (float)nca), 0.0f), (float)(nca - 1u));
+        cb = (uint32_t)fminf(fmaxf(floorf(w[db] / box[db] * (float)ncb), 0.0f), (float)(ncb - 1u));
+    }
+    const uint32_t c = ca * ncb + cb;
+    a.cell_of[(size_t)s * a.n_membrane + i] = c;
+    atomicAdd(&a.cell_count[(size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u) + c], 1u);
+    if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f);
+}
+
+__global__ __launch_bounds__(1024) void k_local_scan(LocalArgs a) {
+    __shared__ uint32_t part[1024];
+    const uint32_t s = blockIdx.x;
+    uint32_t *cnt = a.cell_count + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u);
+    constexpr uint32_t N = kLocalMaxCells1D * kLocalMaxCells1D, PER = N / 1024u;
+    uint32_t local[PER];
+    uint32_t sum = 0;
+    for (uint32_t k = 0; k < PER; k++) {
+        local[k] = cnt[threadIdx.x * PER + k];
+        sum += local[k];
+    }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+    for (uint32_t k = 0; k < PER; k++) {
+        cnt[threadIdx.x * PER + k] = run;
+        run += local[k];
+    }
+    if (threadIdx.x == 1023) cnt[N] = run;
+}
+
+__global__ __launch_bounds__(256) void k_local_scatter(LocalArgs a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t s = blockIdx.y;
+    if (i >= a.n_membrane) return;
+    const uint32_t c = a.cell_of[(size_t)s * a.n_membrane + i];
+    const uint32_t start = a.cell_count[(size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u) + c];
+    const uint32_t k = atomicAdd(&a.cell_fill[(size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D) + c], 1u);
+    a.cell_atoms[(size_t)s * a.n_membrane + start + k] = i;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// block = 256 threads = 4 waves = 4 heads; grid = (ceil(n_mol / 4), n_slab)
+__global__ __launch_bounds__(256) void k_local_flags(LocalArgs a) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t m = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t s = blockIdx.y;
+    if (m >= a.n_mol_total) return;
+    const uint32_t f = a.aframes[s];
+    float box[3];
+    frame_box(a, f, box);
+    uint32_t nca, ncb;
+    int da, db;
+    local_grid(a, box, nca, ncb, da, db);
+    const float *x = a.xyz + (size_t)f * a.n_atoms * 3u;
+    const float *hp = x + 3u * (size_t)a.heads[m];
+    int bad = 0;
+    uint32_t ha = 0, hb = 0;
+    if (a.pbc) {
+        const float wa = gm_wrap(hp[da], box[da], bad), wb = gm_wrap(hp[db], box[db], bad);
+        ha = (uint32_t)fminf(fmaxf(floorf(wa / box[da] * (float)nca), 0.0f), (float)(nca - 1u));
+        hb = (uint32_t)fminf(fmaxf(floorf(wb / box[db] * (float)ncb), 0.0f), (float)(ncb - 1u));
+    }
+    const uint32_t *cstart = a.cell_count + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u);
+    const uint32_t *catoms = a.cell_atoms + (size_t)s * a.n_membrane;
+    const float *trig = a.trig + (size_t)s * a.n_membrane * 6u;
+    const uint32_t na = nca < 3u ? nca : 3u, nb = ncb < 3u ? ncb : 3u;
+
+    // pass 1: member count and circular sums (PBC) or plain sums (NoPBC)
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    double cnt = 0;
+    for (uint32_t ia = 0; ia < na; ia++) {
+        const uint32_t ca = (ha + nca - 1u + ia) % nca;
+        for (uint32_t ib = 0; ib < nb; ib++) {
+            const uint32_t cb = (hb + ncb - 1u + ib) % ncb;
+            const uint32_t c = ca * ncb + cb;
+            for (uint32_t q = cstart[c] + lane; q < cstart[c + 1]; q += 64) {
+                const uint32_t i = catoms[q];
+                const float *p = x + 3u * (size_t)a.membrane[i];
+                float ea = p[da] - hp[da], eb = p[db] - hp[db];
+                if (a.pbc) { ea = gm_min_image(ea, box[da], bad); eb = gm_min_image(eb, box[db], bad); }
+                if (__builtin_sqrtf(ea * ea + eb * eb) < a.radius) {   // groan_rs Cylinder::inside, in-plane part
+                    cnt += 1.0;
+                    if (a.pbc) {
+                        for (int d = 0; d < 6; d++) acc[d] += (double)trig[(size_t)i * 6u + d];
+                    } else {
+                        for (int d = 0; d < 3; d++) acc[d] += (double)p[d];
+                    }
+                }
+            }
+        }
+    }
+    cnt = wave_sum(cnt);
+    for (int d = 0; d < 6; d++) acc[d] = wave_sum(acc[d]);
+    float center[3];
+    if (cnt == 0.0) {
+        if (lane == 0) raise_error(a.err, GORDER_ERR_INVALID_LOCAL_MEMBRANE_CENTER, a.heads[m], f);
+        return;
+    }
+    if (!a.pbc) {
+        for (int d = 0; d < 3; d++) center[d] = (float)(acc[d] / cnt);
+    } else {
+        float est[3];
+        for (int d = 0; d < 3; d++) {
+            const float th = atan2f(-(float)acc[3 + d], -(float)acc[d]) + 3.1415927f;
+            est[d] = th / (6.2831855f / box[d]);
+        }
+        // pass 2: refine with the mean minimum-image displacement from the estimate
+        double ref[3] = {0, 0, 0};
+        for (uint32_t ia = 0; ia < na; ia++) {
+            const uint32_t ca = (ha + nca - 1u + ia) % nca;
+            for (uint32_t ib = 0; ib < nb; ib++) {
+                const uint32_t cb = (hb + ncb - 1u + ib) % ncb;
+                const uint32_t c = ca * ncb + cb;
+                for (uint32_t q = cstart[c] + lane; q < cstart[c + 1]; q += 64) {
+                    const uint32_t i = catoms[q];
+                    const float *p = x + 3u * (size_t)a.membrane[i];
+                    float ea = gm_min_image(p[da] - hp[da], box[da], bad);
+                    float eb = gm_min_image(p[db] - hp[db], box[db], bad);
+                    if (__builtin_sqrtf(ea * ea + eb * eb) < a.radius)
+                        for (int d = 0; d < 3; d++) ref[d] += (double)gm_min_image(p[d] - est[d], box[d], bad);
+                }
+            }
+        }
+        for (int d = 0; d < 3; d++) {
+            ref[d] = wave_sum(ref[d]);
+            center[d] = gm_wrap(est[d] + (float)(ref[d] / cnt), box[d], bad);
+        }
+    }
+    if (lane == 0) {
+        if (center[0] != center[0] || center[1] != center[1] || center[2] != center[2]) {
+            raise_error(a.err, GORDER_ERR_INVALID_LOCAL_MEMBRANE_CENTER, a.heads[m], f);
+            return;
+        }
+        float d = hp[a.dim] - center[a.dim];
+        if (a.pbc) d = gm_min_image(d, box[a.dim], bad);
+        a.aflags[(size_t)(a.row0 + s) * a.n_mol_total + m] = (uint8_t)((d >= 0.0f ? 0 : 1) ^ (a.flip ? 1 : 0));
+        if ((int)s == a.write_dist_frame && a.adist) a.adist[m] = d;
+    }
+    if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f);
+}
+
 }  // namespace
 
 // ============================================================================================
@@ -665,6 +903,9 @@ struct gorder_hip_handle {
     uint8_t *d_aflags = nullptr;
     size_t aflags_rows = 0;
     float *d_adist = nullptr;
+    // Local leaflets scratch (sized for kLocalSlab assignment frames)
+    uint32_t *d_lcell_of = nullptr, *d_lcell_count = nullptr, *d_lcell_fill = nullptr, *d_lcell_atoms = nullptr;
+    float *d_ltrig = nullptr;
     uint32_t *d_arow = nullptr, *d_aframes = nullptr;
     size_t arow_cap = 0, aframes_cap = 0;
     bool have_assignment = false;
@@ -908,7 +1149,6 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
     if (t->ordermap.enabled || t->timewise) return GORDER_ERR_INVALID_ARGUMENT;
     for (uint32_t m = 0; m < t->n_molecule_types; m++)
         if (t->molecule_types[m].n_ua_atoms) return GORDER_ERR_INVALID_ARGUMENT;
-    if (t->leaflets.method == GORDER_LEAFLETS_LOCAL) return GORDER_ERR_INVALID_ARGUMENT;
 
     gorder_hip_handle *h = new (std::nothrow) gorder_hip_handle();
     if (!h) return GORDER_ERR_DEVICE;
@@ -1002,13 +1242,23 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
         if ((st = upload(h, &h->d_heads, heads)) != GORDER_OK) return st;
         if ((st = upload(h, &h->d_methyl_begin, mb)) != GORDER_OK) return st;
         if ((st = upload(h, &h->d_methyl_atoms, ma)) != GORDER_OK) return st;
-        if (lf.method == GORDER_LEAFLETS_GLOBAL) {
+        if (lf.method == GORDER_LEAFLETS_LOCAL && !(lf.radius > 0.0f))
+            return fail(h, GORDER_ERR_INVALID_ARGUMENT, "local leaflets need a positive radius");
+        if (lf.method == GORDER_LEAFLETS_GLOBAL || lf.method == GORDER_LEAFLETS_LOCAL) {
             if (!lf.membrane || lf.n_membrane == 0)
-                return fail(h, GORDER_ERR_INVALID_ARGUMENT, "global leaflets need the membrane group");
+                return fail(h, GORDER_ERR_INVALID_ARGUMENT, "global/local leaflets need the membrane group");
             std::vector<uint32_t> mem(lf.membrane, lf.membrane + lf.n_membrane);
             for (uint32_t a : mem)
                 if (a >= t->n_atoms) return fail(h, GORDER_ERR_INVALID_ARGUMENT, "membrane index out of range");
             if ((st = upload(h, &h->d_membrane, mem)) != GORDER_OK) return st;
+        }
+        if (lf.method == GORDER_LEAFLETS_LOCAL) {
+            const size_t nm = lf.n_membrane, ncell = (size_t)kLocalMaxCells1D * kLocalMaxCells1D;
+            HIP_TRY(h, hipMalloc((void **)&h->d_lcell_of, kLocalSlab * nm * sizeof(uint32_t)));
+            HIP_TRY(h, hipMalloc((void **)&h->d_lcell_atoms, kLocalSlab * nm * sizeof(uint32_t)));
+            HIP_TRY(h, hipMalloc((void **)&h->d_ltrig, kLocalSlab * nm * 6 * sizeof(float)));
+            HIP_TRY(h, hipMalloc((void **)&h->d_lcell_count, kLocalSlab * (ncell + 1) * sizeof(uint32_t)));
+            HIP_TRY(h, hipMalloc((void **)&h->d_lcell_fill, kLocalSlab * ncell * sizeof(uint32_t)));
         }
         HIP_TRY(h, hipMalloc((void **)&h->d_adist, sizeof(float) * (p.n_mol_total ? p.n_mol_total : 1)));
     }
@@ -1027,6 +1277,8 @@ void gorder_hip_destroy(gorder_hip_handle *h) {
     (void)hipFree(h->d_heads); (void)hipFree(h->d_membrane); (void)hipFree(h->d_methyl_begin);
     (void)hipFree(h->d_methyl_atoms); (void)hipFree(h->d_aflags); (void)hipFree(h->d_adist);
     (void)hipFree(h->d_arow); (void)hipFree(h->d_aframes);
+    (void)hipFree(h->d_lcell_of); (void)hipFree(h->d_lcell_count); (void)hipFree(h->d_lcell_fill);
+    (void)hipFree(h->d_lcell_atoms); (void)hipFree(h->d_ltrig);
     (void)hipFree(h->d_stage_xyz); (void)hipFree(h->d_stage_box);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -1089,6 +1341,31 @@ static int run_leaflets(gorder_hip_handle *h, const float *d_xyz, const float *d
             hipLaunchKernelGGL(k_leaflets_individual, dim3((la.n_mol_total + 255) / 256, ny), dim3(256), 0,
                                h->stream, lb);
             done += ny;
+        }
+    }
+    else if (lf.method == GORDER_LEAFLETS_LOCAL) {
+        const size_t ncell = (size_t)kLocalMaxCells1D * kLocalMaxCells1D;
+        LocalArgs lo{};
+        lo.xyz = d_xyz; lo.box9 = d_box; lo.n_atoms = h->plan.n_atoms;
+        lo.aflags = h->d_aflags; lo.adist = h->d_adist; lo.n_mol_total = h->plan.n_mol_total;
+        lo.heads = h->d_heads; lo.membrane = h->d_membrane; lo.n_membrane = lf.n_membrane;
+        lo.dim = lf.normal_dim; lo.flip = lf.flip ? 1 : 0; lo.pbc = h->tables.handle_pbc ? 1 : 0;
+        lo.radius = lf.radius;
+        lo.cell_of = h->d_lcell_of; lo.trig = h->d_ltrig; lo.cell_count = h->d_lcell_count;
+        lo.cell_fill = h->d_lcell_fill; lo.cell_atoms = h->d_lcell_atoms; lo.err = h->d_err;
+        for (size_t done = 0; done < aframes.size(); done += kLocalSlab) {
+            const uint32_t ns = (uint32_t)std::min<size_t>(aframes.size() - done, kLocalSlab);
+            lo.aframes = h->d_aframes + done;
+            lo.n_slab = ns;
+            lo.row0 = row0 + (uint32_t)done;
+            lo.write_dist_frame = (done + ns == aframes.size()) ? (int)ns - 1 : -1;
+            HIP_TRY(h, hipMemsetAsync(h->d_lcell_count, 0, ns * (ncell + 1) * sizeof(uint32_t), h->stream));
+            HIP_TRY(h, hipMemsetAsync(h->d_lcell_fill, 0, ns * ncell * sizeof(uint32_t), h->stream));
+            const dim3 ga((lf.n_membrane + 255) / 256, ns);
+            hipLaunchKernelGGL(k_local_bin, ga, dim3(256), 0, h->stream, lo);
+            hipLaunchKernelGGL(k_local_scan, dim3(ns), dim3(1024), 0, h->stream, lo);
+            hipLaunchKernelGGL(k_local_scatter, ga, dim3(256), 0, h->stream, lo);
+            hipLaunchKernelGGL(k_local_flags, dim3((lo.n_mol_total + 3) / 4, ns), dim3(256), 0, h->stream, lo);
         }
     }
     HIP_TRY(h, hipGetLastError());

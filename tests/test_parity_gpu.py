@@ -9,8 +9,8 @@ import numpy as np
 import pytest
 
 from gorder_amd import HipEngine, abi, synthetic
-from gorder_amd.abi import (LEAFLETS_GLOBAL, LEAFLETS_INDIVIDUAL, LEAFLETS_MANUAL, LEAFLETS_NONE, MolType,
-                            Tables)
+from gorder_amd.abi import (LEAFLETS_GLOBAL, LEAFLETS_INDIVIDUAL, LEAFLETS_LOCAL, LEAFLETS_MANUAL,
+                            LEAFLETS_NONE, MolType, Tables)
 from oracle import oracle
 
 pytestmark = pytest.mark.gpu
@@ -106,6 +106,31 @@ def test_cg_global_leaflets_mixed_types(built, flags):
     assert fr == ofr == n - 1
     np.testing.assert_array_equal(flags, oflags)
     np.testing.assert_allclose(eng.leaflet_distances(), odist, atol=2e-5)
+
+
+@pytest.mark.parametrize("pbc", [True, False])
+@pytest.mark.parametrize("radius,n_lipids", [(2.5, 800), (1.2, 300), (30.0, 120)])
+def test_local_leaflets(built, radius, n_lipids, pbc):
+    """Local classification (leaflets.rs:661-675 + pbc.rs:273-318): cylinder membership is restated with
+    identical f32 operations, so flags must agree unless a head sits within 1e-4 nm of its local centre."""
+    system = synthetic.cg_membrane(n_lipids, leaflets=LEAFLETS_LOCAL, radius=radius, n_types=2, handle_pbc=pbc)
+    n = 7
+    xyz = system.frames(n, seed=17)
+    if not pbc:
+        xyz = np.ascontiguousarray(xyz)
+    box = system.box9(n) if pbc else None
+    eng, got = run_gpu(system, xyz, box, batches=2)
+    o, want = run_oracle(system, xyz, box)
+    flags, fr = eng.leaflets()
+    oflags, odist, ofr = o.leaflets()
+    assert fr == ofr
+    diff = flags != oflags
+    assert not diff.any() or np.abs(odist[diff]).max() < 1e-4
+    np.testing.assert_allclose(eng.leaflet_distances()[~diff], odist[~diff], atol=5e-5)
+    assert 0 < flags.sum() < len(flags)
+    if not diff.any():
+        np.testing.assert_array_equal(got.sums, want.sums)
+        np.testing.assert_array_equal(got.counts, want.counts)
 
 
 @pytest.mark.parametrize("frequency", [0, 1, 5])
