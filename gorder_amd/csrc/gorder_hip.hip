@@ -508,6 +508,333 @@ __global__ __launch_bounds__(256) void k_bonds_direct(FrameArgs a, const DirectI
     }
 }
 
+
+// =============================================================================================
+// "Extras" kernels: ordermaps (ordermap.rs:100-113), timewise partial sums (timewise.rs:130-186,
+// 277-283) and the united-atom path (uaorder.rs:375-437, 947-1104).  These modes are bound by their
+// scatter atomics, not by the coordinate stream, so they use a plain structure: a thread owns one
+// sample (or one united-atom carbon), gathers its atoms straight from global memory and walks the
+// frames of its chunk one by one.  The main accumulators are kept in registers exactly like K1.
+// =============================================================================================
+struct ExtraArgs {
+    int maps;                        // ordermaps on
+    uint32_t plane;                  // 0 xy, 1 xz, 2 yz -> (z, y)   (input/ordermap.rs:44-50)
+    float x0, y0, binx, biny;
+    uint32_t nx, ny;
+    unsigned long long *map_sums;    // [3][n_acc][nx*ny]
+    unsigned long long *map_cnts;    // [3][n_acc][nx*ny]
+    int tw;                          // timewise on
+    unsigned long long *tw_sums;     // [rows][3][n_acc]
+    unsigned long long *tw_cnts;     // [rows][3][n_acc]
+    unsigned long long tw_row0;      // row of this batch's frame 0
+    // united atoms: sin/cos of the construction angles, evaluated on the host with libm like the reference
+    float sin_tet, cos_tet, sin_ch3, cos_ch3, sin_half, cos_half;
+};
+
+// groan_rs GridMap::get_mut_at: nearest tile centre, None outside (oracle: gridmap_index)
+__device__ __forceinline__ int grid_index(float x, float lo, float bin, uint32_t n) {
+    const float k = __builtin_roundf((x - lo) / bin);
+    if (!(k >= 0.0f) || !(k < (float)n)) return -1;
+    return (int)k;
+}
+
+// BondLike::add_order for the scatter targets (bond.rs:184-215): maps and the per-frame LDS partials
+__device__ __forceinline__ void extras_add(const FrameArgs &a, const ExtraArgs &e, uint32_t gslot, uint32_t lslot,
+                                           int tick, float px, float py, float pz, int leaflet /* -1 none */,
+                                           int *l_tw, uint32_t *l_twn, uint32_t lstride) {
+    if (e.maps) {
+        float x, y;
+        if (e.plane == 0) { x = px; y = py; }
+        else if (e.plane == 1) { x = px; y = pz; }
+        else { x = pz; y = py; }
+        const int ix = grid_index(x, e.x0, e.binx, e.nx), iy = grid_index(y, e.y0, e.biny, e.ny);
+        if (ix >= 0 && iy >= 0) {
+            const size_t nt = (size_t)e.nx * e.ny, t = (size_t)ix * e.ny + (size_t)iy;
+            atomicAdd(&e.map_sums[((size_t)gslot) * nt + t], (unsigned long long)(long long)tick);
+            atomicAdd(&e.map_cnts[((size_t)gslot) * nt + t], 1ull);
+            if (leaflet >= 0) {
+                const size_t w = (size_t)(1 + leaflet) * a.n_acc + gslot;
+                atomicAdd(&e.map_sums[w * nt + t], (unsigned long long)(long long)tick);
+                atomicAdd(&e.map_cnts[w * nt + t], 1ull);
+            }
+        }
+    }
+    if (e.tw) {
+        atomicAdd(&l_tw[lslot], tick);
+        atomicAdd(&l_twn[lslot], 1u);
+        if (leaflet >= 0) {
+            atomicAdd(&l_tw[(1 + leaflet) * lstride + lslot], tick);
+            atomicAdd(&l_twn[(1 + leaflet) * lstride + lslot], 1u);
+        }
+    }
+}
+
+// flush the block's per-frame partial sums to the timewise rows (one frame)
+__device__ __forceinline__ void extras_flush_tw(const FrameArgs &a, const ExtraArgs &e, const uint32_t *slots,
+                                                uint32_t n_slots, uint32_t f, int *l_tw, uint32_t *l_twn,
+                                                uint32_t lstride) {
+    for (uint32_t ls = threadIdx.x; ls < n_slots; ls += blockDim.x) {
+        const size_t row = ((size_t)e.tw_row0 + f) * 3u * a.n_acc;
+        for (uint32_t w = 0; w < 3; w++) {
+            const uint32_t n = l_twn[w * lstride + ls];
+            if (n) {
+                atomicAdd(&e.tw_sums[row + (size_t)w * a.n_acc + slots[ls]],
+                          (unsigned long long)(long long)l_tw[w * lstride + ls]);
+                atomicAdd(&e.tw_cnts[row + (size_t)w * a.n_acc + slots[ls]], (unsigned long long)n);
+            }
+            l_tw[w * lstride + ls] = 0;
+            l_twn[w * lstride + ls] = 0;
+        }
+    }
+}
+
+template <bool ACOS_COS>
+__global__ __launch_bounds__(kBlock) void k_bonds_extras(FrameArgs a_in, ExtraArgs e, const float *__restrict__ xyz,
+                                                          const float *__restrict__ box9,
+                                                          const uint8_t *__restrict__ aflags,
+                                                          const uint32_t *__restrict__ arow,
+                                                          const Tile *__restrict__ tiles,
+                                                          const Item *__restrict__ items,
+                                                          const uint32_t *__restrict__ tile_slots, uint32_t n_tiles) {
+    __shared__ unsigned long long l_s[2 * kBlock];
+    __shared__ uint32_t l_n[2 * kBlock];
+    __shared__ int l_tw[3 * kBlock];
+    __shared__ uint32_t l_twn[3 * kBlock];
+    FrameArgs a = a_in;
+    a.xyz = xyz; a.box9 = box9; a.aflags = aflags; a.arow = arow;
+    const uint32_t tile_id = blockIdx.x % n_tiles, chunk = blockIdx.x / n_tiles;
+    const Tile t = tiles[tile_id];
+    const uint32_t tid = threadIdx.x;
+    const bool active = tid < t.n_items;
+    Item it{0, 0, 0, 0, 0};
+    if (active) it = items[t.item0 + tid];
+    const uint32_t gslot = active ? tile_slots[t.slot0 + it.lslot] : 0;
+    const uint32_t f_begin = chunk * a.frames_per_chunk;
+    const uint32_t f_end = min(a.n_frames, f_begin + a.frames_per_chunk);
+    const size_t fstride = (size_t)a.n_atoms * 3u;
+    const float *pi = xyz + ((size_t)t.atom0 + it.li) * 3u;
+    const float *pj = xyz + ((size_t)t.atom0 + it.lj) * 3u;
+    for (uint32_t k = tid; k < 3 * kBlock; k += kBlock) { l_tw[k] = 0; l_twn[k] = 0; }
+    __syncthreads();
+    SampleAcc acc;
+    int bad = 0;
+    for (uint32_t f = f_begin; f < f_end; f++) {
+        if (active) {
+            const float *q1 = pi + (size_t)f * fstride, *q2 = pj + (size_t)f * fstride;
+            const float p1x = q1[0], p1y = q1[1], p1z = q1[2];
+            float vx = q2[0] - p1x, vy = q2[1] - p1y, vz = q2[2] - p1z;
+            if (a.pbc) {
+                const float *b = a.box9 + 9 * (size_t)f;
+                vx = gm_min_image(vx, b[0], bad);
+                vy = gm_min_image(vy, b[4], bad);
+                vz = gm_min_image(vz, b[8], bad);
+            }
+            const float sch = gm_calc_sch<ACOS_COS>(vx, vy, vz, a.nx, a.ny, a.nz, a.n2, a.n2sq);
+            if (sch != sch) {
+                if (p1x != p1x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, t.atom0 + it.li, f);
+                else if (q2[0] != q2[0]) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, t.atom0 + it.lj, f);
+            }
+            const int tick = gm_tick(sch);
+            int leaflet = -1;
+            if (a.leaflets) leaflet = a.aflags[(size_t)a.arow[f] * a.n_mol_total + it.mol] ? 1 : 0;
+            acc.s_tot += tick;
+            acc.n_tot += 1;
+            if (leaflet == 0) { acc.s_up += tick; acc.n_up += 1; }
+            // bond position = p1 + v / 2 (bond.rs:422)
+            extras_add(a, e, gslot, it.lslot, tick, p1x + vx / 2.0f, p1y + vy / 2.0f, p1z + vz / 2.0f, leaflet, l_tw,
+                       l_twn, kBlock);
+        }
+        if (e.tw) {
+            __syncthreads();
+            extras_flush_tw(a, e, tile_slots + t.slot0, t.n_slots, f, l_tw, l_twn, kBlock);
+            __syncthreads();
+        }
+    }
+    if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f_begin);
+    l_s[tid] = 0; l_s[kBlock + tid] = 0; l_n[tid] = 0; l_n[kBlock + tid] = 0;
+    __syncthreads();
+    if (active && acc.n_tot) {
+        atomicAdd(&l_s[it.lslot], (unsigned long long)acc.s_tot);
+        atomicAdd(&l_n[it.lslot], acc.n_tot);
+        if (acc.n_up) {
+            atomicAdd(&l_s[kBlock + it.lslot], (unsigned long long)acc.s_up);
+            atomicAdd(&l_n[kBlock + it.lslot], acc.n_up);
+        }
+    }
+    __syncthreads();
+    if (tid < t.n_slots && l_n[tid]) {
+        unsigned long long *accp = a.rep + (size_t)(blockIdx.x % a.n_rep) * 4u * a.n_acc;
+        const uint32_t slot = tile_slots[t.slot0 + tid];
+        atomicAdd(&accp[slot], l_s[tid]);
+        atomicAdd(&accp[2u * a.n_acc + slot], (unsigned long long)l_n[tid]);
+        if (l_n[kBlock + tid]) {
+            atomicAdd(&accp[a.n_acc + slot], l_s[kBlock + tid]);
+            atomicAdd(&accp[3u * a.n_acc + slot], (unsigned long long)l_n[kBlock + tid]);
+        }
+    }
+}
+
+// ---- united atoms: hydrogen construction, restating uaorder.rs:947-1104 with the operation order of
+// nalgebra's Rotation3::from_axis_angle / matrix * vector and groan_rs' shift / wrap (oracle:
+// gorder_oracle_predict_hydrogens).  All f32, no FMA.
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 v3_cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ float v3_norm(V3 a) { return __builtin_sqrtf((a.x * a.x + a.y * a.y) + a.z * a.z); }
+__device__ __forceinline__ V3 v3_unit(V3 a) { const float n = v3_norm(a); return {a.x / n, a.y / n, a.z / n}; }
+__device__ __forceinline__ V3 v3_rotate(V3 u, float s, float c, V3 v) {
+    const float sqx = u.x * u.x, sqy = u.y * u.y, sqz = u.z * u.z, omc = 1.0f - c;
+    const float m11 = sqx + (1.0f - sqx) * c, m12 = u.x * u.y * omc - u.z * s, m13 = u.x * u.z * omc + u.y * s;
+    const float m21 = u.x * u.y * omc + u.z * s, m22 = sqy + (1.0f - sqy) * c, m23 = u.y * u.z * omc - u.x * s;
+    const float m31 = u.x * u.z * omc - u.y * s, m32 = u.y * u.z * omc + u.x * s, m33 = sqz + (1.0f - sqz) * c;
+    return {(m11 * v.x + m12 * v.y) + m13 * v.z, (m21 * v.x + m22 * v.y) + m23 * v.z,
+            (m31 * v.x + m32 * v.y) + m33 * v.z};
+}
+__device__ __forceinline__ V3 v3_to(V3 p1, V3 p2, const float *box, bool pbc, int &bad) {
+    V3 v{p2.x - p1.x, p2.y - p1.y, p2.z - p1.z};
+    if (pbc) { v.x = gm_min_image(v.x, box[0], bad); v.y = gm_min_image(v.y, box[1], bad); v.z = gm_min_image(v.z, box[2], bad); }
+    return v;
+}
+__device__ __forceinline__ V3 v3_shift_wrap(V3 t, V3 dir, const float *box, bool pbc, int &bad) {
+    const V3 u = v3_unit(dir);
+    V3 h{t.x + u.x * 0.109f, t.y + u.y * 0.109f, t.z + u.z * 0.109f};   // BOND_LENGTH, uaorder.rs:39
+    if (pbc) { h.x = gm_wrap(h.x, box[0], bad); h.y = gm_wrap(h.y, box[1], bad); h.z = gm_wrap(h.z, box[2], bad); }
+    return h;
+}
+
+template <bool ACOS_COS>
+__global__ __launch_bounds__(kBlock) void k_ua_extras(FrameArgs a_in, ExtraArgs e, const float *__restrict__ xyz,
+                                                       const float *__restrict__ box9,
+                                                       const uint8_t *__restrict__ aflags,
+                                                       const uint32_t *__restrict__ arow,
+                                                       const Tile *__restrict__ tiles,
+                                                       const gorder::UaItem *__restrict__ items,
+                                                       const uint32_t *__restrict__ tile_slots, uint32_t n_tiles) {
+    constexpr uint32_t LS = 3 * kBlock;   // local slots per block (<= 3 hydrogens per carbon)
+    __shared__ unsigned long long l_s[2 * LS];
+    __shared__ uint32_t l_n[2 * LS];
+    __shared__ int l_tw[3 * LS];
+    __shared__ uint32_t l_twn[3 * LS];
+    FrameArgs a = a_in;
+    a.xyz = xyz; a.box9 = box9; a.aflags = aflags; a.arow = arow;
+    const uint32_t tile_id = blockIdx.x % n_tiles, chunk = blockIdx.x / n_tiles;
+    const Tile t = tiles[tile_id];
+    const uint32_t tid = threadIdx.x;
+    const bool active = tid < t.n_items;
+    gorder::UaItem it{};
+    if (active) it = items[t.item0 + tid];
+    const uint32_t kind = it.kind;
+    const int nh = kind == GORDER_UA_CH3 ? 3 : (kind == GORDER_UA_CH2 ? 2 : 1);
+    const uint32_t gslot0 = active ? tile_slots[t.slot0 + it.lslot0] : 0;
+    const uint32_t f_begin = chunk * a.frames_per_chunk;
+    const uint32_t f_end = min(a.n_frames, f_begin + a.frames_per_chunk);
+    const size_t fstride = (size_t)a.n_atoms * 3u;
+    for (uint32_t k = tid; k < 3 * LS; k += kBlock) { l_tw[k] = 0; l_twn[k] = 0; }
+    for (uint32_t k = tid; k < 2 * LS; k += kBlock) { l_s[k] = 0; l_n[k] = 0; }
+    __syncthreads();
+    long long s_tot[3] = {0, 0, 0}, s_up[3] = {0, 0, 0};
+    uint32_t n_tot = 0, n_up = 0;
+    int bad = 0;
+    const bool pbc = a.pbc != 0;
+    for (uint32_t f = f_begin; f < f_end; f++) {
+        if (active) {
+            float box[3] = {1.0f, 1.0f, 1.0f};
+            if (pbc) { const float *b = a.box9 + 9 * (size_t)f; box[0] = b[0]; box[1] = b[4]; box[2] = b[8]; }
+            V3 P[4];
+            const int nidx = kind == GORDER_UA_CH1_SAT ? 4 : 3;
+            for (int q = 0; q < nidx; q++) {
+                const float *p = xyz + (size_t)f * fstride + ((size_t)t.atom0 + it.l[q]) * 3u;
+                P[q] = {p[0], p[1], p[2]};
+                if (p[0] != p[0]) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, t.atom0 + it.l[q], f);
+            }
+            V3 H[3];
+            V3 target;
+            if (kind == GORDER_UA_CH3) {            // uaorder.rs:947-981
+                target = P[1];
+                const V3 th1 = v3_to(target, P[0], box, pbc, bad), th2 = v3_to(target, P[2], box, pbc, bad);
+                const V3 ua = v3_unit(v3_cross(th2, th1));
+                const V3 hv1 = v3_rotate(ua, e.sin_tet, e.cos_tet, th1);
+                H[0] = v3_shift_wrap(target, hv1, box, pbc, bad);
+                const V3 n1 = v3_unit(th1);
+                H[1] = v3_shift_wrap(target, v3_rotate(n1, e.sin_ch3, e.cos_ch3, hv1), box, pbc, bad);
+                H[2] = v3_shift_wrap(target, v3_rotate(n1, -e.sin_ch3, e.cos_ch3, hv1), box, pbc, bad);
+            } else if (kind == GORDER_UA_CH2) {     // uaorder.rs:985-1020
+                target = P[1];
+                const V3 th1 = v3_unit(v3_to(target, P[0], box, pbc, bad)), th2 = v3_unit(v3_to(target, P[2], box, pbc, bad));
+                const V3 pn = v3_cross(th2, th1);
+                const V3 ra = v3_unit(V3{th1.x - th2.x, th1.y - th2.y, th1.z - th2.z});
+                const V3 rv = v3_cross(pn, ra);
+                const V3 ura = v3_unit(ra);
+                H[0] = v3_shift_wrap(target, v3_rotate(ura, e.sin_half, e.cos_half, rv), box, pbc, bad);
+                H[1] = v3_shift_wrap(target, v3_rotate(ura, -e.sin_half, e.cos_half, rv), box, pbc, bad);
+            } else if (kind == GORDER_UA_CH1_UNSAT) {   // uaorder.rs:1024-1045
+                target = P[1];
+                const V3 th1 = v3_to(target, P[0], box, pbc, bad), th2 = v3_to(target, P[2], box, pbc, bad);
+                const float prod = (th1.x * th2.x + th1.y * th2.y) + th1.z * th2.z;
+                const float n1 = v3_norm(th1), n2 = v3_norm(th2);
+                float gamma = 0.0f;
+                if (!(n1 == 0.0f || n2 == 0.0f)) {
+                    float c = prod / (n1 * n2);
+                    c = c < -1.0f ? -1.0f : (c > 1.0f ? 1.0f : c);
+                    gamma = gm_acosf(c);
+                }
+                const float ang = 3.14159265358979323846f - (gamma / 2.0f);
+                float sn, cs;
+                sincosf(ang, &sn, &cs);
+                const V3 ua = v3_unit(v3_cross(th1, th2));
+                H[0] = v3_shift_wrap(target, ang == 0.0f ? th2 : v3_rotate(ua, sn, cs, th2), box, pbc, bad);
+            } else {                                 // CH1 saturated, uaorder.rs:1087-1104 (h1,h2,h3,target)
+                target = P[3];
+                const V3 t1 = v3_unit(v3_to(target, P[0], box, pbc, bad)), t2 = v3_unit(v3_to(target, P[1], box, pbc, bad)),
+                         t3 = v3_unit(v3_to(target, P[2], box, pbc, bad));
+                H[0] = v3_shift_wrap(target, V3{-((t1.x + t2.x) + t3.x), -((t1.y + t2.y) + t3.y), -((t1.z + t2.z) + t3.z)},
+                                     box, pbc, bad);
+            }
+            int leaflet = -1;
+            if (a.leaflets) leaflet = a.aflags[(size_t)a.arow[f] * a.n_mol_total + it.mol] ? 1 : 0;
+            for (int k = 0; k < nh; k++) {
+                // UAAtom::calculate_sch, uaorder.rs:375-397: vec = target -> H, bond position = H + vec / 2 (sic)
+                const V3 v = v3_to(target, H[k], box, pbc, bad);
+                const float sch = gm_calc_sch<ACOS_COS>(v.x, v.y, v.z, a.nx, a.ny, a.nz, a.n2, a.n2sq);
+                const int tick = gm_tick(sch);
+                s_tot[k] += tick;
+                if (leaflet == 0) s_up[k] += tick;
+                extras_add(a, e, gslot0 + (uint32_t)k, it.lslot0 + (uint32_t)k, tick, H[k].x + v.x / 2.0f,
+                           H[k].y + v.y / 2.0f, H[k].z + v.z / 2.0f, leaflet, l_tw, l_twn, LS);
+            }
+            n_tot += 1;
+            if (leaflet == 0) n_up += 1;
+        }
+        if (e.tw) {
+            __syncthreads();
+            extras_flush_tw(a, e, tile_slots + t.slot0, t.n_slots, f, l_tw, l_twn, LS);
+            __syncthreads();
+        }
+    }
+    if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f_begin);
+    if (active && n_tot) {
+        for (int k = 0; k < nh; k++) {
+            atomicAdd(&l_s[it.lslot0 + k], (unsigned long long)s_tot[k]);
+            atomicAdd(&l_n[it.lslot0 + k], n_tot);
+            if (n_up) {
+                atomicAdd(&l_s[LS + it.lslot0 + k], (unsigned long long)s_up[k]);
+                atomicAdd(&l_n[LS + it.lslot0 + k], n_up);
+            }
+        }
+    }
+    __syncthreads();
+    unsigned long long *accp = a.rep + (size_t)(blockIdx.x % a.n_rep) * 4u * a.n_acc;
+    for (uint32_t ls = tid; ls < t.n_slots; ls += kBlock) {
+        if (!l_n[ls]) continue;
+        const uint32_t slot = tile_slots[t.slot0 + ls];
+        atomicAdd(&accp[slot], l_s[ls]);
+        atomicAdd(&accp[2u * a.n_acc + slot], (unsigned long long)l_n[ls]);
+        if (l_n[LS + ls]) {
+            atomicAdd(&accp[a.n_acc + slot], l_s[LS + ls]);
+            atomicAdd(&accp[3u * a.n_acc + slot], (unsigned long long)l_n[LS + ls]);
+        }
+    }
+}
+
 // ---- leaflets ------------------------------------------------------------------------------
 struct LeafletArgs {
     const float *xyz;
@@ -891,6 +1218,15 @@ struct gorder_hip_handle {
     Item *d_items = nullptr;
     uint32_t *d_tile_slots = nullptr;
     DirectItem *d_direct = nullptr;
+    Tile *d_ua_tiles = nullptr;
+    gorder::UaItem *d_ua_items = nullptr;
+    uint32_t *d_ua_tile_slots = nullptr;
+    // ordermaps [3][n_acc][nx*ny] and timewise rows [cap][3][n_acc]
+    uint32_t map_nx = 0, map_ny = 0;
+    unsigned long long *d_map_sums = nullptr, *d_map_cnts = nullptr;
+    unsigned long long *d_tw_sums = nullptr, *d_tw_cnts = nullptr;
+    uint64_t tw_cap = 0;
+    ExtraArgs extra{};
     uint32_t *d_err = nullptr;
     unsigned long long *d_acc = nullptr;   // [4][n_acc] + total_frames
     unsigned long long *d_rep = nullptr;   // [n_rep][4][n_acc] (see k_fold_replicas)
@@ -1002,7 +1338,8 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
     HIP_TRY(h, hipEventCreate(&e0));
     HIP_TRY(h, hipEventCreate(&e1));
     HIP_TRY(h, hipEventRecord(e0, h->stream));
-    if (n_tiles) {
+    const bool extras = h->extra.maps || h->extra.tw;
+    if (n_tiles && !extras) {
         // enough workgroups to fill 256 CUs x 8 blocks, frames split into chunks of whole stages
         // Cut the frame range into chunks of whole stages.  All workgroups do the same amount of work,
         // so the grid should be a whole number of co-resident rounds: exactly one round when the tiles
@@ -1055,13 +1392,9 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
             }                                                                                               \
         } while (0)
         if (h->use_gather) {
-            switch (h->frames_per_stage) {
-                case 2: GORDER_LAUNCH_GATHER(2); break;
-                default: GORDER_LAUNCH_GATHER(4); break;
-            }
+            GORDER_LAUNCH_GATHER(4);
         } else {
             switch (h->frames_per_stage) {
-                case 2: GORDER_LAUNCH_TILED(2, 3); break;
                 case 8: GORDER_LAUNCH_TILED(8, 10); break;
                 default: GORDER_LAUNCH_TILED(4, 5); break;
             }
@@ -1071,6 +1404,35 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
 #undef GORDER_LAUNCH_TILED_V
 #undef GORDER_LAUNCH_TILED
         HIP_TRY(h, hipGetLastError());
+    }
+    if (extras || !p.ua_tiles.empty()) {
+        // scatter-bound modes: plain per-sample kernels (see "Extras" above)
+        ExtraArgs e = h->extra;
+        e.tw_sums = h->d_tw_sums; e.tw_cnts = h->d_tw_cnts; e.tw_row0 = h->n_frames;
+        const bool ac = (h->tables.flags & GORDER_FLAG_TRIG_ACOS_COS) != 0;
+        for (int pass = 0; pass < 2; pass++) {
+            const uint32_t nt = pass == 0 ? (extras ? n_tiles : 0u) : (uint32_t)p.ua_tiles.size();
+            if (!nt) continue;
+            uint32_t n_chunks = std::max(1u, (h->wg_target ? h->wg_target : 8u * h->wg_capacity) / nt);
+            n_chunks = std::min(n_chunks, a.n_frames);
+            const uint32_t fpc = (a.n_frames + n_chunks - 1) / n_chunks;
+            n_chunks = (a.n_frames + fpc - 1) / fpc;
+            FrameArgs b = a;
+            b.frames_per_chunk = fpc;
+            const dim3 g(nt * n_chunks), blk(kBlock);
+            if (pass == 0) {
+                if (ac) hipLaunchKernelGGL(k_bonds_extras<true>, g, blk, 0, h->stream, b, e, b.xyz, b.box9, b.aflags, b.arow,
+                                           h->d_tiles, h->d_items, h->d_tile_slots, nt);
+                else hipLaunchKernelGGL(k_bonds_extras<false>, g, blk, 0, h->stream, b, e, b.xyz, b.box9, b.aflags, b.arow,
+                                        h->d_tiles, h->d_items, h->d_tile_slots, nt);
+            } else {
+                if (ac) hipLaunchKernelGGL(k_ua_extras<true>, g, blk, 0, h->stream, b, e, b.xyz, b.box9, b.aflags, b.arow,
+                                           h->d_ua_tiles, h->d_ua_items, h->d_ua_tile_slots, nt);
+                else hipLaunchKernelGGL(k_ua_extras<false>, g, blk, 0, h->stream, b, e, b.xyz, b.box9, b.aflags, b.arow,
+                                        h->d_ua_tiles, h->d_ua_items, h->d_ua_tile_slots, nt);
+            }
+            HIP_TRY(h, hipGetLastError());
+        }
     }
     if (!p.direct.empty()) {
         const uint32_t n_items = (uint32_t)p.direct.size();
@@ -1145,10 +1507,6 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return GORDER_ERR_NO_DEVICE;
     if (t->device < 0 || t->device >= n_dev) return GORDER_ERR_INVALID_ARGUMENT;
-    // features of the ABI that this build does not implement yet fail loudly, never silently
-    if (t->ordermap.enabled || t->timewise) return GORDER_ERR_INVALID_ARGUMENT;
-    for (uint32_t m = 0; m < t->n_molecule_types; m++)
-        if (t->molecule_types[m].n_ua_atoms) return GORDER_ERR_INVALID_ARGUMENT;
 
     gorder_hip_handle *h = new (std::nothrow) gorder_hip_handle();
     if (!h) return GORDER_ERR_DEVICE;
@@ -1167,6 +1525,40 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
     if ((st = upload(h, &h->d_items, p.items)) != GORDER_OK) return st;
     if ((st = upload(h, &h->d_tile_slots, p.tile_slots)) != GORDER_OK) return st;
     if ((st = upload(h, &h->d_direct, p.direct)) != GORDER_OK) return st;
+    if ((st = upload(h, &h->d_ua_tiles, p.ua_tiles)) != GORDER_OK) return st;
+    if ((st = upload(h, &h->d_ua_items, p.ua_items)) != GORDER_OK) return st;
+    if ((st = upload(h, &h->d_ua_tile_slots, p.ua_tile_slots)) != GORDER_OK) return st;
+    {
+        ExtraArgs &e = h->extra;
+        // construction angles of the united-atom hydrogens (uaorder.rs:34-41); sin/cos with the host
+        // libm, as the reference's nalgebra Rotation3::from_axis_angle does
+        e.sin_tet = sinf(1.910633f); e.cos_tet = cosf(1.910633f);
+        e.sin_ch3 = sinf(2.0943952f); e.cos_ch3 = cosf(2.0943952f);
+        e.sin_half = sinf(0.9553165f); e.cos_half = cosf(0.9553165f);
+        const gorder_ordermap_t &om = t->ordermap;
+        if (om.enabled) {
+            if (!(om.bin[0] > 0.0f) || !(om.bin[1] > 0.0f) || om.plane > 2)
+                return fail(h, GORDER_ERR_INVALID_ARGUMENT, "ordermap bin/plane");
+            // groan_rs GridMap::new: n = round(span / bin) + 1 tiles per axis
+            const float fx = roundf((om.span_x[1] - om.span_x[0]) / om.bin[0]);
+            const float fy = roundf((om.span_y[1] - om.span_y[0]) / om.bin[1]);
+            if (!(fx >= 0.0f) || !(fy >= 0.0f) || fx > 65535.0f || fy > 65535.0f)
+                return fail(h, GORDER_ERR_INVALID_ARGUMENT, "ordermap span");
+            h->map_nx = (uint32_t)fx + 1u;
+            h->map_ny = (uint32_t)fy + 1u;
+            const size_t nmap = 3 * (size_t)p.n_acc * h->map_nx * h->map_ny;
+            HIP_TRY(h, hipMalloc((void **)&h->d_map_sums, nmap * sizeof(unsigned long long)));
+            HIP_TRY(h, hipMalloc((void **)&h->d_map_cnts, nmap * sizeof(unsigned long long)));
+            HIP_TRY(h, hipMemset(h->d_map_sums, 0, nmap * sizeof(unsigned long long)));
+            HIP_TRY(h, hipMemset(h->d_map_cnts, 0, nmap * sizeof(unsigned long long)));
+            e.maps = 1; e.plane = om.plane; e.x0 = om.span_x[0]; e.y0 = om.span_y[0];
+            e.binx = om.bin[0]; e.biny = om.bin[1]; e.nx = h->map_nx; e.ny = h->map_ny;
+            e.map_sums = h->d_map_sums; e.map_cnts = h->d_map_cnts;
+        }
+        e.tw = t->timewise ? 1 : 0;
+        if ((e.maps || e.tw) && !p.direct.empty())
+            return fail(h, GORDER_ERR_INVALID_ARGUMENT, "ordermaps / timewise need every bond to fit an atom window");
+    }
     HIP_TRY(h, hipMalloc((void **)&h->d_err, kErrWords * sizeof(uint32_t)));
     HIP_TRY(h, hipMemset(h->d_err, 0, kErrWords * sizeof(uint32_t)));
     h->acc_words = 4 * (size_t)p.n_acc + 1;
@@ -1188,7 +1580,7 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
     }
     if (const char *e = getenv("GORDER_HIP_FRAMES_PER_STAGE")) {
         const int g = atoi(e);
-        if (g == 2 || g == 4 || g == 8) h->frames_per_stage = g;
+        if (g == 4 || g == 8) h->frames_per_stage = g;
     }
     if (const char *e = getenv("GORDER_HIP_KERNEL")) h->use_gather = strcmp(e, "gather") == 0;
     if (const char *e = getenv("GORDER_HIP_WG_TARGET")) {
@@ -1205,8 +1597,6 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
         const bool ac = (t->flags & GORDER_FLAG_TRIG_ACOS_COS) != 0;
         hipError_t e;
         switch (h->frames_per_stage) {
-            case 2: e = ac ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bonds_tiled<2, 3, true, true, false>, kBlock, h->lds_bytes)
-                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bonds_tiled<2, 3, false, true, false>, kBlock, h->lds_bytes); break;
             case 8: e = ac ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bonds_tiled<8, 10, true, true, false>, kBlock, h->lds_bytes)
                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bonds_tiled<8, 10, false, true, false>, kBlock, h->lds_bytes); break;
             default: e = ac ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bonds_tiled<4, 5, true, true, false>, kBlock, h->lds_bytes)
@@ -1272,6 +1662,8 @@ void gorder_hip_destroy(gorder_hip_handle *h) {
     for (auto &ev : h->timing) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     (void)hipFree(h->d_tiles); (void)hipFree(h->d_items); (void)hipFree(h->d_tile_slots);
     (void)hipFree(h->d_direct); (void)hipFree(h->d_err);
+    (void)hipFree(h->d_ua_tiles); (void)hipFree(h->d_ua_items); (void)hipFree(h->d_ua_tile_slots);
+    (void)hipFree(h->d_map_sums); (void)hipFree(h->d_map_cnts); (void)hipFree(h->d_tw_sums); (void)hipFree(h->d_tw_cnts);
     if (!h->acc_external) (void)hipFree(h->d_acc);
     (void)hipFree(h->d_rep);
     (void)hipFree(h->d_heads); (void)hipFree(h->d_membrane); (void)hipFree(h->d_methyl_begin);
@@ -1285,10 +1677,10 @@ void gorder_hip_destroy(gorder_hip_handle *h) {
 }
 
 uint32_t gorder_hip_n_accumulators(const gorder_hip_handle *h) { return h ? h->plan.n_acc : 0; }
-uint32_t gorder_hip_ordermap_dims(const gorder_hip_handle *, uint32_t *nx, uint32_t *ny) {
-    if (nx) *nx = 0;
-    if (ny) *ny = 0;
-    return 0;
+uint32_t gorder_hip_ordermap_dims(const gorder_hip_handle *h, uint32_t *nx, uint32_t *ny) {
+    if (nx) *nx = h ? h->map_nx : 0;
+    if (ny) *ny = h ? h->map_ny : 0;
+    return h ? h->map_nx * h->map_ny : 0;
 }
 
 int gorder_hip_set_stream(gorder_hip_handle *h, void *hip_stream) {
@@ -1429,6 +1821,23 @@ int gorder_hip_submit_device(gorder_hip_handle *h, const float *d_xyz, const flo
                            h->d_err);
         HIP_TRY(h, hipGetLastError());
     }
+    if (h->extra.tw && h->n_frames + n_frames > h->tw_cap) {   // grow the per-frame rows (timewise.rs:183-186)
+        const size_t row = 3 * (size_t)p.n_acc;
+        const uint64_t ncap = (h->n_frames + n_frames) * 2;
+        unsigned long long *ns = nullptr, *nc = nullptr;
+        HIP_TRY(h, hipMalloc((void **)&ns, ncap * row * sizeof(unsigned long long)));
+        HIP_TRY(h, hipMalloc((void **)&nc, ncap * row * sizeof(unsigned long long)));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, hipMemset(ns, 0, ncap * row * sizeof(unsigned long long)));
+        HIP_TRY(h, hipMemset(nc, 0, ncap * row * sizeof(unsigned long long)));
+        if (h->d_tw_sums) {
+            HIP_TRY(h, hipMemcpy(ns, h->d_tw_sums, h->n_frames * row * sizeof(unsigned long long), hipMemcpyDeviceToDevice));
+            HIP_TRY(h, hipMemcpy(nc, h->d_tw_cnts, h->n_frames * row * sizeof(unsigned long long), hipMemcpyDeviceToDevice));
+            HIP_TRY(h, hipFree(h->d_tw_sums));
+            HIP_TRY(h, hipFree(h->d_tw_cnts));
+        }
+        h->d_tw_sums = ns; h->d_tw_cnts = nc; h->tw_cap = ncap;
+    }
     FrameArgs a{};
     a.xyz = d_xyz; a.box9 = d_box; a.n_atoms = p.n_atoms; a.n_frames = n_frames;
     a.pbc = pbc ? 1 : 0;
@@ -1511,7 +1920,6 @@ int gorder_hip_synchronize(gorder_hip_handle *h) {
 int gorder_hip_finish(gorder_hip_handle *h, int64_t *sums, uint64_t *counts, int64_t *map_sums,
                       uint64_t *map_counts, uint64_t *n_frames_analyzed) {
     if (!h) return GORDER_ERR_INVALID_ARGUMENT;
-    (void)map_sums; (void)map_counts;
     int st = fold_replicas(h);
     if (st != GORDER_OK) return st;
     st = gorder_hip_synchronize(h);
@@ -1535,10 +1943,26 @@ int gorder_hip_finish(gorder_hip_handle *h, int64_t *sums, uint64_t *counts, int
         }
     }
     if (n_frames_analyzed) *n_frames_analyzed = raw[4 * (size_t)n];
+    if (h->extra.maps) {
+        const size_t nmap = 3 * (size_t)n * h->map_nx * h->map_ny;
+        if (map_sums) HIP_TRY(h, hipMemcpy(map_sums, h->d_map_sums, nmap * sizeof(int64_t), hipMemcpyDeviceToHost));
+        if (map_counts) HIP_TRY(h, hipMemcpy(map_counts, h->d_map_cnts, nmap * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    }
     return GORDER_OK;
 }
 
-int gorder_hip_timewise(gorder_hip_handle *, int64_t *, uint64_t *, uint64_t) { return GORDER_ERR_INVALID_ARGUMENT; }
+int gorder_hip_timewise(gorder_hip_handle *h, int64_t *tw_sums, uint64_t *tw_counts, uint64_t capacity_frames) {
+    if (!h || !h->extra.tw || !tw_sums || !tw_counts) return GORDER_ERR_INVALID_ARGUMENT;
+    if (capacity_frames < h->n_frames) return GORDER_ERR_INVALID_ARGUMENT;
+    const int st = gorder_hip_synchronize(h);
+    if (st != GORDER_OK) return st;
+    const size_t n = h->n_frames * 3 * (size_t)h->plan.n_acc;
+    if (n) {
+        HIP_TRY(h, hipMemcpy(tw_sums, h->d_tw_sums, n * sizeof(int64_t), hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(tw_counts, h->d_tw_cnts, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    }
+    return GORDER_OK;
+}
 
 int gorder_hip_leaflets(gorder_hip_handle *h, uint8_t *flags, uint64_t *assignment_frame) {
     if (!h) return GORDER_ERR_INVALID_ARGUMENT;

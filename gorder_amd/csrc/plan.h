@@ -37,6 +37,12 @@ struct Tile {
 struct DirectItem {
     uint32_t i, j, slot, mol;
 };
+struct UaItem {          // one united-atom carbon instance (uaorder.rs:911-915, 1050-1055), 16 bytes
+    uint16_t l[4];       // helper1,target,helper2,- (CH3/CH2/CH1 unsat) or h1,h2,h3,target (CH1 sat), window-relative
+    uint16_t lslot0;     // first local slot; hydrogen k uses lslot0 + k
+    uint16_t kind;       // gorder_ua_kind_t
+    uint32_t mol;
+};
 
 struct Plan {
     uint32_t n_atoms = 0, n_acc = 0, n_mol_total = 0;
@@ -45,12 +51,21 @@ struct Plan {
     std::vector<Item> items;
     std::vector<uint32_t> tile_slots;
     std::vector<DirectItem> direct;
+    // united-atom carbons: same tiling idea, separate item type; no direct fallback (the 3-4 atoms of one
+    // carbon are bonded neighbours — a tuple wider than kMaxWindow atoms is rejected)
+    std::vector<Tile> ua_tiles;
+    std::vector<UaItem> ua_items;
+    std::vector<uint32_t> ua_tile_slots;
     std::vector<uint32_t> mol0;    // first global molecule id per molecule type
     std::vector<uint32_t> slot0;   // first accumulator slot per molecule type
 };
 
 struct Sample {
     uint32_t i, j, slot, mol;
+};
+struct UaSample {
+    uint32_t a[4];
+    uint32_t slot0, kind, mol;
 };
 
 // Returns GORDER_OK or GORDER_ERR_INVALID_ARGUMENT (index out of range, self bond, ...).
@@ -59,6 +74,7 @@ inline int build_plan(const gorder_tables_t &t, bool force_direct, Plan &p) {
     p.n_atoms = t.n_atoms;
     if (t.n_atoms == 0 || (t.n_molecule_types && !t.molecule_types)) return GORDER_ERR_INVALID_ARGUMENT;
     std::vector<Sample> samples;
+    std::vector<UaSample> ua_samples;
     uint32_t slot = 0, mol = 0;
     for (uint32_t m = 0; m < t.n_molecule_types; m++) {
         const gorder_moltype_t &mt = t.molecule_types[m];
@@ -73,14 +89,72 @@ inline int build_plan(const gorder_tables_t &t, bool force_direct, Plan &p) {
             }
         }
         slot += mt.n_bond_types;
+        if (mt.n_ua_atoms && !mt.ua_atoms) return GORDER_ERR_INVALID_ARGUMENT;
         for (uint32_t a = 0; a < mt.n_ua_atoms; a++) {
             const uint32_t kind = mt.ua_atoms[a].kind;
+            if (kind < GORDER_UA_CH1_SAT || kind > GORDER_UA_CH1_UNSAT || !mt.ua_atoms[a].indices)
+                return GORDER_ERR_INVALID_ARGUMENT;
+            const uint32_t nidx = kind == GORDER_UA_CH1_SAT ? 4u : 3u;
+            for (uint32_t k = 0; k < mt.n_molecules; k++) {
+                const uint32_t *ix = mt.ua_atoms[a].indices + 4 * (size_t)k;
+                UaSample us{{ix[0], ix[1], ix[2], nidx == 4 ? ix[3] : ix[1]}, slot, kind, mol + k};
+                for (uint32_t q = 0; q < nidx; q++)
+                    if (ix[q] >= t.n_atoms) return GORDER_ERR_INVALID_ARGUMENT;
+                ua_samples.push_back(us);
+            }
             slot += kind == GORDER_UA_CH3 ? 3 : kind == GORDER_UA_CH2 ? 2 : 1;
         }
         mol += mt.n_molecules;
     }
     p.n_acc = slot;
     p.n_mol_total = mol;
+
+    {   // ---- united-atom tiles
+        auto ulo = [](const UaSample &u) { return std::min(std::min(u.a[0], u.a[1]), std::min(u.a[2], u.a[3])); };
+        auto uhi = [](const UaSample &u) { return std::max(std::max(u.a[0], u.a[1]), std::max(u.a[2], u.a[3])); };
+        std::stable_sort(ua_samples.begin(), ua_samples.end(), [&](const UaSample &x, const UaSample &y) {
+            if (ulo(x) != ulo(y)) return ulo(x) < ulo(y);
+            return uhi(x) < uhi(y);
+        });
+        size_t q = 0;
+        while (q < ua_samples.size()) {
+            const UaSample &first = ua_samples[q];
+            if (uhi(first) - ulo(first) + 1 > kMaxWindow) return GORDER_ERR_INVALID_ARGUMENT;
+            Tile tile{};
+            tile.atom0 = ulo(first);
+            tile.item0 = (uint32_t)p.ua_items.size();
+            tile.slot0 = (uint32_t)p.ua_tile_slots.size();
+            uint32_t top = uhi(first);
+            std::vector<uint32_t> slots;   // local slot list holds the FIRST slot of each carbon; 3 entries reserved
+            while (q < ua_samples.size() && tile.n_items < kBlock) {
+                const UaSample &u = ua_samples[q];
+                if (uhi(u) - ulo(u) + 1 > kMaxWindow) return GORDER_ERR_INVALID_ARGUMENT;
+                const uint32_t ntop = std::max(top, uhi(u));
+                if (ntop - tile.atom0 + 1 > kMaxWindow) break;
+                top = ntop;
+                const uint32_t nh = u.kind == GORDER_UA_CH3 ? 3 : u.kind == GORDER_UA_CH2 ? 2 : 1;
+                uint32_t ls = 0;
+                for (; ls < slots.size(); ls++)
+                    if (slots[ls] == u.slot0) break;
+                if (ls == slots.size()) {
+                    if (slots.size() + nh > 3 * kBlock) break;
+                    for (uint32_t h = 0; h < nh; h++) slots.push_back(u.slot0 + h);
+                }
+                UaItem it{};
+                for (int c = 0; c < 4; c++) it.l[c] = (uint16_t)(u.a[c] - tile.atom0);
+                it.lslot0 = (uint16_t)ls;
+                it.kind = (uint16_t)u.kind;
+                it.mol = u.mol;
+                p.ua_items.push_back(it);
+                tile.n_items++;
+                q++;
+            }
+            tile.n_window = top - tile.atom0 + 1;
+            tile.n_slots = (uint32_t)slots.size();
+            p.ua_tile_slots.insert(p.ua_tile_slots.end(), slots.begin(), slots.end());
+            p.ua_tiles.push_back(tile);
+        }
+    }
 
     auto lo = [](const Sample &s) { return std::min(s.i, s.j); };
     auto hi = [](const Sample &s) { return std::max(s.i, s.j); };

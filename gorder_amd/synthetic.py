@@ -188,3 +188,50 @@ def cg_membrane(n_lipids: int = 3072, box=None, seed: int = 7, leaflets: int = L
     t = Tables(n_atoms=n_atoms, molecule_types=mts, handle_pbc=handle_pbc, normal=normal, leaflets=lf,
                ordermap=ordermap or OrderMap(), timewise=timewise)
     return System(f"cg{n_lipids}", t, base, box, jitter=0.03)
+
+
+# ---- united-atom (Berger-like) lipid: 52 atoms, 32 order carbons with virtual hydrogens ----------
+def ua_membrane(n_lipids: int = 256, box=(9.0, 9.0, 8.0), seed: int = 11, leaflets: int = LEAFLETS_NONE,
+                frequency: int = 1, ordermap: Optional[OrderMap] = None, timewise: bool = False,
+                handle_pbc: bool = True, normal=(0.0, 0.0, 1.0), radius: float = 2.0) -> System:
+    """V-UA: n_lipids x 52 united atoms; atoms 10..41 are the order carbons:
+    26 CH2, 2 CH3, 2 CH1 (double bond) and 2 CH1 (saturated, three helpers) -> 62 virtual C-H bonds."""
+    from .abi import UA_CH1_SAT, UA_CH1_UNSAT, UA_CH2, UA_CH3
+    rng = np.random.default_rng(seed)
+    box = np.asarray(box, dtype=np.float32)
+    apl = 52
+    n_atoms = n_lipids * apl
+    base = np.zeros((n_lipids, apl, 3), dtype=np.float64)
+    zc = box[2] / 2
+    side = int(np.ceil(np.sqrt((n_lipids + 1) // 2)))
+    for m in range(n_lipids):
+        sgn = 1.0 if m % 2 == 0 else -1.0
+        g = m // 2
+        pos = np.array([(g % side + 0.5) * box[0] / side, (g // side + 0.5) * box[1] / side, zc + sgn * 2.2])
+        for k in range(apl):
+            d = rng.normal(size=3) * 0.6 + np.array([0.0, 0.0, -sgn])
+            pos = pos + 0.153 * d / np.linalg.norm(d)
+            base[m, k] = pos
+    base = np.mod(base.reshape(n_atoms, 3), box).astype(np.float32)
+    kinds = {10: UA_CH3, 41: UA_CH3, 20: UA_CH1_UNSAT, 21: UA_CH1_UNSAT, 15: UA_CH1_SAT, 30: UA_CH1_SAT}
+    off = np.arange(n_lipids, dtype=np.int64) * apl
+    ua_atoms = []
+    for c in range(10, 42):
+        kind = kinds.get(c, UA_CH2)
+        if kind == UA_CH3:           # helper1 = bonded neighbour, helper2 = next atom along the chain
+            h1, h2 = (c + 1, c + 2) if c == 10 else (c - 1, c - 2)
+            idx = np.stack([off + h1, off + c, off + h2, off + c], axis=1)
+        elif kind == UA_CH1_SAT:     # helper1..3, target
+            idx = np.stack([off + c - 1, off + c + 1, off + (c + 9) % apl, off + c], axis=1)
+        else:
+            idx = np.stack([off + c - 1, off + c, off + c + 1, off + c], axis=1)
+        ua_atoms.append((kind, idx.astype(np.uint32)))
+    heads = (off + 5).astype(np.uint32)
+    methyls = np.stack([off + 41, off + 51], axis=1).astype(np.uint32)
+    lf = Leaflets(method=leaflets, normal_dim=2, frequency=frequency, radius=radius,
+                  membrane=np.arange(n_atoms, dtype=np.uint32) if leaflets in (LEAFLETS_GLOBAL, LEAFLETS_LOCAL) else None)
+    mt = MolType(n_molecules=n_lipids, ua_atoms=ua_atoms, heads=heads if leaflets else None,
+                 methyls=methyls if leaflets == LEAFLETS_INDIVIDUAL else None, name="POPC")
+    t = Tables(n_atoms=n_atoms, molecule_types=[mt], handle_pbc=handle_pbc, normal=normal, leaflets=lf,
+               ordermap=ordermap or OrderMap(), timewise=timewise)
+    return System(f"ua{n_lipids}", t, base, box, jitter=0.01)

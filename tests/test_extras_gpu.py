@@ -1,0 +1,119 @@
+"""GPU parity for the scatter-bound modes: ordermaps (ordermap.rs:100-113), timewise partial sums
+(timewise.rs:130-186) and united-atom virtual hydrogens (uaorder.rs:375-437, 947-1104)."""
+import numpy as np
+import pytest
+
+from gorder_amd import HipEngine, abi, synthetic
+from gorder_amd.abi import (LEAFLETS_GLOBAL, LEAFLETS_INDIVIDUAL, LEAFLETS_NONE, OrderMap, UA_CH1_UNSAT,
+                            UA_N_H)
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def both(system, xyz, box, batches=2, trig=None):
+    if trig is None:
+        trig = oracle.TRIG_MIRROR if (system.tables.flags & abi.FLAG_TRIG_ACOS_COS) else oracle.TRIG_DIRECT
+    eng = HipEngine(system.tables)
+    o = oracle.OracleEngine(system.tables, trig=trig, n_threads=2)
+    edges = np.linspace(0, xyz.shape[0], batches + 1).astype(int)
+    for a, b in zip(edges[:-1], edges[1:]):
+        fi = np.arange(a, b)
+        eng.submit_host(xyz[a:b], None if box is None else box[a:b], fi)
+        o.submit(xyz[a:b], None if box is None else box[a:b], fi)
+    return eng, o, eng.finish(), o.finish()
+
+
+@pytest.mark.parametrize("plane", [0, 1, 2])
+@pytest.mark.parametrize("leaflets", [LEAFLETS_NONE, LEAFLETS_GLOBAL])
+def test_ordermaps(built, plane, leaflets):
+    spans = {0: (0, 1), 1: (0, 2), 2: (2, 1)}[plane]     # projection2plane: xy, xz, (z, y)
+    system = synthetic.cg_membrane(200, leaflets=leaflets, n_types=2)
+    bx = system.box
+    om = OrderMap(enabled=True, plane=plane, span_x=(0.0, float(bx[spans[0]])), span_y=(0.0, float(bx[spans[1]])),
+                  bin=(0.7, 1.3))
+    system.tables.ordermap = om
+    xyz = system.frames(9, seed=4)
+    eng, o, got, want = both(system, xyz, system.box9(9))
+    assert got.map_sums is not None and got.map_sums.shape == want.map_sums.shape
+    assert got.map_sums.shape[2] == round(float(bx[spans[0]]) / 0.7) + 1      # GridMap: round(span/bin) + 1 tiles
+    np.testing.assert_array_equal(got.sums, want.sums)
+    np.testing.assert_array_equal(got.map_counts, want.map_counts)
+    np.testing.assert_array_equal(got.map_sums, want.map_sums)
+    # a sample lands in at most one tile; the bond position p1 + v/2 is NOT wrapped (bond.rs:422), so a
+    # few midpoints beyond the box edge are dropped — by the reference as well (ordermap.rs:100-113)
+    tot = got.map_counts.sum(axis=(2, 3))
+    assert (tot <= got.counts).all() and tot.sum() > 0.97 * got.counts.sum()
+
+
+def test_ordermap_manual_span_drops_outside_samples(built):
+    system = synthetic.aa_membrane(20)
+    system.tables.ordermap = OrderMap(enabled=True, plane=0, span_x=(2.0, 5.0), span_y=(1.0, 4.0), bin=(0.25, 0.5))
+    xyz = system.frames(5, seed=2)
+    eng, o, got, want = both(system, xyz, system.box9(5), batches=1)
+    np.testing.assert_array_equal(got.map_counts, want.map_counts)
+    np.testing.assert_array_equal(got.map_sums, want.map_sums)
+    assert 0 < got.map_counts[0].sum() < got.counts[0].sum()
+
+
+@pytest.mark.parametrize("leaflets", [LEAFLETS_NONE, LEAFLETS_INDIVIDUAL])
+def test_timewise(built, leaflets):
+    system = synthetic.aa_membrane(24, leaflets=leaflets, timewise=True)
+    n = 31
+    xyz = system.frames(n, seed=6)
+    eng, o, got, want = both(system, xyz, system.box9(n), batches=3)
+    np.testing.assert_array_equal(got.sums, want.sums)
+    gs, gc = eng.timewise(n)
+    ws, wc = o.timewise(n)
+    np.testing.assert_array_equal(gs, ws)
+    np.testing.assert_array_equal(gc, wc)
+    # the per-frame rows add up to the running totals, and feed the reference's error estimate
+    np.testing.assert_array_equal(gs.sum(axis=0), got.sums)
+    np.testing.assert_array_equal(gc.sum(axis=0), got.counts)
+    e_gpu = oracle.estimate_error(gs[:, 0, 3], gc[:, 0, 3], 5)
+    e_ref = oracle.estimate_error(ws[:, 0, 3], wc[:, 0, 3], 5)
+    assert e_gpu == e_ref and e_gpu > 0
+
+
+@pytest.mark.parametrize("pbc", [True, False])
+@pytest.mark.parametrize("leaflets", [LEAFLETS_NONE, LEAFLETS_GLOBAL])
+def test_united_atoms(built, leaflets, pbc):
+    system = synthetic.ua_membrane(40, leaflets=leaflets, handle_pbc=pbc)
+    n = 11
+    xyz = system.frames(n, seed=8)
+    box = system.box9(n) if pbc else None
+    eng, o, got, want = both(system, xyz, box)
+    np.testing.assert_array_equal(got.counts, want.counts)
+    # slots of CH3 / CH2 / saturated CH are built from IEEE f32 operations only -> bit-exact;
+    # the unsaturated CH uses acos + sin/cos of a data-dependent angle (device vs host libm): <= 1e-6
+    slot, exact = 0, []
+    for kind, _ in system.tables.molecule_types[0].ua_atoms:
+        nh = UA_N_H[int(kind)]
+        exact += [kind != UA_CH1_UNSAT] * nh
+        slot += nh
+    exact = np.array(exact)
+    assert exact.size == got.sums.shape[1] == 62
+    np.testing.assert_array_equal(got.sums[:, exact], want.sums[:, exact])
+    assert np.abs(got.order_ticks()[:, ~exact] - want.order_ticks()[:, ~exact]).max() <= 1
+    # and everything within 1e-6 of the libm (reference-faithful) oracle
+    ref = oracle.OracleEngine(system.tables, trig=oracle.TRIG_LIBM)
+    ref.submit(xyz, box)
+    assert np.abs(got.order_ticks() - ref.finish().order_ticks()).max() <= 1
+    # C-H bond length is 0.109 nm by construction -> order parameters are physical
+    s = got.order()[0]
+    assert np.all(s >= -0.5 - 1e-6) and np.all(s <= 1.0 + 1e-6)
+
+
+def test_united_atoms_with_maps_and_timewise(built):
+    system = synthetic.ua_membrane(16, leaflets=LEAFLETS_GLOBAL, timewise=True,
+                                   ordermap=OrderMap(enabled=True, plane=0, span_x=(0.0, 9.0), span_y=(0.0, 9.0),
+                                                     bin=(1.0, 1.0)))
+    n = 7
+    xyz = system.frames(n, seed=3)
+    eng, o, got, want = both(system, xyz, system.box9(n), batches=2)
+    np.testing.assert_array_equal(got.counts, want.counts)
+    assert (got.map_counts.sum(axis=(2, 3)) <= got.counts).all()
+    np.testing.assert_array_equal(got.map_counts, want.map_counts)
+    gs, gc = eng.timewise(n)
+    np.testing.assert_array_equal(gc.sum(axis=0), got.counts)
+    np.testing.assert_array_equal(gs.sum(axis=0), got.sums)

@@ -292,7 +292,7 @@ def test_priming_replaces_cross_thread_wait(built):
     np.testing.assert_array_equal(head.counts + tail.counts, ref.counts)
 
 
-@pytest.mark.parametrize("g", ["2", "4", "8"])
+@pytest.mark.parametrize("g", ["4", "8"])
 def test_frames_per_stage_variants(built, monkeypatch, g):
     monkeypatch.setenv("GORDER_HIP_FRAMES_PER_STAGE", g)
     monkeypatch.setenv("GORDER_HIP_WG_TARGET", "40")
