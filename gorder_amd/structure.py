@@ -69,6 +69,39 @@ def read_bnd(path: str, n_atoms: int) -> List[List[int]]:
     return [sorted(s) for s in adj]
 
 
+def read_pdb(path: str) -> Structure:
+    """ATOM/HETATM records (fixed columns) + CONECT bonds (1-based serials in file order)."""
+    resids, resnames, names, pos, serial_of = [], [], [], [], {}
+    conect = []
+    box = np.zeros(3, dtype=np.float32)
+    with open(path) as f:
+        for line in f:
+            rec = line[:6]
+            if rec in ("ATOM  ", "HETATM"):
+                serial_of[int(line[6:11])] = len(names)
+                names.append(line[12:16].strip())
+                resnames.append(line[17:21].strip())
+                resids.append(int(line[22:26]))
+                pos.append((float(line[30:38]) / 10.0, float(line[38:46]) / 10.0, float(line[46:54]) / 10.0))
+            elif rec == "CONECT":
+                nums = [int(line[k:k + 5]) for k in range(6, len(line.rstrip()), 5) if line[k:k + 5].strip()]
+                conect.append(nums)
+            elif rec == "CRYST1":
+                box = np.array([float(line[6:15]) / 10, float(line[15:24]) / 10, float(line[24:33]) / 10], np.float32)
+            elif rec == "ENDMDL":
+                break
+        # CONECT records may follow ENDMDL
+        for line in f:
+            if line[:6] == "CONECT":
+                conect.append([int(line[k:k + 5]) for k in range(6, len(line.rstrip()), 5) if line[k:k + 5].strip()])
+    adj = [set() for _ in names]
+    for nums in conect:
+        a = serial_of[nums[0]]
+        for b in nums[1:]:
+            adj[a].add(serial_of[b]); adj[serial_of[b]].add(a)
+    return Structure(np.array(resids), resnames, names, box, np.array(pos, dtype=np.float32), [sorted(x) for x in adj])
+
+
 def guess_element(name: str, resname: str = "") -> str:
     """Coarse element guess for lipid atoms (groan_rs guesses elements from atom names; only C/H are
     needed by the AA selections used in the fixtures)."""
@@ -219,6 +252,138 @@ def build_tables(structure: Structure, analysis: str, sel1: np.ndarray, sel2: Op
     tables = Tables(n_atoms=len(midx), molecule_types=mts, handle_pbc=handle_pbc, normal=normal, leaflets=leaf,
                     ordermap=ordermap or OrderMap(), timewise=timewise, flags=flags)
     return tables, labels, midx
+
+
+@dataclass
+class UaCarbonLabel:
+    rel: int
+    name: str
+    kind: int
+    n_h: int
+
+
+@dataclass
+class UaMolLabels:
+    name: str
+    carbons: List[UaCarbonLabel]
+    n_molecules: int = 0
+    slot0: int = 0
+
+
+def build_tables_ua(structure: Structure, saturated: np.ndarray, unsaturated: np.ndarray, master: np.ndarray,
+                    leaflets: Optional[dict] = None, handle_pbc: bool = True, normal=(0.0, 0.0, 1.0),
+                    ordermap: Optional[OrderMap] = None, timewise: bool = False, flags: int = 0):
+    """AtomBasedClassifier + UAOrderAtoms (classify.rs, uaorder.rs:454-665): the number of bonded atoms of
+    a carbon decides how many hydrogens are built; helpers = bonded atoms in index order; a methyl's second
+    helper is the first neighbour of helper1 that is not the methyl itself (uaorder.rs:609-629)."""
+    from .abi import UA_CH1_SAT, UA_CH1_UNSAT, UA_CH2, UA_CH3, UA_N_H
+    adj = structure.bonds
+    order = saturated | unsaturated
+    visited: set = set()
+    types: List[dict] = []
+    for a in np.flatnonzero(order):
+        a = int(a)
+        if a in visited:
+            continue
+        atoms = _molecule_of(adj, a, visited)
+        m0 = atoms[0]
+        key = tuple((structure.resnames[i], structure.names[i], i - m0, tuple(j - m0 for j in adj[i])) for i in atoms)
+        for t in types:
+            if t["key"] == key:
+                t["mols"].append(atoms)
+                break
+        else:
+            resn = []
+            for i in atoms:
+                if structure.resnames[i] not in resn:
+                    resn.append(structure.resnames[i])
+            types.append({"key": key, "name": "-".join(resn), "mols": [atoms], "m0": m0})
+    midx = np.flatnonzero(master)
+    remap = -np.ones(structure.n_atoms, dtype=np.int64)
+    remap[midx] = np.arange(len(midx))
+    lf = leaflets or {}
+    mts, labels, slot0 = [], [], 0
+    for t in types:
+        mols, m0 = t["mols"], t["m0"]
+        carbons, ua_atoms = [], []
+        for i in mols[0]:
+            if not order[i]:
+                continue
+            bonded = adj[i]
+            missing = max(0, 4 - len(bonded))
+            quad = None
+            if saturated[i] and missing == 1:
+                kind, quad = UA_CH1_SAT, (bonded[0], bonded[1], bonded[2], i)
+            elif saturated[i] and missing == 2:
+                kind, quad = UA_CH2, (bonded[0], i, bonded[1], i)
+            elif saturated[i] and missing == 3:
+                h1 = bonded[0]
+                h2 = next((j for j in adj[h1] if j != i), None)
+                if h2 is None:
+                    continue
+                kind, quad = UA_CH3, (h1, i, h2, i)
+            elif unsaturated[i] and missing == 2:
+                kind, quad = UA_CH1_UNSAT, (bonded[0], i, bonded[1], i)
+            else:
+                continue
+            idx = np.zeros((len(mols), 4), dtype=np.uint32)
+            for k, atoms in enumerate(mols):
+                off = atoms[0] - m0
+                idx[k] = [remap[q + off] for q in quad]
+            assert (idx >= 0).all()
+            ua_atoms.append((kind, idx))
+            carbons.append(UaCarbonLabel(i - m0, structure.names[i], kind, UA_N_H[kind]))
+        if not ua_atoms:
+            continue
+        heads = methyls = None
+        if lf.get("method", LEAFLETS_NONE) in (LEAFLETS_GLOBAL, LEAFLETS_LOCAL, LEAFLETS_INDIVIDUAL):
+            heads = np.array([remap[[a for a in atoms if lf["heads"][a]][0]] for atoms in mols], dtype=np.uint32)
+            if lf["method"] == LEAFLETS_INDIVIDUAL:
+                methyls = np.array([[remap[a] for a in atoms if lf["methyls"][a]] for atoms in mols], dtype=np.uint32)
+        mts.append(MolType(n_molecules=len(mols), ua_atoms=ua_atoms, heads=heads, methyls=methyls, name=t["name"]))
+        labels.append(UaMolLabels(t["name"], carbons, len(mols), slot0))
+        slot0 += sum(c.n_h for c in carbons)
+    leaf = Leaflets()
+    if lf.get("method", LEAFLETS_NONE) != LEAFLETS_NONE:
+        mem = None
+        if lf["method"] in (LEAFLETS_GLOBAL, LEAFLETS_LOCAL):
+            mem = remap[np.flatnonzero(lf["membrane"])].astype(np.uint32)
+        leaf = Leaflets(method=lf["method"], normal_dim=lf.get("normal_dim", 2), frequency=lf.get("frequency", 1),
+                        flip=lf.get("flip", False), radius=lf.get("radius", 0.0), membrane=mem)
+    tables = Tables(n_atoms=len(midx), molecule_types=mts, handle_pbc=handle_pbc, normal=normal, leaflets=leaf,
+                    ordermap=ordermap or OrderMap(), timewise=timewise, flags=flags)
+    return tables, labels, midx
+
+
+def results_tree_ua(res: Results, labels: Sequence[UaMolLabels], leaflets: bool, min_samples: int = 1) -> dict:
+    """UA YAML shape (uaresults): per carbon `total` (+ upper/lower) and `bonds`: list per virtual hydrogen."""
+    which = ["total", "upper", "lower"] if leaflets else ["total"]
+
+    def coll(slots):
+        out = {}
+        for w, key in enumerate(which):
+            s = int(sum(int(res.sums[w, k]) for k in slots))
+            n = int(sum(int(res.counts[w, k]) for k in slots))
+            v = _mean_ticks(s, n, min_samples)
+            out[key] = round4(-v) if v == v else float("nan")
+        return out
+
+    tree: Dict[str, object] = {}
+    all_slots: List[int] = []
+    for ml in labels:
+        slot = ml.slot0
+        op: Dict[str, object] = {}
+        mol_slots = []
+        for c in ml.carbons:
+            slots = list(range(slot, slot + c.n_h))
+            slot += c.n_h
+            mol_slots += slots
+            entry = dict(coll(slots))
+            entry["bonds"] = [coll([k]) for k in slots]
+            op[f"{ml.name} {c.name} ({c.rel})"] = entry
+        all_slots += mol_slots
+        tree[ml.name] = {"average order": coll(mol_slots), "order parameters": op}
+    return {"average order": coll(all_slots), **tree}
 
 
 # ---- finalisation (presentation layer arithmetic) -------------------------------------------

@@ -9,6 +9,7 @@ text files of its integration tests.  No reference source code is read or copied
 
   pcpepg  tests/files/pcpepg.gro + pcpepg.bnd + split/pcpepg{1..5}.xtc   (tests_aa.rs:47-77)
   cg      tests/files/cg.gro + cg.bnd + split/cg{1..5}.xtc               (tests_cg.rs:46-66)
+  ua      tests/files/ua_nobox.pdb (names, CONECT bonds) + ua.xtc        (tests_ua.rs:19-68)
 """
 import ctypes as C
 import os
@@ -29,8 +30,13 @@ LIPIDS = {"POPC", "POPE", "POPG", "POPS"}
 
 
 def pack(name, gro, bnd, xtcs):
-    s = st.read_gro(os.path.join(REF, gro))
-    adj = st.read_bnd(os.path.join(REF, bnd), s.n_atoms)
+    if gro.endswith(".pdb"):
+        s = st.read_pdb(os.path.join(REF, gro))     # CONECT records carry the bonds
+        adj = s.bonds
+        s.box = np.zeros(3, dtype=np.float32)
+    else:
+        s = st.read_gro(os.path.join(REF, gro))
+        adj = st.read_bnd(os.path.join(REF, bnd), s.n_atoms)
     keep = np.array([r in LIPIDS for r in s.resnames])
     idx = np.flatnonzero(keep)
     remap = -np.ones(s.n_atoms, dtype=np.int64)
@@ -54,8 +60,10 @@ def pack(name, gro, bnd, xtcs):
 if __name__ == "__main__":
     pack("pcpepg", "pcpepg.gro", "pcpepg.bnd", [f"split/pcpepg{i}.xtc" for i in range(1, 6)])
     pack("cg", "cg.gro", "cg.bnd", [f"split/cg{i}.xtc" for i in range(1, 6)])
+    pack("ua", "ua_nobox.pdb", None, ["ua.xtc"])      # tests_ua.rs:19-68 (names + bonds from the PDB twin of ua.tpr)
     for f in ("aa_order_basic.yaml", "aa_order_begin_end_step.yaml", "aa_order_leaflets.yaml",
-              "cg_order_basic.yaml", "cg_order_begin_end_step.yaml", "cg_order_leaflets.yaml"):
+              "cg_order_basic.yaml", "cg_order_begin_end_step.yaml", "cg_order_leaflets.yaml",
+              "ua_order_basic.yaml", "ua_order_leaflets.yaml"):
         src = os.path.join(REF, f)
         if os.path.exists(src):
             shutil.copy(src, os.path.join(HERE, "expected", f))

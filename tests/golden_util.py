@@ -73,3 +73,21 @@ def cg_setup(fx, leaflets=None, frequency=1, **kw):
 
 
 METHODS = {"global": LEAFLETS_GLOBAL, "local": LEAFLETS_LOCAL, "individual": LEAFLETS_INDIVIDUAL}
+
+
+def ua_setup(fx, leaflets=None, frequency=1, **kw):
+    """UAOrder selections of tests_ua.rs:41-45 (saturated / unsaturated carbons of POPC and POPS)."""
+    s = fx.structure
+    rn = np.array(s.resnames)
+    isc = np.array([n.startswith("C") for n in s.names])
+    sat = ((rn == "POPC") & isc & ~fx.name_in("C15", "C34", "C24", "C25")) | \
+          ((rn == "POPS") & isc & ~fx.name_in("C6", "C18", "C39", "C27", "C28"))
+    unsat = ((rn == "POPC") & fx.name_in("C24", "C25")) | ((rn == "POPS") & fx.name_in("C27", "C28"))
+    allm = np.ones(s.n_atoms, dtype=bool)
+    lf = None
+    if leaflets is not None:
+        heads = np.array([n.startswith("P") for n in s.names])                       # name r'^P'
+        methyls = ((rn == "POPC") & fx.name_in("CA2", "C50")) | ((rn == "POPS") & fx.name_in("C36", "C55"))
+        lf = {"method": leaflets, "membrane": allm, "heads": heads, "methyls": methyls, "frequency": frequency,
+              "radius": 2.5}
+    return st.build_tables_ua(s, sat, unsat, allm, leaflets=lf, **kw)

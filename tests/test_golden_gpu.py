@@ -6,7 +6,7 @@ import pytest
 from gorder_amd import HipEngine, abi
 from gorder_amd import structure as st
 from oracle import oracle
-from golden_util import METHODS, Fixture, aa_setup, cg_setup, expected
+from golden_util import METHODS, Fixture, aa_setup, cg_setup, expected, ua_setup
 
 pytestmark = pytest.mark.gpu
 
@@ -105,4 +105,29 @@ def test_cg_begin_end_step(cg):
     frames = cg.window(352_000.0, 358_000.0, 5)
     eng, res, *_ = gpu_run(tables, cg, midx, frames, frame_index=np.arange(13) * 5)
     bad = st.compare_trees(st.results_tree(res, labels, "cg", leaflets=True), expected("cg_order_begin_end_step.yaml"))
+    assert not bad, bad[:10]
+
+
+@pytest.fixture(scope="module")
+def ua(built):
+    return Fixture("ua")
+
+
+def test_ua_order_basic(ua):
+    tables, labels, midx = ua_setup(ua)
+    frames = ua.window()
+    eng, res, xyz, box, fi = gpu_run(tables, ua, midx, frames)
+    bad = st.compare_trees(st.results_tree_ua(res, labels, leaflets=False), expected("ua_order_basic.yaml"))
+    assert not bad, bad[:10]
+    _, libm = oracle_run(tables, xyz, box, fi, oracle.TRIG_LIBM)
+    np.testing.assert_array_equal(res.counts, libm.counts)
+    assert np.abs(res.order_ticks() - libm.order_ticks()).max() <= 1
+
+
+@pytest.mark.parametrize("method,frequency", [("global", 1), ("local", 5), ("individual", 0)])
+def test_ua_order_leaflets(ua, method, frequency):
+    tables, labels, midx = ua_setup(ua, leaflets=METHODS[method], frequency=frequency)
+    frames = ua.window()
+    eng, res, *_ = gpu_run(tables, ua, midx, frames)
+    bad = st.compare_trees(st.results_tree_ua(res, labels, leaflets=True), expected("ua_order_leaflets.yaml"))
     assert not bad, bad[:10]

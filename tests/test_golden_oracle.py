@@ -10,7 +10,7 @@ import pytest
 
 from gorder_amd import structure as st
 from oracle import oracle
-from golden_util import METHODS, Fixture, aa_setup, cg_setup, expected
+from golden_util import METHODS, Fixture, aa_setup, cg_setup, expected, ua_setup
 
 
 @pytest.fixture(scope="module")
@@ -113,4 +113,34 @@ def test_cg_begin_end_step(cg):
     eng.submit(master_frames(cg, midx, frames), cg.boxes[frames], np.arange(13) * 5)
     tree = st.results_tree(eng.finish(), labels, "cg", leaflets=True)
     bad = st.compare_trees(tree, expected("cg_order_begin_end_step.yaml"))
+    assert not bad, bad[:10]
+
+
+@pytest.fixture(scope="module")
+def ua(built):
+    return Fixture("ua")
+
+
+def test_ua_order_basic(ua):
+    # tests_ua.rs:19-68: pins the virtual-hydrogen construction (uaorder.rs:947-1104) end to end
+    tables, labels, midx = ua_setup(ua)
+    assert [m.name for m in labels] == ["POPC", "POPS"]
+    frames = ua.window()
+    eng = oracle.OracleEngine(tables, trig=oracle.TRIG_LIBM, n_threads=4)
+    eng.submit(master_frames(ua, midx, frames), ua.boxes[frames], frames)
+    res = eng.finish()
+    tree = st.results_tree_ua(res, labels, leaflets=False)
+    bad = st.compare_trees(tree, expected("ua_order_basic.yaml"))
+    assert not bad, bad[:10]
+
+
+@pytest.mark.parametrize("method,frequency", [("global", 1), ("local", 5), ("individual", 100), ("global", 0)])
+def test_ua_order_leaflets(ua, method, frequency):
+    # tests_ua.rs:147-200: every method and every frequency reproduces ua_order_leaflets.yaml
+    tables, labels, midx = ua_setup(ua, leaflets=METHODS[method], frequency=frequency)
+    frames = ua.window()
+    eng = oracle.OracleEngine(tables, trig=oracle.TRIG_LIBM, n_threads=4)
+    eng.submit(master_frames(ua, midx, frames), ua.boxes[frames], frames)
+    tree = st.results_tree_ua(eng.finish(), labels, leaflets=True)
+    bad = st.compare_trees(tree, expected("ua_order_leaflets.yaml"))
     assert not bad, bad[:10]
