@@ -45,7 +45,8 @@ __device__ __forceinline__ float gm_min_image_loop(float dx, float L, int &bad) 
 // cannot; hence b is one select chain on dx itself.
 __device__ __forceinline__ float gm_min_image_step(float dx, float L, bool &slow) {
     const float half = L / 2.0f;
-    const float r = dx > half ? dx - L : (dx < -half ? dx + L : dx);
+    // dx - copysign(L, dx) is dx - L for dx > 0 and dx + L for dx < 0 (x + L == x - (-L) bit for bit)
+    const float r = __builtin_fabsf(dx) > half ? dx - __builtin_copysignf(L, dx) : dx;
     // one shift was enough iff the result lies in [-half, half] (NaN: loops would not iterate either)
     slow = slow || (__builtin_fabsf(r) > half);
     return r;
@@ -147,14 +148,27 @@ __device__ __forceinline__ float gm_cosf(float t) {
 //   square root, one IEEE division.  Every operation is a correctly rounded f32 operation, restated
 //   by the oracle's DIRECT mode.  Against the reference's libm pipeline 5.9 % of samples move by one
 //   1e-6 tick (never more) and the mean moves by 2.6e-10 (tools/trig_fidelity.c).
-template <bool ACOS_COS>
+// AXIS = 0/1/2: the normal is exactly the unit vector of that axis (the reference's default, z).  Then
+// v.n = (vx*0 + vy*0) + vz*1 = v[AXIS] and |n|^2 = 1 for every FINITE v, and the multiplications can
+// be dropped; a non-finite |v|^2 (the only case where 0 * v_k is not 0) sets `*nonfinite` and the
+// caller re-evaluates that sample through the generic path.  AXIS = -1: generic normal.
+template <bool ACOS_COS, int AXIS = -1>
 __device__ __forceinline__ float gm_calc_sch(float vx, float vy, float vz, float nx, float ny, float nz,
-                                             float n2, float n2sq) {
+                                             float n2, float n2sq, bool *nonfinite = nullptr) {
 #ifdef GORDER_DEBUG_NOMATH   // timing experiment only: how fast does the data path alone stream?
     return (vx + vy) + vz;
 #endif
-    const float prod = (vx * nx + vy * ny) + vz * nz;
     const float s2 = (vx * vx + vy * vy) + vz * vz;
+    float prod;
+    if (AXIS >= 0 && !ACOS_COS) {
+        prod = AXIS == 0 ? vx : (AXIS == 1 ? vy : vz);
+        if (nonfinite) *nonfinite = !(__builtin_fabsf(s2) <= 3.4028234663852886e38f);
+        float q = (prod * prod) / s2;
+        q = q > 1.0f ? 1.0f : q;
+        q = (s2 == 0.0f) ? 1.0f : q;
+        return (1.5f * q) - 0.5f;
+    }
+    prod = (vx * nx + vy * ny) + vz * nz;
     if (ACOS_COS) {
         const float n1 = __builtin_sqrtf(s2);
         float c = prod / (n1 * n2);

@@ -155,7 +155,7 @@ __device__ __forceinline__ bool bond_sample(const FrameArgs &a, uint32_t f, floa
 // aligned 16-byte granule that holds the last valid float: it cannot cross into an unmapped page.
 typedef float v4f __attribute__((ext_vector_type(4)));   // native 16-byte vector (SROA-friendly, unlike float4)
 
-template <int G, int NPF, bool ACOS_COS, bool PBC, bool LEAF>
+template <int G, int NPF, bool ACOS_COS, bool PBC, bool LEAF, int AXIS = -1>
 struct TiledStage {
     static constexpr uint32_t TPF = kBlock / G;   // threads that stage one frame
 
@@ -221,8 +221,9 @@ struct TiledStage {
                 vy = gm_min_image_step(vy, by[k], slow);
                 vz = gm_min_image_step(vz, bz[k], slow);
             }
-            const float sch = gm_calc_sch<ACOS_COS>(vx, vy, vz, a.nx, a.ny, a.nz, a.n2, a.n2sq);
-            rare |= ((slow || sch != sch) ? 1u : 0u) << k;
+            bool nonfinite = false;
+            const float sch = gm_calc_sch<ACOS_COS, AXIS>(vx, vy, vz, a.nx, a.ny, a.nz, a.n2, a.n2sq, &nonfinite);
+            rare |= ((slow || nonfinite || sch != sch) ? 1u : 0u) << k;
             tick[k] = gm_tick(sch);
         }
         if (__builtin_expect(rare != 0, 0)) {
@@ -294,7 +295,7 @@ struct TiledStage {
 #ifndef GORDER_TILED_MIN_WAVES
 #define GORDER_TILED_MIN_WAVES 4   // waves per SIMD the register allocation must allow (8 => <= 64 VGPRs)
 #endif
-template <int G, int NPF, bool ACOS_COS, bool PBC, bool LEAF>
+template <int G, int NPF, bool ACOS_COS, bool PBC, bool LEAF, int AXIS>
 __global__ __launch_bounds__(kBlock, GORDER_TILED_MIN_WAVES) void k_bonds_tiled(FrameArgs a_in, const float *__restrict__ xyz,
                                                       const float *__restrict__ box9,
                                                       const uint8_t *__restrict__ aflags,
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(kBlock, GORDER_TILED_MIN_WAVES) void k_bonds_tiled(
                                                       const uint32_t *__restrict__ tile_slots,
                                                       uint32_t n_tiles, uint32_t lw) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    using S = TiledStage<G, NPF, ACOS_COS, PBC, LEAF>;
+    using S = TiledStage<G, NPF, ACOS_COS, PBC, LEAF, AXIS>;
     // the read-only streams come in as __restrict__ kernel arguments so that the compiler can prove
     // that the accumulator / error stores never clobber them (uniform loads become scalar loads)
     FrameArgs a = a_in;
@@ -1250,6 +1251,7 @@ struct gorder_hip_handle {
     float *d_stage_xyz = nullptr, *d_stage_box = nullptr;
     size_t stage_xyz_cap = 0, stage_box_cap = 0;
     float n2 = 1.0f, n2sq = 1.0f;
+    int axis = -1;   // 0/1/2 when the static normal is exactly that unit axis (kernel specialisation)
     int frames_per_stage = kFramesPerStage;   // G (2, 4 or 8); GORDER_HIP_FRAMES_PER_STAGE overrides
     bool use_gather = false;                   // GORDER_HIP_KERNEL=gather: L1-gather kernel instead of LDS staging
     uint32_t wg_capacity = 256u * 6u;          // co-resident workgroups of the tiled kernel on this device
@@ -1357,9 +1359,17 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
         if (grid > 0x7fffffffull) return fail(h, GORDER_ERR_INVALID_ARGUMENT, "batch too large");
         const bool ac = (h->tables.flags & GORDER_FLAG_TRIG_ACOS_COS) != 0;
         const dim3 g((uint32_t)grid), b(kBlock);
+#define GORDER_LAUNCH_TILED_A(G_, NPF_, AC_, PBC_, LF_, AX_)                                               \
+        hipLaunchKernelGGL((k_bonds_tiled<G_, NPF_, AC_, PBC_, LF_, AX_>), g, b, h->lds_bytes, h->stream, a,     \
+                           a.xyz, a.box9, a.aflags, a.arow, h->d_tiles, h->d_items, h->d_tile_slots, n_tiles,   \
+                           h->lw)
 #define GORDER_LAUNCH_TILED_V(G_, NPF_, AC_, PBC_, LF_)                                                    \
-        hipLaunchKernelGGL((k_bonds_tiled<G_, NPF_, AC_, PBC_, LF_>), g, b, h->lds_bytes, h->stream, a, a.xyz,   \
-                           a.box9, a.aflags, a.arow, h->d_tiles, h->d_items, h->d_tile_slots, n_tiles, h->lw)
+        do {                                                                                                \
+            if (!(AC_) && h->axis == 2) GORDER_LAUNCH_TILED_A(G_, NPF_, AC_, PBC_, LF_, 2);                 \
+            else if (!(AC_) && h->axis == 1) GORDER_LAUNCH_TILED_A(G_, NPF_, AC_, PBC_, LF_, 1);            \
+            else if (!(AC_) && h->axis == 0) GORDER_LAUNCH_TILED_A(G_, NPF_, AC_, PBC_, LF_, 0);            \
+            else GORDER_LAUNCH_TILED_A(G_, NPF_, AC_, PBC_, LF_, -1);                                       \
+        } while (0)
 #define GORDER_LAUNCH_TILED(G_, NPF_)                                                                       \
         do {                                                                                                \
             const int v_ = (ac ? 4 : 0) | (a.pbc ? 2 : 0) | (a.leaflets ? 1 : 0);                           \
@@ -1401,6 +1411,7 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
         }
 #undef GORDER_LAUNCH_GATHER
 #undef GORDER_LAUNCH_GATHER_V
+#undef GORDER_LAUNCH_TILED_A
 #undef GORDER_LAUNCH_TILED_V
 #undef GORDER_LAUNCH_TILED
         HIP_TRY(h, hipGetLastError());
@@ -1577,6 +1588,8 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
         const float *n = t->normal;
         h->n2sq = (n[0] * n[0] + n[1] * n[1]) + n[2] * n[2];
         h->n2 = sqrtf(h->n2sq);
+        for (int d = 0; d < 3; d++)
+            if (n[d] == 1.0f && n[(d + 1) % 3] == 0.0f && n[(d + 2) % 3] == 0.0f) h->axis = d;
     }
     if (const char *e = getenv("GORDER_HIP_FRAMES_PER_STAGE")) {
         const int g = atoi(e);
@@ -1597,10 +1610,10 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
         const bool ac = (t->flags & GORDER_FLAG_TRIG_ACOS_COS) != 0;
         hipError_t e;
         switch (h->frames_per_stage) {
-            case 8: e = ac ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bonds_tiled<8, 10, true, true, false>, kBlock, h->lds_bytes)
-                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bonds_tiled<8, 10, false, true, false>, kBlock, h->lds_bytes); break;
-            default: e = ac ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bonds_tiled<4, 5, true, true, false>, kBlock, h->lds_bytes)
-                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bonds_tiled<4, 5, false, true, false>, kBlock, h->lds_bytes); break;
+            case 8: e = ac ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bonds_tiled<8, 10, true, true, false, -1>, kBlock, h->lds_bytes)
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bonds_tiled<8, 10, false, true, false, 2>, kBlock, h->lds_bytes); break;
+            default: e = ac ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bonds_tiled<4, 5, true, true, false, -1>, kBlock, h->lds_bytes)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bonds_tiled<4, 5, false, true, false, 2>, kBlock, h->lds_bytes); break;
         }
         if (e != hipSuccess || per_cu < 1) per_cu = 4;
         h->wg_capacity = (uint32_t)n_cu * (uint32_t)per_cu;
