@@ -40,6 +40,17 @@ def make_system(name):
         return synthetic.aa_membrane(256, leaflets=LEAFLETS_GLOBAL), "AAOrder 256 lipids + global leaflets"
     if name == "cg3k":
         return synthetic.cg_membrane(3072), "CGOrder Martini bilayer 3072 lipids (36864 beads, 33792 bonds/frame)"
+    if name == "cg3k-local":     # BASELINE configs[2]
+        from gorder_amd.abi import LEAFLETS_LOCAL
+        return (synthetic.cg_membrane(3072, leaflets=LEAFLETS_LOCAL, radius=2.5),
+                "CGOrder Martini bilayer 3072 lipids + local leaflets (r = 2.5 nm, every frame)")
+    if name == "ua256-maps":     # BASELINE configs[3]
+        from gorder_amd.abi import OrderMap
+        om = OrderMap(enabled=True, plane=0, span_x=(0.0, 9.0), span_y=(0.0, 9.0), bin=(0.1, 0.1))
+        return (synthetic.ua_membrane(256, ordermap=om),
+                "UAOrder 256 united-atom lipids (62 virtual C-H per lipid) + 91x91 ordermaps")
+    if name == "ua256":
+        return synthetic.ua_membrane(256), "UAOrder 256 united-atom lipids (62 virtual C-H per lipid)"
     if name == "cg1m":
         return synthetic.cg_membrane(83334), "CGOrder synthetic 1M-bead bilayer (1000008 beads, 916674 bonds/frame)"
     raise SystemExit(f"unknown workload {name}")

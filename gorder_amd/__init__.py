@@ -4,8 +4,8 @@ The product is the C-ABI shared library built from ``gorder_amd/csrc`` (see ``in
 this package is the thin Python harness around it (ctypes bindings, synthetic workloads,
 multi-GPU launcher).  Nothing here imports ``oracle/``.
 """
-from .abi import (GorderHipError, HipEngine, Leaflets, MolType, OrderMap, Results, Tables,  # noqa: F401
+from .abi import (Geometry, GorderHipError, HipEngine, Leaflets, MolType, OrderMap, Results, Tables,  # noqa: F401
                   load_library, plan_tables)
 
-__all__ = ["GorderHipError", "HipEngine", "Leaflets", "MolType", "OrderMap", "Results", "Tables",
+__all__ = ["Geometry", "GorderHipError", "HipEngine", "Leaflets", "MolType", "OrderMap", "Results", "Tables",
            "load_library", "plan_tables"]

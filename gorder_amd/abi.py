@@ -64,11 +64,18 @@ class CMolType(C.Structure):
                 ("n_methyls", C.c_uint32), ("methyls", _u32p)]
 
 
+class CGeometry(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("invert", C.c_uint32), ("reference", C.c_uint32), ("point", C.c_float * 3),
+                ("n_group", C.c_uint32), ("group", _u32p), ("xdim", C.c_float * 2), ("ydim", C.c_float * 2),
+                ("zdim", C.c_float * 2), ("radius", C.c_float), ("span", C.c_float * 2), ("orientation", C.c_uint32),
+                ("structure_box", C.c_float * 3)]
+
+
 class CTables(C.Structure):
     _fields_ = [("n_atoms", C.c_uint32), ("n_molecule_types", C.c_uint32),
                 ("molecule_types", C.POINTER(CMolType)), ("handle_pbc", C.c_int32),
                 ("normal", C.c_float * 3), ("leaflets", CLeaflets), ("ordermap", COrderMap),
-                ("timewise", C.c_int32), ("device", C.c_int32), ("flags", C.c_uint32)]
+                ("timewise", C.c_int32), ("device", C.c_int32), ("flags", C.c_uint32), ("geometry", CGeometry)]
 
 
 class CPlan(C.Structure):
@@ -131,6 +138,28 @@ class OrderMap:
     bin: Sequence[float] = (0.1, 0.1)
 
 
+GEOM_NONE, GEOM_CUBOID, GEOM_CYLINDER, GEOM_SPHERE = range(4)
+GEOMREF_POINT, GEOMREF_BOX_CENTER, GEOMREF_GROUP = range(3)
+_INF = float("inf")
+
+
+@dataclass
+class Geometry:
+    """input/geometry.rs: cuboid / cylinder / sphere relative to a point, the box centre or a group centre."""
+    kind: int = GEOM_NONE
+    invert: bool = False
+    reference: int = GEOMREF_POINT
+    point: Sequence[float] = (0.0, 0.0, 0.0)
+    group: Optional[np.ndarray] = None
+    xdim: Sequence[float] = (-_INF, _INF)
+    ydim: Sequence[float] = (-_INF, _INF)
+    zdim: Sequence[float] = (-_INF, _INF)
+    radius: float = 0.0
+    span: Sequence[float] = (-_INF, _INF)
+    orientation: int = 2
+    structure_box: Sequence[float] = (0.0, 0.0, 0.0)   # needed for reference = point with PBC
+
+
 @dataclass
 class Tables:
     n_atoms: int
@@ -142,6 +171,7 @@ class Tables:
     timewise: bool = False
     device: int = 0
     flags: int = 0          # FLAG_TRIG_ACOS_COS: acos->cos round trip like the reference
+    geometry: Geometry = field(default_factory=Geometry)
 
     @property
     def n_acc(self) -> int:
@@ -203,7 +233,22 @@ class Tables:
         t.timewise = 1 if self.timewise else 0
         t.device = self.device
         t.flags = self.flags
-        keep += [mts, mem]
+        ge = self.geometry
+        grp = _u32(ge.group) if ge.group is not None else None
+        t.geometry.kind = ge.kind
+        t.geometry.invert = 1 if ge.invert else 0
+        t.geometry.reference = ge.reference
+        t.geometry.point[:] = [float(x) for x in ge.point]
+        t.geometry.n_group = 0 if grp is None else grp.size
+        t.geometry.group = _ptr(grp)
+        t.geometry.xdim[:] = [float(x) for x in ge.xdim]
+        t.geometry.ydim[:] = [float(x) for x in ge.ydim]
+        t.geometry.zdim[:] = [float(x) for x in ge.zdim]
+        t.geometry.radius = ge.radius
+        t.geometry.span[:] = [float(x) for x in ge.span]
+        t.geometry.orientation = ge.orientation
+        t.geometry.structure_box[:] = [float(x) for x in ge.structure_box]
+        keep += [mts, mem, grp]
         return t, keep
 
 

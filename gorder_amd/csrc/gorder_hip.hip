@@ -530,7 +530,34 @@ struct ExtraArgs {
     unsigned long long tw_row0;      // row of this batch's frame 0
     // united atoms: sin/cos of the construction angles, evaluated on the host with libm like the reference
     float sin_tet, cos_tet, sin_ch3, cos_ch3, sin_half, cos_half;
+    // geometry selection (geometry.rs): per-frame shapes [n_frames][8] = anchor xyz, extents xyz, radius, height
+    int geom_kind, geom_invert, geom_orient;
+    const float *shapes;
 };
+
+// groan_rs Rectangular / Cylinder / Sphere ::inside (oracle: inside_shape), XOR invert (geometry.rs:181-189)
+__device__ __forceinline__ bool geom_inside(const ExtraArgs &e, const float *sh, float px, float py, float pz,
+                                            const float *box, bool pbc, int &bad) {
+    const float p[3] = {px, py, pz};
+    bool in = true;
+    if (e.geom_kind == GORDER_GEOM_CUBOID) {
+        for (int d = 0; d < 3; d++) {
+            float x = p[d] - sh[d];
+            if (pbc) { x = gm_wrap(x, box[d], bad); in = in && (x <= sh[3 + d]); }
+            else in = in && (x >= 0.0f) && (x <= sh[3 + d]);
+        }
+    } else if (e.geom_kind == GORDER_GEOM_CYLINDER) {
+        const int o = e.geom_orient, a = (o + 1) % 3, b = (o + 2) % 3;
+        float da = p[a] - sh[a], db = p[b] - sh[b], x = p[o] - sh[o];
+        if (pbc) { da = gm_min_image(da, box[a], bad); db = gm_min_image(db, box[b], bad); x = gm_wrap(x, box[o], bad); }
+        in = (__builtin_sqrtf(da * da + db * db) < sh[6]) && (pbc ? true : (x >= 0.0f)) && (x <= sh[7]);
+    } else {
+        float d[3];
+        for (int k = 0; k < 3; k++) { d[k] = p[k] - sh[k]; if (pbc) d[k] = gm_min_image(d[k], box[k], bad); }
+        in = __builtin_sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) < sh[6];
+    }
+    return in != (e.geom_invert != 0);
+}
 
 // groan_rs GridMap::get_mut_at: nearest tile centre, None outside (oracle: gridmap_index)
 __device__ __forceinline__ int grid_index(float x, float lo, float bin, uint32_t n) {
@@ -636,14 +663,22 @@ __global__ __launch_bounds__(kBlock) void k_bonds_extras(FrameArgs a_in, ExtraAr
                 else if (q2[0] != q2[0]) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, t.atom0 + it.lj, f);
             }
             const int tick = gm_tick(sch);
-            int leaflet = -1;
-            if (a.leaflets) leaflet = a.aflags[(size_t)a.arow[f] * a.n_mol_total + it.mol] ? 1 : 0;
-            acc.s_tot += tick;
-            acc.n_tot += 1;
-            if (leaflet == 0) { acc.s_up += tick; acc.n_up += 1; }
-            // bond position = p1 + v / 2 (bond.rs:422)
-            extras_add(a, e, gslot, it.lslot, tick, p1x + vx / 2.0f, p1y + vy / 2.0f, p1z + vz / 2.0f, leaflet, l_tw,
-                       l_twn, kBlock);
+            // bond position = p1 + v / 2 (bond.rs:422); geometry filter (bond.rs:424-426)
+            const float mx = p1x + vx / 2.0f, my = p1y + vy / 2.0f, mz = p1z + vz / 2.0f;
+            bool in = true;
+            if (e.geom_kind) {
+                float box[3] = {1.0f, 1.0f, 1.0f};
+                if (a.pbc) { const float *b = a.box9 + 9 * (size_t)f; box[0] = b[0]; box[1] = b[4]; box[2] = b[8]; }
+                in = geom_inside(e, e.shapes + 8 * (size_t)f, mx, my, mz, box, a.pbc != 0, bad);
+            }
+            if (in) {
+                int leaflet = -1;
+                if (a.leaflets) leaflet = a.aflags[(size_t)a.arow[f] * a.n_mol_total + it.mol] ? 1 : 0;
+                acc.s_tot += tick;
+                acc.n_tot += 1;
+                if (leaflet == 0) { acc.s_up += tick; acc.n_up += 1; }
+                extras_add(a, e, gslot, it.lslot, tick, mx, my, mz, leaflet, l_tw, l_twn, kBlock);
+            }
         }
         if (e.tw) {
             __syncthreads();
@@ -733,7 +768,7 @@ __global__ __launch_bounds__(kBlock) void k_ua_extras(FrameArgs a_in, ExtraArgs 
     for (uint32_t k = tid; k < 2 * LS; k += kBlock) { l_s[k] = 0; l_n[k] = 0; }
     __syncthreads();
     long long s_tot[3] = {0, 0, 0}, s_up[3] = {0, 0, 0};
-    uint32_t n_tot = 0, n_up = 0;
+    uint32_t n_tot[3] = {0, 0, 0}, n_up[3] = {0, 0, 0};
     int bad = 0;
     const bool pbc = a.pbc != 0;
     for (uint32_t f = f_begin; f < f_end; f++) {
@@ -797,13 +832,13 @@ __global__ __launch_bounds__(kBlock) void k_ua_extras(FrameArgs a_in, ExtraArgs 
                 const V3 v = v3_to(target, H[k], box, pbc, bad);
                 const float sch = gm_calc_sch<ACOS_COS>(v.x, v.y, v.z, a.nx, a.ny, a.nz, a.n2, a.n2sq);
                 const int tick = gm_tick(sch);
+                const float bx = H[k].x + v.x / 2.0f, by = H[k].y + v.y / 2.0f, bz = H[k].z + v.z / 2.0f;
+                if (e.geom_kind && !geom_inside(e, e.shapes + 8 * (size_t)f, bx, by, bz, box, pbc, bad)) continue;
                 s_tot[k] += tick;
-                if (leaflet == 0) s_up[k] += tick;
-                extras_add(a, e, gslot0 + (uint32_t)k, it.lslot0 + (uint32_t)k, tick, H[k].x + v.x / 2.0f,
-                           H[k].y + v.y / 2.0f, H[k].z + v.z / 2.0f, leaflet, l_tw, l_twn, LS);
+                n_tot[k] += 1;
+                if (leaflet == 0) { s_up[k] += tick; n_up[k] += 1; }
+                extras_add(a, e, gslot0 + (uint32_t)k, it.lslot0 + (uint32_t)k, tick, bx, by, bz, leaflet, l_tw, l_twn, LS);
             }
-            n_tot += 1;
-            if (leaflet == 0) n_up += 1;
         }
         if (e.tw) {
             __syncthreads();
@@ -812,13 +847,14 @@ __global__ __launch_bounds__(kBlock) void k_ua_extras(FrameArgs a_in, ExtraArgs 
         }
     }
     if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f_begin);
-    if (active && n_tot) {
+    if (active) {
         for (int k = 0; k < nh; k++) {
+            if (!n_tot[k]) continue;
             atomicAdd(&l_s[it.lslot0 + k], (unsigned long long)s_tot[k]);
-            atomicAdd(&l_n[it.lslot0 + k], n_tot);
-            if (n_up) {
+            atomicAdd(&l_n[it.lslot0 + k], n_tot[k]);
+            if (n_up[k]) {
                 atomicAdd(&l_s[LS + it.lslot0 + k], (unsigned long long)s_up[k]);
-                atomicAdd(&l_n[LS + it.lslot0 + k], n_up);
+                atomicAdd(&l_n[LS + it.lslot0 + k], n_up[k]);
             }
         }
     }
@@ -868,6 +904,90 @@ __device__ __forceinline__ double block_sum(double v, double *scratch) {
     const double r = scratch[0];
     __syncthreads();
     return r;
+}
+
+// ---- per-frame shapes of the geometry selection: GeometrySelection::init_reference (geometry.rs:192-210)
+// + construct_shape (geometry.rs:328-357, 422-451, 507-514).  One block per frame; a group reference needs
+// the centre of geometry of the group (refined Bai-Breen, like the global membrane centre).
+struct GeomArgs {
+    const float *xyz;
+    const float *box9;
+    uint32_t n_atoms;
+    int pbc;
+    uint32_t kind, reference, orientation;
+    float point[3];
+    const uint32_t *group;
+    uint32_t n_group;
+    float xdim[2], ydim[2], zdim[2], radius, span[2], structure_box[3];
+    float *shapes;   // [n_frames][8]
+    uint32_t *err;
+};
+
+__global__ __launch_bounds__(256) void k_geom_shapes(GeomArgs g) {
+    __shared__ double scratch[256];
+    const uint32_t f = blockIdx.x;
+    float box[3] = {1.0f, 1.0f, 1.0f};
+    if (g.pbc) { const float *b = g.box9 + 9 * (size_t)f; box[0] = b[0]; box[1] = b[4]; box[2] = b[8]; }
+    int bad = 0;
+    float ref[3] = {g.point[0], g.point[1], g.point[2]};
+    float shape_box[3] = {box[0], box[1], box[2]};
+    if (g.reference == GORDER_GEOMREF_BOX_CENTER) {
+        for (int d = 0; d < 3; d++) ref[d] = box[d] / 2.0f;
+    } else if (g.reference == GORDER_GEOMREF_GROUP) {
+        const float *x = g.xyz + (size_t)f * g.n_atoms * 3u;
+        float est[3] = {0.0f, 0.0f, 0.0f};
+        if (g.pbc) {
+            double sc[3] = {0, 0, 0}, ss[3] = {0, 0, 0};
+            for (uint32_t i = threadIdx.x; i < g.n_group; i += blockDim.x) {
+                const float *p = x + 3u * (size_t)g.group[i];
+                for (int d = 0; d < 3; d++) {
+                    float sn, cs;
+                    sincosf(gm_wrap(p[d], box[d], bad) * (6.2831855f / box[d]), &sn, &cs);
+                    sc[d] += (double)cs;
+                    ss[d] += (double)sn;
+                }
+            }
+            for (int d = 0; d < 3; d++) {
+                const double tc = block_sum(sc[d], scratch), ts = block_sum(ss[d], scratch);
+                est[d] = (atan2f(-(float)ts, -(float)tc) + 3.1415927f) / (6.2831855f / box[d]);
+            }
+        }
+        double acc[3] = {0, 0, 0};
+        for (uint32_t i = threadIdx.x; i < g.n_group; i += blockDim.x) {
+            const float *p = x + 3u * (size_t)g.group[i];
+            for (int d = 0; d < 3; d++) {
+                const float dx = p[d] - est[d];
+                acc[d] += (double)(g.pbc ? gm_min_image(dx, box[d], bad) : dx);
+            }
+        }
+        for (int d = 0; d < 3; d++) {
+            const double tot = block_sum(acc[d], scratch);
+            float c = est[d] + (float)(tot / (double)g.n_group);
+            if (g.pbc) c = gm_wrap(c, box[d], bad);
+            ref[d] = c;
+        }
+    } else {
+        for (int d = 0; d < 3; d++) shape_box[d] = g.structure_box[d];   // fixed point: built once, structure box
+    }
+    if (threadIdx.x == 0) {
+        const float anchor = g.pbc ? 0.0f : -3.40282347e+38f;   // get_infinite_span, pbc.rs:236-240, 392-396
+        const float inf = __builtin_inff();
+        float sh[8] = {ref[0], ref[1], ref[2], 0.0f, 0.0f, 0.0f, g.radius, 0.0f};
+        if (g.kind == GORDER_GEOM_CUBOID) {
+            const float *dims[3] = {g.xdim, g.ydim, g.zdim};
+            for (int d = 0; d < 3; d++) {
+                if (dims[d][0] == -inf && dims[d][1] == inf) { sh[d] = anchor; sh[3 + d] = inf; }
+                else { sh[d] = ref[d] + dims[d][0]; sh[3 + d] = dims[d][1] - dims[d][0]; }
+            }
+        } else if (g.kind == GORDER_GEOM_CYLINDER) {
+            const int o = (int)g.orientation;
+            if (g.span[0] == -inf && g.span[1] == inf) { sh[o] = anchor; sh[7] = inf; }
+            else { sh[o] = ref[o] + g.span[0]; sh[7] = g.span[1] - g.span[0]; }
+        }
+        if (g.pbc) for (int d = 0; d < 3; d++) sh[d] = gm_wrap(sh[d], shape_box[d], bad);
+        for (int k = 0; k < 8; k++) g.shapes[8 * (size_t)f + k] = sh[k];
+    }
+    if (bad) raise_error(g.err, GORDER_ERR_BOX_RANGE, 0, f);
 }
 
 // One block per assignment frame: refined Bai-Breen centre of the membrane group
@@ -1228,6 +1348,9 @@ struct gorder_hip_handle {
     unsigned long long *d_tw_sums = nullptr, *d_tw_cnts = nullptr;
     uint64_t tw_cap = 0;
     ExtraArgs extra{};
+    uint32_t *d_geom_group = nullptr;
+    float *d_shapes = nullptr;
+    size_t shapes_cap = 0;
     uint32_t *d_err = nullptr;
     unsigned long long *d_acc = nullptr;   // [4][n_acc] + total_frames
     unsigned long long *d_rep = nullptr;   // [n_rep][4][n_acc] (see k_fold_replicas)
@@ -1340,7 +1463,21 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
     HIP_TRY(h, hipEventCreate(&e0));
     HIP_TRY(h, hipEventCreate(&e1));
     HIP_TRY(h, hipEventRecord(e0, h->stream));
-    const bool extras = h->extra.maps || h->extra.tw;
+    const bool extras = h->extra.maps || h->extra.tw || h->extra.geom_kind;
+    if (h->extra.geom_kind) {
+        int st2;
+        if ((st2 = ensure(h, &h->d_shapes, &h->shapes_cap, (size_t)a.n_frames * 8)) != GORDER_OK) return st2;
+        const gorder_geometry_t &ge = h->tables.geometry;
+        GeomArgs ga{};
+        ga.xyz = a.xyz; ga.box9 = a.box9; ga.n_atoms = a.n_atoms; ga.pbc = a.pbc;
+        ga.kind = ge.kind; ga.reference = ge.reference; ga.orientation = ge.orientation;
+        for (int d = 0; d < 3; d++) { ga.point[d] = ge.point[d]; ga.structure_box[d] = ge.structure_box[d]; }
+        for (int d = 0; d < 2; d++) { ga.xdim[d] = ge.xdim[d]; ga.ydim[d] = ge.ydim[d]; ga.zdim[d] = ge.zdim[d]; ga.span[d] = ge.span[d]; }
+        ga.radius = ge.radius; ga.group = h->d_geom_group; ga.n_group = ge.n_group;
+        ga.shapes = h->d_shapes; ga.err = h->d_err;
+        hipLaunchKernelGGL(k_geom_shapes, dim3(a.n_frames), dim3(256), 0, h->stream, ga);
+        HIP_TRY(h, hipGetLastError());
+    }
     if (n_tiles && !extras) {
         // enough workgroups to fill 256 CUs x 8 blocks, frames split into chunks of whole stages
         // Cut the frame range into chunks of whole stages.  All workgroups do the same amount of work,
@@ -1420,6 +1557,7 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
         // scatter-bound modes: plain per-sample kernels (see "Extras" above)
         ExtraArgs e = h->extra;
         e.tw_sums = h->d_tw_sums; e.tw_cnts = h->d_tw_cnts; e.tw_row0 = h->n_frames;
+        e.shapes = h->d_shapes;
         const bool ac = (h->tables.flags & GORDER_FLAG_TRIG_ACOS_COS) != 0;
         for (int pass = 0; pass < 2; pass++) {
             const uint32_t nt = pass == 0 ? (extras ? n_tiles : 0u) : (uint32_t)p.ua_tiles.size();
@@ -1567,8 +1705,28 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
             e.map_sums = h->d_map_sums; e.map_cnts = h->d_map_cnts;
         }
         e.tw = t->timewise ? 1 : 0;
-        if ((e.maps || e.tw) && !p.direct.empty())
-            return fail(h, GORDER_ERR_INVALID_ARGUMENT, "ordermaps / timewise need every bond to fit an atom window");
+        const gorder_geometry_t &ge = t->geometry;
+        if (ge.kind != GORDER_GEOM_NONE) {
+            if (ge.kind > GORDER_GEOM_SPHERE || ge.reference > GORDER_GEOMREF_GROUP || ge.orientation > 2)
+                return fail(h, GORDER_ERR_INVALID_ARGUMENT, "geometry kind/reference/orientation");
+            if (ge.reference == GORDER_GEOMREF_BOX_CENTER && !t->handle_pbc)
+                return fail(h, GORDER_ERR_INVALID_ARGUMENT, "box-centre reference needs handle_pbc (pbc.rs:243-245)");
+            if (ge.reference == GORDER_GEOMREF_POINT && t->handle_pbc &&
+                !(ge.structure_box[0] > 0.0f && ge.structure_box[1] > 0.0f && ge.structure_box[2] > 0.0f))
+                return fail(h, GORDER_ERR_INVALID_ARGUMENT, "geometry.structure_box");
+            if (ge.reference == GORDER_GEOMREF_GROUP) {
+                if (!ge.group || ge.n_group == 0) return fail(h, GORDER_ERR_INVALID_ARGUMENT, "geometry.group");
+                std::vector<uint32_t> grp(ge.group, ge.group + ge.n_group);
+                for (uint32_t a : grp)
+                    if (a >= t->n_atoms) return fail(h, GORDER_ERR_INVALID_ARGUMENT, "geometry group index out of range");
+                if ((st = upload(h, &h->d_geom_group, grp)) != GORDER_OK) return st;
+            }
+            e.geom_kind = (int)ge.kind; e.geom_invert = ge.invert ? 1 : 0; e.geom_orient = (int)ge.orientation;
+            h->tables.geometry.group = nullptr;
+        }
+        if ((e.maps || e.tw || e.geom_kind) && !p.direct.empty())
+            return fail(h, GORDER_ERR_INVALID_ARGUMENT,
+                        "ordermaps / timewise / geometry need every bond to fit an atom window");
     }
     HIP_TRY(h, hipMalloc((void **)&h->d_err, kErrWords * sizeof(uint32_t)));
     HIP_TRY(h, hipMemset(h->d_err, 0, kErrWords * sizeof(uint32_t)));
@@ -1677,6 +1835,7 @@ void gorder_hip_destroy(gorder_hip_handle *h) {
     (void)hipFree(h->d_direct); (void)hipFree(h->d_err);
     (void)hipFree(h->d_ua_tiles); (void)hipFree(h->d_ua_items); (void)hipFree(h->d_ua_tile_slots);
     (void)hipFree(h->d_map_sums); (void)hipFree(h->d_map_cnts); (void)hipFree(h->d_tw_sums); (void)hipFree(h->d_tw_cnts);
+    (void)hipFree(h->d_geom_group); (void)hipFree(h->d_shapes);
     if (!h->acc_external) (void)hipFree(h->d_acc);
     (void)hipFree(h->d_rep);
     (void)hipFree(h->d_heads); (void)hipFree(h->d_membrane); (void)hipFree(h->d_methyl_begin);

@@ -185,7 +185,7 @@ def classify(structure: Structure, group1: np.ndarray, group2: np.ndarray, same_
 def build_tables(structure: Structure, analysis: str, sel1: np.ndarray, sel2: Optional[np.ndarray] = None,
                  master: Optional[np.ndarray] = None, leaflets: Optional[dict] = None, handle_pbc: bool = True,
                  normal=(0.0, 0.0, 1.0), ordermap: Optional[OrderMap] = None, timewise: bool = False,
-                 flags: int = 0):
+                 flags: int = 0, geometry=None):
     """analysis: 'aa' (sel1 = heavy atoms, sel2 = hydrogens) or 'cg' (sel1 = beads).
     `master`: boolean mask of the atoms present in the coordinate frames handed to the engine (the
     "Master" group, common.rs:92-103); default = union of every selection involved.
@@ -251,6 +251,8 @@ def build_tables(structure: Structure, analysis: str, sel1: np.ndarray, sel2: Op
                         flip=lf.get("flip", False), radius=lf.get("radius", 0.0), membrane=mem)
     tables = Tables(n_atoms=len(midx), molecule_types=mts, handle_pbc=handle_pbc, normal=normal, leaflets=leaf,
                     ordermap=ordermap or OrderMap(), timewise=timewise, flags=flags)
+    if geometry is not None:
+        tables.geometry = geometry
     return tables, labels, midx
 
 
@@ -469,6 +471,7 @@ def compare_trees(got, want, tol=2e-4, path="") -> List[str]:
         return [] if got == want else [f"{path}: {got!r} != {want!r}"]
     if (g != g) and (w != w):
         return []
-    if not abs(g - w) <= tol:
+    # the reference parses both tokens as f32 and applies approx's `abs_diff <= epsilon` in f32
+    if not np.abs(np.float32(g) - np.float32(w)) <= np.float32(tol):
         bad.append(f"{path}: {g} vs {w}")
     return bad

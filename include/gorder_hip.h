@@ -118,6 +118,27 @@ typedef struct {
     const uint32_t *methyls;   /* [n_molecules][n_methyls] or NULL */
 } gorder_moltype_t;
 
+/* ---- geometry selection (src/analysis/geometry.rs:24-136, 181-210; input/geometry.rs) ----------
+ * Only samples whose bond position lies inside (or, inverted, outside) the shape are accumulated
+ * (bond.rs:424-426, uaorder.rs:388-390).  The shape is re-anchored every frame (geometry.rs:192-210). */
+typedef enum { GORDER_GEOM_NONE = 0, GORDER_GEOM_CUBOID = 1, GORDER_GEOM_CYLINDER = 2, GORDER_GEOM_SPHERE = 3 } gorder_geom_kind_t;
+typedef enum { GORDER_GEOMREF_POINT = 0, GORDER_GEOMREF_BOX_CENTER = 1, GORDER_GEOMREF_GROUP = 2 } gorder_geom_ref_t;
+typedef struct {
+    uint32_t kind;          /* gorder_geom_kind_t */
+    uint32_t invert;
+    uint32_t reference;     /* gorder_geom_ref_t: fixed point / box centre / centre of geometry of a group */
+    float point[3];
+    uint32_t n_group;
+    const uint32_t *group;  /* atom indices of group "GeomReference" */
+    float xdim[2], ydim[2], zdim[2];   /* cuboid extents relative to the reference; {-inf, +inf} = unbounded */
+    float radius;           /* cylinder, sphere */
+    float span[2];          /* cylinder: extent along its axis relative to the reference; {-inf, +inf} = unbounded */
+    uint32_t orientation;   /* cylinder axis 0/1/2 */
+    float structure_box[3]; /* box of the STRUCTURE file: a shape anchored at a fixed point is built (and its
+                               anchor wrapped) once, at setup, with that box (geometry.rs:296-311 + :194);
+                               box-centre / group references are rebuilt with each frame's box */
+} gorder_geometry_t;
+
 /* How cos(theta) of calc_sch (mod.rs:78-82) is evaluated.
  * Default (0): cos(theta) = clamp(v.n / (|v||n|), -1, 1) taken DIRECTLY.  The reference evaluates
  *   `angle = acos(clamp(..))` and then `angle.cos()` in f32; that round trip returns the same number
@@ -140,6 +161,7 @@ typedef struct {
     int32_t timewise;           /* 1 = keep per-frame partial sums (estimate_error; timewise.rs:130-186) */
     int32_t device;             /* HIP device ordinal */
     uint32_t flags;             /* gorder_flags_t */
+    gorder_geometry_t geometry; /* kind = GORDER_GEOM_NONE: every sample counts (geometry.rs:215-284) */
 } gorder_tables_t;
 
 /* Accumulator slots are numbered in reference iteration order: molecule type major, then bond

@@ -351,6 +351,59 @@ int gorder_oracle_predict_hydrogens(uint32_t kind, const float pos[4][3], const 
     return -2;
 }
 
+/* ---- geometry selection ----------------------------------------------------------------------
+ * Shape construction: CuboidAnalysis / CylinderAnalysis / SphereAnalysis::construct_shape
+ * (geometry.rs:328-357, 422-451, 507-514) with get_infinite_span (pbc.rs:236-240, 392-396): an
+ * unbounded extent anchors at 0 (PBC) or f32::MIN (NoPBC).  [3rd-party] groan_rs Rectangular /
+ * Cylinder / Sphere ::inside: offsets from the anchor are wrapped into [0, L] (PBC) and must not exceed
+ * the extent; radial tests use the minimum-image distance, strict `<`. */
+typedef struct { float pos[3]; float size[3]; float radius, height; } o_shape;
+
+static int make_shape(const gorder_geometry_t *g, const float *ref, const float *box, int pbc, o_shape *sh) {
+    int bad = 0;
+    const float unbounded_anchor = pbc ? 0.0f : -3.40282347e+38f;
+    memset(sh, 0, sizeof(*sh));
+    for (int d = 0; d < 3; d++) sh->pos[d] = ref[d];
+    if (g->kind == GORDER_GEOM_CUBOID) {
+        const float *dims[3] = {g->xdim, g->ydim, g->zdim};
+        for (int d = 0; d < 3; d++) {
+            if (dims[d][0] == -INFINITY && dims[d][1] == INFINITY) { sh->pos[d] = unbounded_anchor; sh->size[d] = INFINITY; }
+            else { sh->pos[d] = ref[d] + dims[d][0]; sh->size[d] = dims[d][1] - dims[d][0]; }
+        }
+    } else if (g->kind == GORDER_GEOM_CYLINDER) {
+        const int o = (int)g->orientation;
+        sh->radius = g->radius;
+        if (g->span[0] == -INFINITY && g->span[1] == INFINITY) { sh->pos[o] = unbounded_anchor; sh->height = INFINITY; }
+        else { sh->pos[o] = ref[o] + g->span[0]; sh->height = g->span[1] - g->span[0]; }
+    } else {
+        sh->radius = g->radius;
+    }
+    if (pbc) for (int d = 0; d < 3; d++) sh->pos[d] = wrap1(sh->pos[d], box[d], &bad);
+    return bad;
+}
+
+static inline int inside_shape(const gorder_geometry_t *g, const o_shape *sh, const float *p, const float *box,
+                               int pbc, int *bad) {
+    int in = 1;
+    if (g->kind == GORDER_GEOM_CUBOID) {
+        for (int d = 0; d < 3; d++) {
+            float e = p[d] - sh->pos[d];
+            if (pbc) { e = wrap1(e, box[d], bad); in = in && (e <= sh->size[d]); }
+            else in = in && (e >= 0.0f) && (e <= sh->size[d]);
+        }
+    } else if (g->kind == GORDER_GEOM_CYLINDER) {
+        const int o = (int)g->orientation, a = (o + 1) % 3, b = (o + 2) % 3;
+        float da = p[a] - sh->pos[a], db = p[b] - sh->pos[b], e = p[o] - sh->pos[o];
+        if (pbc) { da = min_image(da, box[a], bad); db = min_image(db, box[b], bad); e = wrap1(e, box[o], bad); }
+        in = (sqrtf(da * da + db * db) < sh->radius) && (pbc ? 1 : (e >= 0.0f)) && (e <= sh->height);
+    } else if (g->kind == GORDER_GEOM_SPHERE) {
+        float d[3];
+        for (int k = 0; k < 3; k++) { d[k] = p[k] - sh->pos[k]; if (pbc) d[k] = min_image(d[k], box[k], bad); }
+        in = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) < sh->radius;
+    }
+    return in ^ (g->invert ? 1 : 0);
+}
+
 /* ---- timewise statistics ------------------------------------------------------------------ */
 /* TimeWiseData::estimate_error, timewise.rs:191-231; [3rd-party] statistical::standard_deviation
  * = sqrt(sum((x-mean)^2)/(n-1)) in f32. */
@@ -428,6 +481,8 @@ struct gorder_oracle_handle {
     uint32_t *membrane;
     gorder_ordermap_t om;
     uint32_t nx, ny;
+    gorder_geometry_t geom;
+    uint32_t *geom_group;
     o_acc acc;
     /* leaflets: flags of the most recent assignment (AssignedLeaflets::local, leaflets.rs:1371-1380) */
     uint8_t *flags;
@@ -499,6 +554,18 @@ int gorder_oracle_create(const gorder_tables_t *t, int trig_mode, int n_threads,
     h->lf = t->leaflets;
     h->membrane = (uint32_t *)dup_mem(t->leaflets.membrane, sizeof(uint32_t) * t->leaflets.n_membrane);
     h->lf.membrane = h->membrane;
+    h->geom = t->geometry;
+    h->geom_group = (uint32_t *)dup_mem(t->geometry.group, sizeof(uint32_t) * t->geometry.n_group);
+    h->geom.group = h->geom_group;
+    if (h->geom.kind != GORDER_GEOM_NONE && h->pbc && h->geom.reference == GORDER_GEOMREF_POINT &&
+        !(h->geom.structure_box[0] > 0.0f && h->geom.structure_box[1] > 0.0f && h->geom.structure_box[2] > 0.0f)) {
+        free(h->geom_group); free(h->membrane); free(h);
+        return GORDER_ERR_INVALID_ARGUMENT;
+    }
+    if (h->geom.kind != GORDER_GEOM_NONE && h->geom.reference == GORDER_GEOMREF_BOX_CENTER && !h->pbc) {
+        free(h->geom_group); free(h->membrane); free(h);
+        return GORDER_ERR_INVALID_ARGUMENT;   /* NoPBC::get_box_center panics, pbc.rs:243-245 */
+    }
     h->om = t->ordermap;
     if (h->om.enabled) {
         h->nx = gridmap_n(h->om.span_x[0], h->om.span_x[1], h->om.bin[0]);
@@ -550,7 +617,7 @@ void gorder_oracle_destroy(gorder_oracle_handle *h) {
         for (uint32_t a = 0; a < d->n_ua_atoms; a++) free(d->ua_idx[a]);
         free(d->ua_kind); free(d->ua_idx); free(d->ua_slot0); free(d->heads); free(d->methyls);
     }
-    free(h->mt); free(h->membrane); acc_free(&h->acc);
+    free(h->mt); free(h->membrane); free(h->geom_group); acc_free(&h->acc);
     free(h->flags); free(h->flag_dist); free(h->tw_sums); free(h->tw_counts);
     free(h);
 }
@@ -687,6 +754,16 @@ static int analyze_frame_orders(const gorder_oracle_handle *h, o_acc *a, int64_t
                                 uint64_t *err_index) {
     int bad = 0;
     const int lf = h->lf.method != GORDER_LEAFLETS_NONE;
+    const int geom = h->geom.kind != GORDER_GEOM_NONE;
+    o_shape shape;
+    if (geom) {   /* GeometrySelection::init_reference, geometry.rs:192-210 */
+        float ref[3] = {h->geom.point[0], h->geom.point[1], h->geom.point[2]};
+        const float *shape_box = box;
+        if (h->geom.reference == GORDER_GEOMREF_BOX_CENTER) { ref[0] = box[0] / 2.0f; ref[1] = box[1] / 2.0f; ref[2] = box[2] / 2.0f; }
+        else if (h->geom.reference == GORDER_GEOMREF_GROUP) bad |= center_of(xyz, h->geom_group, h->geom.n_group, box, h->pbc, ref);
+        else shape_box = h->geom.structure_box;   /* fixed point: built once, with the structure's box (:194) */
+        bad |= make_shape(&h->geom, ref, shape_box, h->pbc, &shape);
+    }
     for (uint32_t m = 0; m < h->n_mt; m++) {
         const o_moltype *mt = &h->mt[m];
         for (uint32_t bt = 0; bt < mt->n_bond_types; bt++) {
@@ -699,6 +776,7 @@ static int analyze_frame_orders(const gorder_oracle_handle *h, o_acc *a, int64_t
                 float v[3], mid[3];
                 bad |= vector_to(p1, p2, box, h->pbc, v);
                 for (int d = 0; d < 3; d++) mid[d] = p1[d] + v[d] / 2.0f; /* bond.rs:422 */
+                if (geom && !inside_shape(&h->geom, &shape, mid, box, h->pbc, &bad)) continue; /* bond.rs:424-426 */
                 const float sch = calc_sch(v, h->normal, h->trig);
                 add_order(h, a, tw_s, tw_n, mt->slot0 + bt, sch, mid, lf ? flags[mt->mol0 + i] : -1);
             }
@@ -723,6 +801,7 @@ static int analyze_frame_orders(const gorder_oracle_handle *h, o_acc *a, int64_t
                     float v[3], bp[3];
                     bad |= vector_to(pos[ti], hy[k], box, h->pbc, v);
                     for (int d = 0; d < 3; d++) bp[d] = hy[k][d] + v[d] / 2.0f;
+                    if (geom && !inside_shape(&h->geom, &shape, bp, box, h->pbc, &bad)) continue; /* uaorder.rs:388-390 */
                     const float sch = calc_sch(v, h->normal, h->trig);
                     add_order(h, a, tw_s, tw_n, mt->ua_slot0[ua] + (uint32_t)k, sch, bp,
                               lf ? flags[mt->mol0 + i] : -1);

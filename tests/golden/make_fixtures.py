@@ -63,7 +63,9 @@ if __name__ == "__main__":
     pack("ua", "ua_nobox.pdb", None, ["ua.xtc"])      # tests_ua.rs:19-68 (names + bonds from the PDB twin of ua.tpr)
     for f in ("aa_order_basic.yaml", "aa_order_begin_end_step.yaml", "aa_order_leaflets.yaml",
               "cg_order_basic.yaml", "cg_order_begin_end_step.yaml", "cg_order_leaflets.yaml",
-              "ua_order_basic.yaml", "ua_order_leaflets.yaml"):
+              "ua_order_basic.yaml", "ua_order_leaflets.yaml",
+              "aa_order_cuboid_square.yaml", "aa_order_cylinder.yaml", "aa_order_sphere_static.yaml",
+              "aa_order_cuboid_patch.yaml", "aa_order_cylinder_x.yaml", "aa_order_sphere_center.yaml"):
         src = os.path.join(REF, f)
         if os.path.exists(src):
             shutil.copy(src, os.path.join(HERE, "expected", f))

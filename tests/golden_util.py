@@ -50,10 +50,12 @@ def expected(name):
         return yaml.safe_load(f)
 
 
-def aa_setup(fx, leaflets=None, frequency=1, **kw):
+def aa_setup(fx, leaflets=None, frequency=1, heavy=None, **kw):
     """AAOrder '@membrane and element name carbon' / '... hydrogen' (tests_aa.rs:63-66); the fixture
     holds exactly the @membrane lipids."""
-    heavy, hyd = fx.element("carbon"), fx.element("hydrogen")
+    hyd = fx.element("hydrogen")
+    if heavy is None:
+        heavy = fx.element("carbon")
     lf = None
     if leaflets is not None:
         allm = np.ones(fx.structure.n_atoms, dtype=bool)

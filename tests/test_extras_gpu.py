@@ -4,8 +4,9 @@ import numpy as np
 import pytest
 
 from gorder_amd import HipEngine, abi, synthetic
-from gorder_amd.abi import (LEAFLETS_GLOBAL, LEAFLETS_INDIVIDUAL, LEAFLETS_NONE, OrderMap, UA_CH1_UNSAT,
-                            UA_N_H)
+from gorder_amd.abi import (GEOM_CUBOID, GEOM_CYLINDER, GEOM_SPHERE, GEOMREF_BOX_CENTER, GEOMREF_GROUP,
+                            GEOMREF_POINT, LEAFLETS_GLOBAL, LEAFLETS_INDIVIDUAL, LEAFLETS_NONE, Geometry, OrderMap,
+                            UA_CH1_UNSAT, UA_N_H)
 from oracle import oracle
 
 pytestmark = pytest.mark.gpu
@@ -117,3 +118,53 @@ def test_united_atoms_with_maps_and_timewise(built):
     gs, gc = eng.timewise(n)
     np.testing.assert_array_equal(gc.sum(axis=0), got.counts)
     np.testing.assert_array_equal(gs.sum(axis=0), got.sums)
+
+
+INF = float("inf")
+
+
+@pytest.mark.parametrize("pbc", [True, False])
+@pytest.mark.parametrize("geom", [
+    Geometry(kind=GEOM_CUBOID, reference=GEOMREF_GROUP, xdim=(-3.0, 2.0), ydim=(-INF, INF), zdim=(-1.0, 4.0)),
+    Geometry(kind=GEOM_CUBOID, reference=GEOMREF_POINT, point=(9.0, 1.0, 3.0), xdim=(-2.0, 1.5), ydim=(-2.0, 3.0), invert=True),
+    Geometry(kind=GEOM_CYLINDER, reference=GEOMREF_GROUP, radius=2.5, span=(-2.0, 2.5), orientation=2),
+    Geometry(kind=GEOM_CYLINDER, reference=GEOMREF_POINT, point=(1.0, 11.0, 2.0), radius=2.0, orientation=0, invert=True),
+    Geometry(kind=GEOM_SPHERE, reference=GEOMREF_GROUP, radius=3.0),
+    Geometry(kind=GEOM_SPHERE, reference=GEOMREF_POINT, point=(0.3, 0.2, 5.0), radius=3.2),
+])
+def test_geometry_selection(built, geom, pbc):
+    """geometry.rs: cuboid / cylinder / sphere, fixed-point and group-centre references, inverted or not,
+    with and without PBC; leaflets + timewise on top so that the filtered counts flow everywhere."""
+    system = synthetic.cg_membrane(160, leaflets=LEAFLETS_GLOBAL, n_types=2, handle_pbc=pbc, timewise=True)
+    geom.structure_box = tuple(float(x) for x in system.box)
+    if geom.reference == GEOMREF_GROUP:
+        geom.group = np.arange(0, system.n_atoms, 7, dtype=np.uint32)
+    system.tables.geometry = geom
+    n = 9
+    xyz = system.frames(n, seed=13)
+    eng, o, got, want = both(system, xyz, system.box9(n) if pbc else None)
+    total = n * system.tables.n_samples_per_frame
+    assert 0 < got.counts[0].sum() <= total
+    if pbc:
+        assert got.counts[0].sum() < total      # every shape above really filters in the periodic box
+    np.testing.assert_array_equal(got.counts, want.counts)
+    np.testing.assert_array_equal(got.sums, want.sums)
+    gs, gc = eng.timewise(n)
+    ws, wc = o.timewise(n)
+    np.testing.assert_array_equal(gc, wc)
+    np.testing.assert_array_equal(gs, ws)
+
+
+def test_geometry_box_centre_and_united_atoms(built):
+    system = synthetic.ua_membrane(24)
+    system.tables.geometry = Geometry(kind=GEOM_CYLINDER, reference=GEOMREF_BOX_CENTER, radius=2.5, orientation=2)
+    xyz = system.frames(6, seed=1)
+    eng, o, got, want = both(system, xyz, system.box9(6))
+    np.testing.assert_array_equal(got.counts, want.counts)
+    assert 0 < got.counts[0].sum() < 6 * system.tables.n_samples_per_frame
+    # box-centre reference without PBC is refused (NoPBC::get_box_center panics, pbc.rs:243-245)
+    s2 = synthetic.cg_membrane(20, handle_pbc=False)
+    s2.tables.geometry = Geometry(kind=GEOM_SPHERE, reference=GEOMREF_BOX_CENTER, radius=1.0)
+    with pytest.raises(abi.GorderHipError) as e:
+        HipEngine(s2.tables)
+    assert e.value.status == abi.ERR_INVALID_ARGUMENT

@@ -131,3 +131,19 @@ def test_ua_order_leaflets(ua, method, frequency):
     eng, res, *_ = gpu_run(tables, ua, midx, frames)
     bad = st.compare_trees(st.results_tree_ua(res, labels, leaflets=True), expected("ua_order_leaflets.yaml"))
     assert not bad, bad[:10]
+
+
+# ---- geometry selection --------------------------------------------------------------------------
+from test_golden_oracle import GEOMETRY_CASES, geometry_tables   # noqa: E402
+
+
+@pytest.mark.parametrize("case", sorted(GEOMETRY_CASES))
+def test_aa_geometry_selection(pcpepg, case):
+    tables, labels, midx, want = geometry_tables(pcpepg, case)
+    frames = pcpepg.window()
+    eng, res, xyz, box, fi = gpu_run(tables, pcpepg, midx, frames)
+    bad = st.compare_trees(st.results_tree(res, labels, "aa", leaflets=False), expected(want))
+    assert not bad, bad[:10]
+    _, ref = oracle_run(tables, xyz, box, fi, oracle.TRIG_DIRECT)
+    np.testing.assert_array_equal(res.counts, ref.counts)     # the same samples pass the filter
+    np.testing.assert_array_equal(res.sums, ref.sums)

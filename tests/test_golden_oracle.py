@@ -144,3 +144,59 @@ def test_ua_order_leaflets(ua, method, frequency):
     tree = st.results_tree_ua(eng.finish(), labels, leaflets=True)
     bad = st.compare_trees(tree, expected("ua_order_leaflets.yaml"))
     assert not bad, bad[:10]
+
+
+# ---- geometry selection (geometry.rs; tests_aa.rs:3022-3262) ------------------------------------
+from gorder_amd.abi import (GEOM_CUBOID, GEOM_CYLINDER, GEOM_SPHERE, GEOMREF_BOX_CENTER, GEOMREF_POINT,  # noqa: E402
+                            Geometry)
+
+INF = float("inf")
+GEOMETRY_CASES = {
+    # name: (heavy-atom selection is the POPC C22/C24/C218 subset?, Geometry, expected file)
+    "cuboid_square": (True, Geometry(kind=GEOM_CUBOID, reference=GEOMREF_POINT, point=(8.0, 2.0, 0.0),
+                                     xdim=(-2.0, 4.0), ydim=(-4.0, 1.0)), "aa_order_cuboid_square.yaml"),
+    "cylinder": (True, Geometry(kind=GEOM_CYLINDER, reference=GEOMREF_POINT, point=(8.0, 2.0, 0.0), radius=2.5,
+                                orientation=2), "aa_order_cylinder.yaml"),
+    "sphere_static": (False, Geometry(kind=GEOM_SPHERE, reference=GEOMREF_POINT, point=(8.0, 2.0, 4.5), radius=2.5),
+                      "aa_order_sphere_static.yaml"),
+    "cuboid_patch": (False, Geometry(kind=GEOM_CUBOID, reference=GEOMREF_BOX_CENTER, xdim=(-1.0, 3.0)),
+                     "aa_order_cuboid_patch.yaml"),
+    "cylinder_x": (False, Geometry(kind=GEOM_CYLINDER, reference=GEOMREF_BOX_CENTER, radius=3.0, span=(-1.0, 3.0),
+                                   orientation=0), "aa_order_cylinder_x.yaml"),
+    "sphere_center": (False, Geometry(kind=GEOM_SPHERE, reference=GEOMREF_BOX_CENTER, radius=2.5),
+                      "aa_order_sphere_center.yaml"),
+}
+
+
+def geometry_tables(fx, case):
+    subset, geom, want = GEOMETRY_CASES[case]
+    heavy = None
+    if subset:   # "resname POPC and name C22 C24 C218" (tests_aa.rs:3062)
+        heavy = np.array(fx.structure.resnames) == "POPC"
+        heavy &= fx.name_in("C22", "C24", "C218")
+    geom.structure_box = tuple(float(x) for x in fx.structure.box)
+    tables, labels, midx = aa_setup(fx, heavy=heavy, geometry=geom)
+    return tables, labels, midx, want
+
+
+@pytest.mark.parametrize("case", sorted(GEOMETRY_CASES))
+def test_aa_geometry_selection(pcpepg, case):
+    tables, labels, midx, want = geometry_tables(pcpepg, case)
+    frames = pcpepg.window()
+    eng = oracle.OracleEngine(tables, trig=oracle.TRIG_LIBM, n_threads=4)
+    eng.submit(master_frames(pcpepg, midx, frames), pcpepg.boxes[frames], frames)
+    res = eng.finish()
+    assert 0 < res.counts[0].sum() < 51 * tables.n_samples_per_frame      # the shape really filters
+    tree = st.results_tree(res, labels, "aa", leaflets=False)
+    bad = st.compare_trees(tree, expected(want))
+    assert not bad, bad[:10]
+
+
+def test_unbounded_sphere_is_no_selection(pcpepg):
+    # tests_aa.rs:3000-3020: an infinite sphere reproduces aa_order_basic.yaml
+    tables, labels, midx = aa_setup(pcpepg, geometry=Geometry(kind=GEOM_SPHERE, reference=GEOMREF_BOX_CENTER, radius=INF))
+    frames = pcpepg.window()
+    eng = oracle.OracleEngine(tables, trig=oracle.TRIG_LIBM, n_threads=4)
+    eng.submit(master_frames(pcpepg, midx, frames), pcpepg.boxes[frames], frames)
+    bad = st.compare_trees(st.results_tree(eng.finish(), labels, "aa", leaflets=False), expected("aa_order_basic.yaml"))
+    assert not bad, bad[:10]
