@@ -104,13 +104,14 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         args.gpus = world
-    if rank == 0:
-        entry.build()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        dist.barrier()
+    if rank == 0:
+        entry.build()          # no-op when the in-tree libraries are current
+    if world > 1:
+        dist.barrier()         # nobody loads the library while rank 0 may still be linking it
 
     from gorder_amd import HipEngine
     system, workload = make_system(args.workload)

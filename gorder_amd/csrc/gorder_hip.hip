@@ -892,16 +892,28 @@ struct LeafletArgs {
     uint32_t *err;
 };
 
+// cos / sin of 2*pi*u by the hardware v_cos_f32 / v_sin_f32 (argument in revolutions, ~1e-6 absolute
+// error).  Used only for the Bai-Breen circular-mean ESTIMATE: the estimate merely anchors the
+// minimum-image refinement pass that produces the centre, so its last digits do not matter.
+__device__ __forceinline__ void fast_sincos_rev(float u, float *sn, float *cs) {
+    *sn = __builtin_amdgcn_sinf(u);
+    *cs = __builtin_amdgcn_cosf(u);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// deterministic block reduction: butterfly inside each wave, then every thread adds the <= 16 wave
+// totals in the same order (2 barriers)
 __device__ __forceinline__ double block_sum(double v, double *scratch) {
-    // deterministic tree reduction over the block
-    const uint32_t tid = threadIdx.x;
-    scratch[tid] = v;
+    v = wave_sum(v);
+    const uint32_t wave = threadIdx.x >> 6, n_waves = (blockDim.x + 63u) >> 6;
+    if ((threadIdx.x & 63u) == 0) scratch[wave] = v;
     __syncthreads();
-    for (uint32_t s = blockDim.x >> 1; s > 0; s >>= 1) {
-        if (tid < s) scratch[tid] += scratch[tid + s];
-        __syncthreads();
-    }
-    const double r = scratch[0];
+    double r = 0.0;
+    for (uint32_t w = 0; w < n_waves; w++) r += scratch[w];
     __syncthreads();
     return r;
 }
@@ -942,7 +954,7 @@ __global__ __launch_bounds__(256) void k_geom_shapes(GeomArgs g) {
                 const float *p = x + 3u * (size_t)g.group[i];
                 for (int d = 0; d < 3; d++) {
                     float sn, cs;
-                    sincosf(gm_wrap(p[d], box[d], bad) * (6.2831855f / box[d]), &sn, &cs);
+                    fast_sincos_rev(gm_wrap(p[d], box[d], bad) / box[d], &sn, &cs);
                     sc[d] += (double)cs;
                     ss[d] += (double)sn;
                 }
@@ -992,70 +1004,100 @@ __global__ __launch_bounds__(256) void k_geom_shapes(GeomArgs g) {
 
 // One block per assignment frame: refined Bai-Breen centre of the membrane group
 // (leaflets.rs:186-197 -> groan_rs group_get_center) followed by common_identify_leaflet
-// (leaflets.rs:711-732) for every molecule.  Sums are accumulated in f64 (the reference sums f32
-// sequentially; only the sign of head - centre is consumed).
+// (leaflets.rs:711-732) for every molecule.  Per-thread f32 partial sums are combined in f64 (the
+// reference sums f32 sequentially; only the sign of head - centre is consumed).
 __global__ __launch_bounds__(1024) void k_leaflets_global(LeafletArgs a) {
-    __shared__ double scratch[1024];
-    __shared__ float s_center[3];
+    __shared__ double scratch[16];
+    __shared__ float s_center;
     const uint32_t f = a.aframes[blockIdx.x];
     const float *x = a.xyz + (size_t)f * a.n_atoms * 3u;
-    float box[3] = {1.0f, 1.0f, 1.0f};
-    if (a.pbc) {
-        const float *b = a.box9 + 9 * (size_t)f;
-        box[0] = b[0]; box[1] = b[4]; box[2] = b[8];
-    }
+    const uint32_t dn = a.dim;
+    float L = 1.0f;
+    if (a.pbc) L = a.box9[9 * (size_t)f + 4 * dn];
     int bad = 0;
-    float est[3];
-    if (a.pbc) {
-        double sc[3] = {0, 0, 0}, ss[3] = {0, 0, 0};
-        const float two_pi = 6.2831855f;
-        for (uint32_t i = threadIdx.x; i < a.n_membrane; i += blockDim.x) {
-            const float *p = x + 3u * (size_t)a.membrane[i];
-            for (int d = 0; d < 3; d++) {
-                const float c = gm_wrap(p[d], box[d], bad);
-                const float theta = c * (two_pi / box[d]);
+    // Only the component of the centre along the normal is consumed (leaflets.rs:725); the other two
+    // matter only through the reference's NaN check (leaflets.rs:190-192): a non-finite coordinate of
+    // any membrane atom makes the centre NaN -> InvalidGlobalMembraneCenter.
+    float nonfinite = 0.0f;   // stays 0 while every coordinate is finite (x - x is 0 or NaN)
+    float est = 0.0f;
+    // the first KEEP normal-coordinates of each thread stay in registers for the second pass
+    constexpr int KEEP = 32;
+    float keep[KEEP];
+    const uint32_t nthr = blockDim.x;
+    float sc = 0.0f, ss = 0.0f;   // per-thread partials (<= n/1024 terms), combined in f64 below
+    const float inv = a.pbc ? 1.0f / L : 0.0f;
+    // batches of 8 atoms: the 24 loads of a batch are issued back to back (index clamped: lanes past the
+    // end re-read the last atom and are masked out), then the batch is consumed
+#pragma unroll
+    for (int kb = 0; kb < KEEP; kb += 8) {
+        float nf8[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t i = threadIdx.x + (uint32_t)(kb + k) * nthr;
+            const float *p = x + 3u * (size_t)a.membrane[i < a.n_membrane ? i : a.n_membrane - 1u];
+            const float px = p[0], py = p[1], pz = p[2];
+            nf8[k] = ((px - px) + (py - py)) + (pz - pz);
+            keep[kb + k] = dn == 0 ? px : (dn == 1 ? py : pz);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const bool valid = threadIdx.x + (uint32_t)(kb + k) * nthr < a.n_membrane;
+            nonfinite += valid ? nf8[k] : 0.0f;
+            if (a.pbc) {
                 float sn, cs;
-                sincosf(theta, &sn, &cs);
-                sc[d] += (double)cs;
-                ss[d] += (double)sn;
+                fast_sincos_rev(gm_wrap(keep[kb + k], L, bad) * inv, &sn, &cs);
+                sc += valid ? cs : 0.0f;
+                ss += valid ? sn : 0.0f;
             }
         }
-        for (int d = 0; d < 3; d++) {
-            const double tc = block_sum(sc[d], scratch);
-            const double ts = block_sum(ss[d], scratch);
-            const float th = atan2f(-(float)ts, -(float)tc) + 3.1415927f;
-            est[d] = th / (two_pi / box[d]);
-        }
-    } else {
-        est[0] = est[1] = est[2] = 0.0f;
     }
-    double acc[3] = {0, 0, 0};
-    for (uint32_t i = threadIdx.x; i < a.n_membrane; i += blockDim.x) {
+    for (uint32_t i = threadIdx.x + (uint32_t)KEEP * nthr; i < a.n_membrane; i += nthr) {   // very large groups
         const float *p = x + 3u * (size_t)a.membrane[i];
-        for (int d = 0; d < 3; d++) {
-            const float dx = p[d] - est[d];
-            acc[d] += (double)(a.pbc ? gm_min_image(dx, box[d], bad) : dx);
+        const float px = p[0], py = p[1], pz = p[2];
+        nonfinite += ((px - px) + (py - py)) + (pz - pz);
+        if (a.pbc) {
+            float sn, cs;
+            fast_sincos_rev(gm_wrap(dn == 0 ? px : (dn == 1 ? py : pz), L, bad) * inv, &sn, &cs);
+            sc += cs;
+            ss += sn;
         }
     }
-    for (int d = 0; d < 3; d++) {
-        const double tot = block_sum(acc[d], scratch);
-        if (threadIdx.x == 0) {
-            float c = est[d] + (float)(tot / (double)a.n_membrane);
-            if (a.pbc) c = gm_wrap(c, box[d], bad);
-            s_center[d] = c;
+    if (a.pbc) {
+        const double tc = block_sum((double)sc, scratch), ts = block_sum((double)ss, scratch);
+        est = (atan2f(-(float)ts, -(float)tc) + 3.1415927f) / (6.2831855f / L);
+    }
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < KEEP; k++) {
+        const uint32_t i = threadIdx.x + (uint32_t)k * nthr;
+        if (i < a.n_membrane) {
+            const float dx = keep[k] - est;
+            acc += a.pbc ? gm_min_image(dx, L, bad) : dx;
         }
+    }
+    for (uint32_t i = threadIdx.x + (uint32_t)KEEP * nthr; i < a.n_membrane; i += nthr) {
+        const float dx = x[3u * (size_t)a.membrane[i] + dn] - est;
+        acc += a.pbc ? gm_min_image(dx, L, bad) : dx;
+    }
+    const double tot = block_sum((double)acc, scratch);
+    const double nf = block_sum((double)nonfinite, scratch);
+    if (threadIdx.x == 0) {
+        float c = est + (float)(tot / (double)a.n_membrane);
+        if (a.pbc) c = gm_wrap(c, L, bad);
+        if (c != c || nf != 0.0 || a.n_membrane == 0) {
+            raise_error(a.err, GORDER_ERR_INVALID_GLOBAL_MEMBRANE_CENTER, 0, f);
+            c = __builtin_nanf("");
+        }
+        s_center = c;
     }
     __syncthreads();
-    const float cx = s_center[0], cy = s_center[1], cz = s_center[2];
-    if (threadIdx.x == 0 && (cx != cx || cy != cy || cz != cz || a.n_membrane == 0))
-        raise_error(a.err, GORDER_ERR_INVALID_GLOBAL_MEMBRANE_CENTER, 0, f);
-    const float cdim = a.dim == 0 ? cx : (a.dim == 1 ? cy : cz);
+    const float cdim = s_center;
     uint8_t *row = a.aflags + (size_t)(a.row0 + blockIdx.x) * a.n_mol_total;
     const bool last = blockIdx.x + 1 == gridDim.x;
     for (uint32_t m = threadIdx.x; m < a.n_mol_total; m += blockDim.x) {
-        const float hp = x[3u * (size_t)a.heads[m] + a.dim];
+        const float hp = x[3u * (size_t)a.heads[m] + dn];
         float d = hp - cdim;
-        if (a.pbc) d = gm_min_image(d, box[a.dim], bad);
+        if (a.pbc) d = gm_min_image(d, L, bad);
         row[m] = (uint8_t)((d >= 0.0f ? 0 : 1) ^ (a.flip ? 1 : 0));
         if (last && a.adist) a.adist[m] = d;
     }
@@ -1164,7 +1206,7 @@ __global__ __launch_bounds__(256) void k_local_bin(LocalArgs a) {
         w[d] = a.pbc ? gm_wrap(p[d], box[d], bad) : p[d];
         if (a.pbc) {
             float sn, cs;
-            sincosf(w[d] * (6.2831855f / box[d]), &sn, &cs);
+            fast_sincos_rev(w[d] / box[d], &sn, &cs);
             tr[d] = cs;
             tr[3 + d] = sn;
         }
@@ -1215,11 +1257,6 @@ __global__ __launch_bounds__(256) void k_local_scatter(LocalArgs a) {
     const uint32_t start = a.cell_count[(size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u) + c];
     const uint32_t k = atomicAdd(&a.cell_fill[(size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D) + c], 1u);
     a.cell_atoms[(size_t)s * a.n_membrane + start + k] = i;
-}
-
-__device__ __forceinline__ double wave_sum(double v) {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
 }
 
 // block = 256 threads = 4 waves = 4 heads; grid = (ceil(n_mol / 4), n_slab)
