@@ -1134,9 +1134,9 @@ __global__ __launch_bounds__(256) void k_leaflets_individual(LeafletArgs a) {
 // normal), then common_identify_leaflet (leaflets.rs:711-732).  The reference prunes the search with a
 // CellGrid of cell edge = radius (neighbours +-1 in-plane, all cells along the normal, pbc.rs:287-292);
 // here: a 2-D in-plane cell list per assignment frame, cell edge >= radius, built on the device.
-//   k_local_bin     : per (slab frame, membrane atom): cell id, per-atom cos/sin of the 3 angles, count
+//   k_local_bin     : per (slab frame, membrane atom): cell id, count
 //   k_local_scan    : per slab frame: exclusive scan of the cell counts (one block)
-//   k_local_scatter : per (slab frame, membrane atom): place the atom in its cell's list
+//   k_local_scatter : per (slab frame, membrane atom): cell-ordered record (coordinates + cos/sin)
 //   k_local_flags   : one wave per (slab frame, head): two passes over the 3x3 neighbour cells
 constexpr uint32_t kLocalMaxCells1D = 128;
 constexpr uint32_t kLocalSlab = 32;   // assignment frames processed per launch group
@@ -1160,10 +1160,10 @@ struct LocalArgs {
     float radius;
     // scratch, per slab frame
     uint32_t *cell_of;          // [n_slab][n_membrane]
-    float *trig;                // [n_slab][n_membrane][6]: cos x,y,z then sin x,y,z of 2 pi wrap(c)/L
+    float *trig;                // [n_slab][n_membrane] float4 records in cell order (see k_local_scatter)
+    float *rsn;                 // [n_slab][n_membrane] sin of the normal angle, cell order
     uint32_t *cell_count;       // [n_slab][kLocalMaxCells1D^2 + 1] counts -> starts
     uint32_t *cell_fill;        // [n_slab][kLocalMaxCells1D^2]
-    uint32_t *cell_atoms;       // [n_slab][n_membrane] positions in the membrane list, grouped by cell
     uint32_t *err;
 };
 
@@ -1188,38 +1188,52 @@ __device__ __forceinline__ void frame_box(const LocalArgs &a, uint32_t f, float 
     }
 }
 
+// in-plane cell of membrane atom i in slab frame s (also stored in cell_of)
+__device__ __forceinline__ uint32_t local_cell_of(const LocalArgs &a, uint32_t s, uint32_t f, uint32_t i,
+                                                  const float *box, uint32_t nca, uint32_t ncb, int da, int db) {
+    const float *p = a.xyz + ((size_t)f * a.n_atoms + a.membrane[i]) * 3u;
+    int bad = 0;
+    uint32_t ca = 0, cb = 0;
+    if (a.pbc) {
+        const float wa = gm_wrap(p[da], box[da], bad), wb = gm_wrap(p[db], box[db], bad);
+        ca = (uint32_t)fminf(fmaxf(floorf(wa / box[da] * (float)nca), 0.0f), (float)(nca - 1u));
+        cb = (uint32_t)fminf(fmaxf(floorf(wb / box[db] * (float)ncb), 0.0f), (float)(ncb - 1u));
+    }
+    const uint32_t c = ca * ncb + cb;
+    a.cell_of[(size_t)s * a.n_membrane + i] = c;
+    if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f);
+    return c;
+}
+
+constexpr uint32_t kLocalLdsCells = 4096;   // cell counts are first aggregated per block in LDS up to this grid size
+
 __global__ __launch_bounds__(256) void k_local_bin(LocalArgs a) {
+    __shared__ uint32_t hist[kLocalLdsCells];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t s = blockIdx.y;
-    if (i >= a.n_membrane) return;
     const uint32_t f = a.aframes[s];
     float box[3];
     frame_box(a, f, box);
     uint32_t nca, ncb;
     int da, db;
     local_grid(a, box, nca, ncb, da, db);
-    const float *p = a.xyz + ((size_t)f * a.n_atoms + a.membrane[i]) * 3u;
-    int bad = 0;
-    float w[3];
-    float *tr = a.trig + ((size_t)s * a.n_membrane + i) * 6u;
-    for (int d = 0; d < 3; d++) {
-        w[d] = a.pbc ? gm_wrap(p[d], box[d], bad) : p[d];
-        if (a.pbc) {
-            float sn, cs;
-            fast_sincos_rev(w[d] / box[d], &sn, &cs);
-            tr[d] = cs;
-            tr[3 + d] = sn;
-        }
+    const uint32_t ncell = nca * ncb;
+    uint32_t *count = a.cell_count + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u);
+    const bool lds = ncell <= kLocalLdsCells;   // uniform
+    if (lds) {
+        for (uint32_t k = threadIdx.x; k < ncell; k += blockDim.x) hist[k] = 0;
+        __syncthreads();
     }
-    uint32_t ca = 0, cb = 0;
-    if (a.pbc) {
-        ca = (uint32_t)fminf(fmaxf(floorf(w[da] / box[da] * (float)nca), 0.0f), (float)(nca - 1u));
-        cb = (uint32_t)fminf(fmaxf(floorf(w[db] / box[db] * (float)ncb), 0.0f), (float)(ncb - 1u));
+    if (i < a.n_membrane) {
+        const uint32_t c = local_cell_of(a, s, f, i, box, nca, ncb, da, db);
+        if (lds) atomicAdd(&hist[c], 1u);
+        else atomicAdd(&count[c], 1u);
     }
-    const uint32_t c = ca * ncb + cb;
-    a.cell_of[(size_t)s * a.n_membrane + i] = c;
-    atomicAdd(&a.cell_count[(size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u) + c], 1u);
-    if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f);
+    if (lds) {   // one global atomic per cell the block touched (neighbouring atoms share cells)
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < ncell; k += blockDim.x)
+            if (hist[k]) atomicAdd(&count[k], hist[k]);
+    }
 }
 
 __global__ __launch_bounds__(1024) void k_local_scan(LocalArgs a) {
@@ -1249,14 +1263,48 @@ __global__ __launch_bounds__(1024) void k_local_scan(LocalArgs a) {
     if (threadIdx.x == 1023) cnt[N] = run;
 }
 
+// Places every membrane atom in its cell's run and writes a cell-ordered RECORD next to it so that the
+// flags kernel streams contiguous data instead of chasing two indices per candidate:
+//   rec[q] = (in-plane a, in-plane b, normal coordinate, cos(2 pi wrap(normal)/L)),  rsn[q] = sin(...)
+// Only the normal component of the local centre is consumed (leaflets.rs:725), hence one angle.
 __global__ __launch_bounds__(256) void k_local_scatter(LocalArgs a) {
+    __shared__ uint32_t hist[kLocalLdsCells];   // per-block count, then the block's base offset in each cell
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t s = blockIdx.y;
-    if (i >= a.n_membrane) return;
-    const uint32_t c = a.cell_of[(size_t)s * a.n_membrane + i];
+    const uint32_t f = a.aframes[s];
+    float box[3];
+    frame_box(a, f, box);
+    uint32_t nca, ncb;
+    int da, db;
+    local_grid(a, box, nca, ncb, da, db);
+    const uint32_t ncell = nca * ncb;
+    const int dn = (int)a.dim;
+    const bool lds = ncell <= kLocalLdsCells;   // uniform
+    uint32_t *fill = a.cell_fill + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D);
+    const bool valid = i < a.n_membrane;
+    uint32_t c = 0, rank = 0;
+    if (valid) c = a.cell_of[(size_t)s * a.n_membrane + i];
+    if (lds) {
+        for (uint32_t k = threadIdx.x; k < ncell; k += blockDim.x) hist[k] = 0;
+        __syncthreads();
+        if (valid) rank = atomicAdd(&hist[c], 1u);
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < ncell; k += blockDim.x)
+            if (hist[k]) hist[k] = atomicAdd(&fill[k], hist[k]);   // reserve the block's run inside the cell
+        __syncthreads();
+        if (valid) rank += hist[c];
+    } else if (valid) {
+        rank = atomicAdd(&fill[c], 1u);
+    }
+    if (!valid) return;
     const uint32_t start = a.cell_count[(size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u) + c];
-    const uint32_t k = atomicAdd(&a.cell_fill[(size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D) + c], 1u);
-    a.cell_atoms[(size_t)s * a.n_membrane + start + k] = i;
+    const float *p = a.xyz + ((size_t)f * a.n_atoms + a.membrane[i]) * 3u;
+    int bad = 0;
+    float sn = 0.0f, cs = 0.0f;
+    if (a.pbc) fast_sincos_rev(gm_wrap(p[dn], box[dn], bad) / box[dn], &sn, &cs);
+    const size_t q = (size_t)s * a.n_membrane + start + rank;
+    reinterpret_cast<float4 *>(a.trig)[q] = make_float4(p[da], p[db], p[dn], cs);
+    a.rsn[q] = sn;
 }
 
 // block = 256 threads = 4 waves = 4 heads; grid = (ceil(n_mol / 4), n_slab)
@@ -1271,88 +1319,94 @@ __global__ __launch_bounds__(256) void k_local_flags(LocalArgs a) {
     uint32_t nca, ncb;
     int da, db;
     local_grid(a, box, nca, ncb, da, db);
+    const int dn = (int)a.dim;
     const float *x = a.xyz + (size_t)f * a.n_atoms * 3u;
     const float *hp = x + 3u * (size_t)a.heads[m];
+    const float ha_pos = hp[da], hb_pos = hp[db], hn_pos = hp[dn];
     int bad = 0;
     uint32_t ha = 0, hb = 0;
     if (a.pbc) {
-        const float wa = gm_wrap(hp[da], box[da], bad), wb = gm_wrap(hp[db], box[db], bad);
+        const float wa = gm_wrap(ha_pos, box[da], bad), wb = gm_wrap(hb_pos, box[db], bad);
         ha = (uint32_t)fminf(fmaxf(floorf(wa / box[da] * (float)nca), 0.0f), (float)(nca - 1u));
         hb = (uint32_t)fminf(fmaxf(floorf(wb / box[db] * (float)ncb), 0.0f), (float)(ncb - 1u));
     }
     const uint32_t *cstart = a.cell_count + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u);
-    const uint32_t *catoms = a.cell_atoms + (size_t)s * a.n_membrane;
-    const float *trig = a.trig + (size_t)s * a.n_membrane * 6u;
+    const float4 *rec = reinterpret_cast<const float4 *>(a.trig) + (size_t)s * a.n_membrane;
+    const float *rsn = a.rsn + (size_t)s * a.n_membrane;
     const uint32_t na = nca < 3u ? nca : 3u, nb = ncb < 3u ? ncb : 3u;
+    const float La = box[da], Lb = box[db], Ln = box[dn];
 
-    // pass 1: member count and circular sums (PBC) or plain sums (NoPBC)
-    double acc[6] = {0, 0, 0, 0, 0, 0};
-    double cnt = 0;
+    // pass 1: members (in-plane minimum-image distance < radius; groan_rs Cylinder::inside), their count
+    // and the circular sums of the normal coordinate (PBC) or its plain sum (NoPBC).  The membership
+    // of the first 64 candidates of each lane is remembered as a bit mask for pass 2.
+    float sc = 0.0f, ss = 0.0f, sp = 0.0f, nonfinite = 0.0f;
+    uint32_t cnt = 0;
+    unsigned long long member = 0ull;
+    uint32_t it = 0;
     for (uint32_t ia = 0; ia < na; ia++) {
         const uint32_t ca = (ha + nca - 1u + ia) % nca;
         for (uint32_t ib = 0; ib < nb; ib++) {
             const uint32_t cb = (hb + ncb - 1u + ib) % ncb;
             const uint32_t c = ca * ncb + cb;
-            for (uint32_t q = cstart[c] + lane; q < cstart[c + 1]; q += 64) {
-                const uint32_t i = catoms[q];
-                const float *p = x + 3u * (size_t)a.membrane[i];
-                float ea = p[da] - hp[da], eb = p[db] - hp[db];
-                if (a.pbc) { ea = gm_min_image(ea, box[da], bad); eb = gm_min_image(eb, box[db], bad); }
-                if (__builtin_sqrtf(ea * ea + eb * eb) < a.radius) {   // groan_rs Cylinder::inside, in-plane part
-                    cnt += 1.0;
-                    if (a.pbc) {
-                        for (int d = 0; d < 6; d++) acc[d] += (double)trig[(size_t)i * 6u + d];
-                    } else {
-                        for (int d = 0; d < 3; d++) acc[d] += (double)p[d];
-                    }
+            for (uint32_t q = cstart[c] + lane; q < cstart[c + 1]; q += 64, it++) {
+                const float4 r = rec[q];
+                float ea = r.x - ha_pos, eb = r.y - hb_pos;
+                if (a.pbc) { ea = gm_min_image(ea, La, bad); eb = gm_min_image(eb, Lb, bad); }
+                if (__builtin_sqrtf(ea * ea + eb * eb) < a.radius) {
+                    cnt += 1;
+                    if (it < 64) member |= 1ull << it;
+                    nonfinite += r.z - r.z;
+                    if (a.pbc) { sc += r.w; ss += rsn[q]; }
+                    else sp += r.z;
                 }
             }
         }
     }
-    cnt = wave_sum(cnt);
-    for (int d = 0; d < 6; d++) acc[d] = wave_sum(acc[d]);
-    float center[3];
-    if (cnt == 0.0) {
+    const double tcnt = wave_sum((double)cnt);
+    const double nf = wave_sum((double)nonfinite);
+    if (tcnt == 0.0 || nf != 0.0) {
         if (lane == 0) raise_error(a.err, GORDER_ERR_INVALID_LOCAL_MEMBRANE_CENTER, a.heads[m], f);
         return;
     }
+    float center;
     if (!a.pbc) {
-        for (int d = 0; d < 3; d++) center[d] = (float)(acc[d] / cnt);
+        center = (float)(wave_sum((double)sp) / tcnt);
     } else {
-        float est[3];
-        for (int d = 0; d < 3; d++) {
-            const float th = atan2f(-(float)acc[3 + d], -(float)acc[d]) + 3.1415927f;
-            est[d] = th / (6.2831855f / box[d]);
-        }
-        // pass 2: refine with the mean minimum-image displacement from the estimate
-        double ref[3] = {0, 0, 0};
+        const double tc = wave_sum((double)sc), ts = wave_sum((double)ss);
+        const float est = (atan2f(-(float)ts, -(float)tc) + 3.1415927f) / (6.2831855f / Ln);
+        // pass 2: refine with the mean minimum-image displacement of the members from the estimate
+        float ref = 0.0f;
+        it = 0;
         for (uint32_t ia = 0; ia < na; ia++) {
             const uint32_t ca = (ha + nca - 1u + ia) % nca;
             for (uint32_t ib = 0; ib < nb; ib++) {
                 const uint32_t cb = (hb + ncb - 1u + ib) % ncb;
                 const uint32_t c = ca * ncb + cb;
-                for (uint32_t q = cstart[c] + lane; q < cstart[c + 1]; q += 64) {
-                    const uint32_t i = catoms[q];
-                    const float *p = x + 3u * (size_t)a.membrane[i];
-                    float ea = gm_min_image(p[da] - hp[da], box[da], bad);
-                    float eb = gm_min_image(p[db] - hp[db], box[db], bad);
-                    if (__builtin_sqrtf(ea * ea + eb * eb) < a.radius)
-                        for (int d = 0; d < 3; d++) ref[d] += (double)gm_min_image(p[d] - est[d], box[d], bad);
+                for (uint32_t q = cstart[c] + lane; q < cstart[c + 1]; q += 64, it++) {
+                    bool in;
+                    float pn;
+                    if (it < 64) {
+                        in = (member >> it) & 1ull;
+                        pn = in ? rec[q].z : 0.0f;
+                    } else {
+                        const float4 r = rec[q];
+                        const float ea = gm_min_image(r.x - ha_pos, La, bad), eb = gm_min_image(r.y - hb_pos, Lb, bad);
+                        in = __builtin_sqrtf(ea * ea + eb * eb) < a.radius;
+                        pn = r.z;
+                    }
+                    if (in) ref += gm_min_image(pn - est, Ln, bad);
                 }
             }
         }
-        for (int d = 0; d < 3; d++) {
-            ref[d] = wave_sum(ref[d]);
-            center[d] = gm_wrap(est[d] + (float)(ref[d] / cnt), box[d], bad);
-        }
+        center = gm_wrap(est + (float)(wave_sum((double)ref) / tcnt), Ln, bad);
     }
     if (lane == 0) {
-        if (center[0] != center[0] || center[1] != center[1] || center[2] != center[2]) {
+        if (center != center) {
             raise_error(a.err, GORDER_ERR_INVALID_LOCAL_MEMBRANE_CENTER, a.heads[m], f);
             return;
         }
-        float d = hp[a.dim] - center[a.dim];
-        if (a.pbc) d = gm_min_image(d, box[a.dim], bad);
+        float d = hn_pos - center;
+        if (a.pbc) d = gm_min_image(d, Ln, bad);
         a.aflags[(size_t)(a.row0 + s) * a.n_mol_total + m] = (uint8_t)((d >= 0.0f ? 0 : 1) ^ (a.flip ? 1 : 0));
         if ((int)s == a.write_dist_frame && a.adist) a.adist[m] = d;
     }
@@ -1853,8 +1907,8 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
         if (lf.method == GORDER_LEAFLETS_LOCAL) {
             const size_t nm = lf.n_membrane, ncell = (size_t)kLocalMaxCells1D * kLocalMaxCells1D;
             HIP_TRY(h, hipMalloc((void **)&h->d_lcell_of, kLocalSlab * nm * sizeof(uint32_t)));
-            HIP_TRY(h, hipMalloc((void **)&h->d_lcell_atoms, kLocalSlab * nm * sizeof(uint32_t)));
-            HIP_TRY(h, hipMalloc((void **)&h->d_ltrig, kLocalSlab * nm * 6 * sizeof(float)));
+            HIP_TRY(h, hipMalloc((void **)&h->d_lcell_atoms, kLocalSlab * nm * sizeof(float)));   // sin column
+            HIP_TRY(h, hipMalloc((void **)&h->d_ltrig, kLocalSlab * nm * 4 * sizeof(float)));
             HIP_TRY(h, hipMalloc((void **)&h->d_lcell_count, kLocalSlab * (ncell + 1) * sizeof(uint32_t)));
             HIP_TRY(h, hipMalloc((void **)&h->d_lcell_fill, kLocalSlab * ncell * sizeof(uint32_t)));
         }
@@ -1953,7 +2007,7 @@ static int run_leaflets(gorder_hip_handle *h, const float *d_xyz, const float *d
         lo.dim = lf.normal_dim; lo.flip = lf.flip ? 1 : 0; lo.pbc = h->tables.handle_pbc ? 1 : 0;
         lo.radius = lf.radius;
         lo.cell_of = h->d_lcell_of; lo.trig = h->d_ltrig; lo.cell_count = h->d_lcell_count;
-        lo.cell_fill = h->d_lcell_fill; lo.cell_atoms = h->d_lcell_atoms; lo.err = h->d_err;
+        lo.cell_fill = h->d_lcell_fill; lo.rsn = reinterpret_cast<float *>(h->d_lcell_atoms); lo.err = h->d_err;
         for (size_t done = 0; done < aframes.size(); done += kLocalSlab) {
             const uint32_t ns = (uint32_t)std::min<size_t>(aframes.size() - done, kLocalSlab);
             lo.aframes = h->d_aframes + done;
