@@ -725,19 +725,121 @@ __device__ __forceinline__ V3 v3_rotate(V3 u, float s, float c, V3 v) {
     return {(m11 * v.x + m12 * v.y) + m13 * v.z, (m21 * v.x + m22 * v.y) + m23 * v.z,
             (m31 * v.x + m32 * v.y) + m33 * v.z};
 }
-__device__ __forceinline__ V3 v3_to(V3 p1, V3 p2, const float *box, bool pbc, int &bad) {
-    V3 v{p2.x - p1.x, p2.y - p1.y, p2.z - p1.z};
-    if (pbc) { v.x = gm_min_image(v.x, box[0], bad); v.y = gm_min_image(v.y, box[1], bad); v.z = gm_min_image(v.z, box[2], bad); }
-    return v;
+// Periodic-boundary policies for the hydrogen construction.  PbcStep does one select-only shift per
+// operation and raises `slow` when that was not enough; PbcLoop is the literal `while` form of the
+// reference.  The kernel evaluates a carbon with PbcStep and, only if `slow` came up, again with PbcLoop.
+// (all state in scalars and every aggregate passed by value: nothing here may end up in scratch)
+struct PbcStep {
+    V3 box;
+    bool pbc;
+    bool slow = false;
+    int bad = 0;
+    __device__ __forceinline__ float len(int k) const { return k == 0 ? box.x : (k == 1 ? box.y : box.z); }
+    __device__ __forceinline__ float mi(float d, int k) { return pbc ? gm_min_image_step(d, len(k), slow) : d; }
+    __device__ __forceinline__ float wr(float x, int k) {
+        if (!pbc) return x;
+        const float L = len(k);
+        const float r = x > L ? x - L : (x < 0.0f ? x + L : x);
+        slow = slow || (r > L) || (r < 0.0f);
+        return r;
+    }
+};
+struct PbcLoop {
+    V3 box;
+    bool pbc;
+    bool slow = false;
+    int bad = 0;
+    __device__ __forceinline__ float len(int k) const { return k == 0 ? box.x : (k == 1 ? box.y : box.z); }
+    __device__ __forceinline__ float mi(float d, int k) { return pbc ? gm_min_image_loop(d, len(k), bad) : d; }
+    __device__ __forceinline__ float wr(float x, int k) { return pbc ? gm_wrap(x, len(k), bad) : x; }
+};
+template <typename PB>
+__device__ __forceinline__ V3 v3_to(V3 p1, V3 p2, PB &pb) {
+    return {pb.mi(p2.x - p1.x, 0), pb.mi(p2.y - p1.y, 1), pb.mi(p2.z - p1.z, 2)};
 }
-__device__ __forceinline__ V3 v3_shift_wrap(V3 t, V3 dir, const float *box, bool pbc, int &bad) {
+template <typename PB>
+__device__ __forceinline__ V3 v3_shift_wrap(V3 t, V3 dir, PB &pb) {
     const V3 u = v3_unit(dir);
-    V3 h{t.x + u.x * 0.109f, t.y + u.y * 0.109f, t.z + u.z * 0.109f};   // BOND_LENGTH, uaorder.rs:39
-    if (pbc) { h.x = gm_wrap(h.x, box[0], bad); h.y = gm_wrap(h.y, box[1], bad); h.z = gm_wrap(h.z, box[2], bad); }
-    return h;
+    return {pb.wr(t.x + u.x * 0.109f, 0), pb.wr(t.y + u.y * 0.109f, 1), pb.wr(t.z + u.z * 0.109f, 2)};   // BOND_LENGTH
 }
 
-template <bool ACOS_COS>
+struct UaConsts {
+    float sin_tet, cos_tet, sin_ch3, cos_ch3, sin_half, cos_half;
+};
+struct UaCarbon {       // the carbon's atoms: helper1,target,helper2,- or h1,h2,h3,target (CH1 saturated)
+    V3 p0, p1, p2, p3;
+};
+struct UaBonds {        // per hydrogen: the C->H vector and the bond position (unused entries are zero)
+    V3 v0, v1, v2, b0, b1, b2;
+    int bad;
+};
+
+// hydrogens of one united-atom carbon, then per hydrogen the C->H vector and the bond position
+// (UAAtom::calculate_sch, uaorder.rs:375-397: vec = target -> H, position = H + vec / 2 (sic))
+template <typename PB>
+__device__ __forceinline__ UaBonds ua_carbon(uint32_t kind, UaCarbon c, UaConsts e, PB &pb) {
+    const V3 zero{0.0f, 0.0f, 0.0f};
+    V3 h0 = zero, h1 = zero, h2 = zero, target = c.p1;
+    if (kind == GORDER_UA_CH3) {            // uaorder.rs:947-981
+        const V3 th1 = v3_to(target, c.p0, pb), th2 = v3_to(target, c.p2, pb);
+        const V3 ua = v3_unit(v3_cross(th2, th1));
+        const V3 hv1 = v3_rotate(ua, e.sin_tet, e.cos_tet, th1);
+        h0 = v3_shift_wrap(target, hv1, pb);
+        const V3 n1 = v3_unit(th1);
+        h1 = v3_shift_wrap(target, v3_rotate(n1, e.sin_ch3, e.cos_ch3, hv1), pb);
+        h2 = v3_shift_wrap(target, v3_rotate(n1, -e.sin_ch3, e.cos_ch3, hv1), pb);
+    } else if (kind == GORDER_UA_CH2) {     // uaorder.rs:985-1020
+        const V3 th1 = v3_unit(v3_to(target, c.p0, pb)), th2 = v3_unit(v3_to(target, c.p2, pb));
+        const V3 pn = v3_cross(th2, th1);
+        const V3 ra = v3_unit(V3{th1.x - th2.x, th1.y - th2.y, th1.z - th2.z});
+        const V3 rv = v3_cross(pn, ra);
+        const V3 ura = v3_unit(ra);
+        h0 = v3_shift_wrap(target, v3_rotate(ura, e.sin_half, e.cos_half, rv), pb);
+        h1 = v3_shift_wrap(target, v3_rotate(ura, -e.sin_half, e.cos_half, rv), pb);
+    } else if (kind == GORDER_UA_CH1_UNSAT) {   // uaorder.rs:1024-1045
+        const V3 th1 = v3_to(target, c.p0, pb), th2 = v3_to(target, c.p2, pb);
+        const float prod = (th1.x * th2.x + th1.y * th2.y) + th1.z * th2.z;
+        const float n1 = v3_norm(th1), n2 = v3_norm(th2);
+        float gamma = 0.0f;
+        if (!(n1 == 0.0f || n2 == 0.0f)) {
+            float cs = prod / (n1 * n2);
+            cs = cs < -1.0f ? -1.0f : (cs > 1.0f ? 1.0f : cs);
+            gamma = gm_acosf(cs);
+        }
+        const float ang = 3.14159265358979323846f - (gamma / 2.0f);
+        float sn, cs;
+        sincosf(ang, &sn, &cs);
+        const V3 ua = v3_unit(v3_cross(th1, th2));
+        h0 = v3_shift_wrap(target, ang == 0.0f ? th2 : v3_rotate(ua, sn, cs, th2), pb);
+    } else {                                // CH1 saturated, uaorder.rs:1087-1104 (h1, h2, h3, target)
+        target = c.p3;
+        const V3 t1 = v3_unit(v3_to(target, c.p0, pb)), t2 = v3_unit(v3_to(target, c.p1, pb)),
+                 t3 = v3_unit(v3_to(target, c.p2, pb));
+        h0 = v3_shift_wrap(target, V3{-((t1.x + t2.x) + t3.x), -((t1.y + t2.y) + t3.y), -((t1.z + t2.z) + t3.z)}, pb);
+    }
+    UaBonds r;
+    r.v0 = v3_to(target, h0, pb);
+    r.b0 = {h0.x + r.v0.x / 2.0f, h0.y + r.v0.y / 2.0f, h0.z + r.v0.z / 2.0f};
+    r.v1 = r.v2 = r.b1 = r.b2 = zero;
+    if (kind == GORDER_UA_CH3 || kind == GORDER_UA_CH2) {
+        r.v1 = v3_to(target, h1, pb);
+        r.b1 = {h1.x + r.v1.x / 2.0f, h1.y + r.v1.y / 2.0f, h1.z + r.v1.z / 2.0f};
+    }
+    if (kind == GORDER_UA_CH3) {
+        r.v2 = v3_to(target, h2, pb);
+        r.b2 = {h2.x + r.v2.x / 2.0f, h2.y + r.v2.y / 2.0f, h2.z + r.v2.z / 2.0f};
+    }
+    r.bad = pb.bad;
+    return r;
+}
+// the literal-loop variant, kept out of line: it runs only for carbons more than 1.5 box lengths away
+// from a helper
+__device__ __noinline__ UaBonds ua_carbon_slow(uint32_t kind, UaCarbon c, UaConsts e, V3 box, bool pbc) {
+    PbcLoop pl{box, pbc};
+    return ua_carbon(kind, c, e, pl);
+}
+
+template <bool ACOS_COS, bool EXTRAS>
 __global__ __launch_bounds__(kBlock) void k_ua_extras(FrameArgs a_in, ExtraArgs e, const float *__restrict__ xyz,
                                                        const float *__restrict__ box9,
                                                        const uint8_t *__restrict__ aflags,
@@ -748,8 +850,8 @@ __global__ __launch_bounds__(kBlock) void k_ua_extras(FrameArgs a_in, ExtraArgs 
     constexpr uint32_t LS = 3 * kBlock;   // local slots per block (<= 3 hydrogens per carbon)
     __shared__ unsigned long long l_s[2 * LS];
     __shared__ uint32_t l_n[2 * LS];
-    __shared__ int l_tw[3 * LS];
-    __shared__ uint32_t l_twn[3 * LS];
+    __shared__ int l_tw[EXTRAS ? 3 * LS : 1];
+    __shared__ uint32_t l_twn[EXTRAS ? 3 * LS : 1];
     FrameArgs a = a_in;
     a.xyz = xyz; a.box9 = box9; a.aflags = aflags; a.arow = arow;
     const uint32_t tile_id = blockIdx.x % n_tiles, chunk = blockIdx.x / n_tiles;
@@ -764,83 +866,63 @@ __global__ __launch_bounds__(kBlock) void k_ua_extras(FrameArgs a_in, ExtraArgs 
     const uint32_t f_begin = chunk * a.frames_per_chunk;
     const uint32_t f_end = min(a.n_frames, f_begin + a.frames_per_chunk);
     const size_t fstride = (size_t)a.n_atoms * 3u;
-    for (uint32_t k = tid; k < 3 * LS; k += kBlock) { l_tw[k] = 0; l_twn[k] = 0; }
+    if (EXTRAS)
+        for (uint32_t k = tid; k < 3 * LS; k += kBlock) { l_tw[k] = 0; l_twn[k] = 0; }
     for (uint32_t k = tid; k < 2 * LS; k += kBlock) { l_s[k] = 0; l_n[k] = 0; }
     __syncthreads();
     long long s_tot[3] = {0, 0, 0}, s_up[3] = {0, 0, 0};
     uint32_t n_tot[3] = {0, 0, 0}, n_up[3] = {0, 0, 0};
     int bad = 0;
     const bool pbc = a.pbc != 0;
+    const UaConsts uc{e.sin_tet, e.cos_tet, e.sin_ch3, e.cos_ch3, e.sin_half, e.cos_half};
+    const float *src[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) src[q] = xyz + ((size_t)t.atom0 + (active ? it.l[q] : 0u)) * 3u;
+    auto fetch = [&](uint32_t f) {
+        UaCarbon c;
+        const size_t o = (size_t)f * fstride;
+        c.p0 = {src[0][o], src[0][o + 1], src[0][o + 2]};
+        c.p1 = {src[1][o], src[1][o + 1], src[1][o + 2]};
+        c.p2 = {src[2][o], src[2][o + 1], src[2][o + 2]};
+        c.p3 = {src[3][o], src[3][o + 1], src[3][o + 2]};
+        return c;
+    };
     for (uint32_t f = f_begin; f < f_end; f++) {
         if (active) {
-            float box[3] = {1.0f, 1.0f, 1.0f};
-            if (pbc) { const float *b = a.box9 + 9 * (size_t)f; box[0] = b[0]; box[1] = b[4]; box[2] = b[8]; }
-            V3 P[4];
-            const int nidx = kind == GORDER_UA_CH1_SAT ? 4 : 3;
-            for (int q = 0; q < nidx; q++) {
-                const float *p = xyz + (size_t)f * fstride + ((size_t)t.atom0 + it.l[q]) * 3u;
-                P[q] = {p[0], p[1], p[2]};
-                if (p[0] != p[0]) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, t.atom0 + it.l[q], f);
-            }
-            V3 H[3];
-            V3 target;
-            if (kind == GORDER_UA_CH3) {            // uaorder.rs:947-981
-                target = P[1];
-                const V3 th1 = v3_to(target, P[0], box, pbc, bad), th2 = v3_to(target, P[2], box, pbc, bad);
-                const V3 ua = v3_unit(v3_cross(th2, th1));
-                const V3 hv1 = v3_rotate(ua, e.sin_tet, e.cos_tet, th1);
-                H[0] = v3_shift_wrap(target, hv1, box, pbc, bad);
-                const V3 n1 = v3_unit(th1);
-                H[1] = v3_shift_wrap(target, v3_rotate(n1, e.sin_ch3, e.cos_ch3, hv1), box, pbc, bad);
-                H[2] = v3_shift_wrap(target, v3_rotate(n1, -e.sin_ch3, e.cos_ch3, hv1), box, pbc, bad);
-            } else if (kind == GORDER_UA_CH2) {     // uaorder.rs:985-1020
-                target = P[1];
-                const V3 th1 = v3_unit(v3_to(target, P[0], box, pbc, bad)), th2 = v3_unit(v3_to(target, P[2], box, pbc, bad));
-                const V3 pn = v3_cross(th2, th1);
-                const V3 ra = v3_unit(V3{th1.x - th2.x, th1.y - th2.y, th1.z - th2.z});
-                const V3 rv = v3_cross(pn, ra);
-                const V3 ura = v3_unit(ra);
-                H[0] = v3_shift_wrap(target, v3_rotate(ura, e.sin_half, e.cos_half, rv), box, pbc, bad);
-                H[1] = v3_shift_wrap(target, v3_rotate(ura, -e.sin_half, e.cos_half, rv), box, pbc, bad);
-            } else if (kind == GORDER_UA_CH1_UNSAT) {   // uaorder.rs:1024-1045
-                target = P[1];
-                const V3 th1 = v3_to(target, P[0], box, pbc, bad), th2 = v3_to(target, P[2], box, pbc, bad);
-                const float prod = (th1.x * th2.x + th1.y * th2.y) + th1.z * th2.z;
-                const float n1 = v3_norm(th1), n2 = v3_norm(th2);
-                float gamma = 0.0f;
-                if (!(n1 == 0.0f || n2 == 0.0f)) {
-                    float c = prod / (n1 * n2);
-                    c = c < -1.0f ? -1.0f : (c > 1.0f ? 1.0f : c);
-                    gamma = gm_acosf(c);
-                }
-                const float ang = 3.14159265358979323846f - (gamma / 2.0f);
-                float sn, cs;
-                sincosf(ang, &sn, &cs);
-                const V3 ua = v3_unit(v3_cross(th1, th2));
-                H[0] = v3_shift_wrap(target, ang == 0.0f ? th2 : v3_rotate(ua, sn, cs, th2), box, pbc, bad);
-            } else {                                 // CH1 saturated, uaorder.rs:1087-1104 (h1,h2,h3,target)
-                target = P[3];
-                const V3 t1 = v3_unit(v3_to(target, P[0], box, pbc, bad)), t2 = v3_unit(v3_to(target, P[1], box, pbc, bad)),
-                         t3 = v3_unit(v3_to(target, P[2], box, pbc, bad));
-                H[0] = v3_shift_wrap(target, V3{-((t1.x + t2.x) + t3.x), -((t1.y + t2.y) + t3.y), -((t1.z + t2.z) + t3.z)},
-                                     box, pbc, bad);
+            const UaCarbon c = fetch(f);
+            V3 bx3{1.0f, 1.0f, 1.0f};
+            if (pbc) { const float *b = a.box9 + 9 * (size_t)f; bx3 = {b[0], b[4], b[8]}; }
+            if (c.p0.x != c.p0.x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, t.atom0 + it.l[0], f);
+            if (c.p1.x != c.p1.x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, t.atom0 + it.l[1], f);
+            if (c.p2.x != c.p2.x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, t.atom0 + it.l[2], f);
+            if (c.p3.x != c.p3.x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, t.atom0 + it.l[3], f);
+            PbcStep ps{bx3, pbc};
+            UaBonds ub = ua_carbon(kind, c, uc, ps);
+            if (__builtin_expect(ps.slow, 0)) {
+                ub = ua_carbon_slow(kind, c, uc, bx3, pbc);
+                bad |= ub.bad;
             }
             int leaflet = -1;
             if (a.leaflets) leaflet = a.aflags[(size_t)a.arow[f] * a.n_mol_total + it.mol] ? 1 : 0;
-            for (int k = 0; k < nh; k++) {
-                // UAAtom::calculate_sch, uaorder.rs:375-397: vec = target -> H, bond position = H + vec / 2 (sic)
-                const V3 v = v3_to(target, H[k], box, pbc, bad);
+            auto sample = [&](const int k, const V3 v, const V3 b) {
+                if (k >= nh) return;
                 const float sch = gm_calc_sch<ACOS_COS>(v.x, v.y, v.z, a.nx, a.ny, a.nz, a.n2, a.n2sq);
                 const int tick = gm_tick(sch);
-                const float bx = H[k].x + v.x / 2.0f, by = H[k].y + v.y / 2.0f, bz = H[k].z + v.z / 2.0f;
-                if (e.geom_kind && !geom_inside(e, e.shapes + 8 * (size_t)f, bx, by, bz, box, pbc, bad)) continue;
+                if (EXTRAS) {
+                    const float box[3] = {bx3.x, bx3.y, bx3.z};
+                    if (e.geom_kind && !geom_inside(e, e.shapes + 8 * (size_t)f, b.x, b.y, b.z, box, pbc, bad)) return;
+                }
                 s_tot[k] += tick;
                 n_tot[k] += 1;
                 if (leaflet == 0) { s_up[k] += tick; n_up[k] += 1; }
-                extras_add(a, e, gslot0 + (uint32_t)k, it.lslot0 + (uint32_t)k, tick, bx, by, bz, leaflet, l_tw, l_twn, LS);
-            }
+                if (EXTRAS)
+                    extras_add(a, e, gslot0 + (uint32_t)k, it.lslot0 + (uint32_t)k, tick, b.x, b.y, b.z, leaflet, l_tw, l_twn, LS);
+            };
+            sample(0, ub.v0, ub.b0);
+            sample(1, ub.v1, ub.b1);
+            sample(2, ub.v2, ub.b2);
         }
-        if (e.tw) {
+        if (EXTRAS && e.tw) {
             __syncthreads();
             extras_flush_tw(a, e, tile_slots + t.slot0, t.n_slots, f, l_tw, l_twn, LS);
             __syncthreads();
@@ -848,7 +930,8 @@ __global__ __launch_bounds__(kBlock) void k_ua_extras(FrameArgs a_in, ExtraArgs 
     }
     if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f_begin);
     if (active) {
-        for (int k = 0; k < nh; k++) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
             if (!n_tot[k]) continue;
             atomicAdd(&l_s[it.lslot0 + k], (unsigned long long)s_tot[k]);
             atomicAdd(&l_n[it.lslot0 + k], n_tot[k]);
@@ -1666,10 +1749,12 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
                 else hipLaunchKernelGGL(k_bonds_extras<false>, g, blk, 0, h->stream, b, e, b.xyz, b.box9, b.aflags, b.arow,
                                         h->d_tiles, h->d_items, h->d_tile_slots, nt);
             } else {
-                if (ac) hipLaunchKernelGGL(k_ua_extras<true>, g, blk, 0, h->stream, b, e, b.xyz, b.box9, b.aflags, b.arow,
-                                           h->d_ua_tiles, h->d_ua_items, h->d_ua_tile_slots, nt);
-                else hipLaunchKernelGGL(k_ua_extras<false>, g, blk, 0, h->stream, b, e, b.xyz, b.box9, b.aflags, b.arow,
-                                        h->d_ua_tiles, h->d_ua_items, h->d_ua_tile_slots, nt);
+#define GORDER_LAUNCH_UA(AC, EX)                                                                                  \
+    hipLaunchKernelGGL((k_ua_extras<AC, EX>), g, blk, 0, h->stream, b, e, b.xyz, b.box9, b.aflags, b.arow,          \
+                       h->d_ua_tiles, h->d_ua_items, h->d_ua_tile_slots, nt)
+                if (extras) { if (ac) GORDER_LAUNCH_UA(true, true); else GORDER_LAUNCH_UA(false, true); }
+                else { if (ac) GORDER_LAUNCH_UA(true, false); else GORDER_LAUNCH_UA(false, false); }
+#undef GORDER_LAUNCH_UA
             }
             HIP_TRY(h, hipGetLastError());
         }

@@ -151,6 +151,9 @@ inline int build_plan(const gorder_tables_t &t, bool force_direct, Plan &p) {
             }
             tile.n_window = top - tile.atom0 + 1;
             tile.n_slots = (uint32_t)slots.size();
+            // carbons of one kind next to each other: the lanes of a wave then run the same construction
+            std::stable_sort(p.ua_items.begin() + tile.item0, p.ua_items.end(),
+                             [](const UaItem &x, const UaItem &y) { return x.kind < y.kind; });
             p.ua_tile_slots.insert(p.ua_tile_slots.end(), slots.begin(), slots.end());
             p.ua_tiles.push_back(tile);
         }

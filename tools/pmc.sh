@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box): tools/pmc.sh <outdir-name> <workload> <frames>   -> gpurun_out/<name>/pmc_*.csv
+# usage (on the GPU box): tools/pmc.sh <outdir-name> <workload> <frames> [kernel-substring]  -> gpurun_out/<name>/pmc_*.csv
 # PMC passes are separate runs, each with --kernel-trace only (never combined with other trace domains).
 set -e
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
@@ -18,7 +18,7 @@ import csv,glob,collections
 for p in sorted(glob.glob("$OUT/p*/*/*counter_collection.csv")):
     agg=collections.defaultdict(lambda: [0,0.0])
     for r in csv.DictReader(open(p)):
-        if 'k_bonds' in r['Kernel_Name']:
+        if '${4:-k_bonds}' in r['Kernel_Name']:
             k=r['Counter_Name']; agg[k][0]+=1; agg[k][1]+=float(r['Counter_Value'])
     for k,(n,v) in agg.items(): print(f"{k:28s} dispatches={n:3d} mean={v/n:.6g}")
 PY
