@@ -47,7 +47,8 @@ struct FrameArgs {
     const float *xyz;        // [n_frames][n_atoms][3]
     const float *box9;       // [n_frames][9]
     uint32_t n_atoms;
-    uint32_t n_frames;
+    uint32_t n_frames;       // end of the frame range this launch covers
+    uint32_t frame0;         // its begin (only the scatter kernels launch sub-ranges; 0 elsewhere)
     uint32_t frames_per_chunk;
     int pbc;
     float nx, ny, nz, n2, n2sq;   // static normal, its norm and squared norm
@@ -99,6 +100,38 @@ __global__ void k_fold_replicas(unsigned long long *acc, unsigned long long *rep
         rep[(size_t)r * n + i] = 0;
     }
     acc[i] += s;
+}
+
+// ---- ordermap words --------------------------------------------------------------------------
+// The scatter kernels add (1 << 42) + tick into one 64-bit word per (plane, slot, tile): the low 42 bits
+// hold the signed tick sum, the bits above the sample count.  |tick| <= 1e6, so the sum of c samples stays
+// inside 42 signed bits while c < 2^21; the host folds the words into the i64 sum / u64 count maps before
+// any tile can have received that many samples (gorder_hip_handle::map_pending).
+constexpr unsigned long long kMapOne = 1ull << 42;
+constexpr unsigned long long kMapFoldLimit = 1ull << 21;
+__device__ __forceinline__ void map_unpack(unsigned long long w, long long &sum, unsigned long long &cnt) {
+    sum = (long long)(w << 22) >> 22;                      // sign-extend the low 42 bits
+    cnt = (w - (unsigned long long)sum) >> 42;
+}
+// packed [planes][n] -> sums/cnts [3][n] (total, upper, lower); planes = 2 with leaflets (upper, lower), else 1
+__global__ void k_fold_maps(unsigned long long *__restrict__ packed, unsigned long long *__restrict__ sums,
+                            unsigned long long *__restrict__ cnts, size_t n, int leaflets) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned long long w0 = packed[i], w1 = leaflets ? packed[n + i] : 0ull;
+        if (!(w0 | w1)) continue;
+        long long s0, s1 = 0;
+        unsigned long long c0, c1 = 0;
+        map_unpack(w0, s0, c0);
+        if (leaflets) map_unpack(w1, s1, c1);
+        sums[i] += (unsigned long long)(s0 + s1);
+        cnts[i] += c0 + c1;
+        if (leaflets) {
+            if (w0) { sums[n + i] += (unsigned long long)s0; cnts[n + i] += c0; packed[i] = 0; }
+            if (w1) { sums[2 * n + i] += (unsigned long long)s1; cnts[2 * n + i] += c1; packed[n + i] = 0; }
+        } else {
+            packed[i] = 0;
+        }
+    }
 }
 
 // ---- one bond sample (bond.rs:407-443) -----------------------------------------------------
@@ -522,8 +555,7 @@ struct ExtraArgs {
     uint32_t plane;                  // 0 xy, 1 xz, 2 yz -> (z, y)   (input/ordermap.rs:44-50)
     float x0, y0, binx, biny;
     uint32_t nx, ny;
-    unsigned long long *map_sums;    // [3][n_acc][nx*ny]
-    unsigned long long *map_cnts;    // [3][n_acc][nx*ny]
+    unsigned long long *map_packed;  // [leaflets ? 2 : 1][n_acc][nx*ny] packed (count << 42) + sum, see k_fold_maps
     int tw;                          // timewise on
     unsigned long long *tw_sums;     // [rows][3][n_acc]
     unsigned long long *tw_cnts;     // [rows][3][n_acc]
@@ -577,14 +609,13 @@ __device__ __forceinline__ void extras_add(const FrameArgs &a, const ExtraArgs &
         else { x = pz; y = py; }
         const int ix = grid_index(x, e.x0, e.binx, e.nx), iy = grid_index(y, e.y0, e.biny, e.ny);
         if (ix >= 0 && iy >= 0) {
+            // ONE atomic per sample: count and tick sum share a 64-bit word, and with leaflets only the
+            // sample's own leaflet plane is touched (total = upper + lower, bond.rs:199-213); k_fold_maps
+            // unpacks.  Scattered 64-bit atomics run at ~24 G/s on gfx950 whatever the scope or table size
+            // (tools/microbench/atomic_scatter.hip), so their number is what counts.
             const size_t nt = (size_t)e.nx * e.ny, t = (size_t)ix * e.ny + (size_t)iy;
-            atomicAdd(&e.map_sums[((size_t)gslot) * nt + t], (unsigned long long)(long long)tick);
-            atomicAdd(&e.map_cnts[((size_t)gslot) * nt + t], 1ull);
-            if (leaflet >= 0) {
-                const size_t w = (size_t)(1 + leaflet) * a.n_acc + gslot;
-                atomicAdd(&e.map_sums[w * nt + t], (unsigned long long)(long long)tick);
-                atomicAdd(&e.map_cnts[w * nt + t], 1ull);
-            }
+            const size_t w = leaflet > 0 ? a.n_acc : 0;
+            atomicAdd(&e.map_packed[(w + gslot) * nt + t], kMapOne + (unsigned long long)(long long)tick);
         }
     }
     if (e.tw) {
@@ -637,7 +668,7 @@ __global__ __launch_bounds__(kBlock) void k_bonds_extras(FrameArgs a_in, ExtraAr
     Item it{0, 0, 0, 0, 0};
     if (active) it = items[t.item0 + tid];
     const uint32_t gslot = active ? tile_slots[t.slot0 + it.lslot] : 0;
-    const uint32_t f_begin = chunk * a.frames_per_chunk;
+    const uint32_t f_begin = a.frame0 + chunk * a.frames_per_chunk;
     const uint32_t f_end = min(a.n_frames, f_begin + a.frames_per_chunk);
     const size_t fstride = (size_t)a.n_atoms * 3u;
     const float *pi = xyz + ((size_t)t.atom0 + it.li) * 3u;
@@ -863,7 +894,7 @@ __global__ __launch_bounds__(kBlock) void k_ua_extras(FrameArgs a_in, ExtraArgs 
     const uint32_t kind = it.kind;
     const int nh = kind == GORDER_UA_CH3 ? 3 : (kind == GORDER_UA_CH2 ? 2 : 1);
     const uint32_t gslot0 = active ? tile_slots[t.slot0 + it.lslot0] : 0;
-    const uint32_t f_begin = chunk * a.frames_per_chunk;
+    const uint32_t f_begin = a.frame0 + chunk * a.frames_per_chunk;
     const uint32_t f_end = min(a.n_frames, f_begin + a.frames_per_chunk);
     const size_t fstride = (size_t)a.n_atoms * 3u;
     if (EXTRAS)
@@ -1518,7 +1549,11 @@ struct gorder_hip_handle {
     uint32_t *d_ua_tile_slots = nullptr;
     // ordermaps [3][n_acc][nx*ny] and timewise rows [cap][3][n_acc]
     uint32_t map_nx = 0, map_ny = 0;
-    unsigned long long *d_map_sums = nullptr, *d_map_cnts = nullptr;
+    unsigned long long *d_map_sums = nullptr, *d_map_cnts = nullptr;   // [3][n_acc][nx*ny], folded
+    unsigned long long *d_map_packed = nullptr;   // [1 or 2][n_acc][nx*ny], what the kernels add into
+    uint64_t map_pending = 0;      // upper bound of the samples one packed word may hold since the last fold
+    uint64_t map_fold_limit = kMapFoldLimit;   // GORDER_HIP_MAP_FOLD_LIMIT lowers it (tests)
+    uint32_t map_max_mol = 1;      // most molecules of one type = most samples per tile and frame
     unsigned long long *d_tw_sums = nullptr, *d_tw_cnts = nullptr;
     uint64_t tw_cap = 0;
     ExtraArgs extra{};
@@ -1630,6 +1665,18 @@ int fold_replicas(gorder_hip_handle *h) {
     return GORDER_OK;
 }
 
+// unpack the ordermap words the scatter kernels filled since the last fold (k_fold_maps)
+int fold_maps(gorder_hip_handle *h) {
+    if (!h->extra.maps || !h->map_pending) return GORDER_OK;
+    const size_t n = (size_t)h->plan.n_acc * h->map_nx * h->map_ny;
+    const uint32_t blocks = (uint32_t)std::min<size_t>((n + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(k_fold_maps, dim3(blocks), dim3(256), 0, h->stream, h->d_map_packed, h->d_map_sums, h->d_map_cnts,
+                       n, h->tables.leaflets.method != GORDER_LEAFLETS_NONE ? 1 : 0);
+    HIP_TRY(h, hipGetLastError());
+    h->map_pending = 0;
+    return GORDER_OK;
+}
+
 int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
     const Plan &p = h->plan;
     const uint32_t n_tiles = (uint32_t)p.tiles.size();
@@ -1733,30 +1780,45 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
         e.tw_sums = h->d_tw_sums; e.tw_cnts = h->d_tw_cnts; e.tw_row0 = h->n_frames;
         e.shapes = h->d_shapes;
         const bool ac = (h->tables.flags & GORDER_FLAG_TRIG_ACOS_COS) != 0;
-        for (int pass = 0; pass < 2; pass++) {
-            const uint32_t nt = pass == 0 ? (extras ? n_tiles : 0u) : (uint32_t)p.ua_tiles.size();
-            if (!nt) continue;
-            uint32_t n_chunks = std::max(1u, (h->wg_target ? h->wg_target : 8u * h->wg_capacity) / nt);
-            n_chunks = std::min(n_chunks, a.n_frames);
-            const uint32_t fpc = (a.n_frames + n_chunks - 1) / n_chunks;
-            n_chunks = (a.n_frames + fpc - 1) / fpc;
-            FrameArgs b = a;
-            b.frames_per_chunk = fpc;
-            const dim3 g(nt * n_chunks), blk(kBlock);
-            if (pass == 0) {
-                if (ac) hipLaunchKernelGGL(k_bonds_extras<true>, g, blk, 0, h->stream, b, e, b.xyz, b.box9, b.aflags, b.arow,
-                                           h->d_tiles, h->d_items, h->d_tile_slots, nt);
-                else hipLaunchKernelGGL(k_bonds_extras<false>, g, blk, 0, h->stream, b, e, b.xyz, b.box9, b.aflags, b.arow,
-                                        h->d_tiles, h->d_items, h->d_tile_slots, nt);
-            } else {
+        // with ordermaps the frames go in sub-ranges short enough for the packed map words (k_fold_maps)
+        const uint32_t sub = e.maps ? (uint32_t)std::max<uint64_t>(1, (h->map_fold_limit - 1) / h->map_max_mol) : a.n_frames;
+        for (uint32_t lo = 0; lo < a.n_frames; lo += sub) {
+            const uint32_t hi = std::min(a.n_frames, lo + sub), nf = hi - lo;
+            if (e.maps) {
+                const uint64_t cost = (uint64_t)nf * h->map_max_mol;
+                if (h->map_pending + cost >= h->map_fold_limit) {
+                    const int st = fold_maps(h);
+                    if (st != GORDER_OK) return st;
+                }
+                h->map_pending += cost;
+            }
+            for (int pass = 0; pass < 2; pass++) {
+                const uint32_t nt = pass == 0 ? (extras ? n_tiles : 0u) : (uint32_t)p.ua_tiles.size();
+                if (!nt) continue;
+                uint32_t n_chunks = std::max(1u, (h->wg_target ? h->wg_target : 8u * h->wg_capacity) / nt);
+                n_chunks = std::min(n_chunks, nf);
+                const uint32_t fpc = (nf + n_chunks - 1) / n_chunks;
+                n_chunks = (nf + fpc - 1) / fpc;
+                FrameArgs b = a;
+                b.frame0 = lo;
+                b.n_frames = hi;
+                b.frames_per_chunk = fpc;
+                const dim3 g(nt * n_chunks), blk(kBlock);
+                if (pass == 0) {
+                    if (ac) hipLaunchKernelGGL(k_bonds_extras<true>, g, blk, 0, h->stream, b, e, b.xyz, b.box9, b.aflags,
+                                               b.arow, h->d_tiles, h->d_items, h->d_tile_slots, nt);
+                    else hipLaunchKernelGGL(k_bonds_extras<false>, g, blk, 0, h->stream, b, e, b.xyz, b.box9, b.aflags,
+                                            b.arow, h->d_tiles, h->d_items, h->d_tile_slots, nt);
+                } else {
 #define GORDER_LAUNCH_UA(AC, EX)                                                                                  \
     hipLaunchKernelGGL((k_ua_extras<AC, EX>), g, blk, 0, h->stream, b, e, b.xyz, b.box9, b.aflags, b.arow,          \
                        h->d_ua_tiles, h->d_ua_items, h->d_ua_tile_slots, nt)
-                if (extras) { if (ac) GORDER_LAUNCH_UA(true, true); else GORDER_LAUNCH_UA(false, true); }
-                else { if (ac) GORDER_LAUNCH_UA(true, false); else GORDER_LAUNCH_UA(false, false); }
+                    if (extras) { if (ac) GORDER_LAUNCH_UA(true, true); else GORDER_LAUNCH_UA(false, true); }
+                    else { if (ac) GORDER_LAUNCH_UA(true, false); else GORDER_LAUNCH_UA(false, false); }
 #undef GORDER_LAUNCH_UA
+                }
+                HIP_TRY(h, hipGetLastError());
             }
-            HIP_TRY(h, hipGetLastError());
         }
     }
     if (!p.direct.empty()) {
@@ -1876,9 +1938,14 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
             HIP_TRY(h, hipMalloc((void **)&h->d_map_cnts, nmap * sizeof(unsigned long long)));
             HIP_TRY(h, hipMemset(h->d_map_sums, 0, nmap * sizeof(unsigned long long)));
             HIP_TRY(h, hipMemset(h->d_map_cnts, 0, nmap * sizeof(unsigned long long)));
+            const size_t npk = (t->leaflets.method != GORDER_LEAFLETS_NONE ? 2 : 1) * (nmap / 3);
+            HIP_TRY(h, hipMalloc((void **)&h->d_map_packed, npk * sizeof(unsigned long long)));
+            HIP_TRY(h, hipMemset(h->d_map_packed, 0, npk * sizeof(unsigned long long)));
+            for (uint32_t m = 0; m < t->n_molecule_types; m++)
+                h->map_max_mol = std::max(h->map_max_mol, t->molecule_types[m].n_molecules);
             e.maps = 1; e.plane = om.plane; e.x0 = om.span_x[0]; e.y0 = om.span_y[0];
             e.binx = om.bin[0]; e.biny = om.bin[1]; e.nx = h->map_nx; e.ny = h->map_ny;
-            e.map_sums = h->d_map_sums; e.map_cnts = h->d_map_cnts;
+            e.map_packed = h->d_map_packed;
         }
         e.tw = t->timewise ? 1 : 0;
         const gorder_geometry_t &ge = t->geometry;
@@ -1909,6 +1976,10 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
     h->acc_words = 4 * (size_t)p.n_acc + 1;
     HIP_TRY(h, hipMalloc((void **)&h->d_acc, h->acc_words * sizeof(unsigned long long)));
     HIP_TRY(h, hipMemset(h->d_acc, 0, h->acc_words * sizeof(unsigned long long)));
+    if (const char *e = getenv("GORDER_HIP_MAP_FOLD_LIMIT")) {
+        const long v = atol(e);
+        if (v >= 2 && (unsigned long long)v <= kMapFoldLimit) h->map_fold_limit = (uint64_t)v;
+    }
     if (const char *e = getenv("GORDER_HIP_REPLICAS")) {
         const int r = atoi(e);
         if (r >= 1 && r <= 1024) h->n_rep = (uint32_t)r;
@@ -2010,7 +2081,7 @@ void gorder_hip_destroy(gorder_hip_handle *h) {
     (void)hipFree(h->d_tiles); (void)hipFree(h->d_items); (void)hipFree(h->d_tile_slots);
     (void)hipFree(h->d_direct); (void)hipFree(h->d_err);
     (void)hipFree(h->d_ua_tiles); (void)hipFree(h->d_ua_items); (void)hipFree(h->d_ua_tile_slots);
-    (void)hipFree(h->d_map_sums); (void)hipFree(h->d_map_cnts); (void)hipFree(h->d_tw_sums); (void)hipFree(h->d_tw_cnts);
+    (void)hipFree(h->d_map_sums); (void)hipFree(h->d_map_cnts); (void)hipFree(h->d_map_packed); (void)hipFree(h->d_tw_sums); (void)hipFree(h->d_tw_cnts);
     (void)hipFree(h->d_geom_group); (void)hipFree(h->d_shapes);
     if (!h->acc_external) (void)hipFree(h->d_acc);
     (void)hipFree(h->d_rep);
@@ -2270,6 +2341,7 @@ int gorder_hip_finish(gorder_hip_handle *h, int64_t *sums, uint64_t *counts, int
     if (!h) return GORDER_ERR_INVALID_ARGUMENT;
     int st = fold_replicas(h);
     if (st != GORDER_OK) return st;
+    if ((st = fold_maps(h)) != GORDER_OK) return st;
     st = gorder_hip_synchronize(h);
     if (st != GORDER_OK) return st;
     const uint32_t n = h->plan.n_acc;

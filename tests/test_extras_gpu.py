@@ -47,6 +47,24 @@ def test_ordermaps(built, plane, leaflets):
     assert (tot <= got.counts).all() and tot.sum() > 0.97 * got.counts.sum()
 
 
+@pytest.mark.parametrize("leaflets", [LEAFLETS_NONE, LEAFLETS_GLOBAL])
+def test_ordermap_words_are_folded_before_they_overflow(built, monkeypatch, leaflets):
+    """The kernels add count and tick sum into one packed word per tile (k_fold_maps); with the fold
+    limit lowered to a handful of samples the frames go in sub-ranges of 2 with a fold between them, and
+    the unpacked maps must still be the oracle's — including negative tick sums next to the count bits."""
+    monkeypatch.setenv("GORDER_HIP_MAP_FOLD_LIMIT", "250")
+    system = synthetic.cg_membrane(100, leaflets=leaflets)
+    bx = system.box
+    system.tables.ordermap = OrderMap(enabled=True, plane=0, span_x=(0.0, float(bx[0])), span_y=(0.0, float(bx[1])),
+                                      bin=(2.5, 2.5))       # coarse tiles: many samples (and sign changes) per word
+    xyz = system.frames(23, seed=8)
+    eng, o, got, want = both(system, xyz, system.box9(23), batches=3)
+    assert (want.map_sums < 0).any() and (want.map_counts > 100).any()
+    np.testing.assert_array_equal(got.map_counts, want.map_counts)
+    np.testing.assert_array_equal(got.map_sums, want.map_sums)
+    np.testing.assert_array_equal(got.sums, want.sums)
+
+
 def test_ordermap_manual_span_drops_outside_samples(built):
     system = synthetic.aa_membrane(20)
     system.tables.ordermap = OrderMap(enabled=True, plane=0, span_x=(2.0, 5.0), span_y=(1.0, 4.0), bin=(0.25, 0.5))
