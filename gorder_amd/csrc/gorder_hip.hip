@@ -1281,17 +1281,36 @@ struct LocalArgs {
     uint32_t *err;
 };
 
+// In-plane cell grid of one frame.  A dimension with at least 3 radii of box gets cells of radius / k
+// (k = kLocalFine, less when the 128-cell cap or the box says so) and a head looks at the 2k+1 cells
+// around its own; a smaller dimension is ONE cell (every atom is a candidate exactly once).  Finer cells
+// cut the candidates per head from 9 r^2 (k = 1) towards the disk area pi r^2: k = 4 gives 5.1 r^2.
+// The grid is this engine's own pruning device — membership itself is the exact distance test.
+constexpr uint32_t kLocalFine = 4;
+__device__ __forceinline__ void local_axis(float L, float radius, uint32_t &nc, uint32_t &k) {
+    nc = 1; k = 0;
+    for (uint32_t kk = kLocalFine; kk >= 1u; kk--) {
+        // cells are at least 1.0001 radius / kk wide (floor + margin), so +-kk cells reach one radius even
+        // when the wrapped coordinates the cells are made from are off by a rounding error
+        const float fine = floorf(L / (radius / (float)kk) * 0.9999f);
+        if (fine >= (float)(2u * kk + 1u) && fine <= (float)kLocalMaxCells1D) { nc = (uint32_t)fine; k = kk; return; }
+    }
+}
 __device__ __forceinline__ void local_grid(const LocalArgs &a, const float *box, uint32_t &nca, uint32_t &ncb,
-                                           int &da, int &db) {
+                                           int &da, int &db, uint32_t &ka, uint32_t &kb) {
     da = (int)((a.dim + 1u) % 3u);
     db = (int)((a.dim + 2u) % 3u);
+    nca = ncb = 1;   // no periodic images to prune with: one cell holds every atom
+    ka = kb = 0;
     if (a.pbc) {
-        const float fa = floorf(box[da] / a.radius), fb = floorf(box[db] / a.radius);
-        nca = (uint32_t)fminf(fmaxf(fa, 1.0f), (float)kLocalMaxCells1D);
-        ncb = (uint32_t)fminf(fmaxf(fb, 1.0f), (float)kLocalMaxCells1D);
-    } else {
-        nca = ncb = 1;   // no periodic images to prune with: one cell holds every atom
+        local_axis(box[da], a.radius, nca, ka);
+        local_axis(box[db], a.radius, ncb, kb);
     }
+}
+__device__ __forceinline__ void local_grid(const LocalArgs &a, const float *box, uint32_t &nca, uint32_t &ncb,
+                                           int &da, int &db) {
+    uint32_t ka, kb;
+    local_grid(a, box, nca, ncb, da, db, ka, kb);
 }
 
 __device__ __forceinline__ void frame_box(const LocalArgs &a, uint32_t f, float *box) {
@@ -1421,7 +1440,43 @@ __global__ __launch_bounds__(256) void k_local_scatter(LocalArgs a) {
     a.rsn[q] = sn;
 }
 
-// block = 256 threads = 4 waves = 4 heads; grid = (ceil(n_mol / 4), n_slab)
+__device__ __forceinline__ float local_radius_threshold(float r) {
+    if (!(r > 0.0f)) return 0.0f;            // sqrt(x) < r never holds
+    float thr = r * r;
+    for (int i = 0; i < 8 && __builtin_sqrtf(thr) < r; i++) thr = nextafterf(thr, INFINITY);
+    for (int i = 0; i < 8; i++) {
+        const float p = nextafterf(thr, 0.0f);
+        if (!(p < thr) || !(__builtin_sqrtf(p) >= r)) break;
+        thr = p;
+    }
+    return thr;
+}
+
+// Sum over the 64 lanes by DPP row shifts (cheaper than six ds_bpermute round trips per sum).
+// Within a row of 16 lanes a Hillis-Steele scan leaves the row total in its last lane; row_bcast:15 and
+// row_bcast:31 carry the totals on, lane 63 ends with the wave total.  Fixed order => deterministic.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+    return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_total(double v) {
+    v = dpp_add_f64<0x111, 0xf>(v);   // row_shr:1
+    v = dpp_add_f64<0x112, 0xf>(v);   // row_shr:2
+    v = dpp_add_f64<0x114, 0xf>(v);   // row_shr:4
+    v = dpp_add_f64<0x118, 0xf>(v);   // row_shr:8
+    v = dpp_add_f64<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v = dpp_add_f64<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
+
+// block = 256 threads = 4 waves = 4 heads; grid = (ceil(n_mol / 4), n_slab).  A head's candidates are
+// the records of the (2ka+1) x (2kb+1) cells around its own: per row of cells ONE contiguous run of
+// records (two when the run wraps around the box), lanes over the run.
 __global__ __launch_bounds__(256) void k_local_flags(LocalArgs a) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t m = blockIdx.x * 4u + (threadIdx.x >> 6);
@@ -1430,9 +1485,9 @@ __global__ __launch_bounds__(256) void k_local_flags(LocalArgs a) {
     const uint32_t f = a.aframes[s];
     float box[3];
     frame_box(a, f, box);
-    uint32_t nca, ncb;
+    uint32_t nca, ncb, ka, kb;
     int da, db;
-    local_grid(a, box, nca, ncb, da, db);
+    local_grid(a, box, nca, ncb, da, db, ka, kb);
     const int dn = (int)a.dim;
     const float *x = a.xyz + (size_t)f * a.n_atoms * 3u;
     const float *hp = x + 3u * (size_t)a.heads[m];
@@ -1447,72 +1502,143 @@ __global__ __launch_bounds__(256) void k_local_flags(LocalArgs a) {
     const uint32_t *cstart = a.cell_count + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u);
     const float4 *rec = reinterpret_cast<const float4 *>(a.trig) + (size_t)s * a.n_membrane;
     const float *rsn = a.rsn + (size_t)s * a.n_membrane;
-    const uint32_t na = nca < 3u ? nca : 3u, nb = ncb < 3u ? ncb : 3u;
     const float La = box[da], Lb = box[db], Ln = box[dn];
+    const float thr = local_radius_threshold(a.radius);
+    // rows (ha - ka .. ha + ka) mod nca; in a row the cells (hb - kb .. hb + kb) mod ncb = runs [b0, b1) and [0, b2)
+    const uint32_t n_rows = 2u * ka + 1u, n_cols = 2u * kb + 1u;       // <= nca, ncb by local_axis
+    const uint32_t a0 = (ha + nca - ka) % nca, b0 = (hb + ncb - kb) % ncb;
+    const uint32_t b1 = min(b0 + n_cols, ncb), b2 = b0 + n_cols - b1;
+    const bool pbc = a.pbc != 0;
+    auto inside = [&](float ra, float rb) {
+        float ea = ra - ha_pos, eb = rb - hb_pos;
+        if (pbc) {
+            bool slow = false;
+            const float fa = gm_min_image_step(ea, La, slow), fb = gm_min_image_step(eb, Lb, slow);
+            if (__builtin_expect(slow, 0)) {
+                ea = gm_min_image_loop(ea, La, bad);
+                eb = gm_min_image_loop(eb, Lb, bad);
+            } else {
+                ea = fa; eb = fb;
+            }
+        }
+        return ea * ea + eb * eb < thr;                 // == sqrt(..) < radius, see local_radius_threshold
+    };
+
+    // The runs as a flat list of wave iterations: lane i keeps (first record, end of run) of iteration i.
+    // Every load address of the passes below then comes from a lane read-out instead of a chain of
+    // dependent cell-table loads, so the loads of several iterations are in flight together — this
+    // kernel is bound by load latency, not by arithmetic.
+    const uint32_t n_runs = 2u * n_rows;
+    uint32_t rq0 = 0, rq1 = 0;
+    if (lane < n_runs) {
+        const uint32_t row = ((a0 + (lane >> 1)) % nca) * ncb;
+        rq0 = (lane & 1u) ? cstart[row] : cstart[row + b0];
+        rq1 = (lane & 1u) ? cstart[row + b2] : cstart[row + b1];
+    }
+    uint32_t n_it = 0, it_base = 0, it_end = 0;
+    for (uint32_t r = 0; r < n_runs; r++) {
+        const uint32_t q0 = __builtin_amdgcn_readlane(rq0, r), q1 = __builtin_amdgcn_readlane(rq1, r);
+        const uint32_t n = (q1 - q0 + 63u) >> 6;
+        if (lane >= n_it && lane < n_it + n) { it_base = q0 + 64u * (lane - n_it); it_end = q1; }
+        n_it += n;
+    }
+    const bool flat = n_it <= 64u;       // else (> 4096 candidates): the plain run loops
 
     // pass 1: members (in-plane minimum-image distance < radius; groan_rs Cylinder::inside), their count
     // and the circular sums of the normal coordinate (PBC) or its plain sum (NoPBC).  The membership
     // of the first 64 candidates of each lane is remembered as a bit mask for pass 2.
-    float sc = 0.0f, ss = 0.0f, sp = 0.0f, nonfinite = 0.0f;
-    uint32_t cnt = 0;
+    float sc = 0.0f, ss = 0.0f, sp = 0.0f;
+    uint32_t cnt = 0, nf = 0, it = 0;
     unsigned long long member = 0ull;
-    uint32_t it = 0;
-    for (uint32_t ia = 0; ia < na; ia++) {
-        const uint32_t ca = (ha + nca - 1u + ia) % nca;
-        for (uint32_t ib = 0; ib < nb; ib++) {
-            const uint32_t cb = (hb + ncb - 1u + ib) % ncb;
-            const uint32_t c = ca * ncb + cb;
-            for (uint32_t q = cstart[c] + lane; q < cstart[c + 1]; q += 64, it++) {
-                const float4 r = rec[q];
-                float ea = r.x - ha_pos, eb = r.y - hb_pos;
-                if (a.pbc) { ea = gm_min_image(ea, La, bad); eb = gm_min_image(eb, Lb, bad); }
-                if (__builtin_sqrtf(ea * ea + eb * eb) < a.radius) {
-                    cnt += 1;
-                    if (it < 64) member |= 1ull << it;
-                    nonfinite += r.z - r.z;
-                    if (a.pbc) { sc += r.w; ss += rsn[q]; }
-                    else sp += r.z;
-                }
+    auto take = [&](const float4 r, const float sn, const uint32_t iter) {
+        if (inside(r.x, r.y)) {
+            cnt += 1;
+            if (iter < 64u) member |= 1ull << iter;
+            nf |= (r.z - r.z == 0.0f) ? 0u : 1u;
+            if (pbc) { sc += r.w; ss += sn; }
+            else sp += r.z;
+        }
+    };
+    if (flat) {
+        for (uint32_t it0 = 0; it0 < n_it; it0 += 4u) {
+            float4 r[4];
+            float sn[4];
+            bool v[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; u++) {
+                const uint32_t iter = min(it0 + u, 63u);
+                const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)it_base, (int)iter) + lane;
+                v[u] = q < (uint32_t)__builtin_amdgcn_readlane((int)it_end, (int)iter);   // lanes >= n_it hold 0: never
+                const uint32_t qc = v[u] ? q : 0u;
+                r[u] = rec[qc];
+                sn[u] = pbc ? rsn[qc] : 0.0f;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; u++)
+                if (v[u]) take(r[u], sn[u], it0 + u);
+        }
+    } else {
+        for (uint32_t ia = 0; ia < n_rows; ia++) {
+            const uint32_t row = ((a0 + ia) % nca) * ncb;
+            for (uint32_t part = 0; part < 2u; part++) {
+                const uint32_t q0 = part == 0 ? cstart[row + b0] : cstart[row];
+                const uint32_t q1 = part == 0 ? cstart[row + b1] : cstart[row + b2];
+                for (uint32_t q = q0 + lane; q < q1; q += 64u, it++) take(rec[q], pbc ? rsn[q] : 0.0f, it);
             }
         }
     }
-    const double tcnt = wave_sum((double)cnt);
-    const double nf = wave_sum((double)nonfinite);
-    if (tcnt == 0.0 || nf != 0.0) {
+    const double tcnt = wave_total((double)cnt);
+    if (tcnt == 0.0 || __any(nf != 0u)) {
         if (lane == 0) raise_error(a.err, GORDER_ERR_INVALID_LOCAL_MEMBRANE_CENTER, a.heads[m], f);
         return;
     }
     float center;
-    if (!a.pbc) {
-        center = (float)(wave_sum((double)sp) / tcnt);
+    if (!pbc) {
+        center = (float)(wave_total((double)sp) / tcnt);
     } else {
-        const double tc = wave_sum((double)sc), ts = wave_sum((double)ss);
+        const double tc = wave_total((double)sc), ts = wave_total((double)ss);
         const float est = (atan2f(-(float)ts, -(float)tc) + 3.1415927f) / (6.2831855f / Ln);
         // pass 2: refine with the mean minimum-image displacement of the members from the estimate
         float ref = 0.0f;
-        it = 0;
-        for (uint32_t ia = 0; ia < na; ia++) {
-            const uint32_t ca = (ha + nca - 1u + ia) % nca;
-            for (uint32_t ib = 0; ib < nb; ib++) {
-                const uint32_t cb = (hb + ncb - 1u + ib) % ncb;
-                const uint32_t c = ca * ncb + cb;
-                for (uint32_t q = cstart[c] + lane; q < cstart[c + 1]; q += 64, it++) {
-                    bool in;
-                    float pn;
-                    if (it < 64) {
-                        in = (member >> it) & 1ull;
-                        pn = in ? rec[q].z : 0.0f;
-                    } else {
-                        const float4 r = rec[q];
-                        const float ea = gm_min_image(r.x - ha_pos, La, bad), eb = gm_min_image(r.y - hb_pos, Lb, bad);
-                        in = __builtin_sqrtf(ea * ea + eb * eb) < a.radius;
-                        pn = r.z;
+        if (flat) {
+            for (uint32_t it0 = 0; it0 < n_it; it0 += 4u) {
+                float pn[4];
+                bool in[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; u++) {
+                    const uint32_t iter = min(it0 + u, 63u);
+                    in[u] = it0 + u < 64u && ((member >> iter) & 1ull);
+                    const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)it_base, (int)iter) + lane;
+                    pn[u] = rec[in[u] ? q : 0u].z;
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; u++)
+                    if (in[u]) ref += gm_min_image(pn[u] - est, Ln, bad);
+            }
+        } else {
+            it = 0;
+            for (uint32_t ia = 0; ia < n_rows; ia++) {
+                const uint32_t row = ((a0 + ia) % nca) * ncb;
+                for (uint32_t part = 0; part < 2u; part++) {
+                    const uint32_t q0 = part == 0 ? cstart[row + b0] : cstart[row];
+                    const uint32_t q1 = part == 0 ? cstart[row + b1] : cstart[row + b2];
+                    for (uint32_t q = q0 + lane; q < q1; q += 64u, it++) {
+                        bool in;
+                        float pn;
+                        if (it < 64u) {
+                            in = (member >> it) & 1ull;
+                            pn = in ? rec[q].z : 0.0f;
+                        } else {
+                            const float4 r = rec[q];
+                            in = inside(r.x, r.y);
+                            pn = r.z;
+                        }
+                        if (in) ref += gm_min_image(pn - est, Ln, bad);
                     }
-                    if (in) ref += gm_min_image(pn - est, Ln, bad);
                 }
             }
         }
-        center = gm_wrap(est + (float)(wave_sum((double)ref) / tcnt), Ln, bad);
+        center = gm_wrap(est + (float)(wave_total((double)ref) / tcnt), Ln, bad);
     }
     if (lane == 0) {
         if (center != center) {
@@ -1520,7 +1646,7 @@ __global__ __launch_bounds__(256) void k_local_flags(LocalArgs a) {
             return;
         }
         float d = hn_pos - center;
-        if (a.pbc) d = gm_min_image(d, Ln, bad);
+        if (pbc) d = gm_min_image(d, Ln, bad);
         a.aflags[(size_t)(a.row0 + s) * a.n_mol_total + m] = (uint8_t)((d >= 0.0f ? 0 : 1) ^ (a.flip ? 1 : 0));
         if ((int)s == a.write_dist_frame && a.adist) a.adist[m] = d;
     }

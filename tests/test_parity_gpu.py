@@ -109,7 +109,7 @@ def test_cg_global_leaflets_mixed_types(built, flags):
 
 
 @pytest.mark.parametrize("pbc", [True, False])
-@pytest.mark.parametrize("radius,n_lipids", [(2.5, 800), (1.2, 300), (30.0, 120)])
+@pytest.mark.parametrize("radius,n_lipids", [(2.5, 800), (1.2, 300), (30.0, 120), (6.0, 1000)])
 def test_local_leaflets(built, radius, n_lipids, pbc):
     """Local classification (leaflets.rs:661-675 + pbc.rs:273-318): cylinder membership is restated with
     identical f32 operations, so flags must agree unless a head sits within 1e-4 nm of its local centre."""
