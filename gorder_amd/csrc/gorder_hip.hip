@@ -1272,6 +1272,7 @@ struct LocalArgs {
     uint32_t dim;               // normal
     int flip, pbc;
     float radius;
+    float radius_thr;           // local_radius_threshold(radius)
     // scratch, per slab frame
     uint32_t *cell_of;          // [n_slab][n_membrane]
     float *trig;                // [n_slab][n_membrane] float4 records in cell order (see k_local_scatter)
@@ -1440,13 +1441,16 @@ __global__ __launch_bounds__(256) void k_local_scatter(LocalArgs a) {
     a.rsn[q] = sn;
 }
 
-__device__ __forceinline__ float local_radius_threshold(float r) {
+// `sqrt(d2) < radius` (groan_rs Cylinder::inside) is evaluated as `d2 < thr` with thr = the smallest float
+// whose correctly rounded square root reaches the radius: sqrt is monotonic, so the two tests select
+// exactly the same atoms.  Computed once on the host; k_local_flags gets it as LocalArgs::radius_thr.
+__host__ __device__ inline float local_radius_threshold(float r) {
     if (!(r > 0.0f)) return 0.0f;            // sqrt(x) < r never holds
     float thr = r * r;
-    for (int i = 0; i < 8 && __builtin_sqrtf(thr) < r; i++) thr = nextafterf(thr, INFINITY);
+    for (int i = 0; i < 8 && sqrtf(thr) < r; i++) thr = nextafterf(thr, INFINITY);
     for (int i = 0; i < 8; i++) {
         const float p = nextafterf(thr, 0.0f);
-        if (!(p < thr) || !(__builtin_sqrtf(p) >= r)) break;
+        if (!(p < thr) || !(sqrtf(p) >= r)) break;
         thr = p;
     }
     return thr;
@@ -1503,7 +1507,7 @@ __global__ __launch_bounds__(256) void k_local_flags(LocalArgs a) {
     const float4 *rec = reinterpret_cast<const float4 *>(a.trig) + (size_t)s * a.n_membrane;
     const float *rsn = a.rsn + (size_t)s * a.n_membrane;
     const float La = box[da], Lb = box[db], Ln = box[dn];
-    const float thr = local_radius_threshold(a.radius);
+    const float thr = a.radius_thr;
     // rows (ha - ka .. ha + ka) mod nca; in a row the cells (hb - kb .. hb + kb) mod ncb = runs [b0, b1) and [0, b2)
     const uint32_t n_rows = 2u * ka + 1u, n_cols = 2u * kb + 1u;       // <= nca, ncb by local_axis
     const uint32_t a0 = (ha + nca - ka) % nca, b0 = (hb + ncb - kb) % ncb;
@@ -2288,6 +2292,7 @@ static int run_leaflets(gorder_hip_handle *h, const float *d_xyz, const float *d
         lo.heads = h->d_heads; lo.membrane = h->d_membrane; lo.n_membrane = lf.n_membrane;
         lo.dim = lf.normal_dim; lo.flip = lf.flip ? 1 : 0; lo.pbc = h->tables.handle_pbc ? 1 : 0;
         lo.radius = lf.radius;
+        lo.radius_thr = local_radius_threshold(lf.radius);
         lo.cell_of = h->d_lcell_of; lo.trig = h->d_ltrig; lo.cell_count = h->d_lcell_count;
         lo.cell_fill = h->d_lcell_fill; lo.rsn = reinterpret_cast<float *>(h->d_lcell_atoms); lo.err = h->d_err;
         for (size_t done = 0; done < aframes.size(); done += kLocalSlab) {
