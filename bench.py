@@ -17,6 +17,7 @@ stream around the per-frame kernels; `cpu_baseline` is the oracle (C restatement
 algorithm, libm trig exactly like the Rust code) timed on this box's host cores on a bounded sample.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -161,6 +162,17 @@ def main():
     ok_counts = int(res.counts[0].min()) > 0
 
     if rank == 0:
+        # HBM traffic of the dominant kernel comes from PMC counters, which need their own rocprofv3 passes
+        # (tools/pmc.sh); the committed summary for this workload and launch size is reported, else null
+        traffic, traffic_src = None, None
+        prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+        for cand in sorted(glob.glob(os.path.join(prof_dir, f"r*_pmc_{args.workload}_k_bonds_tiled.json")), reverse=True):
+            with open(cand) as fh:
+                pmc = json.load(fh)
+            if pmc.get("algorithmic_bytes_per_launch") == system.bytes_per_frame * frames and \
+                    "hbm_traffic_bytes_per_launch" in pmc:
+                traffic, traffic_src = pmc["hbm_traffic_bytes_per_launch"], os.path.relpath(cand, os.path.dirname(prof_dir))
+                break
         total_frames = args.steps * frames * world
         value = total_frames / dt
         per_launch_bytes = system.bytes_per_frame * frames
@@ -176,7 +188,8 @@ def main():
                        "parallelism": f"frame-sharded x{world}, one RCCL int64 all-reduce at the end"
                        if world > 1 else "single GPU", "plan": eng.plan()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
+                         "traffic_source": traffic_src,
                          "kernel": "k_bonds_tiled", "launches": launches, "avg_launch_ms": avg_launch_s * 1e3,
                          "algorithmic_bytes_per_launch": per_launch_bytes},
             "sanity": {"frames_accumulated": res.n_frames, "expected": expect_frames, "counts_ok": ok_counts},
