@@ -61,7 +61,11 @@ class CUaAtom(C.Structure):
 class CMolType(C.Structure):
     _fields_ = [("n_molecules", C.c_uint32), ("n_bond_types", C.c_uint32), ("bonds", _u32p),
                 ("n_ua_atoms", C.c_uint32), ("ua_atoms", C.POINTER(CUaAtom)), ("heads", _u32p),
-                ("n_methyls", C.c_uint32), ("methyls", _u32p)]
+                ("n_methyls", C.c_uint32), ("methyls", _u32p), ("normal_heads", _u32p)]
+
+
+class CDynamicNormal(C.Structure):
+    _fields_ = [("enabled", C.c_uint32), ("radius", C.c_float), ("n_cloud", C.c_uint32), ("cloud", _u32p)]
 
 
 class CGeometry(C.Structure):
@@ -75,7 +79,8 @@ class CTables(C.Structure):
     _fields_ = [("n_atoms", C.c_uint32), ("n_molecule_types", C.c_uint32),
                 ("molecule_types", C.POINTER(CMolType)), ("handle_pbc", C.c_int32),
                 ("normal", C.c_float * 3), ("leaflets", CLeaflets), ("ordermap", COrderMap),
-                ("timewise", C.c_int32), ("device", C.c_int32), ("flags", C.c_uint32), ("geometry", CGeometry)]
+                ("timewise", C.c_int32), ("device", C.c_int32), ("flags", C.c_uint32), ("geometry", CGeometry),
+                ("dynamic_normal", CDynamicNormal)]
 
 
 class CPlan(C.Structure):
@@ -109,6 +114,7 @@ class MolType:
     heads: Optional[np.ndarray] = None        # [n_molecules]
     methyls: Optional[np.ndarray] = None      # [n_molecules, n_methyls]
     name: str = ""
+    normal_heads: Optional[np.ndarray] = None  # [n_molecules] (dynamic membrane normals)
 
     @property
     def n_bond_types(self) -> int:
@@ -161,6 +167,14 @@ class Geometry:
 
 
 @dataclass
+class DynamicNormal:
+    """input/membrane_normal.rs DynamicNormal: local normals from the cloud of `heads` atoms within `radius`."""
+    enabled: bool = False
+    radius: float = 2.0
+    cloud: Optional[np.ndarray] = None        # atom indices of group "NormalHeads"
+
+
+@dataclass
 class Tables:
     n_atoms: int
     molecule_types: List[MolType]
@@ -172,6 +186,7 @@ class Tables:
     device: int = 0
     flags: int = 0          # FLAG_TRIG_ACOS_COS: acos->cos round trip like the reference
     geometry: Geometry = field(default_factory=Geometry)
+    dynamic_normal: DynamicNormal = field(default_factory=DynamicNormal)
 
     @property
     def n_acc(self) -> int:
@@ -208,7 +223,9 @@ class Tables:
             me = _u32(m.methyls, (m.n_molecules, -1)) if m.methyls is not None else None
             c.n_methyls = 0 if me is None else me.shape[1]
             c.methyls = _ptr(me)
-            keep += [b, ua, h, me]
+            nh = _u32(m.normal_heads, (m.n_molecules,)) if m.normal_heads is not None else None
+            c.normal_heads = _ptr(nh)
+            keep += [b, ua, h, me, nh]
         t = CTables()
         t.n_atoms = self.n_atoms
         t.n_molecule_types = len(self.molecule_types)
@@ -248,7 +265,13 @@ class Tables:
         t.geometry.span[:] = [float(x) for x in ge.span]
         t.geometry.orientation = ge.orientation
         t.geometry.structure_box[:] = [float(x) for x in ge.structure_box]
-        keep += [mts, mem, grp]
+        dn = self.dynamic_normal
+        cloud = _u32(dn.cloud) if dn.cloud is not None else None
+        t.dynamic_normal.enabled = 1 if dn.enabled else 0
+        t.dynamic_normal.radius = dn.radius
+        t.dynamic_normal.n_cloud = 0 if cloud is None else cloud.size
+        t.dynamic_normal.cloud = _ptr(cloud)
+        keep += [mts, mem, grp, cloud]
         return t, keep
 
 
@@ -258,6 +281,7 @@ _EXPORTS = [
     "gorder_hip_set_stream", "gorder_hip_submit_device", "gorder_hip_submit_host",
     "gorder_hip_prime_leaflets", "gorder_hip_set_manual_leaflets", "gorder_hip_synchronize",
     "gorder_hip_finish", "gorder_hip_timewise", "gorder_hip_leaflets", "gorder_hip_leaflet_distances",
+    "gorder_hip_normals",
     "gorder_hip_accumulators_device", "gorder_hip_bind_accumulators", "gorder_hip_last_error_index",
     "gorder_hip_last_error_message", "gorder_hip_strerror", "gorder_hip_kernel_time", "gorder_hip_plan",
     "gorder_hip_plan_tables",
@@ -310,6 +334,7 @@ def load_library() -> C.CDLL:
     lib.gorder_hip_timewise.argtypes = [vp, vp, vp, u64]
     lib.gorder_hip_leaflets.argtypes = [vp, vp, C.POINTER(u64)]
     lib.gorder_hip_leaflet_distances.argtypes = [vp, vp]
+    lib.gorder_hip_normals.argtypes = [vp, vp, vp]
     lib.gorder_hip_accumulators_device.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
     lib.gorder_hip_bind_accumulators.argtypes = [vp, vp, u64]
     lib.gorder_hip_last_error_index.argtypes = [vp]
@@ -489,6 +514,13 @@ class HipEngine:
         d = np.zeros(self.tables.n_molecules_total, dtype=np.float32)
         self._check(self.lib.gorder_hip_leaflet_distances(self._h, d.ctypes.data_as(C.c_void_p)))
         return d
+
+    def normals(self):
+        """Dynamic membrane normals of the last submitted frame -> (normals [n_mol, 3] f32, n_points [n_mol])."""
+        n = np.zeros((self.tables.n_molecules_total, 3), dtype=np.float32)
+        k = np.zeros(self.tables.n_molecules_total, dtype=np.uint32)
+        self._check(self.lib.gorder_hip_normals(self._h, n.ctypes.data_as(C.c_void_p), k.ctypes.data_as(C.c_void_p)))
+        return n, k
 
     def accumulator_words(self) -> int:
         p, n = C.c_void_p(), C.c_uint64()

@@ -556,6 +556,7 @@ struct ExtraArgs {
     float x0, y0, binx, biny;
     uint32_t nx, ny;
     unsigned long long *map_packed;  // [leaflets ? 2 : 1][n_acc][nx*ny] packed (count << 42) + sum, see k_fold_maps
+    const float4 *dyn;               // dynamic membrane normals [n_frames][n_mol_total] (nx, ny, nz, cloud size) or null
     int tw;                          // timewise on
     unsigned long long *tw_sums;     // [rows][3][n_acc]
     unsigned long long *tw_cnts;     // [rows][3][n_acc]
@@ -688,12 +689,8 @@ __global__ __launch_bounds__(kBlock) void k_bonds_extras(FrameArgs a_in, ExtraAr
                 vy = gm_min_image(vy, b[4], bad);
                 vz = gm_min_image(vz, b[8], bad);
             }
-            const float sch = gm_calc_sch<ACOS_COS>(vx, vy, vz, a.nx, a.ny, a.nz, a.n2, a.n2sq);
-            if (sch != sch) {
-                if (p1x != p1x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, t.atom0 + it.li, f);
-                else if (q2[0] != q2[0]) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, t.atom0 + it.lj, f);
-            }
-            const int tick = gm_tick(sch);
+            if (p1x != p1x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, t.atom0 + it.li, f);
+            else if (q2[0] != q2[0]) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, t.atom0 + it.lj, f);
             // bond position = p1 + v / 2 (bond.rs:422); geometry filter (bond.rs:424-426)
             const float mx = p1x + vx / 2.0f, my = p1y + vy / 2.0f, mz = p1z + vz / 2.0f;
             bool in = true;
@@ -703,6 +700,16 @@ __global__ __launch_bounds__(kBlock) void k_bonds_extras(FrameArgs a_in, ExtraAr
                 in = geom_inside(e, e.shapes + 8 * (size_t)f, mx, my, mz, box, a.pbc != 0, bad);
             }
             if (in) {
+                float sch;
+                if (e.dyn) {   // the molecule's own normal of this frame, fetched after the geometry test (bond.rs:429-431)
+                    const float4 n = e.dyn[(size_t)f * a.n_mol_total + it.mol];
+                    if (n.w < 3.0f) raise_error(a.err, GORDER_ERR_DYNAMIC_NORMAL, (uint32_t)n.w, f);
+                    const float n2sq = (n.x * n.x + n.y * n.y) + n.z * n.z;
+                    sch = gm_calc_sch<ACOS_COS>(vx, vy, vz, n.x, n.y, n.z, __builtin_sqrtf(n2sq), n2sq);
+                } else {
+                    sch = gm_calc_sch<ACOS_COS>(vx, vy, vz, a.nx, a.ny, a.nz, a.n2, a.n2sq);
+                }
+                const int tick = gm_tick(sch);
                 int leaflet = -1;
                 if (a.leaflets) leaflet = a.aflags[(size_t)a.arow[f] * a.n_mol_total + it.mol] ? 1 : 0;
                 acc.s_tot += tick;
@@ -935,9 +942,17 @@ __global__ __launch_bounds__(kBlock) void k_ua_extras(FrameArgs a_in, ExtraArgs 
             }
             int leaflet = -1;
             if (a.leaflets) leaflet = a.aflags[(size_t)a.arow[f] * a.n_mol_total + it.mol] ? 1 : 0;
+            float nrx = a.nx, nry = a.ny, nrz = a.nz, nr2 = a.n2, nr2sq = a.n2sq;
+            if (EXTRAS && e.dyn) {   // fetched for every molecule, before the geometry test (uaorder.rs:412-413)
+                const float4 n = e.dyn[(size_t)f * a.n_mol_total + it.mol];
+                if (n.w < 3.0f) raise_error(a.err, GORDER_ERR_DYNAMIC_NORMAL, (uint32_t)n.w, f);
+                nrx = n.x; nry = n.y; nrz = n.z;
+                nr2sq = (n.x * n.x + n.y * n.y) + n.z * n.z;
+                nr2 = __builtin_sqrtf(nr2sq);
+            }
             auto sample = [&](const int k, const V3 v, const V3 b) {
                 if (k >= nh) return;
-                const float sch = gm_calc_sch<ACOS_COS>(v.x, v.y, v.z, a.nx, a.ny, a.nz, a.n2, a.n2sq);
+                const float sch = gm_calc_sch<ACOS_COS>(v.x, v.y, v.z, nrx, nry, nrz, nr2, nr2sq);
                 const int tick = gm_tick(sch);
                 if (EXTRAS) {
                     const float box[3] = {bx3.x, bx3.y, bx3.z};
@@ -1259,7 +1274,9 @@ struct LocalArgs {
     const float *xyz;
     const float *box9;
     uint32_t n_atoms;
-    const uint32_t *aframes;    // [n_slab] local frame index of each assignment frame of this slab
+    const uint32_t *aframes;    // [n_slab] local frame index of each assignment frame of this slab;
+                                // null: the slab is the frame range frame0 .. frame0 + n_slab - 1
+    uint32_t frame0;
     uint32_t n_slab;
     uint32_t row0;
     uint8_t *aflags;
@@ -1345,7 +1362,7 @@ __global__ __launch_bounds__(256) void k_local_bin(LocalArgs a) {
     __shared__ uint32_t hist[kLocalLdsCells];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t s = blockIdx.y;
-    const uint32_t f = a.aframes[s];
+    const uint32_t f = a.aframes ? a.aframes[s] : a.frame0 + s;
     float box[3];
     frame_box(a, f, box);
     uint32_t nca, ncb;
@@ -1405,7 +1422,7 @@ __global__ __launch_bounds__(256) void k_local_scatter(LocalArgs a) {
     __shared__ uint32_t hist[kLocalLdsCells];   // per-block count, then the block's base offset in each cell
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t s = blockIdx.y;
-    const uint32_t f = a.aframes[s];
+    const uint32_t f = a.aframes ? a.aframes[s] : a.frame0 + s;
     float box[3];
     frame_box(a, f, box);
     uint32_t nca, ncb;
@@ -1486,7 +1503,7 @@ __global__ __launch_bounds__(256) void k_local_flags(LocalArgs a) {
     const uint32_t m = blockIdx.x * 4u + (threadIdx.x >> 6);
     const uint32_t s = blockIdx.y;
     if (m >= a.n_mol_total) return;
-    const uint32_t f = a.aframes[s];
+    const uint32_t f = a.aframes ? a.aframes[s] : a.frame0 + s;
     float box[3];
     frame_box(a, f, box);
     uint32_t nca, ncb, ka, kb;
@@ -1657,6 +1674,132 @@ __global__ __launch_bounds__(256) void k_local_flags(LocalArgs a) {
     if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f);
 }
 
+// ---- dynamic membrane normals ---------------------------------------------------------------------
+// DynamicMembraneNormal::calculate_normal (normal.rs:160-199) for every molecule of every frame:
+// cloud = "NormalHeads" atoms with 3-D (minimum-image) distance < radius from the molecule's head
+// (pbc.rs:142-161, 321-350), normal = direction of least variance of the cloud (normal.rs:421-458).
+// The cloud atoms go through the same cell list as the local-leaflet atoms (k_local_bin/scan/scatter,
+// in-plane x-y cells whatever the membrane's orientation: the cells only prune); a wave per molecule
+// accumulates count, sum d and sum d d^T of the minimum-image vectors d in f64 — the covariance does not
+// depend on the origin — and lane 0 diagonalises it by cyclic Jacobi rotations in f64, the same operation
+// sequence as the oracle.  nalgebra's f32 SVD cannot be restated bit for bit: this path is pinned by the
+// reference's 4-decimal goldens only.  Sign convention: last non-zero component positive.
+__device__ void sym3_smallest_eigenvector(double a00, double a01, double a02, double a11, double a12, double a22,
+                                          double (&out)[3]) {
+    double v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    double a[3][3] = {{a00, a01, a02}, {a01, a11, a12}, {a02, a12, a22}};
+    for (int sweep = 0; sweep < 32; sweep++) {
+        const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+        const double dia = a[0][0] * a[0][0] + a[1][1] * a[1][1] + a[2][2] * a[2][2];
+        if (!(off > 1e-34 * dia)) break;
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+#pragma unroll
+            for (int q = p + 1; q < 3; q++) {
+                if (a[p][q] == 0.0) continue;
+                const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                const int r = 3 - p - q;
+                const double apq = a[p][q], arp = a[r][p], arq = a[r][q];
+                a[p][p] = a[p][p] - t * apq;
+                a[q][q] = a[q][q] + t * apq;
+                a[p][q] = a[q][p] = 0.0;
+                a[r][p] = a[p][r] = c * arp - sn * arq;
+                a[r][q] = a[q][r] = sn * arp + c * arq;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const double vkp = v[k][p], vkq = v[k][q];
+                    v[k][p] = c * vkp - sn * vkq;
+                    v[k][q] = sn * vkp + c * vkq;
+                }
+            }
+    }
+    const bool m1 = a[1][1] < a[0][0];
+    const double d01 = m1 ? a[1][1] : a[0][0];
+    const bool m2 = a[2][2] < d01;
+    out[0] = m2 ? v[0][2] : (m1 ? v[0][1] : v[0][0]);
+    out[1] = m2 ? v[1][2] : (m1 ? v[1][1] : v[1][0]);
+    out[2] = m2 ? v[2][2] : (m1 ? v[2][1] : v[2][0]);
+    const double lead = out[2] != 0.0 ? out[2] : (out[1] != 0.0 ? out[1] : out[0]);
+    if (lead < 0.0) { out[0] = -out[0]; out[1] = -out[1]; out[2] = -out[2]; }
+}
+
+// block = 4 waves = 4 molecules; grid = (ceil(n_mol / 4), n_slab); a.heads = the molecules' normal heads,
+// a.membrane = the cloud; out[(frame0 + s) * n_mol + m] = (nx, ny, nz, cloud size)
+__global__ __launch_bounds__(256) void k_dyn_normals(LocalArgs a, float4 *__restrict__ out) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t m = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t s = blockIdx.y;
+    if (m >= a.n_mol_total) return;
+    const uint32_t f = a.aframes ? a.aframes[s] : a.frame0 + s;
+    float box[3];
+    frame_box(a, f, box);
+    uint32_t nca, ncb, ka, kb;
+    int da, db;
+    local_grid(a, box, nca, ncb, da, db, ka, kb);
+    const float *x = a.xyz + (size_t)f * a.n_atoms * 3u;
+    const float *hp = x + 3u * (size_t)a.heads[m];
+    const float hx = hp[0], hy = hp[1], hz = hp[2];
+    if (hx != hx) {
+        if (lane == 0) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, a.heads[m], f);
+        return;
+    }
+    int bad = 0;
+    uint32_t ha = 0, hb = 0;
+    if (a.pbc) {
+        const float wa = gm_wrap(hp[da], box[da], bad), wb = gm_wrap(hp[db], box[db], bad);
+        ha = (uint32_t)fminf(fmaxf(floorf(wa / box[da] * (float)nca), 0.0f), (float)(nca - 1u));
+        hb = (uint32_t)fminf(fmaxf(floorf(wb / box[db] * (float)ncb), 0.0f), (float)(ncb - 1u));
+    }
+    const uint32_t *cstart = a.cell_count + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u);
+    const float4 *rec = reinterpret_cast<const float4 *>(a.trig) + (size_t)s * a.n_membrane;
+    const float thr = a.radius_thr;
+    const bool pbc = a.pbc != 0;
+    const uint32_t n_rows = 2u * ka + 1u, n_cols = 2u * kb + 1u;
+    const uint32_t a0 = (ha + nca - ka) % nca, b0 = (hb + ncb - kb) % ncb;
+    const uint32_t b1 = min(b0 + n_cols, ncb), b2 = b0 + n_cols - b1;
+    // records are (coordinate da, coordinate db, coordinate dim, -) = (x, y, z, -) for dim = 2
+    double sx = 0.0, sy = 0.0, sz = 0.0, sxx = 0.0, sxy = 0.0, sxz = 0.0, syy = 0.0, syz = 0.0, szz = 0.0;
+    uint32_t cnt = 0;
+    for (uint32_t ia = 0; ia < n_rows; ia++) {
+        const uint32_t row = ((a0 + ia) % nca) * ncb;
+        for (uint32_t part = 0; part < 2u; part++) {
+            const uint32_t q0 = part == 0 ? cstart[row + b0] : cstart[row];
+            const uint32_t q1 = part == 0 ? cstart[row + b1] : cstart[row + b2];
+            for (uint32_t q = q0 + lane; q < q1; q += 64u) {
+                const float4 r = rec[q];
+                float dx = r.x - hx, dy = r.y - hy, dz = r.z - hz;
+                if (pbc) { dx = gm_min_image(dx, box[0], bad); dy = gm_min_image(dy, box[1], bad); dz = gm_min_image(dz, box[2], bad); }
+                if ((dx * dx + dy * dy) + dz * dz < thr) {          // == sqrt(..) < radius (local_radius_threshold)
+                    cnt += 1;
+                    sx += (double)dx; sy += (double)dy; sz += (double)dz;
+                    sxx += (double)dx * dx; sxy += (double)dx * dy; sxz += (double)dx * dz;
+                    syy += (double)dy * dy; syz += (double)dy * dz; szz += (double)dz * dz;
+                }
+            }
+        }
+    }
+    const double n = wave_total((double)cnt);
+    sx = wave_total(sx); sy = wave_total(sy); sz = wave_total(sz);
+    sxx = wave_total(sxx); sxy = wave_total(sxy); sxz = wave_total(sxz);
+    syy = wave_total(syy); syz = wave_total(syz); szz = wave_total(szz);
+    if (lane == 0) {
+        float4 o = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), (float)n);
+        if (n >= 3.0) {
+            const double inv = 1.0 / n;
+            double e[3];
+            sym3_smallest_eigenvector(sxx - sx * sx * inv, sxy - sx * sy * inv, sxz - sx * sz * inv,
+                                      syy - sy * sy * inv, syz - sy * sz * inv, szz - sz * sz * inv, e);
+            const float fx = (float)e[0], fy = (float)e[1], fz = (float)e[2];
+            const float len = __builtin_sqrtf((fx * fx + fy * fy) + fz * fz);     // Vector3D::to_unit
+            o.x = fx / len; o.y = fy / len; o.z = fz / len;
+        }
+        out[(size_t)f * a.n_mol_total + m] = o;
+    }
+    if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f);
+}
+
 }  // namespace
 
 // ============================================================================================
@@ -1689,6 +1832,14 @@ struct gorder_hip_handle {
     ExtraArgs extra{};
     uint32_t *d_geom_group = nullptr;
     float *d_shapes = nullptr;
+    // dynamic membrane normals: cloud + per-molecule heads, cell-list scratch (kLocalSlab frames), normals of the batch
+    bool dyn = false;
+    uint32_t *d_dyn_cloud = nullptr, *d_dyn_heads = nullptr;
+    uint32_t *d_dyn_cell_of = nullptr, *d_dyn_count = nullptr;
+    float *d_dyn_rec = nullptr, *d_dyn_rsn = nullptr;
+    float4 *d_dyn_normals = nullptr;
+    size_t dyn_normals_cap = 0;
+    std::vector<float> last_normals;   // [n_mol_total][4] of the last submitted frame
     size_t shapes_cap = 0;
     uint32_t *d_err = nullptr;
     unsigned long long *d_acc = nullptr;   // [4][n_acc] + total_frames
@@ -1807,6 +1958,39 @@ int fold_maps(gorder_hip_handle *h) {
     return GORDER_OK;
 }
 
+// normals of every molecule for the frames of this batch -> h->d_dyn_normals [n_frames][n_mol_total]
+int run_dynamic_normals(gorder_hip_handle *h, const FrameArgs &a) {
+    int st;
+    const uint32_t n_mol = h->plan.n_mol_total;
+    if ((st = ensure(h, &h->d_dyn_normals, &h->dyn_normals_cap, (size_t)a.n_frames * n_mol)) != GORDER_OK) return st;
+    const gorder_dynamic_normal_t &dn = h->tables.dynamic_normal;
+    const size_t ncell = (size_t)kLocalMaxCells1D * kLocalMaxCells1D;
+    LocalArgs lo{};
+    lo.xyz = a.xyz; lo.box9 = a.box9; lo.n_atoms = a.n_atoms;
+    lo.n_mol_total = n_mol; lo.heads = h->d_dyn_heads; lo.membrane = h->d_dyn_cloud; lo.n_membrane = dn.n_cloud;
+    lo.dim = 2; lo.pbc = a.pbc; lo.radius = dn.radius; lo.radius_thr = local_radius_threshold(dn.radius);
+    lo.cell_of = h->d_dyn_cell_of; lo.trig = h->d_dyn_rec; lo.rsn = h->d_dyn_rsn;
+    lo.cell_count = h->d_dyn_count; lo.cell_fill = h->d_dyn_count + kLocalSlab * (ncell + 1);
+    lo.err = h->d_err; lo.aframes = nullptr; lo.write_dist_frame = -1;
+    for (uint32_t done = 0; done < a.n_frames; done += kLocalSlab) {
+        const uint32_t ns = std::min(a.n_frames - done, kLocalSlab);
+        lo.frame0 = done;
+        lo.n_slab = ns;
+        HIP_TRY(h, hipMemsetAsync(h->d_dyn_count, 0, kLocalSlab * (2 * ncell + 1) * sizeof(uint32_t), h->stream));
+        const dim3 ga((dn.n_cloud + 255) / 256, ns);
+        hipLaunchKernelGGL(k_local_bin, ga, dim3(256), 0, h->stream, lo);
+        hipLaunchKernelGGL(k_local_scan, dim3(ns), dim3(1024), 0, h->stream, lo);
+        hipLaunchKernelGGL(k_local_scatter, ga, dim3(256), 0, h->stream, lo);
+        hipLaunchKernelGGL(k_dyn_normals, dim3((n_mol + 3) / 4, ns), dim3(256), 0, h->stream, lo, h->d_dyn_normals);
+    }
+    HIP_TRY(h, hipGetLastError());
+    // keep the last frame's normals for gorder_hip_normals (stream-ordered copy into pageable memory)
+    h->last_normals.resize(4 * (size_t)n_mol);
+    HIP_TRY(h, hipMemcpyAsync(h->last_normals.data(), h->d_dyn_normals + (size_t)(a.n_frames - 1) * n_mol,
+                              4 * sizeof(float) * (size_t)n_mol, hipMemcpyDeviceToHost, h->stream));
+    return GORDER_OK;
+}
+
 int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
     const Plan &p = h->plan;
     const uint32_t n_tiles = (uint32_t)p.tiles.size();
@@ -1814,7 +1998,11 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
     HIP_TRY(h, hipEventCreate(&e0));
     HIP_TRY(h, hipEventCreate(&e1));
     HIP_TRY(h, hipEventRecord(e0, h->stream));
-    const bool extras = h->extra.maps || h->extra.tw || h->extra.geom_kind;
+    const bool extras = h->extra.maps || h->extra.tw || h->extra.geom_kind || h->dyn;
+    if (h->dyn) {
+        const int st2 = run_dynamic_normals(h, a);
+        if (st2 != GORDER_OK) return st2;
+    }
     if (h->extra.geom_kind) {
         int st2;
         if ((st2 = ensure(h, &h->d_shapes, &h->shapes_cap, (size_t)a.n_frames * 8)) != GORDER_OK) return st2;
@@ -1909,6 +2097,7 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
         ExtraArgs e = h->extra;
         e.tw_sums = h->d_tw_sums; e.tw_cnts = h->d_tw_cnts; e.tw_row0 = h->n_frames;
         e.shapes = h->d_shapes;
+        e.dyn = h->dyn ? h->d_dyn_normals : nullptr;
         const bool ac = (h->tables.flags & GORDER_FLAG_TRIG_ACOS_COS) != 0;
         // with ordermaps the frames go in sub-ranges short enough for the packed map words (k_fold_maps)
         const uint32_t sub = e.maps ? (uint32_t)std::max<uint64_t>(1, (h->map_fold_limit - 1) / h->map_max_mol) : a.n_frames;
@@ -1990,6 +2179,7 @@ const char *gorder_hip_strerror(int status) {
         case GORDER_ERR_UNDEFINED_POSITION: return "atom has an undefined position";
         case GORDER_ERR_INVALID_GLOBAL_MEMBRANE_CENTER: return "could not calculate global membrane center";
         case GORDER_ERR_INVALID_LOCAL_MEMBRANE_CENTER: return "could not calculate local membrane center";
+        case GORDER_ERR_DYNAMIC_NORMAL: return "not enough points for dynamic local membrane normal calculation (need 3)";
         case GORDER_ERR_INVALID_ARGUMENT: return "invalid argument";
         case GORDER_ERR_DEVICE: return "HIP runtime error";
         case GORDER_ERR_NO_DEVICE: return "no HIP device available (this library has no CPU fallback)";
@@ -2154,6 +2344,32 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
         h->wg_capacity = (uint32_t)n_cu * (uint32_t)per_cu;
     }
 
+    const gorder_dynamic_normal_t &dn = t->dynamic_normal;
+    if (dn.enabled) {
+        if (!(dn.radius > 0.0f)) return fail(h, GORDER_ERR_INVALID_ARGUMENT, "dynamic normals need a positive radius");
+        if (!dn.cloud || dn.n_cloud == 0) return fail(h, GORDER_ERR_INVALID_ARGUMENT, "dynamic normals need the NormalHeads group");
+        if (!p.direct.empty()) return fail(h, GORDER_ERR_INVALID_ARGUMENT, "dynamic normals: a bond spans more than the LDS window");
+        std::vector<uint32_t> cloud(dn.cloud, dn.cloud + dn.n_cloud), nheads;
+        for (uint32_t a : cloud)
+            if (a >= t->n_atoms) return fail(h, GORDER_ERR_INVALID_ARGUMENT, "NormalHeads index out of range");
+        for (uint32_t m = 0; m < t->n_molecule_types; m++) {
+            const gorder_moltype_t &mt = t->molecule_types[m];
+            if (!mt.normal_heads) return fail(h, GORDER_ERR_INVALID_ARGUMENT, "dynamic normals need normal_heads[] per molecule type");
+            for (uint32_t k = 0; k < mt.n_molecules; k++) {
+                if (mt.normal_heads[k] >= t->n_atoms) return fail(h, GORDER_ERR_INVALID_ARGUMENT, "normal head index out of range");
+                nheads.push_back(mt.normal_heads[k]);
+            }
+        }
+        if ((st = upload(h, &h->d_dyn_cloud, cloud)) != GORDER_OK) return st;
+        if ((st = upload(h, &h->d_dyn_heads, nheads)) != GORDER_OK) return st;
+        const size_t nm = dn.n_cloud, ncell = (size_t)kLocalMaxCells1D * kLocalMaxCells1D;
+        HIP_TRY(h, hipMalloc((void **)&h->d_dyn_cell_of, kLocalSlab * nm * sizeof(uint32_t)));
+        HIP_TRY(h, hipMalloc((void **)&h->d_dyn_rsn, kLocalSlab * nm * sizeof(float)));
+        HIP_TRY(h, hipMalloc((void **)&h->d_dyn_rec, kLocalSlab * nm * 4 * sizeof(float)));
+        HIP_TRY(h, hipMalloc((void **)&h->d_dyn_count, kLocalSlab * (2 * ncell + 1) * sizeof(uint32_t)));
+        h->dyn = true;
+    }
+
     const gorder_leaflets_t &lf = t->leaflets;
     if (lf.method != GORDER_LEAFLETS_NONE) {
         if (lf.normal_dim > 2) return fail(h, GORDER_ERR_INVALID_ARGUMENT, "leaflets.normal_dim");
@@ -2213,6 +2429,8 @@ void gorder_hip_destroy(gorder_hip_handle *h) {
     (void)hipFree(h->d_ua_tiles); (void)hipFree(h->d_ua_items); (void)hipFree(h->d_ua_tile_slots);
     (void)hipFree(h->d_map_sums); (void)hipFree(h->d_map_cnts); (void)hipFree(h->d_map_packed); (void)hipFree(h->d_tw_sums); (void)hipFree(h->d_tw_cnts);
     (void)hipFree(h->d_geom_group); (void)hipFree(h->d_shapes);
+    (void)hipFree(h->d_dyn_cloud); (void)hipFree(h->d_dyn_heads); (void)hipFree(h->d_dyn_cell_of); (void)hipFree(h->d_dyn_count);
+    (void)hipFree(h->d_dyn_rec); (void)hipFree(h->d_dyn_rsn); (void)hipFree(h->d_dyn_normals);
     if (!h->acc_external) (void)hipFree(h->d_acc);
     (void)hipFree(h->d_rep);
     (void)hipFree(h->d_heads); (void)hipFree(h->d_membrane); (void)hipFree(h->d_methyl_begin);
@@ -2498,6 +2716,19 @@ int gorder_hip_finish(gorder_hip_handle *h, int64_t *sums, uint64_t *counts, int
         const size_t nmap = 3 * (size_t)n * h->map_nx * h->map_ny;
         if (map_sums) HIP_TRY(h, hipMemcpy(map_sums, h->d_map_sums, nmap * sizeof(int64_t), hipMemcpyDeviceToHost));
         if (map_counts) HIP_TRY(h, hipMemcpy(map_counts, h->d_map_cnts, nmap * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    }
+    return GORDER_OK;
+}
+
+int gorder_hip_normals(gorder_hip_handle *h, float *normals, uint32_t *n_points) {
+    if (!h || !h->dyn) return GORDER_ERR_INVALID_ARGUMENT;
+    const int st = gorder_hip_synchronize(h);
+    if (st != GORDER_OK) return st;
+    const uint32_t n_mol = h->plan.n_mol_total;
+    if (h->last_normals.size() < 4 * (size_t)n_mol) return fail(h, GORDER_ERR_INVALID_ARGUMENT, "no frame submitted yet");
+    for (uint32_t m = 0; m < n_mol; m++) {
+        if (normals) for (int d = 0; d < 3; d++) normals[3 * (size_t)m + d] = h->last_normals[4 * (size_t)m + d];
+        if (n_points) n_points[m] = (uint32_t)h->last_normals[4 * (size_t)m + 3];
     }
     return GORDER_OK;
 }

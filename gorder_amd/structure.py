@@ -185,8 +185,9 @@ def classify(structure: Structure, group1: np.ndarray, group2: np.ndarray, same_
 def build_tables(structure: Structure, analysis: str, sel1: np.ndarray, sel2: Optional[np.ndarray] = None,
                  master: Optional[np.ndarray] = None, leaflets: Optional[dict] = None, handle_pbc: bool = True,
                  normal=(0.0, 0.0, 1.0), ordermap: Optional[OrderMap] = None, timewise: bool = False,
-                 flags: int = 0, geometry=None):
+                 flags: int = 0, geometry=None, dynamic_normal: Optional[dict] = None):
     """analysis: 'aa' (sel1 = heavy atoms, sel2 = hydrogens) or 'cg' (sel1 = beads).
+    dynamic_normal: {"heads": mask, "radius": r} — DynamicNormal::new(heads, radius), input/membrane_normal.rs.
     `master`: boolean mask of the atoms present in the coordinate frames handed to the engine (the
     "Master" group, common.rs:92-103); default = union of every selection involved.
     leaflets: {"method": ..., "membrane": mask, "heads": mask, "methyls": mask, "frequency": n, "flip": bool,
@@ -202,6 +203,8 @@ def build_tables(structure: Structure, analysis: str, sel1: np.ndarray, sel2: Op
         for k in ("membrane", "heads", "methyls"):
             if lf.get(k) is not None:
                 master = master | lf[k]
+        if dynamic_normal is not None:
+            master = master | dynamic_normal["heads"]
     midx = np.flatnonzero(master)
     remap = -np.ones(structure.n_atoms, dtype=np.int64)
     remap[midx] = np.arange(len(midx))
@@ -228,7 +231,8 @@ def build_tables(structure: Structure, analysis: str, sel1: np.ndarray, sel2: Op
                 ml = [[remap[a] for a in atoms if lf["methyls"][a]] for atoms in mols]
                 assert len(set(len(x) for x in ml)) == 1 and len(ml[0]) > 0
                 methyls = np.array(ml, dtype=np.uint32)
-        mts.append(MolType(n_molecules=n_mol, bonds=bonds, heads=heads, methyls=methyls, name=t["name"]))
+        mts.append(MolType(n_molecules=n_mol, bonds=bonds, heads=heads, methyls=methyls, name=t["name"],
+                           normal_heads=_normal_heads(mols, dynamic_normal, remap, t["name"])))
         m0 = t["m0"]
         bl = [BondLabel(r1, structure.names[m0 + r1], r2, structure.names[m0 + r2]) for r1, r2 in t["bonds"]]
         heavy = []
@@ -253,7 +257,30 @@ def build_tables(structure: Structure, analysis: str, sel1: np.ndarray, sel2: Op
                     ordermap=ordermap or OrderMap(), timewise=timewise, flags=flags)
     if geometry is not None:
         tables.geometry = geometry
+    _set_dynamic_normal(tables, dynamic_normal, remap)
     return tables, labels, midx
+
+
+def _normal_heads(mols, dynamic_normal, remap, name):
+    """get_reference_head for group "NormalHeads" (normal.rs:145-158): exactly one per molecule."""
+    if dynamic_normal is None:
+        return None
+    out = np.zeros(len(mols), dtype=np.uint32)
+    for k, atoms in enumerate(mols):
+        hs = [a for a in atoms if dynamic_normal["heads"][a]]
+        assert len(hs) == 1, f"molecule type {name}: {len(hs)} normal-head identifiers (need exactly 1)"
+        out[k] = remap[hs[0]]
+    return out
+
+
+def _set_dynamic_normal(tables, dynamic_normal, remap):
+    if dynamic_normal is None:
+        return
+    from .abi import DynamicNormal
+    cloud = remap[np.flatnonzero(dynamic_normal["heads"])]
+    assert (cloud >= 0).all()
+    tables.dynamic_normal = DynamicNormal(enabled=True, radius=float(dynamic_normal.get("radius", 2.0)),
+                                          cloud=cloud.astype(np.uint32))
 
 
 @dataclass
@@ -274,7 +301,8 @@ class UaMolLabels:
 
 def build_tables_ua(structure: Structure, saturated: np.ndarray, unsaturated: np.ndarray, master: np.ndarray,
                     leaflets: Optional[dict] = None, handle_pbc: bool = True, normal=(0.0, 0.0, 1.0),
-                    ordermap: Optional[OrderMap] = None, timewise: bool = False, flags: int = 0):
+                    ordermap: Optional[OrderMap] = None, timewise: bool = False, flags: int = 0,
+                    dynamic_normal: Optional[dict] = None):
     """AtomBasedClassifier + UAOrderAtoms (classify.rs, uaorder.rs:454-665): the number of bonded atoms of
     a carbon decides how many hydrogens are built; helpers = bonded atoms in index order; a methyl's second
     helper is the first neighbour of helper1 that is not the methyl itself (uaorder.rs:609-629)."""
@@ -342,7 +370,8 @@ def build_tables_ua(structure: Structure, saturated: np.ndarray, unsaturated: np
             heads = np.array([remap[[a for a in atoms if lf["heads"][a]][0]] for atoms in mols], dtype=np.uint32)
             if lf["method"] == LEAFLETS_INDIVIDUAL:
                 methyls = np.array([[remap[a] for a in atoms if lf["methyls"][a]] for atoms in mols], dtype=np.uint32)
-        mts.append(MolType(n_molecules=len(mols), ua_atoms=ua_atoms, heads=heads, methyls=methyls, name=t["name"]))
+        mts.append(MolType(n_molecules=len(mols), ua_atoms=ua_atoms, heads=heads, methyls=methyls, name=t["name"],
+                           normal_heads=_normal_heads(mols, dynamic_normal, remap, t["name"])))
         labels.append(UaMolLabels(t["name"], carbons, len(mols), slot0))
         slot0 += sum(c.n_h for c in carbons)
     leaf = Leaflets()
@@ -354,6 +383,7 @@ def build_tables_ua(structure: Structure, saturated: np.ndarray, unsaturated: np
                         flip=lf.get("flip", False), radius=lf.get("radius", 0.0), membrane=mem)
     tables = Tables(n_atoms=len(midx), molecule_types=mts, handle_pbc=handle_pbc, normal=normal, leaflets=leaf,
                     ordermap=ordermap or OrderMap(), timewise=timewise, flags=flags)
+    _set_dynamic_normal(tables, dynamic_normal, remap)
     return tables, labels, midx
 
 

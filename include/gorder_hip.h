@@ -38,7 +38,7 @@ extern "C" {
 #endif
 
 /* ---- status codes ---------------------------------------------------------------------------
- * 1..6 mirror the AnalysisError variants the per-frame path can raise (src/errors.rs:121-141).
+ * 1..7 mirror the AnalysisError variants the per-frame path can raise (src/errors.rs:121-141).
  * >= 100 are errors of this library (no counterpart in the reference). */
 typedef enum {
     GORDER_OK = 0,
@@ -48,6 +48,8 @@ typedef enum {
     GORDER_ERR_UNDEFINED_POSITION = 4,              /* AnalysisError::UndefinedPosition(idx)  errors.rs:136 */
     GORDER_ERR_INVALID_GLOBAL_MEMBRANE_CENTER = 5,  /* ...::InvalidGlobalMembraneCenter       errors.rs:139 */
     GORDER_ERR_INVALID_LOCAL_MEMBRANE_CENTER = 6,   /* ...::InvalidLocalMembraneCenter(idx)   errors.rs:143 */
+    GORDER_ERR_DYNAMIC_NORMAL = 7,                  /* ...::DynamicNormalError(NotEnoughPoints(n)) errors.rs:155,
+                                                       172-177; gorder_hip_last_error_index = n */
     GORDER_ERR_INVALID_ARGUMENT = 100,
     GORDER_ERR_DEVICE = 101,          /* a HIP runtime call failed; see gorder_hip_last_error_message */
     GORDER_ERR_NO_DEVICE = 102,       /* no gfx950 device visible: the product path has NO CPU fallback */
@@ -116,7 +118,22 @@ typedef struct {
     const uint32_t *heads;     /* [n_molecules] or NULL */
     uint32_t n_methyls;        /* equal for all molecules of a type (leaflets.rs:760-770) */
     const uint32_t *methyls;   /* [n_molecules][n_methyls] or NULL */
+    /* dynamic membrane normal (normal.rs:145-158, get_reference_head): */
+    const uint32_t *normal_heads; /* [n_molecules] the molecule's atom of group "NormalHeads", or NULL */
 } gorder_moltype_t;
+
+/* ---- dynamic membrane normals (src/analysis/normal.rs:160-199, 421-458; pbc.rs:142-161, 321-350) ----
+ * Per frame and molecule: the cloud of "NormalHeads" atoms within `radius` (3-D, minimum image) of the
+ * molecule's own head, made whole around it; the normal is the direction of least variance of the cloud
+ * (last right singular vector of the demeaned cloud).  Fewer than 3 points: GORDER_ERR_DYNAMIC_NORMAL,
+ * raised only if a sample of that molecule is actually accumulated (the reference computes normals lazily,
+ * after the geometry test, bond.rs:424-431).  With `enabled` the static `normal` of the tables is unused. */
+typedef struct {
+    uint32_t enabled;
+    float radius;
+    uint32_t n_cloud;
+    const uint32_t *cloud;     /* atom indices of group "NormalHeads" (every atom the heads query selects) */
+} gorder_dynamic_normal_t;
 
 /* ---- geometry selection (src/analysis/geometry.rs:24-136, 181-210; input/geometry.rs) ----------
  * Only samples whose bond position lies inside (or, inverted, outside) the shape are accumulated
@@ -162,6 +179,7 @@ typedef struct {
     int32_t device;             /* HIP device ordinal */
     uint32_t flags;             /* gorder_flags_t */
     gorder_geometry_t geometry; /* kind = GORDER_GEOM_NONE: every sample counts (geometry.rs:215-284) */
+    gorder_dynamic_normal_t dynamic_normal;
 } gorder_tables_t;
 
 /* Accumulator slots are numbered in reference iteration order: molecule type major, then bond
@@ -223,6 +241,11 @@ int gorder_hip_timewise(gorder_hip_handle *h, int64_t *tw_sums, uint64_t *tw_cou
 int gorder_hip_leaflets(gorder_hip_handle *h, uint8_t *flags, uint64_t *assignment_frame);
 /* Signed distances (nm) behind those flags, [n_molecules_total] (leaflets.rs:725, 796). */
 int gorder_hip_leaflet_distances(gorder_hip_handle *h, float *distances);
+
+/* Dynamic membrane normals of the LAST submitted frame: normals [n_molecules_total][3] (unit vectors; NaN
+ * for a molecule whose cloud had fewer than 3 points), n_points [n_molecules_total] the cloud sizes
+ * (what NormalsStorage keeps per frame, normal.rs:460-520).  Requires tables.dynamic_normal.enabled. */
+int gorder_hip_normals(gorder_hip_handle *h, float *normals, uint32_t *n_points);
 
 /* Device pointer + element count of the packed u64 accumulator block
  * {i64 sums[3][n_acc], u64 counts[3][n_acc], u64 total_frames, (maps...)} so that a host can issue

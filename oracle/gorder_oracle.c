@@ -357,6 +357,91 @@ int gorder_oracle_predict_hydrogens(uint32_t kind, const float pos[4][3], const 
  * unbounded extent anchors at 0 (PBC) or f32::MIN (NoPBC).  [3rd-party] groan_rs Rectangular /
  * Cylinder / Sphere ::inside: offsets from the anchor are wrapped into [0, L] (PBC) and must not exceed
  * the extent; radial tests use the minimum-image distance, strict `<`. */
+/* ---- dynamic membrane normals ------------------------------------------------------------------
+ * DynamicMembraneNormal::calculate_normal (normal.rs:160-199): cloud of "NormalHeads" atoms inside
+ * Sphere(reference, radius) — PBC3D::get_heads_cloud (pbc.rs:321-350: minimum-image distance, points made
+ * whole as reference + vector_to) or NoPBC::get_heads_cloud (pbc.rs:142-161: naive) — then
+ * membrane_normal_from_cloud (normal.rs:421-458): demean, SVD, last right singular vector, to_unit;
+ * fewer than 3 points -> DynamicNormalError::NotEnoughPoints.
+ *
+ * nalgebra's f32 SVD cannot be restated bit for bit (its source is not under /root/reference).  The
+ * direction it returns is the eigenvector of the smallest eigenvalue of sum (p - c)(p - c)^T; here that
+ * 3x3 matrix is accumulated in f64 from the f32 minimum-image vectors d = vector_to(reference, p)
+ * (translation does not change it) and diagonalised by cyclic Jacobi rotations in f64.  The sign of a
+ * singular vector is arbitrary and P2 does not depend on it; convention here: last non-zero component
+ * positive.  Pinned only through the reference's 4-decimal goldens (the "dynamic" files of tests/golden/expected). */
+static void sym3_smallest_eigenvector(double a00, double a01, double a02, double a11, double a12, double a22,
+                                      double out[3]) {
+    double v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    double a[3][3] = {{a00, a01, a02}, {a01, a11, a12}, {a02, a12, a22}};
+    for (int sweep = 0; sweep < 32; sweep++) {
+        const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+        const double dia = a[0][0] * a[0][0] + a[1][1] * a[1][1] + a[2][2] * a[2][2];
+        if (!(off > 1e-34 * dia)) break;
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                if (a[p][q] == 0.0) continue;
+                const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                const int r = 3 - p - q;                       /* the third index */
+                const double apq = a[p][q], arp = a[r][p], arq = a[r][q];
+                a[p][p] = a[p][p] - t * apq;
+                a[q][q] = a[q][q] + t * apq;
+                a[p][q] = a[q][p] = 0.0;
+                a[r][p] = a[p][r] = c * arp - sn * arq;
+                a[r][q] = a[q][r] = sn * arp + c * arq;
+                for (int k = 0; k < 3; k++) {
+                    const double vkp = v[k][p], vkq = v[k][q];
+                    v[k][p] = c * vkp - sn * vkq;
+                    v[k][q] = sn * vkp + c * vkq;
+                }
+            }
+    }
+    int m = 0;
+    if (a[1][1] < a[m][m]) m = 1;
+    if (a[2][2] < a[m][m]) m = 2;
+    out[0] = v[0][m]; out[1] = v[1][m]; out[2] = v[2][m];
+    const double lead = out[2] != 0.0 ? out[2] : (out[1] != 0.0 ? out[1] : out[0]);
+    if (lead < 0.0) { out[0] = -out[0]; out[1] = -out[1]; out[2] = -out[2]; }
+}
+
+/* normal[4] = (nx, ny, nz, number of cloud points); NaN normal when fewer than 3 points */
+static int dynamic_normal(const float *xyz, const uint32_t *cloud, uint32_t n_cloud, uint32_t head, float radius,
+                          const float *box, int pbc, float *normal, uint64_t *err_index) {
+    const float *ref = xyz + 3 * (size_t)head;
+    if (ref[0] != ref[0]) { *err_index = head; return GORDER_ERR_UNDEFINED_POSITION; }
+    int bad = 0;
+    uint32_t n = 0;
+    double s[3] = {0, 0, 0}, ss[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t i = 0; i < n_cloud; i++) {
+        const float *p = xyz + 3 * (size_t)cloud[i];
+        float d[3];
+        bad |= vector_to(ref, p, box, pbc, d);
+        if (!(sqrtf(dot3(d, d)) < radius)) continue;           /* Sphere::inside: distance < radius */
+        if (p[0] != p[0]) { *err_index = cloud[i]; return GORDER_ERR_UNDEFINED_POSITION; }
+        n++;
+        for (int k = 0; k < 3; k++) s[k] += (double)d[k];
+        ss[0] += (double)d[0] * d[0]; ss[1] += (double)d[0] * d[1]; ss[2] += (double)d[0] * d[2];
+        ss[3] += (double)d[1] * d[1]; ss[4] += (double)d[1] * d[2]; ss[5] += (double)d[2] * d[2];
+    }
+    normal[3] = (float)n;
+    if (n < 3) { normal[0] = normal[1] = normal[2] = NAN; return bad ? GORDER_ERR_BOX_RANGE : GORDER_OK; }
+    const double inv = 1.0 / (double)n;
+    double e[3];
+    sym3_smallest_eigenvector(ss[0] - s[0] * s[0] * inv, ss[1] - s[0] * s[1] * inv, ss[2] - s[0] * s[2] * inv,
+                              ss[3] - s[1] * s[1] * inv, ss[4] - s[1] * s[2] * inv, ss[5] - s[2] * s[2] * inv, e);
+    const float f[3] = {(float)e[0], (float)e[1], (float)e[2]};
+    const float len = norm3(f);                                /* Vector3D::to_unit */
+    normal[0] = f[0] / len; normal[1] = f[1] / len; normal[2] = f[2] / len;
+    return bad ? GORDER_ERR_BOX_RANGE : GORDER_OK;
+}
+int gorder_oracle_dynamic_normal(const float *xyz, const uint32_t *cloud, uint32_t n_cloud, uint32_t head,
+                                 float radius, const float box[3], int handle_pbc, float normal[4]) {
+    uint64_t e = 0;
+    return dynamic_normal(xyz, cloud, n_cloud, head, radius, box, handle_pbc, normal, &e);
+}
+
 typedef struct { float pos[3]; float size[3]; float radius, height; } o_shape;
 
 static int make_shape(const gorder_geometry_t *g, const float *ref, const float *box, int pbc, o_shape *sh) {
@@ -461,6 +546,7 @@ typedef struct {
     uint32_t *ua_slot0;   /* first accumulator slot of each ua atom */
     uint32_t *heads;      /* [n_molecules] or NULL */
     uint32_t *methyls;    /* [n_molecules][n_methyls] or NULL */
+    uint32_t *normal_heads; /* [n_molecules] or NULL (dynamic membrane normals) */
     uint32_t slot0;       /* first accumulator slot of this molecule type */
     uint32_t mol0;        /* index of first molecule in the global molecule numbering */
 } o_moltype;
@@ -483,6 +569,9 @@ struct gorder_oracle_handle {
     uint32_t nx, ny;
     gorder_geometry_t geom;
     uint32_t *geom_group;
+    gorder_dynamic_normal_t dyn;
+    uint32_t *dyn_cloud;
+    float *last_normals;      /* [n_mol_total][4] (nx, ny, nz, n_points) of the last analysed frame */
     o_acc acc;
     /* leaflets: flags of the most recent assignment (AssignedLeaflets::local, leaflets.rs:1371-1380) */
     uint8_t *flags;
@@ -540,6 +629,7 @@ static void *dup_mem(const void *p, size_t n) {
     return q;
 }
 
+#define gorder_oracle_destroy_partial gorder_oracle_destroy
 int gorder_oracle_create(const gorder_tables_t *t, int trig_mode, int n_threads,
                          gorder_oracle_handle **out) {
     if (!t || !out || t->n_atoms == 0) return GORDER_ERR_INVALID_ARGUMENT;
@@ -566,6 +656,9 @@ int gorder_oracle_create(const gorder_tables_t *t, int trig_mode, int n_threads,
         free(h->geom_group); free(h->membrane); free(h);
         return GORDER_ERR_INVALID_ARGUMENT;   /* NoPBC::get_box_center panics, pbc.rs:243-245 */
     }
+    h->dyn = t->dynamic_normal;
+    h->dyn_cloud = (uint32_t *)dup_mem(t->dynamic_normal.cloud, sizeof(uint32_t) * t->dynamic_normal.n_cloud);
+    h->dyn.cloud = h->dyn_cloud;
     h->om = t->ordermap;
     if (h->om.enabled) {
         h->nx = gridmap_n(h->om.span_x[0], h->om.span_x[1], h->om.bin[0]);
@@ -598,6 +691,8 @@ int gorder_oracle_create(const gorder_tables_t *t, int trig_mode, int n_threads,
         }
         d->heads = (uint32_t *)dup_mem(s->heads, sizeof(uint32_t) * s->n_molecules);
         d->methyls = (uint32_t *)dup_mem(s->methyls, sizeof(uint32_t) * (size_t)s->n_molecules * s->n_methyls);
+        d->normal_heads = (uint32_t *)dup_mem(s->normal_heads, sizeof(uint32_t) * s->n_molecules);
+        if (h->dyn.enabled && !d->normal_heads) { gorder_oracle_destroy_partial(h); return GORDER_ERR_INVALID_ARGUMENT; }
         mol += s->n_molecules;
     }
     h->n_acc = slot;
@@ -605,6 +700,7 @@ int gorder_oracle_create(const gorder_tables_t *t, int trig_mode, int n_threads,
     acc_alloc(h, &h->acc);
     h->flags = (uint8_t *)calloc(mol ? mol : 1, 1);
     h->flag_dist = (float *)calloc(mol ? mol : 1, sizeof(float));
+    h->last_normals = (float *)calloc(4 * (size_t)(mol ? mol : 1), sizeof(float));
     *out = h;
     return GORDER_OK;
 }
@@ -615,9 +711,9 @@ void gorder_oracle_destroy(gorder_oracle_handle *h) {
         o_moltype *d = &h->mt[m];
         free(d->bonds);
         for (uint32_t a = 0; a < d->n_ua_atoms; a++) free(d->ua_idx[a]);
-        free(d->ua_kind); free(d->ua_idx); free(d->ua_slot0); free(d->heads); free(d->methyls);
+        free(d->ua_kind); free(d->ua_idx); free(d->ua_slot0); free(d->heads); free(d->methyls); free(d->normal_heads);
     }
-    free(h->mt); free(h->membrane); free(h->geom_group); acc_free(&h->acc);
+    free(h->mt); free(h->membrane); free(h->geom_group); free(h->dyn_cloud); free(h->last_normals); acc_free(&h->acc);
     free(h->flags); free(h->flag_dist); free(h->tw_sums); free(h->tw_counts);
     free(h);
 }
@@ -751,7 +847,7 @@ static inline void add_order(const gorder_oracle_handle *h, o_acc *a, int64_t *t
  * (uaorder.rs:400-437).  `flags` = leaflet assignment that applies to this frame. */
 static int analyze_frame_orders(const gorder_oracle_handle *h, o_acc *a, int64_t *tw_s, uint64_t *tw_n,
                                 const float *xyz, const float *box, const uint8_t *flags,
-                                uint64_t *err_index) {
+                                uint64_t *err_index, float *normals_out /* [n_mol_total][4] scratch */) {
     int bad = 0;
     const int lf = h->lf.method != GORDER_LEAFLETS_NONE;
     const int geom = h->geom.kind != GORDER_GEOM_NONE;
@@ -763,6 +859,20 @@ static int analyze_frame_orders(const gorder_oracle_handle *h, o_acc *a, int64_t
         else if (h->geom.reference == GORDER_GEOMREF_GROUP) bad |= center_of(xyz, h->geom_group, h->geom.n_group, box, h->pbc, ref);
         else shape_box = h->geom.structure_box;   /* fixed point: built once, with the structure's box (:194) */
         bad |= make_shape(&h->geom, ref, shape_box, h->pbc, &shape);
+    }
+    /* dynamic normals: the reference computes a molecule's normal lazily once per frame (OnceCell,
+     * normal.rs:145-158); computing all of them up front gives the same values — only the
+     * NotEnoughPoints error must wait until a sample of that molecule is really accumulated */
+    float *dyn = NULL;
+    if (h->dyn.enabled) {
+        dyn = normals_out;
+        for (uint32_t m = 0; m < h->n_mt; m++)
+            for (uint32_t i = 0; i < h->mt[m].n_molecules; i++) {
+                const int st = dynamic_normal(xyz, h->dyn_cloud, h->dyn.n_cloud, h->mt[m].normal_heads[i], h->dyn.radius,
+                                              box, h->pbc, dyn + 4 * (size_t)(h->mt[m].mol0 + i), err_index);
+                if (st == GORDER_ERR_UNDEFINED_POSITION) return st;
+                if (st != GORDER_OK) bad = 1;
+            }
     }
     for (uint32_t m = 0; m < h->n_mt; m++) {
         const o_moltype *mt = &h->mt[m];
@@ -777,7 +887,12 @@ static int analyze_frame_orders(const gorder_oracle_handle *h, o_acc *a, int64_t
                 bad |= vector_to(p1, p2, box, h->pbc, v);
                 for (int d = 0; d < 3; d++) mid[d] = p1[d] + v[d] / 2.0f; /* bond.rs:422 */
                 if (geom && !inside_shape(&h->geom, &shape, mid, box, h->pbc, &bad)) continue; /* bond.rs:424-426 */
-                const float sch = calc_sch(v, h->normal, h->trig);
+                const float *normal = h->normal;
+                if (dyn) {                                       /* bond.rs:429-431 */
+                    normal = dyn + 4 * (size_t)(mt->mol0 + i);
+                    if (normal[3] < 3.0f) { *err_index = (uint64_t)normal[3]; return GORDER_ERR_DYNAMIC_NORMAL; }
+                }
+                const float sch = calc_sch(v, normal, h->trig);
                 add_order(h, a, tw_s, tw_n, mt->slot0 + bt, sch, mid, lf ? flags[mt->mol0 + i] : -1);
             }
         }
@@ -787,6 +902,11 @@ static int analyze_frame_orders(const gorder_oracle_handle *h, o_acc *a, int64_t
             const int nidx = kind == GORDER_UA_CH1_SAT ? 4 : 3;
             for (uint32_t i = 0; i < mt->n_molecules; i++) {
                 const uint32_t *ix = mt->ua_idx[ua] + 4 * (size_t)i;
+                const float *normal = h->normal;
+                if (dyn) {   /* uaorder.rs:412-413: fetched for every molecule, before the geometry test */
+                    normal = dyn + 4 * (size_t)(mt->mol0 + i);
+                    if (normal[3] < 3.0f) { *err_index = (uint64_t)normal[3]; return GORDER_ERR_DYNAMIC_NORMAL; }
+                }
                 float pos[4][3] = {{0}};
                 for (int k = 0; k < nidx; k++) {
                     const float *p = xyz + 3 * (size_t)ix[k];
@@ -802,7 +922,7 @@ static int analyze_frame_orders(const gorder_oracle_handle *h, o_acc *a, int64_t
                     bad |= vector_to(pos[ti], hy[k], box, h->pbc, v);
                     for (int d = 0; d < 3; d++) bp[d] = hy[k][d] + v[d] / 2.0f;
                     if (geom && !inside_shape(&h->geom, &shape, bp, box, h->pbc, &bad)) continue; /* uaorder.rs:388-390 */
-                    const float sch = calc_sch(v, h->normal, h->trig);
+                    const float sch = calc_sch(v, normal, h->trig);
                     add_order(h, a, tw_s, tw_n, mt->ua_slot0[ua] + (uint32_t)k, sch, bp,
                               lf ? flags[mt->mol0 + i] : -1);
                 }
@@ -832,18 +952,21 @@ static void *worker(void *arg) {
     o_job *j = (o_job *)arg;
     gorder_oracle_handle *h = j->h;
     const size_t row = 3 * (size_t)h->n_acc;
+    float *normals = h->dyn.enabled ? (float *)malloc(4 * sizeof(float) * (size_t)(h->n_mol_total ? h->n_mol_total : 1)) : NULL;
     for (uint32_t f = j->tid; f < j->n_frames; f += j->nthr) {
         float box3[3] = {0, 0, 0};
         if (h->pbc) {
             const int st = check_box(j->box + 9 * (size_t)f, box3);
-            if (st != GORDER_OK) { j->status = st; return NULL; }
+            if (st != GORDER_OK) { j->status = st; break; }
         }
         const int st = analyze_frame_orders(
             h, &j->acc, j->tw_s ? j->tw_s + row * f : NULL, j->tw_n ? j->tw_n + row * f : NULL,
             j->xyz + 3 * (size_t)h->n_atoms * f, box3,
-            j->frame_flags ? j->frame_flags + (size_t)h->n_mol_total * f : NULL, &j->err_index);
-        if (st != GORDER_OK) { j->status = st; return NULL; }
+            j->frame_flags ? j->frame_flags + (size_t)h->n_mol_total * f : NULL, &j->err_index, normals);
+        if (st != GORDER_OK) { j->status = st; break; }
+        if (normals && f + 1 == j->n_frames) memcpy(h->last_normals, normals, 4 * sizeof(float) * (size_t)h->n_mol_total);
     }
+    free(normals);
     return NULL;
 }
 
@@ -968,6 +1091,15 @@ int gorder_oracle_timewise(gorder_oracle_handle *h, int64_t *tw_sums, uint64_t *
     const size_t row = 3 * (size_t)h->n_acc;
     memcpy(tw_sums, h->tw_sums, row * h->n_frames * sizeof(int64_t));
     memcpy(tw_counts, h->tw_counts, row * h->n_frames * sizeof(uint64_t));
+    return GORDER_OK;
+}
+
+int gorder_oracle_normals(gorder_oracle_handle *h, float *normals, uint32_t *n_points) {
+    if (!h || !h->dyn.enabled) return GORDER_ERR_INVALID_ARGUMENT;
+    for (uint32_t m = 0; m < h->n_mol_total; m++) {
+        if (normals) memcpy(normals + 3 * (size_t)m, h->last_normals + 4 * (size_t)m, 3 * sizeof(float));
+        if (n_points) n_points[m] = (uint32_t)h->last_normals[4 * (size_t)m + 3];
+    }
     return GORDER_OK;
 }
 

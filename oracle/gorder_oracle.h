@@ -46,6 +46,11 @@ int gorder_oracle_finish(gorder_oracle_handle *h, int64_t *sums, uint64_t *count
 int gorder_oracle_timewise(gorder_oracle_handle *h, int64_t *tw_sums, uint64_t *tw_counts,
                            uint64_t capacity_frames);
 /* flags of the most recent assignment frame + the signed distances they were derived from */
+/* dynamic membrane normals of the last analysed frame (see gorder_hip_normals) */
+int gorder_oracle_normals(gorder_oracle_handle *h, float *normals, uint32_t *n_points);
+/* one normal: normal[4] = (nx, ny, nz, number of cloud points) — normal.rs:160-199, 421-458 */
+int gorder_oracle_dynamic_normal(const float *xyz, const uint32_t *cloud, uint32_t n_cloud, uint32_t head,
+                                 float radius, const float box[3], int handle_pbc, float normal[4]);
 int gorder_oracle_leaflets(gorder_oracle_handle *h, uint8_t *flags, float *distances,
                            uint64_t *assignment_frame);
 uint64_t gorder_oracle_last_error_index(const gorder_oracle_handle *h);

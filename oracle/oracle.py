@@ -44,6 +44,8 @@ def load():
     lib.gorder_oracle_finish.argtypes = [vp, vp, vp, vp, vp, C.POINTER(u64)]
     lib.gorder_oracle_timewise.argtypes = [vp, vp, vp, u64]
     lib.gorder_oracle_leaflets.argtypes = [vp, vp, vp, C.POINTER(u64)]
+    lib.gorder_oracle_normals.argtypes = [vp, vp, vp]
+    lib.gorder_oracle_dynamic_normal.argtypes = [vp, vp, u32, u32, f32, vp, i32, vp]
     lib.gorder_oracle_last_error_index.argtypes = [vp]
     lib.gorder_oracle_last_error_index.restype = u64
     lib.gorder_oracle_vector_to.argtypes = [vp, vp, vp, i32, vp]
@@ -221,6 +223,13 @@ class OracleEngine:
         c = np.zeros((n_frames, 3, n), dtype=np.uint64)
         self._check(self.lib.gorder_oracle_timewise(self._h, s.ctypes.data, c.ctypes.data, n_frames))
         return s, c
+
+    def normals(self):
+        """Dynamic membrane normals of the last analysed frame -> (normals [n_mol, 3], n_points [n_mol])."""
+        n = np.zeros((self.tables.n_molecules_total, 3), dtype=np.float32)
+        k = np.zeros(self.tables.n_molecules_total, dtype=np.uint32)
+        self._check(self.lib.gorder_oracle_normals(self._h, n.ctypes.data, k.ctypes.data))
+        return n, k
 
     def leaflets(self):
         n = self.tables.n_molecules_total

@@ -186,3 +186,60 @@ def test_geometry_box_centre_and_united_atoms(built):
     with pytest.raises(abi.GorderHipError) as e:
         HipEngine(s2.tables)
     assert e.value.status == abi.ERR_INVALID_ARGUMENT
+
+
+# ---- dynamic membrane normals (normal.rs:160-199, 421-458) ------------------------------------------
+def _with_dynamic_normals(system, radius):
+    from gorder_amd.abi import DynamicNormal
+    cloud = []
+    for mt in system.tables.molecule_types:
+        mt.normal_heads = np.asarray(mt.heads, dtype=np.uint32)
+        cloud.append(mt.normal_heads)
+    system.tables.dynamic_normal = DynamicNormal(enabled=True, radius=radius, cloud=np.concatenate(cloud))
+    return system
+
+
+@pytest.mark.parametrize("pbc", [True, False])
+@pytest.mark.parametrize("kind", ["cg", "ua"])
+def test_dynamic_normals(built, kind, pbc):
+    if kind == "cg":
+        system = synthetic.cg_membrane(300, leaflets=LEAFLETS_INDIVIDUAL, n_types=2, handle_pbc=pbc)
+    else:
+        system = synthetic.ua_membrane(120, leaflets=LEAFLETS_GLOBAL, handle_pbc=pbc)
+    _with_dynamic_normals(system, 2.2)
+    n = 9
+    xyz = system.frames(n, seed=12)
+    box = system.box9(n) if pbc else None
+    eng, o, got, want = both(system, xyz, box, batches=2)
+    np.testing.assert_array_equal(got.counts, want.counts)
+    assert np.abs(got.order_ticks() - want.order_ticks()).max() <= 1
+    n_gpu, k_gpu = eng.normals()
+    n_ref, k_ref = o.normals()
+    np.testing.assert_array_equal(k_gpu, k_ref)
+    assert k_ref.min() >= 3 and np.abs(n_gpu - n_ref).max() < 1e-6
+    # with two leaflets ~4 nm apart only the head's own leaflet is within 2.2 nm: normals near +-z, and they
+    # really differ from the static axis (else this test would not notice a missing normal)
+    assert 0.8 < np.abs(n_ref[:, 2]).mean() < 0.99999
+
+
+def test_dynamic_normals_not_enough_points(built):
+    """DynamicNormalError::NotEnoughPoints(n): raised for a molecule whose cloud has < 3 heads — but only if a
+    sample of that molecule is accumulated (AA/CG: after the geometry test, bond.rs:424-431)."""
+    from gorder_amd import GorderHipError
+    system = _with_dynamic_normals(synthetic.cg_membrane(60, leaflets=LEAFLETS_GLOBAL), 0.3)   # heads are ~0.8 nm apart
+    xyz = system.frames(3, seed=1)
+    eng = HipEngine(system.tables)
+    with pytest.raises(GorderHipError) as ei:
+        eng.submit_host(xyz, system.box9(3), np.arange(3))
+        eng.finish()
+    assert ei.value.status == 7 and ei.value.index in (1, 2)        # the cloud size rides in the error index
+    o = oracle.OracleEngine(system.tables, trig=oracle.TRIG_DIRECT)
+    with pytest.raises(oracle.OracleError) as eo:
+        o.submit(xyz, system.box9(3), np.arange(3))
+    assert eo.value.status == 7
+    # a geometry that contains no sample: nobody asks for a normal, no error
+    system.tables.geometry = Geometry(kind=GEOM_SPHERE, reference=GEOMREF_POINT, point=(1.0, 1.0, 0.2), radius=0.1,
+                                      structure_box=tuple(float(x) for x in system.box))
+    eng = HipEngine(system.tables)
+    eng.submit_host(xyz, system.box9(3), np.arange(3))
+    assert eng.finish().counts.sum() == 0

@@ -147,3 +147,30 @@ def test_aa_geometry_selection(pcpepg, case):
     _, ref = oracle_run(tables, xyz, box, fi, oracle.TRIG_DIRECT)
     np.testing.assert_array_equal(res.counts, ref.counts)     # the same samples pass the filter
     np.testing.assert_array_equal(res.sums, ref.sums)
+
+
+# ---- dynamic membrane normals ------------------------------------------------------------------------
+from test_golden_oracle import dynamic_setup   # noqa: E402
+
+
+@pytest.mark.parametrize("kind", ["aa", "cg", "ua"])
+def test_dynamic_normals(kind, pcpepg, cg, ua):
+    """tests_aa.rs:4774-4807, tests_cg.rs:3358-3388, tests_ua.rs:717-743.  The normals come from an f64
+    eigen-decomposition on both sides (nalgebra's f32 SVD is not restatable), device and oracle only
+    differ in the order the cloud is summed: normals agree to ~1e-7, order parameters to <= 1 tick."""
+    fx = {"aa": pcpepg, "cg": cg, "ua": ua}[kind]
+    tables, labels, midx, lf, want = dynamic_setup(kind, fx)
+    frames = fx.window()
+    eng, res, xyz, box, fi = gpu_run(tables, fx, midx, frames)
+    tree = st.results_tree_ua(res, labels, leaflets=lf) if kind == "ua" else st.results_tree(res, labels, kind, leaflets=lf)
+    bad = st.compare_trees(tree, expected(want))
+    assert not bad, bad[:10]
+    o, ref = oracle_run(tables, xyz, box, fi, oracle.TRIG_DIRECT)
+    np.testing.assert_array_equal(res.counts, ref.counts)
+    assert np.abs(res.order_ticks() - ref.order_ticks()).max() <= 1
+    n_gpu, k_gpu = eng.normals()
+    n_ref, k_ref = o.normals()
+    np.testing.assert_array_equal(k_gpu, k_ref)                    # the same cloud for every molecule
+    assert np.abs(n_gpu - n_ref).max() < 1e-6
+    _, libm = oracle_run(tables, xyz, box, fi, oracle.TRIG_LIBM)
+    assert np.abs(res.order_ticks() - libm.order_ticks()).max() <= 1

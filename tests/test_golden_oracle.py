@@ -200,3 +200,58 @@ def test_unbounded_sphere_is_no_selection(pcpepg):
     eng.submit(master_frames(pcpepg, midx, frames), pcpepg.boxes[frames], frames)
     bad = st.compare_trees(st.results_tree(eng.finish(), labels, "aa", leaflets=False), expected("aa_order_basic.yaml"))
     assert not bad, bad[:10]
+
+
+# ---- dynamic membrane normals (normal.rs:160-199, 421-458) -----------------------------------------
+def dynamic_setup(kind, fx):
+    """The three reference tests with `DynamicNormal::new(heads, 2.0)`: tests_aa.rs:4774-4807,
+    tests_cg.rs:3358-3388, tests_ua.rs:717-743 -> (tables, labels, midx, leaflets?, expected file)."""
+    if kind == "aa":
+        t, l, m = aa_setup(fx, leaflets=METHODS["individual"], frequency=0,
+                           dynamic_normal={"heads": fx.name_in("P"), "radius": 2.0})
+        return t, l, m, True, "aa_order_leaflets_dynamic.yaml"
+    if kind == "cg":
+        t, l, m = cg_setup(fx, leaflets=METHODS["individual"], frequency=0,
+                           dynamic_normal={"heads": fx.name_in("PO4"), "radius": 2.0})
+        return t, l, m, True, "cg_order_leaflets_dynamic.yaml"
+    heads = np.array([n.startswith("P") for n in fx.structure.names])              # name r'^P'
+    t, l, m = ua_setup(fx, dynamic_normal={"heads": heads, "radius": 2.0})
+    return t, l, m, False, "ua_order_dynamic_normals.yaml"
+
+
+@pytest.mark.parametrize("kind", ["aa", "cg", "ua"])
+def test_dynamic_normals(kind, pcpepg, cg, ua):
+    fx = {"aa": pcpepg, "cg": cg, "ua": ua}[kind]
+    tables, labels, midx, lf, want = dynamic_setup(kind, fx)
+    assert tables.dynamic_normal.enabled and len(tables.dynamic_normal.cloud) == tables.n_molecules_total
+    frames = fx.window()
+    eng = oracle.OracleEngine(tables, trig=oracle.TRIG_LIBM, n_threads=4)
+    eng.submit(master_frames(fx, midx, frames), fx.boxes[frames], frames)
+    res = eng.finish()
+    normals, npts = eng.normals()
+    assert npts.min() >= 3 and np.allclose(np.linalg.norm(normals, axis=1), 1.0, atol=1e-6)
+    assert np.abs(normals[:, 2]).mean() > 0.9          # a flat bilayer: local normals stay close to z
+    tree = st.results_tree_ua(res, labels, leaflets=lf) if kind == "ua" else st.results_tree(res, labels, kind, leaflets=lf)
+    bad = st.compare_trees(tree, expected(want))
+    assert not bad, bad[:10]
+
+
+def test_dynamic_normal_of_a_tilted_plane():
+    """membrane_normal_from_cloud on points of a known plane: the normal is the plane's, whatever the sign."""
+    rng = np.random.default_rng(3)
+    n_true = np.array([0.3, -0.2, 0.933], dtype=np.float64); n_true /= np.linalg.norm(n_true)
+    u = np.cross(n_true, [1.0, 0.0, 0.0]); u /= np.linalg.norm(u)
+    v = np.cross(n_true, u)
+    pts = (5.0 + rng.uniform(-1.2, 1.2, (40, 1)) * u + rng.uniform(-1.2, 1.2, (40, 1)) * v
+           + rng.normal(0, 0.01, (40, 1)) * n_true).astype(np.float32)
+    pts[0] = 5.0                                        # the reference head
+    lib = oracle.load()
+    out = np.zeros(4, dtype=np.float32)
+    cloud = np.arange(40, dtype=np.uint32)
+    box = np.array([10.0, 10.0, 10.0], dtype=np.float32)
+    st_ = lib.gorder_oracle_dynamic_normal(pts.ctypes.data, cloud.ctypes.data, 40, 0, 2.0, box.ctypes.data, 1, out.ctypes.data)
+    assert st_ == 0 and out[3] == 40
+    assert abs(abs(float(np.dot(out[:3].astype(np.float64), n_true))) - 1.0) < 2e-4
+    # fewer than three points in reach -> NaN normal, count reported (DynamicNormalError::NotEnoughPoints)
+    st_ = lib.gorder_oracle_dynamic_normal(pts.ctypes.data, cloud.ctypes.data, 2, 0, 0.001, box.ctypes.data, 1, out.ctypes.data)
+    assert st_ == 0 and out[3] == 1 and np.isnan(out[0])
