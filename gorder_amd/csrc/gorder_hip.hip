@@ -1093,19 +1093,22 @@ __global__ __launch_bounds__(256) void k_geom_shapes(GeomArgs g) {
                 est[d] = (atan2f(-(float)ts, -(float)tc) + 3.1415927f) / (6.2831855f / box[d]);
             }
         }
-        double acc[3] = {0, 0, 0};
-        for (uint32_t i = threadIdx.x; i < g.n_group; i += blockDim.x) {
-            const float *p = x + 3u * (size_t)g.group[i];
-            for (int d = 0; d < 3; d++) {
-                const float dx = p[d] - est[d];
-                acc[d] += (double)(g.pbc ? gm_min_image(dx, box[d], bad) : dx);
+        // Refinement = plain centre of the atoms' images nearest to the estimate, summed in f32 in atom
+        // order like the reference does: a sample 1 ulp from the shape's surface depends on the last bit
+        // of this centre (the golden aa_order_sphere_dynamic.yaml has one), so the order of the sum is
+        // part of the result.  One thread per frame does it; reference groups are small (a residue, a
+        // protein), and the estimate above only selects the images, its own last bits do not matter.
+        if (threadIdx.x == 0) {
+            float acc[3] = {0.0f, 0.0f, 0.0f};
+            for (uint32_t i = 0; i < g.n_group; i++) {
+                const float *p = x + 3u * (size_t)g.group[i];
+                for (int d = 0; d < 3; d++)
+                    acc[d] += g.pbc ? est[d] + gm_min_image(p[d] - est[d], box[d], bad) : p[d];
             }
-        }
-        for (int d = 0; d < 3; d++) {
-            const double tot = block_sum(acc[d], scratch);
-            float c = est[d] + (float)(tot / (double)g.n_group);
-            if (g.pbc) c = gm_wrap(c, box[d], bad);
-            ref[d] = c;
+            for (int d = 0; d < 3; d++) {
+                const float c = acc[d] / (float)g.n_group;
+                ref[d] = g.pbc ? gm_wrap(c, box[d], bad) : c;
+            }
         }
     } else {
         for (int d = 0; d < 3; d++) shape_box[d] = g.structure_box[d];   // fixed point: built once, structure box

@@ -224,13 +224,19 @@ static int center_of(const float *xyz, const uint32_t *idx, uint32_t n, const fl
         const float th = atan2f(-ss, -sc) + 3.1415927f;
         est[d] = th / scaling;
     }
+    /* refinement: every atom is moved to its image nearest to the estimate, then the plain centre of
+     * those positions is taken (sum of ABSOLUTE positions, f32, atom order) and wrapped.  This form —
+     * rather than est + mean(displacement), which differs in the last bit — is pinned by the golden
+     * aa_order_sphere_dynamic.yaml (tests_aa.rs:3322-3346): in frame 49 one C217-H17R bond of POPE lies
+     * 2 ulp from the surface of the sphere around the centre of residue 1, and only this form leaves it
+     * outside as the reference does. */
     for (int d = 0; d < 3; d++) {
         float acc = 0.0f;
         for (uint32_t i = 0; i < n; i++) {
             const float dx = xyz[3 * (size_t)idx[i] + d] - est[d];
-            acc += min_image(dx, box[d], &bad);
+            acc += est[d] + min_image(dx, box[d], &bad);
         }
-        out[d] = wrap1(est[d] + acc / (float)n, box[d], &bad);
+        out[d] = wrap1(acc / (float)n, box[d], &bad);
     }
     return bad;
 }

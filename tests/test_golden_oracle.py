@@ -147,8 +147,8 @@ def test_ua_order_leaflets(ua, method, frequency):
 
 
 # ---- geometry selection (geometry.rs; tests_aa.rs:3022-3262) ------------------------------------
-from gorder_amd.abi import (GEOM_CUBOID, GEOM_CYLINDER, GEOM_SPHERE, GEOMREF_BOX_CENTER, GEOMREF_POINT,  # noqa: E402
-                            Geometry)
+from gorder_amd.abi import (GEOM_CUBOID, GEOM_CYLINDER, GEOM_SPHERE, GEOMREF_BOX_CENTER, GEOMREF_GROUP,  # noqa: E402
+                            GEOMREF_POINT, Geometry)
 
 INF = float("inf")
 GEOMETRY_CASES = {
@@ -165,6 +165,13 @@ GEOMETRY_CASES = {
                                    orientation=0), "aa_order_cylinder_x.yaml"),
     "sphere_center": (False, Geometry(kind=GEOM_SPHERE, reference=GEOMREF_BOX_CENTER, radius=2.5),
                       "aa_order_sphere_center.yaml"),
+    # reference = centre of geometry of "resid 1", re-evaluated every frame (tests_aa.rs:3263-3346)
+    "cuboid_dynamic": (False, Geometry(kind=GEOM_CUBOID, reference=GEOMREF_GROUP, xdim=(-1.0, 3.0), ydim=(1.0, 4.0),
+                                       zdim=(-3.0, 3.0)), "aa_order_cuboid_dynamic.yaml"),
+    "cylinder_dynamic": (False, Geometry(kind=GEOM_CYLINDER, reference=GEOMREF_GROUP, radius=2.1, orientation=1),
+                         "aa_order_cylinder_dynamic.yaml"),
+    "sphere_dynamic": (False, Geometry(kind=GEOM_SPHERE, reference=GEOMREF_GROUP, radius=2.5),
+                       "aa_order_sphere_dynamic.yaml"),
 }
 
 
@@ -175,7 +182,15 @@ def geometry_tables(fx, case):
         heavy = np.array(fx.structure.resnames) == "POPC"
         heavy &= fx.name_in("C22", "C24", "C218")
     geom.structure_box = tuple(float(x) for x in fx.structure.box)
-    tables, labels, midx = aa_setup(fx, heavy=heavy, geometry=geom)
+    if geom.reference == GEOMREF_GROUP:      # every atom of residue 1 must then be part of the decoded frames
+        grp = np.array(fx.structure.resids) == 1
+        master = fx.element("carbon") | fx.element("hydrogen") | grp
+        remap = -np.ones(fx.structure.n_atoms, dtype=np.int64)
+        remap[np.flatnonzero(master)] = np.arange(int(master.sum()))
+        geom.group = remap[np.flatnonzero(grp)].astype(np.uint32)
+        tables, labels, midx = aa_setup(fx, heavy=heavy, geometry=geom, master=master)
+    else:
+        tables, labels, midx = aa_setup(fx, heavy=heavy, geometry=geom)
     return tables, labels, midx, want
 
 
