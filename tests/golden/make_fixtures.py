@@ -67,7 +67,8 @@ if __name__ == "__main__":
               "aa_order_cuboid_square.yaml", "aa_order_cylinder.yaml", "aa_order_sphere_static.yaml",
               "aa_order_cuboid_patch.yaml", "aa_order_cylinder_x.yaml", "aa_order_sphere_center.yaml",
               "aa_order_cuboid_dynamic.yaml", "aa_order_cylinder_dynamic.yaml", "aa_order_sphere_dynamic.yaml",
-              "aa_order_leaflets_dynamic.yaml", "cg_order_leaflets_dynamic.yaml", "ua_order_dynamic_normals.yaml"):
+              "aa_order_leaflets_dynamic.yaml", "cg_order_leaflets_dynamic.yaml", "ua_order_dynamic_normals.yaml",
+              "aa_leaflets_every1.yaml"):
         src = os.path.join(REF, f)
         if os.path.exists(src):
             shutil.copy(src, os.path.join(HERE, "expected", f))

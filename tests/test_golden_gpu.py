@@ -174,3 +174,19 @@ def test_dynamic_normals(kind, pcpepg, cg, ua):
     assert np.abs(n_gpu - n_ref).max() < 1e-6
     _, libm = oracle_run(tables, xyz, box, fi, oracle.TRIG_LIBM)
     assert np.abs(res.order_ticks() - libm.order_ticks()).max() <= 1
+
+
+# ---- exported leaflet assignment -----------------------------------------------------------------------
+from test_golden_oracle import expected_leaflets   # noqa: E402
+
+
+@pytest.mark.parametrize("method", ["global", "local", "individual"])
+def test_aa_leaflet_assignment_per_molecule(pcpepg, method):
+    # tests_aa.rs:682-722: every method exports the assignment of aa_leaflets_every1.yaml, frame by frame
+    tables, labels, midx = aa_setup(pcpepg, leaflets=METHODS[method])
+    eng = HipEngine(tables)
+    for f in range(0, 51, 5):
+        eng.submit_host(np.ascontiguousarray(pcpepg.xyz[[f]][:, midx, :]), pcpepg.boxes[[f]], [f])
+        flags, frame = eng.leaflets()
+        assert frame == f
+        np.testing.assert_array_equal(flags, expected_leaflets(labels, f))

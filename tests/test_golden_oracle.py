@@ -270,3 +270,24 @@ def test_dynamic_normal_of_a_tilted_plane():
     # fewer than three points in reach -> NaN normal, count reported (DynamicNormalError::NotEnoughPoints)
     st_ = lib.gorder_oracle_dynamic_normal(pts.ctypes.data, cloud.ctypes.data, 2, 0, 0.001, box.ctypes.data, 1, out.ctypes.data)
     assert st_ == 0 and out[3] == 1 and np.isnan(out[0])
+
+
+# ---- exported leaflet assignment (tests_aa.rs:588-722) ------------------------------------------------
+def expected_leaflets(labels, frame_row=0):
+    """aa_leaflets_every1.yaml: per molecule type one row per assignment frame, 1 = upper, 0 = lower
+    -> this repo's encoding (Upper = 0, Lower = 1, lib.rs:416-422) for all molecules in type order."""
+    exp = expected("aa_leaflets_every1.yaml")
+    return np.concatenate([1 - np.array(exp[m.name][frame_row], dtype=np.uint8) for m in labels])
+
+
+@pytest.mark.parametrize("method", ["global", "local", "individual"])
+def test_aa_leaflet_assignment_per_molecule(pcpepg, method):
+    """global, local (2.5 nm) and individual classification all export the same per-molecule assignment
+    for every frame; checked here on the first, a middle and the last frame."""
+    tables, labels, midx = aa_setup(pcpepg, leaflets=METHODS[method])
+    for f in (0, 25, 50):
+        eng = oracle.OracleEngine(tables, trig=oracle.TRIG_DIRECT)
+        eng.submit(master_frames(pcpepg, midx, [f]), pcpepg.boxes[[f]], [f])
+        flags, _, frame = eng.leaflets()
+        assert frame == f
+        np.testing.assert_array_equal(flags, expected_leaflets(labels, f))
