@@ -2419,6 +2419,8 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
         }
         HIP_TRY(h, hipMalloc((void **)&h->d_adist, sizeof(float) * (p.n_mol_total ? p.n_mol_total : 1)));
     }
+    // the memsets above ran on the null stream, which the handle's non-blocking stream does not wait for
+    HIP_TRY(h, hipDeviceSynchronize());
     return GORDER_OK;
 }
 
@@ -2572,8 +2574,9 @@ int gorder_hip_submit_device(gorder_hip_handle *h, const float *d_xyz, const flo
             const size_t nrows = rows + rows / 4;
             HIP_TRY(h, hipMalloc((void **)&nb, nrows * (size_t)p.n_mol_total));
             if (h->d_aflags) {
+                // stream-ordered: the handle's stream is non-blocking, a null-stream copy would not be
+                HIP_TRY(h, hipMemcpyAsync(nb, h->d_aflags, p.n_mol_total, hipMemcpyDeviceToDevice, h->stream));
                 HIP_TRY(h, hipStreamSynchronize(h->stream));
-                HIP_TRY(h, hipMemcpy(nb, h->d_aflags, p.n_mol_total, hipMemcpyDeviceToDevice));
                 HIP_TRY(h, hipFree(h->d_aflags));
             }
             h->d_aflags = nb;
@@ -2598,12 +2601,14 @@ int gorder_hip_submit_device(gorder_hip_handle *h, const float *d_xyz, const flo
         unsigned long long *ns = nullptr, *nc = nullptr;
         HIP_TRY(h, hipMalloc((void **)&ns, ncap * row * sizeof(unsigned long long)));
         HIP_TRY(h, hipMalloc((void **)&nc, ncap * row * sizeof(unsigned long long)));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-        HIP_TRY(h, hipMemset(ns, 0, ncap * row * sizeof(unsigned long long)));
-        HIP_TRY(h, hipMemset(nc, 0, ncap * row * sizeof(unsigned long long)));
+        // everything on the handle's own (non-blocking) stream: a null-stream memset / copy is NOT ordered
+        // with the kernels that follow and left stale rows behind (seen as a wrong error estimate)
+        HIP_TRY(h, hipMemsetAsync(ns, 0, ncap * row * sizeof(unsigned long long), h->stream));
+        HIP_TRY(h, hipMemsetAsync(nc, 0, ncap * row * sizeof(unsigned long long), h->stream));
         if (h->d_tw_sums) {
-            HIP_TRY(h, hipMemcpy(ns, h->d_tw_sums, h->n_frames * row * sizeof(unsigned long long), hipMemcpyDeviceToDevice));
-            HIP_TRY(h, hipMemcpy(nc, h->d_tw_cnts, h->n_frames * row * sizeof(unsigned long long), hipMemcpyDeviceToDevice));
+            HIP_TRY(h, hipMemcpyAsync(ns, h->d_tw_sums, h->n_frames * row * sizeof(unsigned long long), hipMemcpyDeviceToDevice, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(nc, h->d_tw_cnts, h->n_frames * row * sizeof(unsigned long long), hipMemcpyDeviceToDevice, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
             HIP_TRY(h, hipFree(h->d_tw_sums));
             HIP_TRY(h, hipFree(h->d_tw_cnts));
         }
@@ -2785,8 +2790,8 @@ int gorder_hip_bind_accumulators(gorder_hip_handle *h, void *d_ptr, uint64_t n_u
         const int st = fold_replicas(h);
         if (st != GORDER_OK) return st;
     }
+    HIP_TRY(h, hipMemcpyAsync(d_ptr, h->d_acc, h->acc_words * sizeof(unsigned long long), hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    HIP_TRY(h, hipMemcpy(d_ptr, h->d_acc, h->acc_words * sizeof(unsigned long long), hipMemcpyDeviceToDevice));
     if (!h->acc_external) HIP_TRY(h, hipFree(h->d_acc));
     h->d_acc = (unsigned long long *)d_ptr;
     h->acc_external = true;

@@ -428,6 +428,34 @@ def _mean_ticks(s: int, n: int, min_samples: int = 1) -> float:
     return float(np.float32(q / 1e6))
 
 
+def estimate_error(sums: np.ndarray, counts: np.ndarray, n_blocks: int = 5) -> float:
+    """TimeWiseData::estimate_error (timewise.rs:191-231) on per-frame (tick sum, sample count) rows: blocks of
+    len // n_blocks frames (the remainder is dropped), per-block mean by the truncating i64 division, sample
+    standard deviation in f32 (crate `statistical`); NaN if a block has no samples."""
+    n = len(sums)
+    if n == 0 or n_blocks < 2 or n // n_blocks == 0:
+        return float("nan")
+    bs = n // n_blocks
+    o = []
+    for b in range(n_blocks):
+        s_ = int(np.asarray(sums[b * bs:(b + 1) * bs], dtype=np.int64).sum())
+        c_ = int(np.asarray(counts[b * bs:(b + 1) * bs], dtype=np.uint64).sum())
+        if c_ == 0:
+            return float("nan")
+        q = abs(s_) // c_
+        o.append(np.float32((-q if s_ < 0 else q) / 1e6))
+    o = np.array(o, dtype=np.float32)
+    mean = np.float32(0)
+    for x in o:
+        mean = np.float32(mean + x)
+    mean = np.float32(mean / np.float32(n_blocks))
+    var = np.float32(0)
+    for x in o:
+        d = np.float32(mean - x)
+        var = np.float32(var + np.float32(d * d))
+    return float(np.sqrt(np.float32(var / np.float32(n_blocks - 1)), dtype=np.float32))
+
+
 def round4(x: float) -> float:
     """RoundTo4 (presentation/mod.rs:496-504): (x as f64 * 10000).round() / 10000, half away from zero."""
     if x != x:
@@ -437,9 +465,13 @@ def round4(x: float) -> float:
     return float(r / 10000.0)
 
 
-def results_tree(res: Results, labels: Sequence[MolLabels], analysis: str, leaflets: bool, min_samples: int = 1) -> dict:
+def results_tree(res: Results, labels: Sequence[MolLabels], analysis: str, leaflets: bool, min_samples: int = 1,
+                 timewise=None, n_blocks: int = 5) -> dict:
     """Nested dict shaped like gorder's YAML output (aaresults.rs:47-61, cgresults.rs:202-217), values
-    rounded to 4 decimals; AA reports -S (presentation/mod.rs:618-625)."""
+    rounded to 4 decimals; AA reports -S (presentation/mod.rs:618-625).
+    timewise = (tw_sums, tw_counts) [frames][3][n_acc] switches to the `estimate_error` layout: every value
+    becomes {mean, error}; an aggregate's error comes from its members' per-frame rows added up
+    (TimeWiseData merge, timewise.rs:31-76)."""
     sign = -1.0 if analysis in ("aa", "ua") else 1.0
     which = ["total", "upper", "lower"] if leaflets else ["total"]
 
@@ -449,7 +481,14 @@ def results_tree(res: Results, labels: Sequence[MolLabels], analysis: str, leafl
             s = int(sum(int(res.sums[w, k]) for k in slots))
             n = int(sum(int(res.counts[w, k]) for k in slots))
             v = _mean_ticks(s, n, min_samples)
-            out[key] = round4(sign * v) if v == v else float("nan")
+            mean = round4(sign * v) if v == v else float("nan")
+            if timewise is None:
+                out[key] = mean
+            else:
+                ts = np.asarray(timewise[0])[:, w, slots].sum(axis=1)
+                tc = np.asarray(timewise[1])[:, w, slots].sum(axis=1)
+                e = estimate_error(ts, tc, n_blocks)
+                out[key] = {"mean": mean, "error": round4(e) if e == e else float("nan")}
         return out
 
     tree: Dict[str, object] = {}

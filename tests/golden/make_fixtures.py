@@ -68,7 +68,13 @@ if __name__ == "__main__":
               "aa_order_cuboid_patch.yaml", "aa_order_cylinder_x.yaml", "aa_order_sphere_center.yaml",
               "aa_order_cuboid_dynamic.yaml", "aa_order_cylinder_dynamic.yaml", "aa_order_sphere_dynamic.yaml",
               "aa_order_leaflets_dynamic.yaml", "cg_order_leaflets_dynamic.yaml", "ua_order_dynamic_normals.yaml",
-              "aa_leaflets_every1.yaml"):
+              "aa_leaflets_every1.yaml", "aa_order_error.yaml", "aa_order_error_leaflets.yaml",
+              "cg_order_error.yaml", "cg_order_error_leaflets.yaml"):
         src = os.path.join(REF, f)
         if os.path.exists(src):
             shutil.copy(src, os.path.join(HERE, "expected", f))
+    # the 12 united-atom ordermaps compared by tests_ua.rs:351-410 (made from ua.xtc)
+    os.makedirs(os.path.join(HERE, "expected", "ordermaps_ua"), exist_ok=True)
+    for f in sorted(os.listdir(os.path.join(REF, "ordermaps_ua"))):
+        if f.endswith("_full.dat"):
+            shutil.copy(os.path.join(REF, "ordermaps_ua", f), os.path.join(HERE, "expected", "ordermaps_ua", f))

@@ -93,3 +93,40 @@ def ua_setup(fx, leaflets=None, frequency=1, **kw):
         lf = {"method": leaflets, "membrane": allm, "heads": heads, "methyls": methyls, "frequency": frequency,
               "radius": 2.5}
     return st.build_tables_ua(s, sat, unsat, allm, leaflets=lf, **kw)
+
+
+def read_map(name, directory="ordermaps_ua"):
+    """An ordermap .dat of the reference (ordermap_*.dat: `x y value` lines, NaN for tiles with fewer than
+    min_samples samples) -> {(x, y): value}."""
+    out = {}
+    with open(os.path.join(GOLDEN, "expected", directory, name)) as f:
+        for line in f:
+            p = line.split()
+            if len(p) == 3 and p[0][0] in "0123456789-":
+                out[(p[0], p[1])] = float(p[2])
+    return out
+
+
+def map_of(res, slots, w, om, min_samples, sign=-1.0):
+    """Finalise one ordermap like the reference's writer: tiles x-major at span_min + k * bin, value = mean of
+    the aggregated slots by truncating i64 division, x sign, rounded to 4 decimals; NaN below min_samples."""
+    s = res.map_sums[w, slots].sum(axis=0)
+    c = res.map_counts[w, slots].sum(axis=0)
+    out = {}
+    for ix in range(s.shape[0]):
+        for iy in range(s.shape[1]):
+            key = (f"{om.span_x[0] + ix * om.bin[0]:.4f}", f"{om.span_y[0] + iy * om.bin[1]:.4f}")
+            v = st._mean_ticks(int(s[ix, iy]), int(c[ix, iy]), min_samples)
+            out[key] = st.round4(sign * v) if v == v else float("nan")
+    return out
+
+
+def compare_maps(got, want, tol=2e-4):
+    bad = []
+    if set(got) != set(want):
+        return [f"tile sets differ: {len(got)} vs {len(want)}"]
+    for k, w in want.items():
+        g = got[k]
+        if (g != g) != (w != w) or (w == w and abs(np.float32(g) - np.float32(w)) > tol):
+            bad.append(f"{k}: {g} vs {w}")
+    return bad

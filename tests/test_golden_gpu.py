@@ -190,3 +190,36 @@ def test_aa_leaflet_assignment_per_molecule(pcpepg, method):
         flags, frame = eng.leaflets()
         assert frame == f
         np.testing.assert_array_equal(flags, expected_leaflets(labels, f))
+
+
+# ---- error estimation -----------------------------------------------------------------------------------
+from test_golden_oracle import ERROR_CASES, error_setup   # noqa: E402
+
+
+@pytest.mark.parametrize("kind,lf,want", ERROR_CASES)
+def test_error_estimation(kind, lf, want, pcpepg, cg):
+    fx = pcpepg if kind == "aa" else cg
+    tables, labels, midx = error_setup(kind, lf, fx)
+    frames = fx.window()
+    eng, res, xyz, box, fi = gpu_run(tables, fx, midx, frames)
+    tw = eng.timewise(len(frames))
+    bad = st.compare_trees(st.results_tree(res, labels, kind, leaflets=lf, timewise=tw), expected(want))
+    assert not bad, bad[:10]
+    o, ref = oracle_run(tables, xyz, box, fi, oracle.TRIG_DIRECT)
+    ws, wc = o.timewise(len(frames))
+    np.testing.assert_array_equal(tw[0], ws)        # per-frame rows bit-exact
+    np.testing.assert_array_equal(tw[1], wc)
+
+
+# ---- ordermaps ---------------------------------------------------------------------------------------------
+from test_golden_oracle import check_ordermaps, ordermap_setup   # noqa: E402
+
+
+def test_ua_ordermaps(ua):
+    # tests_ua.rs:351-410: the 12 ordermaps of the reference's united-atom test, tile for tile
+    tables, labels, midx, om = ordermap_setup(ua)
+    frames = ua.window()
+    eng, res, xyz, box, fi = gpu_run(tables, ua, midx, frames)
+    assert check_ordermaps(res, labels, om) == 7
+    _, ref = oracle_run(tables, xyz, box, fi, oracle.TRIG_DIRECT)
+    np.testing.assert_array_equal(res.map_counts, ref.map_counts)

@@ -291,3 +291,82 @@ def test_aa_leaflet_assignment_per_molecule(pcpepg, method):
         flags, _, frame = eng.leaflets()
         assert frame == f
         np.testing.assert_array_equal(flags, expected_leaflets(labels, f))
+
+
+# ---- error estimation (timewise.rs:130-231; tests_aa.rs:2170-2280, tests_cg.rs:1367-1460) ------------
+ERROR_CASES = [("aa", False, "aa_order_error.yaml"), ("aa", True, "aa_order_error_leaflets.yaml"),
+               ("cg", False, "cg_order_error.yaml"), ("cg", True, "cg_order_error_leaflets.yaml")]
+
+
+def error_setup(kind, lf, fx):
+    setup = aa_setup if kind == "aa" else cg_setup
+    return setup(fx, leaflets=METHODS["global"] if lf else None, timewise=True)
+
+
+@pytest.mark.parametrize("kind,lf,want", ERROR_CASES)
+def test_error_estimation(kind, lf, want, pcpepg, cg):
+    """EstimateError::default(): 5 blocks over the per-frame partial sums.  Pins the timewise rows, the
+    block arithmetic and how aggregates (atoms, molecules, system) inherit their members' rows."""
+    fx = pcpepg if kind == "aa" else cg
+    tables, labels, midx = error_setup(kind, lf, fx)
+    frames = fx.window()
+    eng = oracle.OracleEngine(tables, trig=oracle.TRIG_LIBM, n_threads=3)
+    eng.submit(master_frames(fx, midx, frames), fx.boxes[frames], frames)
+    res = eng.finish()
+    tw = eng.timewise(len(frames))
+    tree = st.results_tree(res, labels, kind, leaflets=lf, timewise=tw)
+    bad = st.compare_trees(tree, expected(want))
+    assert not bad, bad[:10]
+
+
+# ---- ordermaps (ordermap.rs:40-113; tests_ua.rs:351-410) ------------------------------------------------
+# (The all-atom ordermap goldens, tests/files/ordermaps/, were made from tests/files/pcpepg.xtc, which the
+# reference checkout does not contain; with bins of 0.1 nm and bond midpoints that are multiples of 0.0005 nm
+# 5 % of the samples sit exactly on a tile edge, and the split/pcpepg*.xtc frames do not reproduce those maps
+# tile for tile whatever the tie rule.  The united-atom maps come from tests/files/ua.xtc, which IS there.)
+from gorder_amd.abi import OrderMap   # noqa: E402
+from golden_util import compare_maps, map_of, read_map   # noqa: E402
+
+
+def ordermap_setup(fx):
+    """`resname POPC and name C50 C20 C13` saturated, `resname POPC and name C24` unsaturated, bin [0.5, 2.0],
+    span Auto = (0, box of the structure), xy plane, min_samples 5."""
+    s = fx.structure
+    popc = np.array(s.resnames) == "POPC"
+    sat = popc & fx.name_in("C50", "C20", "C13")
+    unsat = popc & fx.name_in("C24")
+    bx = fx.boxes[0]            # ua.tpr's box = the box of the trajectory's first frame (6.28779 nm)
+    om = OrderMap(enabled=True, plane=0, span_x=(0.0, float(bx[0, 0])), span_y=(0.0, float(bx[1, 1])), bin=(0.5, 2.0))
+    tables, labels, midx = st.build_tables_ua(s, sat, unsat, np.ones(s.n_atoms, dtype=bool), ordermap=om)
+    return tables, labels, midx, om
+
+
+def check_ordermaps(res, labels, om):
+    """Every map the reference's test compares: per virtual bond, per carbon (its bonds aggregated) and the
+    average over all bonds."""
+    (ml,) = labels
+    assert ml.name == "POPC"
+    slot, allslots, n_maps = ml.slot0, [], 0
+    for c in ml.carbons:
+        slots = list(range(slot, slot + c.n_h))
+        slot += c.n_h
+        allslots += slots
+        bad = compare_maps(map_of(res, slots, 0, om, 5), read_map(f"ordermap_POPC-{c.name}-{c.rel}_full.dat"))
+        assert not bad, (c.name, bad[:5])
+        for k, sl in enumerate(slots):
+            bad = compare_maps(map_of(res, [sl], 0, om, 5), read_map(f"ordermap_POPC-{c.name}-{c.rel}--POPC-H{k + 1}-{c.rel}_full.dat"))
+            assert not bad, (c.name, k, bad[:5])
+            n_maps += 1
+    bad = compare_maps(map_of(res, allslots, 0, om, 5), read_map("ordermap_average_full.dat"))
+    assert not bad, bad[:5]
+    return n_maps
+
+
+def test_ua_ordermaps(ua):
+    tables, labels, midx, om = ordermap_setup(ua)
+    frames = ua.window()
+    eng = oracle.OracleEngine(tables, trig=oracle.TRIG_LIBM, n_threads=3)
+    eng.submit(master_frames(ua, midx, frames), ua.boxes[frames], frames)
+    res = eng.finish()
+    assert res.map_sums.shape[2:] == (14, 4)          # GridMap: round(6.288 / 0.5) + 1, round(6.288 / 2) + 1
+    assert check_ordermaps(res, labels, om) == 7
