@@ -352,3 +352,21 @@ def test_full_size_properties(built):
     # order parameters are physical
     s = full.order()[0]
     assert np.all(s >= -0.5 - 1e-6) and np.all(s <= 1.0 + 1e-6)
+
+
+@pytest.mark.parametrize("flags", [0, abi.FLAG_TRIG_ACOS_COS])
+def test_reference_known_answer_on_the_device(built, flags):
+    """The reference's own unit test of the sample arithmetic (test_calc_sch, mod.rs:94-105): atoms at
+    (1.7, 2.1, 9.7) and (1.9, 2.4, 0.8) in a 10-nm box, normal z -> the bond crosses the box face, the
+    minimum-image vector is (0.2, 0.3, 1.1) and S = 0.8544775.  One molecule, one bond, through the C ABI."""
+    bonds = np.array([[[0, 1]]], dtype=np.uint32)
+    tables = Tables(n_atoms=2, molecule_types=[MolType(n_molecules=1, bonds=bonds)], flags=flags)
+    xyz = np.array([[[1.7, 2.1, 9.7], [1.9, 2.4, 0.8]]], dtype=np.float32)
+    box = np.zeros((1, 3, 3), dtype=np.float32)
+    box[0, 0, 0] = box[0, 1, 1] = box[0, 2, 2] = 10.0
+    eng = HipEngine(tables)
+    eng.submit_host(xyz, box, np.arange(1))
+    res = eng.finish()
+    assert res.counts[0, 0] == 1
+    assert abs(int(res.sums[0, 0]) - 854478) <= 1          # round(0.8544775 * 1e6), within one tick
+    np.testing.assert_allclose(res.order()[0, 0], 0.8544775, atol=1.5e-6)

@@ -1,0 +1,20 @@
+#!/bin/bash
+# usage (on the GPU box): tools/bench_all.sh <outfile>  — one bench.py line per workload of BASELINE.json's configs
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=${1:-$ROOT/gpurun_out/bench_all.jsonl}
+: > $OUT
+run() { python3 $ROOT/bench.py --no-cpu-baseline --workload $1 --frames $2 --steps $3 --warmup $4 | grep '^{' >> $OUT; }
+run aa256 10000 100 40
+run aa256-leaflets 4000 50 20
+run cg3k 4000 50 20
+run cg3k-local 512 10 3
+run ua256 3000 50 20
+run ua256-maps 3000 30 10
+run cg1m 500 20 5
+python3 - <<PY
+import json
+for line in open("$OUT"):
+    d = json.loads(line)
+    r = d["roofline"]
+    print(f'{d["config"]["workload"][:70]:70s} {d["value"]/1e6:9.3f} Mframes/s  kernel {r["avg_launch_ms"]:8.3f} ms/launch  {r["frac"]*100:5.1f}% HBM')
+PY
