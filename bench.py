@@ -149,6 +149,13 @@ def main():
     eng.flush()   # fold the kernel's accumulator replicas into the packed block (stream-ordered, tiny)
     if world > 1:
         dist.all_reduce(acc, op=dist.ReduceOp.SUM)   # RCCL over xGMI: the only collective of the path
+        if system.tables.ordermap.enabled:           # ... plus the ordermap grids when they are on (Map::add)
+            n_map = 3 * eng.tables.n_acc * int(np.prod(eng.ordermap_dims()))
+            ms = torch.zeros(n_map, dtype=torch.int64, device=f"cuda:{local_rank}")
+            mc = torch.zeros_like(ms)
+            eng.export_maps(ms, mc)
+            dist.all_reduce(ms, op=dist.ReduceOp.SUM)
+            dist.all_reduce(mc, op=dist.ReduceOp.SUM)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:

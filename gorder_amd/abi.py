@@ -281,7 +281,7 @@ _EXPORTS = [
     "gorder_hip_set_stream", "gorder_hip_submit_device", "gorder_hip_submit_host",
     "gorder_hip_prime_leaflets", "gorder_hip_set_manual_leaflets", "gorder_hip_synchronize",
     "gorder_hip_finish", "gorder_hip_timewise", "gorder_hip_leaflets", "gorder_hip_leaflet_distances",
-    "gorder_hip_normals",
+    "gorder_hip_normals", "gorder_hip_export_maps",
     "gorder_hip_accumulators_device", "gorder_hip_bind_accumulators", "gorder_hip_last_error_index",
     "gorder_hip_last_error_message", "gorder_hip_strerror", "gorder_hip_kernel_time", "gorder_hip_plan",
     "gorder_hip_plan_tables",
@@ -335,6 +335,7 @@ def load_library() -> C.CDLL:
     lib.gorder_hip_leaflets.argtypes = [vp, vp, C.POINTER(u64)]
     lib.gorder_hip_leaflet_distances.argtypes = [vp, vp]
     lib.gorder_hip_normals.argtypes = [vp, vp, vp]
+    lib.gorder_hip_export_maps.argtypes = [vp, vp, vp, u64]
     lib.gorder_hip_accumulators_device.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
     lib.gorder_hip_bind_accumulators.argtypes = [vp, vp, u64]
     lib.gorder_hip_last_error_index.argtypes = [vp]
@@ -479,6 +480,12 @@ class HipEngine:
     def synchronize(self):
         self._check(self.lib.gorder_hip_synchronize(self._h))
 
+    def ordermap_dims(self):
+        """(nx, ny) tiles of every ordermap; (0, 0) when ordermaps are off."""
+        nx, ny = C.c_uint32(), C.c_uint32()
+        nt = self.lib.gorder_hip_ordermap_dims(self._h, C.byref(nx), C.byref(ny))
+        return (int(nx.value), int(ny.value)) if nt else (0, 0)
+
     def finish(self) -> Results:
         n = self.n_acc
         sums = np.zeros((3, n), dtype=np.int64)
@@ -537,6 +544,15 @@ class HipEngine:
         assert tensor.is_cuda and tensor.is_contiguous() and tensor.element_size() == 8
         self._keep.append(tensor)
         self._check(self.lib.gorder_hip_bind_accumulators(self._h, C.c_void_p(tensor.data_ptr()), tensor.numel()))
+
+    def export_maps(self, sums, counts):
+        """Copy the ordermaps (i64 sums, u64 counts, [3][n_acc][nx*ny]) into two caller-owned torch.int64 CUDA
+        tensors so that torch.distributed can all-reduce them like the accumulator block."""
+        for t in (sums, counts):
+            assert t.is_cuda and t.is_contiguous() and t.element_size() == 8
+        assert sums.numel() == counts.numel()
+        self._check(self.lib.gorder_hip_export_maps(self._h, C.c_void_p(sums.data_ptr()), C.c_void_p(counts.data_ptr()),
+                                                     sums.numel()))
 
     def kernel_time(self, reset: bool = False):
         ms, n = C.c_double(), C.c_uint64()

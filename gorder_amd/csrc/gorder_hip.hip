@@ -2783,6 +2783,19 @@ int gorder_hip_accumulators_device(gorder_hip_handle *h, void **d_ptr, uint64_t 
     return GORDER_OK;
 }
 
+int gorder_hip_export_maps(gorder_hip_handle *h, void *d_sums, void *d_counts, uint64_t n_u64) {
+    if (!h || !h->extra.maps || !d_sums || !d_counts) return GORDER_ERR_INVALID_ARGUMENT;
+    const uint64_t n = 3ull * h->plan.n_acc * h->map_nx * h->map_ny;
+    if (n_u64 < n) return GORDER_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int st = fold_maps(h);
+    if (st != GORDER_OK) return st;
+    HIP_TRY(h, hipMemcpyAsync(d_sums, h->d_map_sums, n * sizeof(unsigned long long), hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(d_counts, h->d_map_cnts, n * sizeof(unsigned long long), hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return check_device_error(h);
+}
+
 int gorder_hip_bind_accumulators(gorder_hip_handle *h, void *d_ptr, uint64_t n_u64) {
     if (!h || !d_ptr || n_u64 < h->acc_words || ((uintptr_t)d_ptr & 7u)) return GORDER_ERR_INVALID_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->device));

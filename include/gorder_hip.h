@@ -253,6 +253,12 @@ int gorder_hip_normals(gorder_hip_handle *h, float *normals, uint32_t *n_points)
  * SystemTopology::reduce (topology/mod.rs:256-272). */
 int gorder_hip_accumulators_device(gorder_hip_handle *h, void **d_ptr, uint64_t *n_u64);
 
+/* Ordermaps for the same reduction: copies the folded maps, i64 sums and u64 counts laid out
+ * [3][n_acc][nx*ny] (n_u64 = 3 * n_acc * nx * ny words each, see gorder_hip_ordermap_dims), into caller-owned
+ * device buffers (e.g. two torch.int64 tensors) that the host all-reduces like the accumulator block
+ * (Map::add, ordermap.rs:116-138).  Stream-ordered after everything submitted so far; synchronises. */
+int gorder_hip_export_maps(gorder_hip_handle *h, void *d_sums, void *d_counts, uint64_t n_u64);
+
 /* Make the handle accumulate into caller-owned device memory (>= n_u64 words, 8-byte aligned; e.g.
  * a torch.int64 tensor that the host then hands to torch.distributed.all_reduce = RCCL).  The
  * current contents of the handle's accumulators are copied over. */

@@ -243,3 +243,32 @@ def test_dynamic_normals_not_enough_points(built):
     eng = HipEngine(system.tables)
     eng.submit_host(xyz, system.box9(3), np.arange(3))
     assert eng.finish().counts.sum() == 0
+
+
+def test_ordermaps_reduce_across_ranks(built):
+    """Multi-GPU form of Map::add (ordermap.rs:116-138): each rank exports its maps into tensors it owns, the
+    host sums them (here: two handles on one GPU stand in for two ranks; bench.py does it with RCCL) — the
+    result is bit-identical to one handle that saw every frame."""
+    import torch
+    system = synthetic.ua_membrane(30, leaflets=LEAFLETS_GLOBAL)
+    bx = system.box
+    system.tables.ordermap = OrderMap(enabled=True, plane=0, span_x=(0.0, float(bx[0])), span_y=(0.0, float(bx[1])),
+                                      bin=(0.9, 1.1))
+    n = 14
+    xyz, box9 = system.frames(n, seed=21), system.box9(n)
+    whole = HipEngine(system.tables)
+    whole.submit_host(xyz, box9, np.arange(n))
+    want = whole.finish()
+    parts = []
+    for lo, hi in ((0, 6), (6, n)):
+        eng = HipEngine(system.tables)
+        eng.submit_host(xyz[lo:hi], box9[lo:hi], np.arange(lo, hi))
+        s = torch.zeros(want.map_sums.size, dtype=torch.int64, device="cuda")
+        c = torch.zeros_like(s)
+        eng.export_maps(s, c)
+        parts.append((s, c, eng))
+    s = (parts[0][0] + parts[1][0]).cpu().numpy().reshape(want.map_sums.shape)
+    c = (parts[0][1] + parts[1][1]).cpu().numpy().reshape(want.map_counts.shape)
+    np.testing.assert_array_equal(s, want.map_sums)
+    np.testing.assert_array_equal(c.astype(np.uint64), want.map_counts)
+    assert c.sum() > 0
