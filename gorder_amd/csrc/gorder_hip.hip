@@ -113,6 +113,7 @@ __device__ __forceinline__ void map_unpack(unsigned long long w, long long &sum,
     sum = (long long)(w << 22) >> 22;                      // sign-extend the low 42 bits
     cnt = (w - (unsigned long long)sum) >> 42;
 }
+constexpr unsigned long long kMapNoSample = ~0ull;   // staged entry of a lane without a sample in the map
 // packed [planes][n] -> sums/cnts [3][n] (total, upper, lower); planes = 2 with leaflets (upper, lower), else 1
 __global__ void k_fold_maps(unsigned long long *__restrict__ packed, unsigned long long *__restrict__ sums,
                             unsigned long long *__restrict__ cnts, size_t n, int leaflets) {
@@ -556,6 +557,8 @@ struct ExtraArgs {
     float x0, y0, binx, biny;
     uint32_t nx, ny;
     unsigned long long *map_packed;  // [leaflets ? 2 : 1][n_acc][nx*ny] packed (count << 42) + sum, see k_fold_maps
+    unsigned long long *map_rec;     // united-atom staging (k_map_accumulate): [tile][frame - rec_frame0][3][kBlock] samples or null
+    uint32_t rec_frame0, rec_frames;
     const float4 *dyn;               // dynamic membrane normals [n_frames][n_mol_total] (nx, ny, nz, cloud size) or null
     int tw;                          // timewise on
     unsigned long long *tw_sums;     // [rows][3][n_acc]
@@ -602,7 +605,8 @@ __device__ __forceinline__ int grid_index(float x, float lo, float bin, uint32_t
 // BondLike::add_order for the scatter targets (bond.rs:184-215): maps and the per-frame LDS partials
 __device__ __forceinline__ void extras_add(const FrameArgs &a, const ExtraArgs &e, uint32_t gslot, uint32_t lslot,
                                            int tick, float px, float py, float pz, int leaflet /* -1 none */,
-                                           int *l_tw, uint32_t *l_twn, uint32_t lstride) {
+                                           int *l_tw, uint32_t *l_twn, uint32_t lstride,
+                                           unsigned long long *rec = nullptr) {
     if (e.maps) {
         float x, y;
         if (e.plane == 0) { x = px; y = py; }
@@ -615,8 +619,12 @@ __device__ __forceinline__ void extras_add(const FrameArgs &a, const ExtraArgs &
             // unpacks.  Scattered 64-bit atomics run at ~24 G/s on gfx950 whatever the scope or table size
             // (tools/microbench/atomic_scatter.hip), so their number is what counts.
             const size_t nt = (size_t)e.nx * e.ny, t = (size_t)ix * e.ny + (size_t)iy;
-            const size_t w = leaflet > 0 ? a.n_acc : 0;
-            atomicAdd(&e.map_packed[(w + gslot) * nt + t], kMapOne + (unsigned long long)(long long)tick);
+            if (rec) {   // staged: (plane * tiles + tile) << 32 | tick, added to the map by k_map_accumulate
+                *rec = ((unsigned long long)((leaflet > 0 ? nt : 0) + t) << 32) | (unsigned long long)(uint32_t)tick;
+            } else {
+                const size_t w = leaflet > 0 ? a.n_acc : 0;
+                atomicAdd(&e.map_packed[(w + gslot) * nt + t], kMapOne + (unsigned long long)(long long)tick);
+            }
         }
     }
     if (e.tw) {
@@ -950,6 +958,7 @@ __global__ __launch_bounds__(kBlock) void k_ua_extras(FrameArgs a_in, ExtraArgs 
                 nr2sq = (n.x * n.x + n.y * n.y) + n.z * n.z;
                 nr2 = __builtin_sqrtf(nr2sq);
             }
+            unsigned long long recs[3] = {kMapNoSample, kMapNoSample, kMapNoSample};
             auto sample = [&](const int k, const V3 v, const V3 b) {
                 if (k >= nh) return;
                 const float sch = gm_calc_sch<ACOS_COS>(v.x, v.y, v.z, nrx, nry, nrz, nr2, nr2sq);
@@ -962,11 +971,19 @@ __global__ __launch_bounds__(kBlock) void k_ua_extras(FrameArgs a_in, ExtraArgs 
                 n_tot[k] += 1;
                 if (leaflet == 0) { s_up[k] += tick; n_up[k] += 1; }
                 if (EXTRAS)
-                    extras_add(a, e, gslot0 + (uint32_t)k, it.lslot0 + (uint32_t)k, tick, b.x, b.y, b.z, leaflet, l_tw, l_twn, LS);
+                    extras_add(a, e, gslot0 + (uint32_t)k, it.lslot0 + (uint32_t)k, tick, b.x, b.y, b.z, leaflet, l_tw, l_twn, LS,
+                               e.map_rec ? &recs[k] : nullptr);
             };
             sample(0, ub.v0, ub.b0);
             sample(1, ub.v1, ub.b1);
             sample(2, ub.v2, ub.b2);
+            if (EXTRAS && e.map_rec) {   // every lane of the tile writes its three entries: coalesced rows of kBlock words
+                unsigned long long *row = e.map_rec + (((size_t)tile_id * e.rec_frames + (f - e.rec_frame0)) * 3u) * kBlock + tid;
+                row[0] = recs[0]; row[kBlock] = recs[1]; row[2u * kBlock] = recs[2];
+            }
+        } else if (EXTRAS && e.map_rec) {
+            unsigned long long *row = e.map_rec + (((size_t)tile_id * e.rec_frames + (f - e.rec_frame0)) * 3u) * kBlock + tid;
+            row[0] = kMapNoSample; row[kBlock] = kMapNoSample; row[2u * kBlock] = kMapNoSample;
         }
         if (EXTRAS && e.tw) {
             __syncthreads();
@@ -998,6 +1015,45 @@ __global__ __launch_bounds__(kBlock) void k_ua_extras(FrameArgs a_in, ExtraArgs 
             atomicAdd(&accp[a.n_acc + slot], l_s[LS + ls]);
             atomicAdd(&accp[3u * a.n_acc + slot], (unsigned long long)l_n[LS + ls]);
         }
+    }
+}
+
+// ---- ordermaps of the united-atom path, second step -----------------------------------------------
+// k_ua_extras stages every sample as (plane-tile << 32 | tick) in tile order (coalesced rows); here a block
+// owns ONE accumulator slot for a range of frames: it gathers the slot's samples (runs of consecutive lanes,
+// gorder::MapRun), adds them into a packed map held in LDS (ds_add_u64) and flushes the tiles it touched
+// into the global packed map with one atomic each.  Scattered global atomics run at ~24 G/s on this chip
+// whatever one does (tools/microbench/atomic_scatter.hip); this way their number drops from one per sample to
+// at most one per (slot, chunk, tile).
+__global__ __launch_bounds__(1024) void k_map_accumulate(const unsigned long long *__restrict__ rec,
+                                                         const gorder::MapRun *__restrict__ runs,
+                                                         const uint32_t *__restrict__ run_begin, uint32_t n_slots,
+                                                         uint32_t rec_frames, uint32_t frames_per_chunk,
+                                                         uint32_t n_words /* planes * tiles */, uint32_t n_tiles_map,
+                                                         unsigned long long *__restrict__ map_packed, uint32_t n_acc) {
+    extern __shared__ unsigned long long l_map[];
+    const uint32_t slot = blockIdx.x % n_slots, chunk = blockIdx.x / n_slots;
+    const uint32_t r0 = run_begin[slot], r1 = run_begin[slot + 1];
+    if (r0 == r1) return;                               // not a united-atom slot
+    const uint32_t f0 = chunk * frames_per_chunk, f1 = min(rec_frames, f0 + frames_per_chunk);
+    for (uint32_t w = threadIdx.x; w < n_words; w += blockDim.x) l_map[w] = 0ull;
+    __syncthreads();
+    for (uint32_t r = r0; r < r1; r++) {
+        const gorder::MapRun run = runs[r];
+        const uint32_t total = (f1 - f0) * run.n;
+        for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) {
+            const uint32_t f = f0 + i / run.n, j = i % run.n;
+            const unsigned long long v = rec[(((size_t)run.tile * rec_frames + f) * 3u + run.k) * kBlock + run.tid0 + j];
+            if (v != kMapNoSample)
+                atomicAdd(&l_map[(uint32_t)(v >> 32)], kMapOne + (unsigned long long)(long long)(int)(uint32_t)v);
+        }
+    }
+    __syncthreads();
+    for (uint32_t w = threadIdx.x; w < n_words; w += blockDim.x) {
+        const unsigned long long v = l_map[w];
+        if (!v) continue;
+        const uint32_t plane = w / n_tiles_map, t = w % n_tiles_map;
+        atomicAdd(&map_packed[((size_t)plane * n_acc + slot) * n_tiles_map + t], v);
     }
 }
 
@@ -1827,6 +1883,11 @@ struct gorder_hip_handle {
     uint32_t map_nx = 0, map_ny = 0;
     unsigned long long *d_map_sums = nullptr, *d_map_cnts = nullptr;   // [3][n_acc][nx*ny], folded
     unsigned long long *d_map_packed = nullptr;   // [1 or 2][n_acc][nx*ny], what the kernels add into
+    unsigned long long *d_map_rec = nullptr;      // united-atom staging for k_map_accumulate (see ExtraArgs::map_rec)
+    size_t map_rec_cap = 0;
+    gorder::MapRun *d_ua_runs = nullptr;
+    uint32_t *d_ua_run_begin = nullptr;
+    bool map_staged = false;       // the packed map of one slot fits LDS: stage + accumulate instead of one atomic per sample
     uint64_t map_pending = 0;      // upper bound of the samples one packed word may hold since the last fold
     uint64_t map_fold_limit = kMapFoldLimit;   // GORDER_HIP_MAP_FOLD_LIMIT lowers it (tests)
     uint32_t map_max_mol = 1;      // most molecules of one type = most samples per tile and frame
@@ -2103,7 +2164,15 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
         e.dyn = h->dyn ? h->d_dyn_normals : nullptr;
         const bool ac = (h->tables.flags & GORDER_FLAG_TRIG_ACOS_COS) != 0;
         // with ordermaps the frames go in sub-ranges short enough for the packed map words (k_fold_maps)
-        const uint32_t sub = e.maps ? (uint32_t)std::max<uint64_t>(1, (h->map_fold_limit - 1) / h->map_max_mol) : a.n_frames;
+        uint32_t sub = e.maps ? (uint32_t)std::max<uint64_t>(1, (h->map_fold_limit - 1) / h->map_max_mol) : a.n_frames;
+        const bool staged = e.maps && h->map_staged && !p.ua_tiles.empty();
+        const size_t rec_per_frame = p.ua_tiles.size() * 3u * kBlock;     // staged words per frame
+        if (staged) {   // at most 1 GiB of staging per sub-range
+            sub = std::min<uint32_t>(sub, (uint32_t)std::max<size_t>(1, ((size_t)1 << 27) / rec_per_frame));
+            sub = std::min(sub, a.n_frames);
+            const int st2 = ensure(h, &h->d_map_rec, &h->map_rec_cap, rec_per_frame * sub);
+            if (st2 != GORDER_OK) return st2;
+        }
         for (uint32_t lo = 0; lo < a.n_frames; lo += sub) {
             const uint32_t hi = std::min(a.n_frames, lo + sub), nf = hi - lo;
             if (e.maps) {
@@ -2125,6 +2194,9 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
                 b.frame0 = lo;
                 b.n_frames = hi;
                 b.frames_per_chunk = fpc;
+                e.map_rec = (pass == 1 && staged) ? h->d_map_rec : nullptr;
+                e.rec_frame0 = lo;
+                e.rec_frames = nf;
                 const dim3 g(nt * n_chunks), blk(kBlock);
                 if (pass == 0) {
                     if (ac) hipLaunchKernelGGL(k_bonds_extras<true>, g, blk, 0, h->stream, b, e, b.xyz, b.box9, b.aflags,
@@ -2138,6 +2210,18 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
                     if (extras) { if (ac) GORDER_LAUNCH_UA(true, true); else GORDER_LAUNCH_UA(false, true); }
                     else { if (ac) GORDER_LAUNCH_UA(true, false); else GORDER_LAUNCH_UA(false, false); }
 #undef GORDER_LAUNCH_UA
+                    if (staged) {   // second step: slot-major accumulation of the staged samples in LDS
+                        const uint32_t planes = h->tables.leaflets.method != GORDER_LEAFLETS_NONE ? 2u : 1u;
+                        const uint32_t ntm = h->map_nx * h->map_ny, n_words = planes * ntm;
+                        // enough blocks for ~2 per CU; a block flushes <= n_words atomics, so keep its chunk long
+                        uint32_t mchunks = std::max(1u, 512u / std::max(1u, p.n_acc));
+                        mchunks = std::min(mchunks, std::max(1u, nf / 16u));
+                        const uint32_t mfpc = (nf + mchunks - 1) / mchunks;
+                        mchunks = (nf + mfpc - 1) / mfpc;
+                        hipLaunchKernelGGL(k_map_accumulate, dim3(p.n_acc * mchunks), dim3(1024),
+                                           n_words * sizeof(unsigned long long), h->stream, h->d_map_rec, h->d_ua_runs,
+                                           h->d_ua_run_begin, p.n_acc, nf, mfpc, n_words, ntm, h->d_map_packed, p.n_acc);
+                    }
                 }
                 HIP_TRY(h, hipGetLastError());
             }
@@ -2266,6 +2350,15 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
             HIP_TRY(h, hipMemset(h->d_map_packed, 0, npk * sizeof(unsigned long long)));
             for (uint32_t m = 0; m < t->n_molecule_types; m++)
                 h->map_max_mol = std::max(h->map_max_mol, t->molecule_types[m].n_molecules);
+            // united atoms: stage + accumulate in LDS when one slot's packed map (x2 with leaflets) fits
+            const size_t lds_bytes = npk / p.n_acc * sizeof(unsigned long long);
+            if (!p.ua_tiles.empty() && lds_bytes <= 150u * 1024u && !env_flag("GORDER_HIP_MAP_DIRECT")) {
+                if ((st = upload(h, &h->d_ua_runs, p.ua_runs)) != GORDER_OK) return st;
+                if ((st = upload(h, &h->d_ua_run_begin, p.ua_run_begin)) != GORDER_OK) return st;
+                HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_map_accumulate),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                h->map_staged = true;
+            }
             e.maps = 1; e.plane = om.plane; e.x0 = om.span_x[0]; e.y0 = om.span_y[0];
             e.binx = om.bin[0]; e.biny = om.bin[1]; e.nx = h->map_nx; e.ny = h->map_ny;
             e.map_packed = h->d_map_packed;
@@ -2434,6 +2527,7 @@ void gorder_hip_destroy(gorder_hip_handle *h) {
     (void)hipFree(h->d_ua_tiles); (void)hipFree(h->d_ua_items); (void)hipFree(h->d_ua_tile_slots);
     (void)hipFree(h->d_map_sums); (void)hipFree(h->d_map_cnts); (void)hipFree(h->d_map_packed); (void)hipFree(h->d_tw_sums); (void)hipFree(h->d_tw_cnts);
     (void)hipFree(h->d_geom_group); (void)hipFree(h->d_shapes);
+    (void)hipFree(h->d_map_rec); (void)hipFree(h->d_ua_runs); (void)hipFree(h->d_ua_run_begin);
     (void)hipFree(h->d_dyn_cloud); (void)hipFree(h->d_dyn_heads); (void)hipFree(h->d_dyn_cell_of); (void)hipFree(h->d_dyn_count);
     (void)hipFree(h->d_dyn_rec); (void)hipFree(h->d_dyn_rsn); (void)hipFree(h->d_dyn_normals);
     if (!h->acc_external) (void)hipFree(h->d_acc);

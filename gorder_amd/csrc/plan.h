@@ -11,6 +11,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <utility>
 #include <vector>
 
 #include "../../include/gorder_hip.h"
@@ -44,6 +45,10 @@ struct UaItem {          // one united-atom carbon instance (uaorder.rs:911-915,
     uint32_t mol;
 };
 
+struct MapRun {          // `n` consecutive threads of a united-atom tile (from tid0) are the molecules of ONE slot:
+    uint32_t tile, tid0, n, k;   // their hydrogen k.  Lets k_map_accumulate read a slot's staged samples in runs.
+};
+
 struct Plan {
     uint32_t n_atoms = 0, n_acc = 0, n_mol_total = 0;
     uint32_t max_window = 0;
@@ -56,6 +61,8 @@ struct Plan {
     std::vector<Tile> ua_tiles;
     std::vector<UaItem> ua_items;
     std::vector<uint32_t> ua_tile_slots;
+    std::vector<MapRun> ua_runs;            // grouped by accumulator slot:
+    std::vector<uint32_t> ua_run_begin;     // [n_acc + 1] (CSR)
     std::vector<uint32_t> mol0;    // first global molecule id per molecule type
     std::vector<uint32_t> slot0;   // first accumulator slot per molecule type
 };
@@ -117,6 +124,7 @@ inline int build_plan(const gorder_tables_t &t, bool force_direct, Plan &p) {
             return uhi(x) < uhi(y);
         });
         size_t q = 0;
+        std::vector<std::pair<uint32_t, MapRun>> run_of_slot;
         while (q < ua_samples.size()) {
             const UaSample &first = ua_samples[q];
             if (uhi(first) - ulo(first) + 1 > kMaxWindow) return GORDER_ERR_INVALID_ARGUMENT;
@@ -151,12 +159,29 @@ inline int build_plan(const gorder_tables_t &t, bool force_direct, Plan &p) {
             }
             tile.n_window = top - tile.atom0 + 1;
             tile.n_slots = (uint32_t)slots.size();
-            // carbons of one kind next to each other: the lanes of a wave then run the same construction
-            std::stable_sort(p.ua_items.begin() + tile.item0, p.ua_items.end(),
-                             [](const UaItem &x, const UaItem &y) { return x.kind < y.kind; });
+            // carbons of one kind next to each other (the lanes of a wave then run the same construction), and
+            // within a kind the molecules of one slot next to each other (the staged ordermap samples of a slot
+            // are then contiguous runs, see MapRun)
+            std::stable_sort(p.ua_items.begin() + tile.item0, p.ua_items.end(), [](const UaItem &x, const UaItem &y) {
+                return x.kind != y.kind ? x.kind < y.kind : x.lslot0 < y.lslot0;
+            });
+            const uint32_t tile_id = (uint32_t)p.ua_tiles.size();
+            for (uint32_t i = 0; i < tile.n_items;) {
+                const UaItem &it = p.ua_items[tile.item0 + i];
+                uint32_t n = 1;
+                while (i + n < tile.n_items && p.ua_items[tile.item0 + i + n].lslot0 == it.lslot0) n++;
+                const uint32_t nh = it.kind == GORDER_UA_CH3 ? 3 : it.kind == GORDER_UA_CH2 ? 2 : 1;
+                for (uint32_t k = 0; k < nh; k++) run_of_slot.push_back({slots[it.lslot0 + k], MapRun{tile_id, i, n, k}});
+                i += n;
+            }
             p.ua_tile_slots.insert(p.ua_tile_slots.end(), slots.begin(), slots.end());
             p.ua_tiles.push_back(tile);
         }
+        std::stable_sort(run_of_slot.begin(), run_of_slot.end(),
+                         [](const std::pair<uint32_t, MapRun> &x, const std::pair<uint32_t, MapRun> &y) { return x.first < y.first; });
+        p.ua_run_begin.assign((size_t)p.n_acc + 1, 0);
+        for (const auto &r : run_of_slot) { p.ua_run_begin[r.first + 1]++; p.ua_runs.push_back(r.second); }
+        for (uint32_t sl = 0; sl < p.n_acc; sl++) p.ua_run_begin[sl + 1] += p.ua_run_begin[sl];
     }
 
     auto lo = [](const Sample &s) { return std::min(s.i, s.j); };

@@ -272,3 +272,31 @@ def test_ordermaps_reduce_across_ranks(built):
     np.testing.assert_array_equal(s, want.map_sums)
     np.testing.assert_array_equal(c.astype(np.uint64), want.map_counts)
     assert c.sum() > 0
+
+
+@pytest.mark.parametrize("direct", [False, True])
+@pytest.mark.parametrize("leaflets", [LEAFLETS_NONE, LEAFLETS_GLOBAL])
+def test_united_atom_ordermaps_staged_and_direct(built, monkeypatch, leaflets, direct):
+    """United-atom ordermaps go through a staging buffer + slot-major LDS accumulation (k_map_accumulate) by
+    default, through one atomic per sample with GORDER_HIP_MAP_DIRECT=1; both must give the oracle's maps, also
+    when the frames are cut into sub-ranges of 2 (fold limit) that reuse the staging buffer."""
+    if direct:
+        monkeypatch.setenv("GORDER_HIP_MAP_DIRECT", "1")
+    monkeypatch.setenv("GORDER_HIP_MAP_FOLD_LIMIT", "100")          # 40 molecules -> sub-ranges of 2 frames
+    system = synthetic.ua_membrane(40, leaflets=leaflets)
+    bx = system.box
+    system.tables.ordermap = OrderMap(enabled=True, plane=0, span_x=(0.0, float(bx[0])), span_y=(0.0, float(bx[1])),
+                                      bin=(1.5, 1.5))
+    n = 11
+    xyz = system.frames(n, seed=31)
+    eng, o, got, want = both(system, xyz, system.box9(n), batches=2)
+    np.testing.assert_array_equal(got.map_counts, want.map_counts)
+    ch1u = np.zeros(got.map_sums.shape[1], dtype=bool)              # unsaturated CH: device sincosf vs host libm
+    slot = 0
+    for kind, _ in system.tables.molecule_types[0].ua_atoms:
+        nh = abi.UA_N_H[int(kind)]
+        ch1u[slot:slot + nh] = int(kind) == abi.UA_CH1_UNSAT
+        slot += nh
+    np.testing.assert_array_equal(got.map_sums[:, ~ch1u], want.map_sums[:, ~ch1u])
+    assert np.abs(got.map_sums[:, ch1u] - want.map_sums[:, ch1u]).max() <= got.map_counts[:, ch1u].max()   # <= 1 tick a sample
+    assert got.map_counts.sum() > 0
