@@ -557,7 +557,7 @@ struct ExtraArgs {
     float x0, y0, binx, biny;
     uint32_t nx, ny;
     unsigned long long *map_packed;  // [leaflets ? 2 : 1][n_acc][nx*ny] packed (count << 42) + sum, see k_fold_maps
-    unsigned long long *map_rec;     // united-atom staging (k_map_accumulate): [tile][frame - rec_frame0][3][kBlock] samples or null
+    unsigned long long *map_rec;     // sample staging (k_map_accumulate): [tile][frame - rec_frame0][1 | 3][kBlock] or null
     uint32_t rec_frame0, rec_frames;
     const float4 *dyn;               // dynamic membrane normals [n_frames][n_mol_total] (nx, ny, nz, cloud size) or null
     int tw;                          // timewise on
@@ -687,6 +687,7 @@ __global__ __launch_bounds__(kBlock) void k_bonds_extras(FrameArgs a_in, ExtraAr
     SampleAcc acc;
     int bad = 0;
     for (uint32_t f = f_begin; f < f_end; f++) {
+        unsigned long long rec = kMapNoSample;
         if (active) {
             const float *q1 = pi + (size_t)f * fstride, *q2 = pj + (size_t)f * fstride;
             const float p1x = q1[0], p1y = q1[1], p1z = q1[2];
@@ -723,9 +724,10 @@ __global__ __launch_bounds__(kBlock) void k_bonds_extras(FrameArgs a_in, ExtraAr
                 acc.s_tot += tick;
                 acc.n_tot += 1;
                 if (leaflet == 0) { acc.s_up += tick; acc.n_up += 1; }
-                extras_add(a, e, gslot, it.lslot, tick, mx, my, mz, leaflet, l_tw, l_twn, kBlock);
+                extras_add(a, e, gslot, it.lslot, tick, mx, my, mz, leaflet, l_tw, l_twn, kBlock, e.map_rec ? &rec : nullptr);
             }
         }
+        if (e.map_rec) e.map_rec[((size_t)tile_id * e.rec_frames + (f - e.rec_frame0)) * kBlock + tid] = rec;
         if (e.tw) {
             __syncthreads();
             extras_flush_tw(a, e, tile_slots + t.slot0, t.n_slots, f, l_tw, l_twn, kBlock);
@@ -1028,13 +1030,13 @@ __global__ __launch_bounds__(kBlock) void k_ua_extras(FrameArgs a_in, ExtraArgs 
 __global__ __launch_bounds__(1024) void k_map_accumulate(const unsigned long long *__restrict__ rec,
                                                          const gorder::MapRun *__restrict__ runs,
                                                          const uint32_t *__restrict__ run_begin, uint32_t n_slots,
-                                                         uint32_t rec_frames, uint32_t frames_per_chunk,
+                                                         uint32_t rec_frames, uint32_t frames_per_chunk, uint32_t k_max,
                                                          uint32_t n_words /* planes * tiles */, uint32_t n_tiles_map,
                                                          unsigned long long *__restrict__ map_packed, uint32_t n_acc) {
     extern __shared__ unsigned long long l_map[];
     const uint32_t slot = blockIdx.x % n_slots, chunk = blockIdx.x / n_slots;
     const uint32_t r0 = run_begin[slot], r1 = run_begin[slot + 1];
-    if (r0 == r1) return;                               // not a united-atom slot
+    if (r0 == r1) return;                               // no samples of this kind (bond / united atom) in the slot
     const uint32_t f0 = chunk * frames_per_chunk, f1 = min(rec_frames, f0 + frames_per_chunk);
     for (uint32_t w = threadIdx.x; w < n_words; w += blockDim.x) l_map[w] = 0ull;
     __syncthreads();
@@ -1043,7 +1045,7 @@ __global__ __launch_bounds__(1024) void k_map_accumulate(const unsigned long lon
         const uint32_t total = (f1 - f0) * run.n;
         for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) {
             const uint32_t f = f0 + i / run.n, j = i % run.n;
-            const unsigned long long v = rec[(((size_t)run.tile * rec_frames + f) * 3u + run.k) * kBlock + run.tid0 + j];
+            const unsigned long long v = rec[(((size_t)run.tile * rec_frames + f) * k_max + run.k) * kBlock + run.tid0 + j];
             if (v != kMapNoSample)
                 atomicAdd(&l_map[(uint32_t)(v >> 32)], kMapOne + (unsigned long long)(long long)(int)(uint32_t)v);
         }
@@ -1885,8 +1887,9 @@ struct gorder_hip_handle {
     unsigned long long *d_map_packed = nullptr;   // [1 or 2][n_acc][nx*ny], what the kernels add into
     unsigned long long *d_map_rec = nullptr;      // united-atom staging for k_map_accumulate (see ExtraArgs::map_rec)
     size_t map_rec_cap = 0;
-    gorder::MapRun *d_ua_runs = nullptr;
-    uint32_t *d_ua_run_begin = nullptr;
+    gorder::MapRun *d_ua_runs = nullptr, *d_runs = nullptr;
+    uint32_t *d_ua_run_begin = nullptr, *d_run_begin = nullptr;
+    Item *d_items_by_slot = nullptr;
     bool map_staged = false;       // the packed map of one slot fits LDS: stage + accumulate instead of one atomic per sample
     uint64_t map_pending = 0;      // upper bound of the samples one packed word may hold since the last fold
     uint64_t map_fold_limit = kMapFoldLimit;   // GORDER_HIP_MAP_FOLD_LIMIT lowers it (tests)
@@ -2165,8 +2168,8 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
         const bool ac = (h->tables.flags & GORDER_FLAG_TRIG_ACOS_COS) != 0;
         // with ordermaps the frames go in sub-ranges short enough for the packed map words (k_fold_maps)
         uint32_t sub = e.maps ? (uint32_t)std::max<uint64_t>(1, (h->map_fold_limit - 1) / h->map_max_mol) : a.n_frames;
-        const bool staged = e.maps && h->map_staged && !p.ua_tiles.empty();
-        const size_t rec_per_frame = p.ua_tiles.size() * 3u * kBlock;     // staged words per frame
+        const bool staged = e.maps && h->map_staged;
+        const size_t rec_per_frame = std::max(p.ua_tiles.size() * 3u, extras ? p.tiles.size() : (size_t)0) * kBlock;   // staged words per frame
         if (staged) {   // at most 1 GiB of staging per sub-range
             sub = std::min<uint32_t>(sub, (uint32_t)std::max<size_t>(1, ((size_t)1 << 27) / rec_per_frame));
             sub = std::min(sub, a.n_frames);
@@ -2194,15 +2197,16 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
                 b.frame0 = lo;
                 b.n_frames = hi;
                 b.frames_per_chunk = fpc;
-                e.map_rec = (pass == 1 && staged) ? h->d_map_rec : nullptr;
+                e.map_rec = staged ? h->d_map_rec : nullptr;
                 e.rec_frame0 = lo;
                 e.rec_frames = nf;
                 const dim3 g(nt * n_chunks), blk(kBlock);
                 if (pass == 0) {
+                    const Item *items = staged ? h->d_items_by_slot : h->d_items;
                     if (ac) hipLaunchKernelGGL(k_bonds_extras<true>, g, blk, 0, h->stream, b, e, b.xyz, b.box9, b.aflags,
-                                               b.arow, h->d_tiles, h->d_items, h->d_tile_slots, nt);
+                                               b.arow, h->d_tiles, items, h->d_tile_slots, nt);
                     else hipLaunchKernelGGL(k_bonds_extras<false>, g, blk, 0, h->stream, b, e, b.xyz, b.box9, b.aflags,
-                                            b.arow, h->d_tiles, h->d_items, h->d_tile_slots, nt);
+                                            b.arow, h->d_tiles, items, h->d_tile_slots, nt);
                 } else {
 #define GORDER_LAUNCH_UA(AC, EX)                                                                                  \
     hipLaunchKernelGGL((k_ua_extras<AC, EX>), g, blk, 0, h->stream, b, e, b.xyz, b.box9, b.aflags, b.arow,          \
@@ -2210,6 +2214,8 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
                     if (extras) { if (ac) GORDER_LAUNCH_UA(true, true); else GORDER_LAUNCH_UA(false, true); }
                     else { if (ac) GORDER_LAUNCH_UA(true, false); else GORDER_LAUNCH_UA(false, false); }
 #undef GORDER_LAUNCH_UA
+                }
+                {
                     if (staged) {   // second step: slot-major accumulation of the staged samples in LDS
                         const uint32_t planes = h->tables.leaflets.method != GORDER_LEAFLETS_NONE ? 2u : 1u;
                         const uint32_t ntm = h->map_nx * h->map_ny, n_words = planes * ntm;
@@ -2219,8 +2225,9 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
                         const uint32_t mfpc = (nf + mchunks - 1) / mchunks;
                         mchunks = (nf + mfpc - 1) / mfpc;
                         hipLaunchKernelGGL(k_map_accumulate, dim3(p.n_acc * mchunks), dim3(1024),
-                                           n_words * sizeof(unsigned long long), h->stream, h->d_map_rec, h->d_ua_runs,
-                                           h->d_ua_run_begin, p.n_acc, nf, mfpc, n_words, ntm, h->d_map_packed, p.n_acc);
+                                           n_words * sizeof(unsigned long long), h->stream, h->d_map_rec,
+                                           pass == 0 ? h->d_runs : h->d_ua_runs, pass == 0 ? h->d_run_begin : h->d_ua_run_begin,
+                                           p.n_acc, nf, mfpc, pass == 0 ? 1u : 3u, n_words, ntm, h->d_map_packed, p.n_acc);
                     }
                 }
                 HIP_TRY(h, hipGetLastError());
@@ -2352,9 +2359,12 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
                 h->map_max_mol = std::max(h->map_max_mol, t->molecule_types[m].n_molecules);
             // united atoms: stage + accumulate in LDS when one slot's packed map (x2 with leaflets) fits
             const size_t lds_bytes = npk / p.n_acc * sizeof(unsigned long long);
-            if (!p.ua_tiles.empty() && lds_bytes <= 150u * 1024u && !env_flag("GORDER_HIP_MAP_DIRECT")) {
+            if (lds_bytes <= 150u * 1024u && !env_flag("GORDER_HIP_MAP_DIRECT")) {
                 if ((st = upload(h, &h->d_ua_runs, p.ua_runs)) != GORDER_OK) return st;
                 if ((st = upload(h, &h->d_ua_run_begin, p.ua_run_begin)) != GORDER_OK) return st;
+                if ((st = upload(h, &h->d_runs, p.runs)) != GORDER_OK) return st;
+                if ((st = upload(h, &h->d_run_begin, p.run_begin)) != GORDER_OK) return st;
+                if ((st = upload(h, &h->d_items_by_slot, p.items_by_slot)) != GORDER_OK) return st;
                 HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_map_accumulate),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
                 h->map_staged = true;
@@ -2528,6 +2538,7 @@ void gorder_hip_destroy(gorder_hip_handle *h) {
     (void)hipFree(h->d_map_sums); (void)hipFree(h->d_map_cnts); (void)hipFree(h->d_map_packed); (void)hipFree(h->d_tw_sums); (void)hipFree(h->d_tw_cnts);
     (void)hipFree(h->d_geom_group); (void)hipFree(h->d_shapes);
     (void)hipFree(h->d_map_rec); (void)hipFree(h->d_ua_runs); (void)hipFree(h->d_ua_run_begin);
+    (void)hipFree(h->d_runs); (void)hipFree(h->d_run_begin); (void)hipFree(h->d_items_by_slot);
     (void)hipFree(h->d_dyn_cloud); (void)hipFree(h->d_dyn_heads); (void)hipFree(h->d_dyn_cell_of); (void)hipFree(h->d_dyn_count);
     (void)hipFree(h->d_dyn_rec); (void)hipFree(h->d_dyn_rsn); (void)hipFree(h->d_dyn_normals);
     if (!h->acc_external) (void)hipFree(h->d_acc);

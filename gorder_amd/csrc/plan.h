@@ -63,6 +63,11 @@ struct Plan {
     std::vector<uint32_t> ua_tile_slots;
     std::vector<MapRun> ua_runs;            // grouped by accumulator slot:
     std::vector<uint32_t> ua_run_begin;     // [n_acc + 1] (CSR)
+    // the same for bond tiles: `items_by_slot` = every tile's items re-ordered so that the molecules of one slot
+    // sit on consecutive lanes (used by the scatter kernel only; K1 keeps the atom order of `items`)
+    std::vector<Item> items_by_slot;
+    std::vector<MapRun> runs;
+    std::vector<uint32_t> run_begin;
     std::vector<uint32_t> mol0;    // first global molecule id per molecule type
     std::vector<uint32_t> slot0;   // first accumulator slot per molecule type
 };
@@ -228,6 +233,27 @@ inline int build_plan(const gorder_tables_t &t, bool force_direct, Plan &p) {
         p.tile_slots.insert(p.tile_slots.end(), slots.begin(), slots.end());
         p.max_window = std::max(p.max_window, tile.n_window);
         p.tiles.push_back(tile);
+    }
+    {   // slot-ordered copy of the tile items + the runs of every slot (see MapRun)
+        p.items_by_slot = p.items;
+        std::vector<std::pair<uint32_t, MapRun>> run_of_slot;
+        for (uint32_t ti = 0; ti < p.tiles.size(); ti++) {
+            const Tile &tile = p.tiles[ti];
+            std::stable_sort(p.items_by_slot.begin() + tile.item0, p.items_by_slot.begin() + tile.item0 + tile.n_items,
+                             [](const Item &x, const Item &y) { return x.lslot < y.lslot; });
+            for (uint32_t i = 0; i < tile.n_items;) {
+                const uint16_t ls = p.items_by_slot[tile.item0 + i].lslot;
+                uint32_t n = 1;
+                while (i + n < tile.n_items && p.items_by_slot[tile.item0 + i + n].lslot == ls) n++;
+                run_of_slot.push_back({p.tile_slots[tile.slot0 + ls], MapRun{ti, i, n, 0}});
+                i += n;
+            }
+        }
+        std::stable_sort(run_of_slot.begin(), run_of_slot.end(),
+                         [](const std::pair<uint32_t, MapRun> &x, const std::pair<uint32_t, MapRun> &y) { return x.first < y.first; });
+        p.run_begin.assign((size_t)p.n_acc + 1, 0);
+        for (const auto &r : run_of_slot) { p.run_begin[r.first + 1]++; p.runs.push_back(r.second); }
+        for (uint32_t sl = 0; sl < p.n_acc; sl++) p.run_begin[sl + 1] += p.run_begin[sl];
     }
     return GORDER_OK;
 }
