@@ -302,6 +302,40 @@ inline int selfcheck_plan(const gorder_tables_t &t, const Plan &p) {
         if (want[q].i != got[q].i || want[q].j != got[q].j || want[q].slot != got[q].slot ||
             want[q].mol != got[q].mol)
             return 7;
+    // the slot-ordered copy is a permutation of each tile's items, and the runs of every slot cover exactly the
+    // lanes that hold that slot (bond tiles: one entry per lane; united-atom tiles: one per lane and hydrogen)
+    if (p.items_by_slot.size() != p.items.size() || p.run_begin.size() != (size_t)p.n_acc + 1) return 8;
+    std::vector<uint32_t> covered(p.items.size(), 0);
+    for (uint32_t sl = 0; sl < p.n_acc; sl++)
+        for (uint32_t r = p.run_begin[sl]; r < p.run_begin[sl + 1]; r++) {
+            const MapRun &run = p.runs[r];
+            if (run.tile >= p.tiles.size() || run.k != 0 || run.tid0 + run.n > p.tiles[run.tile].n_items) return 9;
+            const Tile &tile = p.tiles[run.tile];
+            for (uint32_t j = 0; j < run.n; j++) {
+                const Item &it = p.items_by_slot[tile.item0 + run.tid0 + j];
+                if (p.tile_slots[tile.slot0 + it.lslot] != sl) return 10;
+                covered[tile.item0 + run.tid0 + j]++;
+            }
+        }
+    for (uint32_t c : covered)
+        if (c != 1) return 11;
+    if (!p.ua_tiles.empty()) {
+        if (p.ua_run_begin.size() != (size_t)p.n_acc + 1) return 12;
+        size_t lanes = 0, want_lanes = 0;
+        for (const UaItem &it : p.ua_items) want_lanes += it.kind == GORDER_UA_CH3 ? 3 : it.kind == GORDER_UA_CH2 ? 2 : 1;
+        for (uint32_t sl = 0; sl < p.n_acc; sl++)
+            for (uint32_t r = p.ua_run_begin[sl]; r < p.ua_run_begin[sl + 1]; r++) {
+                const MapRun &run = p.ua_runs[r];
+                if (run.tile >= p.ua_tiles.size() || run.k > 2 || run.tid0 + run.n > p.ua_tiles[run.tile].n_items) return 13;
+                const Tile &tile = p.ua_tiles[run.tile];
+                for (uint32_t j = 0; j < run.n; j++) {
+                    const UaItem &it = p.ua_items[tile.item0 + run.tid0 + j];
+                    if (p.ua_tile_slots[tile.slot0 + it.lslot0 + run.k] != sl) return 14;
+                    lanes++;
+                }
+            }
+        if (lanes != want_lanes) return 15;
+    }
     return 0;
 }
 
