@@ -1,0 +1,416 @@
+// kernels_bonds.h — K1 k_bonds_tiled (+ gather / direct variants): BondType::analyze_frame, bond.rs:396-446.
+// Part of the single translation unit gorder_hip.hip (included there, in this order: common, bonds, extras,
+// leaflets, normals); device code for gfx950 only.
+#pragma once
+
+namespace {
+
+// ---- one bond sample (bond.rs:407-443) -----------------------------------------------------
+struct SampleAcc {
+    long long s_tot = 0, s_up = 0;
+    uint32_t n_tot = 0, n_up = 0;
+};
+
+// returns true when S came out NaN (undefined position or a non-finite coordinate)
+template <bool ACOS_COS>
+__device__ __forceinline__ bool bond_sample(const FrameArgs &a, uint32_t f, float p1x, float p1y, float p1z,
+                                            float p2x, float p2y, float p2z, uint32_t mol, SampleAcc &acc,
+                                            int &bad) {
+    float vx = p2x - p1x, vy = p2y - p1y, vz = p2z - p1z;
+    if (a.pbc) {
+        const float *b = a.box9 + 9 * (size_t)f;
+        const float bx = b[0], by = b[4], bz = b[8];
+        bool slow = false;   // one select-only step per dimension; the literal loops only when needed
+        const float rx = gm_min_image_step(vx, bx, slow);
+        const float ry = gm_min_image_step(vy, by, slow);
+        const float rz = gm_min_image_step(vz, bz, slow);
+        if (__builtin_expect(slow, 0)) {
+            vx = gm_min_image_loop(vx, bx, bad);
+            vy = gm_min_image_loop(vy, by, bad);
+            vz = gm_min_image_loop(vz, bz, bad);
+        } else {
+            vx = rx; vy = ry; vz = rz;
+        }
+    }
+    const float sch = gm_calc_sch<ACOS_COS>(vx, vy, vz, a.nx, a.ny, a.nz, a.n2, a.n2sq);
+    const long long tick = gm_tick(sch);
+    acc.s_tot += tick;
+    acc.n_tot += 1;
+    if (a.leaflets) {
+        const uint8_t fl = a.aflags[(size_t)a.arow[f] * a.n_mol_total + mol];
+        if (fl == 0) {   // Leaflet::Upper = 0 (lib.rs:416-422)
+            acc.s_up += tick;
+            acc.n_up += 1;
+        }
+    }
+    return sch != sch;
+}
+
+// ---- K1: tiled bonds ----------------------------------------------------------------------
+// grid.x = n_tiles * n_chunks; block = 256 = 4 waves; dynamic LDS = G * lw floats.
+// Each block owns one tile (<= 256 samples, one contiguous atom window) for frames_per_chunk frames.
+// Per stage the window of G frames goes HBM -> registers -> LDS (256/G threads per frame, 16 B per
+// lane, fully coalesced, every byte read once) and every thread evaluates its sample for the G
+// frames.  The loads of stage s+1 are issued BEFORE the arithmetic of stage s (NPF float4 registers
+// per thread), so each resident block keeps a whole stage of HBM traffic in flight while it computes.
+//
+// The 16-byte loads start at the window's first float rounded DOWN to 16 B and end at its last float
+// rounded UP to 16 B.  xyz is 16-byte aligned, so the last load of the whole buffer stays inside the
+// aligned 16-byte granule that holds the last valid float: it cannot cross into an unmapped page.
+typedef float v4f __attribute__((ext_vector_type(4)));   // native 16-byte vector (SROA-friendly, unlike float4)
+
+template <int G, int NPF, bool ACOS_COS, bool PBC, bool LEAF, int AXIS = -1>
+struct TiledStage {
+    static constexpr uint32_t TPF = kBlock / G;   // threads that stage one frame
+
+    // issue the loads of my frame slot of the stage that starts at frame f0
+    template <bool TAIL>
+    static __device__ __forceinline__ void load(const FrameArgs &a, const Tile &t, uint32_t f0, uint32_t f_end,
+                                                uint32_t sk, uint32_t si, v4f (&pre)[NPF]) {
+        const uint32_t f = f0 + sk;
+        if (TAIL && f >= f_end) return;
+        const size_t base = ((size_t)f * a.n_atoms + t.atom0) * 3u;
+        const uint32_t n4 = ((uint32_t)(base & 3u) + 3u * t.n_window + 3u) >> 2;
+        const v4f *src = reinterpret_cast<const v4f *>(a.xyz + (base & ~(size_t)3));
+#pragma unroll
+        for (int j = 0; j < NPF; j++) {   // unconditional (index clamped): keeps pre[] in registers
+            const uint32_t i = si + (uint32_t)j * TPF;
+            pre[j] = __builtin_nontemporal_load(src + (i < n4 ? i : n4 - 1u));   // streamed once: nt
+        }
+    }
+    // registers (and, for windows wider than NPF * TPF float4, late loads) -> LDS
+    template <bool TAIL>
+    static __device__ __forceinline__ void store(const FrameArgs &a, const Tile &t, uint32_t f0, uint32_t f_end,
+                                                 uint32_t sk, uint32_t si, const v4f (&pre)[NPF], float *lds,
+                                                 uint32_t lw) {
+        const uint32_t f = f0 + sk;
+        if (TAIL && f >= f_end) return;
+        const size_t base = ((size_t)f * a.n_atoms + t.atom0) * 3u;
+        const uint32_t n4 = ((uint32_t)(base & 3u) + 3u * t.n_window + 3u) >> 2;
+        const v4f *src = reinterpret_cast<const v4f *>(a.xyz + (base & ~(size_t)3));
+        v4f *dst = reinterpret_cast<v4f *>(lds + (size_t)sk * lw);
+#pragma unroll
+        for (int j = 0; j < NPF; j++) {
+            const uint32_t i = si + (uint32_t)j * TPF;
+            if (i < n4) dst[i] = pre[j];
+        }
+        for (uint32_t i = si + (uint32_t)NPF * TPF; i < n4; i += TPF) dst[i] = __builtin_nontemporal_load(src + i);
+    }
+    // My sample in each of the G frames of a stage; P[k] = {p1x,p1y,p1z,p2x,p2y,p2z} of frame f0 + k.
+    // The common path is straight-line code (selects only) so that the G independent dependency chains
+    // interleave; the rare cases (atoms more than 1.5 box lengths apart -> literal minimum-image loops;
+    // NaN result -> which atom is undefined?) are collected in a bit mask and handled after the stage.
+    static __device__ __forceinline__ void compute_core(const FrameArgs &a, const Tile &t, const Item &it,
+                                                        uint32_t f0, const float (&P)[G][6], SampleAcc &acc,
+                                                        int &bad, uint32_t &nan_atom, uint32_t &nan_frame) {
+        int tick[G];
+        uint8_t fl[G];
+        float bx[G], by[G], bz[G];
+        uint32_t rare = 0;
+        // uniform per-frame inputs of the whole stage first (scalar loads, issued back to back)
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+            if (PBC) {
+                const float *b = a.box9 + 9 * (size_t)(f0 + k);
+                bx[k] = b[0]; by[k] = b[4]; bz[k] = b[8];
+            }
+            if (LEAF) fl[k] = a.aflags[(size_t)a.arow[f0 + k] * a.n_mol_total + it.mol];
+        }
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+            float vx = P[k][3] - P[k][0], vy = P[k][4] - P[k][1], vz = P[k][5] - P[k][2];
+            bool slow = false;
+            if (PBC) {
+                vx = gm_min_image_step(vx, bx[k], slow);
+                vy = gm_min_image_step(vy, by[k], slow);
+                vz = gm_min_image_step(vz, bz[k], slow);
+            }
+            bool nonfinite = false;
+            const float sch = gm_calc_sch<ACOS_COS, AXIS>(vx, vy, vz, a.nx, a.ny, a.nz, a.n2, a.n2sq, &nonfinite);
+            rare |= ((slow || nonfinite || sch != sch) ? 1u : 0u) << k;
+            tick[k] = gm_tick(sch);
+        }
+        if (__builtin_expect(rare != 0, 0)) {
+#pragma unroll
+            for (int k = 0; k < G; k++) {
+                if (!((rare >> k) & 1u)) continue;
+                float vx = P[k][3] - P[k][0], vy = P[k][4] - P[k][1], vz = P[k][5] - P[k][2];
+                if (PBC) {
+                    vx = gm_min_image_loop(vx, bx[k], bad);
+                    vy = gm_min_image_loop(vy, by[k], bad);
+                    vz = gm_min_image_loop(vz, bz[k], bad);
+                }
+                const float sch = gm_calc_sch<ACOS_COS>(vx, vy, vz, a.nx, a.ny, a.nz, a.n2, a.n2sq);
+                tick[k] = gm_tick(sch);
+                if (sch != sch) {
+                    if (P[k][0] != P[k][0]) { nan_atom = t.atom0 + it.li; nan_frame = f0 + k; }
+                    else if (P[k][3] != P[k][3]) { nan_atom = t.atom0 + it.lj; nan_frame = f0 + k; }
+                }
+            }
+        }
+        int st = 0, su = 0;
+        uint32_t nu = 0;
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+            st += tick[k];
+            if (LEAF) {   // Leaflet::Upper = 0 (lib.rs:416-422)
+                su += fl[k] == 0 ? tick[k] : 0;
+                nu += fl[k] == 0 ? 1u : 0u;
+            }
+        }
+        acc.s_tot += st;
+        acc.n_tot += G;
+        acc.s_up += su;
+        acc.n_up += nu;
+    }
+    // LDS-staged variant: pick my two atoms out of the staged windows
+    static __device__ __forceinline__ void compute(const FrameArgs &a, const Tile &t, const Item &it, uint32_t f0,
+                                                   const float *lds, uint32_t lw, SampleAcc &acc, int &bad,
+                                                   uint32_t &nan_atom, uint32_t &nan_frame) {
+        float P[G][6];
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+            const uint32_t sh = (uint32_t)((((size_t)(f0 + k) * a.n_atoms + t.atom0) * 3u) & 3u);
+            const float *w = lds + (size_t)k * lw + sh;
+            P[k][0] = w[3u * it.li]; P[k][1] = w[3u * it.li + 1]; P[k][2] = w[3u * it.li + 2];
+            P[k][3] = w[3u * it.lj]; P[k][4] = w[3u * it.lj + 1]; P[k][5] = w[3u * it.lj + 2];
+        }
+        compute_core(a, t, it, f0, P, acc, bad, nan_atom, nan_frame);
+    }
+    // partial last stage: frames f0 .. f_end-1, one at a time (not performance relevant)
+    static __device__ __forceinline__ void compute_tail(const FrameArgs &a, const Tile &t, const Item &it,
+                                                        uint32_t f0, uint32_t f_end, const float *lds, uint32_t lw,
+                                                        SampleAcc &acc, int &bad, uint32_t &nan_atom,
+                                                        uint32_t &nan_frame) {
+#pragma unroll 1
+        for (uint32_t f = f0; f < f_end; f++) {
+            const uint32_t sh = (uint32_t)((((size_t)f * a.n_atoms + t.atom0) * 3u) & 3u);
+            const float *w = lds + (size_t)(f - f0) * lw + sh;
+            const float p1x = w[3u * it.li], p1y = w[3u * it.li + 1], p1z = w[3u * it.li + 2];
+            const float p2x = w[3u * it.lj], p2y = w[3u * it.lj + 1], p2z = w[3u * it.lj + 2];
+            if (bond_sample<ACOS_COS>(a, f, p1x, p1y, p1z, p2x, p2y, p2z, it.mol, acc, bad)) {
+                if (p1x != p1x) { nan_atom = t.atom0 + it.li; nan_frame = f; }
+                else if (p2x != p2x) { nan_atom = t.atom0 + it.lj; nan_frame = f; }
+            }
+        }
+    }
+};
+
+#ifndef GORDER_TILED_MIN_WAVES
+#define GORDER_TILED_MIN_WAVES 4   // waves per SIMD the register allocation must allow (8 => <= 64 VGPRs)
+#endif
+template <int G, int NPF, bool ACOS_COS, bool PBC, bool LEAF, int AXIS>
+__global__ __launch_bounds__(kBlock, GORDER_TILED_MIN_WAVES) void k_bonds_tiled(FrameArgs a_in, const float *__restrict__ xyz,
+                                                      const float *__restrict__ box9,
+                                                      const uint8_t *__restrict__ aflags,
+                                                      const uint32_t *__restrict__ arow,
+                                                      const Tile *__restrict__ tiles,
+                                                      const Item *__restrict__ items,
+                                                      const uint32_t *__restrict__ tile_slots,
+                                                      uint32_t n_tiles, uint32_t lw) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    using S = TiledStage<G, NPF, ACOS_COS, PBC, LEAF, AXIS>;
+    // the read-only streams come in as __restrict__ kernel arguments so that the compiler can prove
+    // that the accumulator / error stores never clobber them (uniform loads become scalar loads)
+    FrameArgs a = a_in;
+    a.xyz = xyz; a.box9 = box9; a.aflags = aflags; a.arow = arow;
+    const uint32_t tile_id = blockIdx.x % n_tiles;
+    const uint32_t chunk = blockIdx.x / n_tiles;
+    const Tile t = tiles[tile_id];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t sk = tid / S::TPF, si = tid % S::TPF;   // staging role: frame slot, first float4
+    const bool active = tid < t.n_items;
+    Item it{0, 0, 0, 0, 0};
+    if (active) it = items[t.item0 + tid];
+
+    const uint32_t f_begin = chunk * a.frames_per_chunk;
+    const uint32_t f_end = min(a.n_frames, f_begin + a.frames_per_chunk);
+    const uint32_t f_full = f_begin + ((f_end - f_begin) / G) * G;   // end of the whole stages
+
+    SampleAcc acc;
+    int bad = 0;
+    uint32_t nan_atom = 0xffffffffu, nan_frame = 0;
+    v4f pre[NPF];
+
+    if (f_begin < f_full) S::template load<false>(a, t, f_begin, f_end, sk, si, pre);
+    for (uint32_t f0 = f_begin; f0 < f_full; f0 += G) {
+        S::template store<false>(a, t, f0, f_end, sk, si, pre, lds, lw);
+        __syncthreads();
+        if (f0 + G < f_full) S::template load<false>(a, t, f0 + G, f_end, sk, si, pre);   // next stage in flight
+        if (active) S::compute(a, t, it, f0, lds, lw, acc, bad, nan_atom, nan_frame);
+        __syncthreads();
+    }
+    if (f_full < f_end) {   // last, partial stage of the batch
+        S::template load<true>(a, t, f_full, f_end, sk, si, pre);
+        S::template store<true>(a, t, f_full, f_end, sk, si, pre, lds, lw);
+        __syncthreads();
+        if (active) S::compute_tail(a, t, it, f_full, f_end, lds, lw, acc, bad, nan_atom, nan_frame);
+        __syncthreads();
+    }
+
+    if (nan_atom != 0xffffffffu) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, nan_atom, nan_frame);
+    if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f_begin);
+
+    // ---- epilogue: fold the block's samples per accumulator slot in LDS, then one global atomic
+    // per (slot, field).  Integer sums: the result does not depend on the order (order.rs:44-60).
+    unsigned long long *l_s = reinterpret_cast<unsigned long long *>(lds);   // [2][256]
+    uint32_t *l_n = reinterpret_cast<uint32_t *>(l_s + 2 * kBlock);          // [2][256]
+    l_s[tid] = 0; l_s[kBlock + tid] = 0; l_n[tid] = 0; l_n[kBlock + tid] = 0;
+    __syncthreads();
+    if (active && acc.n_tot) {
+        atomicAdd(&l_s[it.lslot], (unsigned long long)acc.s_tot);
+        atomicAdd(&l_n[it.lslot], acc.n_tot);
+        if (acc.n_up) {
+            atomicAdd(&l_s[kBlock + it.lslot], (unsigned long long)acc.s_up);
+            atomicAdd(&l_n[kBlock + it.lslot], acc.n_up);
+        }
+    }
+    __syncthreads();
+#ifdef GORDER_DEBUG_NOEPILOGUE   // timing experiment only
+    if (a.n_frames == 0xffffffffu)
+#endif
+    if (tid < t.n_slots && l_n[tid]) {
+        // spread the blocks over n_rep replicas of the accumulator block: same-address atomics of
+        // thousands of blocks would otherwise serialise in L2
+        unsigned long long *acc = a.rep + (size_t)(blockIdx.x % a.n_rep) * 4u * a.n_acc;
+        const uint32_t slot = tile_slots[t.slot0 + tid];
+        atomicAdd(&acc[slot], l_s[tid]);
+        atomicAdd(&acc[2u * a.n_acc + slot], (unsigned long long)l_n[tid]);
+        if (l_n[kBlock + tid]) {
+            atomicAdd(&acc[a.n_acc + slot], l_s[kBlock + tid]);
+            atomicAdd(&acc[3u * a.n_acc + slot], (unsigned long long)l_n[kBlock + tid]);
+        }
+    }
+}
+
+// ---- K1g: same tiles, but every lane gathers its two atoms straight from global memory (through the
+// per-CU vector L1) instead of going through an LDS-staged window: no LDS traffic and no barriers in
+// the frame loop, waves run fully decoupled.  Each HBM byte is still fetched about once: the lanes
+// of a wave touch one contiguous ~1 KiB run of the frame and neighbouring waves share only its ends.
+// The loads of stage s+1 are issued before the arithmetic of stage s (2 x G x 6 registers).
+template <int G, bool ACOS_COS, bool PBC, bool LEAF>
+__global__ __launch_bounds__(kBlock) void k_bonds_gather(FrameArgs a_in, const float *__restrict__ xyz,
+                                                       const float *__restrict__ box9,
+                                                       const uint8_t *__restrict__ aflags,
+                                                       const uint32_t *__restrict__ arow,
+                                                       const Tile *__restrict__ tiles,
+                                                       const Item *__restrict__ items,
+                                                       const uint32_t *__restrict__ tile_slots, uint32_t n_tiles) {
+    __shared__ unsigned long long l_s[2 * kBlock];
+    __shared__ uint32_t l_n[2 * kBlock];
+    using S = TiledStage<G, 1, ACOS_COS, PBC, LEAF>;
+    FrameArgs a = a_in;
+    a.xyz = xyz; a.box9 = box9; a.aflags = aflags; a.arow = arow;
+    const uint32_t tile_id = blockIdx.x % n_tiles;
+    const uint32_t chunk = blockIdx.x / n_tiles;
+    const Tile t = tiles[tile_id];
+    const uint32_t tid = threadIdx.x;
+    const bool active = tid < t.n_items;
+    Item it{0, 0, 0, 0, 0};
+    if (active) it = items[t.item0 + tid];
+    const uint32_t f_begin = chunk * a.frames_per_chunk;
+    const uint32_t f_end = min(a.n_frames, f_begin + a.frames_per_chunk);
+    const uint32_t f_full = f_begin + ((f_end - f_begin) / G) * G;
+    const size_t fstride = (size_t)a.n_atoms * 3u;
+    const float *pi = xyz + ((size_t)t.atom0 + it.li) * 3u;
+    const float *pj = xyz + ((size_t)t.atom0 + it.lj) * 3u;
+
+    SampleAcc acc;
+    int bad = 0;
+    uint32_t nan_atom = 0xffffffffu, nan_frame = 0;
+    float cur[G][6], nxt[G][6];
+    auto fetch = [&](float (&P)[G][6], uint32_t f0) {
+#pragma unroll
+        for (int k = 0; k < G; k++) {
+            const float *q1 = pi + (size_t)(f0 + k) * fstride, *q2 = pj + (size_t)(f0 + k) * fstride;
+            P[k][0] = q1[0]; P[k][1] = q1[1]; P[k][2] = q1[2];
+            P[k][3] = q2[0]; P[k][4] = q2[1]; P[k][5] = q2[2];
+        }
+    };
+    if (active) {
+        if (f_begin < f_full) fetch(cur, f_begin);
+        for (uint32_t f0 = f_begin; f0 < f_full; f0 += G) {
+            const bool more = f0 + G < f_full;
+            if (more) fetch(nxt, f0 + G);
+            S::compute_core(a, t, it, f0, cur, acc, bad, nan_atom, nan_frame);
+            if (more) {
+#pragma unroll
+                for (int k = 0; k < G; k++)
+#pragma unroll
+                    for (int c = 0; c < 6; c++) cur[k][c] = nxt[k][c];
+            }
+        }
+        for (uint32_t f = f_full; f < f_end; f++) {
+            const float *q1 = pi + (size_t)f * fstride, *q2 = pj + (size_t)f * fstride;
+            const float p1x = q1[0], p1y = q1[1], p1z = q1[2], p2x = q2[0], p2y = q2[1], p2z = q2[2];
+            if (bond_sample<ACOS_COS>(a, f, p1x, p1y, p1z, p2x, p2y, p2z, it.mol, acc, bad)) {
+                if (p1x != p1x) { nan_atom = t.atom0 + it.li; nan_frame = f; }
+                else if (p2x != p2x) { nan_atom = t.atom0 + it.lj; nan_frame = f; }
+            }
+        }
+    }
+    if (nan_atom != 0xffffffffu) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, nan_atom, nan_frame);
+    if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f_begin);
+
+    l_s[tid] = 0; l_s[kBlock + tid] = 0; l_n[tid] = 0; l_n[kBlock + tid] = 0;
+    __syncthreads();
+    if (active && acc.n_tot) {
+        atomicAdd(&l_s[it.lslot], (unsigned long long)acc.s_tot);
+        atomicAdd(&l_n[it.lslot], acc.n_tot);
+        if (acc.n_up) {
+            atomicAdd(&l_s[kBlock + it.lslot], (unsigned long long)acc.s_up);
+            atomicAdd(&l_n[kBlock + it.lslot], acc.n_up);
+        }
+    }
+    __syncthreads();
+#ifdef GORDER_DEBUG_NOEPILOGUE   // timing experiment only
+    if (a.n_frames == 0xffffffffu)
+#endif
+    if (tid < t.n_slots && l_n[tid]) {
+        // spread the blocks over n_rep replicas of the accumulator block: same-address atomics of
+        // thousands of blocks would otherwise serialise in L2
+        unsigned long long *acc = a.rep + (size_t)(blockIdx.x % a.n_rep) * 4u * a.n_acc;
+        const uint32_t slot = tile_slots[t.slot0 + tid];
+        atomicAdd(&acc[slot], l_s[tid]);
+        atomicAdd(&acc[2u * a.n_acc + slot], (unsigned long long)l_n[tid]);
+        if (l_n[kBlock + tid]) {
+            atomicAdd(&acc[a.n_acc + slot], l_s[kBlock + tid]);
+            atomicAdd(&acc[3u * a.n_acc + slot], (unsigned long long)l_n[kBlock + tid]);
+        }
+    }
+}
+
+// ---- K1b: direct gather (samples whose atoms do not fit one LDS window; also the A/B baseline)
+template <bool ACOS_COS>
+__global__ __launch_bounds__(256) void k_bonds_direct(FrameArgs a, const DirectItem *__restrict__ items,
+                                                       uint32_t n_items, uint32_t blocks_per_chunk) {
+    const uint32_t chunk = blockIdx.x / blocks_per_chunk;
+    const uint32_t q = (blockIdx.x % blocks_per_chunk) * blockDim.x + threadIdx.x;
+    if (q >= n_items) return;
+    const DirectItem it = items[q];
+    const uint32_t f_begin = chunk * a.frames_per_chunk;
+    const uint32_t f_end = min(a.n_frames, f_begin + a.frames_per_chunk);
+    SampleAcc acc;
+    int bad = 0;
+    for (uint32_t f = f_begin; f < f_end; f++) {
+        const float *p1 = a.xyz + ((size_t)f * a.n_atoms + it.i) * 3u;
+        const float *p2 = a.xyz + ((size_t)f * a.n_atoms + it.j) * 3u;
+        const float p1x = p1[0], p1y = p1[1], p1z = p1[2];
+        const float p2x = p2[0], p2y = p2[1], p2z = p2[2];
+        if (__builtin_expect(bond_sample<ACOS_COS>(a, f, p1x, p1y, p1z, p2x, p2y, p2z, it.mol, acc, bad), 0)) {
+            if (p1x != p1x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, it.i, f);
+            else if (p2x != p2x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, it.j, f);
+        }
+    }
+    if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f_begin);
+    if (acc.n_tot) {
+        atomicAdd(&a.acc[it.slot], (unsigned long long)acc.s_tot);
+        atomicAdd(&a.acc[2u * a.n_acc + it.slot], (unsigned long long)acc.n_tot);
+        if (acc.n_up) {
+            atomicAdd(&a.acc[a.n_acc + it.slot], (unsigned long long)acc.s_up);
+            atomicAdd(&a.acc[3u * a.n_acc + it.slot], (unsigned long long)acc.n_up);
+        }
+    }
+}
+
+}  // namespace

@@ -1,0 +1,103 @@
+// kernels_common.h — shared kernel arguments, error record, check_box, accumulator folds, ordermap words.
+// Part of the single translation unit gorder_hip.hip (included there, in this order: common, bonds, extras,
+// leaflets, normals); device code for gfx950 only.
+#pragma once
+
+namespace {
+
+constexpr int kFramesPerStage = 4;   // G: frames staged in LDS per barrier pair (= waves per block)
+constexpr uint32_t kErrWords = 4;    // device error record: code, payload, frame, spare
+
+struct FrameArgs {
+    const float *xyz;        // [n_frames][n_atoms][3]
+    const float *box9;       // [n_frames][9]
+    uint32_t n_atoms;
+    uint32_t n_frames;       // end of the frame range this launch covers
+    uint32_t frame0;         // its begin (only the scatter kernels launch sub-ranges; 0 elsewhere)
+    uint32_t frames_per_chunk;
+    int pbc;
+    float nx, ny, nz, n2, n2sq;   // static normal, its norm and squared norm
+    int leaflets;            // 0/1
+    const uint8_t *aflags;   // [rows][n_mol_total]
+    const uint32_t *arow;    // [n_frames] assignment row of each frame
+    uint32_t n_mol_total;
+    unsigned long long *acc; // [4][n_acc]: sum_total, sum_upper, cnt_total, cnt_upper
+    unsigned long long *rep; // [n_rep][4][n_acc] replicas the tiled kernels add into (folded into acc later)
+    uint32_t n_rep;
+    uint32_t n_acc;
+    uint32_t *err;
+};
+
+__device__ __forceinline__ void raise_error(uint32_t *err, uint32_t code, uint32_t payload, uint32_t frame) {
+    if (atomicCAS(&err[0], 0u, code) == 0u) {
+        err[1] = payload;
+        err[2] = frame;
+    }
+}
+
+// ---- check_box (common.rs:186-198), one thread per frame -----------------------------------
+__global__ void k_check_box(const float *__restrict__ box9, uint32_t n_frames, uint32_t *err) {
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_frames) return;
+    const float *b = box9 + 9 * (size_t)f;
+    bool all_nan = true;
+    for (int i = 0; i < 9; i++) all_nan = all_nan && (b[i] != b[i]);
+    if (all_nan) { raise_error(err, GORDER_ERR_UNDEFINED_BOX, 0, f); return; }
+    if (b[1] != 0.0f || b[2] != 0.0f || b[3] != 0.0f || b[5] != 0.0f || b[6] != 0.0f || b[7] != 0.0f) {
+        raise_error(err, GORDER_ERR_NOT_ORTHOGONAL_BOX, 0, f);
+        return;
+    }
+    if (b[0] == 0.0f && b[4] == 0.0f && b[8] == 0.0f) { raise_error(err, GORDER_ERR_ZERO_BOX, 0, f); return; }
+    if (!(b[0] > 0.0f) || !(b[4] > 0.0f) || !(b[8] > 0.0f)) raise_error(err, GORDER_ERR_BOX_RANGE, 0, f);
+}
+
+// total_frames (topology/mod.rs:141-144) lives in the last word of the accumulator block so that a
+// multi-GPU all-reduce sums it together with the order sums (topology/mod.rs:243)
+__global__ void k_count_frames(unsigned long long *word, uint32_t n_frames) { atomicAdd(word, (unsigned long long)n_frames); }
+
+// acc[i] += sum_r rep[r][i]; rep := 0   (i < 4 * n_acc)
+__global__ void k_fold_replicas(unsigned long long *acc, unsigned long long *rep, uint32_t n_rep, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long s = 0;
+    for (uint32_t r = 0; r < n_rep; r++) {
+        s += rep[(size_t)r * n + i];
+        rep[(size_t)r * n + i] = 0;
+    }
+    acc[i] += s;
+}
+
+// ---- ordermap words --------------------------------------------------------------------------
+// The scatter kernels add (1 << 42) + tick into one 64-bit word per (plane, slot, tile): the low 42 bits
+// hold the signed tick sum, the bits above the sample count.  |tick| <= 1e6, so the sum of c samples stays
+// inside 42 signed bits while c < 2^21; the host folds the words into the i64 sum / u64 count maps before
+// any tile can have received that many samples (gorder_hip_handle::map_pending).
+constexpr unsigned long long kMapOne = 1ull << 42;
+constexpr unsigned long long kMapFoldLimit = 1ull << 21;
+__device__ __forceinline__ void map_unpack(unsigned long long w, long long &sum, unsigned long long &cnt) {
+    sum = (long long)(w << 22) >> 22;                      // sign-extend the low 42 bits
+    cnt = (w - (unsigned long long)sum) >> 42;
+}
+constexpr unsigned long long kMapNoSample = ~0ull;   // staged entry of a lane without a sample in the map
+// packed [planes][n] -> sums/cnts [3][n] (total, upper, lower); planes = 2 with leaflets (upper, lower), else 1
+__global__ void k_fold_maps(unsigned long long *__restrict__ packed, unsigned long long *__restrict__ sums,
+                            unsigned long long *__restrict__ cnts, size_t n, int leaflets) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned long long w0 = packed[i], w1 = leaflets ? packed[n + i] : 0ull;
+        if (!(w0 | w1)) continue;
+        long long s0, s1 = 0;
+        unsigned long long c0, c1 = 0;
+        map_unpack(w0, s0, c0);
+        if (leaflets) map_unpack(w1, s1, c1);
+        sums[i] += (unsigned long long)(s0 + s1);
+        cnts[i] += c0 + c1;
+        if (leaflets) {
+            if (w0) { sums[n + i] += (unsigned long long)s0; cnts[n + i] += c0; packed[i] = 0; }
+            if (w1) { sums[2 * n + i] += (unsigned long long)s1; cnts[2 * n + i] += c1; packed[n + i] = 0; }
+        } else {
+            packed[i] = 0;
+        }
+    }
+}
+
+}  // namespace

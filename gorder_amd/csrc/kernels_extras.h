@@ -1,0 +1,523 @@
+// kernels_extras.h — scatter modes: ordermaps, timewise rows, geometry filter, united-atom hydrogens (k_bonds_extras, k_ua_extras, k_map_accumulate).
+// Part of the single translation unit gorder_hip.hip (included there, in this order: common, bonds, extras,
+// leaflets, normals); device code for gfx950 only.
+#pragma once
+
+namespace {
+
+// =============================================================================================
+// "Extras" kernels: ordermaps (ordermap.rs:100-113), timewise partial sums (timewise.rs:130-186,
+// 277-283) and the united-atom path (uaorder.rs:375-437, 947-1104).  These modes are bound by their
+// scatter atomics, not by the coordinate stream, so they use a plain structure: a thread owns one
+// sample (or one united-atom carbon), gathers its atoms straight from global memory and walks the
+// frames of its chunk one by one.  The main accumulators are kept in registers exactly like K1.
+// =============================================================================================
+struct ExtraArgs {
+    int maps;                        // ordermaps on
+    uint32_t plane;                  // 0 xy, 1 xz, 2 yz -> (z, y)   (input/ordermap.rs:44-50)
+    float x0, y0, binx, biny;
+    uint32_t nx, ny;
+    unsigned long long *map_packed;  // [leaflets ? 2 : 1][n_acc][nx*ny] packed (count << 42) + sum, see k_fold_maps
+    unsigned long long *map_rec;     // sample staging (k_map_accumulate): [tile][frame - rec_frame0][1 | 3][kBlock] or null
+    uint32_t rec_frame0, rec_frames;
+    const float4 *dyn;               // dynamic membrane normals [n_frames][n_mol_total] (nx, ny, nz, cloud size) or null
+    int tw;                          // timewise on
+    unsigned long long *tw_sums;     // [rows][3][n_acc]
+    unsigned long long *tw_cnts;     // [rows][3][n_acc]
+    unsigned long long tw_row0;      // row of this batch's frame 0
+    // united atoms: sin/cos of the construction angles, evaluated on the host with libm like the reference
+    float sin_tet, cos_tet, sin_ch3, cos_ch3, sin_half, cos_half;
+    // geometry selection (geometry.rs): per-frame shapes [n_frames][8] = anchor xyz, extents xyz, radius, height
+    int geom_kind, geom_invert, geom_orient;
+    const float *shapes;
+};
+
+// groan_rs Rectangular / Cylinder / Sphere ::inside (oracle: inside_shape), XOR invert (geometry.rs:181-189)
+__device__ __forceinline__ bool geom_inside(const ExtraArgs &e, const float *sh, float px, float py, float pz,
+                                            const float *box, bool pbc, int &bad) {
+    const float p[3] = {px, py, pz};
+    bool in = true;
+    if (e.geom_kind == GORDER_GEOM_CUBOID) {
+        for (int d = 0; d < 3; d++) {
+            float x = p[d] - sh[d];
+            if (pbc) { x = gm_wrap(x, box[d], bad); in = in && (x <= sh[3 + d]); }
+            else in = in && (x >= 0.0f) && (x <= sh[3 + d]);
+        }
+    } else if (e.geom_kind == GORDER_GEOM_CYLINDER) {
+        const int o = e.geom_orient, a = (o + 1) % 3, b = (o + 2) % 3;
+        float da = p[a] - sh[a], db = p[b] - sh[b], x = p[o] - sh[o];
+        if (pbc) { da = gm_min_image(da, box[a], bad); db = gm_min_image(db, box[b], bad); x = gm_wrap(x, box[o], bad); }
+        in = (__builtin_sqrtf(da * da + db * db) < sh[6]) && (pbc ? true : (x >= 0.0f)) && (x <= sh[7]);
+    } else {
+        float d[3];
+        for (int k = 0; k < 3; k++) { d[k] = p[k] - sh[k]; if (pbc) d[k] = gm_min_image(d[k], box[k], bad); }
+        in = __builtin_sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) < sh[6];
+    }
+    return in != (e.geom_invert != 0);
+}
+
+// groan_rs GridMap::get_mut_at: nearest tile centre, None outside (oracle: gridmap_index)
+__device__ __forceinline__ int grid_index(float x, float lo, float bin, uint32_t n) {
+    const float k = __builtin_roundf((x - lo) / bin);
+    if (!(k >= 0.0f) || !(k < (float)n)) return -1;
+    return (int)k;
+}
+
+// BondLike::add_order for the scatter targets (bond.rs:184-215): maps and the per-frame LDS partials
+__device__ __forceinline__ void extras_add(const FrameArgs &a, const ExtraArgs &e, uint32_t gslot, uint32_t lslot,
+                                           int tick, float px, float py, float pz, int leaflet /* -1 none */,
+                                           int *l_tw, uint32_t *l_twn, uint32_t lstride,
+                                           unsigned long long *rec = nullptr) {
+    if (e.maps) {
+        float x, y;
+        if (e.plane == 0) { x = px; y = py; }
+        else if (e.plane == 1) { x = px; y = pz; }
+        else { x = pz; y = py; }
+        const int ix = grid_index(x, e.x0, e.binx, e.nx), iy = grid_index(y, e.y0, e.biny, e.ny);
+        if (ix >= 0 && iy >= 0) {
+            // ONE atomic per sample: count and tick sum share a 64-bit word, and with leaflets only the
+            // sample's own leaflet plane is touched (total = upper + lower, bond.rs:199-213); k_fold_maps
+            // unpacks.  Scattered 64-bit atomics run at ~24 G/s on gfx950 whatever the scope or table size
+            // (tools/microbench/atomic_scatter.hip), so their number is what counts.
+            const size_t nt = (size_t)e.nx * e.ny, t = (size_t)ix * e.ny + (size_t)iy;
+            if (rec) {   // staged: (plane * tiles + tile) << 32 | tick, added to the map by k_map_accumulate
+                *rec = ((unsigned long long)((leaflet > 0 ? nt : 0) + t) << 32) | (unsigned long long)(uint32_t)tick;
+            } else {
+                const size_t w = leaflet > 0 ? a.n_acc : 0;
+                atomicAdd(&e.map_packed[(w + gslot) * nt + t], kMapOne + (unsigned long long)(long long)tick);
+            }
+        }
+    }
+    if (e.tw) {
+        atomicAdd(&l_tw[lslot], tick);
+        atomicAdd(&l_twn[lslot], 1u);
+        if (leaflet >= 0) {
+            atomicAdd(&l_tw[(1 + leaflet) * lstride + lslot], tick);
+            atomicAdd(&l_twn[(1 + leaflet) * lstride + lslot], 1u);
+        }
+    }
+}
+
+// flush the block's per-frame partial sums to the timewise rows (one frame)
+__device__ __forceinline__ void extras_flush_tw(const FrameArgs &a, const ExtraArgs &e, const uint32_t *slots,
+                                                uint32_t n_slots, uint32_t f, int *l_tw, uint32_t *l_twn,
+                                                uint32_t lstride) {
+    for (uint32_t ls = threadIdx.x; ls < n_slots; ls += blockDim.x) {
+        const size_t row = ((size_t)e.tw_row0 + f) * 3u * a.n_acc;
+        for (uint32_t w = 0; w < 3; w++) {
+            const uint32_t n = l_twn[w * lstride + ls];
+            if (n) {
+                atomicAdd(&e.tw_sums[row + (size_t)w * a.n_acc + slots[ls]],
+                          (unsigned long long)(long long)l_tw[w * lstride + ls]);
+                atomicAdd(&e.tw_cnts[row + (size_t)w * a.n_acc + slots[ls]], (unsigned long long)n);
+            }
+            l_tw[w * lstride + ls] = 0;
+            l_twn[w * lstride + ls] = 0;
+        }
+    }
+}
+
+template <bool ACOS_COS>
+__global__ __launch_bounds__(kBlock) void k_bonds_extras(FrameArgs a_in, ExtraArgs e, const float *__restrict__ xyz,
+                                                          const float *__restrict__ box9,
+                                                          const uint8_t *__restrict__ aflags,
+                                                          const uint32_t *__restrict__ arow,
+                                                          const Tile *__restrict__ tiles,
+                                                          const Item *__restrict__ items,
+                                                          const uint32_t *__restrict__ tile_slots, uint32_t n_tiles) {
+    __shared__ unsigned long long l_s[2 * kBlock];
+    __shared__ uint32_t l_n[2 * kBlock];
+    __shared__ int l_tw[3 * kBlock];
+    __shared__ uint32_t l_twn[3 * kBlock];
+    FrameArgs a = a_in;
+    a.xyz = xyz; a.box9 = box9; a.aflags = aflags; a.arow = arow;
+    const uint32_t tile_id = blockIdx.x % n_tiles, chunk = blockIdx.x / n_tiles;
+    const Tile t = tiles[tile_id];
+    const uint32_t tid = threadIdx.x;
+    const bool active = tid < t.n_items;
+    Item it{0, 0, 0, 0, 0};
+    if (active) it = items[t.item0 + tid];
+    const uint32_t gslot = active ? tile_slots[t.slot0 + it.lslot] : 0;
+    const uint32_t f_begin = a.frame0 + chunk * a.frames_per_chunk;
+    const uint32_t f_end = min(a.n_frames, f_begin + a.frames_per_chunk);
+    const size_t fstride = (size_t)a.n_atoms * 3u;
+    const float *pi = xyz + ((size_t)t.atom0 + it.li) * 3u;
+    const float *pj = xyz + ((size_t)t.atom0 + it.lj) * 3u;
+    for (uint32_t k = tid; k < 3 * kBlock; k += kBlock) { l_tw[k] = 0; l_twn[k] = 0; }
+    __syncthreads();
+    SampleAcc acc;
+    int bad = 0;
+    for (uint32_t f = f_begin; f < f_end; f++) {
+        unsigned long long rec = kMapNoSample;
+        if (active) {
+            const float *q1 = pi + (size_t)f * fstride, *q2 = pj + (size_t)f * fstride;
+            const float p1x = q1[0], p1y = q1[1], p1z = q1[2];
+            float vx = q2[0] - p1x, vy = q2[1] - p1y, vz = q2[2] - p1z;
+            if (a.pbc) {
+                const float *b = a.box9 + 9 * (size_t)f;
+                vx = gm_min_image(vx, b[0], bad);
+                vy = gm_min_image(vy, b[4], bad);
+                vz = gm_min_image(vz, b[8], bad);
+            }
+            if (p1x != p1x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, t.atom0 + it.li, f);
+            else if (q2[0] != q2[0]) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, t.atom0 + it.lj, f);
+            // bond position = p1 + v / 2 (bond.rs:422); geometry filter (bond.rs:424-426)
+            const float mx = p1x + vx / 2.0f, my = p1y + vy / 2.0f, mz = p1z + vz / 2.0f;
+            bool in = true;
+            if (e.geom_kind) {
+                float box[3] = {1.0f, 1.0f, 1.0f};
+                if (a.pbc) { const float *b = a.box9 + 9 * (size_t)f; box[0] = b[0]; box[1] = b[4]; box[2] = b[8]; }
+                in = geom_inside(e, e.shapes + 8 * (size_t)f, mx, my, mz, box, a.pbc != 0, bad);
+            }
+            if (in) {
+                float sch;
+                if (e.dyn) {   // the molecule's own normal of this frame, fetched after the geometry test (bond.rs:429-431)
+                    const float4 n = e.dyn[(size_t)f * a.n_mol_total + it.mol];
+                    if (n.w < 3.0f) raise_error(a.err, GORDER_ERR_DYNAMIC_NORMAL, (uint32_t)n.w, f);
+                    const float n2sq = (n.x * n.x + n.y * n.y) + n.z * n.z;
+                    sch = gm_calc_sch<ACOS_COS>(vx, vy, vz, n.x, n.y, n.z, __builtin_sqrtf(n2sq), n2sq);
+                } else {
+                    sch = gm_calc_sch<ACOS_COS>(vx, vy, vz, a.nx, a.ny, a.nz, a.n2, a.n2sq);
+                }
+                const int tick = gm_tick(sch);
+                int leaflet = -1;
+                if (a.leaflets) leaflet = a.aflags[(size_t)a.arow[f] * a.n_mol_total + it.mol] ? 1 : 0;
+                acc.s_tot += tick;
+                acc.n_tot += 1;
+                if (leaflet == 0) { acc.s_up += tick; acc.n_up += 1; }
+                extras_add(a, e, gslot, it.lslot, tick, mx, my, mz, leaflet, l_tw, l_twn, kBlock, e.map_rec ? &rec : nullptr);
+            }
+        }
+        if (e.map_rec) e.map_rec[((size_t)tile_id * e.rec_frames + (f - e.rec_frame0)) * kBlock + tid] = rec;
+        if (e.tw) {
+            __syncthreads();
+            extras_flush_tw(a, e, tile_slots + t.slot0, t.n_slots, f, l_tw, l_twn, kBlock);
+            __syncthreads();
+        }
+    }
+    if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f_begin);
+    l_s[tid] = 0; l_s[kBlock + tid] = 0; l_n[tid] = 0; l_n[kBlock + tid] = 0;
+    __syncthreads();
+    if (active && acc.n_tot) {
+        atomicAdd(&l_s[it.lslot], (unsigned long long)acc.s_tot);
+        atomicAdd(&l_n[it.lslot], acc.n_tot);
+        if (acc.n_up) {
+            atomicAdd(&l_s[kBlock + it.lslot], (unsigned long long)acc.s_up);
+            atomicAdd(&l_n[kBlock + it.lslot], acc.n_up);
+        }
+    }
+    __syncthreads();
+    if (tid < t.n_slots && l_n[tid]) {
+        unsigned long long *accp = a.rep + (size_t)(blockIdx.x % a.n_rep) * 4u * a.n_acc;
+        const uint32_t slot = tile_slots[t.slot0 + tid];
+        atomicAdd(&accp[slot], l_s[tid]);
+        atomicAdd(&accp[2u * a.n_acc + slot], (unsigned long long)l_n[tid]);
+        if (l_n[kBlock + tid]) {
+            atomicAdd(&accp[a.n_acc + slot], l_s[kBlock + tid]);
+            atomicAdd(&accp[3u * a.n_acc + slot], (unsigned long long)l_n[kBlock + tid]);
+        }
+    }
+}
+
+// ---- united atoms: hydrogen construction, restating uaorder.rs:947-1104 with the operation order of
+// nalgebra's Rotation3::from_axis_angle / matrix * vector and groan_rs' shift / wrap (oracle:
+// gorder_oracle_predict_hydrogens).  All f32, no FMA.
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 v3_cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ float v3_norm(V3 a) { return __builtin_sqrtf((a.x * a.x + a.y * a.y) + a.z * a.z); }
+__device__ __forceinline__ V3 v3_unit(V3 a) { const float n = v3_norm(a); return {a.x / n, a.y / n, a.z / n}; }
+__device__ __forceinline__ V3 v3_rotate(V3 u, float s, float c, V3 v) {
+    const float sqx = u.x * u.x, sqy = u.y * u.y, sqz = u.z * u.z, omc = 1.0f - c;
+    const float m11 = sqx + (1.0f - sqx) * c, m12 = u.x * u.y * omc - u.z * s, m13 = u.x * u.z * omc + u.y * s;
+    const float m21 = u.x * u.y * omc + u.z * s, m22 = sqy + (1.0f - sqy) * c, m23 = u.y * u.z * omc - u.x * s;
+    const float m31 = u.x * u.z * omc - u.y * s, m32 = u.y * u.z * omc + u.x * s, m33 = sqz + (1.0f - sqz) * c;
+    return {(m11 * v.x + m12 * v.y) + m13 * v.z, (m21 * v.x + m22 * v.y) + m23 * v.z,
+            (m31 * v.x + m32 * v.y) + m33 * v.z};
+}
+// Periodic-boundary policies for the hydrogen construction.  PbcStep does one select-only shift per
+// operation and raises `slow` when that was not enough; PbcLoop is the literal `while` form of the
+// reference.  The kernel evaluates a carbon with PbcStep and, only if `slow` came up, again with PbcLoop.
+// (all state in scalars and every aggregate passed by value: nothing here may end up in scratch)
+struct PbcStep {
+    V3 box;
+    bool pbc;
+    bool slow = false;
+    int bad = 0;
+    __device__ __forceinline__ float len(int k) const { return k == 0 ? box.x : (k == 1 ? box.y : box.z); }
+    __device__ __forceinline__ float mi(float d, int k) { return pbc ? gm_min_image_step(d, len(k), slow) : d; }
+    __device__ __forceinline__ float wr(float x, int k) {
+        if (!pbc) return x;
+        const float L = len(k);
+        const float r = x > L ? x - L : (x < 0.0f ? x + L : x);
+        slow = slow || (r > L) || (r < 0.0f);
+        return r;
+    }
+};
+struct PbcLoop {
+    V3 box;
+    bool pbc;
+    bool slow = false;
+    int bad = 0;
+    __device__ __forceinline__ float len(int k) const { return k == 0 ? box.x : (k == 1 ? box.y : box.z); }
+    __device__ __forceinline__ float mi(float d, int k) { return pbc ? gm_min_image_loop(d, len(k), bad) : d; }
+    __device__ __forceinline__ float wr(float x, int k) { return pbc ? gm_wrap(x, len(k), bad) : x; }
+};
+template <typename PB>
+__device__ __forceinline__ V3 v3_to(V3 p1, V3 p2, PB &pb) {
+    return {pb.mi(p2.x - p1.x, 0), pb.mi(p2.y - p1.y, 1), pb.mi(p2.z - p1.z, 2)};
+}
+template <typename PB>
+__device__ __forceinline__ V3 v3_shift_wrap(V3 t, V3 dir, PB &pb) {
+    const V3 u = v3_unit(dir);
+    return {pb.wr(t.x + u.x * 0.109f, 0), pb.wr(t.y + u.y * 0.109f, 1), pb.wr(t.z + u.z * 0.109f, 2)};   // BOND_LENGTH
+}
+
+struct UaConsts {
+    float sin_tet, cos_tet, sin_ch3, cos_ch3, sin_half, cos_half;
+};
+struct UaCarbon {       // the carbon's atoms: helper1,target,helper2,- or h1,h2,h3,target (CH1 saturated)
+    V3 p0, p1, p2, p3;
+};
+struct UaBonds {        // per hydrogen: the C->H vector and the bond position (unused entries are zero)
+    V3 v0, v1, v2, b0, b1, b2;
+    int bad;
+};
+
+// hydrogens of one united-atom carbon, then per hydrogen the C->H vector and the bond position
+// (UAAtom::calculate_sch, uaorder.rs:375-397: vec = target -> H, position = H + vec / 2 (sic))
+template <typename PB>
+__device__ __forceinline__ UaBonds ua_carbon(uint32_t kind, UaCarbon c, UaConsts e, PB &pb) {
+    const V3 zero{0.0f, 0.0f, 0.0f};
+    V3 h0 = zero, h1 = zero, h2 = zero, target = c.p1;
+    if (kind == GORDER_UA_CH3) {            // uaorder.rs:947-981
+        const V3 th1 = v3_to(target, c.p0, pb), th2 = v3_to(target, c.p2, pb);
+        const V3 ua = v3_unit(v3_cross(th2, th1));
+        const V3 hv1 = v3_rotate(ua, e.sin_tet, e.cos_tet, th1);
+        h0 = v3_shift_wrap(target, hv1, pb);
+        const V3 n1 = v3_unit(th1);
+        h1 = v3_shift_wrap(target, v3_rotate(n1, e.sin_ch3, e.cos_ch3, hv1), pb);
+        h2 = v3_shift_wrap(target, v3_rotate(n1, -e.sin_ch3, e.cos_ch3, hv1), pb);
+    } else if (kind == GORDER_UA_CH2) {     // uaorder.rs:985-1020
+        const V3 th1 = v3_unit(v3_to(target, c.p0, pb)), th2 = v3_unit(v3_to(target, c.p2, pb));
+        const V3 pn = v3_cross(th2, th1);
+        const V3 ra = v3_unit(V3{th1.x - th2.x, th1.y - th2.y, th1.z - th2.z});
+        const V3 rv = v3_cross(pn, ra);
+        const V3 ura = v3_unit(ra);
+        h0 = v3_shift_wrap(target, v3_rotate(ura, e.sin_half, e.cos_half, rv), pb);
+        h1 = v3_shift_wrap(target, v3_rotate(ura, -e.sin_half, e.cos_half, rv), pb);
+    } else if (kind == GORDER_UA_CH1_UNSAT) {   // uaorder.rs:1024-1045
+        const V3 th1 = v3_to(target, c.p0, pb), th2 = v3_to(target, c.p2, pb);
+        const float prod = (th1.x * th2.x + th1.y * th2.y) + th1.z * th2.z;
+        const float n1 = v3_norm(th1), n2 = v3_norm(th2);
+        float gamma = 0.0f;
+        if (!(n1 == 0.0f || n2 == 0.0f)) {
+            float cs = prod / (n1 * n2);
+            cs = cs < -1.0f ? -1.0f : (cs > 1.0f ? 1.0f : cs);
+            gamma = gm_acosf(cs);
+        }
+        const float ang = 3.14159265358979323846f - (gamma / 2.0f);
+        float sn, cs;
+        sincosf(ang, &sn, &cs);
+        const V3 ua = v3_unit(v3_cross(th1, th2));
+        h0 = v3_shift_wrap(target, ang == 0.0f ? th2 : v3_rotate(ua, sn, cs, th2), pb);
+    } else {                                // CH1 saturated, uaorder.rs:1087-1104 (h1, h2, h3, target)
+        target = c.p3;
+        const V3 t1 = v3_unit(v3_to(target, c.p0, pb)), t2 = v3_unit(v3_to(target, c.p1, pb)),
+                 t3 = v3_unit(v3_to(target, c.p2, pb));
+        h0 = v3_shift_wrap(target, V3{-((t1.x + t2.x) + t3.x), -((t1.y + t2.y) + t3.y), -((t1.z + t2.z) + t3.z)}, pb);
+    }
+    UaBonds r;
+    r.v0 = v3_to(target, h0, pb);
+    r.b0 = {h0.x + r.v0.x / 2.0f, h0.y + r.v0.y / 2.0f, h0.z + r.v0.z / 2.0f};
+    r.v1 = r.v2 = r.b1 = r.b2 = zero;
+    if (kind == GORDER_UA_CH3 || kind == GORDER_UA_CH2) {
+        r.v1 = v3_to(target, h1, pb);
+        r.b1 = {h1.x + r.v1.x / 2.0f, h1.y + r.v1.y / 2.0f, h1.z + r.v1.z / 2.0f};
+    }
+    if (kind == GORDER_UA_CH3) {
+        r.v2 = v3_to(target, h2, pb);
+        r.b2 = {h2.x + r.v2.x / 2.0f, h2.y + r.v2.y / 2.0f, h2.z + r.v2.z / 2.0f};
+    }
+    r.bad = pb.bad;
+    return r;
+}
+// the literal-loop variant, kept out of line: it runs only for carbons more than 1.5 box lengths away
+// from a helper
+__device__ __noinline__ UaBonds ua_carbon_slow(uint32_t kind, UaCarbon c, UaConsts e, V3 box, bool pbc) {
+    PbcLoop pl{box, pbc};
+    return ua_carbon(kind, c, e, pl);
+}
+
+template <bool ACOS_COS, bool EXTRAS>
+__global__ __launch_bounds__(kBlock) void k_ua_extras(FrameArgs a_in, ExtraArgs e, const float *__restrict__ xyz,
+                                                       const float *__restrict__ box9,
+                                                       const uint8_t *__restrict__ aflags,
+                                                       const uint32_t *__restrict__ arow,
+                                                       const Tile *__restrict__ tiles,
+                                                       const gorder::UaItem *__restrict__ items,
+                                                       const uint32_t *__restrict__ tile_slots, uint32_t n_tiles) {
+    constexpr uint32_t LS = 3 * kBlock;   // local slots per block (<= 3 hydrogens per carbon)
+    __shared__ unsigned long long l_s[2 * LS];
+    __shared__ uint32_t l_n[2 * LS];
+    __shared__ int l_tw[EXTRAS ? 3 * LS : 1];
+    __shared__ uint32_t l_twn[EXTRAS ? 3 * LS : 1];
+    FrameArgs a = a_in;
+    a.xyz = xyz; a.box9 = box9; a.aflags = aflags; a.arow = arow;
+    const uint32_t tile_id = blockIdx.x % n_tiles, chunk = blockIdx.x / n_tiles;
+    const Tile t = tiles[tile_id];
+    const uint32_t tid = threadIdx.x;
+    const bool active = tid < t.n_items;
+    gorder::UaItem it{};
+    if (active) it = items[t.item0 + tid];
+    const uint32_t kind = it.kind;
+    const int nh = kind == GORDER_UA_CH3 ? 3 : (kind == GORDER_UA_CH2 ? 2 : 1);
+    const uint32_t gslot0 = active ? tile_slots[t.slot0 + it.lslot0] : 0;
+    const uint32_t f_begin = a.frame0 + chunk * a.frames_per_chunk;
+    const uint32_t f_end = min(a.n_frames, f_begin + a.frames_per_chunk);
+    const size_t fstride = (size_t)a.n_atoms * 3u;
+    if (EXTRAS)
+        for (uint32_t k = tid; k < 3 * LS; k += kBlock) { l_tw[k] = 0; l_twn[k] = 0; }
+    for (uint32_t k = tid; k < 2 * LS; k += kBlock) { l_s[k] = 0; l_n[k] = 0; }
+    __syncthreads();
+    long long s_tot[3] = {0, 0, 0}, s_up[3] = {0, 0, 0};
+    uint32_t n_tot[3] = {0, 0, 0}, n_up[3] = {0, 0, 0};
+    int bad = 0;
+    const bool pbc = a.pbc != 0;
+    const UaConsts uc{e.sin_tet, e.cos_tet, e.sin_ch3, e.cos_ch3, e.sin_half, e.cos_half};
+    const float *src[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) src[q] = xyz + ((size_t)t.atom0 + (active ? it.l[q] : 0u)) * 3u;
+    auto fetch = [&](uint32_t f) {
+        UaCarbon c;
+        const size_t o = (size_t)f * fstride;
+        c.p0 = {src[0][o], src[0][o + 1], src[0][o + 2]};
+        c.p1 = {src[1][o], src[1][o + 1], src[1][o + 2]};
+        c.p2 = {src[2][o], src[2][o + 1], src[2][o + 2]};
+        c.p3 = {src[3][o], src[3][o + 1], src[3][o + 2]};
+        return c;
+    };
+    for (uint32_t f = f_begin; f < f_end; f++) {
+        if (active) {
+            const UaCarbon c = fetch(f);
+            V3 bx3{1.0f, 1.0f, 1.0f};
+            if (pbc) { const float *b = a.box9 + 9 * (size_t)f; bx3 = {b[0], b[4], b[8]}; }
+            if (c.p0.x != c.p0.x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, t.atom0 + it.l[0], f);
+            if (c.p1.x != c.p1.x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, t.atom0 + it.l[1], f);
+            if (c.p2.x != c.p2.x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, t.atom0 + it.l[2], f);
+            if (c.p3.x != c.p3.x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, t.atom0 + it.l[3], f);
+            PbcStep ps{bx3, pbc};
+            UaBonds ub = ua_carbon(kind, c, uc, ps);
+            if (__builtin_expect(ps.slow, 0)) {
+                ub = ua_carbon_slow(kind, c, uc, bx3, pbc);
+                bad |= ub.bad;
+            }
+            int leaflet = -1;
+            if (a.leaflets) leaflet = a.aflags[(size_t)a.arow[f] * a.n_mol_total + it.mol] ? 1 : 0;
+            float nrx = a.nx, nry = a.ny, nrz = a.nz, nr2 = a.n2, nr2sq = a.n2sq;
+            if (EXTRAS && e.dyn) {   // fetched for every molecule, before the geometry test (uaorder.rs:412-413)
+                const float4 n = e.dyn[(size_t)f * a.n_mol_total + it.mol];
+                if (n.w < 3.0f) raise_error(a.err, GORDER_ERR_DYNAMIC_NORMAL, (uint32_t)n.w, f);
+                nrx = n.x; nry = n.y; nrz = n.z;
+                nr2sq = (n.x * n.x + n.y * n.y) + n.z * n.z;
+                nr2 = __builtin_sqrtf(nr2sq);
+            }
+            unsigned long long recs[3] = {kMapNoSample, kMapNoSample, kMapNoSample};
+            auto sample = [&](const int k, const V3 v, const V3 b) {
+                if (k >= nh) return;
+                const float sch = gm_calc_sch<ACOS_COS>(v.x, v.y, v.z, nrx, nry, nrz, nr2, nr2sq);
+                const int tick = gm_tick(sch);
+                if (EXTRAS) {
+                    const float box[3] = {bx3.x, bx3.y, bx3.z};
+                    if (e.geom_kind && !geom_inside(e, e.shapes + 8 * (size_t)f, b.x, b.y, b.z, box, pbc, bad)) return;
+                }
+                s_tot[k] += tick;
+                n_tot[k] += 1;
+                if (leaflet == 0) { s_up[k] += tick; n_up[k] += 1; }
+                if (EXTRAS)
+                    extras_add(a, e, gslot0 + (uint32_t)k, it.lslot0 + (uint32_t)k, tick, b.x, b.y, b.z, leaflet, l_tw, l_twn, LS,
+                               e.map_rec ? &recs[k] : nullptr);
+            };
+            sample(0, ub.v0, ub.b0);
+            sample(1, ub.v1, ub.b1);
+            sample(2, ub.v2, ub.b2);
+            if (EXTRAS && e.map_rec) {   // every lane of the tile writes its three entries: coalesced rows of kBlock words
+                unsigned long long *row = e.map_rec + (((size_t)tile_id * e.rec_frames + (f - e.rec_frame0)) * 3u) * kBlock + tid;
+                row[0] = recs[0]; row[kBlock] = recs[1]; row[2u * kBlock] = recs[2];
+            }
+        } else if (EXTRAS && e.map_rec) {
+            unsigned long long *row = e.map_rec + (((size_t)tile_id * e.rec_frames + (f - e.rec_frame0)) * 3u) * kBlock + tid;
+            row[0] = kMapNoSample; row[kBlock] = kMapNoSample; row[2u * kBlock] = kMapNoSample;
+        }
+        if (EXTRAS && e.tw) {
+            __syncthreads();
+            extras_flush_tw(a, e, tile_slots + t.slot0, t.n_slots, f, l_tw, l_twn, LS);
+            __syncthreads();
+        }
+    }
+    if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f_begin);
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            if (!n_tot[k]) continue;
+            atomicAdd(&l_s[it.lslot0 + k], (unsigned long long)s_tot[k]);
+            atomicAdd(&l_n[it.lslot0 + k], n_tot[k]);
+            if (n_up[k]) {
+                atomicAdd(&l_s[LS + it.lslot0 + k], (unsigned long long)s_up[k]);
+                atomicAdd(&l_n[LS + it.lslot0 + k], n_up[k]);
+            }
+        }
+    }
+    __syncthreads();
+    unsigned long long *accp = a.rep + (size_t)(blockIdx.x % a.n_rep) * 4u * a.n_acc;
+    for (uint32_t ls = tid; ls < t.n_slots; ls += kBlock) {
+        if (!l_n[ls]) continue;
+        const uint32_t slot = tile_slots[t.slot0 + ls];
+        atomicAdd(&accp[slot], l_s[ls]);
+        atomicAdd(&accp[2u * a.n_acc + slot], (unsigned long long)l_n[ls]);
+        if (l_n[LS + ls]) {
+            atomicAdd(&accp[a.n_acc + slot], l_s[LS + ls]);
+            atomicAdd(&accp[3u * a.n_acc + slot], (unsigned long long)l_n[LS + ls]);
+        }
+    }
+}
+
+// ---- ordermaps of the united-atom path, second step -----------------------------------------------
+// k_ua_extras stages every sample as (plane-tile << 32 | tick) in tile order (coalesced rows); here a block
+// owns ONE accumulator slot for a range of frames: it gathers the slot's samples (runs of consecutive lanes,
+// gorder::MapRun), adds them into a packed map held in LDS (ds_add_u64) and flushes the tiles it touched
+// into the global packed map with one atomic each.  Scattered global atomics run at ~24 G/s on this chip
+// whatever one does (tools/microbench/atomic_scatter.hip); this way their number drops from one per sample to
+// at most one per (slot, chunk, tile).
+__global__ __launch_bounds__(1024) void k_map_accumulate(const unsigned long long *__restrict__ rec,
+                                                         const gorder::MapRun *__restrict__ runs,
+                                                         const uint32_t *__restrict__ run_begin, uint32_t n_slots,
+                                                         uint32_t rec_frames, uint32_t frames_per_chunk, uint32_t k_max,
+                                                         uint32_t n_words /* planes * tiles */, uint32_t n_tiles_map,
+                                                         unsigned long long *__restrict__ map_packed, uint32_t n_acc) {
+    extern __shared__ unsigned long long l_map[];
+    const uint32_t slot = blockIdx.x % n_slots, chunk = blockIdx.x / n_slots;
+    const uint32_t r0 = run_begin[slot], r1 = run_begin[slot + 1];
+    if (r0 == r1) return;                               // no samples of this kind (bond / united atom) in the slot
+    const uint32_t f0 = chunk * frames_per_chunk, f1 = min(rec_frames, f0 + frames_per_chunk);
+    for (uint32_t w = threadIdx.x; w < n_words; w += blockDim.x) l_map[w] = 0ull;
+    __syncthreads();
+    for (uint32_t r = r0; r < r1; r++) {
+        const gorder::MapRun run = runs[r];
+        const uint32_t total = (f1 - f0) * run.n;
+        for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) {
+            const uint32_t f = f0 + i / run.n, j = i % run.n;
+            const unsigned long long v = rec[(((size_t)run.tile * rec_frames + f) * k_max + run.k) * kBlock + run.tid0 + j];
+            if (v != kMapNoSample)
+                atomicAdd(&l_map[(uint32_t)(v >> 32)], kMapOne + (unsigned long long)(long long)(int)(uint32_t)v);
+        }
+    }
+    __syncthreads();
+    for (uint32_t w = threadIdx.x; w < n_words; w += blockDim.x) {
+        const unsigned long long v = l_map[w];
+        if (!v) continue;
+        const uint32_t plane = w / n_tiles_map, t = w % n_tiles_map;
+        atomicAdd(&map_packed[((size_t)plane * n_acc + slot) * n_tiles_map + t], v);
+    }
+}
+
+}  // namespace

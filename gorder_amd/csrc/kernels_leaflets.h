@@ -1,0 +1,684 @@
+// kernels_leaflets.h — leaflet classifiers (global, individual, local) and the per-frame shapes of the geometry selection.
+// Part of the single translation unit gorder_hip.hip (included there, in this order: common, bonds, extras,
+// leaflets, normals); device code for gfx950 only.
+#pragma once
+
+namespace {
+
+// ---- leaflets ------------------------------------------------------------------------------
+struct LeafletArgs {
+    const float *xyz;
+    const float *box9;
+    uint32_t n_atoms;
+    const uint32_t *aframes;   // [n_assign] local frame index of each assignment frame
+    uint32_t row0;             // first output row
+    uint8_t *aflags;           // [rows][n_mol_total]
+    float *adist;              // [n_mol_total] signed distance of the LAST assignment frame (debug/tests)
+    uint32_t n_mol_total;
+    const uint32_t *heads;     // [n_mol_total] head atom per molecule
+    const uint32_t *membrane;  // Global: membrane atom list
+    uint32_t n_membrane;
+    const uint32_t *methyl_begin;  // Individual: [n_mol_total+1] ranges into methyl_atoms
+    const uint32_t *methyl_atoms;
+    uint32_t dim;
+    int flip, pbc;
+    uint32_t *err;
+};
+
+// cos / sin of 2*pi*u by the hardware v_cos_f32 / v_sin_f32 (argument in revolutions, ~1e-6 absolute
+// error).  Used only for the Bai-Breen circular-mean ESTIMATE: the estimate merely anchors the
+// minimum-image refinement pass that produces the centre, so its last digits do not matter.
+__device__ __forceinline__ void fast_sincos_rev(float u, float *sn, float *cs) {
+    *sn = __builtin_amdgcn_sinf(u);
+    *cs = __builtin_amdgcn_cosf(u);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// deterministic block reduction: butterfly inside each wave, then every thread adds the <= 16 wave
+// totals in the same order (2 barriers)
+__device__ __forceinline__ double block_sum(double v, double *scratch) {
+    v = wave_sum(v);
+    const uint32_t wave = threadIdx.x >> 6, n_waves = (blockDim.x + 63u) >> 6;
+    if ((threadIdx.x & 63u) == 0) scratch[wave] = v;
+    __syncthreads();
+    double r = 0.0;
+    for (uint32_t w = 0; w < n_waves; w++) r += scratch[w];
+    __syncthreads();
+    return r;
+}
+
+// ---- per-frame shapes of the geometry selection: GeometrySelection::init_reference (geometry.rs:192-210)
+// + construct_shape (geometry.rs:328-357, 422-451, 507-514).  One block per frame; a group reference needs
+// the centre of geometry of the group (refined Bai-Breen, like the global membrane centre).
+struct GeomArgs {
+    const float *xyz;
+    const float *box9;
+    uint32_t n_atoms;
+    int pbc;
+    uint32_t kind, reference, orientation;
+    float point[3];
+    const uint32_t *group;
+    uint32_t n_group;
+    float xdim[2], ydim[2], zdim[2], radius, span[2], structure_box[3];
+    float *shapes;   // [n_frames][8]
+    uint32_t *err;
+};
+
+__global__ __launch_bounds__(256) void k_geom_shapes(GeomArgs g) {
+    __shared__ double scratch[256];
+    const uint32_t f = blockIdx.x;
+    float box[3] = {1.0f, 1.0f, 1.0f};
+    if (g.pbc) { const float *b = g.box9 + 9 * (size_t)f; box[0] = b[0]; box[1] = b[4]; box[2] = b[8]; }
+    int bad = 0;
+    float ref[3] = {g.point[0], g.point[1], g.point[2]};
+    float shape_box[3] = {box[0], box[1], box[2]};
+    if (g.reference == GORDER_GEOMREF_BOX_CENTER) {
+        for (int d = 0; d < 3; d++) ref[d] = box[d] / 2.0f;
+    } else if (g.reference == GORDER_GEOMREF_GROUP) {
+        const float *x = g.xyz + (size_t)f * g.n_atoms * 3u;
+        float est[3] = {0.0f, 0.0f, 0.0f};
+        if (g.pbc) {
+            double sc[3] = {0, 0, 0}, ss[3] = {0, 0, 0};
+            for (uint32_t i = threadIdx.x; i < g.n_group; i += blockDim.x) {
+                const float *p = x + 3u * (size_t)g.group[i];
+                for (int d = 0; d < 3; d++) {
+                    float sn, cs;
+                    fast_sincos_rev(gm_wrap(p[d], box[d], bad) / box[d], &sn, &cs);
+                    sc[d] += (double)cs;
+                    ss[d] += (double)sn;
+                }
+            }
+            for (int d = 0; d < 3; d++) {
+                const double tc = block_sum(sc[d], scratch), ts = block_sum(ss[d], scratch);
+                est[d] = (atan2f(-(float)ts, -(float)tc) + 3.1415927f) / (6.2831855f / box[d]);
+            }
+        }
+        // Refinement = plain centre of the atoms' images nearest to the estimate, summed in f32 in atom
+        // order like the reference does: a sample 1 ulp from the shape's surface depends on the last bit
+        // of this centre (the golden aa_order_sphere_dynamic.yaml has one), so the order of the sum is
+        // part of the result.  One thread per frame does it; reference groups are small (a residue, a
+        // protein), and the estimate above only selects the images, its own last bits do not matter.
+        if (threadIdx.x == 0) {
+            float acc[3] = {0.0f, 0.0f, 0.0f};
+            for (uint32_t i = 0; i < g.n_group; i++) {
+                const float *p = x + 3u * (size_t)g.group[i];
+                for (int d = 0; d < 3; d++)
+                    acc[d] += g.pbc ? est[d] + gm_min_image(p[d] - est[d], box[d], bad) : p[d];
+            }
+            for (int d = 0; d < 3; d++) {
+                const float c = acc[d] / (float)g.n_group;
+                ref[d] = g.pbc ? gm_wrap(c, box[d], bad) : c;
+            }
+        }
+    } else {
+        for (int d = 0; d < 3; d++) shape_box[d] = g.structure_box[d];   // fixed point: built once, structure box
+    }
+    if (threadIdx.x == 0) {
+        const float anchor = g.pbc ? 0.0f : -3.40282347e+38f;   // get_infinite_span, pbc.rs:236-240, 392-396
+        const float inf = __builtin_inff();
+        float sh[8] = {ref[0], ref[1], ref[2], 0.0f, 0.0f, 0.0f, g.radius, 0.0f};
+        if (g.kind == GORDER_GEOM_CUBOID) {
+            const float *dims[3] = {g.xdim, g.ydim, g.zdim};
+            for (int d = 0; d < 3; d++) {
+                if (dims[d][0] == -inf && dims[d][1] == inf) { sh[d] = anchor; sh[3 + d] = inf; }
+                else { sh[d] = ref[d] + dims[d][0]; sh[3 + d] = dims[d][1] - dims[d][0]; }
+            }
+        } else if (g.kind == GORDER_GEOM_CYLINDER) {
+            const int o = (int)g.orientation;
+            if (g.span[0] == -inf && g.span[1] == inf) { sh[o] = anchor; sh[7] = inf; }
+            else { sh[o] = ref[o] + g.span[0]; sh[7] = g.span[1] - g.span[0]; }
+        }
+        if (g.pbc) for (int d = 0; d < 3; d++) sh[d] = gm_wrap(sh[d], shape_box[d], bad);
+        for (int k = 0; k < 8; k++) g.shapes[8 * (size_t)f + k] = sh[k];
+    }
+    if (bad) raise_error(g.err, GORDER_ERR_BOX_RANGE, 0, f);
+}
+
+// One block per assignment frame: refined Bai-Breen centre of the membrane group
+// (leaflets.rs:186-197 -> groan_rs group_get_center) followed by common_identify_leaflet
+// (leaflets.rs:711-732) for every molecule.  Per-thread f32 partial sums are combined in f64 (the
+// reference sums f32 sequentially; only the sign of head - centre is consumed).
+__global__ __launch_bounds__(1024) void k_leaflets_global(LeafletArgs a) {
+    __shared__ double scratch[16];
+    __shared__ float s_center;
+    const uint32_t f = a.aframes[blockIdx.x];
+    const float *x = a.xyz + (size_t)f * a.n_atoms * 3u;
+    const uint32_t dn = a.dim;
+    float L = 1.0f;
+    if (a.pbc) L = a.box9[9 * (size_t)f + 4 * dn];
+    int bad = 0;
+    // Only the component of the centre along the normal is consumed (leaflets.rs:725); the other two
+    // matter only through the reference's NaN check (leaflets.rs:190-192): a non-finite coordinate of
+    // any membrane atom makes the centre NaN -> InvalidGlobalMembraneCenter.
+    float nonfinite = 0.0f;   // stays 0 while every coordinate is finite (x - x is 0 or NaN)
+    float est = 0.0f;
+    // the first KEEP normal-coordinates of each thread stay in registers for the second pass
+    constexpr int KEEP = 32;
+    float keep[KEEP];
+    const uint32_t nthr = blockDim.x;
+    float sc = 0.0f, ss = 0.0f;   // per-thread partials (<= n/1024 terms), combined in f64 below
+    const float inv = a.pbc ? 1.0f / L : 0.0f;
+    // batches of 8 atoms: the 24 loads of a batch are issued back to back (index clamped: lanes past the
+    // end re-read the last atom and are masked out), then the batch is consumed
+#pragma unroll
+    for (int kb = 0; kb < KEEP; kb += 8) {
+        float nf8[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t i = threadIdx.x + (uint32_t)(kb + k) * nthr;
+            const float *p = x + 3u * (size_t)a.membrane[i < a.n_membrane ? i : a.n_membrane - 1u];
+            const float px = p[0], py = p[1], pz = p[2];
+            nf8[k] = ((px - px) + (py - py)) + (pz - pz);
+            keep[kb + k] = dn == 0 ? px : (dn == 1 ? py : pz);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const bool valid = threadIdx.x + (uint32_t)(kb + k) * nthr < a.n_membrane;
+            nonfinite += valid ? nf8[k] : 0.0f;
+            if (a.pbc) {
+                float sn, cs;
+                fast_sincos_rev(gm_wrap(keep[kb + k], L, bad) * inv, &sn, &cs);
+                sc += valid ? cs : 0.0f;
+                ss += valid ? sn : 0.0f;
+            }
+        }
+    }
+    for (uint32_t i = threadIdx.x + (uint32_t)KEEP * nthr; i < a.n_membrane; i += nthr) {   // very large groups
+        const float *p = x + 3u * (size_t)a.membrane[i];
+        const float px = p[0], py = p[1], pz = p[2];
+        nonfinite += ((px - px) + (py - py)) + (pz - pz);
+        if (a.pbc) {
+            float sn, cs;
+            fast_sincos_rev(gm_wrap(dn == 0 ? px : (dn == 1 ? py : pz), L, bad) * inv, &sn, &cs);
+            sc += cs;
+            ss += sn;
+        }
+    }
+    if (a.pbc) {
+        const double tc = block_sum((double)sc, scratch), ts = block_sum((double)ss, scratch);
+        est = (atan2f(-(float)ts, -(float)tc) + 3.1415927f) / (6.2831855f / L);
+    }
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < KEEP; k++) {
+        const uint32_t i = threadIdx.x + (uint32_t)k * nthr;
+        if (i < a.n_membrane) {
+            const float dx = keep[k] - est;
+            acc += a.pbc ? gm_min_image(dx, L, bad) : dx;
+        }
+    }
+    for (uint32_t i = threadIdx.x + (uint32_t)KEEP * nthr; i < a.n_membrane; i += nthr) {
+        const float dx = x[3u * (size_t)a.membrane[i] + dn] - est;
+        acc += a.pbc ? gm_min_image(dx, L, bad) : dx;
+    }
+    const double tot = block_sum((double)acc, scratch);
+    const double nf = block_sum((double)nonfinite, scratch);
+    if (threadIdx.x == 0) {
+        float c = est + (float)(tot / (double)a.n_membrane);
+        if (a.pbc) c = gm_wrap(c, L, bad);
+        if (c != c || nf != 0.0 || a.n_membrane == 0) {
+            raise_error(a.err, GORDER_ERR_INVALID_GLOBAL_MEMBRANE_CENTER, 0, f);
+            c = __builtin_nanf("");
+        }
+        s_center = c;
+    }
+    __syncthreads();
+    const float cdim = s_center;
+    uint8_t *row = a.aflags + (size_t)(a.row0 + blockIdx.x) * a.n_mol_total;
+    const bool last = blockIdx.x + 1 == gridDim.x;
+    for (uint32_t m = threadIdx.x; m < a.n_mol_total; m += blockDim.x) {
+        const float hp = x[3u * (size_t)a.heads[m] + dn];
+        float d = hp - cdim;
+        if (a.pbc) d = gm_min_image(d, L, bad);
+        row[m] = (uint8_t)((d >= 0.0f ? 0 : 1) ^ (a.flip ? 1 : 0));
+        if (last && a.adist) a.adist[m] = d;
+    }
+    if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f);
+}
+
+// grid = (ceil(n_mol/256), n_assign).  IndividualClassification::identify_leaflet, leaflets.rs:777-801:
+// sequential f32 sum of signed head-methyl distances along the normal.
+__global__ __launch_bounds__(256) void k_leaflets_individual(LeafletArgs a) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= a.n_mol_total) return;
+    const uint32_t f = a.aframes[blockIdx.y];
+    const float *x = a.xyz + (size_t)f * a.n_atoms * 3u;
+    float L = 1.0f;
+    if (a.pbc) L = a.box9[9 * (size_t)f + 4 * a.dim];
+    int bad = 0;
+    const float hp = x[3u * (size_t)a.heads[m] + a.dim];
+    float total = 0.0f;
+    for (uint32_t k = a.methyl_begin[m]; k < a.methyl_begin[m + 1]; k++) {
+        const float mp = x[3u * (size_t)a.methyl_atoms[k] + a.dim];
+        const float d = hp - mp;
+        total += a.pbc ? gm_min_image(d, L, bad) : d;
+    }
+    a.aflags[(size_t)(a.row0 + blockIdx.y) * a.n_mol_total + m] =
+        (uint8_t)((total >= 0.0f ? 0 : 1) ^ (a.flip ? 1 : 0));
+    if (blockIdx.y + 1 == gridDim.y && a.adist) a.adist[m] = total;
+    if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f);
+}
+
+// ---- Local leaflets (LocalClassification, leaflets.rs:661-675 -> PBC3D::calc_local_membrane_centers,
+// pbc.rs:273-318; NoPBC: pbc.rs:107-139) ---------------------------------------------------------
+// For every lipid head: centre of geometry (refined Bai-Breen, like the global centre) of the membrane
+// atoms whose in-plane minimum-image distance from the head is < radius (an infinite cylinder along the
+// normal), then common_identify_leaflet (leaflets.rs:711-732).  The reference prunes the search with a
+// CellGrid of cell edge = radius (neighbours +-1 in-plane, all cells along the normal, pbc.rs:287-292);
+// here: a 2-D in-plane cell list per assignment frame, cell edge >= radius, built on the device.
+//   k_local_bin     : per (slab frame, membrane atom): cell id, count
+//   k_local_scan    : per slab frame: exclusive scan of the cell counts (one block)
+//   k_local_scatter : per (slab frame, membrane atom): cell-ordered record (coordinates + cos/sin)
+//   k_local_flags   : one wave per (slab frame, head): two passes over the 3x3 neighbour cells
+constexpr uint32_t kLocalMaxCells1D = 128;
+constexpr uint32_t kLocalSlab = 32;   // assignment frames processed per launch group
+
+struct LocalArgs {
+    const float *xyz;
+    const float *box9;
+    uint32_t n_atoms;
+    const uint32_t *aframes;    // [n_slab] local frame index of each assignment frame of this slab;
+                                // null: the slab is the frame range frame0 .. frame0 + n_slab - 1
+    uint32_t frame0;
+    uint32_t n_slab;
+    uint32_t row0;
+    uint8_t *aflags;
+    float *adist;               // written for the last frame of the whole batch only (may be null)
+    int write_dist_frame;       // slab-local index whose distances go to adist (-1: none)
+    uint32_t n_mol_total;
+    const uint32_t *heads;
+    const uint32_t *membrane;
+    uint32_t n_membrane;
+    uint32_t dim;               // normal
+    int flip, pbc;
+    float radius;
+    float radius_thr;           // local_radius_threshold(radius)
+    // scratch, per slab frame
+    uint32_t *cell_of;          // [n_slab][n_membrane]
+    float *trig;                // [n_slab][n_membrane] float4 records in cell order (see k_local_scatter)
+    float *rsn;                 // [n_slab][n_membrane] sin of the normal angle, cell order
+    uint32_t *cell_count;       // [n_slab][kLocalMaxCells1D^2 + 1] counts -> starts
+    uint32_t *cell_fill;        // [n_slab][kLocalMaxCells1D^2]
+    uint32_t *err;
+};
+
+// In-plane cell grid of one frame.  A dimension with at least 3 radii of box gets cells of radius / k
+// (k = kLocalFine, less when the 128-cell cap or the box says so) and a head looks at the 2k+1 cells
+// around its own; a smaller dimension is ONE cell (every atom is a candidate exactly once).  Finer cells
+// cut the candidates per head from 9 r^2 (k = 1) towards the disk area pi r^2: k = 4 gives 5.1 r^2.
+// The grid is this engine's own pruning device — membership itself is the exact distance test.
+constexpr uint32_t kLocalFine = 4;
+__device__ __forceinline__ void local_axis(float L, float radius, uint32_t &nc, uint32_t &k) {
+    nc = 1; k = 0;
+    for (uint32_t kk = kLocalFine; kk >= 1u; kk--) {
+        // cells are at least 1.0001 radius / kk wide (floor + margin), so +-kk cells reach one radius even
+        // when the wrapped coordinates the cells are made from are off by a rounding error
+        const float fine = floorf(L / (radius / (float)kk) * 0.9999f);
+        if (fine >= (float)(2u * kk + 1u) && fine <= (float)kLocalMaxCells1D) { nc = (uint32_t)fine; k = kk; return; }
+    }
+}
+__device__ __forceinline__ void local_grid(const LocalArgs &a, const float *box, uint32_t &nca, uint32_t &ncb,
+                                           int &da, int &db, uint32_t &ka, uint32_t &kb) {
+    da = (int)((a.dim + 1u) % 3u);
+    db = (int)((a.dim + 2u) % 3u);
+    nca = ncb = 1;   // no periodic images to prune with: one cell holds every atom
+    ka = kb = 0;
+    if (a.pbc) {
+        local_axis(box[da], a.radius, nca, ka);
+        local_axis(box[db], a.radius, ncb, kb);
+    }
+}
+__device__ __forceinline__ void local_grid(const LocalArgs &a, const float *box, uint32_t &nca, uint32_t &ncb,
+                                           int &da, int &db) {
+    uint32_t ka, kb;
+    local_grid(a, box, nca, ncb, da, db, ka, kb);
+}
+
+__device__ __forceinline__ void frame_box(const LocalArgs &a, uint32_t f, float *box) {
+    box[0] = box[1] = box[2] = 1.0f;
+    if (a.pbc) {
+        const float *b = a.box9 + 9 * (size_t)f;
+        box[0] = b[0]; box[1] = b[4]; box[2] = b[8];
+    }
+}
+
+// in-plane cell of membrane atom i in slab frame s (also stored in cell_of)
+__device__ __forceinline__ uint32_t local_cell_of(const LocalArgs &a, uint32_t s, uint32_t f, uint32_t i,
+                                                  const float *box, uint32_t nca, uint32_t ncb, int da, int db) {
+    const float *p = a.xyz + ((size_t)f * a.n_atoms + a.membrane[i]) * 3u;
+    int bad = 0;
+    uint32_t ca = 0, cb = 0;
+    if (a.pbc) {
+        const float wa = gm_wrap(p[da], box[da], bad), wb = gm_wrap(p[db], box[db], bad);
+        ca = (uint32_t)fminf(fmaxf(floorf(wa / box[da] * (float)nca), 0.0f), (float)(nca - 1u));
+        cb = (uint32_t)fminf(fmaxf(floorf(wb / box[db] * (float)ncb), 0.0f), (float)(ncb - 1u));
+    }
+    const uint32_t c = ca * ncb + cb;
+    a.cell_of[(size_t)s * a.n_membrane + i] = c;
+    if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f);
+    return c;
+}
+
+constexpr uint32_t kLocalLdsCells = 4096;   // cell counts are first aggregated per block in LDS up to this grid size
+
+__global__ __launch_bounds__(256) void k_local_bin(LocalArgs a) {
+    __shared__ uint32_t hist[kLocalLdsCells];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t s = blockIdx.y;
+    const uint32_t f = a.aframes ? a.aframes[s] : a.frame0 + s;
+    float box[3];
+    frame_box(a, f, box);
+    uint32_t nca, ncb;
+    int da, db;
+    local_grid(a, box, nca, ncb, da, db);
+    const uint32_t ncell = nca * ncb;
+    uint32_t *count = a.cell_count + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u);
+    const bool lds = ncell <= kLocalLdsCells;   // uniform
+    if (lds) {
+        for (uint32_t k = threadIdx.x; k < ncell; k += blockDim.x) hist[k] = 0;
+        __syncthreads();
+    }
+    if (i < a.n_membrane) {
+        const uint32_t c = local_cell_of(a, s, f, i, box, nca, ncb, da, db);
+        if (lds) atomicAdd(&hist[c], 1u);
+        else atomicAdd(&count[c], 1u);
+    }
+    if (lds) {   // one global atomic per cell the block touched (neighbouring atoms share cells)
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < ncell; k += blockDim.x)
+            if (hist[k]) atomicAdd(&count[k], hist[k]);
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_local_scan(LocalArgs a) {
+    __shared__ uint32_t part[1024];
+    const uint32_t s = blockIdx.x;
+    uint32_t *cnt = a.cell_count + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u);
+    constexpr uint32_t N = kLocalMaxCells1D * kLocalMaxCells1D, PER = N / 1024u;
+    uint32_t local[PER];
+    uint32_t sum = 0;
+    for (uint32_t k = 0; k < PER; k++) {
+        local[k] = cnt[threadIdx.x * PER + k];
+        sum += local[k];
+    }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+    for (uint32_t k = 0; k < PER; k++) {
+        cnt[threadIdx.x * PER + k] = run;
+        run += local[k];
+    }
+    if (threadIdx.x == 1023) cnt[N] = run;
+}
+
+// Places every membrane atom in its cell's run and writes a cell-ordered RECORD next to it so that the
+// flags kernel streams contiguous data instead of chasing two indices per candidate:
+//   rec[q] = (in-plane a, in-plane b, normal coordinate, cos(2 pi wrap(normal)/L)),  rsn[q] = sin(...)
+// Only the normal component of the local centre is consumed (leaflets.rs:725), hence one angle.
+__global__ __launch_bounds__(256) void k_local_scatter(LocalArgs a) {
+    __shared__ uint32_t hist[kLocalLdsCells];   // per-block count, then the block's base offset in each cell
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t s = blockIdx.y;
+    const uint32_t f = a.aframes ? a.aframes[s] : a.frame0 + s;
+    float box[3];
+    frame_box(a, f, box);
+    uint32_t nca, ncb;
+    int da, db;
+    local_grid(a, box, nca, ncb, da, db);
+    const uint32_t ncell = nca * ncb;
+    const int dn = (int)a.dim;
+    const bool lds = ncell <= kLocalLdsCells;   // uniform
+    uint32_t *fill = a.cell_fill + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D);
+    const bool valid = i < a.n_membrane;
+    uint32_t c = 0, rank = 0;
+    if (valid) c = a.cell_of[(size_t)s * a.n_membrane + i];
+    if (lds) {
+        for (uint32_t k = threadIdx.x; k < ncell; k += blockDim.x) hist[k] = 0;
+        __syncthreads();
+        if (valid) rank = atomicAdd(&hist[c], 1u);
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < ncell; k += blockDim.x)
+            if (hist[k]) hist[k] = atomicAdd(&fill[k], hist[k]);   // reserve the block's run inside the cell
+        __syncthreads();
+        if (valid) rank += hist[c];
+    } else if (valid) {
+        rank = atomicAdd(&fill[c], 1u);
+    }
+    if (!valid) return;
+    const uint32_t start = a.cell_count[(size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u) + c];
+    const float *p = a.xyz + ((size_t)f * a.n_atoms + a.membrane[i]) * 3u;
+    int bad = 0;
+    float sn = 0.0f, cs = 0.0f;
+    if (a.pbc) fast_sincos_rev(gm_wrap(p[dn], box[dn], bad) / box[dn], &sn, &cs);
+    const size_t q = (size_t)s * a.n_membrane + start + rank;
+    reinterpret_cast<float4 *>(a.trig)[q] = make_float4(p[da], p[db], p[dn], cs);
+    a.rsn[q] = sn;
+}
+
+// `sqrt(d2) < radius` (groan_rs Cylinder::inside) is evaluated as `d2 < thr` with thr = the smallest float
+// whose correctly rounded square root reaches the radius: sqrt is monotonic, so the two tests select
+// exactly the same atoms.  Computed once on the host; k_local_flags gets it as LocalArgs::radius_thr.
+__host__ __device__ inline float local_radius_threshold(float r) {
+    if (!(r > 0.0f)) return 0.0f;            // sqrt(x) < r never holds
+    float thr = r * r;
+    for (int i = 0; i < 8 && sqrtf(thr) < r; i++) thr = nextafterf(thr, INFINITY);
+    for (int i = 0; i < 8; i++) {
+        const float p = nextafterf(thr, 0.0f);
+        if (!(p < thr) || !(sqrtf(p) >= r)) break;
+        thr = p;
+    }
+    return thr;
+}
+
+// Sum over the 64 lanes by DPP row shifts (cheaper than six ds_bpermute round trips per sum).
+// Within a row of 16 lanes a Hillis-Steele scan leaves the row total in its last lane; row_bcast:15 and
+// row_bcast:31 carry the totals on, lane 63 ends with the wave total.  Fixed order => deterministic.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+    return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_total(double v) {
+    v = dpp_add_f64<0x111, 0xf>(v);   // row_shr:1
+    v = dpp_add_f64<0x112, 0xf>(v);   // row_shr:2
+    v = dpp_add_f64<0x114, 0xf>(v);   // row_shr:4
+    v = dpp_add_f64<0x118, 0xf>(v);   // row_shr:8
+    v = dpp_add_f64<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v = dpp_add_f64<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
+
+// block = 256 threads = 4 waves = 4 heads; grid = (ceil(n_mol / 4), n_slab).  A head's candidates are
+// the records of the (2ka+1) x (2kb+1) cells around its own: per row of cells ONE contiguous run of
+// records (two when the run wraps around the box), lanes over the run.
+__global__ __launch_bounds__(256) void k_local_flags(LocalArgs a) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t m = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t s = blockIdx.y;
+    if (m >= a.n_mol_total) return;
+    const uint32_t f = a.aframes ? a.aframes[s] : a.frame0 + s;
+    float box[3];
+    frame_box(a, f, box);
+    uint32_t nca, ncb, ka, kb;
+    int da, db;
+    local_grid(a, box, nca, ncb, da, db, ka, kb);
+    const int dn = (int)a.dim;
+    const float *x = a.xyz + (size_t)f * a.n_atoms * 3u;
+    const float *hp = x + 3u * (size_t)a.heads[m];
+    const float ha_pos = hp[da], hb_pos = hp[db], hn_pos = hp[dn];
+    int bad = 0;
+    uint32_t ha = 0, hb = 0;
+    if (a.pbc) {
+        const float wa = gm_wrap(ha_pos, box[da], bad), wb = gm_wrap(hb_pos, box[db], bad);
+        ha = (uint32_t)fminf(fmaxf(floorf(wa / box[da] * (float)nca), 0.0f), (float)(nca - 1u));
+        hb = (uint32_t)fminf(fmaxf(floorf(wb / box[db] * (float)ncb), 0.0f), (float)(ncb - 1u));
+    }
+    const uint32_t *cstart = a.cell_count + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u);
+    const float4 *rec = reinterpret_cast<const float4 *>(a.trig) + (size_t)s * a.n_membrane;
+    const float *rsn = a.rsn + (size_t)s * a.n_membrane;
+    const float La = box[da], Lb = box[db], Ln = box[dn];
+    const float thr = a.radius_thr;
+    // rows (ha - ka .. ha + ka) mod nca; in a row the cells (hb - kb .. hb + kb) mod ncb = runs [b0, b1) and [0, b2)
+    const uint32_t n_rows = 2u * ka + 1u, n_cols = 2u * kb + 1u;       // <= nca, ncb by local_axis
+    const uint32_t a0 = (ha + nca - ka) % nca, b0 = (hb + ncb - kb) % ncb;
+    const uint32_t b1 = min(b0 + n_cols, ncb), b2 = b0 + n_cols - b1;
+    const bool pbc = a.pbc != 0;
+    auto inside = [&](float ra, float rb) {
+        float ea = ra - ha_pos, eb = rb - hb_pos;
+        if (pbc) {
+            bool slow = false;
+            const float fa = gm_min_image_step(ea, La, slow), fb = gm_min_image_step(eb, Lb, slow);
+            if (__builtin_expect(slow, 0)) {
+                ea = gm_min_image_loop(ea, La, bad);
+                eb = gm_min_image_loop(eb, Lb, bad);
+            } else {
+                ea = fa; eb = fb;
+            }
+        }
+        return ea * ea + eb * eb < thr;                 // == sqrt(..) < radius, see local_radius_threshold
+    };
+
+    // The runs as a flat list of wave iterations: lane i keeps (first record, end of run) of iteration i.
+    // Every load address of the passes below then comes from a lane read-out instead of a chain of
+    // dependent cell-table loads, so the loads of several iterations are in flight together — this
+    // kernel is bound by load latency, not by arithmetic.
+    const uint32_t n_runs = 2u * n_rows;
+    uint32_t rq0 = 0, rq1 = 0;
+    if (lane < n_runs) {
+        const uint32_t row = ((a0 + (lane >> 1)) % nca) * ncb;
+        rq0 = (lane & 1u) ? cstart[row] : cstart[row + b0];
+        rq1 = (lane & 1u) ? cstart[row + b2] : cstart[row + b1];
+    }
+    uint32_t n_it = 0, it_base = 0, it_end = 0;
+    for (uint32_t r = 0; r < n_runs; r++) {
+        const uint32_t q0 = __builtin_amdgcn_readlane(rq0, r), q1 = __builtin_amdgcn_readlane(rq1, r);
+        const uint32_t n = (q1 - q0 + 63u) >> 6;
+        if (lane >= n_it && lane < n_it + n) { it_base = q0 + 64u * (lane - n_it); it_end = q1; }
+        n_it += n;
+    }
+    const bool flat = n_it <= 64u;       // else (> 4096 candidates): the plain run loops
+
+    // pass 1: members (in-plane minimum-image distance < radius; groan_rs Cylinder::inside), their count
+    // and the circular sums of the normal coordinate (PBC) or its plain sum (NoPBC).  The membership
+    // of the first 64 candidates of each lane is remembered as a bit mask for pass 2.
+    float sc = 0.0f, ss = 0.0f, sp = 0.0f;
+    uint32_t cnt = 0, nf = 0, it = 0;
+    unsigned long long member = 0ull;
+    auto take = [&](const float4 r, const float sn, const uint32_t iter) {
+        if (inside(r.x, r.y)) {
+            cnt += 1;
+            if (iter < 64u) member |= 1ull << iter;
+            nf |= (r.z - r.z == 0.0f) ? 0u : 1u;
+            if (pbc) { sc += r.w; ss += sn; }
+            else sp += r.z;
+        }
+    };
+    if (flat) {
+        for (uint32_t it0 = 0; it0 < n_it; it0 += 4u) {
+            float4 r[4];
+            float sn[4];
+            bool v[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; u++) {
+                const uint32_t iter = min(it0 + u, 63u);
+                const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)it_base, (int)iter) + lane;
+                v[u] = q < (uint32_t)__builtin_amdgcn_readlane((int)it_end, (int)iter);   // lanes >= n_it hold 0: never
+                const uint32_t qc = v[u] ? q : 0u;
+                r[u] = rec[qc];
+                sn[u] = pbc ? rsn[qc] : 0.0f;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; u++)
+                if (v[u]) take(r[u], sn[u], it0 + u);
+        }
+    } else {
+        for (uint32_t ia = 0; ia < n_rows; ia++) {
+            const uint32_t row = ((a0 + ia) % nca) * ncb;
+            for (uint32_t part = 0; part < 2u; part++) {
+                const uint32_t q0 = part == 0 ? cstart[row + b0] : cstart[row];
+                const uint32_t q1 = part == 0 ? cstart[row + b1] : cstart[row + b2];
+                for (uint32_t q = q0 + lane; q < q1; q += 64u, it++) take(rec[q], pbc ? rsn[q] : 0.0f, it);
+            }
+        }
+    }
+    const double tcnt = wave_total((double)cnt);
+    if (tcnt == 0.0 || __any(nf != 0u)) {
+        if (lane == 0) raise_error(a.err, GORDER_ERR_INVALID_LOCAL_MEMBRANE_CENTER, a.heads[m], f);
+        return;
+    }
+    float center;
+    if (!pbc) {
+        center = (float)(wave_total((double)sp) / tcnt);
+    } else {
+        const double tc = wave_total((double)sc), ts = wave_total((double)ss);
+        const float est = (atan2f(-(float)ts, -(float)tc) + 3.1415927f) / (6.2831855f / Ln);
+        // pass 2: refine with the mean minimum-image displacement of the members from the estimate
+        float ref = 0.0f;
+        if (flat) {
+            for (uint32_t it0 = 0; it0 < n_it; it0 += 4u) {
+                float pn[4];
+                bool in[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; u++) {
+                    const uint32_t iter = min(it0 + u, 63u);
+                    in[u] = it0 + u < 64u && ((member >> iter) & 1ull);
+                    const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)it_base, (int)iter) + lane;
+                    pn[u] = rec[in[u] ? q : 0u].z;
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; u++)
+                    if (in[u]) ref += gm_min_image(pn[u] - est, Ln, bad);
+            }
+        } else {
+            it = 0;
+            for (uint32_t ia = 0; ia < n_rows; ia++) {
+                const uint32_t row = ((a0 + ia) % nca) * ncb;
+                for (uint32_t part = 0; part < 2u; part++) {
+                    const uint32_t q0 = part == 0 ? cstart[row + b0] : cstart[row];
+                    const uint32_t q1 = part == 0 ? cstart[row + b1] : cstart[row + b2];
+                    for (uint32_t q = q0 + lane; q < q1; q += 64u, it++) {
+                        bool in;
+                        float pn;
+                        if (it < 64u) {
+                            in = (member >> it) & 1ull;
+                            pn = in ? rec[q].z : 0.0f;
+                        } else {
+                            const float4 r = rec[q];
+                            in = inside(r.x, r.y);
+                            pn = r.z;
+                        }
+                        if (in) ref += gm_min_image(pn - est, Ln, bad);
+                    }
+                }
+            }
+        }
+        center = gm_wrap(est + (float)(wave_total((double)ref) / tcnt), Ln, bad);
+    }
+    if (lane == 0) {
+        if (center != center) {
+            raise_error(a.err, GORDER_ERR_INVALID_LOCAL_MEMBRANE_CENTER, a.heads[m], f);
+            return;
+        }
+        float d = hn_pos - center;
+        if (pbc) d = gm_min_image(d, Ln, bad);
+        a.aflags[(size_t)(a.row0 + s) * a.n_mol_total + m] = (uint8_t)((d >= 0.0f ? 0 : 1) ^ (a.flip ? 1 : 0));
+        if ((int)s == a.write_dist_frame && a.adist) a.adist[m] = d;
+    }
+    if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f);
+}
+
+}  // namespace
