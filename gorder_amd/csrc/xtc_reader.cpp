@@ -129,10 +129,19 @@ float bef(const uint8_t *p) {
     return f;
 }
 
+double bed(const uint8_t *p) {
+    uint64_t u = 0;
+    for (int k = 0; k < 8; k++) u = (u << 8) | p[k];
+    double d;
+    memcpy(&d, &u, 8);
+    return d;
+}
+
 }  // namespace
 
 struct gorder_xtc_reader {
     FILE *fp = nullptr;
+    bool trr = false;                 // GROMACS TRR (magic 1993, uncompressed reals) instead of XTC (magic 1995)
     uint32_t natoms = 0;
     std::vector<uint32_t> group;      // atoms to convert (empty = all)
     std::vector<int32_t> slot_of;     // atom -> output slot or -1 (only when group given)
@@ -227,6 +236,91 @@ int decode_ints(gorder_xtc_reader *r, const int minint[3], const int maxint[3], 
     return GORDER_XTC_OK;
 }
 
+// ---- TRR ------------------------------------------------------------------------------------------
+// GROMACS full-precision trajectory (the reference reads it through groan_rs' TrrReader, common.rs:306-320).
+// XDR, big-endian.  Frame = header {magic 1993, version string "GMX_trn_file", 13 ints: ir, e, box, vir, pres,
+// top, sym, x, v, f sizes in bytes, natoms, step, nre; then t and lambda as reals} + box + (virial, pressure)
+// + positions (+ velocities, forces).  A real is a float when box_size / 9 (or x_size / 3N) is 4, a double when 8.
+struct TrrHeader {
+    uint32_t sizes[10];   // ir e box vir pres top sym x v f
+    uint32_t natoms;
+    int32_t step;
+    uint32_t real_size;
+    double t;
+};
+
+int trr_read_header(gorder_xtc_reader *r, TrrHeader &h) {
+    uint8_t b[8];
+    const size_t got = fread(b, 1, 8, r->fp);
+    if (got == 0) return GORDER_XTC_EOF;
+    if (got != 8 || be32(b) != 1993u) return GORDER_XTC_ERR_FORMAT;
+    const uint32_t slen = be32(b + 4);                       // length of the version string incl. terminator
+    uint8_t s4[4];
+    if (slen > 128 || !read_exact(r->fp, s4, 4)) return GORDER_XTC_ERR_FORMAT;
+    const uint32_t n = be32(s4), padded = (n + 3u) & ~3u;
+    uint8_t str[132];
+    if (n > 128 || !read_exact(r->fp, str, padded)) return GORDER_XTC_ERR_FORMAT;
+    uint8_t ints[13 * 4];
+    if (!read_exact(r->fp, ints, sizeof(ints))) return GORDER_XTC_ERR_FORMAT;
+    for (int k = 0; k < 10; k++) h.sizes[k] = be32(ints + 4 * k);
+    h.natoms = be32(ints + 40);
+    h.step = (int32_t)be32(ints + 44);
+    if (h.sizes[2]) h.real_size = h.sizes[2] / 9u;
+    else if (h.sizes[7] && h.natoms) h.real_size = h.sizes[7] / (3u * h.natoms);
+    else if (h.sizes[8] && h.natoms) h.real_size = h.sizes[8] / (3u * h.natoms);
+    else if (h.sizes[9] && h.natoms) h.real_size = h.sizes[9] / (3u * h.natoms);
+    else h.real_size = 4;
+    if (h.real_size != 4 && h.real_size != 8) return GORDER_XTC_ERR_FORMAT;
+    uint8_t tl[16];
+    if (!read_exact(r->fp, tl, 2 * h.real_size)) return GORDER_XTC_ERR_FORMAT;
+    h.t = h.real_size == 4 ? (double)bef(tl) : bed(tl);
+    return GORDER_XTC_OK;
+}
+
+int trr_next(gorder_xtc_reader *r, float *xyz, float *box9, int64_t *step, float *time_ps, float *precision) {
+    for (;;) {
+        TrrHeader h{};
+        const int st = trr_read_header(r, h);
+        if (st != GORDER_XTC_OK) return st;
+        if (h.natoms != r->natoms) return GORDER_XTC_ERR_FORMAT;
+        const size_t body = (size_t)h.sizes[0] + h.sizes[1] + h.sizes[2] + h.sizes[3] + h.sizes[4] + h.sizes[5] +
+                            h.sizes[6] + h.sizes[7] + h.sizes[8] + h.sizes[9];
+        if (h.sizes[7] == 0) {           // a frame without positions (velocities / forces only): not a frame for us
+            if (fseek(r->fp, (long)body, SEEK_CUR) != 0) return GORDER_XTC_ERR_FORMAT;
+            continue;
+        }
+        if (h.sizes[7] != (size_t)h.natoms * 3 * h.real_size) return GORDER_XTC_ERR_FORMAT;
+        if (step) *step = h.step;
+        if (time_ps) *time_ps = (float)h.t;
+        if (precision) *precision = 0.0f;
+        if (fseek(r->fp, (long)(h.sizes[0] + h.sizes[1]), SEEK_CUR) != 0) return GORDER_XTC_ERR_FORMAT;
+        if (h.sizes[2]) {
+            uint8_t b[72];
+            if (h.sizes[2] > sizeof(b) || !read_exact(r->fp, b, h.sizes[2])) return GORDER_XTC_ERR_FORMAT;
+            if (box9) for (int k = 0; k < 9; k++) box9[k] = h.real_size == 4 ? bef(b + 4 * k) : (float)bed(b + 8 * k);
+        } else if (box9) {
+            for (int k = 0; k < 9; k++) box9[k] = 0.0f;
+        }
+        if (fseek(r->fp, (long)(h.sizes[3] + h.sizes[4] + h.sizes[5] + h.sizes[6]), SEEK_CUR) != 0) return GORDER_XTC_ERR_FORMAT;
+        if (!xyz) {
+            if (fseek(r->fp, (long)(h.sizes[7] + h.sizes[8] + h.sizes[9]), SEEK_CUR) != 0) return GORDER_XTC_ERR_FORMAT;
+            return GORDER_XTC_OK;
+        }
+        r->buf.resize(h.sizes[7]);
+        if (!read_exact(r->fp, r->buf.data(), h.sizes[7])) return GORDER_XTC_ERR_FORMAT;
+        const uint8_t *q = r->buf.data();
+        const bool all = r->group.empty();
+        const size_t nout = all ? h.natoms : r->group.size();
+        for (size_t k = 0; k < nout; k++) {
+            const size_t a = all ? k : r->group[k];
+            for (int c = 0; c < 3; c++)
+                xyz[3 * k + c] = h.real_size == 4 ? bef(q + 4 * (3 * a + c)) : (float)bed(q + 8 * (3 * a + c));
+        }
+        if (fseek(r->fp, (long)(h.sizes[8] + h.sizes[9]), SEEK_CUR) != 0) return GORDER_XTC_ERR_FORMAT;
+        return GORDER_XTC_OK;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -237,14 +331,25 @@ int gorder_xtc_open(const char *path, const uint32_t *group, uint32_t n_group, g
     FILE *fp = fopen(path, "rb");
     if (!fp) return GORDER_XTC_ERR_OPEN;
     uint8_t head[8];
-    if (!read_exact(fp, head, 8) || be32(head) != 1995u) {
+    if (!read_exact(fp, head, 8) || (be32(head) != 1995u && be32(head) != 1993u)) {
         fclose(fp);
         return GORDER_XTC_ERR_FORMAT;
     }
     gorder_xtc_reader *r = new gorder_xtc_reader();
     r->fp = fp;
-    r->natoms = be32(head + 4);
     fseek(fp, 0, SEEK_SET);
+    if (be32(head) == 1993u) {           // TRR: the atom count sits behind the version string
+        r->trr = true;
+        TrrHeader h{};
+        if (trr_read_header(r, h) != GORDER_XTC_OK) {
+            gorder_xtc_close(r);
+            return GORDER_XTC_ERR_FORMAT;
+        }
+        r->natoms = h.natoms;
+        fseek(fp, 0, SEEK_SET);
+    } else {
+        r->natoms = be32(head + 4);
+    }
     if (group && n_group) {
         r->group.assign(group, group + n_group);
         r->slot_of.assign(r->natoms, -1);
@@ -274,6 +379,7 @@ uint32_t gorder_xtc_n_atoms_out(const gorder_xtc_reader *r) {
 int gorder_xtc_next(gorder_xtc_reader *r, float *xyz, float *box9, int64_t *step, float *time_ps,
                     float *precision) {
     if (!r || !r->fp) return GORDER_XTC_ERR_ARGUMENT;
+    if (r->trr) return trr_next(r, xyz, box9, step, time_ps, precision);
     uint8_t head[16 + 36 + 4];
     const size_t got = fread(head, 1, sizeof(head), r->fp);
     if (got == 0) return GORDER_XTC_EOF;

@@ -73,6 +73,8 @@ if __name__ == "__main__":
         src = os.path.join(REF, f)
         if os.path.exists(src):
             shutil.copy(src, os.path.join(HERE, "expected", f))
+    # one small trajectory file as it is, for the reader's own tests (1 frame, 16 769 beads, 62 KB)
+    shutil.copy(os.path.join(REF, "split", "cg3.xtc"), os.path.join(HERE, "cg3.xtc"))
     # the 12 united-atom ordermaps compared by tests_ua.rs:351-410 (made from ua.xtc)
     os.makedirs(os.path.join(HERE, "expected", "ordermaps_ua"), exist_ok=True)
     for f in sorted(os.listdir(os.path.join(REF, "ordermaps_ua"))):
