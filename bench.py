@@ -139,6 +139,9 @@ def main():
     for _ in range(args.warmup):
         step()
     eng.synchronize()
+    if world > 1:   # untimed: RCCL sets up its communicator and buffers on the first collective of a size
+        dist.all_reduce(torch.zeros_like(acc), op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
     eng.kernel_time(reset=True)
 
     def fence():
