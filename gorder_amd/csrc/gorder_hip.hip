@@ -330,7 +330,11 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
         } else {
             switch (h->frames_per_stage) {
                 case 8: GORDER_LAUNCH_TILED(8, 10); break;
-                default: GORDER_LAUNCH_TILED(4, 5); break;
+                default:
+                    // prefetch registers per thread: enough float4 for the widest window (64 threads stage a frame)
+                    if ((3u * p.max_window + 6u) / 4u <= 4u * 64u && !env_flag("GORDER_HIP_NPF5")) GORDER_LAUNCH_TILED(4, 4);
+                    else GORDER_LAUNCH_TILED(4, 5);
+                    break;
             }
         }
 #undef GORDER_LAUNCH_GATHER

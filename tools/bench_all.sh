@@ -4,13 +4,15 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=${1:-$ROOT/gpurun_out/bench_all.jsonl}
 : > $OUT
 run() { python3 $ROOT/bench.py --no-cpu-baseline --workload $1 --frames $2 --steps $3 --warmup $4 | grep '^{' >> $OUT; }
+# warm-up launches cover >= 20 ms: the chip needs that long to settle its clocks
 run aa256 10000 100 40
-run aa256-leaflets 4000 50 20
-run cg3k 4000 50 20
-run cg3k-local 512 10 3
-run ua256 3000 50 20
-run ua256-maps 3000 30 10
-run cg1m 500 20 5
+run aa256-leaflets 4000 50 40
+run aa256-maps 3000 50 40
+run cg3k 4000 100 60
+run cg3k-local 512 10 4
+run ua256 3000 50 40
+run ua256-maps 3000 50 30
+run cg1m 500 40 30
 python3 - <<PY
 import json
 for line in open("$OUT"):

@@ -12,7 +12,7 @@ system, name = bench.make_system(wl)
 system.tables.flags = 1 if os.environ.get("QB_ACOS") else 0
 d_xyz, d_box = system.frames_device(frames, seed=1)
 eng = HipEngine(system.tables); eng.use_torch_stream()
-for _ in range(3): eng.submit_device(d_xyz, d_box)
+for _ in range(int(os.environ.get('QB_WARM', '40'))): eng.submit_device(d_xyz, d_box)   # ~20 ms: clocks settle
 eng.synchronize(); eng.kernel_time(reset=True)
 ts, wall = [], []
 for _ in range(reps):
