@@ -57,6 +57,9 @@ __device__ __forceinline__ bool bond_sample(const FrameArgs &a, uint32_t f, floa
 // The 16-byte loads start at the window's first float rounded DOWN to 16 B and end at its last float
 // rounded UP to 16 B.  xyz is 16-byte aligned, so the last load of the whole buffer stays inside the
 // aligned 16-byte granule that holds the last valid float: it cannot cross into an unmapped page.
+#ifndef GORDER_COMPUTE_NF
+#define GORDER_COMPUTE_NF 8        // frames evaluated together per thread (capped at G)
+#endif
 typedef float v4f __attribute__((ext_vector_type(4)));   // native 16-byte vector (SROA-friendly, unlike float4)
 
 template <int G, int NPF, bool ACOS_COS, bool PBC, bool LEAF, int AXIS = -1>
@@ -100,16 +103,17 @@ struct TiledStage {
     // The common path is straight-line code (selects only) so that the G independent dependency chains
     // interleave; the rare cases (atoms more than 1.5 box lengths apart -> literal minimum-image loops;
     // NaN result -> which atom is undefined?) are collected in a bit mask and handled after the stage.
+    template <int NF>
     static __device__ __forceinline__ void compute_core(const FrameArgs &a, const Tile &t, const Item &it,
-                                                        uint32_t f0, const float (&P)[G][6], SampleAcc &acc,
+                                                        uint32_t f0, const float (&P)[NF][6], SampleAcc &acc,
                                                         int &bad, uint32_t &nan_atom, uint32_t &nan_frame) {
-        int tick[G];
-        uint8_t fl[G];
-        float bx[G], by[G], bz[G];
+        int tick[NF];
+        uint8_t fl[NF];
+        float bx[NF], by[NF], bz[NF];
         uint32_t rare = 0;
         // uniform per-frame inputs of the whole stage first (scalar loads, issued back to back)
 #pragma unroll
-        for (int k = 0; k < G; k++) {
+        for (int k = 0; k < NF; k++) {
             if (PBC) {
                 const float *b = a.box9 + 9 * (size_t)(f0 + k);
                 bx[k] = b[0]; by[k] = b[4]; bz[k] = b[8];
@@ -117,7 +121,7 @@ struct TiledStage {
             if (LEAF) fl[k] = a.aflags[(size_t)a.arow[f0 + k] * a.n_mol_total + it.mol];
         }
 #pragma unroll
-        for (int k = 0; k < G; k++) {
+        for (int k = 0; k < NF; k++) {
             float vx = P[k][3] - P[k][0], vy = P[k][4] - P[k][1], vz = P[k][5] - P[k][2];
             bool slow = false;
             if (PBC) {
@@ -132,7 +136,7 @@ struct TiledStage {
         }
         if (__builtin_expect(rare != 0, 0)) {
 #pragma unroll
-            for (int k = 0; k < G; k++) {
+            for (int k = 0; k < NF; k++) {
                 if (!((rare >> k) & 1u)) continue;
                 float vx = P[k][3] - P[k][0], vy = P[k][4] - P[k][1], vz = P[k][5] - P[k][2];
                 if (PBC) {
@@ -151,7 +155,7 @@ struct TiledStage {
         int st = 0, su = 0;
         uint32_t nu = 0;
 #pragma unroll
-        for (int k = 0; k < G; k++) {
+        for (int k = 0; k < NF; k++) {
             st += tick[k];
             if (LEAF) {   // Leaflet::Upper = 0 (lib.rs:416-422)
                 su += fl[k] == 0 ? tick[k] : 0;
@@ -159,7 +163,7 @@ struct TiledStage {
             }
         }
         acc.s_tot += st;
-        acc.n_tot += G;
+        acc.n_tot += NF;
         acc.s_up += su;
         acc.n_up += nu;
     }
@@ -167,15 +171,20 @@ struct TiledStage {
     static __device__ __forceinline__ void compute(const FrameArgs &a, const Tile &t, const Item &it, uint32_t f0,
                                                    const float *lds, uint32_t lw, SampleAcc &acc, int &bad,
                                                    uint32_t &nan_atom, uint32_t &nan_frame) {
-        float P[G][6];
+        // NF frames at a time: NF independent dependency chains interleave; fewer live registers than all G at once
+        constexpr int NF = GORDER_COMPUTE_NF < G ? GORDER_COMPUTE_NF : G;
 #pragma unroll
-        for (int k = 0; k < G; k++) {
-            const uint32_t sh = (uint32_t)((((size_t)(f0 + k) * a.n_atoms + t.atom0) * 3u) & 3u);
-            const float *w = lds + (size_t)k * lw + sh;
-            P[k][0] = w[3u * it.li]; P[k][1] = w[3u * it.li + 1]; P[k][2] = w[3u * it.li + 2];
-            P[k][3] = w[3u * it.lj]; P[k][4] = w[3u * it.lj + 1]; P[k][5] = w[3u * it.lj + 2];
+        for (int h = 0; h < G; h += NF) {
+            float P[NF][6];
+#pragma unroll
+            for (int k = 0; k < NF; k++) {
+                const uint32_t sh = (uint32_t)((((size_t)(f0 + h + k) * a.n_atoms + t.atom0) * 3u) & 3u);
+                const float *w = lds + (size_t)(h + k) * lw + sh;
+                P[k][0] = w[3u * it.li]; P[k][1] = w[3u * it.li + 1]; P[k][2] = w[3u * it.li + 2];
+                P[k][3] = w[3u * it.lj]; P[k][4] = w[3u * it.lj + 1]; P[k][5] = w[3u * it.lj + 2];
+            }
+            compute_core<NF>(a, t, it, f0 + h, P, acc, bad, nan_atom, nan_frame);
         }
-        compute_core(a, t, it, f0, P, acc, bad, nan_atom, nan_frame);
     }
     // partial last stage: frames f0 .. f_end-1, one at a time (not performance relevant)
     static __device__ __forceinline__ void compute_tail(const FrameArgs &a, const Tile &t, const Item &it,
@@ -332,7 +341,7 @@ __global__ __launch_bounds__(kBlock) void k_bonds_gather(FrameArgs a_in, const f
         for (uint32_t f0 = f_begin; f0 < f_full; f0 += G) {
             const bool more = f0 + G < f_full;
             if (more) fetch(nxt, f0 + G);
-            S::compute_core(a, t, it, f0, cur, acc, bad, nan_atom, nan_frame);
+            S::template compute_core<G>(a, t, it, f0, cur, acc, bad, nan_atom, nan_frame);
             if (more) {
 #pragma unroll
                 for (int k = 0; k < G; k++)
