@@ -114,6 +114,7 @@ struct gorder_hip_handle {
     float n2 = 1.0f, n2sq = 1.0f;
     int axis = -1;   // 0/1/2 when the static normal is exactly that unit axis (kernel specialisation)
     int frames_per_stage = kFramesPerStage;   // G (2, 4 or 8); GORDER_HIP_FRAMES_PER_STAGE overrides
+    bool membrane_is_frame = false;            // the membrane group is every atom of the frame, in order
     bool use_gather = false;                   // GORDER_HIP_KERNEL=gather: L1-gather kernel instead of LDS staging
     uint32_t wg_capacity = 256u * 6u;          // co-resident workgroups of the tiled kernel on this device
     uint32_t wg_target = 0;                    // GORDER_HIP_WG_TARGET: force the workgroup count aimed at
@@ -696,6 +697,8 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
             for (uint32_t a : mem)
                 if (a >= t->n_atoms) return fail(h, GORDER_ERR_INVALID_ARGUMENT, "membrane index out of range");
             if ((st = upload(h, &h->d_membrane, mem)) != GORDER_OK) return st;
+            h->membrane_is_frame = lf.n_membrane == t->n_atoms && !env_flag("GORDER_HIP_LEAFLETS_GENERIC");
+            for (uint32_t i = 0; i < lf.n_membrane && h->membrane_is_frame; i++) h->membrane_is_frame = mem[i] == i;
         }
         if (lf.method == GORDER_LEAFLETS_LOCAL) {
             const size_t nm = lf.n_membrane, ncell = (size_t)kLocalMaxCells1D * kLocalMaxCells1D;
@@ -781,7 +784,9 @@ static int run_leaflets(gorder_hip_handle *h, const float *d_xyz, const float *d
     la.dim = lf.normal_dim; la.flip = lf.flip ? 1 : 0; la.pbc = h->tables.handle_pbc ? 1 : 0;
     la.err = h->d_err;
     if (lf.method == GORDER_LEAFLETS_GLOBAL) {
-        hipLaunchKernelGGL(k_leaflets_global, dim3((uint32_t)aframes.size()), dim3(1024), 0, h->stream, la);
+        const dim3 g((uint32_t)aframes.size()), b(1024);
+        if (h->membrane_is_frame) hipLaunchKernelGGL(k_leaflets_global_contig, g, dim3(256), 0, h->stream, la);
+        else hipLaunchKernelGGL(k_leaflets_global, g, b, 0, h->stream, la);
     } else if (lf.method == GORDER_LEAFLETS_INDIVIDUAL) {
         // gridDim.y <= 65535: launch in slabs
         size_t done = 0;

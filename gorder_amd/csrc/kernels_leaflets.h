@@ -51,6 +51,19 @@ __device__ __forceinline__ double block_sum(double v, double *scratch) {
     return r;
 }
 
+// two sums for the price (barriers) of one; scratch holds 2 x 16 doubles
+__device__ __forceinline__ void block_sum2(double &v0, double &v1, double *scratch) {
+    v0 = wave_sum(v0);
+    v1 = wave_sum(v1);
+    const uint32_t wave = threadIdx.x >> 6, n_waves = (blockDim.x + 63u) >> 6;
+    if ((threadIdx.x & 63u) == 0) { scratch[wave] = v0; scratch[16 + wave] = v1; }
+    __syncthreads();
+    double r0 = 0.0, r1 = 0.0;
+    for (uint32_t w = 0; w < n_waves; w++) { r0 += scratch[w]; r1 += scratch[16 + w]; }
+    __syncthreads();
+    v0 = r0; v1 = r1;
+}
+
 // ---- per-frame shapes of the geometry selection: GeometrySelection::init_reference (geometry.rs:192-210)
 // + construct_shape (geometry.rs:328-357, 422-451, 507-514).  One block per frame; a group reference needs
 // the centre of geometry of the group (refined Bai-Breen, like the global membrane centre).
@@ -234,6 +247,153 @@ __global__ __launch_bounds__(1024) void k_leaflets_global(LeafletArgs a) {
         const float hp = x[3u * (size_t)a.heads[m] + dn];
         float d = hp - cdim;
         if (a.pbc) d = gm_min_image(d, L, bad);
+        row[m] = (uint8_t)((d >= 0.0f ? 0 : 1) ^ (a.flip ? 1 : 0));
+        if (last && a.adist) a.adist[m] = d;
+    }
+    if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f);
+}
+
+// The same classifier for the usual case that the membrane group is EVERY atom of the frame, in order (all
+// lipid atoms are decoded and "@membrane" selects them all): the frame is then one contiguous run of 3N floats,
+// read ONCE with coalesced 16-byte loads instead of three strided dwords per atom through an index list.
+// Float g of the frame is component g mod 3 of atom g / 3; a 16-byte chunk holds one or two normal components.
+//
+// One pass: next to the circular sums (estimate) every thread also sums u = minimum image of (z - z_ref), z_ref
+// = the normal coordinate of the first molecule's head, and tracks min / max of u.  Once the estimate is known:
+// if every atom's image relative to z_ref is also its image relative to the estimate (u_min, u_max inside the
+// half box around it — any membrane thinner than half the box), then sum MI(z - est) = sum u + n (z_ref - est)
+// and the refinement needs no second look at the data; otherwise the frame is read again.  256-thread blocks,
+// nothing kept per atom: several frames per CU overlap their load and reduction phases.
+__device__ __forceinline__ void block_minmax(float &lo, float &hi, float *scratch /* 2 x 16 */) {
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, off, 64));
+        hi = fmaxf(hi, __shfl_xor(hi, off, 64));
+    }
+    const uint32_t wave = threadIdx.x >> 6, n_waves = (blockDim.x + 63u) >> 6;
+    if ((threadIdx.x & 63u) == 0) { scratch[wave] = lo; scratch[16 + wave] = hi; }
+    __syncthreads();
+    for (uint32_t w = 0; w < n_waves; w++) { lo = fminf(lo, scratch[w]); hi = fmaxf(hi, scratch[16 + w]); }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_leaflets_global_contig(LeafletArgs a) {
+    __shared__ double scratch[32];
+    __shared__ float fscratch[32];
+    __shared__ float s_center;
+    const uint32_t f = a.aframes[blockIdx.x];
+    const uint32_t dn = a.dim;
+    float L = 1.0f;
+    if (a.pbc) L = a.box9[9 * (size_t)f + 4 * dn];
+    int bad = 0;
+    const size_t start = (size_t)f * a.n_atoms * 3u;                 // first float of the frame
+    const uint32_t sh = (uint32_t)(start & 3u), n_float = 3u * a.n_atoms;
+    const uint32_t n4 = (sh + n_float + 3u) >> 2;
+    const v4f *src = reinterpret_cast<const v4f *>(a.xyz + (start - sh));   // xyz is 16-byte aligned
+    const float *x = a.xyz + start;
+    const bool pbc = a.pbc != 0;
+    const float inv = pbc ? 1.0f / L : 0.0f;
+    const float zref = a.n_mol_total ? x[3u * (size_t)a.heads[0] + dn] : 0.0f;
+    // chunk c = tid + 256 k starts at frame float 4c - sh; its element j is a normal component iff
+    // (4c - sh + j) % 3 == dn, i.e. j % 3 == (dn + sh - tid - k) % 3 (4 and 256 are 1 mod 3)
+    uint32_t r = (dn + sh + 3u * 256u - threadIdx.x) % 3u;            // j0 of this thread's chunk k; k -> k+1: r -> r-1
+    float nonfinite = 0.0f, sc = 0.0f, ss = 0.0f, su = 0.0f, ulo = 3.0e38f, uhi = -3.0e38f;
+    auto take = [&](float z, bool ok) {
+        if (pbc) {
+            bad |= (ok && !(z <= 9.0f * L && z >= -8.0f * L)) ? 1 : 0;   // gm_wrap would give up: coordinate far outside
+            float sn, cs;
+            fast_sincos_rev(z * inv, &sn, &cs);                             // v_sin / v_cos reduce the range themselves
+            sc += ok ? cs : 0.0f;
+            ss += ok ? sn : 0.0f;
+        }
+        const float u = pbc ? gm_min_image(z - zref, L, bad) : z - zref;
+        su += ok ? u : 0.0f;
+        ulo = ok ? fminf(ulo, u) : ulo;
+        uhi = ok ? fmaxf(uhi, u) : uhi;
+    };
+    auto chunk = [&](const v4f v, uint32_t c, uint32_t j0) {
+        float za = v.x;
+        za = j0 == 1 ? v.y : za;
+        za = j0 == 2 ? v.z : za;
+        const uint32_t e0 = 4u * c;                                   // position of v.x counted from src
+        if (e0 >= sh && e0 + 4u <= sh + n_float) {                    // every float of the chunk belongs to the frame
+            const float t = (v.x + v.y) + (v.z + v.w);
+            nonfinite += t - t;                                       // NaN / inf in any of them survives the sum
+            take(za, true);
+            take(v.w, j0 == 0);
+        } else {                                                       // first / last chunk of the frame
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                const bool in = e0 + j >= sh && e0 + j < sh + n_float;
+                nonfinite += in ? e[j] - e[j] : 0.0f;
+            }
+            take(za, e0 + j0 >= sh && e0 + j0 < sh + n_float);
+            take(v.w, j0 == 0 && e0 + 3u >= sh && e0 + 3u < sh + n_float);
+        }
+    };
+    uint32_t c = threadIdx.x;
+    for (; c + 3u * 256u < n4; c += 4u * 256u) {                     // four loads in flight
+        v4f v[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) v[k] = __builtin_nontemporal_load(src + c + k * 256u);
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            chunk(v[k], c + k * 256u, r);
+            r = r == 0 ? 2u : r - 1u;
+        }
+    }
+    for (; c < n4; c += 256u) {
+        chunk(__builtin_nontemporal_load(src + c), c, r);
+        r = r == 0 ? 2u : r - 1u;
+    }
+    double tc = (double)sc, ts = (double)ss;
+    block_sum2(tc, ts, scratch);
+    double tu = (double)su, nf = (double)nonfinite;
+    block_sum2(tu, nf, scratch);
+    block_minmax(ulo, uhi, fscratch);
+    float center;
+    if (!pbc) {
+        center = zref + (float)(tu / (double)a.n_atoms);
+    } else {
+        const float est = (atan2f(-(float)ts, -(float)tc) + 3.1415927f) / (6.2831855f / L);
+        const float shift = gm_min_image(zref - est, L, bad);         // z_ref as seen from the estimate
+        const float half = L / 2.0f, margin = 1e-4f * L;
+        if (ulo + shift > -half + margin && uhi + shift < half - margin) {
+            // every atom's image around z_ref is its image around the estimate:
+            // est + mean MI(z - est) = est + shift + mean u
+            center = gm_wrap((est + shift) + (float)(tu / (double)a.n_atoms), L, bad);
+        } else {                                                      // a membrane thicker than half the box: read again
+            float acc = 0.0f;
+            uint32_t r2 = (dn + sh + 3u * 256u - threadIdx.x) % 3u;
+            for (uint32_t c2 = threadIdx.x; c2 < n4; c2 += 256u) {
+                const v4f v = src[c2];
+                const uint32_t e0 = 4u * c2, j0 = r2;
+                float za = v.x;
+                za = j0 == 1 ? v.y : za;
+                za = j0 == 2 ? v.z : za;
+                if (e0 + j0 >= sh && e0 + j0 < sh + n_float) acc += gm_min_image(za - est, L, bad);
+                if (j0 == 0 && e0 + 3u >= sh && e0 + 3u < sh + n_float) acc += gm_min_image(v.w - est, L, bad);
+                r2 = r2 == 0 ? 2u : r2 - 1u;
+            }
+            const double tot = block_sum((double)acc, scratch);
+            center = gm_wrap(est + (float)(tot / (double)a.n_atoms), L, bad);
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (center != center || nf != 0.0 || a.n_atoms == 0) {
+            raise_error(a.err, GORDER_ERR_INVALID_GLOBAL_MEMBRANE_CENTER, 0, f);
+            center = __builtin_nanf("");
+        }
+        s_center = center;
+    }
+    __syncthreads();
+    const float cdim = s_center;
+    uint8_t *row = a.aflags + (size_t)(a.row0 + blockIdx.x) * a.n_mol_total;
+    const bool last = blockIdx.x + 1 == gridDim.x;
+    for (uint32_t m = threadIdx.x; m < a.n_mol_total; m += blockDim.x) {
+        const float hp = x[3u * (size_t)a.heads[m] + dn];
+        float d = hp - cdim;
+        if (pbc) d = gm_min_image(d, L, bad);
         row[m] = (uint8_t)((d >= 0.0f ? 0 : 1) ^ (a.flip ? 1 : 0));
         if (last && a.adist) a.adist[m] = d;
     }

@@ -370,3 +370,33 @@ def test_reference_known_answer_on_the_device(built, flags):
     assert res.counts[0, 0] == 1
     assert abs(int(res.sums[0, 0]) - 854478) <= 1          # round(0.8544775 * 1e6), within one tick
     np.testing.assert_allclose(res.order()[0, 0], 0.8544775, atol=1.5e-6)
+
+
+@pytest.mark.parametrize("variant", ["contiguous", "generic", "thick", "subset"])
+def test_global_leaflet_kernels(built, monkeypatch, variant):
+    """Global classification has two kernels: the one-pass kernel for a membrane group that is the whole frame
+    (with a second read when the membrane is thicker than half the box) and the generic one (index list)."""
+    box = None
+    if variant == "generic":
+        monkeypatch.setenv("GORDER_HIP_LEAFLETS_GENERIC", "1")
+    if variant == "thick":
+        box = (8.0, 8.0, 6.2)          # leaflet heads +-2 nm from the mid-plane: 4 nm of membrane in a 6.2-nm box
+    system = synthetic.cg_membrane(100, leaflets=LEAFLETS_GLOBAL, n_types=2, box=box)
+    if variant == "subset":            # membrane group = every second atom: only the generic kernel can take it
+        system.tables.leaflets.membrane = np.arange(0, system.n_atoms, 2, dtype=np.uint32)
+    n = 9
+    xyz = system.frames(n, seed=23)
+    if variant == "thick":             # ... and shifted so that it straddles the periodic boundary
+        xyz[:, :, 2] = np.mod(xyz[:, :, 2] + 3.0, 6.2).astype(np.float32)
+    eng, got = run_gpu(system, xyz, system.box9(n), batches=2)
+    o, want = run_oracle(system, xyz, system.box9(n))
+    flags, fr = eng.leaflets()
+    oflags, odist, ofr = o.leaflets()
+    assert fr == ofr == n - 1
+    diff = flags != oflags
+    assert not diff.any() or np.abs(odist[diff]).max() < 1e-4
+    np.testing.assert_allclose(eng.leaflet_distances()[~diff], odist[~diff], atol=5e-5)
+    assert 0 < flags.sum() < len(flags)
+    if not diff.any():
+        np.testing.assert_array_equal(got.sums, want.sums)
+        np.testing.assert_array_equal(got.counts, want.counts)
