@@ -13,6 +13,8 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/gorder_xtc.h"
@@ -140,6 +142,7 @@ double bed(const uint8_t *p) {
 }  // namespace
 
 struct gorder_xtc_reader {
+    std::string path;                 // for the worker threads of gorder_xtc_read_window_mt (own file handles)
     FILE *fp = nullptr;
     bool trr = false;                 // GROMACS TRR (magic 1993, uncompressed reals) instead of XTC (magic 1995)
     uint32_t natoms = 0;
@@ -337,6 +340,7 @@ int gorder_xtc_open(const char *path, const uint32_t *group, uint32_t n_group, g
     }
     gorder_xtc_reader *r = new gorder_xtc_reader();
     r->fp = fp;
+    r->path = path;
     fseek(fp, 0, SEEK_SET);
     if (be32(head) == 1993u) {           // TRR: the atom count sits behind the version string
         r->trr = true;
@@ -464,6 +468,51 @@ int64_t gorder_xtc_read_window(gorder_xtc_reader *r, float begin_ps, float end_p
         written++;
     }
     return (int64_t)written;
+}
+
+int64_t gorder_xtc_read_window_mt(gorder_xtc_reader *r, float begin_ps, float end_ps, uint32_t step,
+                                  uint64_t *state, double *last_time, float *xyz, float *box9, float *time_ps,
+                                  uint64_t capacity, uint32_t n_threads) {
+    if (!r || !state || !last_time || !xyz || !box9 || step == 0) return GORDER_XTC_ERR_ARGUMENT;
+    if (n_threads <= 1) return gorder_xtc_read_window(r, begin_ps, end_ps, step, state, last_time, xyz, box9, time_ps, capacity);
+    // pass 1 (sequential, headers only): which frames, and where they start
+    std::vector<long> offsets;
+    while (offsets.size() < capacity) {
+        const long pos = ftell(r->fp);
+        float t = 0.0f;
+        const int st = gorder_xtc_next(r, nullptr, nullptr, nullptr, &t, nullptr);
+        if (st == GORDER_XTC_EOF) break;
+        if (st != GORDER_XTC_OK) return st;
+        if ((double)t == *last_time) continue;             // duplicate frame at a file boundary
+        *last_time = (double)t;
+        if (t < begin_ps) continue;
+        if (end_ps >= 0.0f && t > end_ps) { fseek(r->fp, 0, SEEK_END); break; }
+        const uint64_t k = (*state)++;
+        if (k % step != 0) continue;
+        offsets.push_back(pos);
+    }
+    // pass 2: every worker decodes its share through a reader of its own
+    const size_t nout = gorder_xtc_n_atoms_out(r), n = offsets.size();
+    const uint32_t nt = (uint32_t)std::min<size_t>(n_threads, std::max<size_t>(n, 1));
+    std::vector<int> status(nt, GORDER_XTC_OK);
+    std::vector<std::thread> pool;
+    for (uint32_t w = 0; w < nt; w++)
+        pool.emplace_back([&, w]() {
+            gorder_xtc_reader *mine = nullptr;
+            int st = gorder_xtc_open(r->path.c_str(), r->group.empty() ? nullptr : r->group.data(), (uint32_t)r->group.size(), &mine);
+            for (size_t i = w; st == GORDER_XTC_OK && i < n; i += nt) {
+                if (fseek(mine->fp, offsets[i], SEEK_SET) != 0) { st = GORDER_XTC_ERR_FORMAT; break; }
+                float t = 0.0f;
+                st = gorder_xtc_next(mine, xyz + i * nout * 3, box9 + i * 9, nullptr, &t, nullptr);
+                if (st == GORDER_XTC_OK && time_ps) time_ps[i] = t;
+            }
+            gorder_xtc_close(mine);
+            status[w] = st;
+        });
+    for (auto &th : pool) th.join();
+    for (int st : status)
+        if (st != GORDER_XTC_OK) return st == GORDER_XTC_EOF ? GORDER_XTC_ERR_FORMAT : st;
+    return (int64_t)n;
 }
 
 }  // extern "C"

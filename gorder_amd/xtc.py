@@ -27,12 +27,15 @@ def _lib():
         lib.gorder_xtc_read_window.argtypes = [vp, C.c_float, C.c_float, C.c_uint32, C.POINTER(C.c_uint64),
                                                C.POINTER(C.c_double), vp, vp, vp, C.c_uint64]
         lib.gorder_xtc_read_window.restype = C.c_int64
+        lib.gorder_xtc_read_window_mt.argtypes = [vp, C.c_float, C.c_float, C.c_uint32, C.POINTER(C.c_uint64),
+                                                  C.POINTER(C.c_double), vp, vp, vp, C.c_uint64, C.c_uint32]
+        lib.gorder_xtc_read_window_mt.restype = C.c_int64
         _bound = True
     return lib
 
 
 def read_trajectory(paths: Sequence[str], group: Optional[np.ndarray] = None, begin: float = 0.0, end: float = -1.0,
-                    step: int = 1, chunk: int = 64, return_precision: bool = False):
+                    step: int = 1, chunk: int = 64, return_precision: bool = False, threads: int = 1):
     """Read (and concatenate) XTC files like gorder's `read_trajectory`
     (/root/reference/src/analysis/common.rs:239-342): time window in ps, every `step`-th frame,
     duplicate boundary frames of consecutive files dropped.
@@ -62,8 +65,8 @@ def read_trajectory(paths: Sequence[str], group: Optional[np.ndarray] = None, be
                 x = np.empty((chunk, n, 3), dtype=np.float32)
                 b = np.empty((chunk, 3, 3), dtype=np.float32)
                 t = np.empty(chunk, dtype=np.float32)
-                got = lib.gorder_xtc_read_window(r, begin, end, step, C.byref(state), C.byref(last), x.ctypes.data,
-                                                 b.ctypes.data, t.ctypes.data, chunk)
+                got = lib.gorder_xtc_read_window_mt(r, begin, end, step, C.byref(state), C.byref(last), x.ctypes.data,
+                                                    b.ctypes.data, t.ctypes.data, chunk, threads)
                 if got < 0:
                     raise IOError(f"{path}: XTC read error {got}")
                 if got == 0:

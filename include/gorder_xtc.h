@@ -56,6 +56,14 @@ int64_t gorder_xtc_read_window(gorder_xtc_reader *r, float begin_ps, float end_p
                                uint64_t *state, double *last_time, float *xyz, float *box9, float *time_ps,
                                uint64_t capacity);
 
+/* The same with `n_threads` decoder threads: the frame headers are scanned sequentially (cheap), the selected
+ * frames are then decompressed in parallel, each worker through a file handle of its own.  Output, state and
+ * return value are identical to gorder_xtc_read_window for every n_threads (the reference decodes one reader
+ * thread per analysis thread, common.rs:283-339; decoding is its bottleneck). */
+int64_t gorder_xtc_read_window_mt(gorder_xtc_reader *r, float begin_ps, float end_ps, uint32_t step,
+                                  uint64_t *state, double *last_time, float *xyz, float *box9, float *time_ps,
+                                  uint64_t capacity, uint32_t n_threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,6 +29,8 @@ def test_xtc_frame_equals_the_fixture_integers(cg):
     group = np.arange(n - 1, -1, -7, dtype=np.uint32)          # any subset, any order
     part, _, _ = xtc.read_trajectory([CG3], group=group)
     np.testing.assert_array_equal(part[0], cg.xyz[k][group])
+    part, _, _ = xtc.read_trajectory([CG3], group=group, threads=4)
+    np.testing.assert_array_equal(part[0], cg.xyz[k][group])
 
 
 def test_window_step_and_concatenation():
@@ -92,6 +94,11 @@ def test_trr(tmp_path, double):
     for k in range(4):
         np.testing.assert_array_equal(xyz[k], frames[k])      # f32 survives the f64 round trip exactly
         np.testing.assert_array_equal(b9[k], box.astype(np.float32))
+    for threads in (2, 3, 8):            # the multi-threaded window reader returns exactly the same
+        again = xtc.read_trajectory([str(path)], threads=threads)
+        assert all(np.array_equal(p, q) for p, q in zip((xyz, b9, t), again))
+        part2 = xtc.read_trajectory([str(path)], begin=2.0, end=6.0, step=2, threads=threads)
+        np.testing.assert_array_equal(part2[2], np.array([2.5], dtype=np.float32))
     group = np.array([5, 0, 36], dtype=np.uint32)
     part, _, tt = xtc.read_trajectory([str(path)], group=group, begin=2.0, end=6.0, step=1)
     np.testing.assert_array_equal(tt, np.array([2.5, 5.0], dtype=np.float32))
