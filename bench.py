@@ -45,6 +45,8 @@ def make_system(name):
         from gorder_amd.abi import LEAFLETS_LOCAL
         return (synthetic.cg_membrane(3072, leaflets=LEAFLETS_LOCAL, radius=2.5),
                 "CGOrder Martini bilayer 3072 lipids + local leaflets (r = 2.5 nm, every frame)")
+    if name == "aa256-timewise":
+        return synthetic.aa_membrane(256, timewise=True), "AAOrder 256 lipids + per-frame rows (error estimation)"
     if name == "aa256-maps":
         from gorder_amd.abi import OrderMap
         om = OrderMap(enabled=True, plane=0, span_x=(0.0, 9.0), span_y=(0.0, 9.0), bin=(0.1, 0.1))

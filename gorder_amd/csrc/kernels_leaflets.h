@@ -298,6 +298,7 @@ __global__ __launch_bounds__(256) void k_leaflets_global_contig(LeafletArgs a) {
     uint32_t r = (dn + sh + 3u * 256u - threadIdx.x) % 3u;            // j0 of this thread's chunk k; k -> k+1: r -> r-1
     float nonfinite = 0.0f, sc = 0.0f, ss = 0.0f, su = 0.0f, ulo = 3.0e38f, uhi = -3.0e38f;
     auto take = [&](float z, bool ok) {
+        z = ok ? z : zref;               // a masked lane holds an in-plane coordinate: keep it out of the image search
         if (pbc) {
             bad |= (ok && !(z <= 9.0f * L && z >= -8.0f * L)) ? 1 : 0;   // gm_wrap would give up: coordinate far outside
             float sn, cs;

@@ -372,13 +372,15 @@ def test_reference_known_answer_on_the_device(built, flags):
     np.testing.assert_allclose(res.order()[0, 0], 0.8544775, atol=1.5e-6)
 
 
-@pytest.mark.parametrize("variant", ["contiguous", "generic", "thick", "subset"])
+@pytest.mark.parametrize("variant", ["contiguous", "generic", "thick", "subset", "wide"])
 def test_global_leaflet_kernels(built, monkeypatch, variant):
     """Global classification has two kernels: the one-pass kernel for a membrane group that is the whole frame
     (with a second read when the membrane is thicker than half the box) and the generic one (index list)."""
     box = None
     if variant == "generic":
         monkeypatch.setenv("GORDER_HIP_LEAFLETS_GENERIC", "1")
+    if variant == "wide":
+        box = (120.0, 110.0, 10.0)     # in-plane coordinates many box heights away from 0 (the 1M-bead system's shape)
     if variant == "thick":
         box = (8.0, 8.0, 6.2)          # leaflet heads +-2 nm from the mid-plane: 4 nm of membrane in a 6.2-nm box
     system = synthetic.cg_membrane(100, leaflets=LEAFLETS_GLOBAL, n_types=2, box=box)
