@@ -23,6 +23,11 @@ def make_case(seed):
     frequency = int(rng.choice([0, 1, 1, 3]))
     timewise = bool(rng.random() < 0.4)
     kw = dict(leaflets=leaflets, frequency=frequency, timewise=timewise, handle_pbc=pbc)
+    shape = rng.choice(["default", "default", "wide", "tall"])     # box shapes: flat and wide like the 1M-bead system, or tall
+    if shape == "wide":
+        kw["box"] = (float(rng.uniform(60, 130)), float(rng.uniform(60, 130)), 10.0 if kind == "cg" else 8.0)
+    elif shape == "tall":
+        kw["box"] = (float(rng.uniform(9, 14)), float(rng.uniform(9, 14)), float(rng.uniform(25, 40)))
     if kind == "aa":
         system = synthetic.aa_membrane(int(rng.integers(12, 40)), **kw)
     elif kind == "cg":
