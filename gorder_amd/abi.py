@@ -281,7 +281,7 @@ _EXPORTS = [
     "gorder_hip_set_stream", "gorder_hip_submit_device", "gorder_hip_submit_host",
     "gorder_hip_prime_leaflets", "gorder_hip_set_manual_leaflets", "gorder_hip_synchronize",
     "gorder_hip_finish", "gorder_hip_timewise", "gorder_hip_leaflets", "gorder_hip_leaflet_distances",
-    "gorder_hip_normals", "gorder_hip_export_maps",
+    "gorder_hip_normals", "gorder_hip_export_maps", "gorder_hip_set_normals",
     "gorder_hip_accumulators_device", "gorder_hip_bind_accumulators", "gorder_hip_last_error_index",
     "gorder_hip_last_error_message", "gorder_hip_strerror", "gorder_hip_kernel_time", "gorder_hip_plan",
     "gorder_hip_plan_tables",
@@ -336,6 +336,7 @@ def load_library() -> C.CDLL:
     lib.gorder_hip_leaflet_distances.argtypes = [vp, vp]
     lib.gorder_hip_normals.argtypes = [vp, vp, vp]
     lib.gorder_hip_export_maps.argtypes = [vp, vp, vp, u64]
+    lib.gorder_hip_set_normals.argtypes = [vp, vp, u32]
     lib.gorder_hip_accumulators_device.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
     lib.gorder_hip_bind_accumulators.argtypes = [vp, vp, u64]
     lib.gorder_hip_last_error_index.argtypes = [vp]
@@ -521,6 +522,12 @@ class HipEngine:
         d = np.zeros(self.tables.n_molecules_total, dtype=np.float32)
         self._check(self.lib.gorder_hip_leaflet_distances(self._h, d.ctypes.data_as(C.c_void_p)))
         return d
+
+    def set_normals(self, normals: np.ndarray):
+        """Manual membrane normals [n_frames, n_molecules_total, 3] for the NEXT submit call."""
+        n = np.ascontiguousarray(normals, dtype=np.float32)
+        assert n.ndim == 3 and n.shape[1:] == (self.tables.n_molecules_total, 3)
+        self._check(self.lib.gorder_hip_set_normals(self._h, n.ctypes.data_as(C.c_void_p), n.shape[0]))
 
     def normals(self):
         """Dynamic membrane normals of the last submitted frame -> (normals [n_mol, 3] f32, n_points [n_mol])."""

@@ -88,6 +88,10 @@ struct gorder_hip_handle {
     float4 *d_dyn_normals = nullptr;
     size_t dyn_normals_cap = 0;
     std::vector<float> last_normals;   // [n_mol_total][4] of the last submitted frame
+    // manual membrane normals (ManualMembraneNormal, normal.rs:266-300): handed over per batch by the host
+    std::vector<float> manual_normals; // [frames][n_mol_total][4] (nx, ny, nz, 3) for the NEXT submit
+    uint32_t manual_frames = 0;
+    bool manual_active = false;        // this batch's samples read d_dyn_normals filled from manual_normals
     size_t shapes_cap = 0;
     uint32_t *d_err = nullptr;
     unsigned long long *d_acc = nullptr;   // [4][n_acc] + total_frames
@@ -247,8 +251,8 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
     HIP_TRY(h, hipEventCreate(&e0));
     HIP_TRY(h, hipEventCreate(&e1));
     HIP_TRY(h, hipEventRecord(e0, h->stream));
-    const bool extras = h->extra.maps || h->extra.tw || h->extra.geom_kind || h->dyn;
-    if (h->dyn) {
+    const bool extras = h->extra.maps || h->extra.tw || h->extra.geom_kind || h->dyn || h->manual_active;
+    if (h->dyn && !h->manual_active) {
         const int st2 = run_dynamic_normals(h, a);
         if (st2 != GORDER_OK) return st2;
     }
@@ -350,7 +354,7 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
         ExtraArgs e = h->extra;
         e.tw_sums = h->d_tw_sums; e.tw_cnts = h->d_tw_cnts; e.tw_row0 = h->n_frames;
         e.shapes = h->d_shapes;
-        e.dyn = h->dyn ? h->d_dyn_normals : nullptr;
+        e.dyn = (h->dyn || h->manual_active) ? h->d_dyn_normals : nullptr;
         const bool ac = (h->tables.flags & GORDER_FLAG_TRIG_ACOS_COS) != 0;
         // with ordermaps the frames go in sub-ranges short enough for the packed map words (k_fold_maps)
         uint32_t sub = e.maps ? (uint32_t)std::max<uint64_t>(1, (h->map_fold_limit - 1) / h->map_max_mol) : a.n_frames;
@@ -915,7 +919,20 @@ int gorder_hip_submit_device(gorder_hip_handle *h, const float *d_xyz, const flo
     a.nx = h->tables.normal[0]; a.ny = h->tables.normal[1]; a.nz = h->tables.normal[2]; a.n2 = h->n2; a.n2sq = h->n2sq;
     a.leaflets = leaflets ? 1 : 0; a.aflags = h->d_aflags; a.arow = h->d_arow; a.n_mol_total = p.n_mol_total;
     a.acc = h->d_acc; a.rep = h->d_rep; a.n_rep = h->n_rep; a.n_acc = p.n_acc; a.err = h->d_err;
-    if ((st = launch_orders(h, a)) != GORDER_OK) return st;
+    h->manual_active = false;
+    if (h->manual_frames) {   // normals the host supplied for exactly this batch
+        if (h->manual_frames != n_frames) return fail(h, GORDER_ERR_INVALID_ARGUMENT, "gorder_hip_set_normals: frame count differs from the batch");
+        if (!p.direct.empty()) return fail(h, GORDER_ERR_INVALID_ARGUMENT, "manual normals: a bond spans more than the LDS window");
+        const size_t n4 = (size_t)n_frames * p.n_mol_total;
+        if ((st = ensure(h, &h->d_dyn_normals, &h->dyn_normals_cap, n4)) != GORDER_OK) return st;
+        HIP_TRY(h, hipStreamSynchronize(h->stream));   // earlier batches may still read the buffer
+        HIP_TRY(h, hipMemcpy(h->d_dyn_normals, h->manual_normals.data(), n4 * 4 * sizeof(float), hipMemcpyHostToDevice));
+        h->manual_active = true;
+        h->manual_frames = 0;
+    }
+    st = launch_orders(h, a);
+    h->manual_active = false;
+    if (st != GORDER_OK) return st;
     h->rep_dirty = true;
     if (n_new_rows) {   // newest assignment becomes the carry row of the next batch
         HIP_TRY(h, hipMemcpyAsync(h->d_aflags, h->d_aflags + n_new_rows * (size_t)p.n_mol_total, p.n_mol_total,
@@ -1020,6 +1037,20 @@ int gorder_hip_finish(gorder_hip_handle *h, int64_t *sums, uint64_t *counts, int
         if (map_sums) HIP_TRY(h, hipMemcpy(map_sums, h->d_map_sums, nmap * sizeof(int64_t), hipMemcpyDeviceToHost));
         if (map_counts) HIP_TRY(h, hipMemcpy(map_counts, h->d_map_cnts, nmap * sizeof(uint64_t), hipMemcpyDeviceToHost));
     }
+    return GORDER_OK;
+}
+
+int gorder_hip_set_normals(gorder_hip_handle *h, const float *normals, uint32_t n_frames) {
+    if (!h || !normals || n_frames == 0) return GORDER_ERR_INVALID_ARGUMENT;
+    const size_t n = (size_t)n_frames * h->plan.n_mol_total;
+    h->manual_normals.resize(4 * n);
+    for (size_t i = 0; i < n; i++) {
+        h->manual_normals[4 * i + 0] = normals[3 * i + 0];
+        h->manual_normals[4 * i + 1] = normals[3 * i + 1];
+        h->manual_normals[4 * i + 2] = normals[3 * i + 2];
+        h->manual_normals[4 * i + 3] = 3.0f;     // "enough points": the sample kernels treat it like a computed normal
+    }
+    h->manual_frames = n_frames;
     return GORDER_OK;
 }
 

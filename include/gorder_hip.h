@@ -242,6 +242,13 @@ int gorder_hip_leaflets(gorder_hip_handle *h, uint8_t *flags, uint64_t *assignme
 /* Signed distances (nm) behind those flags, [n_molecules_total] (leaflets.rs:725, 796). */
 int gorder_hip_leaflet_distances(gorder_hip_handle *h, float *distances);
 
+/* Manual membrane normals (MembraneNormal::Manual, ManualMembraneNormal::get_normal, normal.rs:266-300): the host
+ * resolves the normals file and hands over, before a submit call, one vector per frame of that batch and per
+ * molecule — normals [n_frames][n_molecules_total][3] (host memory, copied; any length, calc_sch normalises).
+ * They replace the static / dynamic normal for exactly the next gorder_hip_submit_* call, whose n_frames must
+ * match. */
+int gorder_hip_set_normals(gorder_hip_handle *h, const float *normals, uint32_t n_frames);
+
 /* Dynamic membrane normals of the LAST submitted frame: normals [n_molecules_total][3] (unit vectors; NaN
  * for a molecule whose cloud had fewer than 3 points), n_points [n_molecules_total] the cloud sizes
  * (what NormalsStorage keeps per frame, normal.rs:460-520).  Requires tables.dynamic_normal.enabled. */

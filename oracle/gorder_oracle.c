@@ -578,6 +578,8 @@ struct gorder_oracle_handle {
     gorder_dynamic_normal_t dyn;
     uint32_t *dyn_cloud;
     float *last_normals;      /* [n_mol_total][4] (nx, ny, nz, n_points) of the last analysed frame */
+    float *manual_normals;    /* [manual_frames][n_mol_total][3] for the next submit (ManualMembraneNormal, normal.rs:266-300) */
+    uint32_t manual_frames;
     o_acc acc;
     /* leaflets: flags of the most recent assignment (AssignedLeaflets::local, leaflets.rs:1371-1380) */
     uint8_t *flags;
@@ -719,7 +721,7 @@ void gorder_oracle_destroy(gorder_oracle_handle *h) {
         for (uint32_t a = 0; a < d->n_ua_atoms; a++) free(d->ua_idx[a]);
         free(d->ua_kind); free(d->ua_idx); free(d->ua_slot0); free(d->heads); free(d->methyls); free(d->normal_heads);
     }
-    free(h->mt); free(h->membrane); free(h->geom_group); free(h->dyn_cloud); free(h->last_normals); acc_free(&h->acc);
+    free(h->mt); free(h->membrane); free(h->geom_group); free(h->dyn_cloud); free(h->last_normals); free(h->manual_normals); acc_free(&h->acc);
     free(h->flags); free(h->flag_dist); free(h->tw_sums); free(h->tw_counts);
     free(h);
 }
@@ -853,7 +855,8 @@ static inline void add_order(const gorder_oracle_handle *h, o_acc *a, int64_t *t
  * (uaorder.rs:400-437).  `flags` = leaflet assignment that applies to this frame. */
 static int analyze_frame_orders(const gorder_oracle_handle *h, o_acc *a, int64_t *tw_s, uint64_t *tw_n,
                                 const float *xyz, const float *box, const uint8_t *flags,
-                                uint64_t *err_index, float *normals_out /* [n_mol_total][4] scratch */) {
+                                uint64_t *err_index, float *normals_out /* [n_mol_total][4] scratch */,
+                                const float *manual /* [n_mol_total][3] normals of this frame or NULL */) {
     int bad = 0;
     const int lf = h->lf.method != GORDER_LEAFLETS_NONE;
     const int geom = h->geom.kind != GORDER_GEOM_NONE;
@@ -870,7 +873,15 @@ static int analyze_frame_orders(const gorder_oracle_handle *h, o_acc *a, int64_t
      * normal.rs:145-158); computing all of them up front gives the same values — only the
      * NotEnoughPoints error must wait until a sample of that molecule is really accumulated */
     float *dyn = NULL;
-    if (h->dyn.enabled) {
+    if (manual) {             /* ManualMembraneNormal::get_normal(frame, molecule): the vector the host supplied */
+        dyn = normals_out;
+        for (uint32_t i = 0; i < h->n_mol_total; i++) {
+            dyn[4 * (size_t)i + 0] = manual[3 * (size_t)i + 0];
+            dyn[4 * (size_t)i + 1] = manual[3 * (size_t)i + 1];
+            dyn[4 * (size_t)i + 2] = manual[3 * (size_t)i + 2];
+            dyn[4 * (size_t)i + 3] = 3.0f;
+        }
+    } else if (h->dyn.enabled) {
         dyn = normals_out;
         for (uint32_t m = 0; m < h->n_mt; m++)
             for (uint32_t i = 0; i < h->mt[m].n_molecules; i++) {
@@ -951,6 +962,7 @@ typedef struct {
     uint32_t n_frames, tid, nthr;
     o_acc acc;
     int64_t *tw_s; uint64_t *tw_n; /* batch timewise rows (shared, disjoint rows per thread) */
+    const float *manual;           /* manual normals of the batch or NULL */
     int status; uint64_t err_index;
 } o_job;
 
@@ -958,7 +970,8 @@ static void *worker(void *arg) {
     o_job *j = (o_job *)arg;
     gorder_oracle_handle *h = j->h;
     const size_t row = 3 * (size_t)h->n_acc;
-    float *normals = h->dyn.enabled ? (float *)malloc(4 * sizeof(float) * (size_t)(h->n_mol_total ? h->n_mol_total : 1)) : NULL;
+    const int use_normals = h->dyn.enabled || j->manual;
+    float *normals = use_normals ? (float *)malloc(4 * sizeof(float) * (size_t)(h->n_mol_total ? h->n_mol_total : 1)) : NULL;
     for (uint32_t f = j->tid; f < j->n_frames; f += j->nthr) {
         float box3[3] = {0, 0, 0};
         if (h->pbc) {
@@ -968,7 +981,8 @@ static void *worker(void *arg) {
         const int st = analyze_frame_orders(
             h, &j->acc, j->tw_s ? j->tw_s + row * f : NULL, j->tw_n ? j->tw_n + row * f : NULL,
             j->xyz + 3 * (size_t)h->n_atoms * f, box3,
-            j->frame_flags ? j->frame_flags + (size_t)h->n_mol_total * f : NULL, &j->err_index, normals);
+            j->frame_flags ? j->frame_flags + (size_t)h->n_mol_total * f : NULL, &j->err_index, normals,
+            j->manual ? j->manual + 3 * (size_t)h->n_mol_total * f : NULL);
         if (st != GORDER_OK) { j->status = st; break; }
         if (normals && f + 1 == j->n_frames) memcpy(h->last_normals, normals, 4 * sizeof(float) * (size_t)h->n_mol_total);
     }
@@ -1024,6 +1038,7 @@ int gorder_oracle_submit(gorder_oracle_handle *h, const float *xyz, const float 
         for (uint32_t t = 0; t < nthr; t++) {
             jobs[t].h = h; jobs[t].xyz = xyz; jobs[t].box = box; jobs[t].frame_flags = frame_flags;
             jobs[t].n_frames = n_frames; jobs[t].tid = t; jobs[t].nthr = nthr;
+            jobs[t].manual = (h->manual_frames == n_frames) ? h->manual_normals : NULL;
             jobs[t].tw_s = tw_s; jobs[t].tw_n = tw_n; jobs[t].status = GORDER_OK;
             acc_alloc(h, &jobs[t].acc);
             if (nthr > 1) pthread_create(&th[t], NULL, worker, &jobs[t]);
@@ -1053,6 +1068,7 @@ int gorder_oracle_submit(gorder_oracle_handle *h, const float *xyz, const float 
     }
     if (status == GORDER_OK) h->n_frames += n_frames;
 done:
+    h->manual_frames = 0;   /* manual normals apply to one submit call */
     free(frame_flags);
     return status;
 }
@@ -1097,6 +1113,15 @@ int gorder_oracle_timewise(gorder_oracle_handle *h, int64_t *tw_sums, uint64_t *
     const size_t row = 3 * (size_t)h->n_acc;
     memcpy(tw_sums, h->tw_sums, row * h->n_frames * sizeof(int64_t));
     memcpy(tw_counts, h->tw_counts, row * h->n_frames * sizeof(uint64_t));
+    return GORDER_OK;
+}
+
+int gorder_oracle_set_normals(gorder_oracle_handle *h, const float *normals, uint32_t n_frames) {
+    if (!h || !normals || n_frames == 0) return GORDER_ERR_INVALID_ARGUMENT;
+    const size_t n = 3 * (size_t)n_frames * h->n_mol_total;
+    h->manual_normals = (float *)realloc(h->manual_normals, n * sizeof(float));
+    memcpy(h->manual_normals, normals, n * sizeof(float));
+    h->manual_frames = n_frames;
     return GORDER_OK;
 }
 

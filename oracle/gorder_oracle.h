@@ -46,6 +46,8 @@ int gorder_oracle_finish(gorder_oracle_handle *h, int64_t *sums, uint64_t *count
 int gorder_oracle_timewise(gorder_oracle_handle *h, int64_t *tw_sums, uint64_t *tw_counts,
                            uint64_t capacity_frames);
 /* flags of the most recent assignment frame + the signed distances they were derived from */
+/* manual membrane normals [n_frames][n_mol_total][3] for the next submit call (see gorder_hip_set_normals) */
+int gorder_oracle_set_normals(gorder_oracle_handle *h, const float *normals, uint32_t n_frames);
 /* dynamic membrane normals of the last analysed frame (see gorder_hip_normals) */
 int gorder_oracle_normals(gorder_oracle_handle *h, float *normals, uint32_t *n_points);
 /* one normal: normal[4] = (nx, ny, nz, number of cloud points) — normal.rs:160-199, 421-458 */

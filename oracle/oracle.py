@@ -45,6 +45,7 @@ def load():
     lib.gorder_oracle_timewise.argtypes = [vp, vp, vp, u64]
     lib.gorder_oracle_leaflets.argtypes = [vp, vp, vp, C.POINTER(u64)]
     lib.gorder_oracle_normals.argtypes = [vp, vp, vp]
+    lib.gorder_oracle_set_normals.argtypes = [vp, vp, u32]
     lib.gorder_oracle_dynamic_normal.argtypes = [vp, vp, u32, u32, f32, vp, i32, vp]
     lib.gorder_oracle_last_error_index.argtypes = [vp]
     lib.gorder_oracle_last_error_index.restype = u64
@@ -223,6 +224,10 @@ class OracleEngine:
         c = np.zeros((n_frames, 3, n), dtype=np.uint64)
         self._check(self.lib.gorder_oracle_timewise(self._h, s.ctypes.data, c.ctypes.data, n_frames))
         return s, c
+
+    def set_normals(self, normals):
+        n = np.ascontiguousarray(normals, dtype=np.float32)
+        self._check(self.lib.gorder_oracle_set_normals(self._h, n.ctypes.data, n.shape[0]))
 
     def normals(self):
         """Dynamic membrane normals of the last analysed frame -> (normals [n_mol, 3], n_points [n_mol])."""

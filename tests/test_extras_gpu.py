@@ -300,3 +300,43 @@ def test_united_atom_ordermaps_staged_and_direct(built, monkeypatch, leaflets, d
     np.testing.assert_array_equal(got.map_sums[:, ~ch1u], want.map_sums[:, ~ch1u])
     assert np.abs(got.map_sums[:, ch1u] - want.map_sums[:, ch1u]).max() <= got.map_counts[:, ch1u].max()   # <= 1 tick a sample
     assert got.map_counts.sum() > 0
+
+
+@pytest.mark.parametrize("kind", ["cg", "ua"])
+def test_manual_normals(built, kind):
+    """MembraneNormal::Manual (normal.rs:266-300): one vector per frame and molecule, supplied by the host for
+    each batch.  z for everybody reproduces the static-axis run bit for bit; arbitrary vectors match the oracle."""
+    system = synthetic.cg_membrane(90, leaflets=LEAFLETS_GLOBAL, n_types=2) if kind == "cg" else \
+        synthetic.ua_membrane(30, leaflets=LEAFLETS_GLOBAL)
+    n, n_mol = 10, system.tables.n_molecules_total
+    xyz, box = system.frames(n, seed=41), system.box9(n)
+    static = HipEngine(system.tables)
+    static.submit_host(xyz, box, np.arange(n))
+    want_static = static.finish()
+    z = np.zeros((n, n_mol, 3), dtype=np.float32)
+    z[:, :, 2] = 1.0
+    rng = np.random.default_rng(2)
+    tilted = rng.normal(size=(n, n_mol, 3)).astype(np.float32) * 0.4 + z       # not unit length: calc_sch normalises
+    for normals, same_as_static in ((z, True), (tilted, False)):
+        eng = HipEngine(system.tables)
+        o = oracle.OracleEngine(system.tables, trig=oracle.TRIG_DIRECT, n_threads=2)
+        for a, b in ((0, 4), (4, n)):
+            eng.set_normals(normals[a:b])
+            eng.submit_host(xyz[a:b], box[a:b], np.arange(a, b))
+            o.set_normals(normals[a:b])
+            o.submit(xyz[a:b], box[a:b], np.arange(a, b))
+        got, want = eng.finish(), o.finish()
+        np.testing.assert_array_equal(got.counts, want.counts)
+        if kind == "cg":
+            np.testing.assert_array_equal(got.sums, want.sums)
+            if same_as_static:
+                np.testing.assert_array_equal(got.sums, want_static.sums)
+            else:
+                assert (got.sums != want_static.sums).any()
+        else:           # unsaturated CH hydrogens: device sincosf vs host libm, <= 1 tick
+            assert np.abs(got.order_ticks() - want.order_ticks()).max() <= 1
+    # the batch size must match
+    eng = HipEngine(system.tables)
+    eng.set_normals(z[:3])
+    with pytest.raises(abi.GorderHipError):
+        eng.submit_host(xyz[:4], box[:4], np.arange(4))
