@@ -110,3 +110,41 @@ def test_threads_do_not_change_results(built):
         np.testing.assert_array_equal(r.sums, ref.sums)
         np.testing.assert_array_equal(r.counts, ref.counts)
         assert r.n_frames == 29
+
+
+# ---- united-atom hydrogen construction: the reference's own position KATs (uaorder.rs:1113-1200) ---------------
+# The tests there read tests/files/ua.tpr; its PDB twin tests/files/ua_nobox.pdb carries the same coordinates to
+# 1e-4 nm, and these thirteen atoms (nm, as printed there) are all the four KATs touch.
+UA_KAT_ATOMS = {11: (1.713, 2.717, 1.731), 12: (1.601, 2.675, 1.826), 13: (1.594, 2.754, 1.946),
+                22: (1.193, 2.903, 2.586), 23: (1.118, 2.901, 2.720), 24: (1.075, 2.781, 2.774),
+                31: (1.622, 2.525, 1.847), 38: (2.158, 2.258, 2.104), 39: (2.310, 2.254, 2.123),
+                40: (2.346, 2.325, 2.254), 47: (3.052, 2.834, 2.149), 48: (3.172, 2.742, 2.176),
+                49: (3.287, 2.820, 2.239)}
+UA_KATS = [
+    # kind, (helper1, target, helper2, -) or (helper1, helper2, helper3, target), expected hydrogens
+    ("CH2", (38, 39, 40, 39), [(2.3435528, 2.1503785, 2.1272178), (2.35857, 2.3045487, 2.039533)]),
+    ("CH3", (48, 49, 47, 49), [(3.3708375, 2.7527616, 2.257202), (3.254057, 2.8633823, 2.3334126),
+                               (3.3182635, 2.8995805, 2.1713943)]),
+    ("CH1_UNSAT", (22, 23, 24, 23), [(1.0985602, 2.994375, 2.7727659)]),
+    ("CH1_SAT", (11, 31, 13, 12), [(1.5022101, 2.6938448, 1.7839708)]),
+]
+
+
+@pytest.mark.parametrize("kind,atoms,want", UA_KATS)
+def test_predicted_hydrogen_positions(built, kind, atoms, want):
+    """All seven predicted positions within 2 ulp (5e-7 nm) of the reference's values — which hydrogen is which,
+    the rotation conventions and their signs, shift along the NORMALISED direction by 0.109 nm."""
+    import ctypes as C
+    from gorder_amd import abi
+    lib = oracle.load()
+    code = {"CH2": abi.UA_CH2, "CH3": abi.UA_CH3, "CH1_UNSAT": abi.UA_CH1_UNSAT, "CH1_SAT": abi.UA_CH1_SAT}[kind]
+    pos = np.array([UA_KAT_ATOMS[a] for a in atoms], dtype=np.float32)
+    box = np.array([6.28779, 6.28779, 7.66264], dtype=np.float32)          # box of ua.tpr / ua.xtc
+    for pbc in (1, 0):
+        out = np.zeros((3, 3), dtype=np.float32)
+        n = lib.gorder_oracle_predict_hydrogens(code, pos.ctypes.data, box.ctypes.data, pbc, out.ctypes.data)
+        assert n == len(want)
+        assert np.abs(out[:n] - np.array(want, dtype=np.float32)).max() <= 5e-7
+        # each hydrogen sits BOND_LENGTH = 0.109 nm from its carbon
+        target = pos[3] if kind == "CH1_SAT" else pos[1]
+        np.testing.assert_allclose(np.linalg.norm(out[:n] - target, axis=1), 0.109, atol=1e-6)
