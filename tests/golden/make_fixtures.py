@@ -57,7 +57,34 @@ def pack(name, gro, bnd, xtcs):
           "->", os.path.getsize(out) // 1024, "KiB")
 
 
+def single_frame_kats():
+    """The literal expectation arrays of the reference's single-frame tests (aaorder.rs:226-464, cgorder.rs:188-351:
+    per bond type the SUM of the order parameters of one frame — the structure file's coordinates — total / upper /
+    lower) + those coordinates as the .gro twins of the .tpr files print them (1e-3 nm, which loosens the pin)."""
+    import json
+    import re
+    out = {}
+    for name, rs, gro, tag in (("aa", "aaorder.rs", "pcpepg.gro", "pcpepg"), ("cg", "cgorder.rs", "cg.gro", "cg")):
+        src = open(os.path.join(REF, "..", "..", "src", "analysis", rs)).read()
+        d = {}
+        for fn in ("expected_total_orders", "expected_upper_orders", "expected_lower_orders"):
+            body = src[src.index(f"fn {fn}()"):]
+            body = body[:body.index("\n    }\n")]
+            vecs = re.findall(r"vec!\[(.*?)\]", body, re.S)
+            d[fn.replace("expected_", "").replace("_orders", "")] = [
+                [float(x) for x in v.replace("\n", " ").split(",") if x.strip()] for v in vecs]
+        out[name] = d
+        g = st.read_gro(os.path.join(REF, gro))
+        keep = np.array([r in LIPIDS for r in g.resnames])
+        ints = np.rint(g.positions[keep].astype(np.float64) * 1000).astype(np.int32)
+        np.savez_compressed(os.path.join(HERE, f"{tag}_structure_frame.npz"), ints=ints.astype(np.int16),
+                            box=np.asarray(g.box, dtype=np.float32))
+    with open(os.path.join(HERE, "expected", "single_frame_sums.json"), "w") as f:
+        json.dump(out, f)
+
+
 if __name__ == "__main__":
+    single_frame_kats()
     pack("pcpepg", "pcpepg.gro", "pcpepg.bnd", [f"split/pcpepg{i}.xtc" for i in range(1, 6)])
     pack("cg", "cg.gro", "cg.bnd", [f"split/cg{i}.xtc" for i in range(1, 6)])
     pack("ua", "ua_nobox.pdb", None, ["ua.xtc"])      # tests_ua.rs:19-68 (names + bonds from the PDB twin of ua.tpr)

@@ -223,3 +223,17 @@ def test_ua_ordermaps(ua):
     assert check_ordermaps(res, labels, om) == 7
     _, ref = oracle_run(tables, xyz, box, fi, oracle.TRIG_DIRECT)
     np.testing.assert_array_equal(res.map_counts, ref.map_counts)
+
+
+# ---- single-frame tests of the reference ------------------------------------------------------------------
+from test_golden_oracle import check_single_frame, single_frame   # noqa: E402
+
+
+@pytest.mark.parametrize("kind", ["aa", "cg"])
+def test_single_frame_leaflet_populations_and_sums(kind, pcpepg, cg):
+    # aaorder.rs:226-464, cgorder.rs:188-351: leaflet populations 65-64-8 / 66-64-7 and 121-121-12, sums per bond type
+    fx = pcpepg if kind == "aa" else cg
+    tables, labels, xyz, box, want = single_frame(kind, fx)
+    eng = HipEngine(tables)
+    eng.submit_host(xyz, box, [0])
+    check_single_frame(kind, eng.finish(), labels, want)

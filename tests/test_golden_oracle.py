@@ -370,3 +370,44 @@ def test_ua_ordermaps(ua):
     res = eng.finish()
     assert res.map_sums.shape[2:] == (14, 4)          # GridMap: round(6.288 / 0.5) + 1, round(6.288 / 2) + 1
     assert check_ordermaps(res, labels, om) == 7
+
+
+# ---- single-frame tests of the reference (aaorder.rs:226-464, cgorder.rs:188-351) ------------------------------
+def single_frame(kind, fx):
+    """The structure file's own coordinates (its .gro twin, 1e-3 nm) as one frame with global leaflets, and the
+    literal expectation arrays of the reference's unit tests."""
+    import json
+    import os
+    from golden_util import GOLDEN
+    z = np.load(os.path.join(GOLDEN, ("pcpepg" if kind == "aa" else "cg") + "_structure_frame.npz"))
+    xyz = (z["ints"].astype(np.float32) * np.float32(0.001)).astype(np.float32)
+    box = np.zeros((1, 3, 3), dtype=np.float32)
+    box[0, 0, 0], box[0, 1, 1], box[0, 2, 2] = z["box"]
+    with open(os.path.join(GOLDEN, "expected", "single_frame_sums.json")) as f:
+        want = json.load(f)[kind]
+    setup = aa_setup if kind == "aa" else cg_setup
+    tables, labels, midx = setup(fx, leaflets=METHODS["global"])
+    return tables, labels, np.ascontiguousarray(xyz[midx][None]), box, want
+
+
+def check_single_frame(kind, res, labels, want):
+    counts = {"aa": ([131, 128, 15], [65, 64, 8], [66, 64, 7]), "cg": ([242, 242, 24], [121, 121, 12], [121, 121, 12])}[kind]
+    sign = -1.0 if kind == "aa" else 1.0
+    for w, key in enumerate(("total", "upper", "lower")):
+        for m, ml in enumerate(labels):
+            sl = slice(ml.slot0, ml.slot0 + len(ml.bonds))
+            # the leaflet populations are exact: this pins the global classifier (and its Bai-Breen centre)
+            assert set(res.counts[w, sl].tolist()) == {counts[w][m]}
+            # the sums only as far as 1e-3-nm coordinates allow (the test itself uses the .tpr's full precision)
+            got = sign * res.sums[w, sl] / 1e6
+            assert np.abs(got - np.array(want[key][m])).max() < 0.2
+            assert abs(got.sum() - np.sum(want[key][m])) < 0.6
+
+
+@pytest.mark.parametrize("kind", ["aa", "cg"])
+def test_single_frame_leaflet_populations_and_sums(kind, pcpepg, cg):
+    fx = pcpepg if kind == "aa" else cg
+    tables, labels, xyz, box, want = single_frame(kind, fx)
+    eng = oracle.OracleEngine(tables, trig=oracle.TRIG_LIBM)
+    eng.submit(xyz, box, [0])
+    check_single_frame(kind, eng.finish(), labels, want)
