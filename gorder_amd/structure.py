@@ -487,7 +487,7 @@ def results_tree(res: Results, labels: Sequence[MolLabels], analysis: str, leafl
             else:
                 ts = np.asarray(timewise[0])[:, w, slots].sum(axis=1)
                 tc = np.asarray(timewise[1])[:, w, slots].sum(axis=1)
-                e = estimate_error(ts, tc, n_blocks)
+                e = estimate_error(ts, tc, n_blocks) if mean == mean else float("nan")   # below min_samples: no error either
                 out[key] = {"mean": mean, "error": round4(e) if e == e else float("nan")}
         return out
 

@@ -96,7 +96,10 @@ if __name__ == "__main__":
               "aa_order_cuboid_dynamic.yaml", "aa_order_cylinder_dynamic.yaml", "aa_order_sphere_dynamic.yaml",
               "aa_order_leaflets_dynamic.yaml", "cg_order_leaflets_dynamic.yaml", "ua_order_dynamic_normals.yaml",
               "aa_leaflets_every1.yaml", "aa_order_error.yaml", "aa_order_error_leaflets.yaml",
-              "cg_order_error.yaml", "cg_order_error_leaflets.yaml"):
+              "cg_order_error.yaml", "cg_order_error_leaflets.yaml",
+              "aa_order_limit.yaml", "aa_order_leaflets_limit.yaml", "aa_order_step.yaml", "aa_order_begin_end.yaml",
+              "aa_order_cylinder_z_inverted.yaml",
+              "aa_order_sphere_dynamic_inverted.yaml", "aa_order_error_blocks10.yaml", "aa_order_error_limit.yaml"):
         src = os.path.join(REF, f)
         if os.path.exists(src):
             shutil.copy(src, os.path.join(HERE, "expected", f))

@@ -237,3 +237,17 @@ def test_single_frame_leaflet_populations_and_sums(kind, pcpepg, cg):
     eng = HipEngine(tables)
     eng.submit_host(xyz, box, [0])
     check_single_frame(kind, eng.finish(), labels, want)
+
+
+# ---- more of the reference's goldens: min_samples, windows, inverted shapes, block counts -------------------------
+from test_golden_oracle import MORE_CASES, more_setup   # noqa: E402
+
+
+@pytest.mark.parametrize("name", sorted(MORE_CASES))
+def test_more_reference_goldens(pcpepg, name):
+    tables, labels, midx, frames, fidx, min_samples, blocks, lf = more_setup(pcpepg, name)
+    eng, res, xyz, box, fi = gpu_run(tables, pcpepg, midx, frames, frame_index=fidx)
+    tw = eng.timewise(len(frames)) if blocks else None
+    tree = st.results_tree(res, labels, "aa", leaflets=lf, min_samples=min_samples, timewise=tw, n_blocks=blocks or 5)
+    bad = st.compare_trees(tree, expected(name))
+    assert not bad, bad[:10]
