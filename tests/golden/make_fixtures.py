@@ -99,7 +99,9 @@ if __name__ == "__main__":
               "cg_order_error.yaml", "cg_order_error_leaflets.yaml",
               "aa_order_limit.yaml", "aa_order_leaflets_limit.yaml", "aa_order_step.yaml", "aa_order_begin_end.yaml",
               "aa_order_cylinder_z_inverted.yaml",
-              "aa_order_sphere_dynamic_inverted.yaml", "aa_order_error_blocks10.yaml", "aa_order_error_limit.yaml"):
+              "aa_order_sphere_dynamic_inverted.yaml", "aa_order_error_blocks10.yaml", "aa_order_error_limit.yaml",
+              "cg_order_cuboid_square.yaml", "cg_order_cylinder.yaml", "cg_order_cylinder_z_inverted.yaml",
+              "cg_order_begin_end.yaml", "cg_order_limit.yaml"):
         src = os.path.join(REF, f)
         if os.path.exists(src):
             shutil.copy(src, os.path.join(HERE, "expected", f))

@@ -251,3 +251,16 @@ def test_more_reference_goldens(pcpepg, name):
     tree = st.results_tree(res, labels, "aa", leaflets=lf, min_samples=min_samples, timewise=tw, n_blocks=blocks or 5)
     bad = st.compare_trees(tree, expected(name))
     assert not bad, bad[:10]
+
+
+from test_golden_oracle import CG_MORE, cg_more_setup   # noqa: E402
+
+
+@pytest.mark.parametrize("name", sorted(CG_MORE))
+def test_more_cg_goldens(cg, name):
+    tables, labels, midx, frames, min_samples, lf = cg_more_setup(cg, name)
+    eng, res, xyz, box, fi = gpu_run(tables, cg, midx, frames, frame_index=np.arange(len(frames)))
+    bad = st.compare_trees(st.results_tree(res, labels, "cg", leaflets=lf, min_samples=min_samples), expected(name))
+    assert not bad, bad[:10]
+    _, ref = oracle_run(tables, xyz, box, fi, oracle.TRIG_DIRECT)
+    np.testing.assert_array_equal(res.counts, ref.counts)

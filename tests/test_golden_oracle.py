@@ -475,3 +475,39 @@ def test_more_reference_goldens(pcpepg, name):
     tree = st.results_tree(res, labels, "aa", leaflets=lf, min_samples=min_samples, timewise=tw, n_blocks=blocks or 5)
     bad = st.compare_trees(tree, expected(name))
     assert not bad, bad[:10]
+
+
+# ---- the coarse-grained counterparts (tests_cg.rs:620-650, 893-916, 2468-2530, 2682-2715) ---------------------
+CG_MORE = {
+    "cg_order_limit.yaml": (dict(), (None, None, 1), 5000, False),
+    "cg_order_begin_end.yaml": (dict(leaflets="global"), (352_000.0, 358_000.0, 1), 1, True),
+    "cg_order_cuboid_square.yaml": (dict(geometry=Geometry(kind=GEOM_CUBOID, reference=GEOMREF_BOX_CENTER,
+                                                           xdim=(-8.0, -2.0), ydim=(2.0, 8.0))), (None, None, 1), 1, False),
+    "cg_order_cylinder.yaml": (dict(geometry=Geometry(kind=GEOM_CYLINDER, reference=GEOMREF_POINT, point=(2.0, 1.0, 0.0),
+                                                      radius=3.25, orientation=2)), (None, None, 1), 1, False),
+    "cg_order_cylinder_z_inverted.yaml": (dict(geometry=Geometry(kind=GEOM_CYLINDER, reference=GEOMREF_POINT,
+                                                                 point=(3.0, 3.0, 3.0), radius=4.0, orientation=2,
+                                                                 invert=True)), (None, None, 1), 1, False),
+}
+
+
+def cg_more_setup(fx, name):
+    kw, window, min_samples, lf = CG_MORE[name]
+    kw = dict(kw)
+    if "leaflets" in kw:
+        kw["leaflets"] = METHODS[kw["leaflets"]]
+    if "geometry" in kw:
+        kw["geometry"].structure_box = tuple(float(x) for x in fx.structure.box)
+    tables, labels, midx = cg_setup(fx, **kw)
+    frames = fx.window(*window)
+    return tables, labels, midx, frames, min_samples, lf
+
+
+@pytest.mark.parametrize("name", sorted(CG_MORE))
+def test_more_cg_goldens(cg, name):
+    tables, labels, midx, frames, min_samples, lf = cg_more_setup(cg, name)
+    eng = oracle.OracleEngine(tables, trig=oracle.TRIG_LIBM, n_threads=3)
+    eng.submit(master_frames(cg, midx, frames), cg.boxes[frames], np.arange(len(frames)))
+    tree = st.results_tree(eng.finish(), labels, "cg", leaflets=lf, min_samples=min_samples)
+    bad = st.compare_trees(tree, expected(name))
+    assert not bad, bad[:10]
