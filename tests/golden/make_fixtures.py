@@ -88,6 +88,7 @@ if __name__ == "__main__":
     pack("pcpepg", "pcpepg.gro", "pcpepg.bnd", [f"split/pcpepg{i}.xtc" for i in range(1, 6)])
     pack("cg", "cg.gro", "cg.bnd", [f"split/cg{i}.xtc" for i in range(1, 6)])
     pack("ua", "ua_nobox.pdb", None, ["ua.xtc"])      # tests_ua.rs:19-68 (names + bonds from the PDB twin of ua.tpr)
+    pack("ua_nobox", "ua_nobox.pdb", None, ["ua_whole_nobox.xtc"])   # tests_ua.rs:686-714: molecules whole, no box, handle_pbc(false)
     for f in ("aa_order_basic.yaml", "aa_order_begin_end_step.yaml", "aa_order_leaflets.yaml",
               "cg_order_basic.yaml", "cg_order_begin_end_step.yaml", "cg_order_leaflets.yaml",
               "ua_order_basic.yaml", "ua_order_leaflets.yaml",
@@ -101,7 +102,7 @@ if __name__ == "__main__":
               "aa_order_cylinder_z_inverted.yaml",
               "aa_order_sphere_dynamic_inverted.yaml", "aa_order_error_blocks10.yaml", "aa_order_error_limit.yaml",
               "cg_order_cuboid_square.yaml", "cg_order_cylinder.yaml", "cg_order_cylinder_z_inverted.yaml",
-              "cg_order_begin_end.yaml", "cg_order_limit.yaml"):
+              "cg_order_begin_end.yaml", "cg_order_limit.yaml", "ua_order_leaflets_nopbc.yaml"):
         src = os.path.join(REF, f)
         if os.path.exists(src):
             shutil.copy(src, os.path.join(HERE, "expected", f))

@@ -264,3 +264,26 @@ def test_more_cg_goldens(cg, name):
     assert not bad, bad[:10]
     _, ref = oracle_run(tables, xyz, box, fi, oracle.TRIG_DIRECT)
     np.testing.assert_array_equal(res.counts, ref.counts)
+
+
+@pytest.fixture(scope="module")
+def ua_nobox(built):
+    return Fixture("ua_nobox")
+
+
+def test_ua_order_leaflets_without_pbc(ua_nobox):
+    # tests_ua.rs:686-714: handle_pbc(false) on whole molecules without a box — the NoPBC arms of every operation
+    tables, labels, midx = ua_setup(ua_nobox, leaflets=METHODS["global"], handle_pbc=False)
+    frames = ua_nobox.window()
+    eng = HipEngine(tables)
+    xyz = np.ascontiguousarray(ua_nobox.xyz[frames][:, midx, :])
+    for a, b in ((0, 20), (20, len(frames))):
+        eng.submit_host(xyz[a:b], None, frames[a:b])
+    res = eng.finish()
+    bad = st.compare_trees(st.results_tree_ua(res, labels, leaflets=True), expected("ua_order_leaflets_nopbc.yaml"))
+    assert not bad, bad[:10]
+    o = oracle.OracleEngine(tables, trig=oracle.TRIG_DIRECT, n_threads=4)
+    o.submit(xyz, None, frames)
+    ref = o.finish()
+    np.testing.assert_array_equal(res.counts, ref.counts)
+    assert np.abs(res.order_ticks() - ref.order_ticks()).max() <= 1

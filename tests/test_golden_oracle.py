@@ -511,3 +511,19 @@ def test_more_cg_goldens(cg, name):
     tree = st.results_tree(eng.finish(), labels, "cg", leaflets=lf, min_samples=min_samples)
     bad = st.compare_trees(tree, expected(name))
     assert not bad, bad[:10]
+
+
+# ---- NoPBC (pbc.rs:98-253): molecules made whole, no box, handle_pbc(false) — tests_ua.rs:686-714 -------------
+@pytest.fixture(scope="module")
+def ua_nobox(built):
+    return Fixture("ua_nobox")
+
+
+def test_ua_order_leaflets_without_pbc(ua_nobox):
+    tables, labels, midx = ua_setup(ua_nobox, leaflets=METHODS["global"], handle_pbc=False)
+    frames = ua_nobox.window()
+    eng = oracle.OracleEngine(tables, trig=oracle.TRIG_LIBM, n_threads=4)
+    eng.submit(master_frames(ua_nobox, midx, frames), None, frames)
+    tree = st.results_tree_ua(eng.finish(), labels, leaflets=True)
+    bad = st.compare_trees(tree, expected("ua_order_leaflets_nopbc.yaml"))
+    assert not bad, bad[:10]
