@@ -736,7 +736,11 @@ __global__ __launch_bounds__(256) void k_local_flags(LocalArgs a) {
     // pass 1: members (in-plane minimum-image distance < radius; groan_rs Cylinder::inside), their count
     // and the circular sums of the normal coordinate (PBC) or its plain sum (NoPBC).  The membership
     // of the first 64 candidates of each lane is remembered as a bit mask for pass 2.
-    float sc = 0.0f, ss = 0.0f, sp = 0.0f;
+    // The refinement sum of pass 2 is taken here already, relative to the head's own normal coordinate:
+    // u = MI(z - z_head), with its minimum and maximum over the members.  If, once the estimate is known, every
+    // member's image around the head is also its image around the estimate, then sum MI(z - est) = sum u +
+    // n MI(z_head - est) and pass 2 is not needed (k_leaflets_global_contig explains the argument).
+    float sc = 0.0f, ss = 0.0f, sp = 0.0f, su = 0.0f, ulo = 3.0e38f, uhi = -3.0e38f;
     uint32_t cnt = 0, nf = 0, it = 0;
     unsigned long long member = 0ull;
     auto take = [&](const float4 r, const float sn, const uint32_t iter) {
@@ -744,8 +748,15 @@ __global__ __launch_bounds__(256) void k_local_flags(LocalArgs a) {
             cnt += 1;
             if (iter < 64u) member |= 1ull << iter;
             nf |= (r.z - r.z == 0.0f) ? 0u : 1u;
-            if (pbc) { sc += r.w; ss += sn; }
-            else sp += r.z;
+            if (pbc) {
+                sc += r.w; ss += sn;
+                const float u = gm_min_image(r.z - hn_pos, Ln, bad);
+                su += u;
+                ulo = fminf(ulo, u);
+                uhi = fmaxf(uhi, u);
+            } else {
+                sp += r.z;
+            }
         }
     };
     if (flat) {
@@ -787,9 +798,18 @@ __global__ __launch_bounds__(256) void k_local_flags(LocalArgs a) {
     } else {
         const double tc = wave_total((double)sc), ts = wave_total((double)ss);
         const float est = (atan2f(-(float)ts, -(float)tc) + 3.1415927f) / (6.2831855f / Ln);
-        // pass 2: refine with the mean minimum-image displacement of the members from the estimate
+        for (int off = 32; off > 0; off >>= 1) {
+            ulo = fminf(ulo, __shfl_xor(ulo, off, 64));
+            uhi = fmaxf(uhi, __shfl_xor(uhi, off, 64));
+        }
+        const float shift = gm_min_image(hn_pos - est, Ln, bad), half = Ln / 2.0f, margin = 1e-4f * Ln;
+        const bool one_pass = ulo + shift > -half + margin && uhi + shift < half - margin;   // wave-uniform
+        // pass 2 (only for a membrane thicker than half the box): refine with the mean minimum-image displacement
+        // of the members from the estimate
         float ref = 0.0f;
-        if (flat) {
+        if (one_pass) {
+            ref = 0.0f;
+        } else if (flat) {
             for (uint32_t it0 = 0; it0 < n_it; it0 += 4u) {
                 float pn[4];
                 bool in[4];
@@ -827,7 +847,8 @@ __global__ __launch_bounds__(256) void k_local_flags(LocalArgs a) {
                 }
             }
         }
-        center = gm_wrap(est + (float)(wave_total((double)ref) / tcnt), Ln, bad);
+        if (one_pass) center = gm_wrap((est + shift) + (float)(wave_total((double)su) / tcnt), Ln, bad);
+        else center = gm_wrap(est + (float)(wave_total((double)ref) / tcnt), Ln, bad);
     }
     if (lane == 0) {
         if (center != center) {

@@ -402,3 +402,23 @@ def test_global_leaflet_kernels(built, monkeypatch, variant):
     if not diff.any():
         np.testing.assert_array_equal(got.sums, want.sums)
         np.testing.assert_array_equal(got.counts, want.counts)
+
+
+def test_local_leaflets_membrane_thicker_than_half_the_box(built):
+    """The local-centre kernel takes its refinement sum in the first pass when every member's image around the
+    head is also its image around the estimate; a 4-nm membrane in a 6.2-nm box, straddling the periodic
+    boundary, needs the second pass instead."""
+    system = synthetic.cg_membrane(160, leaflets=LEAFLETS_LOCAL, radius=2.0, n_types=2, box=(9.0, 9.0, 6.2))
+    n = 6
+    xyz = system.frames(n, seed=29)
+    xyz[:, :, 2] = np.mod(xyz[:, :, 2] + 3.0, 6.2).astype(np.float32)
+    eng, got = run_gpu(system, xyz, system.box9(n), batches=2)
+    o, want = run_oracle(system, xyz, system.box9(n))
+    flags, _ = eng.leaflets()
+    oflags, odist, _ = o.leaflets()
+    diff = flags != oflags
+    assert not diff.any() or np.abs(odist[diff]).max() < 1e-4
+    np.testing.assert_allclose(eng.leaflet_distances()[~diff], odist[~diff], atol=5e-5)
+    assert 0 < flags.sum() < len(flags)
+    if not diff.any():
+        np.testing.assert_array_equal(got.sums, want.sums)
