@@ -734,19 +734,16 @@ __global__ __launch_bounds__(256) void k_local_flags(LocalArgs a) {
     const bool flat = n_it <= 64u;       // else (> 4096 candidates): the plain run loops
 
     // pass 1: members (in-plane minimum-image distance < radius; groan_rs Cylinder::inside), their count
-    // and the circular sums of the normal coordinate (PBC) or its plain sum (NoPBC).  The membership
-    // of the first 64 candidates of each lane is remembered as a bit mask for pass 2.
+    // and the circular sums of the normal coordinate (PBC) or its plain sum (NoPBC).
     // The refinement sum of pass 2 is taken here already, relative to the head's own normal coordinate:
     // u = MI(z - z_head), with its minimum and maximum over the members.  If, once the estimate is known, every
     // member's image around the head is also its image around the estimate, then sum MI(z - est) = sum u +
     // n MI(z_head - est) and pass 2 is not needed (k_leaflets_global_contig explains the argument).
     float sc = 0.0f, ss = 0.0f, sp = 0.0f, su = 0.0f, ulo = 3.0e38f, uhi = -3.0e38f;
-    uint32_t cnt = 0, nf = 0, it = 0;
-    unsigned long long member = 0ull;
-    auto take = [&](const float4 r, const float sn, const uint32_t iter) {
+    uint32_t cnt = 0, nf = 0;
+    auto take = [&](const float4 r, const float sn) {
         if (inside(r.x, r.y)) {
             cnt += 1;
-            if (iter < 64u) member |= 1ull << iter;
             nf |= (r.z - r.z == 0.0f) ? 0u : 1u;
             if (pbc) {
                 sc += r.w; ss += sn;
@@ -775,7 +772,7 @@ __global__ __launch_bounds__(256) void k_local_flags(LocalArgs a) {
             }
 #pragma unroll
             for (uint32_t u = 0; u < 4u; u++)
-                if (v[u]) take(r[u], sn[u], it0 + u);
+                if (v[u]) take(r[u], sn[u]);
         }
     } else {
         for (uint32_t ia = 0; ia < n_rows; ia++) {
@@ -783,7 +780,7 @@ __global__ __launch_bounds__(256) void k_local_flags(LocalArgs a) {
             for (uint32_t part = 0; part < 2u; part++) {
                 const uint32_t q0 = part == 0 ? cstart[row + b0] : cstart[row];
                 const uint32_t q1 = part == 0 ? cstart[row + b1] : cstart[row + b2];
-                for (uint32_t q = q0 + lane; q < q1; q += 64u, it++) take(rec[q], pbc ? rsn[q] : 0.0f, it);
+                for (uint32_t q = q0 + lane; q < q1; q += 64u) take(rec[q], pbc ? rsn[q] : 0.0f);
             }
         }
     }
@@ -807,42 +804,15 @@ __global__ __launch_bounds__(256) void k_local_flags(LocalArgs a) {
         // pass 2 (only for a membrane thicker than half the box): refine with the mean minimum-image displacement
         // of the members from the estimate
         float ref = 0.0f;
-        if (one_pass) {
-            ref = 0.0f;
-        } else if (flat) {
-            for (uint32_t it0 = 0; it0 < n_it; it0 += 4u) {
-                float pn[4];
-                bool in[4];
-#pragma unroll
-                for (uint32_t u = 0; u < 4u; u++) {
-                    const uint32_t iter = min(it0 + u, 63u);
-                    in[u] = it0 + u < 64u && ((member >> iter) & 1ull);
-                    const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)it_base, (int)iter) + lane;
-                    pn[u] = rec[in[u] ? q : 0u].z;
-                }
-#pragma unroll
-                for (uint32_t u = 0; u < 4u; u++)
-                    if (in[u]) ref += gm_min_image(pn[u] - est, Ln, bad);
-            }
-        } else {
-            it = 0;
+        if (!one_pass) {       // rare: membership is simply tested again, run by run
             for (uint32_t ia = 0; ia < n_rows; ia++) {
                 const uint32_t row = ((a0 + ia) % nca) * ncb;
                 for (uint32_t part = 0; part < 2u; part++) {
                     const uint32_t q0 = part == 0 ? cstart[row + b0] : cstart[row];
                     const uint32_t q1 = part == 0 ? cstart[row + b1] : cstart[row + b2];
-                    for (uint32_t q = q0 + lane; q < q1; q += 64u, it++) {
-                        bool in;
-                        float pn;
-                        if (it < 64u) {
-                            in = (member >> it) & 1ull;
-                            pn = in ? rec[q].z : 0.0f;
-                        } else {
-                            const float4 r = rec[q];
-                            in = inside(r.x, r.y);
-                            pn = r.z;
-                        }
-                        if (in) ref += gm_min_image(pn - est, Ln, bad);
+                    for (uint32_t q = q0 + lane; q < q1; q += 64u) {
+                        const float4 r = rec[q];
+                        if (inside(r.x, r.y)) ref += gm_min_image(r.z - est, Ln, bad);
                     }
                 }
             }
