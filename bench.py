@@ -111,10 +111,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         args.gpus = world
+    # rehearsal on a one-GPU box: GORDER_BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses gloo (RCCL cannot run
+    # two ranks on one device); the driver's multi-GPU runs never set it
+    rehearsal = os.environ.get("GORDER_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if rank == 0:
         entry.build()          # no-op when the in-tree libraries are current
     if world > 1:
