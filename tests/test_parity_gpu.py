@@ -422,3 +422,30 @@ def test_local_leaflets_membrane_thicker_than_half_the_box(built):
     assert 0 < flags.sum() < len(flags)
     if not diff.any():
         np.testing.assert_array_equal(got.sums, want.sums)
+
+
+def test_independent_handles_interleaved_and_threaded(built):
+    """A handle is thread-compatible like one SystemTopology clone (topology/mod.rs:256-278): several handles, each
+    with its own stream, fed from different host threads at the same time, do not disturb each other."""
+    import threading
+    systems = [synthetic.cg_membrane(80 + 40 * k, leaflets=LEAFLETS_GLOBAL if k % 2 else LEAFLETS_NONE, n_types=1 + k % 3)
+               for k in range(4)]
+    data = [(s.frames(12, seed=50 + k), s.box9(12)) for k, s in enumerate(systems)]
+    results = [None] * len(systems)
+
+    def work(k):
+        eng = HipEngine(systems[k].tables)
+        xyz, box = data[k]
+        for a in range(0, 12, 3):
+            eng.submit_host(xyz[a:a + 3], box[a:a + 3], np.arange(a, a + 3))
+        results[k] = eng.finish()
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(systems))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for k, s in enumerate(systems):
+        _, want = run_oracle(s, data[k][0], data[k][1])
+        np.testing.assert_array_equal(results[k].sums, want.sums)
+        np.testing.assert_array_equal(results[k].counts, want.counts)
