@@ -4,8 +4,9 @@
     python tests/golden/make_fixtures.py        (needs /root/reference; run once, output is committed)
 
 Only data travels: lipid-only subsets of the reference's structure / bond / trajectory fixtures
-(re-packed as integer coordinates exactly as stored in the XTC files) and the expected-output
-text files of its integration tests.  No reference source code is read or copied.
+(re-packed as integer coordinates exactly as stored in the XTC files), the expected-output text files of
+its integration tests, and the literal expectation arrays (numbers) of two of its unit tests
+(single_frame_kats below).  No reference code is copied.
 
   pcpepg  tests/files/pcpepg.gro + pcpepg.bnd + split/pcpepg{1..5}.xtc   (tests_aa.rs:47-77)
   cg      tests/files/cg.gro + cg.bnd + split/cg{1..5}.xtc               (tests_cg.rs:46-66)
