@@ -59,6 +59,20 @@ __device__ __forceinline__ float gm_min_image(float dx, float L, int &bad) {
     return r;
 }
 
+// the periodic image of x nearest to ref: x itself shifted by whole box lengths while |x - ref| > L/2
+// (oracle: nearest_image).  Used where a coordinate, not a displacement, is averaged (centre of a group).
+__device__ __forceinline__ float gm_nearest_image(float x, float ref, float L, int &bad) {
+    const float half = L / 2.0f;
+    float d = x - ref;
+    int it = 0;
+#pragma clang loop unroll(disable)
+    while (d > half) { d -= L; x -= L; if (++it > GM_MI_MAX_ITER) { bad = 1; return x; } }
+    it = 0;
+#pragma clang loop unroll(disable)
+    while (d < -half) { d += L; x += L; if (++it > GM_MI_MAX_ITER) { bad = 1; return x; } }
+    return x;
+}
+
 // groan_rs Vector3D::wrap into [0, L]
 __device__ __forceinline__ float gm_wrap(float x, float L, int &bad) {
     int it = 0;

@@ -110,8 +110,9 @@ __global__ __launch_bounds__(256) void k_geom_shapes(GeomArgs g) {
                 est[d] = (atan2f(-(float)ts, -(float)tc) + 3.1415927f) / (6.2831855f / box[d]);
             }
         }
-        // Refinement = plain centre of the atoms' images nearest to the estimate, summed in f32 in atom
-        // order like the reference does: a sample 1 ulp from the shape's surface depends on the last bit
+        // Refinement = plain centre of the atoms' images nearest to the estimate (the atom's own coordinate
+        // shifted by whole box lengths: the estimate only picks the image), summed in f32 in atom order like
+        // the reference does: a sample 1 ulp from the shape's surface depends on the last bit
         // of this centre (the golden aa_order_sphere_dynamic.yaml has one), so the order of the sum is
         // part of the result.  One thread per frame does it; reference groups are small (a residue, a
         // protein), and the estimate above only selects the images, its own last bits do not matter.
@@ -119,8 +120,7 @@ __global__ __launch_bounds__(256) void k_geom_shapes(GeomArgs g) {
             float acc[3] = {0.0f, 0.0f, 0.0f};
             for (uint32_t i = 0; i < g.n_group; i++) {
                 const float *p = x + 3u * (size_t)g.group[i];
-                for (int d = 0; d < 3; d++)
-                    acc[d] += g.pbc ? est[d] + gm_min_image(p[d] - est[d], box[d], bad) : p[d];
+                for (int d = 0; d < 3; d++) acc[d] += g.pbc ? gm_nearest_image(p[d], est[d], box[d], bad) : p[d];
             }
             for (int d = 0; d < 3; d++) {
                 const float c = acc[d] / (float)g.n_group;

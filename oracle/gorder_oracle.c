@@ -197,6 +197,17 @@ float gorder_oracle_calc_order(int64_t sum, uint64_t n, uint64_t min_samples) {
  * Only the SIGN of (head - centre) along the normal feeds the results (leaflets.rs:725-731), so
  * last-bit differences from the crate cannot change a flag except for a lipid sitting within
  * ~1e-6 nm of the centre plane; pinned through the leaflet counts of aaorder.rs:268-350. */
+/* the periodic image of x nearest to `ref`: x shifted by whole box lengths while |x - ref| > L/2 */
+static inline float nearest_image(float x, float ref, float L, int *bad) {
+    const float half = L / 2.0f;
+    float d = x - ref;
+    int it = 0;
+    while (d > half) { d -= L; x -= L; if (++it > MI_MAX_ITER) { *bad = 1; return x; } }
+    it = 0;
+    while (d < -half) { d += L; x += L; if (++it > MI_MAX_ITER) { *bad = 1; return x; } }
+    return x;
+}
+
 static int center_of(const float *xyz, const uint32_t *idx, uint32_t n, const float *box, int pbc,
                      float *out) {
     int bad = 0;
@@ -230,12 +241,12 @@ static int center_of(const float *xyz, const uint32_t *idx, uint32_t n, const fl
      * aa_order_sphere_dynamic.yaml (tests_aa.rs:3322-3346): in frame 49 one C217-H17R bond of POPE lies
      * 2 ulp from the surface of the sphere around the centre of residue 1, and only this form leaves it
      * outside as the reference does. */
+    /* The image is written as the atom's own coordinate shifted by whole box lengths (x -+ L), not as
+     * est + displacement: for a compact group both are the atom's coordinate itself, bit for bit, but this form
+     * does not carry the last bits of the estimate into the result — the estimate only picks the image. */
     for (int d = 0; d < 3; d++) {
         float acc = 0.0f;
-        for (uint32_t i = 0; i < n; i++) {
-            const float dx = xyz[3 * (size_t)idx[i] + d] - est[d];
-            acc += est[d] + min_image(dx, box[d], &bad);
-        }
+        for (uint32_t i = 0; i < n; i++) acc += nearest_image(xyz[3 * (size_t)idx[i] + d], est[d], box[d], &bad);
         out[d] = wrap1(acc / (float)n, box[d], &bad);
     }
     return bad;

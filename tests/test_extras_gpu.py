@@ -156,7 +156,11 @@ def test_geometry_selection(built, geom, pbc):
     system = synthetic.cg_membrane(160, leaflets=LEAFLETS_GLOBAL, n_types=2, handle_pbc=pbc, timewise=True)
     geom.structure_box = tuple(float(x) for x in system.box)
     if geom.reference == GEOMREF_GROUP:
-        geom.group = np.arange(0, system.n_atoms, 7, dtype=np.uint32)
+        p0 = system.frames(1, seed=0)[0].astype(np.float64)      # a localised group (2-nm blob): its centre is well defined
+        d = p0 - p0[0]
+        if pbc:
+            d -= system.box.astype(np.float64) * np.round(d / system.box.astype(np.float64))
+        geom.group = np.flatnonzero(np.linalg.norm(d, axis=1) < 2.0).astype(np.uint32)
     system.tables.geometry = geom
     n = 9
     xyz = system.frames(n, seed=13)
