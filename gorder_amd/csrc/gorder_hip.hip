@@ -24,7 +24,6 @@
 #include <cstring>
 #include <new>
 #include <string>
-#include <type_traits>
 #include <vector>
 
 #include "../../include/gorder_hip.h"

@@ -295,90 +295,90 @@ __global__ __launch_bounds__(256) void k_leaflets_global_contig(LeafletArgs a) {
     const float zref = a.n_mol_total ? x[3u * (size_t)a.heads[0] + dn] : 0.0f;
     // chunk c = tid + 256 k starts at frame float 4c - sh; its element j is a normal component iff
     // (4c - sh + j) % 3 == dn, i.e. j % 3 == (dn + sh - tid - k) % 3 (4 and 256 are 1 mod 3)
+    uint32_t r = (dn + sh + 3u * 256u - threadIdx.x) % 3u;            // j0 of this thread's chunk k; k -> k+1: r -> r-1
     float nonfinite = 0.0f, sc = 0.0f, ss = 0.0f, su = 0.0f, ulo = 3.0e38f, uhi = -3.0e38f;
-    // one sweep over the frame; TRIG = false: u = MI(z - z_ref), its sum, minimum and maximum (+ the finiteness
-    // check); TRIG = true: the circular sums for the Bai-Breen estimate (only needed for thick membranes, below)
-    auto sweep = [&](auto trig_tag) {
-        constexpr bool TRIG = decltype(trig_tag)::value;
-        auto take = [&](float z, bool ok) {
-            z = ok ? z : zref;           // a masked lane holds an in-plane coordinate: keep it out of the image search
-            if (TRIG) {
-                float sn, cs;
-                fast_sincos_rev(z * inv, &sn, &cs);                         // v_sin / v_cos reduce the range themselves
-                sc += ok ? cs : 0.0f;
-                ss += ok ? sn : 0.0f;
-            } else {
-                if (pbc) bad |= (ok && !(z <= 9.0f * L && z >= -8.0f * L)) ? 1 : 0;   // gm_wrap would give up: far outside
-                const float u = pbc ? gm_min_image(z - zref, L, bad) : z - zref;
-                su += ok ? u : 0.0f;
-                ulo = ok ? fminf(ulo, u) : ulo;
-                uhi = ok ? fmaxf(uhi, u) : uhi;
-            }
-        };
-        auto chunk = [&](const v4f v, uint32_t c, uint32_t j0) {
-            float za = v.x;
-            za = j0 == 1 ? v.y : za;
-            za = j0 == 2 ? v.z : za;
-            const uint32_t e0 = 4u * c;                               // position of v.x counted from src
-            if (e0 >= sh && e0 + 4u <= sh + n_float) {                // every float of the chunk belongs to the frame
-                if (!TRIG) {
-                    const float t = (v.x + v.y) + (v.z + v.w);
-                    nonfinite += t - t;                               // NaN / inf in any of them survives the sum
-                }
-                take(za, true);
-                take(v.w, j0 == 0);
-            } else {                                                   // first / last chunk of the frame
-                const float e[4] = {v.x, v.y, v.z, v.w};
-                if (!TRIG) {
-#pragma unroll
-                    for (uint32_t j = 0; j < 4; j++) {
-                        const bool in = e0 + j >= sh && e0 + j < sh + n_float;
-                        nonfinite += in ? e[j] - e[j] : 0.0f;
-                    }
-                }
-                take(za, e0 + j0 >= sh && e0 + j0 < sh + n_float);
-                take(v.w, j0 == 0 && e0 + 3u >= sh && e0 + 3u < sh + n_float);
-            }
-        };
-        uint32_t r = (dn + sh + 3u * 256u - threadIdx.x) % 3u;        // j0 of this thread's chunk k; k -> k+1: r -> r-1
-        uint32_t c = threadIdx.x;
-        for (; c + 3u * 256u < n4; c += 4u * 256u) {                 // four loads in flight
-            v4f v[4];
-#pragma unroll
-            for (uint32_t k = 0; k < 4; k++) v[k] = __builtin_nontemporal_load(src + c + k * 256u);
-#pragma unroll
-            for (uint32_t k = 0; k < 4; k++) {
-                chunk(v[k], c + k * 256u, r);
-                r = r == 0 ? 2u : r - 1u;
-            }
+    auto take = [&](float z, bool ok) {
+        z = ok ? z : zref;               // a masked lane holds an in-plane coordinate: keep it out of the image search
+        if (pbc) {
+            bad |= (ok && !(z <= 9.0f * L && z >= -8.0f * L)) ? 1 : 0;   // gm_wrap would give up: coordinate far outside
+            float sn, cs;
+            fast_sincos_rev(z * inv, &sn, &cs);                             // v_sin / v_cos reduce the range themselves
+            sc += ok ? cs : 0.0f;
+            ss += ok ? sn : 0.0f;
         }
-        for (; c < n4; c += 256u) {
-            chunk(__builtin_nontemporal_load(src + c), c, r);
-            r = r == 0 ? 2u : r - 1u;
+        const float u = pbc ? gm_min_image(z - zref, L, bad) : z - zref;
+        su += ok ? u : 0.0f;
+        ulo = ok ? fminf(ulo, u) : ulo;
+        uhi = ok ? fmaxf(uhi, u) : uhi;
+    };
+    auto chunk = [&](const v4f v, uint32_t c, uint32_t j0) {
+        float za = v.x;
+        za = j0 == 1 ? v.y : za;
+        za = j0 == 2 ? v.z : za;
+        const uint32_t e0 = 4u * c;                                   // position of v.x counted from src
+        if (e0 >= sh && e0 + 4u <= sh + n_float) {                    // every float of the chunk belongs to the frame
+            const float t = (v.x + v.y) + (v.z + v.w);
+            nonfinite += t - t;                                       // NaN / inf in any of them survives the sum
+            take(za, true);
+            take(v.w, j0 == 0);
+        } else {                                                       // first / last chunk of the frame
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                const bool in = e0 + j >= sh && e0 + j < sh + n_float;
+                nonfinite += in ? e[j] - e[j] : 0.0f;
+            }
+            take(za, e0 + j0 >= sh && e0 + j0 < sh + n_float);
+            take(v.w, j0 == 0 && e0 + 3u >= sh && e0 + 3u < sh + n_float);
         }
     };
-    sweep(std::false_type{});
+    uint32_t c = threadIdx.x;
+    for (; c + 3u * 256u < n4; c += 4u * 256u) {                     // four loads in flight
+        v4f v[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) v[k] = __builtin_nontemporal_load(src + c + k * 256u);
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            chunk(v[k], c + k * 256u, r);
+            r = r == 0 ? 2u : r - 1u;
+        }
+    }
+    for (; c < n4; c += 256u) {
+        chunk(__builtin_nontemporal_load(src + c), c, r);
+        r = r == 0 ? 2u : r - 1u;
+    }
+    double tc = (double)sc, ts = (double)ss;
+    block_sum2(tc, ts, scratch);
     double tu = (double)su, nf = (double)nonfinite;
     block_sum2(tu, nf, scratch);
     block_minmax(ulo, uhi, fscratch);
     float center;
-    const float half = L / 2.0f, margin = 1e-4f * L;
     if (!pbc) {
         center = zref + (float)(tu / (double)a.n_atoms);
-    } else if (uhi - ulo < half - margin) {
-        // All atoms lie in a window narrower than half the box that contains z_ref.  The circular mean of points on
-        // an arc shorter than a half circle lies on that arc, so every atom's image nearest to the estimate is its
-        // image nearest to z_ref: est + mean MI(z - est) = z_ref + mean u, and the estimate is never needed.
-        center = gm_wrap(zref + (float)(tu / (double)a.n_atoms), L, bad);
-    } else {                                                           // a thick membrane: the full Bai-Breen way
-        sweep(std::true_type{});
-        double tc = (double)sc, ts = (double)ss;
-        block_sum2(tc, ts, scratch);
+    } else {
         const float est = (atan2f(-(float)ts, -(float)tc) + 3.1415927f) / (6.2831855f / L);
-        float acc = 0.0f;
-        for (uint32_t i = threadIdx.x; i < a.n_atoms; i += 256u) acc += gm_min_image(x[3u * (size_t)i + dn] - est, L, bad);
-        const double tot = block_sum((double)acc, scratch);
-        center = gm_wrap(est + (float)(tot / (double)a.n_atoms), L, bad);
+        const float shift = gm_min_image(zref - est, L, bad);         // z_ref as seen from the estimate
+        const float half = L / 2.0f, margin = 1e-4f * L;
+        if (ulo + shift > -half + margin && uhi + shift < half - margin) {
+            // every atom's image around z_ref is its image around the estimate:
+            // est + mean MI(z - est) = est + shift + mean u
+            center = gm_wrap((est + shift) + (float)(tu / (double)a.n_atoms), L, bad);
+        } else {                                                      // a membrane thicker than half the box: read again
+            float acc = 0.0f;
+            uint32_t r2 = (dn + sh + 3u * 256u - threadIdx.x) % 3u;
+            for (uint32_t c2 = threadIdx.x; c2 < n4; c2 += 256u) {
+                const v4f v = src[c2];
+                const uint32_t e0 = 4u * c2, j0 = r2;
+                float za = v.x;
+                za = j0 == 1 ? v.y : za;
+                za = j0 == 2 ? v.z : za;
+                if (e0 + j0 >= sh && e0 + j0 < sh + n_float) acc += gm_min_image(za - est, L, bad);
+                if (j0 == 0 && e0 + 3u >= sh && e0 + 3u < sh + n_float) acc += gm_min_image(v.w - est, L, bad);
+                r2 = r2 == 0 ? 2u : r2 - 1u;
+            }
+            const double tot = block_sum((double)acc, scratch);
+            center = gm_wrap(est + (float)(tot / (double)a.n_atoms), L, bad);
+        }
     }
     if (threadIdx.x == 0) {
         if (center != center || nf != 0.0 || a.n_atoms == 0) {
