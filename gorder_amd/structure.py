@@ -121,13 +121,15 @@ class BondLabel:
     name1: str
     rel2: int
     name2: str
+    res1: str = ""      # residue names of the two atoms (the output keys carry these, not the molecule-type name)
+    res2: str = ""
 
 
 @dataclass
 class MolLabels:
     name: str
     bonds: List[BondLabel]
-    heavy_atoms: List[Tuple[int, str]] = field(default_factory=list)    # AA: (relative index, name)
+    heavy_atoms: List[Tuple[int, str, str]] = field(default_factory=list)    # AA: (relative index, name, residue)
     n_molecules: int = 0
     slot0: int = 0
 
@@ -179,7 +181,21 @@ def classify(structure: Structure, group1: np.ndarray, group2: np.ndarray, same_
                 if structure.resnames[i] not in resn:
                     resn.append(structure.resnames[i])
             types.append({"key": key, "name": "-".join(resn), "mols": [atoms], "bonds": sorted(bonds), "m0": m0})
-    return [t for t in types if t["bonds"]]
+    return _solve_name_conflicts([t for t in types if t["bonds"]])
+
+
+def _solve_name_conflicts(types: List[dict]) -> List[dict]:
+    """classify.rs:267-294: molecule types that share a name but differ in topology are numbered in order of
+    appearance (POPE1, POPE2, ...)."""
+    counts: Dict[str, int] = {}
+    for t in types:
+        counts[t["name"]] = counts.get(t["name"], 0) + 1
+    seen: Dict[str, int] = {}
+    for t in types:
+        if counts[t["name"]] > 1:
+            seen[t["name"]] = seen.get(t["name"], 0) + 1
+            t["name"] = f'{t["name"]}{seen[t["name"]]}'
+    return types
 
 
 def build_tables(structure: Structure, analysis: str, sel1: np.ndarray, sel2: Optional[np.ndarray] = None,
@@ -234,7 +250,8 @@ def build_tables(structure: Structure, analysis: str, sel1: np.ndarray, sel2: Op
         mts.append(MolType(n_molecules=n_mol, bonds=bonds, heads=heads, methyls=methyls, name=t["name"],
                            normal_heads=_normal_heads(mols, dynamic_normal, remap, t["name"])))
         m0 = t["m0"]
-        bl = [BondLabel(r1, structure.names[m0 + r1], r2, structure.names[m0 + r2]) for r1, r2 in t["bonds"]]
+        bl = [BondLabel(r1, structure.names[m0 + r1], r2, structure.names[m0 + r2], structure.resnames[m0 + r1],
+                        structure.resnames[m0 + r2]) for r1, r2 in t["bonds"]]
         heavy = []
         if analysis == "aa":
             seen = set()
@@ -242,7 +259,7 @@ def build_tables(structure: Structure, analysis: str, sel1: np.ndarray, sel2: Op
                 for r in (r1, r2):
                     if sel1[m0 + r] and r not in seen:
                         seen.add(r)
-                        heavy.append((r, structure.names[m0 + r]))
+                        heavy.append((r, structure.names[m0 + r], structure.resnames[m0 + r]))
             heavy.sort()
         labels.append(MolLabels(t["name"], bl, heavy, n_mol, slot0))
         slot0 += len(bl)
@@ -289,6 +306,7 @@ class UaCarbonLabel:
     name: str
     kind: int
     n_h: int
+    res: str = ""
 
 
 @dataclass
@@ -302,10 +320,12 @@ class UaMolLabels:
 def build_tables_ua(structure: Structure, saturated: np.ndarray, unsaturated: np.ndarray, master: np.ndarray,
                     leaflets: Optional[dict] = None, handle_pbc: bool = True, normal=(0.0, 0.0, 1.0),
                     ordermap: Optional[OrderMap] = None, timewise: bool = False, flags: int = 0,
-                    dynamic_normal: Optional[dict] = None):
+                    dynamic_normal: Optional[dict] = None, ignore: Optional[np.ndarray] = None, geometry=None):
     """AtomBasedClassifier + UAOrderAtoms (classify.rs, uaorder.rs:454-665): the number of bonded atoms of
     a carbon decides how many hydrogens are built; helpers = bonded atoms in index order; a methyl's second
-    helper is the first neighbour of helper1 that is not the methyl itself (uaorder.rs:609-629)."""
+    helper is the first neighbour of helper1 that is not the methyl itself (uaorder.rs:609-629).
+    `ignore` (uaorder.rs:193-224, 583-587): atoms that do not count as bonded neighbours of a carbon (the explicit
+    hydrogens of an all-atom system); they stay part of the molecule, so relative indices count them."""
     from .abi import UA_CH1_SAT, UA_CH1_UNSAT, UA_CH2, UA_CH3, UA_N_H
     adj = structure.bonds
     order = saturated | unsaturated
@@ -328,6 +348,7 @@ def build_tables_ua(structure: Structure, saturated: np.ndarray, unsaturated: np
                 if structure.resnames[i] not in resn:
                     resn.append(structure.resnames[i])
             types.append({"key": key, "name": "-".join(resn), "mols": [atoms], "m0": m0})
+    _solve_name_conflicts(types)
     midx = np.flatnonzero(master)
     remap = -np.ones(structure.n_atoms, dtype=np.int64)
     remap[midx] = np.arange(len(midx))
@@ -339,7 +360,7 @@ def build_tables_ua(structure: Structure, saturated: np.ndarray, unsaturated: np
         for i in mols[0]:
             if not order[i]:
                 continue
-            bonded = adj[i]
+            bonded = adj[i] if ignore is None else [j for j in adj[i] if not ignore[j]]
             missing = max(0, 4 - len(bonded))
             quad = None
             if saturated[i] and missing == 1:
@@ -362,7 +383,7 @@ def build_tables_ua(structure: Structure, saturated: np.ndarray, unsaturated: np
                 idx[k] = [remap[q + off] for q in quad]
             assert (idx >= 0).all()
             ua_atoms.append((kind, idx))
-            carbons.append(UaCarbonLabel(i - m0, structure.names[i], kind, UA_N_H[kind]))
+            carbons.append(UaCarbonLabel(i - m0, structure.names[i], kind, UA_N_H[kind], structure.resnames[i]))
         if not ua_atoms:
             continue
         heads = methyls = None
@@ -383,12 +404,16 @@ def build_tables_ua(structure: Structure, saturated: np.ndarray, unsaturated: np
                         flip=lf.get("flip", False), radius=lf.get("radius", 0.0), membrane=mem)
     tables = Tables(n_atoms=len(midx), molecule_types=mts, handle_pbc=handle_pbc, normal=normal, leaflets=leaf,
                     ordermap=ordermap or OrderMap(), timewise=timewise, flags=flags)
+    if geometry is not None:
+        tables.geometry = geometry
     _set_dynamic_normal(tables, dynamic_normal, remap)
     return tables, labels, midx
 
 
-def results_tree_ua(res: Results, labels: Sequence[UaMolLabels], leaflets: bool, min_samples: int = 1) -> dict:
-    """UA YAML shape (uaresults): per carbon `total` (+ upper/lower) and `bonds`: list per virtual hydrogen."""
+def _collector(res: Results, leaflets: bool, sign: float, min_samples: int, timewise, n_blocks: int):
+    """Value of a set of accumulator slots as the writers print it: mean of the summed accumulators (x sign, 4
+    decimals, NaN below min_samples); with timewise = (tw_sums, tw_counts) [frames][3][n_acc] the `estimate_error`
+    layout {mean, error}, the error from the members' per-frame rows added up (TimeWiseData merge, timewise.rs:31-76)."""
     which = ["total", "upper", "lower"] if leaflets else ["total"]
 
     def coll(slots):
@@ -397,8 +422,22 @@ def results_tree_ua(res: Results, labels: Sequence[UaMolLabels], leaflets: bool,
             s = int(sum(int(res.sums[w, k]) for k in slots))
             n = int(sum(int(res.counts[w, k]) for k in slots))
             v = _mean_ticks(s, n, min_samples)
-            out[key] = round4(-v) if v == v else float("nan")
+            mean = round4(sign * v) if v == v else float("nan")
+            if timewise is None:
+                out[key] = mean
+            else:
+                ts = np.asarray(timewise[0])[:, w, slots].sum(axis=1)
+                tc = np.asarray(timewise[1])[:, w, slots].sum(axis=1)
+                e = estimate_error(ts, tc, n_blocks) if mean == mean else float("nan")   # below min_samples: no error either
+                out[key] = {"mean": mean, "error": round4(e) if e == e else float("nan")}
         return out
+    return coll
+
+
+def results_tree_ua(res: Results, labels: Sequence[UaMolLabels], leaflets: bool, min_samples: int = 1,
+                    timewise=None, n_blocks: int = 5) -> dict:
+    """UA YAML shape (uaresults): per carbon `total` (+ upper/lower) and `bonds`: list per virtual hydrogen."""
+    coll = _collector(res, leaflets, -1.0, min_samples, timewise, n_blocks)
 
     tree: Dict[str, object] = {}
     all_slots: List[int] = []
@@ -412,7 +451,7 @@ def results_tree_ua(res: Results, labels: Sequence[UaMolLabels], leaflets: bool,
             mol_slots += slots
             entry = dict(coll(slots))
             entry["bonds"] = [coll([k]) for k in slots]
-            op[f"{ml.name} {c.name} ({c.rel})"] = entry
+            op[f"{c.res or ml.name} {c.name} ({c.rel})"] = entry
         all_slots += mol_slots
         tree[ml.name] = {"average order": coll(mol_slots), "order parameters": op}
     return {"average order": coll(all_slots), **tree}
@@ -473,23 +512,7 @@ def results_tree(res: Results, labels: Sequence[MolLabels], analysis: str, leafl
     becomes {mean, error}; an aggregate's error comes from its members' per-frame rows added up
     (TimeWiseData merge, timewise.rs:31-76)."""
     sign = -1.0 if analysis in ("aa", "ua") else 1.0
-    which = ["total", "upper", "lower"] if leaflets else ["total"]
-
-    def coll(slots):
-        out = {}
-        for w, key in enumerate(which):
-            s = int(sum(int(res.sums[w, k]) for k in slots))
-            n = int(sum(int(res.counts[w, k]) for k in slots))
-            v = _mean_ticks(s, n, min_samples)
-            mean = round4(sign * v) if v == v else float("nan")
-            if timewise is None:
-                out[key] = mean
-            else:
-                ts = np.asarray(timewise[0])[:, w, slots].sum(axis=1)
-                tc = np.asarray(timewise[1])[:, w, slots].sum(axis=1)
-                e = estimate_error(ts, tc, n_blocks) if mean == mean else float("nan")   # below min_samples: no error either
-                out[key] = {"mean": mean, "error": round4(e) if e == e else float("nan")}
-        return out
+    coll = _collector(res, leaflets, sign, min_samples, timewise, n_blocks)
 
     tree: Dict[str, object] = {}
     all_slots: List[int] = []
@@ -499,20 +522,20 @@ def results_tree(res: Results, labels: Sequence[MolLabels], analysis: str, leafl
         mol: Dict[str, object] = {"average order": coll(slots)}
         op: Dict[str, object] = {}
         if analysis == "aa":
-            for rel, name in ml.heavy_atoms:
+            for rel, name, resn in ml.heavy_atoms:
                 mine = [(k, b) for k, b in enumerate(ml.bonds) if b.rel1 == rel or b.rel2 == rel]
                 if not mine:
                     continue
                 entry = dict(coll([ml.slot0 + k for k, _ in mine]))
                 bonds = {}
                 for k, b in mine:
-                    orel, oname = (b.rel2, b.name2) if b.rel1 == rel else (b.rel1, b.name1)
-                    bonds[f"{ml.name} {oname} ({orel})"] = coll([ml.slot0 + k])
+                    orel, oname, ores = (b.rel2, b.name2, b.res2) if b.rel1 == rel else (b.rel1, b.name1, b.res1)
+                    bonds[f"{ores or ml.name} {oname} ({orel})"] = coll([ml.slot0 + k])
                 entry["bonds"] = bonds
-                op[f"{ml.name} {name} ({rel})"] = entry
+                op[f"{resn or ml.name} {name} ({rel})"] = entry
         else:
             for k, b in enumerate(ml.bonds):
-                op[f"{ml.name} {b.name1} ({b.rel1}) - {ml.name} {b.name2} ({b.rel2})"] = coll([ml.slot0 + k])
+                op[f"{b.res1 or ml.name} {b.name1} ({b.rel1}) - {b.res2 or ml.name} {b.name2} ({b.rel2})"] = coll([ml.slot0 + k])
         mol["order parameters"] = op
         tree[ml.name] = mol
     return {"average order": coll(all_slots), **tree}
@@ -533,6 +556,12 @@ def compare_trees(got, want, tol=2e-4, path="") -> List[str]:
         for k in got:
             if k not in want:
                 bad.append(f"{path}/{k}: unexpected")
+        return bad
+    if isinstance(want, (list, tuple)):
+        if not isinstance(got, (list, tuple)) or len(got) != len(want):
+            return [f"{path}: expected a list of {len(want)}"]
+        for k, (g_, w_) in enumerate(zip(got, want)):
+            bad += compare_trees(g_, w_, tol, f"{path}[{k}]")
         return bad
     try:
         g, w = float(got), float(want)

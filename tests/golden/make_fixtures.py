@@ -30,7 +30,7 @@ from gorder_amd import xtc              # noqa: E402
 LIPIDS = {"POPC", "POPE", "POPG", "POPS"}
 
 
-def pack(name, gro, bnd, xtcs):
+def pack(name, gro, bnd, xtcs, alt_bnd=None, same_frames=None):
     if gro.endswith(".pdb"):
         s = st.read_pdb(os.path.join(REF, gro))     # CONECT records carry the bonds
         adj = s.bonds
@@ -49,8 +49,18 @@ def pack(name, gro, bnd, xtcs):
     back = (ints.astype(np.float32) * np.float32(1.0 / np.float32(prec))).astype(np.float32)
     assert np.array_equal(back, frames), "integer round trip must reproduce the decoder's floats exactly"
     assert np.abs(ints).max() < 32768
+    extra = {}
+    if alt_bnd:          # a second bond definition of the same system (tests_cg.rs:380-430: .bonds() overrides the structure's)
+        adj2 = st.read_bnd(os.path.join(REF, alt_bnd), s.n_atoms)
+        extra["bonds_alt"] = np.array(sorted({(int(remap[a]), int(remap[b])) for a in idx for b in adj2[a]
+                                              if keep[b] and a < b}), dtype=np.int32)
+    if same_frames:      # a shorter trajectory of the reference that holds some of the same frames: keep their indices only
+        f2, b2, t2 = xtc.read_trajectory([os.path.join(REF, same_frames)], group=idx.astype(np.uint32))
+        where = np.searchsorted(times, t2)
+        assert np.array_equal(times[where], t2) and np.array_equal(frames[where], f2) and np.array_equal(boxes[where], b2)
+        extra["frames_" + os.path.splitext(same_frames)[0]] = where.astype(np.int32)
     out = os.path.join(HERE, name + ".npz")
-    np.savez_compressed(out, resids=s.resids[idx].astype(np.int32), resnames=np.array([s.resnames[i] for i in idx]),
+    np.savez_compressed(out, **extra, resids=s.resids[idx].astype(np.int32), resnames=np.array([s.resnames[i] for i in idx]),
                         names=np.array([s.names[i] for i in idx]), bonds=np.array(pairs, dtype=np.int32),
                         structure_box=s.box, ints=ints.astype(np.int16), precision=np.float32(prec),
                         boxes=boxes.astype(np.float32), times=times.astype(np.float32))
@@ -86,8 +96,9 @@ def single_frame_kats():
 
 if __name__ == "__main__":
     single_frame_kats()
-    pack("pcpepg", "pcpepg.gro", "pcpepg.bnd", [f"split/pcpepg{i}.xtc" for i in range(1, 6)])
-    pack("cg", "cg.gro", "cg.bnd", [f"split/cg{i}.xtc" for i in range(1, 6)])
+    pack("pcpepg", "pcpepg.gro", "pcpepg.bnd", [f"split/pcpepg{i}.xtc" for i in range(1, 6)],
+         same_frames="pcpepg_selected.xtc")
+    pack("cg", "cg.gro", "cg.bnd", [f"split/cg{i}.xtc" for i in range(1, 6)], alt_bnd="cg_redefined.bnd")
     pack("ua", "ua_nobox.pdb", None, ["ua.xtc"])      # tests_ua.rs:19-68 (names + bonds from the PDB twin of ua.tpr)
     pack("ua_nobox", "ua_nobox.pdb", None, ["ua_whole_nobox.xtc"])   # tests_ua.rs:686-714: molecules whole, no box, handle_pbc(false)
     for f in ("aa_order_basic.yaml", "aa_order_begin_end_step.yaml", "aa_order_leaflets.yaml",
@@ -103,7 +114,17 @@ if __name__ == "__main__":
               "aa_order_cylinder_z_inverted.yaml",
               "aa_order_sphere_dynamic_inverted.yaml", "aa_order_error_blocks10.yaml", "aa_order_error_limit.yaml",
               "cg_order_cuboid_square.yaml", "cg_order_cylinder.yaml", "cg_order_cylinder_z_inverted.yaml",
-              "cg_order_begin_end.yaml", "cg_order_limit.yaml", "ua_order_leaflets_nopbc.yaml"):
+              "cg_order_begin_end.yaml", "cg_order_limit.yaml", "ua_order_leaflets_nopbc.yaml",
+              # the wider sweep of tests/golden_cases.py
+              "aa_order_small.yaml", "aa_order_leaflets_small.yaml", "aa_order_selected.yaml", "aa_leaflets_once.yaml",
+              "aa_leaflets_every5.yaml", "aa_order_error_leaflets_limit.yaml",
+              "cg_order_small.yaml", "cg_order_leaflets_small.yaml", "cg_order_leaflets_only_upper.yaml",
+              "cg_order_redefined_bonds.yaml", "cg_order_sphere.yaml", "cg_order_error_limit.yaml",
+              "cg_order_error_leaflets_limit.yaml", "cg_order_leaflets_limit.yaml",
+              "ua_order_basic_saturated.yaml", "ua_order_basic_unsaturated.yaml", "ua_order_begin_end_step.yaml",
+              "ua_order_cuboid_point.yaml", "ua_order_cylinder_center.yaml", "ua_order_error.yaml",
+              "ua_order_leaflets_error.yaml", "ua_order_leaflets_flipped.yaml", "ua_leaflets_once.yaml",
+              "ua_normals.yaml", "ua_order_from_aa.yaml"):
         src = os.path.join(REF, f)
         if os.path.exists(src):
             shutil.copy(src, os.path.join(HERE, "expected", f))

@@ -26,6 +26,19 @@ class Fixture:
         self.boxes = z["boxes"].astype(np.float32)
         self.times = z["times"]
         self.names = np.array(self.structure.names)
+        self.resnames = np.array(self.structure.resnames)
+        self.extra = {k: z[k] for k in z.files if k.startswith(("bonds_", "frames_"))}
+
+    def with_bonds(self, key):
+        """The same system under another bond definition of the reference (a second .bnd file)."""
+        import copy
+        other = copy.copy(self)
+        other.structure = copy.copy(self.structure)
+        adj = [[] for _ in range(self.structure.n_atoms)]
+        for a, b in self.extra[key]:
+            adj[a].append(int(b)); adj[b].append(int(a))
+        other.structure.bonds = [sorted(x) for x in adj]
+        return other
 
     def window(self, begin=None, end=None, step=1):
         """groan_rs time window (common.rs:239-246): frames with begin <= t <= end, every step-th."""
@@ -77,7 +90,7 @@ def cg_setup(fx, leaflets=None, frequency=1, **kw):
 METHODS = {"global": LEAFLETS_GLOBAL, "local": LEAFLETS_LOCAL, "individual": LEAFLETS_INDIVIDUAL}
 
 
-def ua_setup(fx, leaflets=None, frequency=1, **kw):
+def ua_setup(fx, leaflets=None, frequency=1, flip=False, sat_only=False, unsat_only=False, **kw):
     """UAOrder selections of tests_ua.rs:41-45 (saturated / unsaturated carbons of POPC and POPS)."""
     s = fx.structure
     rn = np.array(s.resnames)
@@ -91,7 +104,11 @@ def ua_setup(fx, leaflets=None, frequency=1, **kw):
         heads = np.array([n.startswith("P") for n in s.names])                       # name r'^P'
         methyls = ((rn == "POPC") & fx.name_in("CA2", "C50")) | ((rn == "POPS") & fx.name_in("C36", "C55"))
         lf = {"method": leaflets, "membrane": allm, "heads": heads, "methyls": methyls, "frequency": frequency,
-              "radius": 2.5}
+              "radius": 2.5, "flip": flip}
+    if sat_only:
+        unsat = np.zeros_like(unsat)
+    if unsat_only:
+        sat = np.zeros_like(sat)
     return st.build_tables_ua(s, sat, unsat, allm, leaflets=lf, **kw)
 
 
