@@ -320,10 +320,11 @@ def test_error_estimation(kind, lf, want, pcpepg, cg):
 
 
 # ---- ordermaps (ordermap.rs:40-113; tests_ua.rs:351-410) ------------------------------------------------
-# (The all-atom ordermap goldens, tests/files/ordermaps/, were made from tests/files/pcpepg.xtc, which the
-# reference checkout does not contain; with bins of 0.1 nm and bond midpoints that are multiples of 0.0005 nm
-# 5 % of the samples sit exactly on a tile edge, and the split/pcpepg*.xtc frames do not reproduce those maps
-# tile for tile whatever the tie rule.  The united-atom maps come from tests/files/ua.xtc, which IS there.)
+# (The all-atom and coarse-grained ordermap goldens, tests/files/ordermaps{,_cg}/, were made from pcpepg.xtc / cg.xtc,
+# which the reference checkout does not contain; its split/*.xtc twins carry XTC precision 100, so bond midpoints
+# are multiples of 0.005 nm: with 0.1-nm tiles 5 % of the samples sit exactly on a tile edge, with 1-nm tiles 1 %
+# change tile, and the maps are not reproduced tile for tile whatever the tie rule.  The united-atom maps come from
+# tests/files/ua.xtc (precision 1000), which IS there.)
 from gorder_amd.abi import OrderMap   # noqa: E402
 from golden_util import compare_maps, map_of, read_map   # noqa: E402
 
@@ -426,9 +427,9 @@ MORE_CASES = {
     "aa_order_step.yaml": (dict(leaflets="global", frequency=5), (None, None, 5), 1, None, True),   # :1300-1345 (real frequency = 1 x step)
     "aa_order_begin_end.yaml": (dict(leaflets="global"), (450_200.0, 450_400.0, 1), 1, None, True),  # :1398-1423
     # (aa_order_cuboid_square_inverted.yaml, tests_aa.rs:3505-3545, is NOT here: the cuboid's face sits at x = 6.0 and
-    #  XTC coordinates are multiples of 5e-4 nm, so a few dozen bond midpoints lie exactly ON the face.  The plain
-    #  cuboid golden has them inside; the inverted one is reproduced for 690 of 698 values, the other 8 are off by
-    #  2-7e-4 — one on-face sample each, counted there as outside.  Neither tie rule nor XTC conversion explains both.)
+    #  the split/pcpepg*.xtc files are written with XTC precision 100 — bond midpoints are multiples of 5e-3 nm and a
+    #  few dozen lie exactly ON the face.  The golden came from the full-precision pcpepg.xtc (not in the checkout):
+    #  690 of its 698 values are reproduced, 8 are off by 2-7e-4, one on-face sample each.)
     "aa_order_cylinder_z_inverted.yaml": (dict(geometry=("cylinder_inv",)), (None, None, 1), 1, None, False),    # :3548-3585
     "aa_order_sphere_dynamic_inverted.yaml": (dict(geometry=("sphere_dyn_inv",)), (None, None, 1), 1, None, False),  # :3588-3616
     "aa_order_error_blocks10.yaml": (dict(timewise=True), (None, None, 1), 1, 10, False),       # :2530-2552
