@@ -71,6 +71,7 @@ struct gorder_hip_handle {
     gorder::MapRun *d_ua_runs = nullptr, *d_runs = nullptr;
     uint32_t *d_ua_run_begin = nullptr, *d_run_begin = nullptr;
     Item *d_items_by_slot = nullptr;
+    uint32_t *d_item_run = nullptr, *d_ua_item_run = nullptr;
     bool map_staged = false;       // the packed map of one slot fits LDS: stage + accumulate instead of one atomic per sample
     uint64_t map_pending = 0;      // upper bound of the samples one packed word may hold since the last fold
     uint64_t map_fold_limit = kMapFoldLimit;   // GORDER_HIP_MAP_FOLD_LIMIT lowers it (tests)
@@ -363,7 +364,7 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
         if (staged) {   // at most 1 GiB of staging per sub-range
             sub = std::min<uint32_t>(sub, (uint32_t)std::max<size_t>(1, ((size_t)1 << 27) / rec_per_frame));
             sub = std::min(sub, a.n_frames);
-            const int st2 = ensure(h, &h->d_map_rec, &h->map_rec_cap, rec_per_frame * sub);
+            const int st2 = ensure(h, &h->d_map_rec, &h->map_rec_cap, rec_per_frame * (((size_t)sub + 15) / 16 * 16));
             if (st2 != GORDER_OK) return st2;
         }
         for (uint32_t lo = 0; lo < a.n_frames; lo += sub) {
@@ -381,15 +382,17 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
                 if (!nt) continue;
                 uint32_t n_chunks = std::max(1u, (h->wg_target ? h->wg_target : 8u * h->wg_capacity) / nt);
                 n_chunks = std::min(n_chunks, nf);
-                const uint32_t fpc = (nf + n_chunks - 1) / n_chunks;
+                uint32_t fpc = (nf + n_chunks - 1) / n_chunks;
+                if (staged) fpc = (fpc + 15u) / 16u * 16u;   // whole frame blocks (kRecFrames) and whole lines per workgroup
                 n_chunks = (nf + fpc - 1) / fpc;
                 FrameArgs b = a;
                 b.frame0 = lo;
                 b.n_frames = hi;
                 b.frames_per_chunk = fpc;
                 e.map_rec = staged ? h->d_map_rec : nullptr;
+                e.item_run = pass == 0 ? h->d_item_run : h->d_ua_item_run;
                 e.rec_frame0 = lo;
-                e.rec_frames = nf;
+                e.rec_stride = (nf + 15u) / 16u * 16u;
                 const dim3 g(nt * n_chunks), blk(kBlock);
                 if (pass == 0) {
                     const Item *items = staged ? h->d_items_by_slot : h->d_items;
@@ -412,12 +415,13 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
                         // enough blocks for ~2 per CU; a block flushes <= n_words atomics, so keep its chunk long
                         uint32_t mchunks = std::max(1u, 512u / std::max(1u, p.n_acc));
                         mchunks = std::min(mchunks, std::max(1u, nf / 16u));
-                        const uint32_t mfpc = (nf + mchunks - 1) / mchunks;
+                        const uint32_t mfpc = ((nf + mchunks - 1) / mchunks + 15u) / 16u * 16u;   // whole frame blocks
                         mchunks = (nf + mfpc - 1) / mfpc;
                         hipLaunchKernelGGL(k_map_accumulate, dim3(p.n_acc * mchunks), dim3(1024),
                                            n_words * sizeof(unsigned long long), h->stream, h->d_map_rec,
                                            pass == 0 ? h->d_runs : h->d_ua_runs, pass == 0 ? h->d_run_begin : h->d_ua_run_begin,
-                                           p.n_acc, nf, mfpc, pass == 0 ? 1u : 3u, n_words, ntm, h->d_map_packed, p.n_acc);
+                                           p.n_acc, nf, e.rec_stride, mfpc, pass == 0 ? 1u : 3u, n_words, ntm, h->d_map_packed,
+                                           p.n_acc);
                     }
                 }
                 HIP_TRY(h, hipGetLastError());
@@ -555,6 +559,8 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
                 if ((st = upload(h, &h->d_runs, p.runs)) != GORDER_OK) return st;
                 if ((st = upload(h, &h->d_run_begin, p.run_begin)) != GORDER_OK) return st;
                 if ((st = upload(h, &h->d_items_by_slot, p.items_by_slot)) != GORDER_OK) return st;
+                if ((st = upload(h, &h->d_item_run, p.item_run)) != GORDER_OK) return st;
+                if ((st = upload(h, &h->d_ua_item_run, p.ua_item_run)) != GORDER_OK) return st;
                 HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_map_accumulate),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
                 h->map_staged = true;
@@ -731,6 +737,7 @@ void gorder_hip_destroy(gorder_hip_handle *h) {
     (void)hipFree(h->d_geom_group); (void)hipFree(h->d_shapes);
     (void)hipFree(h->d_map_rec); (void)hipFree(h->d_ua_runs); (void)hipFree(h->d_ua_run_begin);
     (void)hipFree(h->d_runs); (void)hipFree(h->d_run_begin); (void)hipFree(h->d_items_by_slot);
+    (void)hipFree(h->d_item_run); (void)hipFree(h->d_ua_item_run);
     (void)hipFree(h->d_dyn_cloud); (void)hipFree(h->d_dyn_heads); (void)hipFree(h->d_dyn_cell_of); (void)hipFree(h->d_dyn_count);
     (void)hipFree(h->d_dyn_rec); (void)hipFree(h->d_dyn_rsn); (void)hipFree(h->d_dyn_normals);
     if (!h->acc_external) (void)hipFree(h->d_acc);

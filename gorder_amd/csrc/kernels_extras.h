@@ -18,8 +18,15 @@ struct ExtraArgs {
     float x0, y0, binx, biny;
     uint32_t nx, ny;
     unsigned long long *map_packed;  // [leaflets ? 2 : 1][n_acc][nx*ny] packed (count << 42) + sum, see k_fold_maps
-    unsigned long long *map_rec;     // sample staging (k_map_accumulate): [tile][frame - rec_frame0][1 | 3][kBlock] or null
-    uint32_t rec_frame0, rec_frames;
+    // sample staging (k_map_accumulate), or null.  The `n` lanes of a tile that hold the molecules of one slot (a
+    // MapRun, from lane tid0) own the words [((tile * K + k) * kBlock + tid0) * rec_stride ...) laid out
+    // [frame - rec_frame0][n]: what one slot reads back is one contiguous piece per run (K = 1 bonds, 3 united atoms).
+    // Bond tiles (runs of a few lanes only) block the frames by kRecFrames instead: a tile's words of one block of
+    // frames are contiguous, [frame block][tid0 * kRecFrames + (frame in block) * n + lane in run] — written as whole
+    // rows after a transposition in LDS, read back as pieces of kRecFrames * n words.
+    unsigned long long *map_rec;
+    const uint32_t *item_run;        // per item: (tid0 << 16) | n
+    uint32_t rec_frame0, rec_stride; // rec_stride: words per lane = frames of the sub-range rounded up to 16
     const float4 *dyn;               // dynamic membrane normals [n_frames][n_mol_total] (nx, ny, nz, cloud size) or null
     int tw;                          // timewise on
     unsigned long long *tw_sums;     // [rows][3][n_acc]
@@ -117,6 +124,9 @@ __device__ __forceinline__ void extras_flush_tw(const FrameArgs &a, const ExtraA
     }
 }
 
+constexpr uint32_t kRecFrames = 4;               // frames per block of the bond tiles' staging layout
+constexpr uint32_t kRecPitch = kBlock + 4;       // LDS row pitch in words (the flush reads columns)
+
 template <bool ACOS_COS>
 __global__ __launch_bounds__(kBlock) void k_bonds_extras(FrameArgs a_in, ExtraArgs e, const float *__restrict__ xyz,
                                                           const float *__restrict__ box9,
@@ -129,6 +139,8 @@ __global__ __launch_bounds__(kBlock) void k_bonds_extras(FrameArgs a_in, ExtraAr
     __shared__ uint32_t l_n[2 * kBlock];
     __shared__ int l_tw[3 * kBlock];
     __shared__ uint32_t l_twn[3 * kBlock];
+    __shared__ unsigned long long l_rec[kRecFrames * kRecPitch];
+    __shared__ uint32_t l_run[kBlock];
     FrameArgs a = a_in;
     a.xyz = xyz; a.box9 = box9; a.aflags = aflags; a.arow = arow;
     const uint32_t tile_id = blockIdx.x % n_tiles, chunk = blockIdx.x / n_tiles;
@@ -144,6 +156,7 @@ __global__ __launch_bounds__(kBlock) void k_bonds_extras(FrameArgs a_in, ExtraAr
     const float *pi = xyz + ((size_t)t.atom0 + it.li) * 3u;
     const float *pj = xyz + ((size_t)t.atom0 + it.lj) * 3u;
     for (uint32_t k = tid; k < 3 * kBlock; k += kBlock) { l_tw[k] = 0; l_twn[k] = 0; }
+    l_run[tid] = (active && e.map_rec) ? e.item_run[t.item0 + tid] : ((tid << 16) | 1u);   // a padding lane: a run of its own
     __syncthreads();
     SampleAcc acc;
     int bad = 0;
@@ -188,7 +201,23 @@ __global__ __launch_bounds__(kBlock) void k_bonds_extras(FrameArgs a_in, ExtraAr
                 extras_add(a, e, gslot, it.lslot, tick, mx, my, mz, leaflet, l_tw, l_twn, kBlock, e.map_rec ? &rec : nullptr);
             }
         }
-        if (e.map_rec) e.map_rec[((size_t)tile_id * e.rec_frames + (f - e.rec_frame0)) * kBlock + tid] = rec;
+        if (e.map_rec) {   // staged samples: kRecFrames frames gathered in LDS, then written as rows of the blocked layout
+            const uint32_t c = (f - f_begin) % kRecFrames;      // the host keeps f_begin - rec_frame0 a multiple of kRecFrames
+            l_rec[c * kRecPitch + tid] = rec;
+            if (c == kRecFrames - 1 || f + 1 == f_end) {
+                __syncthreads();
+                unsigned long long *row = e.map_rec + (size_t)tile_id * kBlock * e.rec_stride +
+                                          (size_t)((f - c - e.rec_frame0) / kRecFrames) * (kRecFrames * kBlock);
+#pragma unroll
+                for (uint32_t m = 0; m < kRecFrames; m++) {
+                    const uint32_t w = tid + kBlock * m, run = l_run[w / kRecFrames];
+                    const uint32_t tid0 = run >> 16, n = run & 0xffffu, rem = w - kRecFrames * tid0;
+                    const uint32_t cc = (rem >= n ? 1u : 0u) + (rem >= 2u * n ? 1u : 0u) + (rem >= 3u * n ? 1u : 0u);
+                    row[w] = cc <= c ? l_rec[cc * kRecPitch + tid0 + (rem - cc * n)] : kMapNoSample;
+                }
+                __syncthreads();
+            }
+        }
         if (e.tw) {
             __syncthreads();
             extras_flush_tw(a, e, tile_slots + t.slot0, t.n_slots, f, l_tw, l_twn, kBlock);
@@ -349,7 +378,7 @@ __device__ __noinline__ UaBonds ua_carbon_slow(uint32_t kind, UaCarbon c, UaCons
 }
 
 template <bool ACOS_COS, bool EXTRAS>
-__global__ __launch_bounds__(kBlock) void k_ua_extras(FrameArgs a_in, ExtraArgs e, const float *__restrict__ xyz,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ua_extras(FrameArgs a_in, ExtraArgs e, const float *__restrict__ xyz,
                                                        const float *__restrict__ box9,
                                                        const uint8_t *__restrict__ aflags,
                                                        const uint32_t *__restrict__ arow,
@@ -384,6 +413,14 @@ __global__ __launch_bounds__(kBlock) void k_ua_extras(FrameArgs a_in, ExtraArgs 
     int bad = 0;
     const bool pbc = a.pbc != 0;
     const UaConsts uc{e.sin_tet, e.cos_tet, e.sin_ch3, e.cos_ch3, e.sin_half, e.cos_half};
+    unsigned long long *rec_row = nullptr;
+    uint32_t rec_n = 0;
+    const size_t rec_plane = (size_t)kBlock * e.rec_stride;      // hydrogen k of the same lanes: k planes further
+    if (EXTRAS && e.map_rec && active) {
+        const uint32_t run = e.item_run[t.item0 + tid], tid0 = run >> 16;
+        rec_n = run & 0xffffu;
+        rec_row = e.map_rec + ((size_t)tile_id * 3u * kBlock + tid0) * e.rec_stride + (tid - tid0);
+    }
     const float *src[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) src[q] = xyz + ((size_t)t.atom0 + (active ? it.l[q] : 0u)) * 3u;
@@ -440,13 +477,12 @@ __global__ __launch_bounds__(kBlock) void k_ua_extras(FrameArgs a_in, ExtraArgs 
             sample(0, ub.v0, ub.b0);
             sample(1, ub.v1, ub.b1);
             sample(2, ub.v2, ub.b2);
-            if (EXTRAS && e.map_rec) {   // every lane of the tile writes its three entries: coalesced rows of kBlock words
-                unsigned long long *row = e.map_rec + (((size_t)tile_id * e.rec_frames + (f - e.rec_frame0)) * 3u) * kBlock + tid;
-                row[0] = recs[0]; row[kBlock] = recs[1]; row[2u * kBlock] = recs[2];
+            if (EXTRAS && e.map_rec) {   // one word per hydrogen this carbon has, into its run's piece
+                unsigned long long *row = rec_row + (size_t)(f - e.rec_frame0) * rec_n;
+                row[0] = recs[0];
+                if (nh > 1) row[rec_plane] = recs[1];
+                if (nh > 2) row[2u * rec_plane] = recs[2];
             }
-        } else if (EXTRAS && e.map_rec) {
-            unsigned long long *row = e.map_rec + (((size_t)tile_id * e.rec_frames + (f - e.rec_frame0)) * 3u) * kBlock + tid;
-            row[0] = kMapNoSample; row[kBlock] = kMapNoSample; row[2u * kBlock] = kMapNoSample;
         }
         if (EXTRAS && e.tw) {
             __syncthreads();
@@ -491,7 +527,8 @@ __global__ __launch_bounds__(kBlock) void k_ua_extras(FrameArgs a_in, ExtraArgs 
 __global__ __launch_bounds__(1024) void k_map_accumulate(const unsigned long long *__restrict__ rec,
                                                          const gorder::MapRun *__restrict__ runs,
                                                          const uint32_t *__restrict__ run_begin, uint32_t n_slots,
-                                                         uint32_t rec_frames, uint32_t frames_per_chunk, uint32_t k_max,
+                                                         uint32_t rec_frames, uint32_t rec_stride,
+                                                         uint32_t frames_per_chunk, uint32_t k_max,
                                                          uint32_t n_words /* planes * tiles */, uint32_t n_tiles_map,
                                                          unsigned long long *__restrict__ map_packed, uint32_t n_acc) {
     extern __shared__ unsigned long long l_map[];
@@ -501,14 +538,27 @@ __global__ __launch_bounds__(1024) void k_map_accumulate(const unsigned long lon
     const uint32_t f0 = chunk * frames_per_chunk, f1 = min(rec_frames, f0 + frames_per_chunk);
     for (uint32_t w = threadIdx.x; w < n_words; w += blockDim.x) l_map[w] = 0ull;
     __syncthreads();
-    for (uint32_t r = r0; r < r1; r++) {
+    // one wave per run at a time
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, n_waves = blockDim.x >> 6;
+    for (uint32_t r = r0 + wave; r < r1; r += n_waves) {
         const gorder::MapRun run = runs[r];
-        const uint32_t total = (f1 - f0) * run.n;
-        for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) {
-            const uint32_t f = f0 + i / run.n, j = i % run.n;
-            const unsigned long long v = rec[(((size_t)run.tile * rec_frames + f) * k_max + run.k) * kBlock + run.tid0 + j];
-            if (v != kMapNoSample)
-                atomicAdd(&l_map[(uint32_t)(v >> 32)], kMapOne + (unsigned long long)(long long)(int)(uint32_t)v);
+        if (k_max == 1u) {     // bond tiles: per block of kRecFrames frames one piece of kRecFrames * n words
+            const uint32_t pl = kRecFrames * run.n, fb0 = f0 / kRecFrames, fb1 = (f1 + kRecFrames - 1) / kRecFrames;
+            const unsigned long long *tile = rec + (size_t)run.tile * kBlock * rec_stride + kRecFrames * run.tid0;
+            for (uint32_t i = lane; i < (fb1 - fb0) * pl; i += 64u) {
+                const uint32_t b = i / pl;
+                const unsigned long long v = tile[(size_t)(fb0 + b) * (kRecFrames * kBlock) + (i - b * pl)];
+                if (v != kMapNoSample)
+                    atomicAdd(&l_map[(uint32_t)(v >> 32)], kMapOne + (unsigned long long)(long long)(int)(uint32_t)v);
+            }
+        } else {               // united-atom tiles: the run's words of the frames [f0, f1) are one contiguous piece
+            const uint32_t total = (f1 - f0) * run.n;
+            const unsigned long long *piece = rec + (((size_t)run.tile * k_max + run.k) * kBlock + run.tid0) * rec_stride + (size_t)f0 * run.n;
+            for (uint32_t i = lane; i < total; i += 64u) {
+                const unsigned long long v = piece[i];
+                if (v != kMapNoSample)
+                    atomicAdd(&l_map[(uint32_t)(v >> 32)], kMapOne + (unsigned long long)(long long)(int)(uint32_t)v);
+            }
         }
     }
     __syncthreads();

@@ -66,6 +66,7 @@ struct Plan {
     // the same for bond tiles: `items_by_slot` = every tile's items re-ordered so that the molecules of one slot
     // sit on consecutive lanes (used by the scatter kernel only; K1 keeps the atom order of `items`)
     std::vector<Item> items_by_slot;
+    std::vector<uint32_t> item_run, ua_item_run;   // per item of items_by_slot / ua_items: (tid0 << 16) | n of its run
     std::vector<MapRun> runs;
     std::vector<uint32_t> run_begin;
     std::vector<uint32_t> mol0;    // first global molecule id per molecule type
@@ -177,6 +178,8 @@ inline int build_plan(const gorder_tables_t &t, bool force_direct, Plan &p) {
                 while (i + n < tile.n_items && p.ua_items[tile.item0 + i + n].lslot0 == it.lslot0) n++;
                 const uint32_t nh = it.kind == GORDER_UA_CH3 ? 3 : it.kind == GORDER_UA_CH2 ? 2 : 1;
                 for (uint32_t k = 0; k < nh; k++) run_of_slot.push_back({slots[it.lslot0 + k], MapRun{tile_id, i, n, k}});
+                p.ua_item_run.resize((size_t)tile.item0 + tile.n_items, 0u);
+                for (uint32_t j = 0; j < n; j++) p.ua_item_run[tile.item0 + i + j] = (i << 16) | n;
                 i += n;
             }
             p.ua_tile_slots.insert(p.ua_tile_slots.end(), slots.begin(), slots.end());
@@ -241,11 +244,13 @@ inline int build_plan(const gorder_tables_t &t, bool force_direct, Plan &p) {
             const Tile &tile = p.tiles[ti];
             std::stable_sort(p.items_by_slot.begin() + tile.item0, p.items_by_slot.begin() + tile.item0 + tile.n_items,
                              [](const Item &x, const Item &y) { return x.lslot < y.lslot; });
+            p.item_run.resize((size_t)tile.item0 + tile.n_items, 0u);
             for (uint32_t i = 0; i < tile.n_items;) {
                 const uint16_t ls = p.items_by_slot[tile.item0 + i].lslot;
                 uint32_t n = 1;
                 while (i + n < tile.n_items && p.items_by_slot[tile.item0 + i + n].lslot == ls) n++;
                 run_of_slot.push_back({p.tile_slots[tile.slot0 + ls], MapRun{ti, i, n, 0}});
+                for (uint32_t j = 0; j < n; j++) p.item_run[tile.item0 + i + j] = (i << 16) | n;
                 i += n;
             }
         }
@@ -314,6 +319,8 @@ inline int selfcheck_plan(const gorder_tables_t &t, const Plan &p) {
             for (uint32_t j = 0; j < run.n; j++) {
                 const Item &it = p.items_by_slot[tile.item0 + run.tid0 + j];
                 if (p.tile_slots[tile.slot0 + it.lslot] != sl) return 10;
+                if (p.item_run.size() != p.items.size() || p.item_run[tile.item0 + run.tid0 + j] != ((run.tid0 << 16) | run.n))
+                    return 16;
                 covered[tile.item0 + run.tid0 + j]++;
             }
         }
@@ -331,6 +338,9 @@ inline int selfcheck_plan(const gorder_tables_t &t, const Plan &p) {
                 for (uint32_t j = 0; j < run.n; j++) {
                     const UaItem &it = p.ua_items[tile.item0 + run.tid0 + j];
                     if (p.ua_tile_slots[tile.slot0 + it.lslot0 + run.k] != sl) return 14;
+                    if (p.ua_item_run.size() != p.ua_items.size() ||
+                        p.ua_item_run[tile.item0 + run.tid0 + j] != ((run.tid0 << 16) | run.n))
+                        return 17;
                     lanes++;
                 }
             }
