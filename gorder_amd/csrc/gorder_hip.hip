@@ -396,16 +396,22 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
                 const dim3 g(nt * n_chunks), blk(kBlock);
                 if (pass == 0) {
                     const Item *items = staged ? h->d_items_by_slot : h->d_items;
-                    if (ac) hipLaunchKernelGGL(k_bonds_extras<true>, g, blk, 0, h->stream, b, e, b.xyz, b.box9, b.aflags,
-                                               b.arow, h->d_tiles, items, h->d_tile_slots, nt);
-                    else hipLaunchKernelGGL(k_bonds_extras<false>, g, blk, 0, h->stream, b, e, b.xyz, b.box9, b.aflags,
-                                            b.arow, h->d_tiles, items, h->d_tile_slots, nt);
+#define GORDER_LAUNCH_BONDS(AC, MO)                                                                               \
+    hipLaunchKernelGGL((k_bonds_extras<AC, MO>), g, blk, 0, h->stream, b, e, b.xyz, b.box9, b.aflags, b.arow,       \
+                       h->d_tiles, items, h->d_tile_slots, nt)
+                    const bool maps_only = staged && !e.tw && !e.geom_kind && !e.dyn;
+                    if (maps_only) { if (ac) GORDER_LAUNCH_BONDS(true, true); else GORDER_LAUNCH_BONDS(false, true); }
+                    else { if (ac) GORDER_LAUNCH_BONDS(true, false); else GORDER_LAUNCH_BONDS(false, false); }
+#undef GORDER_LAUNCH_BONDS
                 } else {
-#define GORDER_LAUNCH_UA(AC, EX)                                                                                  \
-    hipLaunchKernelGGL((k_ua_extras<AC, EX>), g, blk, 0, h->stream, b, e, b.xyz, b.box9, b.aflags, b.arow,          \
+#define GORDER_LAUNCH_UA(AC, MODE)                                                                                \
+    hipLaunchKernelGGL((k_ua_extras<AC, MODE>), g, blk, 0, h->stream, b, e, b.xyz, b.box9, b.aflags, b.arow,        \
                        h->d_ua_tiles, h->d_ua_items, h->d_ua_tile_slots, nt)
-                    if (extras) { if (ac) GORDER_LAUNCH_UA(true, true); else GORDER_LAUNCH_UA(false, true); }
-                    else { if (ac) GORDER_LAUNCH_UA(true, false); else GORDER_LAUNCH_UA(false, false); }
+                    // staged ordermap samples and nothing else: the lean kernel
+                    const bool maps_only = extras && staged && !e.tw && !e.geom_kind && !e.dyn;
+                    if (maps_only) { if (ac) GORDER_LAUNCH_UA(true, 1); else GORDER_LAUNCH_UA(false, 1); }
+                    else if (extras) { if (ac) GORDER_LAUNCH_UA(true, 2); else GORDER_LAUNCH_UA(false, 2); }
+                    else { if (ac) GORDER_LAUNCH_UA(true, 0); else GORDER_LAUNCH_UA(false, 0); }
 #undef GORDER_LAUNCH_UA
                 }
                 {

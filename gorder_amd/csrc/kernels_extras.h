@@ -71,11 +71,12 @@ __device__ __forceinline__ int grid_index(float x, float lo, float bin, uint32_t
 }
 
 // BondLike::add_order for the scatter targets (bond.rs:184-215): maps and the per-frame LDS partials
+template <bool STAGED_ONLY = false>
 __device__ __forceinline__ void extras_add(const FrameArgs &a, const ExtraArgs &e, uint32_t gslot, uint32_t lslot,
                                            int tick, float px, float py, float pz, int leaflet /* -1 none */,
                                            int *l_tw, uint32_t *l_twn, uint32_t lstride,
                                            unsigned long long *rec = nullptr) {
-    if (e.maps) {
+    if (STAGED_ONLY || e.maps) {
         float x, y;
         if (e.plane == 0) { x = px; y = py; }
         else if (e.plane == 1) { x = px; y = pz; }
@@ -87,7 +88,7 @@ __device__ __forceinline__ void extras_add(const FrameArgs &a, const ExtraArgs &
             // unpacks.  Scattered 64-bit atomics run at ~24 G/s on gfx950 whatever the scope or table size
             // (tools/microbench/atomic_scatter.hip), so their number is what counts.
             const size_t nt = (size_t)e.nx * e.ny, t = (size_t)ix * e.ny + (size_t)iy;
-            if (rec) {   // staged: (plane * tiles + tile) << 32 | tick, added to the map by k_map_accumulate
+            if (STAGED_ONLY || rec) {   // staged: (plane * tiles + tile) << 32 | tick, added to the map by k_map_accumulate
                 *rec = ((unsigned long long)((leaflet > 0 ? nt : 0) + t) << 32) | (unsigned long long)(uint32_t)tick;
             } else {
                 const size_t w = leaflet > 0 ? a.n_acc : 0;
@@ -95,7 +96,7 @@ __device__ __forceinline__ void extras_add(const FrameArgs &a, const ExtraArgs &
             }
         }
     }
-    if (e.tw) {
+    if (!STAGED_ONLY && e.tw) {
         atomicAdd(&l_tw[lslot], tick);
         atomicAdd(&l_twn[lslot], 1u);
         if (leaflet >= 0) {
@@ -127,7 +128,8 @@ __device__ __forceinline__ void extras_flush_tw(const FrameArgs &a, const ExtraA
 constexpr uint32_t kRecFrames = 4;               // frames per block of the bond tiles' staging layout
 constexpr uint32_t kRecPitch = kBlock + 4;       // LDS row pitch in words (the flush reads columns)
 
-template <bool ACOS_COS>
+// MAPS_ONLY: staged ordermap samples and nothing else (no geometry selection, timewise rows, per-molecule normals)
+template <bool ACOS_COS, bool MAPS_ONLY>
 __global__ __launch_bounds__(kBlock) void k_bonds_extras(FrameArgs a_in, ExtraArgs e, const float *__restrict__ xyz,
                                                           const float *__restrict__ box9,
                                                           const uint8_t *__restrict__ aflags,
@@ -137,8 +139,8 @@ __global__ __launch_bounds__(kBlock) void k_bonds_extras(FrameArgs a_in, ExtraAr
                                                           const uint32_t *__restrict__ tile_slots, uint32_t n_tiles) {
     __shared__ unsigned long long l_s[2 * kBlock];
     __shared__ uint32_t l_n[2 * kBlock];
-    __shared__ int l_tw[3 * kBlock];
-    __shared__ uint32_t l_twn[3 * kBlock];
+    __shared__ int l_tw[MAPS_ONLY ? 1 : 3 * kBlock];
+    __shared__ uint32_t l_twn[MAPS_ONLY ? 1 : 3 * kBlock];
     __shared__ unsigned long long l_rec[kRecFrames * kRecPitch];
     __shared__ uint32_t l_run[kBlock];
     FrameArgs a = a_in;
@@ -155,17 +157,39 @@ __global__ __launch_bounds__(kBlock) void k_bonds_extras(FrameArgs a_in, ExtraAr
     const size_t fstride = (size_t)a.n_atoms * 3u;
     const float *pi = xyz + ((size_t)t.atom0 + it.li) * 3u;
     const float *pj = xyz + ((size_t)t.atom0 + it.lj) * 3u;
-    for (uint32_t k = tid; k < 3 * kBlock; k += kBlock) { l_tw[k] = 0; l_twn[k] = 0; }
-    l_run[tid] = (active && e.map_rec) ? e.item_run[t.item0 + tid] : ((tid << 16) | 1u);   // a padding lane: a run of its own
+    if (!MAPS_ONLY)
+        for (uint32_t k = tid; k < 3 * kBlock; k += kBlock) { l_tw[k] = 0; l_twn[k] = 0; }
+    l_run[tid] = (active && (MAPS_ONLY || e.map_rec)) ? e.item_run[t.item0 + tid] : ((tid << 16) | 1u);   // a padding lane: a run of its own
     __syncthreads();
     SampleAcc acc;
     int bad = 0;
+    // the two atoms of the next frames are fetched ahead of the arithmetic of this one (the gather is latency-bound)
+    constexpr uint32_t kAhead = 2;
+    float nx1[kAhead][3], nx2[kAhead][3];
+#pragma unroll
+    for (uint32_t u = 0; u < kAhead; u++) {
+        const uint32_t fu = min(f_begin + u, a.n_frames - 1u);
+#pragma unroll
+        for (int d = 0; d < 3; d++) { nx1[u][d] = pi[(size_t)fu * fstride + d]; nx2[u][d] = pj[(size_t)fu * fstride + d]; }
+    }
     for (uint32_t f = f_begin; f < f_end; f++) {
         unsigned long long rec = kMapNoSample;
+        const float p1x = nx1[0][0], p1y = nx1[0][1], p1z = nx1[0][2];
+        const float p2x = nx2[0][0], p2y = nx2[0][1], p2z = nx2[0][2];
+#pragma unroll
+        for (uint32_t u = 0; u + 1 < kAhead; u++)
+#pragma unroll
+            for (int d = 0; d < 3; d++) { nx1[u][d] = nx1[u + 1][d]; nx2[u][d] = nx2[u + 1][d]; }
+        {
+            const uint32_t fu = min(f + kAhead, a.n_frames - 1u);
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                nx1[kAhead - 1][d] = pi[(size_t)fu * fstride + d];
+                nx2[kAhead - 1][d] = pj[(size_t)fu * fstride + d];
+            }
+        }
         if (active) {
-            const float *q1 = pi + (size_t)f * fstride, *q2 = pj + (size_t)f * fstride;
-            const float p1x = q1[0], p1y = q1[1], p1z = q1[2];
-            float vx = q2[0] - p1x, vy = q2[1] - p1y, vz = q2[2] - p1z;
+            float vx = p2x - p1x, vy = p2y - p1y, vz = p2z - p1z;
             if (a.pbc) {
                 const float *b = a.box9 + 9 * (size_t)f;
                 vx = gm_min_image(vx, b[0], bad);
@@ -173,18 +197,18 @@ __global__ __launch_bounds__(kBlock) void k_bonds_extras(FrameArgs a_in, ExtraAr
                 vz = gm_min_image(vz, b[8], bad);
             }
             if (p1x != p1x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, t.atom0 + it.li, f);
-            else if (q2[0] != q2[0]) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, t.atom0 + it.lj, f);
+            else if (p2x != p2x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, t.atom0 + it.lj, f);
             // bond position = p1 + v / 2 (bond.rs:422); geometry filter (bond.rs:424-426)
             const float mx = p1x + vx / 2.0f, my = p1y + vy / 2.0f, mz = p1z + vz / 2.0f;
             bool in = true;
-            if (e.geom_kind) {
+            if (!MAPS_ONLY && e.geom_kind) {
                 float box[3] = {1.0f, 1.0f, 1.0f};
                 if (a.pbc) { const float *b = a.box9 + 9 * (size_t)f; box[0] = b[0]; box[1] = b[4]; box[2] = b[8]; }
                 in = geom_inside(e, e.shapes + 8 * (size_t)f, mx, my, mz, box, a.pbc != 0, bad);
             }
             if (in) {
                 float sch;
-                if (e.dyn) {   // the molecule's own normal of this frame, fetched after the geometry test (bond.rs:429-431)
+                if (!MAPS_ONLY && e.dyn) {   // the molecule's own normal of this frame, fetched after the geometry test (bond.rs:429-431)
                     const float4 n = e.dyn[(size_t)f * a.n_mol_total + it.mol];
                     if (n.w < 3.0f) raise_error(a.err, GORDER_ERR_DYNAMIC_NORMAL, (uint32_t)n.w, f);
                     const float n2sq = (n.x * n.x + n.y * n.y) + n.z * n.z;
@@ -198,10 +222,11 @@ __global__ __launch_bounds__(kBlock) void k_bonds_extras(FrameArgs a_in, ExtraAr
                 acc.s_tot += tick;
                 acc.n_tot += 1;
                 if (leaflet == 0) { acc.s_up += tick; acc.n_up += 1; }
-                extras_add(a, e, gslot, it.lslot, tick, mx, my, mz, leaflet, l_tw, l_twn, kBlock, e.map_rec ? &rec : nullptr);
+                extras_add<MAPS_ONLY>(a, e, gslot, it.lslot, tick, mx, my, mz, leaflet, l_tw, l_twn, kBlock,
+                                      (MAPS_ONLY || e.map_rec) ? &rec : nullptr);
             }
         }
-        if (e.map_rec) {   // staged samples: kRecFrames frames gathered in LDS, then written as rows of the blocked layout
+        if (MAPS_ONLY || e.map_rec) {   // staged samples: kRecFrames frames gathered in LDS, then written as rows of the blocked layout
             const uint32_t c = (f - f_begin) % kRecFrames;      // the host keeps f_begin - rec_frame0 a multiple of kRecFrames
             l_rec[c * kRecPitch + tid] = rec;
             if (c == kRecFrames - 1 || f + 1 == f_end) {
@@ -218,7 +243,7 @@ __global__ __launch_bounds__(kBlock) void k_bonds_extras(FrameArgs a_in, ExtraAr
                 __syncthreads();
             }
         }
-        if (e.tw) {
+        if (!MAPS_ONLY && e.tw) {
             __syncthreads();
             extras_flush_tw(a, e, tile_slots + t.slot0, t.n_slots, f, l_tw, l_twn, kBlock);
             __syncthreads();
@@ -377,7 +402,9 @@ __device__ __noinline__ UaBonds ua_carbon_slow(uint32_t kind, UaCarbon c, UaCons
     return ua_carbon(kind, c, e, pl);
 }
 
-template <bool ACOS_COS, bool EXTRAS>
+// MODE 0: order parameters only; 1: + staged ordermap samples, nothing else (no geometry selection, timewise rows or
+// per-molecule normals — the common ordermap run, and a much smaller kernel); 2: every extra
+template <bool ACOS_COS, int MODE>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ua_extras(FrameArgs a_in, ExtraArgs e, const float *__restrict__ xyz,
                                                        const float *__restrict__ box9,
                                                        const uint8_t *__restrict__ aflags,
@@ -385,11 +412,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                                                        const Tile *__restrict__ tiles,
                                                        const gorder::UaItem *__restrict__ items,
                                                        const uint32_t *__restrict__ tile_slots, uint32_t n_tiles) {
+    constexpr bool EXTRAS = MODE != 0, GENERAL = MODE == 2;
     constexpr uint32_t LS = 3 * kBlock;   // local slots per block (<= 3 hydrogens per carbon)
     __shared__ unsigned long long l_s[2 * LS];
     __shared__ uint32_t l_n[2 * LS];
-    __shared__ int l_tw[EXTRAS ? 3 * LS : 1];
-    __shared__ uint32_t l_twn[EXTRAS ? 3 * LS : 1];
+    __shared__ int l_tw[GENERAL ? 3 * LS : 1];
+    __shared__ uint32_t l_twn[GENERAL ? 3 * LS : 1];
     FrameArgs a = a_in;
     a.xyz = xyz; a.box9 = box9; a.aflags = aflags; a.arow = arow;
     const uint32_t tile_id = blockIdx.x % n_tiles, chunk = blockIdx.x / n_tiles;
@@ -404,7 +432,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     const uint32_t f_begin = a.frame0 + chunk * a.frames_per_chunk;
     const uint32_t f_end = min(a.n_frames, f_begin + a.frames_per_chunk);
     const size_t fstride = (size_t)a.n_atoms * 3u;
-    if (EXTRAS)
+    if (GENERAL)
         for (uint32_t k = tid; k < 3 * LS; k += kBlock) { l_tw[k] = 0; l_twn[k] = 0; }
     for (uint32_t k = tid; k < 2 * LS; k += kBlock) { l_s[k] = 0; l_n[k] = 0; }
     __syncthreads();
@@ -416,7 +444,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     unsigned long long *rec_row = nullptr;
     uint32_t rec_n = 0;
     const size_t rec_plane = (size_t)kBlock * e.rec_stride;      // hydrogen k of the same lanes: k planes further
-    if (EXTRAS && e.map_rec && active) {
+    if (EXTRAS && (!GENERAL || e.map_rec) && active) {
         const uint32_t run = e.item_run[t.item0 + tid], tid0 = run >> 16;
         rec_n = run & 0xffffu;
         rec_row = e.map_rec + ((size_t)tile_id * 3u * kBlock + tid0) * e.rec_stride + (tid - tid0);
@@ -451,7 +479,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             int leaflet = -1;
             if (a.leaflets) leaflet = a.aflags[(size_t)a.arow[f] * a.n_mol_total + it.mol] ? 1 : 0;
             float nrx = a.nx, nry = a.ny, nrz = a.nz, nr2 = a.n2, nr2sq = a.n2sq;
-            if (EXTRAS && e.dyn) {   // fetched for every molecule, before the geometry test (uaorder.rs:412-413)
+            if (GENERAL && e.dyn) {   // fetched for every molecule, before the geometry test (uaorder.rs:412-413)
                 const float4 n = e.dyn[(size_t)f * a.n_mol_total + it.mol];
                 if (n.w < 3.0f) raise_error(a.err, GORDER_ERR_DYNAMIC_NORMAL, (uint32_t)n.w, f);
                 nrx = n.x; nry = n.y; nrz = n.z;
@@ -463,7 +491,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                 if (k >= nh) return;
                 const float sch = gm_calc_sch<ACOS_COS>(v.x, v.y, v.z, nrx, nry, nrz, nr2, nr2sq);
                 const int tick = gm_tick(sch);
-                if (EXTRAS) {
+                if (GENERAL) {
                     const float box[3] = {bx3.x, bx3.y, bx3.z};
                     if (e.geom_kind && !geom_inside(e, e.shapes + 8 * (size_t)f, b.x, b.y, b.z, box, pbc, bad)) return;
                 }
@@ -471,20 +499,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                 n_tot[k] += 1;
                 if (leaflet == 0) { s_up[k] += tick; n_up[k] += 1; }
                 if (EXTRAS)
-                    extras_add(a, e, gslot0 + (uint32_t)k, it.lslot0 + (uint32_t)k, tick, b.x, b.y, b.z, leaflet, l_tw, l_twn, LS,
-                               e.map_rec ? &recs[k] : nullptr);
+                    extras_add<!GENERAL>(a, e, gslot0 + (uint32_t)k, it.lslot0 + (uint32_t)k, tick, b.x, b.y, b.z, leaflet, l_tw,
+                                         l_twn, LS, (!GENERAL || e.map_rec) ? &recs[k] : nullptr);
             };
             sample(0, ub.v0, ub.b0);
             sample(1, ub.v1, ub.b1);
             sample(2, ub.v2, ub.b2);
-            if (EXTRAS && e.map_rec) {   // one word per hydrogen this carbon has, into its run's piece
+            if (EXTRAS && (!GENERAL || e.map_rec)) {   // one word per hydrogen this carbon has, into its run's piece
                 unsigned long long *row = rec_row + (size_t)(f - e.rec_frame0) * rec_n;
                 row[0] = recs[0];
                 if (nh > 1) row[rec_plane] = recs[1];
                 if (nh > 2) row[2u * rec_plane] = recs[2];
             }
         }
-        if (EXTRAS && e.tw) {
+        if (GENERAL && e.tw) {
             __syncthreads();
             extras_flush_tw(a, e, tile_slots + t.slot0, t.n_slots, f, l_tw, l_twn, LS);
             __syncthreads();
