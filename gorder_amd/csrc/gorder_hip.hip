@@ -81,7 +81,8 @@ struct gorder_hip_handle {
     ExtraArgs extra{};
     uint32_t *d_geom_group = nullptr;
     float *d_shapes = nullptr;
-    // dynamic membrane normals: cloud + per-molecule heads, cell-list scratch (kLocalSlab frames), normals of the batch
+    // dynamic membrane normals: cloud + per-molecule heads, cell-list scratch (dyn_slab frames), normals of the batch
+    uint32_t dyn_slab = 4, local_slab = 4;
     bool dyn = false;
     uint32_t *d_dyn_cloud = nullptr, *d_dyn_heads = nullptr;
     uint32_t *d_dyn_cell_of = nullptr, *d_dyn_count = nullptr;
@@ -106,7 +107,7 @@ struct gorder_hip_handle {
     uint8_t *d_aflags = nullptr;
     size_t aflags_rows = 0;
     float *d_adist = nullptr;
-    // Local leaflets scratch (sized for kLocalSlab assignment frames)
+    // Local leaflets scratch (sized for local_slab assignment frames)
     uint32_t *d_lcell_of = nullptr, *d_lcell_count = nullptr, *d_lcell_fill = nullptr, *d_lcell_atoms = nullptr;
     float *d_ltrig = nullptr;
     uint32_t *d_arow = nullptr, *d_aframes = nullptr;
@@ -224,13 +225,13 @@ int run_dynamic_normals(gorder_hip_handle *h, const FrameArgs &a) {
     lo.n_mol_total = n_mol; lo.heads = h->d_dyn_heads; lo.membrane = h->d_dyn_cloud; lo.n_membrane = dn.n_cloud;
     lo.dim = 2; lo.pbc = a.pbc; lo.radius = dn.radius; lo.radius_thr = local_radius_threshold(dn.radius);
     lo.cell_of = h->d_dyn_cell_of; lo.trig = h->d_dyn_rec; lo.rsn = h->d_dyn_rsn;
-    lo.cell_count = h->d_dyn_count; lo.cell_fill = h->d_dyn_count + kLocalSlab * (ncell + 1);
+    lo.cell_count = h->d_dyn_count; lo.cell_fill = h->d_dyn_count + h->dyn_slab * (ncell + 1);
     lo.err = h->d_err; lo.aframes = nullptr; lo.write_dist_frame = -1;
-    for (uint32_t done = 0; done < a.n_frames; done += kLocalSlab) {
-        const uint32_t ns = std::min(a.n_frames - done, kLocalSlab);
+    for (uint32_t done = 0; done < a.n_frames; done += h->dyn_slab) {
+        const uint32_t ns = std::min(a.n_frames - done, h->dyn_slab);
         lo.frame0 = done;
         lo.n_slab = ns;
-        HIP_TRY(h, hipMemsetAsync(h->d_dyn_count, 0, kLocalSlab * (2 * ncell + 1) * sizeof(uint32_t), h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->d_dyn_count, 0, (size_t)h->dyn_slab * (2 * ncell + 1) * sizeof(uint32_t), h->stream));
         const dim3 ga((dn.n_cloud + 255) / 256, ns);
         hipLaunchKernelGGL(k_local_bin, ga, dim3(256), 0, h->stream, lo);
         hipLaunchKernelGGL(k_local_scan, dim3(ns), dim3(1024), 0, h->stream, lo);
@@ -671,10 +672,11 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
         if ((st = upload(h, &h->d_dyn_cloud, cloud)) != GORDER_OK) return st;
         if ((st = upload(h, &h->d_dyn_heads, nheads)) != GORDER_OK) return st;
         const size_t nm = dn.n_cloud, ncell = (size_t)kLocalMaxCells1D * kLocalMaxCells1D;
-        HIP_TRY(h, hipMalloc((void **)&h->d_dyn_cell_of, kLocalSlab * nm * sizeof(uint32_t)));
-        HIP_TRY(h, hipMalloc((void **)&h->d_dyn_rsn, kLocalSlab * nm * sizeof(float)));
-        HIP_TRY(h, hipMalloc((void **)&h->d_dyn_rec, kLocalSlab * nm * 4 * sizeof(float)));
-        HIP_TRY(h, hipMalloc((void **)&h->d_dyn_count, kLocalSlab * (2 * ncell + 1) * sizeof(uint32_t)));
+        const size_t sl = h->dyn_slab = local_slab_frames(nm);
+        HIP_TRY(h, hipMalloc((void **)&h->d_dyn_cell_of, sl * nm * sizeof(uint32_t)));
+        HIP_TRY(h, hipMalloc((void **)&h->d_dyn_rsn, sl * nm * sizeof(float)));
+        HIP_TRY(h, hipMalloc((void **)&h->d_dyn_rec, sl * nm * 4 * sizeof(float)));
+        HIP_TRY(h, hipMalloc((void **)&h->d_dyn_count, sl * (2 * ncell + 1) * sizeof(uint32_t)));
         h->dyn = true;
     }
 
@@ -718,11 +720,12 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
         }
         if (lf.method == GORDER_LEAFLETS_LOCAL) {
             const size_t nm = lf.n_membrane, ncell = (size_t)kLocalMaxCells1D * kLocalMaxCells1D;
-            HIP_TRY(h, hipMalloc((void **)&h->d_lcell_of, kLocalSlab * nm * sizeof(uint32_t)));
-            HIP_TRY(h, hipMalloc((void **)&h->d_lcell_atoms, kLocalSlab * nm * sizeof(float)));   // sin column
-            HIP_TRY(h, hipMalloc((void **)&h->d_ltrig, kLocalSlab * nm * 4 * sizeof(float)));
-            HIP_TRY(h, hipMalloc((void **)&h->d_lcell_count, kLocalSlab * (ncell + 1) * sizeof(uint32_t)));
-            HIP_TRY(h, hipMalloc((void **)&h->d_lcell_fill, kLocalSlab * ncell * sizeof(uint32_t)));
+            const size_t sl = h->local_slab = local_slab_frames(nm);
+            HIP_TRY(h, hipMalloc((void **)&h->d_lcell_of, sl * nm * sizeof(uint32_t)));
+            HIP_TRY(h, hipMalloc((void **)&h->d_lcell_atoms, sl * nm * sizeof(float)));   // sin column
+            HIP_TRY(h, hipMalloc((void **)&h->d_ltrig, sl * nm * 4 * sizeof(float)));
+            HIP_TRY(h, hipMalloc((void **)&h->d_lcell_count, sl * (ncell + 1) * sizeof(uint32_t)));
+            HIP_TRY(h, hipMalloc((void **)&h->d_lcell_fill, sl * ncell * sizeof(uint32_t)));
         }
         HIP_TRY(h, hipMalloc((void **)&h->d_adist, sizeof(float) * (p.n_mol_total ? p.n_mol_total : 1)));
     }
@@ -830,8 +833,8 @@ static int run_leaflets(gorder_hip_handle *h, const float *d_xyz, const float *d
         lo.radius_thr = local_radius_threshold(lf.radius);
         lo.cell_of = h->d_lcell_of; lo.trig = h->d_ltrig; lo.cell_count = h->d_lcell_count;
         lo.cell_fill = h->d_lcell_fill; lo.rsn = reinterpret_cast<float *>(h->d_lcell_atoms); lo.err = h->d_err;
-        for (size_t done = 0; done < aframes.size(); done += kLocalSlab) {
-            const uint32_t ns = (uint32_t)std::min<size_t>(aframes.size() - done, kLocalSlab);
+        for (size_t done = 0; done < aframes.size(); done += h->local_slab) {
+            const uint32_t ns = (uint32_t)std::min<size_t>(aframes.size() - done, h->local_slab);
             lo.aframes = h->d_aframes + done;
             lo.n_slab = ns;
             lo.row0 = row0 + (uint32_t)done;

@@ -436,7 +436,14 @@ __global__ __launch_bounds__(256) void k_leaflets_individual(LeafletArgs a) {
 //   k_local_scatter : per (slab frame, membrane atom): cell-ordered record (coordinates + cos/sin)
 //   k_local_flags   : one wave per (slab frame, head): two passes over the 3x3 neighbour cells
 constexpr uint32_t kLocalMaxCells1D = 128;
-constexpr uint32_t kLocalSlab = 32;   // assignment frames processed per launch group
+// assignment frames processed per launch group: as many as fit 256 MiB of cell-list scratch, at most 128 (a
+// 36 864-bead membrane gains 10 % from 32 -> 128 frames, nothing beyond: the small binning kernels get amortised)
+constexpr uint32_t kLocalSlabMax = 128;
+inline uint32_t local_slab_frames(size_t n_membrane) {
+    const size_t per_frame = n_membrane * 24u + (size_t)2 * kLocalMaxCells1D * kLocalMaxCells1D * 4u + 8u;
+    const size_t n = ((size_t)256 << 20) / per_frame;
+    return (uint32_t)(n < 4 ? 4 : (n > kLocalSlabMax ? kLocalSlabMax : n));
+}
 
 struct LocalArgs {
     const float *xyz;
