@@ -199,6 +199,37 @@ __device__ __forceinline__ float gm_calc_sch(float vx, float vy, float vz, float
     }
 }
 
+// The streaming kernel's sample for a static normal along a coordinate axis: S = 1.5 vz^2 / |v|^2 - 0.5 — the same
+// operations as gm_calc_sch<false, AXIS>, minus what cannot matter inside the guarded range:
+//  * the quotient cannot exceed 1 (s2 = fl(fl(x^2 + y^2) + z^2) >= z^2 by monotonic rounding), so no clamp;
+//  * |v|^2 outside [2^-40, 2^40] (this includes 0, inf and NaN) raises `rare` and the caller recomputes the sample
+//    with the general routine;
+//  * inside that range v_div_scale_f32 / v_div_fixup_f32 of the compiler's IEEE division are the identity except for
+//    a numerator below 2^-103 (then the quotient is below 2^-63 and S is -0.5 whatever its last bit), so the
+//    division is its Newton core alone: the same eight operations in the same order, three instructions less.
+__device__ __forceinline__ float gm_div_core(float n, float d) {
+    float r = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    float q = n * r;
+    const float e2 = __builtin_fmaf(-d, q, n);
+    q = __builtin_fmaf(e2, r, q);
+    const float e3 = __builtin_fmaf(-d, q, n);
+    return __builtin_fmaf(e3, r, q);
+}
+template <int AXIS>
+__device__ __forceinline__ float gm_sch_axis(float vx, float vy, float vz, bool &rare) {
+    const float s2 = (vx * vx + vy * vy) + vz * vz;
+    const float prod = AXIS == 0 ? vx : (AXIS == 1 ? vy : vz);
+    rare = rare || !(s2 >= 0x1p-40f && s2 <= 0x1p+40f);
+    return (1.5f * gm_div_core(prod * prod, s2)) - 0.5f;
+}
+// gm_tick for a sample that is known not to be NaN (the caller's rare path takes those)
+__device__ __forceinline__ int gm_tick_finite(float s) {
+    const double t = (double)s * 1000000.0;
+    return (int)(t + __builtin_copysign(0.5, t));
+}
+
 // round(f64(S) * 1e6) as i64 (order.rs:21-26) — S is in [-0.5, 1] or NaN here, so the tick fits 32 bits.
 // f64::round is half-away-from-zero; NaN -> 0 (Rust `as i64`).
 // t = S * 1e6 is exact in f64 (24-bit x 20-bit significands), has <= 38 significant bits and

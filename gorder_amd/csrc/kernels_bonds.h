@@ -129,10 +129,16 @@ struct TiledStage {
                 vy = gm_min_image_step(vy, by[k], slow);
                 vz = gm_min_image_step(vz, bz[k], slow);
             }
-            bool nonfinite = false;
-            const float sch = gm_calc_sch<ACOS_COS, AXIS>(vx, vy, vz, a.nx, a.ny, a.nz, a.n2, a.n2sq, &nonfinite);
-            rare |= ((slow || nonfinite || sch != sch) ? 1u : 0u) << k;
-            tick[k] = gm_tick(sch);
+            if (AXIS >= 0 && !ACOS_COS) {     // the headline case: static normal along an axis
+                const float sch = gm_sch_axis<AXIS>(vx, vy, vz, slow);
+                rare |= (slow ? 1u : 0u) << k;
+                tick[k] = gm_tick_finite(sch);
+            } else {
+                bool nonfinite = false;
+                const float sch = gm_calc_sch<ACOS_COS, AXIS>(vx, vy, vz, a.nx, a.ny, a.nz, a.n2, a.n2sq, &nonfinite);
+                rare |= ((slow || nonfinite || sch != sch) ? 1u : 0u) << k;
+                tick[k] = gm_tick(sch);
+            }
         }
         if (__builtin_expect(rare != 0, 0)) {
 #pragma unroll
