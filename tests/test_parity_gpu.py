@@ -234,6 +234,46 @@ def test_edge_cases(built):
     assert_parity(system, xyz, system.box9(3))
 
 
+def test_bond_vectors_at_the_edges_of_the_fast_division(built):
+    """K1 divides vz^2 by |v|^2 with the Newton core of the IEEE division while |v|^2 lies in [2^-40, 2^40] and falls
+    back to the full routine outside (gm_sch_axis): bonds of every magnitude around both guards, along and across
+    the normal, tiny and denormal numerators — all bit-exact against the oracle's plain `/`.
+    (Against the reference-faithful libm mode only where the squared form has the range: the default arithmetic
+    squares the bond vector, so below |v| ~ 1e-19 nm or above ~ 1e19 nm — |v|^2 denormal or infinite — it is not
+    the reference's acos/cos of v.n / (|v| |n|) any more; FLAG_TRIG_ACOS_COS is.)"""
+    rng = np.random.default_rng(11)
+
+    def stretch(system, xyz, lengths):
+        pairs = np.asarray(system.tables.molecule_types[0].bonds).reshape(-1, 2)
+        for f in range(xyz.shape[0]):
+            for q, (i, j) in enumerate(pairs[rng.permutation(len(pairs))[:400]]):
+                u = rng.normal(size=3)
+                u /= np.linalg.norm(u)
+                if q % 7 == 0:
+                    u = np.array([0.0, 0.0, 1.0])                 # along the normal: quotient exactly 1
+                if q % 7 == 1:
+                    u = np.array([1.0, 0.0, 1e-20]); u /= np.linalg.norm(u)   # numerator far below 2^-103
+                if q % 7 == 2:
+                    u = np.array([0.6, 0.8, 0.0])                 # numerator 0
+                xyz[f, j] = xyz[f, i] + (np.float32(lengths[q % len(lengths)]) * u).astype(np.float32)
+        return xyz
+
+    def exact(system, xyz, box):
+        _, got = run_gpu(system, xyz, box)
+        _, want = run_oracle(system, xyz, box)
+        np.testing.assert_array_equal(got.counts, want.counts)
+        np.testing.assert_array_equal(got.sums, want.sums)
+
+    system = synthetic.aa_membrane(16)
+    around_lower = [2.0 ** -21, 2.0 ** -20 * 0.999, 2.0 ** -20, 2.0 ** -20 * 1.001, 1e-5, 1e-3, 0.1]
+    assert_parity(system, stretch(system, system.frames(8, seed=5), around_lower), system.box9(8))
+    exact(system, stretch(system, system.frames(8, seed=5), [0.0, 1e-30, 1e-20, 1e-12] + around_lower), system.box9(8))
+    nopbc = synthetic.aa_membrane(16, handle_pbc=False)       # far bonds need no periodic image
+    around_upper = [2.0 ** 19, 2.0 ** 20 * 0.999, 2.0 ** 20, 2.0 ** 20 * 1.001, 1e10]
+    assert_parity(nopbc, stretch(nopbc, nopbc.frames(2, seed=6), around_upper), None)
+    exact(nopbc, stretch(nopbc, nopbc.frames(2, seed=6), around_upper + [1e19, 1e25]), None)
+
+
 def test_errors_mirror_the_reference(built):
     torch = torch_cuda()
     system = synthetic.cg_membrane(20)
