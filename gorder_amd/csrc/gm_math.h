@@ -217,6 +217,16 @@ __device__ __forceinline__ float gm_div_core(float n, float d) {
     const float e3 = __builtin_fmaf(-d, q, n);
     return __builtin_fmaf(e3, r, q);
 }
+// The same idea for the correctly rounded square root: for x in [2^-40, 2^40] the compiler's sequence needs neither
+// its denormal pre-scaling nor the class fix-up — v_sqrt_f32 (1 ulp) and the two-sided correction are what remains.
+__device__ __forceinline__ float gm_sqrt_core(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __int_as_float(__float_as_int(s) - 1), sp = __int_as_float(__float_as_int(s) + 1);
+    const float rm = __builtin_fmaf(-sm, s, x), rp = __builtin_fmaf(-sp, s, x);
+    float r = rm <= 0.0f ? sm : s;
+    r = rp > 0.0f ? sp : r;
+    return r;
+}
 template <int AXIS>
 __device__ __forceinline__ float gm_sch_axis(float vx, float vy, float vz, bool &rare) {
     const float s2 = (vx * vx + vy * vy) + vz * vz;

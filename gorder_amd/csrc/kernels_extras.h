@@ -306,6 +306,22 @@ struct PbcStep {
         slow = slow || (r > L) || (r < 0.0f);
         return r;
     }
+    // a / |a| with the cores of the IEEE square root and division (gm_sqrt_core, gm_div_core) and ONE reciprocal
+    // refinement for the three quotients: the same bits as v3_unit while |a|^2 lies in [2^-40, 2^40] (a component
+    // below 2^-103 aside, which no coordinate difference produces); anything else raises `slow`.
+    __device__ __forceinline__ V3 unit(V3 a) {
+        const float s2 = (a.x * a.x + a.y * a.y) + a.z * a.z;
+        slow = slow || !(s2 >= 0x1p-40f && s2 <= 0x1p+40f);
+        const float n = gm_sqrt_core(s2);
+        float r = __builtin_amdgcn_rcpf(n);
+        r = __builtin_fmaf(__builtin_fmaf(-n, r, 1.0f), r, r);
+        auto quot = [&](float c) {
+            float q = c * r;
+            q = __builtin_fmaf(__builtin_fmaf(-n, q, c), r, q);
+            return __builtin_fmaf(__builtin_fmaf(-n, q, c), r, q);
+        };
+        return {quot(a.x), quot(a.y), quot(a.z)};
+    }
 };
 struct PbcLoop {
     V3 box;
@@ -315,6 +331,7 @@ struct PbcLoop {
     __device__ __forceinline__ float len(int k) const { return k == 0 ? box.x : (k == 1 ? box.y : box.z); }
     __device__ __forceinline__ float mi(float d, int k) { return pbc ? gm_min_image_loop(d, len(k), bad) : d; }
     __device__ __forceinline__ float wr(float x, int k) { return pbc ? gm_wrap(x, len(k), bad) : x; }
+    __device__ __forceinline__ V3 unit(V3 a) { return v3_unit(a); }
 };
 template <typename PB>
 __device__ __forceinline__ V3 v3_to(V3 p1, V3 p2, PB &pb) {
@@ -322,7 +339,7 @@ __device__ __forceinline__ V3 v3_to(V3 p1, V3 p2, PB &pb) {
 }
 template <typename PB>
 __device__ __forceinline__ V3 v3_shift_wrap(V3 t, V3 dir, PB &pb) {
-    const V3 u = v3_unit(dir);
+    const V3 u = pb.unit(dir);
     return {pb.wr(t.x + u.x * 0.109f, 0), pb.wr(t.y + u.y * 0.109f, 1), pb.wr(t.z + u.z * 0.109f, 2)};   // BOND_LENGTH
 }
 
@@ -345,18 +362,18 @@ __device__ __forceinline__ UaBonds ua_carbon(uint32_t kind, UaCarbon c, UaConsts
     V3 h0 = zero, h1 = zero, h2 = zero, target = c.p1;
     if (kind == GORDER_UA_CH3) {            // uaorder.rs:947-981
         const V3 th1 = v3_to(target, c.p0, pb), th2 = v3_to(target, c.p2, pb);
-        const V3 ua = v3_unit(v3_cross(th2, th1));
+        const V3 ua = pb.unit(v3_cross(th2, th1));
         const V3 hv1 = v3_rotate(ua, e.sin_tet, e.cos_tet, th1);
         h0 = v3_shift_wrap(target, hv1, pb);
-        const V3 n1 = v3_unit(th1);
+        const V3 n1 = pb.unit(th1);
         h1 = v3_shift_wrap(target, v3_rotate(n1, e.sin_ch3, e.cos_ch3, hv1), pb);
         h2 = v3_shift_wrap(target, v3_rotate(n1, -e.sin_ch3, e.cos_ch3, hv1), pb);
     } else if (kind == GORDER_UA_CH2) {     // uaorder.rs:985-1020
-        const V3 th1 = v3_unit(v3_to(target, c.p0, pb)), th2 = v3_unit(v3_to(target, c.p2, pb));
+        const V3 th1 = pb.unit(v3_to(target, c.p0, pb)), th2 = pb.unit(v3_to(target, c.p2, pb));
         const V3 pn = v3_cross(th2, th1);
-        const V3 ra = v3_unit(V3{th1.x - th2.x, th1.y - th2.y, th1.z - th2.z});
+        const V3 ra = pb.unit(V3{th1.x - th2.x, th1.y - th2.y, th1.z - th2.z});
         const V3 rv = v3_cross(pn, ra);
-        const V3 ura = v3_unit(ra);
+        const V3 ura = pb.unit(ra);
         h0 = v3_shift_wrap(target, v3_rotate(ura, e.sin_half, e.cos_half, rv), pb);
         h1 = v3_shift_wrap(target, v3_rotate(ura, -e.sin_half, e.cos_half, rv), pb);
     } else if (kind == GORDER_UA_CH1_UNSAT) {   // uaorder.rs:1024-1045
@@ -372,12 +389,12 @@ __device__ __forceinline__ UaBonds ua_carbon(uint32_t kind, UaCarbon c, UaConsts
         const float ang = 3.14159265358979323846f - (gamma / 2.0f);
         float sn, cs;
         sincosf(ang, &sn, &cs);
-        const V3 ua = v3_unit(v3_cross(th1, th2));
+        const V3 ua = pb.unit(v3_cross(th1, th2));
         h0 = v3_shift_wrap(target, ang == 0.0f ? th2 : v3_rotate(ua, sn, cs, th2), pb);
     } else {                                // CH1 saturated, uaorder.rs:1087-1104 (h1, h2, h3, target)
         target = c.p3;
-        const V3 t1 = v3_unit(v3_to(target, c.p0, pb)), t2 = v3_unit(v3_to(target, c.p1, pb)),
-                 t3 = v3_unit(v3_to(target, c.p2, pb));
+        const V3 t1 = pb.unit(v3_to(target, c.p0, pb)), t2 = pb.unit(v3_to(target, c.p1, pb)),
+                 t3 = pb.unit(v3_to(target, c.p2, pb));
         h0 = v3_shift_wrap(target, V3{-((t1.x + t2.x) + t3.x), -((t1.y + t2.y) + t3.y), -((t1.z + t2.z) + t3.z)}, pb);
     }
     UaBonds r;
