@@ -32,37 +32,50 @@ const int kMagicInts[] = {
 constexpr int kFirstIdx = 9;
 constexpr int kLastIdx = (int)(sizeof(kMagicInts) / sizeof(kMagicInts[0]));
 
+// The compressed block is one MSB-first bit stream.  The reader keeps an absolute bit position and takes up to 57
+// bits at a time from one unaligned big-endian 64-bit load (the caller pads the block with 8 zero bytes).
 struct BitReader {
     const uint8_t *p;
-    size_t n, pos = 0;        // byte position
-    uint32_t lastbits = 0;    // bits left over in lastbyte
-    uint32_t lastbyte = 0;
+    size_t n, bitpos = 0;
     bool overrun = false;
 
-    uint32_t bits(int nbits) {
-        const uint32_t mask = nbits >= 32 ? 0xffffffffu : ((1u << nbits) - 1u);
-        uint32_t num = 0;
-        while (nbits >= 8) {
-            lastbyte = (lastbyte << 8) | next();
-            num |= (lastbyte >> lastbits) << (nbits - 8);
-            nbits -= 8;
-        }
-        if (nbits > 0) {
-            if ((int)lastbits < nbits) {
-                lastbits += 8;
-                lastbyte = (lastbyte << 8) | next();
-            }
-            lastbits -= (uint32_t)nbits;
-            num |= (lastbyte >> lastbits) & ((1u << nbits) - 1u);
-        }
-        return num & mask;
+    static uint64_t load_be64(const uint8_t *q) {
+        uint64_t w;
+        memcpy(&w, q, 8);
+        return __builtin_bswap64(w);
     }
-    uint32_t next() {
-        if (pos >= n) { overrun = true; return 0; }
-        return p[pos++];
+    uint64_t bits57(int nbits) {      // 0 <= nbits <= 57
+        if (nbits == 0) return 0;
+        const size_t byte = bitpos >> 3;
+        if (byte >= n) { overrun = true; return 0; }    // n bytes of payload + 8 bytes of padding are readable
+        const uint64_t w = load_be64(p + byte) << (bitpos & 7u);
+        bitpos += (size_t)nbits;
+        return w >> (64 - nbits);
     }
-    // three integers packed as one mixed-radix number of `nbits` bits with radices sizes[0..2]
+    uint32_t bits(int nbits) { return (uint32_t)bits57(nbits); }          // nbits <= 32
+    // three integers packed as one mixed-radix number of `nbits` bits with radices sizes[0..2].  The number is
+    // stored in chunks of 8 bits, FIRST chunk least significant (the last, partial chunk is the top): for up to 64
+    // bits that is a byte swap of the stream bits, then two 64-bit divisions; wider numbers (boxes beyond ~2 million
+    // grid steps per edge) take the byte-wise long division of the original algorithm.
     void ints(int nbits, const uint32_t sizes[3], int out[3]) {
+        if (nbits <= 64) {
+            const int m = (nbits - 1) / 8, rem = nbits - 8 * m;      // m full chunks, then `rem` (1..8) bits
+            uint64_t v = 0;
+            if (m > 0) {
+                // the m leading bytes of the stream, first byte lowest
+                const int lo_bits = 8 * m;
+                uint64_t w = lo_bits <= 57 ? bits57(lo_bits) : ((bits57(32) << (lo_bits - 32)) | bits57(lo_bits - 32));
+                v = __builtin_bswap64(w << (64 - lo_bits));
+            }
+            v |= bits57(rem) << (8 * m);
+            const uint64_t s2 = sizes[2], s1 = sizes[1];
+            const uint64_t q2 = v / s2;
+            out[2] = (int)(v - q2 * s2);
+            const uint64_t q1 = q2 / s1;
+            out[1] = (int)(q2 - q1 * s1);
+            out[0] = (int)(uint32_t)q1;
+            return;
+        }
         uint32_t bytes[32];
         bytes[1] = bytes[2] = bytes[3] = 0;
         int nbytes = 0;
@@ -236,6 +249,7 @@ int decode_ints(gorder_xtc_reader *r, const int minint[3], const int maxint[3], 
         sizesmall[0] = sizesmall[1] = sizesmall[2] = (uint32_t)kMagicInts[smallidx];
         if (br.overrun) return GORDER_XTC_ERR_FORMAT;
     }
+    if (br.bitpos > 8 * nbytes) return GORDER_XTC_ERR_FORMAT;     // read into the padding: truncated block
     return GORDER_XTC_OK;
 }
 
