@@ -52,6 +52,16 @@ __device__ __forceinline__ float gm_min_image_step(float dx, float L, bool &slow
     return r;
 }
 
+// |gm_min_image_step(dx)| for callers that only square the component (gm_sch_axis): dx - copysign(L, dx) is
+// -(L - |dx|) or +(L - |dx|), so its magnitude is |L - |dx|| bit for bit — a subtraction and a select instead of a
+// copysign, a subtraction and a select.  Same `slow` condition.
+__device__ __forceinline__ float gm_min_image_step_abs(float dx, float L, bool &slow) {
+    const float half = L / 2.0f, a = __builtin_fabsf(dx);
+    const float m = a > half ? L - a : a;
+    slow = slow || (__builtin_fabsf(m) > half);
+    return m;
+}
+
 __device__ __forceinline__ float gm_min_image(float dx, float L, int &bad) {
     bool slow = false;
     const float r = gm_min_image_step(dx, L, slow);

@@ -124,7 +124,11 @@ struct TiledStage {
         for (int k = 0; k < NF; k++) {
             float vx = P[k][3] - P[k][0], vy = P[k][4] - P[k][1], vz = P[k][5] - P[k][2];
             bool slow = false;
-            if (PBC) {
+            if (PBC && AXIS >= 0 && !ACOS_COS) {     // only squares are taken below: magnitudes are enough
+                vx = gm_min_image_step_abs(vx, bx[k], slow);
+                vy = gm_min_image_step_abs(vy, by[k], slow);
+                vz = gm_min_image_step_abs(vz, bz[k], slow);
+            } else if (PBC) {
                 vx = gm_min_image_step(vx, bx[k], slow);
                 vy = gm_min_image_step(vy, by[k], slow);
                 vz = gm_min_image_step(vz, bz[k], slow);
