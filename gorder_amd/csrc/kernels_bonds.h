@@ -124,10 +124,16 @@ struct TiledStage {
         for (int k = 0; k < NF; k++) {
             float vx = P[k][3] - P[k][0], vy = P[k][4] - P[k][1], vz = P[k][5] - P[k][2];
             bool slow = false;
-            if (PBC && AXIS >= 0 && !ACOS_COS) {     // only squares are taken below: magnitudes are enough
-                vx = gm_min_image_step_abs(vx, bx[k], slow);
-                vy = gm_min_image_step_abs(vy, by[k], slow);
-                vz = gm_min_image_step_abs(vz, bz[k], slow);
+            if (PBC && AXIS >= 0 && !ACOS_COS) {
+                // only squares are taken below, so magnitudes are enough: |dx - copysign(L, dx)| = |L - |dx|| bit for
+                // bit.  One shift suffices while |dx| <= L (then L - |dx| >= 0 and <= L/2): a negative L - |dx| in any
+                // dimension sends the sample to the literal loops (a superset of gm_min_image_step's `slow`).
+                const float ax = __builtin_fabsf(vx), ay = __builtin_fabsf(vy), az = __builtin_fabsf(vz);
+                const float tx = bx[k] - ax, ty = by[k] - ay, tz = bz[k] - az;
+                vx = ax > bx[k] / 2.0f ? tx : ax;
+                vy = ay > by[k] / 2.0f ? ty : ay;
+                vz = az > bz[k] / 2.0f ? tz : az;
+                slow = __builtin_fminf(__builtin_fminf(tx, ty), tz) < 0.0f;
             } else if (PBC) {
                 vx = gm_min_image_step(vx, bx[k], slow);
                 vy = gm_min_image_step(vy, by[k], slow);
