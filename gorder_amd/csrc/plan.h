@@ -57,7 +57,7 @@ struct Plan {
     std::vector<uint32_t> tile_slots;
     std::vector<DirectItem> direct;
     // united-atom carbons: same tiling idea, separate item type; no direct fallback (the 3-4 atoms of one
-    // carbon are bonded neighbours — a tuple wider than kMaxWindow atoms is rejected)
+    // carbon are bonded neighbours — a tuple wider than 16-bit offsets reach is rejected)
     std::vector<Tile> ua_tiles;
     std::vector<UaItem> ua_items;
     std::vector<uint32_t> ua_tile_slots;
@@ -129,31 +129,24 @@ inline int build_plan(const gorder_tables_t &t, bool force_direct, Plan &p) {
             if (ulo(x) != ulo(y)) return ulo(x) < ulo(y);
             return uhi(x) < uhi(y);
         });
-        size_t q = 0;
         std::vector<std::pair<uint32_t, MapRun>> run_of_slot;
-        while (q < ua_samples.size()) {
-            const UaSample &first = ua_samples[q];
-            if (uhi(first) - ulo(first) + 1 > kMaxWindow) return GORDER_ERR_INVALID_ARGUMENT;
+        // One tile = kBlock consecutive samples of [b, e), which the caller has put into lane order.
+        auto emit_tile = [&](size_t b, size_t e) {
             Tile tile{};
-            tile.atom0 = ulo(first);
+            tile.atom0 = ulo(ua_samples[b]);
+            uint32_t top = 0;
+            for (size_t i = b; i < e; i++) { tile.atom0 = std::min(tile.atom0, ulo(ua_samples[i])); top = std::max(top, uhi(ua_samples[i])); }
             tile.item0 = (uint32_t)p.ua_items.size();
             tile.slot0 = (uint32_t)p.ua_tile_slots.size();
-            uint32_t top = uhi(first);
             std::vector<uint32_t> slots;   // local slot list holds the FIRST slot of each carbon; 3 entries reserved
-            while (q < ua_samples.size() && tile.n_items < kBlock) {
-                const UaSample &u = ua_samples[q];
-                if (uhi(u) - ulo(u) + 1 > kMaxWindow) return GORDER_ERR_INVALID_ARGUMENT;
-                const uint32_t ntop = std::max(top, uhi(u));
-                if (ntop - tile.atom0 + 1 > kMaxWindow) break;
-                top = ntop;
+            for (size_t i = b; i < e; i++) {
+                const UaSample &u = ua_samples[i];
                 const uint32_t nh = u.kind == GORDER_UA_CH3 ? 3 : u.kind == GORDER_UA_CH2 ? 2 : 1;
                 uint32_t ls = 0;
                 for (; ls < slots.size(); ls++)
                     if (slots[ls] == u.slot0) break;
-                if (ls == slots.size()) {
-                    if (slots.size() + nh > 3 * kBlock) break;
+                if (ls == slots.size())
                     for (uint32_t h = 0; h < nh; h++) slots.push_back(u.slot0 + h);
-                }
                 UaItem it{};
                 for (int c = 0; c < 4; c++) it.l[c] = (uint16_t)(u.a[c] - tile.atom0);
                 it.lslot0 = (uint16_t)ls;
@@ -161,18 +154,11 @@ inline int build_plan(const gorder_tables_t &t, bool force_direct, Plan &p) {
                 it.mol = u.mol;
                 p.ua_items.push_back(it);
                 tile.n_items++;
-                q++;
             }
             tile.n_window = top - tile.atom0 + 1;
             tile.n_slots = (uint32_t)slots.size();
-            // carbons of one kind next to each other (the lanes of a wave then run the same construction), and
-            // within a kind the molecules of one slot next to each other (the staged ordermap samples of a slot
-            // are then contiguous runs, see MapRun)
-            std::stable_sort(p.ua_items.begin() + tile.item0, p.ua_items.end(), [](const UaItem &x, const UaItem &y) {
-                return x.kind != y.kind ? x.kind < y.kind : x.lslot0 < y.lslot0;
-            });
             const uint32_t tile_id = (uint32_t)p.ua_tiles.size();
-            for (uint32_t i = 0; i < tile.n_items;) {
+            for (uint32_t i = 0; i < tile.n_items;) {   // the lanes of one slot: a MapRun per hydrogen
                 const UaItem &it = p.ua_items[tile.item0 + i];
                 uint32_t n = 1;
                 while (i + n < tile.n_items && p.ua_items[tile.item0 + i + n].lslot0 == it.lslot0) n++;
@@ -184,6 +170,37 @@ inline int build_plan(const gorder_tables_t &t, bool force_direct, Plan &p) {
             }
             p.ua_tile_slots.insert(p.ua_tile_slots.end(), slots.begin(), slots.end());
             p.ua_tiles.push_back(tile);
+        };
+        // Tiles are cut from GROUPS of up to 64 molecules (consecutive in atom order): inside a group the carbons go
+        // by (kind, slot, molecule), so a wave of 64 lanes holds one kind of carbon — the hydrogen construction
+        // branches on the kind, and a wave that mixes methyl, methylene and methine carbons runs all three — and
+        // mostly one slot (long MapRuns for the staged ordermap samples).  The window of a tile is then the group's
+        // atoms (the kernel gathers through L1 / L2; offsets are 16-bit).
+        constexpr uint32_t kUaMaxWindow = 60000, kUaGroupMolecules = 64;
+        size_t q = 0;
+        while (q < ua_samples.size()) {
+            uint32_t span = kUaGroupMolecules;
+            size_t e = q;
+            for (;;) {
+                const uint32_t mol0 = ua_samples[q].mol;
+                uint32_t lo_atom = ulo(ua_samples[q]), hi_atom = uhi(ua_samples[q]);
+                for (e = q; e < ua_samples.size(); e++) {
+                    const UaSample &u = ua_samples[e];
+                    if (u.mol < mol0 || u.mol - mol0 >= span) break;
+                    lo_atom = std::min(lo_atom, ulo(u));
+                    hi_atom = std::max(hi_atom, uhi(u));
+                }
+                if (hi_atom - lo_atom + 1 <= kUaMaxWindow) break;
+                if (span == 1) return GORDER_ERR_INVALID_ARGUMENT;      // one molecule wider than 16-bit offsets reach
+                span /= 2;
+            }
+            std::stable_sort(ua_samples.begin() + q, ua_samples.begin() + e, [](const UaSample &x, const UaSample &y) {
+                if (x.kind != y.kind) return x.kind < y.kind;
+                if (x.slot0 != y.slot0) return x.slot0 < y.slot0;
+                return x.mol < y.mol;
+            });
+            for (size_t b = q; b < e; b += kBlock) emit_tile(b, std::min(e, b + kBlock));
+            q = e;
         }
         std::stable_sort(run_of_slot.begin(), run_of_slot.end(),
                          [](const std::pair<uint32_t, MapRun> &x, const std::pair<uint32_t, MapRun> &y) { return x.first < y.first; });
