@@ -583,14 +583,18 @@ __global__ __launch_bounds__(1024) void k_map_accumulate(const unsigned long lon
     const uint32_t f0 = chunk * frames_per_chunk, f1 = min(rec_frames, f0 + frames_per_chunk);
     for (uint32_t w = threadIdx.x; w < n_words; w += blockDim.x) l_map[w] = 0ull;
     __syncthreads();
-    // one wave per run at a time
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, n_waves = blockDim.x >> 6;
-    for (uint32_t r = r0 + wave; r < r1; r += n_waves) {
+    // many short runs (bond tiles, small united-atom groups): one wave per run at a time; few long ones: the whole
+    // block strides over each run
+    const uint32_t n_waves = blockDim.x >> 6;
+    const bool per_wave = r1 - r0 >= n_waves;
+    const uint32_t r_first = r0 + (per_wave ? threadIdx.x >> 6 : 0u), r_step = per_wave ? n_waves : 1u;
+    const uint32_t i_first = per_wave ? threadIdx.x & 63u : threadIdx.x, i_step = per_wave ? 64u : blockDim.x;
+    for (uint32_t r = r_first; r < r1; r += r_step) {
         const gorder::MapRun run = runs[r];
         if (k_max == 1u) {     // bond tiles: per block of kRecFrames frames one piece of kRecFrames * n words
             const uint32_t pl = kRecFrames * run.n, fb0 = f0 / kRecFrames, fb1 = (f1 + kRecFrames - 1) / kRecFrames;
             const unsigned long long *tile = rec + (size_t)run.tile * kBlock * rec_stride + kRecFrames * run.tid0;
-            for (uint32_t i = lane; i < (fb1 - fb0) * pl; i += 64u) {
+            for (uint32_t i = i_first; i < (fb1 - fb0) * pl; i += i_step) {
                 const uint32_t b = i / pl;
                 const unsigned long long v = tile[(size_t)(fb0 + b) * (kRecFrames * kBlock) + (i - b * pl)];
                 if (v != kMapNoSample)
@@ -599,7 +603,7 @@ __global__ __launch_bounds__(1024) void k_map_accumulate(const unsigned long lon
         } else {               // united-atom tiles: the run's words of the frames [f0, f1) are one contiguous piece
             const uint32_t total = (f1 - f0) * run.n;
             const unsigned long long *piece = rec + (((size_t)run.tile * k_max + run.k) * kBlock + run.tid0) * rec_stride + (size_t)f0 * run.n;
-            for (uint32_t i = lane; i < total; i += 64u) {
+            for (uint32_t i = i_first; i < total; i += i_step) {
                 const unsigned long long v = piece[i];
                 if (v != kMapNoSample)
                     atomicAdd(&l_map[(uint32_t)(v >> 32)], kMapOne + (unsigned long long)(long long)(int)(uint32_t)v);
