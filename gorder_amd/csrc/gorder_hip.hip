@@ -394,7 +394,7 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
                 e.item_run = pass == 0 ? h->d_item_run : h->d_ua_item_run;
                 e.rec_frame0 = lo;
                 e.rec_stride = (nf + 15u) / 16u * 16u;
-                const dim3 g(nt * n_chunks), blk(kBlock);
+                const dim3 g(pass == 0 ? nt * n_chunks : (nt * n_chunks + 7u) / 8u * 8u), blk(kBlock);   // united atoms: see the XCD mapping in k_ua_extras
                 if (pass == 0) {
                     const Item *items = staged ? h->d_items_by_slot : h->d_items;
 #define GORDER_LAUNCH_BONDS(AC, MO)                                                                               \

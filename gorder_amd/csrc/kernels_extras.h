@@ -437,7 +437,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     __shared__ uint32_t l_twn[GENERAL ? 3 * LS : 1];
     FrameArgs a = a_in;
     a.xyz = xyz; a.box9 = box9; a.aflags = aflags; a.arow = arow;
-    const uint32_t tile_id = blockIdx.x % n_tiles, chunk = blockIdx.x / n_tiles;
+    // Workgroups go to the 8 XCDs round-robin; the tiles of one molecule group share their atoms, so each XCD takes a
+    // contiguous range of (chunk, tile) pairs — a group's tiles then run next to each other behind ONE L2.
+    // (The host pads the grid to a multiple of 8.)
+    const uint32_t per_xcd = gridDim.x / 8u, work = (blockIdx.x % 8u) * per_xcd + blockIdx.x / 8u;
+    const uint32_t tile_id = work % n_tiles, chunk = work / n_tiles;
+    if ((size_t)chunk * a_in.frames_per_chunk >= a_in.n_frames - a_in.frame0) return;    // padding workgroup
     const Tile t = tiles[tile_id];
     const uint32_t tid = threadIdx.x;
     const bool active = tid < t.n_items;
