@@ -763,7 +763,53 @@ __global__ __launch_bounds__(256) void k_local_flags(LocalArgs a) {
             }
         }
     };
-    if (flat) {
+    // The common case — periodic box, <= 4096 candidates, every displacement within one box length — without a branch
+    // per candidate: the in-plane test only squares its components, so magnitudes do (|dx - copysign(L, dx)| =
+    // |L - |dx|| bit for bit), membership becomes a select mask, and whatever would need the literal image loops is
+    // only FLAGGED; if any lane raised the flag the sums are thrown away and the general code below runs instead.
+    bool done = false;
+    if (flat && pbc) {
+        const float halfa = La / 2.0f, halfb = Lb / 2.0f, halfn = Ln / 2.0f;
+        bool redo = false;
+        for (uint32_t it0 = 0; it0 < n_it; it0 += 4u) {
+            float4 r[4];
+            float sn[4];
+            bool v[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; u++) {
+                const uint32_t iter = min(it0 + u, 63u);
+                const uint32_t q = (uint32_t)__builtin_amdgcn_readlane((int)it_base, (int)iter) + lane;
+                v[u] = q < (uint32_t)__builtin_amdgcn_readlane((int)it_end, (int)iter);   // lanes >= n_it hold 0: never
+                const uint32_t qc = v[u] ? q : 0u;
+                r[u] = rec[qc];
+                sn[u] = rsn[qc];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; u++) {
+                const float ea = __builtin_fabsf(r[u].x - ha_pos), eb = __builtin_fabsf(r[u].y - hb_pos);
+                const float ta = La - ea, tb = Lb - eb;
+                const float ma = ea > halfa ? ta : ea, mb = eb > halfb ? tb : eb;
+                const bool in = v[u] & (ma * ma + mb * mb < thr);            // `&`, `|`: no short-circuit branches
+                redo |= v[u] & ((ta < 0.0f) | (tb < 0.0f));
+                if (in) {      // one branch per candidate: a wave whose 64 candidates all lie outside skips the rest
+                    const float dz = r[u].z - hn_pos;
+                    const float uz = __builtin_fabsf(dz) > halfn ? dz - __builtin_copysignf(Ln, dz) : dz;
+                    redo |= __builtin_fabsf(uz) > halfn;
+                    cnt += 1u;
+                    nf |= (r[u].z - r[u].z == 0.0f) ? 0u : 1u;
+                    sc += r[u].w;
+                    ss += sn[u];
+                    su += uz;
+                    ulo = __builtin_fminf(ulo, uz);
+                    uhi = __builtin_fmaxf(uhi, uz);
+                }
+            }
+        }
+        done = !__any(redo);
+        if (!done) { sc = ss = sp = su = 0.0f; ulo = 3.0e38f; uhi = -3.0e38f; cnt = 0; nf = 0; }
+    }
+    if (done) {
+    } else if (flat) {
         for (uint32_t it0 = 0; it0 < n_it; it0 += 4u) {
             float4 r[4];
             float sn[4];
