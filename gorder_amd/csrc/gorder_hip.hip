@@ -72,6 +72,7 @@ struct gorder_hip_handle {
     uint32_t *d_ua_run_begin = nullptr, *d_run_begin = nullptr;
     Item *d_items_by_slot = nullptr;
     uint32_t *d_item_run = nullptr, *d_ua_item_run = nullptr;
+    uint4 *d_lgrid = nullptr;       // per slab frame: the cell grid of the local-leaflet kernels
     bool map_staged = false;       // the packed map of one slot fits LDS: stage + accumulate instead of one atomic per sample
     uint64_t map_pending = 0;      // upper bound of the samples one packed word may hold since the last fold
     uint64_t map_fold_limit = kMapFoldLimit;   // GORDER_HIP_MAP_FOLD_LIMIT lowers it (tests)
@@ -726,6 +727,7 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
             HIP_TRY(h, hipMalloc((void **)&h->d_ltrig, sl * nm * 4 * sizeof(float)));
             HIP_TRY(h, hipMalloc((void **)&h->d_lcell_count, sl * (ncell + 1) * sizeof(uint32_t)));
             HIP_TRY(h, hipMalloc((void **)&h->d_lcell_fill, sl * ncell * sizeof(uint32_t)));
+            HIP_TRY(h, hipMalloc((void **)&h->d_lgrid, sl * sizeof(uint4)));
         }
         HIP_TRY(h, hipMalloc((void **)&h->d_adist, sizeof(float) * (p.n_mol_total ? p.n_mol_total : 1)));
     }
@@ -746,7 +748,7 @@ void gorder_hip_destroy(gorder_hip_handle *h) {
     (void)hipFree(h->d_geom_group); (void)hipFree(h->d_shapes);
     (void)hipFree(h->d_map_rec); (void)hipFree(h->d_ua_runs); (void)hipFree(h->d_ua_run_begin);
     (void)hipFree(h->d_runs); (void)hipFree(h->d_run_begin); (void)hipFree(h->d_items_by_slot);
-    (void)hipFree(h->d_item_run); (void)hipFree(h->d_ua_item_run);
+    (void)hipFree(h->d_item_run); (void)hipFree(h->d_ua_item_run); (void)hipFree(h->d_lgrid);
     (void)hipFree(h->d_dyn_cloud); (void)hipFree(h->d_dyn_heads); (void)hipFree(h->d_dyn_cell_of); (void)hipFree(h->d_dyn_count);
     (void)hipFree(h->d_dyn_rec); (void)hipFree(h->d_dyn_rsn); (void)hipFree(h->d_dyn_normals);
     if (!h->acc_external) (void)hipFree(h->d_acc);
@@ -833,6 +835,7 @@ static int run_leaflets(gorder_hip_handle *h, const float *d_xyz, const float *d
         lo.radius_thr = local_radius_threshold(lf.radius);
         lo.cell_of = h->d_lcell_of; lo.trig = h->d_ltrig; lo.cell_count = h->d_lcell_count;
         lo.cell_fill = h->d_lcell_fill; lo.rsn = reinterpret_cast<float *>(h->d_lcell_atoms); lo.err = h->d_err;
+        lo.grid = h->d_lgrid;
         for (size_t done = 0; done < aframes.size(); done += h->local_slab) {
             const uint32_t ns = (uint32_t)std::min<size_t>(aframes.size() - done, h->local_slab);
             lo.aframes = h->d_aframes + done;

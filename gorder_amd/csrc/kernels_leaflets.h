@@ -461,6 +461,8 @@ struct LocalArgs {
     const uint32_t *heads;
     const uint32_t *membrane;
     uint32_t n_membrane;
+    uint4 *grid;                // [n_slab] (cells along a, cells along b, reach ka, reach kb) of each slab frame, written by
+                                // k_local_scan for k_local_flags (null: not wanted)
     uint32_t dim;               // normal
     int flip, pbc;
     float radius;
@@ -587,6 +589,14 @@ __global__ __launch_bounds__(1024) void k_local_scan(LocalArgs a) {
         run += local[k];
     }
     if (threadIdx.x == 1023) cnt[N] = run;
+    if (threadIdx.x == 0 && a.grid) {     // the frame's cell grid, once per frame instead of once per head
+        float box[3];
+        frame_box(a, a.aframes ? a.aframes[s] : a.frame0 + s, box);
+        uint32_t nca, ncb, ka, kb;
+        int da, db;
+        local_grid(a, box, nca, ncb, da, db, ka, kb);
+        a.grid[s] = make_uint4(nca, ncb, ka, kb);
+    }
 }
 
 // Places every membrane atom in its cell's run and writes a cell-ordered RECORD next to it so that the
@@ -683,7 +693,14 @@ __global__ __launch_bounds__(256) void k_local_flags(LocalArgs a) {
     frame_box(a, f, box);
     uint32_t nca, ncb, ka, kb;
     int da, db;
-    local_grid(a, box, nca, ncb, da, db, ka, kb);
+    if (a.grid) {         // uniform per workgroup: scalar loads
+        const uint4 g = a.grid[s];
+        nca = g.x; ncb = g.y; ka = g.z; kb = g.w;
+        da = (int)((a.dim + 1u) % 3u);
+        db = (int)((a.dim + 2u) % 3u);
+    } else {
+        local_grid(a, box, nca, ncb, da, db, ka, kb);
+    }
     const int dn = (int)a.dim;
     const float *x = a.xyz + (size_t)f * a.n_atoms * 3u;
     const float *hp = x + 3u * (size_t)a.heads[m];
@@ -702,7 +719,10 @@ __global__ __launch_bounds__(256) void k_local_flags(LocalArgs a) {
     const float thr = a.radius_thr;
     // rows (ha - ka .. ha + ka) mod nca; in a row the cells (hb - kb .. hb + kb) mod ncb = runs [b0, b1) and [0, b2)
     const uint32_t n_rows = 2u * ka + 1u, n_cols = 2u * kb + 1u;       // <= nca, ncb by local_axis
-    const uint32_t a0 = (ha + nca - ka) % nca, b0 = (hb + ncb - kb) % ncb;
+    // (x + n - k) mod n for x < n, k <= n: one conditional subtraction (an integer modulo is ~15 instructions)
+    uint32_t a0 = ha + nca - ka, b0 = hb + ncb - kb;
+    a0 -= a0 >= nca ? nca : 0u;
+    b0 -= b0 >= ncb ? ncb : 0u;
     const uint32_t b1 = min(b0 + n_cols, ncb), b2 = b0 + n_cols - b1;
     const bool pbc = a.pbc != 0;
     auto inside = [&](float ra, float rb) {
@@ -727,17 +747,23 @@ __global__ __launch_bounds__(256) void k_local_flags(LocalArgs a) {
     const uint32_t n_runs = 2u * n_rows;
     uint32_t rq0 = 0, rq1 = 0;
     if (lane < n_runs) {
-        const uint32_t row = ((a0 + (lane >> 1)) % nca) * ncb;
+        uint32_t ra = a0 + (lane >> 1);
+        ra -= ra >= nca ? nca : 0u;
+        const uint32_t row = ra * ncb;
         rq0 = (lane & 1u) ? cstart[row] : cstart[row + b0];
         rq1 = (lane & 1u) ? cstart[row + b2] : cstart[row + b1];
     }
+    // Every run overwrites the lanes from its first iteration on (a later run then overwrites its own); the lanes
+    // past the last iteration are cleared at the end.  The second run of a row is empty unless the columns wrap.
     uint32_t n_it = 0, it_base = 0, it_end = 0;
-    for (uint32_t r = 0; r < n_runs; r++) {
+    for (uint32_t r = 0; r < n_runs; r += (b2 ? 1u : 2u)) {
         const uint32_t q0 = __builtin_amdgcn_readlane(rq0, r), q1 = __builtin_amdgcn_readlane(rq1, r);
-        const uint32_t n = (q1 - q0 + 63u) >> 6;
-        if (lane >= n_it && lane < n_it + n) { it_base = q0 + 64u * (lane - n_it); it_end = q1; }
-        n_it += n;
+        const bool from_here = lane >= n_it;
+        it_base = from_here ? q0 + 64u * (lane - n_it) : it_base;
+        it_end = from_here ? q1 : it_end;
+        n_it += (q1 - q0 + 63u) >> 6;
     }
+    if (lane >= n_it) { it_base = 0; it_end = 0; }
     const bool flat = n_it <= 64u;       // else (> 4096 candidates): the plain run loops
 
     // pass 1: members (in-plane minimum-image distance < radius; groan_rs Cylinder::inside), their count
