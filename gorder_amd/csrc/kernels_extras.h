@@ -567,10 +567,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     }
 }
 
-// ---- ordermaps of the united-atom path, second step -----------------------------------------------
-// k_ua_extras stages every sample as (plane-tile << 32 | tick) in tile order (coalesced rows); here a block
-// owns ONE accumulator slot for a range of frames: it gathers the slot's samples (runs of consecutive lanes,
-// gorder::MapRun), adds them into a packed map held in LDS (ds_add_u64) and flushes the tiles it touched
+// ---- ordermaps, second step ------------------------------------------------------------------------
+// The sample kernels stage every sample as (plane-tile << 32 | tick), run by run (ExtraArgs::map_rec); here a block
+// owns ONE accumulator slot for a range of frames: it reads the slot's runs (gorder::MapRun, contiguous pieces),
+// adds the samples into a packed map held in LDS (ds_add_u64) and flushes the tiles it touched
 // into the global packed map with one atomic each.  Scattered global atomics run at ~24 G/s on this chip
 // whatever one does (tools/microbench/atomic_scatter.hip); this way their number drops from one per sample to
 // at most one per (slot, chunk, tile).
