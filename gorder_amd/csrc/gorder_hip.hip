@@ -112,6 +112,9 @@ struct gorder_hip_handle {
     uint32_t *d_lcell_of = nullptr, *d_lcell_count = nullptr, *d_lcell_fill = nullptr, *d_lcell_atoms = nullptr;
     float *d_ltrig = nullptr;
     uint32_t *d_arow = nullptr, *d_aframes = nullptr;
+    // what those two hold right now: equal batches (same length, same assignment pattern) skip the upload
+    std::vector<uint32_t> up_arow, up_aframes;
+    const uint32_t *up_arow_at = nullptr, *up_aframes_at = nullptr;
     size_t arow_cap = 0, aframes_cap = 0;
     bool have_assignment = false;
     uint64_t assignment_frame = 0;
@@ -793,9 +796,15 @@ static int run_leaflets(gorder_hip_handle *h, const float *d_xyz, const float *d
                         const std::vector<uint32_t> &aframes, uint32_t row0) {
     if (aframes.empty()) return GORDER_OK;
     int st;
+    const size_t cap_before = h->aframes_cap;
     if ((st = ensure(h, &h->d_aframes, &h->aframes_cap, aframes.size())) != GORDER_OK) return st;
-    HIP_TRY(h, hipMemcpyAsync(h->d_aframes, aframes.data(), aframes.size() * sizeof(uint32_t),
-                              hipMemcpyHostToDevice, h->stream));
+    if (h->aframes_cap != cap_before) h->up_aframes_at = nullptr;      // a new allocation holds nothing yet
+    if (h->up_aframes_at != h->d_aframes || h->up_aframes != aframes) {
+        HIP_TRY(h, hipMemcpyAsync(h->d_aframes, aframes.data(), aframes.size() * sizeof(uint32_t),
+                                  hipMemcpyHostToDevice, h->stream));
+        h->up_aframes = aframes;
+        h->up_aframes_at = h->d_aframes;
+    }
     const gorder_leaflets_t &lf = h->tables.leaflets;
     LeafletArgs la{};
     la.xyz = d_xyz; la.box9 = d_box; la.n_atoms = h->plan.n_atoms;
@@ -900,9 +909,15 @@ int gorder_hip_submit_device(gorder_hip_handle *h, const float *d_xyz, const flo
             h->d_aflags = nb;
             h->aflags_rows = nrows;
         }
+        const size_t cap_before = h->arow_cap;
         if ((st = ensure(h, &h->d_arow, &h->arow_cap, n_frames)) != GORDER_OK) return st;
-        HIP_TRY(h, hipMemcpyAsync(h->d_arow, arow.data(), n_frames * sizeof(uint32_t), hipMemcpyHostToDevice,
-                                  h->stream));
+        if (h->arow_cap != cap_before) h->up_arow_at = nullptr;        // a new allocation holds nothing yet
+        if (h->up_arow_at != h->d_arow || h->up_arow != arow) {
+            HIP_TRY(h, hipMemcpyAsync(h->d_arow, arow.data(), n_frames * sizeof(uint32_t), hipMemcpyHostToDevice,
+                                      h->stream));
+            h->up_arow = arow;
+            h->up_arow_at = h->d_arow;
+        }
         if ((st = run_leaflets(h, d_xyz, d_box, aframes, 1)) != GORDER_OK) return st;
         h->have_assignment = true;
         h->assignment_frame = last_assign_frame;
