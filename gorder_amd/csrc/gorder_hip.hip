@@ -578,6 +578,7 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
             }
             e.maps = 1; e.plane = om.plane; e.x0 = om.span_x[0]; e.y0 = om.span_y[0];
             e.binx = om.bin[0]; e.biny = om.bin[1]; e.nx = h->map_nx; e.ny = h->map_ny;
+            e.bin_core = (om.bin[0] >= 0x1p-40f && om.bin[0] <= 0x1p+40f && om.bin[1] >= 0x1p-40f && om.bin[1] <= 0x1p+40f) ? 1 : 0;
             e.map_packed = h->d_map_packed;
         }
         e.tw = t->timewise ? 1 : 0;

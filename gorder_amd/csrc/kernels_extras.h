@@ -28,6 +28,7 @@ struct ExtraArgs {
     const uint32_t *item_run;        // per item: (tid0 << 16) | n
     uint32_t rec_frame0, rec_stride; // rec_stride: words per lane = frames of the sub-range rounded up to 16
     const float4 *dyn;               // dynamic membrane normals [n_frames][n_mol_total] (nx, ny, nz, cloud size) or null
+    int bin_core;                    // both bin widths in [2^-40, 2^40]: grid_index may use the division core
     int tw;                          // timewise on
     unsigned long long *tw_sums;     // [rows][3][n_acc]
     unsigned long long *tw_cnts;     // [rows][3][n_acc]
@@ -64,8 +65,11 @@ __device__ __forceinline__ bool geom_inside(const ExtraArgs &e, const float *sh,
 }
 
 // groan_rs GridMap::get_mut_at: nearest tile centre, None outside (oracle: gridmap_index)
-__device__ __forceinline__ int grid_index(float x, float lo, float bin, uint32_t n) {
-    const float k = __builtin_roundf((x - lo) / bin);
+// `core`: the bin width lies in [2^-40, 2^40] (checked once on the host), so the quotient can come from the Newton
+// core of the IEEE division (gm_div_core): a numerator small or large enough for v_div_scale to matter gives a tile
+// index of 0 or none either way.  The reciprocal refinement is loop-invariant (one bin width for all samples).
+__device__ __forceinline__ int grid_index(float x, float lo, float bin, uint32_t n, bool core) {
+    const float k = __builtin_roundf(core ? gm_div_core(x - lo, bin) : (x - lo) / bin);
     if (!(k >= 0.0f) || !(k < (float)n)) return -1;
     return (int)k;
 }
@@ -81,7 +85,7 @@ __device__ __forceinline__ void extras_add(const FrameArgs &a, const ExtraArgs &
         if (e.plane == 0) { x = px; y = py; }
         else if (e.plane == 1) { x = px; y = pz; }
         else { x = pz; y = py; }
-        const int ix = grid_index(x, e.x0, e.binx, e.nx), iy = grid_index(y, e.y0, e.biny, e.ny);
+        const int ix = grid_index(x, e.x0, e.binx, e.nx, e.bin_core != 0), iy = grid_index(y, e.y0, e.biny, e.ny, e.bin_core != 0);
         if (ix >= 0 && iy >= 0) {
             // ONE atomic per sample: count and tick sum share a 64-bit word, and with leaflets only the
             // sample's own leaflet plane is touched (total = upper + lower, bond.rs:199-213); k_fold_maps
