@@ -284,7 +284,7 @@ _EXPORTS = [
     "gorder_hip_normals", "gorder_hip_export_maps", "gorder_hip_set_normals",
     "gorder_hip_accumulators_device", "gorder_hip_bind_accumulators", "gorder_hip_last_error_index",
     "gorder_hip_last_error_message", "gorder_hip_strerror", "gorder_hip_kernel_time", "gorder_hip_plan",
-    "gorder_hip_plan_tables",
+    "gorder_hip_plan_tables", "gorder_hip_selftest_arithmetic",
 ]
 
 _lib = None
@@ -348,8 +348,20 @@ def load_library() -> C.CDLL:
     lib.gorder_hip_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64), i32]
     lib.gorder_hip_plan.argtypes = [vp, C.POINTER(CPlan)]
     lib.gorder_hip_plan_tables.argtypes = [C.POINTER(CTables), C.POINTER(CPlan), C.POINTER(i32)]
+    lib.gorder_hip_selftest_arithmetic.argtypes = [i32, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
     _lib = lib
     return lib
+
+
+def selftest_arithmetic(n: int = 1 << 26, seed: int = 1, device: int = 0):
+    """(division mismatches, square-root mismatches) of the kernels' Newton-core forms against the IEEE operations on
+    n random operand sets inside the guarded ranges (gorder_hip_selftest_arithmetic); both must be 0."""
+    lib = load_library()
+    out = (C.c_uint64 * 2)()
+    st = lib.gorder_hip_selftest_arithmetic(device, n, seed, out)
+    if st != 0:
+        raise GorderHipError(st, lib.gorder_hip_strerror(st).decode())
+    return int(out[0]), int(out[1])
 
 
 def plan_tables(tables: Tables) -> dict:

@@ -489,6 +489,63 @@ const char *gorder_hip_strerror(int status) {
     }
 }
 
+namespace {
+__global__ void k_selftest_arithmetic(uint64_t n, uint64_t seed, unsigned long long *mismatches) {
+    uint64_t bad_div = 0, bad_sqrt = 0;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t x = (i + 1) * 0x9E3779B97F4A7C15ull + seed;          // splitmix64
+        auto next = [&]() {
+            x += 0x9E3779B97F4A7C15ull;
+            uint64_t z = x;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            return z ^ (z >> 31);
+        };
+        auto make = [&](int e_lo, int e_hi, bool sign) {                // random mantissa, exponent uniform in [e_lo, e_hi]
+            const uint64_t r = next();
+            const uint32_t e = (uint32_t)(127 + e_lo + (int)((r >> 32) % (uint64_t)(e_hi - e_lo + 1)));
+            uint32_t bits = (e << 23) | (uint32_t)(r & 0x7fffffu);
+            if (sign && (r >> 63)) bits |= 0x80000000u;
+            return __uint_as_float(bits);
+        };
+        float d = make(-40, 39, false);
+        if (i % 1024u == 0) d = 0x1p+40f;
+        if (i % 1024u == 1) d = 0x1p-40f;
+        float num = make(-100, 60, true);
+        if (i % 64u == 0) num = 0.0f;
+        if (i % 64u == 1) num = d;                                        // quotient exactly 1
+        if (i % 64u == 2) num = d * 0.5f;                                 // exact ties of the rounding to a tile index
+        const float q_core = gm_div_core(num, d), q_ieee = num / d;
+        if (__float_as_uint(q_core) != __float_as_uint(q_ieee)) bad_div++;
+        const float s_core = gm_sqrt_core(d), s_ieee = __builtin_sqrtf(d);
+        if (__float_as_uint(s_core) != __float_as_uint(s_ieee)) bad_sqrt++;
+    }
+    if (bad_div) atomicAdd(&mismatches[0], (unsigned long long)bad_div);
+    if (bad_sqrt) atomicAdd(&mismatches[1], (unsigned long long)bad_sqrt);
+}
+}  // namespace
+
+int gorder_hip_selftest_arithmetic(int device, uint64_t n, uint64_t seed, uint64_t mismatches[2]) {
+    if (!mismatches) return GORDER_ERR_INVALID_ARGUMENT;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return GORDER_ERR_NO_DEVICE;
+    if (device < 0 || device >= count || hipSetDevice(device) != hipSuccess) return GORDER_ERR_INVALID_ARGUMENT;
+    unsigned long long *d = nullptr;
+    if (hipMalloc((void **)&d, 2 * sizeof(unsigned long long)) != hipSuccess) return GORDER_ERR_DEVICE;
+    int st = GORDER_OK;
+    if (hipMemset(d, 0, 2 * sizeof(unsigned long long)) != hipSuccess) st = GORDER_ERR_DEVICE;
+    if (st == GORDER_OK) {
+        hipLaunchKernelGGL(k_selftest_arithmetic, dim3(4096), dim3(256), 0, 0, n, seed, d);
+        unsigned long long out[2] = {0, 0};
+        if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out, d, sizeof(out), hipMemcpyDeviceToHost) != hipSuccess)
+            st = GORDER_ERR_DEVICE;
+        mismatches[0] = out[0];
+        mismatches[1] = out[1];
+    }
+    (void)hipFree(d);
+    return st;
+}
+
 int gorder_hip_plan_tables(const gorder_tables_t *tables, gorder_hip_plan_t *out, int *selfcheck) {
     if (!tables || !out) return GORDER_ERR_INVALID_ARGUMENT;
     Plan p;

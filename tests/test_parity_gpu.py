@@ -274,6 +274,14 @@ def test_bond_vectors_at_the_edges_of_the_fast_division(built):
     exact(nopbc, stretch(nopbc, nopbc.frames(2, seed=6), around_upper + [1e19, 1e25]), None)
 
 
+def test_division_and_sqrt_cores_equal_the_ieee_operations(built):
+    """gm_div_core / gm_sqrt_core against `/` and sqrtf on 2^27 random operand sets inside the guarded ranges,
+    bit for bit, on the device (gorder_hip_selftest_arithmetic)."""
+    torch_cuda()
+    assert abi.selftest_arithmetic(1 << 27, seed=20240213) == (0, 0)
+    assert abi.selftest_arithmetic(1 << 24, seed=7) == (0, 0)
+
+
 def test_errors_mirror_the_reference(built):
     torch = torch_cuda()
     system = synthetic.cg_membrane(20)
