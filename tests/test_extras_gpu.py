@@ -94,6 +94,39 @@ def test_timewise(built, leaflets):
     assert e_gpu == e_ref and e_gpu > 0
 
 
+def interleaved_ua_types(n_lipids=150):
+    """The synthetic united-atom membrane split into two molecule types whose molecules ALTERNATE in the atom order
+    (even lipids: every order carbon; odd lipids: the methylene carbons 11..19 and one methyl only), so that the
+    molecule index is not monotonic along the atoms — the tile builder groups by molecule ranges."""
+    import copy
+    system = synthetic.ua_membrane(n_lipids)
+    (mt,) = system.tables.molecule_types
+    even, odd = np.arange(0, n_lipids, 2), np.arange(1, n_lipids, 2)
+    a = copy.copy(mt)
+    a.n_molecules, a.name = len(even), "EVEN"
+    a.ua_atoms = [(k, np.ascontiguousarray(ix[even])) for k, ix in mt.ua_atoms]
+    b = copy.copy(mt)
+    b.n_molecules, b.name = len(odd), "ODD"
+    b.ua_atoms = [(k, np.ascontiguousarray(ix[odd])) for c, (k, ix) in enumerate(mt.ua_atoms, start=10) if 11 <= c <= 19 or c == 41]
+    for t in (a, b):
+        t.heads = t.methyls = None
+    system.tables = copy.copy(system.tables)
+    system.tables.molecule_types = [a, b]
+    return system
+
+
+def test_united_atoms_with_interleaved_molecule_types(built):
+    system = interleaved_ua_types()
+    assert abi.plan_tables(system.tables)["selfcheck"] == 0
+    n = 7
+    xyz = system.frames(n, seed=3)
+    eng, o, got, want = both(system, xyz, system.box9(n))
+    assert got.sums.shape[1] == 62 + (8 * 2 + 1) + 3       # all carbons; 8 CH2 + the saturated CH of 11..19; one methyl
+    np.testing.assert_array_equal(got.counts, want.counts)
+    assert (got.counts[0] == 75 * n).all()
+    assert np.abs(got.order_ticks() - want.order_ticks()).max() <= 1
+
+
 @pytest.mark.parametrize("pbc", [True, False])
 @pytest.mark.parametrize("leaflets", [LEAFLETS_NONE, LEAFLETS_GLOBAL])
 def test_united_atoms(built, leaflets, pbc):
