@@ -78,7 +78,7 @@ struct Sample {
 };
 struct UaSample {
     uint32_t a[4];
-    uint32_t slot0, kind, mol;
+    uint32_t slot0, kind, mol, type;
 };
 
 // Returns GORDER_OK or GORDER_ERR_INVALID_ARGUMENT (index out of range, self bond, ...).
@@ -110,7 +110,7 @@ inline int build_plan(const gorder_tables_t &t, bool force_direct, Plan &p) {
             const uint32_t nidx = kind == GORDER_UA_CH1_SAT ? 4u : 3u;
             for (uint32_t k = 0; k < mt.n_molecules; k++) {
                 const uint32_t *ix = mt.ua_atoms[a].indices + 4 * (size_t)k;
-                UaSample us{{ix[0], ix[1], ix[2], nidx == 4 ? ix[3] : ix[1]}, slot, kind, mol + k};
+                UaSample us{{ix[0], ix[1], ix[2], nidx == 4 ? ix[3] : ix[1]}, slot, kind, mol + k, m};
                 for (uint32_t q = 0; q < nidx; q++)
                     if (ix[q] >= t.n_atoms) return GORDER_ERR_INVALID_ARGUMENT;
                 ua_samples.push_back(us);
@@ -125,7 +125,9 @@ inline int build_plan(const gorder_tables_t &t, bool force_direct, Plan &p) {
     {   // ---- united-atom tiles
         auto ulo = [](const UaSample &u) { return std::min(std::min(u.a[0], u.a[1]), std::min(u.a[2], u.a[3])); };
         auto uhi = [](const UaSample &u) { return std::max(std::max(u.a[0], u.a[1]), std::max(u.a[2], u.a[3])); };
+        // by molecule type first: the molecules of two types may alternate in the atom order, a group is one type's
         std::stable_sort(ua_samples.begin(), ua_samples.end(), [&](const UaSample &x, const UaSample &y) {
+            if (x.type != y.type) return x.type < y.type;
             if (ulo(x) != ulo(y)) return ulo(x) < ulo(y);
             return uhi(x) < uhi(y);
         });
@@ -186,7 +188,7 @@ inline int build_plan(const gorder_tables_t &t, bool force_direct, Plan &p) {
                 uint32_t lo_atom = ulo(ua_samples[q]), hi_atom = uhi(ua_samples[q]);
                 for (e = q; e < ua_samples.size(); e++) {
                     const UaSample &u = ua_samples[e];
-                    if (u.mol < mol0 || u.mol - mol0 >= span) break;
+                    if (u.type != ua_samples[q].type || u.mol < mol0 || u.mol - mol0 >= span) break;
                     lo_atom = std::min(lo_atom, ulo(u));
                     hi_atom = std::max(hi_atom, uhi(u));
                 }
