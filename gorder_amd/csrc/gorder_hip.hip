@@ -686,6 +686,7 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
         h->n2 = sqrtf(h->n2sq);
         for (int d = 0; d < 3; d++)
             if (n[d] == 1.0f && n[(d + 1) % 3] == 0.0f && n[(d + 2) % 3] == 0.0f) h->axis = d;
+        h->extra.axis = h->axis;
     }
     if (const char *e = getenv("GORDER_HIP_FRAMES_PER_STAGE")) {
         const int g = atoi(e);

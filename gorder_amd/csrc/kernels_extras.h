@@ -29,6 +29,7 @@ struct ExtraArgs {
     uint32_t rec_frame0, rec_stride; // rec_stride: words per lane = frames of the sub-range rounded up to 16
     const float4 *dyn;               // dynamic membrane normals [n_frames][n_mol_total] (nx, ny, nz, cloud size) or null
     int bin_core;                    // both bin widths in [2^-40, 2^40]: grid_index may use the division core
+    int axis;                        // the static normal is this coordinate axis (0..2), or -1
     int tw;                          // timewise on
     unsigned long long *tw_sums;     // [rows][3][n_acc]
     unsigned long long *tw_cnts;     // [rows][3][n_acc]
@@ -515,7 +516,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             unsigned long long recs[3] = {kMapNoSample, kMapNoSample, kMapNoSample};
             auto sample = [&](const int k, const V3 v, const V3 b) {
                 if (k >= nh) return;
-                const float sch = gm_calc_sch<ACOS_COS>(v.x, v.y, v.z, nrx, nry, nrz, nr2, nr2sq);
+                float sch;
+                const float s2 = (v.x * v.x + v.y * v.y) + v.z * v.z;
+                if (!ACOS_COS && e.axis >= 0 && !(GENERAL && e.dyn) && s2 >= 0x1p-40f && s2 <= 0x1p+40f) {
+                    // static normal along an axis, |v|^2 in the guarded range: the squared cosine by the division core,
+                    // no clamp (gm_sch_axis has the argument); anything else takes the general routine
+                    const float prod = e.axis == 0 ? v.x : (e.axis == 1 ? v.y : v.z);
+                    sch = (1.5f * gm_div_core(prod * prod, s2)) - 0.5f;
+                } else {
+                    sch = gm_calc_sch<ACOS_COS>(v.x, v.y, v.z, nrx, nry, nrz, nr2, nr2sq);
+                }
                 const int tick = gm_tick(sch);
                 if (GENERAL) {
                     const float box[3] = {bx3.x, bx3.y, bx3.z};
