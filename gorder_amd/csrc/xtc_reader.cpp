@@ -158,6 +158,7 @@ struct gorder_xtc_reader {
     std::string path;                 // for the worker threads of gorder_xtc_read_window_mt (own file handles)
     FILE *fp = nullptr;
     bool trr = false;                 // GROMACS TRR (magic 1993, uncompressed reals) instead of XTC (magic 1995)
+    bool gro = false;                 // multi-frame GRO text (groan_rs GroReader, common.rs:322-333)
     uint32_t natoms = 0;
     std::vector<uint32_t> group;      // atoms to convert (empty = all)
     std::vector<int32_t> slot_of;     // atom -> output slot or -1 (only when group given)
@@ -340,6 +341,87 @@ int trr_next(gorder_xtc_reader *r, float *xyz, float *box9, int64_t *step, float
 
 }  // namespace
 
+
+// ---- GRO -------------------------------------------------------------------------------------------
+// Text frames: title line (GROMACS writes "... t= <ps> step= <n>"), atom count, one fixed-column line per atom
+// (positions from column 20 in three fields of equal width, "%8.3f" by default; wider fields for more decimals;
+// velocities may follow), then the box line: v1(x) v2(y) v3(z) [v1(y) v1(z) v2(x) v2(z) v3(x) v3(y)].
+namespace {
+bool gro_line(FILE *fp, std::string &line) {
+    line.clear();
+    char buf[512];
+    while (fgets(buf, sizeof(buf), fp)) {
+        line += buf;
+        if (!line.empty() && line.back() == '\n') { line.pop_back(); if (!line.empty() && line.back() == '\r') line.pop_back(); return true; }
+    }
+    return !line.empty();
+}
+int gro_natoms(FILE *fp, uint32_t &natoms) {       // reads the first two lines
+    std::string line;
+    if (!gro_line(fp, line) || !gro_line(fp, line)) return GORDER_XTC_ERR_FORMAT;
+    char *end = nullptr;
+    const long n = strtol(line.c_str(), &end, 10);
+    if (end == line.c_str() || n <= 0 || n > 0x7fffffffl) return GORDER_XTC_ERR_FORMAT;
+    natoms = (uint32_t)n;
+    return GORDER_XTC_OK;
+}
+int gro_next(gorder_xtc_reader *r, float *xyz, float *box9, int64_t *step, float *time_ps, float *precision) {
+    std::string line;
+    if (!gro_line(r->fp, line)) return GORDER_XTC_EOF;
+    if (line.find_first_not_of(" \t") == std::string::npos) {      // blank tail of the file
+        if (!gro_line(r->fp, line)) return GORDER_XTC_EOF;
+    }
+    float t = 0.0f;
+    long st = 0;
+    const size_t pt = line.rfind("t=");
+    if (pt != std::string::npos) t = strtof(line.c_str() + pt + 2, nullptr);
+    const size_t ps = line.rfind("step=");
+    if (ps != std::string::npos) st = strtol(line.c_str() + ps + 5, nullptr, 10);
+    if (!gro_line(r->fp, line)) return GORDER_XTC_ERR_FORMAT;
+    if ((uint32_t)strtol(line.c_str(), nullptr, 10) != r->natoms) return GORDER_XTC_ERR_FORMAT;
+    const bool all = r->group.empty();
+    size_t width = 0;
+    for (uint32_t a = 0; a < r->natoms; a++) {
+        if (!gro_line(r->fp, line)) return GORDER_XTC_ERR_FORMAT;
+        if (!xyz) continue;
+        const int32_t s = all ? (int32_t)a : r->slot_of[a];
+        if (s < 0) continue;
+        if (width == 0) {       // field width = distance between the decimal points of x and y
+            const size_t d1 = line.find('.', 20), d2 = d1 == std::string::npos ? d1 : line.find('.', d1 + 1);
+            if (d2 == std::string::npos) return GORDER_XTC_ERR_FORMAT;
+            width = d2 - d1;
+        }
+        if (line.size() < 20 + 3 * width) return GORDER_XTC_ERR_FORMAT;
+        for (int c = 0; c < 3; c++) {
+            const std::string field = line.substr(20 + (size_t)c * width, width);
+            char *end = nullptr;
+            const float v = strtof(field.c_str(), &end);
+            if (end == field.c_str()) return GORDER_XTC_ERR_FORMAT;
+            xyz[3 * (size_t)s + c] = v;
+        }
+    }
+    if (!gro_line(r->fp, line)) return GORDER_XTC_ERR_FORMAT;
+    float b[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int nb = 0;
+    const char *p = line.c_str();
+    for (; nb < 9; nb++) {
+        char *end = nullptr;
+        b[nb] = strtof(p, &end);
+        if (end == p) break;
+        p = end;
+    }
+    if (nb != 3 && nb != 9) return GORDER_XTC_ERR_FORMAT;
+    if (box9) {
+        box9[0] = b[0]; box9[4] = b[1]; box9[8] = b[2];
+        box9[1] = b[3]; box9[2] = b[4]; box9[3] = b[5]; box9[5] = b[6]; box9[6] = b[7]; box9[7] = b[8];
+    }
+    if (step) *step = st;
+    if (time_ps) *time_ps = t;
+    if (precision) *precision = 0.0f;
+    return GORDER_XTC_OK;
+}
+}  // namespace
+
 extern "C" {
 
 int gorder_xtc_open(const char *path, const uint32_t *group, uint32_t n_group, gorder_xtc_reader **out) {
@@ -348,7 +430,14 @@ int gorder_xtc_open(const char *path, const uint32_t *group, uint32_t n_group, g
     FILE *fp = fopen(path, "rb");
     if (!fp) return GORDER_XTC_ERR_OPEN;
     uint8_t head[8];
-    if (!read_exact(fp, head, 8) || (be32(head) != 1995u && be32(head) != 1993u)) {
+    if (!read_exact(fp, head, 8)) {
+        fclose(fp);
+        return GORDER_XTC_ERR_FORMAT;
+    }
+    const bool binary = be32(head) == 1995u || be32(head) == 1993u;
+    uint32_t gro_atoms = 0;
+    fseek(fp, 0, SEEK_SET);
+    if (!binary && gro_natoms(fp, gro_atoms) != GORDER_XTC_OK) {    // neither magic: a GRO text trajectory, or nothing we read
         fclose(fp);
         return GORDER_XTC_ERR_FORMAT;
     }
@@ -356,7 +445,10 @@ int gorder_xtc_open(const char *path, const uint32_t *group, uint32_t n_group, g
     r->fp = fp;
     r->path = path;
     fseek(fp, 0, SEEK_SET);
-    if (be32(head) == 1993u) {           // TRR: the atom count sits behind the version string
+    if (!binary) {
+        r->gro = true;
+        r->natoms = gro_atoms;
+    } else if (be32(head) == 1993u) {           // TRR: the atom count sits behind the version string
         r->trr = true;
         TrrHeader h{};
         if (trr_read_header(r, h) != GORDER_XTC_OK) {
@@ -398,6 +490,7 @@ int gorder_xtc_next(gorder_xtc_reader *r, float *xyz, float *box9, int64_t *step
                     float *precision) {
     if (!r || !r->fp) return GORDER_XTC_ERR_ARGUMENT;
     if (r->trr) return trr_next(r, xyz, box9, step, time_ps, precision);
+    if (r->gro) return gro_next(r, xyz, box9, step, time_ps, precision);
     uint8_t head[16 + 36 + 4];
     const size_t got = fread(head, 1, sizeof(head), r->fp);
     if (got == 0) return GORDER_XTC_EOF;

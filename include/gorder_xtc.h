@@ -33,7 +33,9 @@ typedef enum {
 
 /* Open one file: XTC, or — recognised by its magic number 1993 — a GROMACS TRR file (uncompressed single- or
  * double-precision positions; frames without positions are skipped; `precision` is reported as 0), which the
- * reference reads through groan_rs' TrrReader (common.rs:306-320).  `group` (may be NULL = all atoms) lists the n_group atom indices to convert;
+ * reference reads through groan_rs' TrrReader (common.rs:306-320); a file with neither magic number is read as a
+ * multi-frame GRO text trajectory (GroReader, common.rs:322-333: time from "t=" in the title line, positions in
+ * three equal-width columns from column 20, 3- or 9-value box line).  `group` (may be NULL = all atoms) lists the n_group atom indices to convert;
  * decoded frames hold exactly those atoms, in that order (the "Master" group of common.rs:283-304). */
 int gorder_xtc_open(const char *path, const uint32_t *group, uint32_t n_group, gorder_xtc_reader **out);
 void gorder_xtc_close(gorder_xtc_reader *r);

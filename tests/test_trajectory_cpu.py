@@ -115,3 +115,53 @@ def test_trr_of_the_reference_when_present(cg):
     k = int(np.flatnonzero(cg.times == t[0])[0])
     np.testing.assert_array_equal(xyz[0, : cg.xyz.shape[1]], cg.xyz[k])
     np.testing.assert_array_equal(box[0], cg.boxes[k])
+
+
+# ---- GRO text trajectories (groan_rs GroReader, common.rs:322-333) -----------------------------------------------
+def _write_gro(path, frames, boxes, times, decimals=3, triclinic=False):
+    w = decimals + 5
+    with open(path, "w") as f:
+        for x, b, t in zip(frames, boxes, times):
+            f.write(f"bilayer t= {t:.5f} step= {int(t * 50)}\n{len(x):5d}\n")
+            for i, p in enumerate(x):
+                f.write(f"{i % 99999 + 1:5d}{'POPC':<5s}{'C' + str(i % 97):>5s}{(i + 1) % 100000:5d}"
+                        + "".join(f"{v:{w}.{decimals}f}" for v in p) + "\n")
+            if triclinic:
+                f.write(" ".join(f"{v:.5f}" for v in (b[0], b[1], b[2], 0.0, 0.0, 0.25, 0.0, 0.5, 0.75)) + "\n")
+            else:
+                f.write(f"{b[0]:10.5f}{b[1]:10.5f}{b[2]:10.5f}\n")
+
+
+@pytest.mark.parametrize("decimals,threads", [(3, 1), (3, 3), (5, 2)])
+def test_gro_trajectory(tmp_path, built, decimals, threads):
+    rng = np.random.default_rng(5)
+    n_frames, n_atoms = 9, 250
+    frames = np.round(rng.uniform(-1.0, 12.0, (n_frames, n_atoms, 3)), decimals).astype(np.float32)
+    boxes = np.round(rng.uniform(9.0, 11.0, (n_frames, 3)), 5).astype(np.float32)
+    times = 100.0 + 20.0 * np.arange(n_frames)
+    path = str(tmp_path / "traj.gro")
+    _write_gro(path, frames, boxes, times, decimals)
+    x, b, t = xtc.read_trajectory([path], threads=threads)
+    np.testing.assert_array_equal(x, frames)
+    np.testing.assert_array_equal(t, times.astype(np.float32))
+    np.testing.assert_array_equal(b[:, [0, 1, 2], [0, 1, 2]], boxes)
+    assert (b.reshape(n_frames, 9)[:, [1, 2, 3, 5, 6, 7]] == 0).all()
+    # group-partial conversion, time window and step like the binary formats
+    grp = np.array([3, 17, 249, 100], dtype=np.uint32)
+    x, b, t = xtc.read_trajectory([path], group=grp, begin=140.0, end=240.0, step=2, threads=threads)
+    np.testing.assert_array_equal(t, np.array([140.0, 180.0, 220.0], dtype=np.float32))
+    np.testing.assert_array_equal(x, frames[[2, 4, 6]][:, grp])
+
+
+def test_gro_triclinic_box_and_truncation(tmp_path, built):
+    frames = np.zeros((2, 4, 3), dtype=np.float32)
+    path = str(tmp_path / "tri.gro")
+    _write_gro(path, frames, np.array([[5.0, 6.0, 7.0]] * 2), [0.0, 1.0], triclinic=True)
+    x, b, t = xtc.read_trajectory([path])
+    assert x.shape == (2, 4, 3)
+    np.testing.assert_array_equal(b[0], np.array([[5.0, 0.0, 0.0], [0.25, 6.0, 0.0], [0.5, 0.75, 7.0]], dtype=np.float32))
+    data = open(path).read()
+    cut = str(tmp_path / "cut.gro")
+    open(cut, "w").write(data[: len(data) - 60])            # the second frame loses its box line and last atom
+    with pytest.raises(IOError):
+        xtc.read_trajectory([cut])
