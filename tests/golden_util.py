@@ -5,6 +5,7 @@ import numpy as np
 import yaml
 
 from gorder_amd import structure as st
+from gorder_amd.select import select
 from gorder_amd.abi import LEAFLETS_GLOBAL, LEAFLETS_INDIVIDUAL, LEAFLETS_LOCAL
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -66,24 +67,25 @@ def expected(name):
 def aa_setup(fx, leaflets=None, frequency=1, heavy=None, **kw):
     """AAOrder '@membrane and element name carbon' / '... hydrogen' (tests_aa.rs:63-66); the fixture
     holds exactly the @membrane lipids."""
-    hyd = fx.element("hydrogen")
+    hyd = select(fx.structure, "@membrane and element name hydrogen")
     if heavy is None:
-        heavy = fx.element("carbon")
+        heavy = select(fx.structure, "@membrane and element name carbon")
+    elif isinstance(heavy, str):
+        heavy = select(fx.structure, heavy)
     lf = None
     if leaflets is not None:
-        allm = np.ones(fx.structure.n_atoms, dtype=bool)
-        lf = {"method": leaflets, "membrane": allm, "heads": fx.name_in("P"),
-              "methyls": fx.name_in("C218", "C316"), "frequency": frequency, "radius": 2.5}
+        lf = {"method": leaflets, "membrane": select(fx.structure, "@membrane"), "heads": select(fx.structure, "name P"),
+              "methyls": select(fx.structure, "name C218 C316"), "frequency": frequency, "radius": 2.5}
     return st.build_tables(fx.structure, "aa", heavy, hyd, leaflets=lf, **kw)
 
 
 def cg_setup(fx, leaflets=None, frequency=1, **kw):
     """CGOrder '@membrane' (tests_cg.rs:194)."""
-    beads = np.ones(fx.structure.n_atoms, dtype=bool)
+    beads = select(fx.structure, "@membrane")
     lf = None
     if leaflets is not None:
-        lf = {"method": leaflets, "membrane": beads, "heads": fx.name_in("PO4"),
-              "methyls": fx.name_in("C4A", "C4B"), "frequency": frequency, "radius": 2.5}
+        lf = {"method": leaflets, "membrane": beads, "heads": select(fx.structure, "name PO4"),
+              "methyls": select(fx.structure, "name C4A C4B"), "frequency": frequency, "radius": 2.5}
     return st.build_tables(fx.structure, "cg", beads, leaflets=lf, **kw)
 
 
@@ -93,16 +95,14 @@ METHODS = {"global": LEAFLETS_GLOBAL, "local": LEAFLETS_LOCAL, "individual": LEA
 def ua_setup(fx, leaflets=None, frequency=1, flip=False, sat_only=False, unsat_only=False, **kw):
     """UAOrder selections of tests_ua.rs:41-45 (saturated / unsaturated carbons of POPC and POPS)."""
     s = fx.structure
-    rn = np.array(s.resnames)
-    isc = np.array([n.startswith("C") for n in s.names])
-    sat = ((rn == "POPC") & isc & ~fx.name_in("C15", "C34", "C24", "C25")) | \
-          ((rn == "POPS") & isc & ~fx.name_in("C6", "C18", "C39", "C27", "C28"))
-    unsat = ((rn == "POPC") & fx.name_in("C24", "C25")) | ((rn == "POPS") & fx.name_in("C27", "C28"))
-    allm = np.ones(s.n_atoms, dtype=bool)
+    sat = select(s, "(resname POPC and name r'^C' and not name C15 C34 C24 C25) or "
+                    "(resname POPS and name r'^C' and not name C6 C18 C39 C27 C28)")
+    unsat = select(s, "(resname POPC and name C24 C25) or (resname POPS and name C27 C28)")
+    allm = select(s, "@membrane")
     lf = None
     if leaflets is not None:
-        heads = np.array([n.startswith("P") for n in s.names])                       # name r'^P'
-        methyls = ((rn == "POPC") & fx.name_in("CA2", "C50")) | ((rn == "POPS") & fx.name_in("C36", "C55"))
+        heads = select(s, "name r'^P'")
+        methyls = select(s, "(resname POPC and name CA2 C50) or (resname POPS and name C36 C55)")
         lf = {"method": leaflets, "membrane": allm, "heads": heads, "methyls": methyls, "frequency": frequency,
               "radius": 2.5, "flip": flip}
     if sat_only:
