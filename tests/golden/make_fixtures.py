@@ -124,7 +124,11 @@ if __name__ == "__main__":
               "ua_order_basic_saturated.yaml", "ua_order_basic_unsaturated.yaml", "ua_order_begin_end_step.yaml",
               "ua_order_cuboid_point.yaml", "ua_order_cylinder_center.yaml", "ua_order_error.yaml",
               "ua_order_leaflets_error.yaml", "ua_order_leaflets_flipped.yaml", "ua_leaflets_once.yaml",
-              "ua_normals.yaml", "ua_order_from_aa.yaml"):
+              "ua_normals.yaml", "ua_order_from_aa.yaml",
+              # the CSV twins of some of them, for the writers (tests/test_writers_cpu.py)
+              "aa_order_basic.csv", "aa_order_leaflets.csv", "cg_order_basic.csv", "cg_order_leaflets.csv",
+              "ua_order_basic.csv", "ua_order_leaflets.csv", "aa_order_error.csv", "cg_order_error_leaflets.csv",
+              "aa_order_leaflets_limit.csv"):
         src = os.path.join(REF, f)
         if os.path.exists(src):
             shutil.copy(src, os.path.join(HERE, "expected", f))

@@ -1,0 +1,72 @@
+"""YAML and CSV text in the reference's layouts (gorder_amd/writers.py), compared with its files by its own rule
+(tests/common/mod.rs:95-150: the same items line by line, numbers within 2e-4)."""
+import os
+
+import numpy as np
+import pytest
+
+from gorder_amd import structure as st
+from gorder_amd import writers
+from oracle import oracle
+from golden_util import GOLDEN, METHODS, Fixture, aa_setup, cg_setup, ua_setup
+
+
+def same_items(got: str, want: str, sep=None, skip=0):
+    ga, wa = got.splitlines()[skip:], want.splitlines()[skip:]
+    assert len(ga) == len(wa), (len(ga), len(wa))
+    for n, (g, w) in enumerate(zip(ga, wa)):
+        if sep is None:     # YAML: indentation is structure
+            assert len(g) - len(g.lstrip()) == len(w) - len(w.lstrip()), (n, g, w)
+        gi, wi = (g.split(sep), w.split(sep))
+        assert len(gi) == len(wi), (n, g, w)
+        for a, b in zip(gi, wi):
+            try:
+                fa, fb = np.float32(a), np.float32(b)
+            except ValueError:
+                assert a == b, (n, g, w)
+                continue
+            assert (np.isnan(fa) and np.isnan(fb)) or abs(fa - fb) <= np.float32(2e-4), (n, g, w)
+
+
+def golden(name):
+    with open(os.path.join(GOLDEN, "expected", name)) as f:
+        return f.read()
+
+
+CASES = [("aa", False, False, "aa_order_basic"), ("aa", True, False, "aa_order_leaflets"), ("aa", False, True, "aa_order_error"),
+         ("cg", False, False, "cg_order_basic"), ("cg", True, False, "cg_order_leaflets"), ("cg", True, True, "cg_order_error_leaflets"),
+         ("ua", False, False, "ua_order_basic"), ("ua", True, False, "ua_order_leaflets")]
+
+
+@pytest.fixture(scope="module")
+def fixtures(built):
+    return {"aa": Fixture("pcpepg"), "cg": Fixture("cg"), "ua": Fixture("ua")}
+
+
+@pytest.mark.parametrize("kind,leaflets,errors,name", CASES)
+def test_yaml_and_csv_text(fixtures, kind, leaflets, errors, name):
+    fx = fixtures[kind]
+    setup = {"aa": aa_setup, "cg": cg_setup, "ua": ua_setup}[kind]
+    tables, labels, midx = setup(fx, leaflets=METHODS["global"] if leaflets else None, timewise=errors)
+    frames = fx.window()
+    eng = oracle.OracleEngine(tables, trig=oracle.TRIG_LIBM, n_threads=4)
+    eng.submit(np.ascontiguousarray(fx.xyz[frames][:, midx, :]), fx.boxes[frames], frames)
+    res = eng.finish()
+    tw = eng.timewise(len(frames)) if errors else None
+    tree = (st.results_tree_ua(res, labels, leaflets=leaflets, timewise=tw) if kind == "ua"
+            else st.results_tree(res, labels, kind, leaflets=leaflets, timewise=tw))
+    same_items(writers.yaml_text(tree, header="# made here"), golden(name + ".yaml"), skip=1)
+    same_items(writers.csv_text(tree), golden(name + ".csv"), sep=",")
+
+
+def test_csv_prints_nan_below_min_samples(fixtures):
+    fx = fixtures["aa"]
+    tables, labels, midx = aa_setup(fx, leaflets=METHODS["global"])
+    frames = fx.window()
+    eng = oracle.OracleEngine(tables, trig=oracle.TRIG_LIBM, n_threads=4)
+    eng.submit(np.ascontiguousarray(fx.xyz[frames][:, midx, :]), fx.boxes[frames], frames)
+    tree = st.results_tree(eng.finish(), labels, "aa", leaflets=True, min_samples=500)
+    text = writers.csv_text(tree)
+    assert "NaN" in text
+    same_items(text, golden("aa_order_leaflets_limit.csv"), sep=",")
+    assert ".nan" in writers.yaml_text(tree)
