@@ -117,3 +117,87 @@ def csv_text(tree: dict) -> str:
                 _, a1, _, _, a2, _ = _BOND_KEY.match(key).groups()
                 lines.append(",".join([mname, a1, a2] + _cells(entry, which, errors)))
     return "\n".join(lines) + "\n"
+
+
+def _pm(value, errors: bool) -> str:
+    if errors:
+        return f"{_fixed(value['mean']):>8s} ± {_fixed(value['error'])}"
+    return f"{_fixed(value):>8s}"
+
+
+def tab_text(tree: dict, header: Optional[str] = None) -> str:
+    """The table layout (presentation/tab_presenter.rs): per molecule type one row per heavy atom (TOTAL and the
+    hydrogens) or per coarse-grained bond, an AVERAGE row, and the average of all molecule types at the end.  The
+    reference compares these files token by token (tests/common/mod.rs:113-124), so column widths are cosmetic."""
+    molecules = [(k, v) for k, v in tree.items() if k != "average order"]
+    sample = tree["average order"]
+    which = [w for w in ("total", "upper", "lower") if w in sample]
+    leaflets = len(which) == 3
+    errors = isinstance(sample["total"], dict)
+    atom_based = "bonds" in next(iter(molecules[0][1]["order parameters"].values()))
+    out = [header or "# order parameters", ""]
+    slot_names = "      ".join(("FULL", "UPPER", "LOWER")) if leaflets else None
+
+    def cell(value) -> str:
+        return "   ".join(_pm(value[w], errors) for w in which)
+
+    def head_rows(groups: List[str], label: str):
+        if atom_based and not (leaflets and groups == ["TOTAL"] and label == "all"):
+            out.append(" " * 10 + "  |  ".join(f"{g:^{len(cell(sample))}s}" for g in groups) + "  |")
+        if leaflets:
+            out.append(" " * 10 + "  |  ".join(slot_names for _ in groups) + "  |")
+        elif not atom_based:
+            out.append(" " * 18 + "FULL   |")
+
+    for mname, mol in molecules:
+        out.append(f"Molecule type {mname}")
+        ops = mol["order parameters"]
+        if atom_based:
+            n_h = max(len(e["bonds"]) for e in ops.values())
+            hname = "HYDROGEN" if (leaflets or errors) else "H"      # the narrow table abbreviates
+            head_rows(["TOTAL"] + [f"{hname} #{k + 1}" for k in range(n_h)], "mol")
+            for key, entry in ops.items():
+                atom = _ATOM_KEY.match(key).group(2)
+                bonds = entry["bonds"]
+                bonds = list(bonds.values()) if isinstance(bonds, dict) else list(bonds)
+                cells = [cell(entry)] + [cell(bonds[k]) if k < len(bonds) else " " * len(cell(entry)) for k in range(n_h)]
+                out.append(f"{atom:<8s}" + "  |  ".join(cells) + "  |")
+        else:
+            head_rows(["FULL"], "mol")
+            for key, entry in ops.items():
+                _, a1, _, _, a2, _ = _BOND_KEY.match(key).groups()
+                out.append(f"{a1 + ' - ' + a2:<15s}" + cell(entry) + "  |")
+        out.append(f"{'AVERAGE':<8s}" + cell(mol["average order"]) + "  |")
+        out.append("")
+    out.append("All molecule types")
+    head_rows(["TOTAL"] if atom_based else ["FULL"], "all")
+    out.append(f"{'AVERAGE':<8s}" + cell(sample) + "  |")
+    return "\n".join(out) + "\n"
+
+
+def xvg_text(tree: dict, molecule: str, header: Optional[str] = None, united: bool = False) -> str:
+    """One molecule type as an xvg data set (presentation/xvg_presenter.rs): a numbered line per heavy atom / bond,
+    full membrane and, with leaflets, upper and lower."""
+    mol = tree[molecule]
+    ops = mol["order parameters"]
+    sample = tree["average order"]
+    which = [w for w in ("total", "upper", "lower") if w in sample]
+    errors = isinstance(sample["total"], dict)
+    atom_based = "bonds" in next(iter(ops.values()))
+    out = [header or "# order parameters",
+           f'@    title "{("United-atom" if united else "Atomistic") if atom_based else "Coarse-grained"} order parameters for molecule type {molecule}"',
+           f'@    xaxis label "{"Atom" if atom_based else "Bond"}"',
+           f'@    yaxis label "{"-Sch" if atom_based else "S"}"']
+    legends = {"total": "Full membrane", "upper": "Upper leaflet", "lower": "Lower leaflet"}
+    for k, w in enumerate(which):
+        out.append(f'@    s{k} legend "{legends[w]}"')
+    out.append("@TYPE xy")
+    for n, (key, entry) in enumerate(ops.items(), start=1):
+        if atom_based:
+            out.append(f"# Atom {_ATOM_KEY.match(key).group(2)}:")
+        else:
+            _, a1, _, _, a2, _ = _BOND_KEY.match(key).groups()
+            out.append(f"# Bond {a1} - {a2}:")
+        vals = [entry[w]["mean"] if errors else entry[w] for w in which]
+        out.append(f"{n:<4d} " + " ".join(f"{_fixed(v):>8s}" for v in vals) + " ")
+    return "\n".join(out) + "\n"

@@ -128,7 +128,11 @@ if __name__ == "__main__":
               # the CSV twins of some of them, for the writers (tests/test_writers_cpu.py)
               "aa_order_basic.csv", "aa_order_leaflets.csv", "cg_order_basic.csv", "cg_order_leaflets.csv",
               "ua_order_basic.csv", "ua_order_leaflets.csv", "aa_order_error.csv", "cg_order_error_leaflets.csv",
-              "aa_order_leaflets_limit.csv"):
+              "aa_order_leaflets_limit.csv",
+              "aa_order_basic.tab", "aa_order_leaflets.tab", "cg_order_basic.tab", "cg_order_leaflets.tab",
+              "ua_order_basic.tab", "ua_order_leaflets.tab", "aa_order_error.tab", "cg_order_error_leaflets.tab",
+              "aa_order_basic_POPC.xvg", "aa_order_leaflets_POPC.xvg", "cg_order_leaflets_POPC.xvg",
+              "ua_order_leaflets_POPC.xvg"):
         src = os.path.join(REF, f)
         if os.path.exists(src):
             shutil.copy(src, os.path.join(HERE, "expected", f))

@@ -28,6 +28,22 @@ def same_items(got: str, want: str, sep=None, skip=0):
             assert (np.isnan(fa) and np.isnan(fb)) or abs(fa - fb) <= np.float32(2e-4), (n, g, w)
 
 
+def same_tokens(got: str, want: str, skip=1):
+    """The reference's rule for .tab / .xvg files: whitespace-separated items line by line."""
+    ga, wa = got.splitlines()[skip:], want.splitlines()[skip:]
+    assert len(ga) == len(wa), (len(ga), len(wa))
+    for n, (g, w) in enumerate(zip(ga, wa)):
+        gi, wi = g.split(), w.split()
+        assert len(gi) == len(wi), (n, g, w)
+        for a, b in zip(gi, wi):
+            try:
+                fa, fb = np.float32(a), np.float32(b)
+            except ValueError:
+                assert a == b, (n, g, w)
+                continue
+            assert (np.isnan(fa) and np.isnan(fb)) or abs(fa - fb) <= np.float32(2e-4), (n, g, w)
+
+
 def golden(name):
     with open(os.path.join(GOLDEN, "expected", name)) as f:
         return f.read()
@@ -57,6 +73,9 @@ def test_yaml_and_csv_text(fixtures, kind, leaflets, errors, name):
             else st.results_tree(res, labels, kind, leaflets=leaflets, timewise=tw))
     same_items(writers.yaml_text(tree, header="# made here"), golden(name + ".yaml"), skip=1)
     same_items(writers.csv_text(tree), golden(name + ".csv"), sep=",")
+    same_tokens(writers.tab_text(tree), golden(name + ".tab"))
+    if not errors and (kind, leaflets) != ("ua", False) and (kind, leaflets) != ("cg", False):
+        same_tokens(writers.xvg_text(tree, "POPC", united=kind == "ua"), golden(name + "_POPC.xvg"))
 
 
 def test_csv_prints_nan_below_min_samples(fixtures):
