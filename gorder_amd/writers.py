@@ -201,3 +201,39 @@ def xvg_text(tree: dict, molecule: str, header: Optional[str] = None, united: bo
         vals = [entry[w]["mean"] if errors else entry[w] for w in which]
         out.append(f"{n:<4d} " + " ".join(f"{_fixed(v):>8s}" for v in vals) + " ")
     return "\n".join(out) + "\n"
+
+
+def convergence_text(timewise, labels, analysis: str, leaflets: bool, header: Optional[str] = None, step: int = 1) -> str:
+    """Convergence of the molecule types' average order parameters (TimeWiseData::prefix_average, timewise.rs:259-274;
+    presentation/convergence.rs): line n holds, per molecule type (and leaflet), the average over the first n analysed
+    frames — cumulative tick sum / cumulative sample count by the truncating integer division, sign as in the
+    other outputs.  `timewise` = (sums, counts) [frames][3][n_acc] as returned by the engines; `labels` as from
+    build_tables*; x = n * step."""
+    import numpy as np
+    sums, counts = (np.asarray(x) for x in timewise)
+    sign = -1.0 if analysis in ("aa", "ua") else 1.0
+    which = ["full", "upper", "lower"] if leaflets else [""]
+    out = [header or "# order parameters",
+           '@    title "Convergence of average order parameters for individual molecule types"',
+           '@    xaxis label "Frame number"',
+           f'@    yaxis label "{"-Sch" if analysis in ("aa", "ua") else "S"}"']
+    cols = []
+    for ml in labels:
+        n_slots = sum(c.n_h for c in ml.carbons) if hasattr(ml, "carbons") else len(ml.bonds)
+        sl = slice(ml.slot0, ml.slot0 + n_slots)
+        for w, name in enumerate(which):
+            out.append(f'@    s{len(cols)} legend "{(ml.name + " " + name).strip()}"')
+            cs = np.cumsum(sums[:, w, sl].sum(axis=1).astype(np.int64))
+            cn = np.cumsum(counts[:, w, sl].sum(axis=1).astype(np.int64))
+            col = []
+            for s_, n_ in zip(cs, cn):
+                if n_ == 0:
+                    col.append(float("nan"))
+                else:
+                    q = abs(int(s_)) // int(n_)
+                    col.append(sign * float(np.float32((-q if s_ < 0 else q) / 1e6)))
+            cols.append(col)
+    out.append("@TYPE xy")
+    for f in range(sums.shape[0]):
+        out.append(f"{(f + 1) * step:<4d} " + " ".join(f"{_fixed(c[f]):>8s}" for c in cols) + " ")
+    return "\n".join(out) + "\n"

@@ -132,7 +132,8 @@ if __name__ == "__main__":
               "aa_order_basic.tab", "aa_order_leaflets.tab", "cg_order_basic.tab", "cg_order_leaflets.tab",
               "ua_order_basic.tab", "ua_order_leaflets.tab", "aa_order_error.tab", "cg_order_error_leaflets.tab",
               "aa_order_basic_POPC.xvg", "aa_order_leaflets_POPC.xvg", "cg_order_leaflets_POPC.xvg",
-              "ua_order_leaflets_POPC.xvg"):
+              "ua_order_leaflets_POPC.xvg",
+              "aa_order_convergence.xvg", "aa_order_leaflets_convergence.xvg", "cg_order_convergence.xvg"):
         src = os.path.join(REF, f)
         if os.path.exists(src):
             shutil.copy(src, os.path.join(HERE, "expected", f))

@@ -71,3 +71,22 @@ def test_exported_dynamic_normals(fixtures):
         eng.submit_host(np.ascontiguousarray(fx.xyz[[f]][:, midx, :]), fx.boxes[[f]], [f])
         loose += check_normals(eng.normals()[0].astype(np.float64), want, labels, f)
     assert loose <= 30
+
+
+@pytest.mark.parametrize("kind,leaflets,name", [("aa", False, "aa_order_convergence.xvg"), ("aa", True, "aa_order_leaflets_convergence.xvg"),
+                                                ("cg", False, "cg_order_convergence.xvg")])
+def test_convergence_of_the_per_frame_rows(fixtures, kind, leaflets, name):
+    """The device's per-frame (timewise) rows reproduce the reference's convergence files frame by frame."""
+    from gorder_amd import writers
+    from golden_util import METHODS, aa_setup, cg_setup
+    from test_writers_cpu import golden, same_tokens
+    fx = fixtures["pcpepg" if kind == "aa" else "cg"]
+    setup = aa_setup if kind == "aa" else cg_setup
+    tables, labels, midx = setup(fx, leaflets=METHODS["global"] if leaflets else None, timewise=True)
+    frames = fx.window()
+    eng = HipEngine(tables)
+    xyz = np.ascontiguousarray(fx.xyz[frames][:, midx, :])
+    for a, b in ((0, 17), (17, 40), (40, len(frames))):
+        eng.submit_host(xyz[a:b], fx.boxes[frames][a:b], frames[a:b])
+    eng.finish()
+    same_tokens(writers.convergence_text(eng.timewise(len(frames)), labels, kind, leaflets), golden(name))

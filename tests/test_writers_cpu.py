@@ -89,3 +89,19 @@ def test_csv_prints_nan_below_min_samples(fixtures):
     assert "NaN" in text
     same_items(text, golden("aa_order_leaflets_limit.csv"), sep=",")
     assert ".nan" in writers.yaml_text(tree)
+
+
+@pytest.mark.parametrize("kind,leaflets,name", [("aa", False, "aa_order_convergence.xvg"), ("aa", True, "aa_order_leaflets_convergence.xvg"),
+                                                ("cg", False, "cg_order_convergence.xvg")])
+def test_convergence_of_the_per_frame_rows(fixtures, kind, leaflets, name):
+    """tests_aa.rs:2580-2630, tests_cg.rs: the running averages after every frame — pins the per-frame (timewise)
+    rows one frame at a time, not just their block statistics."""
+    fx = fixtures[kind]
+    setup = aa_setup if kind == "aa" else cg_setup
+    tables, labels, midx = setup(fx, leaflets=METHODS["global"] if leaflets else None, timewise=True)
+    frames = fx.window()
+    eng = oracle.OracleEngine(tables, trig=oracle.TRIG_LIBM, n_threads=4)
+    eng.submit(np.ascontiguousarray(fx.xyz[frames][:, midx, :]), fx.boxes[frames], frames)
+    eng.finish()
+    text = writers.convergence_text(eng.timewise(len(frames)), labels, kind, leaflets)
+    same_tokens(text, golden(name))
