@@ -208,7 +208,7 @@ def convergence_text(timewise, labels, analysis: str, leaflets: bool, header: Op
     presentation/convergence.rs): line n holds, per molecule type (and leaflet), the average over the first n analysed
     frames — cumulative tick sum / cumulative sample count by the truncating integer division, sign as in the
     other outputs.  `timewise` = (sums, counts) [frames][3][n_acc] as returned by the engines; `labels` as from
-    build_tables*; x = n * step."""
+    build_tables*; x = the frame's number in the trajectory, 1 + n * step."""
     import numpy as np
     sums, counts = (np.asarray(x) for x in timewise)
     sign = -1.0 if analysis in ("aa", "ua") else 1.0
@@ -235,5 +235,5 @@ def convergence_text(timewise, labels, analysis: str, leaflets: bool, header: Op
             cols.append(col)
     out.append("@TYPE xy")
     for f in range(sums.shape[0]):
-        out.append(f"{(f + 1) * step:<4d} " + " ".join(f"{_fixed(c[f]):>8s}" for c in cols) + " ")
+        out.append(f"{f * step + 1:<4d} " + " ".join(f"{_fixed(c[f]):>8s}" for c in cols) + " ")
     return "\n".join(out) + "\n"

@@ -133,7 +133,8 @@ if __name__ == "__main__":
               "ua_order_basic.tab", "ua_order_leaflets.tab", "aa_order_error.tab", "cg_order_error_leaflets.tab",
               "aa_order_basic_POPC.xvg", "aa_order_leaflets_POPC.xvg", "cg_order_leaflets_POPC.xvg",
               "ua_order_leaflets_POPC.xvg",
-              "aa_order_convergence.xvg", "aa_order_leaflets_convergence.xvg", "cg_order_convergence.xvg"):
+              "aa_order_convergence.xvg", "aa_order_leaflets_convergence.xvg", "cg_order_convergence.xvg",
+              "aa_order_convergence_s5.xvg"):
         src = os.path.join(REF, f)
         if os.path.exists(src):
             shutil.copy(src, os.path.join(HERE, "expected", f))

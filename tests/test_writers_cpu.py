@@ -105,3 +105,14 @@ def test_convergence_of_the_per_frame_rows(fixtures, kind, leaflets, name):
     eng.finish()
     text = writers.convergence_text(eng.timewise(len(frames)), labels, kind, leaflets)
     same_tokens(text, golden(name))
+
+
+def test_convergence_with_a_step(fixtures):
+    # tests_aa.rs:2657-2680: every fifth frame; the x column keeps the frame numbers of the trajectory
+    fx = fixtures["aa"]
+    tables, labels, midx = aa_setup(fx, timewise=True)
+    frames = fx.window(None, None, 5)
+    eng = oracle.OracleEngine(tables, trig=oracle.TRIG_LIBM, n_threads=4)
+    eng.submit(np.ascontiguousarray(fx.xyz[frames][:, midx, :]), fx.boxes[frames], np.arange(len(frames)) * 5)
+    eng.finish()
+    same_tokens(writers.convergence_text(eng.timewise(len(frames)), labels, "aa", False, step=5), golden("aa_order_convergence_s5.xvg"))
