@@ -83,6 +83,18 @@ class CTables(C.Structure):
                 ("dynamic_normal", CDynamicNormal)]
 
 
+class CTrajectory(C.Structure):
+    _fields_ = [("paths", C.POINTER(C.c_char_p)), ("n_paths", C.c_uint32), ("group", _u32p), ("n_group", C.c_uint32),
+                ("begin_ps", C.c_float), ("end_ps", C.c_float), ("step", C.c_uint32), ("n_threads", C.c_uint32),
+                ("batch_frames", C.c_uint32), ("first_frame_index", C.c_uint64)]
+
+
+class CTrajectoryStats(C.Structure):
+    _fields_ = [("n_frames", C.c_uint64), ("n_batches", C.c_uint64), ("bytes_h2d", C.c_uint64),
+                ("seconds_total", C.c_double), ("seconds_decode", C.c_double), ("seconds_reader_stalled", C.c_double),
+                ("seconds_gpu_starved", C.c_double), ("batch_frames", C.c_uint32), ("decoder_threads", C.c_uint32)]
+
+
 class CPlan(C.Structure):
     _fields_ = [("n_tiles", C.c_uint32), ("block_threads", C.c_uint32),
                 ("max_window_atoms", C.c_uint32), ("n_direct_items", C.c_uint32),
@@ -284,7 +296,9 @@ _EXPORTS = [
     "gorder_hip_normals", "gorder_hip_export_maps", "gorder_hip_set_normals",
     "gorder_hip_accumulators_device", "gorder_hip_bind_accumulators", "gorder_hip_last_error_index",
     "gorder_hip_last_error_message", "gorder_hip_strerror", "gorder_hip_kernel_time", "gorder_hip_plan",
-    "gorder_hip_plan_tables", "gorder_hip_selftest_arithmetic",
+    "gorder_hip_plan_tables", "gorder_hip_selftest_arithmetic", "gorder_hip_run_trajectory",
+    "gorder_hip_comm_unique_id", "gorder_hip_comm_create", "gorder_hip_comm_destroy", "gorder_hip_allreduce",
+    "gorder_hip_reset",
 ]
 
 _lib = None
@@ -349,6 +363,13 @@ def load_library() -> C.CDLL:
     lib.gorder_hip_plan.argtypes = [vp, C.POINTER(CPlan)]
     lib.gorder_hip_plan_tables.argtypes = [C.POINTER(CTables), C.POINTER(CPlan), C.POINTER(i32)]
     lib.gorder_hip_selftest_arithmetic.argtypes = [i32, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.gorder_hip_run_trajectory.argtypes = [vp, C.POINTER(CTrajectory), C.POINTER(CTrajectoryStats)]
+    lib.gorder_hip_comm_unique_id.argtypes = [vp]
+    lib.gorder_hip_comm_create.argtypes = [vp, vp, i32, i32, C.POINTER(vp)]
+    lib.gorder_hip_comm_destroy.argtypes = [vp]
+    lib.gorder_hip_comm_destroy.restype = None
+    lib.gorder_hip_allreduce.argtypes = [vp, vp]
+    lib.gorder_hip_reset.argtypes = [vp]
     _lib = lib
     return lib
 
@@ -480,6 +501,53 @@ class HipEngine:
             bp = box.ctypes.data_as(C.c_void_p)
         self._check(self.lib.gorder_hip_submit_host(self._h, xyz.ctypes.data_as(C.c_void_p), bp,
                                                     fi.ctypes.data_as(C.c_void_p), n_frames))
+
+    def run_trajectory(self, paths, group=None, begin: float = 0.0, end: float = -1.0, step: int = 1, threads: int = 0,
+                       batch_frames: int = 0, first_frame_index: int = 0) -> dict:
+        """The reference's `read_trajectory` (common.rs:239-342) as one library call: read (and concatenate) the
+        files, apply the time window / step, decode on `threads` host threads and analyse batch by batch with copies
+        and kernels overlapped (gorder_hip_run_trajectory).  -> the pipeline's statistics."""
+        arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+        grp = None if group is None else np.ascontiguousarray(group, dtype=np.uint32)
+        t = CTrajectory()
+        t.paths = C.cast(arr, C.POINTER(C.c_char_p))
+        t.n_paths = len(paths)
+        t.group = _ptr(grp)
+        t.n_group = 0 if grp is None else grp.size
+        t.begin_ps, t.end_ps, t.step = begin, end, step
+        t.n_threads, t.batch_frames, t.first_frame_index = threads, batch_frames, first_frame_index
+        stats = CTrajectoryStats()
+        self._check(self.lib.gorder_hip_run_trajectory(self._h, C.byref(t), C.byref(stats)))
+        return {name: getattr(stats, name) for name, _ in CTrajectoryStats._fields_}
+
+    def reset(self):
+        """A fresh SystemTopology on the same tables (gorder_hip_reset)."""
+        self._check(self.lib.gorder_hip_reset(self._h))
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """Rank 0: the 128-byte RCCL id the other ranks need for comm_create (ship it over any channel)."""
+        lib = load_library()
+        buf = (C.c_uint8 * 128)()
+        st = lib.gorder_hip_comm_unique_id(buf)
+        if st != OK:
+            raise GorderHipError(st, "ncclGetUniqueId failed (is RCCL loadable?)")
+        return bytes(buf)
+
+    def comm_create(self, unique_id: bytes, n_ranks: int, rank: int):
+        """An RCCL communicator (ncclComm_t) on this handle's device -> opaque pointer for allreduce()."""
+        assert len(unique_id) == 128
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        comm = C.c_void_p()
+        self._check(self.lib.gorder_hip_comm_create(self._h, buf, n_ranks, rank, C.byref(comm)))
+        return comm
+
+    def comm_destroy(self, comm):
+        self.lib.gorder_hip_comm_destroy(comm)
+
+    def allreduce(self, comm):
+        """SystemTopology::reduce across the ranks of `comm`: one group of RCCL all-reduces issued by the library."""
+        self._check(self.lib.gorder_hip_allreduce(self._h, comm))
 
     def prime_leaflets_device(self, xyz, box, frame_index: int):
         bp = C.c_void_p(box.data_ptr()) if box is not None else None

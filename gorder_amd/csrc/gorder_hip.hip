@@ -18,6 +18,8 @@
 // Built for gfx950 only.  No CPU fallback: without a device every entry point fails loudly.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -118,9 +120,13 @@ struct gorder_hip_handle {
     size_t arow_cap = 0, aframes_cap = 0;
     bool have_assignment = false;
     uint64_t assignment_frame = 0;
-    // host staging for submit_host
-    float *d_stage_xyz = nullptr, *d_stage_box = nullptr;
-    size_t stage_xyz_cap = 0, stage_box_cap = 0;
+    // host staging for submit_host: two device buffers, filled on a copy stream while the kernels of the other one run
+    float *d_stage_xyz[2] = {nullptr, nullptr}, *d_stage_box[2] = {nullptr, nullptr};
+    size_t stage_xyz_cap[2] = {0, 0}, stage_box_cap[2] = {0, 0};
+    hipEvent_t stage_copied[2] = {nullptr, nullptr}, stage_computed[2] = {nullptr, nullptr};
+    bool stage_used[2] = {false, false};
+    int stage_next = 0;
+    hipStream_t copy_stream = nullptr;
     float n2 = 1.0f, n2sq = 1.0f;
     int axis = -1;   // 0/1/2 when the static normal is exactly that unit axis (kernel specialisation)
     int frames_per_stage = kFramesPerStage;   // G (2, 4 or 8); GORDER_HIP_FRAMES_PER_STAGE overrides
@@ -133,9 +139,18 @@ struct gorder_hip_handle {
     uint64_t n_frames = 0;
     uint64_t err_index = 0;
     std::string err_msg;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> timing;
+    // kernel timing (gorder_hip_kernel_time): OFF until the host asks for it once; then a fixed ring of event pairs
+    // that is drained (oldest first) when it runs full — nothing grows with the length of the trajectory
+    static constexpr uint32_t kTimingRing = 64;
+    bool timing_on = false;
+    hipEvent_t timing_ev[kTimingRing][2] = {};
+    uint32_t timing_head = 0, timing_count = 0;   // pairs [head - count, head) are recorded and not yet read
     double timing_ms = 0.0;
     uint64_t timing_launches = 0;
+    // host copies behind the payload of gorder_hip_last_error_index
+    std::vector<uint32_t> host_heads, host_dyn_heads;
+    uint32_t *d_mol_slot0 = nullptr;
+    uint64_t err_frame = 0;
 };
 
 namespace {
@@ -177,16 +192,82 @@ bool should_assign(uint32_t frequency, uint64_t frame) {   // leaflets.rs:435-44
     return frequency == 0 ? frame == 0 : (frame % frequency) == 0;
 }
 
+// (slot, molecule, which atom) of an order sample -> atom index in the frame (the payload of UndefinedPosition,
+// errors.rs:136).  Error path only: a linear walk over the plan.
+uint32_t sample_atom(const Plan &p, uint32_t slot, uint32_t mol, uint32_t which) {
+    for (const Tile &t : p.tiles)
+        for (uint32_t q = 0; q < t.n_items; q++) {
+            const Item &it = p.items[t.item0 + q];
+            if (it.mol == mol && p.tile_slots[t.slot0 + it.lslot] == slot) return t.atom0 + (which ? it.lj : it.li);
+        }
+    for (const DirectItem &d : p.direct)
+        if (d.mol == mol && d.slot == slot) return which ? d.j : d.i;
+    for (const Tile &t : p.ua_tiles)
+        for (uint32_t q = 0; q < t.n_items; q++) {
+            const gorder::UaItem &it = p.ua_items[t.item0 + q];
+            if (it.mol == mol && p.ua_tile_slots[t.slot0 + it.lslot0] == slot) return t.atom0 + it.l[which & 3u];
+        }
+    return 0;
+}
+
+// Decode the device's error key (kernels_common.h, raise_error): status, frame, payload.
 int check_device_error(gorder_hip_handle *h) {
-    uint32_t e[kErrWords];
-    HIP_TRY(h, hipMemcpy(e, h->d_err, sizeof(e), hipMemcpyDeviceToHost));
-    if (e[0] == 0) return GORDER_OK;
-    h->err_index = e[1];
+    unsigned long long key = kErrNone;
+    HIP_TRY(h, hipMemcpy(&key, h->d_err, sizeof(key), hipMemcpyDeviceToHost));
+    if (key == kErrNone) return GORDER_OK;
+    const uint32_t code = (uint32_t)(key & 15u), detail = (uint32_t)(key >> 4) & 3u, mol = (uint32_t)(key >> 6) & 0x1ffffu;
+    const uint32_t sample = (uint32_t)(key >> 23) & 1u, slot = (uint32_t)(key >> 24) & 0x3fffu;
+    const uint32_t stage = (uint32_t)(key >> 38) & 3u, frame = (uint32_t)(key >> 40) & 0x7fffffu;
+    const int status = code == 8u ? (int)GORDER_ERR_BOX_RANGE : (int)code;
+    h->err_frame = frame;
+    h->err_index = 0;
+    if (status == GORDER_ERR_UNDEFINED_POSITION) {
+        if (stage == kStageTypes && sample) h->err_index = sample_atom(h->plan, slot, mol, detail);
+        else if (mol < h->host_dyn_heads.size()) h->err_index = h->host_dyn_heads[mol];   // head of a dynamic-normal cloud
+    } else if (status == GORDER_ERR_INVALID_LOCAL_MEMBRANE_CENTER) {
+        if (mol < h->host_heads.size()) h->err_index = h->host_heads[mol];                // leaflets.rs:661-675: the head's index
+    } else if (status == GORDER_ERR_DYNAMIC_NORMAL) {
+        h->err_index = detail;                                                             // NotEnoughPoints(n)
+    }
     char buf[160];
-    snprintf(buf, sizeof(buf), "device raised %s (payload %u) in batch frame %u", gorder_hip_strerror((int)e[0]),
-             e[1], e[2]);
+    snprintf(buf, sizeof(buf), "device raised %s (payload %llu) in batch frame %u", gorder_hip_strerror(status),
+             (unsigned long long)h->err_index, frame);
     h->err_msg = buf;
-    return (int)e[0];
+    return status;
+}
+
+// ---- kernel timing ring (see gorder_hip_handle::timing_ev) ---------------------------------------------
+int timing_drain_oldest(gorder_hip_handle *h) {
+    const uint32_t slot = (h->timing_head + gorder_hip_handle::kTimingRing - h->timing_count) % gorder_hip_handle::kTimingRing;
+    float t = 0.0f;
+    HIP_TRY(h, hipEventSynchronize(h->timing_ev[slot][1]));
+    HIP_TRY(h, hipEventElapsedTime(&t, h->timing_ev[slot][0], h->timing_ev[slot][1]));
+    h->timing_ms += t;
+    h->timing_count--;
+    return GORDER_OK;
+}
+// the next free pair (events are created on first use and then reused), or -1 when timing is off
+int timing_begin(gorder_hip_handle *h, int *slot_out) {
+    *slot_out = -1;
+    if (!h->timing_on) return GORDER_OK;
+    if (h->timing_count == gorder_hip_handle::kTimingRing) {
+        const int st = timing_drain_oldest(h);
+        if (st != GORDER_OK) return st;
+    }
+    const uint32_t slot = h->timing_head;
+    for (int k = 0; k < 2; k++)
+        if (!h->timing_ev[slot][k]) HIP_TRY(h, hipEventCreate(&h->timing_ev[slot][k]));
+    HIP_TRY(h, hipEventRecord(h->timing_ev[slot][0], h->stream));
+    *slot_out = (int)slot;
+    return GORDER_OK;
+}
+int timing_end(gorder_hip_handle *h, int slot) {
+    if (slot < 0) return GORDER_OK;
+    HIP_TRY(h, hipEventRecord(h->timing_ev[slot][1], h->stream));
+    h->timing_head = (h->timing_head + 1) % gorder_hip_handle::kTimingRing;   // only a completed pair enters the ring
+    h->timing_count++;
+    h->timing_launches++;
+    return GORDER_OK;
 }
 
 bool env_flag(const char *name) {
@@ -253,10 +334,11 @@ int run_dynamic_normals(gorder_hip_handle *h, const FrameArgs &a) {
 int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
     const Plan &p = h->plan;
     const uint32_t n_tiles = (uint32_t)p.tiles.size();
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    HIP_TRY(h, hipEventCreate(&e0));
-    HIP_TRY(h, hipEventCreate(&e1));
-    HIP_TRY(h, hipEventRecord(e0, h->stream));
+    int tslot = -1;
+    {
+        const int st0 = timing_begin(h, &tslot);
+        if (st0 != GORDER_OK) return st0;
+    }
     const bool extras = h->extra.maps || h->extra.tw || h->extra.geom_kind || h->dyn || h->manual_active;
     if (h->dyn && !h->manual_active) {
         const int st2 = run_dynamic_normals(h, a);
@@ -459,13 +541,61 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
     }
     hipLaunchKernelGGL(k_count_frames, dim3(1), dim3(1), 0, h->stream, a.acc + 4 * (size_t)a.n_acc, a.n_frames);
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipEventRecord(e1, h->stream));
-    h->timing.emplace_back(e0, e1);
-    h->timing_launches += 1;
-    return GORDER_OK;
+    return timing_end(h, tslot);
 }
 
 }  // namespace
+
+// ---- RCCL: SystemTopology::reduce across the GPUs of a node (topology/mod.rs:256-272) -----------------------------
+// The library does not link RCCL: the few entry points are bound at the first call (dlopen by SONAME, so a process
+// that already holds RCCL — e.g. through PyTorch — shares that copy; otherwise /opt/rocm's).
+namespace {
+struct UniqueId { char internal[128]; };     // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
+struct RcclApi {
+    void *lib = nullptr;
+    int (*get_unique_id)(void *) = nullptr;
+    int (*comm_init_rank)(void **, int, UniqueId /* ncclUniqueId, by value */, int) = nullptr;
+    int (*comm_destroy)(void *) = nullptr;
+    int (*all_reduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*group_start)() = nullptr;
+    int (*group_end)() = nullptr;
+    const char *(*get_error_string)(int) = nullptr;
+};
+constexpr int kNcclInt64 = 4, kNcclSum = 0;   // ncclDataType_t / ncclRedOp_t values of rccl.h
+RcclApi *rccl_api(std::string *why) {
+    static RcclApi api;
+    static bool tried = false;
+    static std::string err;
+    if (!tried) {
+        tried = true;
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names)
+            if ((api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!api.lib) {
+            err = std::string("cannot load RCCL: ") + dlerror();
+        } else {
+            api.get_unique_id = (decltype(api.get_unique_id))dlsym(api.lib, "ncclGetUniqueId");
+            api.comm_init_rank = (decltype(api.comm_init_rank))dlsym(api.lib, "ncclCommInitRank");
+            api.comm_destroy = (decltype(api.comm_destroy))dlsym(api.lib, "ncclCommDestroy");
+            api.all_reduce = (decltype(api.all_reduce))dlsym(api.lib, "ncclAllReduce");
+            api.group_start = (decltype(api.group_start))dlsym(api.lib, "ncclGroupStart");
+            api.group_end = (decltype(api.group_end))dlsym(api.lib, "ncclGroupEnd");
+            api.get_error_string = (decltype(api.get_error_string))dlsym(api.lib, "ncclGetErrorString");
+            if (!api.get_unique_id || !api.comm_init_rank || !api.comm_destroy || !api.all_reduce || !api.group_start ||
+                !api.group_end) {
+                err = "RCCL library lacks an expected entry point";
+                api.lib = nullptr;
+            }
+        }
+    }
+    if (!api.lib) { if (why) *why = err; return nullptr; }
+    return &api;
+}
+std::string rccl_error(const RcclApi *api, const char *what, int rc) {
+    return std::string(what) + ": " + (api->get_error_string ? api->get_error_string(rc) : "RCCL error") + " (" + std::to_string(rc) + ")";
+}
+}  // namespace
+
 
 extern "C" {
 
@@ -582,6 +712,8 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
     int st = gorder::build_plan(*t, env_flag("GORDER_HIP_FORCE_DIRECT"), h->plan);
     if (st != GORDER_OK) return fail(h, st, "invalid bond tables");
     const Plan &p = h->plan;
+    for (uint32_t m = 0; m < t->n_molecule_types; m++)
+        h->map_max_mol = std::max(h->map_max_mol, t->molecule_types[m].n_molecules);
     HIP_TRY(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
     if ((st = upload(h, &h->d_tiles, p.tiles)) != GORDER_OK) return st;
@@ -617,8 +749,6 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
             const size_t npk = (t->leaflets.method != GORDER_LEAFLETS_NONE ? 2 : 1) * (nmap / 3);
             HIP_TRY(h, hipMalloc((void **)&h->d_map_packed, npk * sizeof(unsigned long long)));
             HIP_TRY(h, hipMemset(h->d_map_packed, 0, npk * sizeof(unsigned long long)));
-            for (uint32_t m = 0; m < t->n_molecule_types; m++)
-                h->map_max_mol = std::max(h->map_max_mol, t->molecule_types[m].n_molecules);
             // united atoms: stage + accumulate in LDS when one slot's packed map (x2 with leaflets) fits
             const size_t lds_bytes = npk / p.n_acc * sizeof(unsigned long long);
             if (lds_bytes <= 150u * 1024u && !env_flag("GORDER_HIP_MAP_DIRECT")) {
@@ -663,7 +793,7 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
                         "ordermaps / timewise / geometry need every bond to fit an atom window");
     }
     HIP_TRY(h, hipMalloc((void **)&h->d_err, kErrWords * sizeof(uint32_t)));
-    HIP_TRY(h, hipMemset(h->d_err, 0, kErrWords * sizeof(uint32_t)));
+    HIP_TRY(h, hipMemset(h->d_err, 0xff, kErrWords * sizeof(uint32_t)));   // kErrNone
     h->acc_words = 4 * (size_t)p.n_acc + 1;
     HIP_TRY(h, hipMalloc((void **)&h->d_acc, h->acc_words * sizeof(unsigned long long)));
     HIP_TRY(h, hipMemset(h->d_acc, 0, h->acc_words * sizeof(unsigned long long)));
@@ -699,6 +829,10 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
     }
     h->lw = ((3u * p.max_window + 3u + 3u) / 4u) * 4u;
     h->lds_bytes = (size_t)h->frames_per_stage * h->lw * sizeof(float);
+    if (h->frames_per_stage == 8 && h->lds_bytes > 64u * 1024u) {   // wide windows: 8 staged frames exceed the 64 KB a
+        h->frames_per_stage = 4;                                    // launch gets without opting in; 4 always fit (48 KB)
+        h->lds_bytes = (size_t)h->frames_per_stage * h->lw * sizeof(float);
+    }
     if (h->lds_bytes < (size_t)kBlock * 24) h->lds_bytes = (size_t)kBlock * 24;
     {   // how many workgroups of the tiled kernel are co-resident: the frame range of a batch is cut so
         // that the grid is a whole number of such rounds (no half-empty last round)
@@ -734,6 +868,7 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
         }
         if ((st = upload(h, &h->d_dyn_cloud, cloud)) != GORDER_OK) return st;
         if ((st = upload(h, &h->d_dyn_heads, nheads)) != GORDER_OK) return st;
+        h->host_dyn_heads = nheads;
         const size_t nm = dn.n_cloud, ncell = (size_t)kLocalMaxCells1D * kLocalMaxCells1D;
         const size_t sl = h->dyn_slab = local_slab_frames(nm);
         HIP_TRY(h, hipMalloc((void **)&h->d_dyn_cell_of, sl * nm * sizeof(uint32_t)));
@@ -767,6 +902,12 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
             }
         }
         if ((st = upload(h, &h->d_heads, heads)) != GORDER_OK) return st;
+        h->host_heads = heads;
+        if (lf.method == GORDER_LEAFLETS_LOCAL) {   // error key of a failed local centre: first slot of the molecule's type
+            std::vector<uint32_t> ms;
+            for (uint32_t m = 0; m < t->n_molecule_types; m++) ms.insert(ms.end(), t->molecule_types[m].n_molecules, p.slot0[m]);
+            if ((st = upload(h, &h->d_mol_slot0, ms)) != GORDER_OK) return st;
+        }
         if ((st = upload(h, &h->d_methyl_begin, mb)) != GORDER_OK) return st;
         if ((st = upload(h, &h->d_methyl_atoms, ma)) != GORDER_OK) return st;
         if (lf.method == GORDER_LEAFLETS_LOCAL && !(lf.radius > 0.0f))
@@ -802,7 +943,10 @@ void gorder_hip_destroy(gorder_hip_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    for (auto &ev : h->timing) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (auto &pair : h->timing_ev)
+        for (hipEvent_t ev : pair)
+            if (ev) (void)hipEventDestroy(ev);
+    (void)hipFree(h->d_mol_slot0);
     (void)hipFree(h->d_tiles); (void)hipFree(h->d_items); (void)hipFree(h->d_tile_slots);
     (void)hipFree(h->d_direct); (void)hipFree(h->d_err);
     (void)hipFree(h->d_ua_tiles); (void)hipFree(h->d_ua_items); (void)hipFree(h->d_ua_tile_slots);
@@ -820,7 +964,12 @@ void gorder_hip_destroy(gorder_hip_handle *h) {
     (void)hipFree(h->d_arow); (void)hipFree(h->d_aframes);
     (void)hipFree(h->d_lcell_of); (void)hipFree(h->d_lcell_count); (void)hipFree(h->d_lcell_fill);
     (void)hipFree(h->d_lcell_atoms); (void)hipFree(h->d_ltrig);
-    (void)hipFree(h->d_stage_xyz); (void)hipFree(h->d_stage_box);
+    for (int k = 0; k < 2; k++) {
+        (void)hipFree(h->d_stage_xyz[k]); (void)hipFree(h->d_stage_box[k]);
+        if (h->stage_copied[k]) (void)hipEventDestroy(h->stage_copied[k]);
+        if (h->stage_computed[k]) (void)hipEventDestroy(h->stage_computed[k]);
+    }
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
@@ -834,6 +983,7 @@ uint32_t gorder_hip_ordermap_dims(const gorder_hip_handle *h, uint32_t *nx, uint
 
 int gorder_hip_set_stream(gorder_hip_handle *h, void *hip_stream) {
     if (!h) return GORDER_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
     return GORDER_OK;
@@ -897,7 +1047,7 @@ static int run_leaflets(gorder_hip_handle *h, const float *d_xyz, const float *d
         LocalArgs lo{};
         lo.xyz = d_xyz; lo.box9 = d_box; lo.n_atoms = h->plan.n_atoms;
         lo.aflags = h->d_aflags; lo.adist = h->d_adist; lo.n_mol_total = h->plan.n_mol_total;
-        lo.heads = h->d_heads; lo.membrane = h->d_membrane; lo.n_membrane = lf.n_membrane;
+        lo.heads = h->d_heads; lo.mol_slot0 = h->d_mol_slot0; lo.membrane = h->d_membrane; lo.n_membrane = lf.n_membrane;
         lo.dim = lf.normal_dim; lo.flip = lf.flip ? 1 : 0; lo.pbc = h->tables.handle_pbc ? 1 : 0;
         lo.radius = lf.radius;
         lo.radius_thr = local_radius_threshold(lf.radius);
@@ -934,6 +1084,11 @@ int gorder_hip_submit_device(gorder_hip_handle *h, const float *d_xyz, const flo
     const Plan &p = h->plan;
     const gorder_leaflets_t &lf = h->tables.leaflets;
     int st;
+    // OrderValue is a checked i64 (order.rs:44-60 panics on overflow).  |tick| <= 1e6 and a slot receives at most one
+    // sample per molecule of its type and frame, so no sum can overflow while frames * molecules stays below 2^63 / 1e6:
+    // refuse the batch that would cross that bound instead of wrapping silently.
+    if ((h->n_frames + n_frames) > (uint64_t)(9223372036854775807ll / 1000000ll) / h->map_max_mol)
+        return fail(h, GORDER_ERR_OVERFLOW, "order accumulators could overflow i64 (frames x molecules >= 2^63 / 1e6)");
 
     // ---- leaflet assignment rows of this batch; row 0 = assignment carried over from earlier
     // batches (AssignedLeaflets::local, leaflets.rs:1371-1380), rows 1.. = assignment frames here
@@ -1042,22 +1197,45 @@ int gorder_hip_submit_host(gorder_hip_handle *h, const float *xyz, const float *
     HIP_TRY(h, hipSetDevice(h->device));
     int st;
     const size_t nx = (size_t)n_frames * h->plan.n_atoms * 3u, nb = (size_t)n_frames * 9u;
-    // the staging buffer may still be read by kernels of the previous batch
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    if ((st = ensure(h, &h->d_stage_xyz, &h->stage_xyz_cap, nx)) != GORDER_OK) return st;
-    HIP_TRY(h, hipMemcpyAsync(h->d_stage_xyz, xyz, nx * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    if (box) {
-        if ((st = ensure(h, &h->d_stage_box, &h->stage_box_cap, nb)) != GORDER_OK) return st;
-        HIP_TRY(h, hipMemcpyAsync(h->d_stage_box, box, nb * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (!h->copy_stream) {
+        HIP_TRY(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; k++) {
+            HIP_TRY(h, hipEventCreateWithFlags(&h->stage_copied[k], hipEventDisableTiming));
+            HIP_TRY(h, hipEventCreateWithFlags(&h->stage_computed[k], hipEventDisableTiming));
+        }
     }
-    return gorder_hip_submit_device(h, h->d_stage_xyz, box ? h->d_stage_box : nullptr, frame_index, n_frames);
+    const int b = h->stage_next;
+    h->stage_next ^= 1;
+    // this buffer was last read by the kernels of two calls ago (normally long finished); the kernels of the
+    // previous call keep running on the other buffer while this copy is in flight
+    if (h->stage_used[b]) HIP_TRY(h, hipEventSynchronize(h->stage_computed[b]));
+    if ((st = ensure(h, &h->d_stage_xyz[b], &h->stage_xyz_cap[b], nx)) != GORDER_OK) return st;
+    HIP_TRY(h, hipMemcpyAsync(h->d_stage_xyz[b], xyz, nx * sizeof(float), hipMemcpyHostToDevice, h->copy_stream));
+    if (box) {
+        if ((st = ensure(h, &h->d_stage_box[b], &h->stage_box_cap[b], nb)) != GORDER_OK) return st;
+        HIP_TRY(h, hipMemcpyAsync(h->d_stage_box[b], box, nb * sizeof(float), hipMemcpyHostToDevice, h->copy_stream));
+    }
+    HIP_TRY(h, hipEventRecord(h->stage_copied[b], h->copy_stream));
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->stage_copied[b], 0));
+    st = gorder_hip_submit_device(h, h->d_stage_xyz[b], box ? h->d_stage_box[b] : nullptr, frame_index, n_frames);
+    if (st != GORDER_OK) return st;
+    HIP_TRY(h, hipEventRecord(h->stage_computed[b], h->stream));
+    h->stage_used[b] = true;
+    // the caller owns its buffer again when this returns
+    HIP_TRY(h, hipEventSynchronize(h->stage_copied[b]));
+    return GORDER_OK;
 }
 
 int gorder_hip_prime_leaflets(gorder_hip_handle *h, const float *d_xyz, const float *d_box, uint64_t frame_index) {
     if (!h || !d_xyz) return GORDER_ERR_INVALID_ARGUMENT;
     const gorder_leaflets_t &lf = h->tables.leaflets;
     if (lf.method == GORDER_LEAFLETS_NONE || lf.method == GORDER_LEAFLETS_MANUAL) return GORDER_ERR_INVALID_ARGUMENT;
+    if (h->tables.handle_pbc && !d_box) return fail(h, GORDER_ERR_INVALID_ARGUMENT, "box required when handle_pbc = 1");
     HIP_TRY(h, hipSetDevice(h->device));
+    if (h->tables.handle_pbc) {   // the priming frame goes through check_box like any analysed frame (common.rs:186-198)
+        hipLaunchKernelGGL(k_check_box, dim3(1), dim3(256), 0, h->stream, d_box, 1u, h->d_err);
+        HIP_TRY(h, hipGetLastError());
+    }
     if (h->aflags_rows < 2) {
         uint8_t *nb = nullptr;
         HIP_TRY(h, hipMalloc((void **)&nb, 2 * (size_t)h->plan.n_mol_total));
@@ -1101,6 +1279,7 @@ int gorder_hip_synchronize(gorder_hip_handle *h) {
 int gorder_hip_finish(gorder_hip_handle *h, int64_t *sums, uint64_t *counts, int64_t *map_sums,
                       uint64_t *map_counts, uint64_t *n_frames_analyzed) {
     if (!h) return GORDER_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
     int st = fold_replicas(h);
     if (st != GORDER_OK) return st;
     if ((st = fold_maps(h)) != GORDER_OK) return st;
@@ -1193,6 +1372,7 @@ int gorder_hip_leaflet_distances(gorder_hip_handle *h, float *dist) {
 
 int gorder_hip_accumulators_device(gorder_hip_handle *h, void **d_ptr, uint64_t *n_u64) {
     if (!h || !d_ptr || !n_u64) return GORDER_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
     {   // the packed block must be complete before a collective reads it (stream-ordered)
         const int st = fold_replicas(h);
         if (st != GORDER_OK) return st;
@@ -1230,21 +1410,102 @@ int gorder_hip_bind_accumulators(gorder_hip_handle *h, void *d_ptr, uint64_t n_u
     return GORDER_OK;
 }
 
+// ---- a fresh SystemTopology on the same tables --------------------------------------------------------------------
+int gorder_hip_reset(gorder_hip_handle *h) {
+    if (!h) return GORDER_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const Plan &p = h->plan;
+    HIP_TRY(h, hipMemsetAsync(h->d_acc, 0, h->acc_words * sizeof(unsigned long long), h->stream));
+    if (h->d_rep) HIP_TRY(h, hipMemsetAsync(h->d_rep, 0, (size_t)h->n_rep * 4u * p.n_acc * sizeof(unsigned long long), h->stream));
+    h->rep_dirty = false;
+    if (h->extra.maps) {
+        const size_t nmap = 3 * (size_t)p.n_acc * h->map_nx * h->map_ny;
+        const size_t npk = (h->tables.leaflets.method != GORDER_LEAFLETS_NONE ? 2 : 1) * (nmap / 3);
+        HIP_TRY(h, hipMemsetAsync(h->d_map_sums, 0, nmap * sizeof(unsigned long long), h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->d_map_cnts, 0, nmap * sizeof(unsigned long long), h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->d_map_packed, 0, npk * sizeof(unsigned long long), h->stream));
+        h->map_pending = 0;
+    }
+    if (h->d_tw_sums) {
+        const size_t n = h->tw_cap * 3 * (size_t)p.n_acc * sizeof(unsigned long long);
+        HIP_TRY(h, hipMemsetAsync(h->d_tw_sums, 0, n, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->d_tw_cnts, 0, n, h->stream));
+    }
+    HIP_TRY(h, hipMemsetAsync(h->d_err, 0xff, kErrWords * sizeof(uint32_t), h->stream));
+    h->n_frames = 0;
+    h->have_assignment = false;
+    h->assignment_frame = 0;
+    h->manual_frames = 0;
+    h->err_index = 0;
+    h->err_msg.clear();
+    return GORDER_OK;
+}
+
+int gorder_hip_comm_unique_id(uint8_t id[128]) {
+    if (!id) return GORDER_ERR_INVALID_ARGUMENT;
+    RcclApi *api = rccl_api(nullptr);
+    if (!api) return GORDER_ERR_DEVICE;
+    UniqueId u;
+    if (api->get_unique_id(&u) != 0) return GORDER_ERR_DEVICE;
+    memcpy(id, u.internal, 128);
+    return GORDER_OK;
+}
+
+int gorder_hip_comm_create(gorder_hip_handle *h, const uint8_t id[128], int n_ranks, int rank, void **comm_out) {
+    if (!h || !id || !comm_out || n_ranks < 1 || rank < 0 || rank >= n_ranks) return GORDER_ERR_INVALID_ARGUMENT;
+    *comm_out = nullptr;
+    std::string why;
+    RcclApi *api = rccl_api(&why);
+    if (!api) return fail(h, GORDER_ERR_DEVICE, why);
+    HIP_TRY(h, hipSetDevice(h->device));
+    UniqueId u;
+    memcpy(u.internal, id, 128);
+    const int rc = api->comm_init_rank(comm_out, n_ranks, u, rank);
+    if (rc != 0) return fail(h, GORDER_ERR_DEVICE, rccl_error(api, "ncclCommInitRank", rc));
+    return GORDER_OK;
+}
+
+void gorder_hip_comm_destroy(void *comm) {
+    RcclApi *api = rccl_api(nullptr);
+    if (api && comm) (void)api->comm_destroy(comm);
+}
+
+int gorder_hip_allreduce(gorder_hip_handle *h, void *nccl_comm) {
+    if (!h || !nccl_comm) return GORDER_ERR_INVALID_ARGUMENT;
+    std::string why;
+    RcclApi *api = rccl_api(&why);
+    if (!api) return fail(h, GORDER_ERR_DEVICE, why);
+    HIP_TRY(h, hipSetDevice(h->device));
+    int st = fold_replicas(h);
+    if (st != GORDER_OK) return st;
+    if ((st = fold_maps(h)) != GORDER_OK) return st;
+    // everything that SystemTopology::add sums (topology/mod.rs:236-254) in one group on the handle's stream: the packed
+    // accumulator block (order sums, counts, total_frames) and, with ordermaps, the folded i64 / u64 maps (Map::add,
+    // ordermap.rs:116-138).  Integer sums: the result is bit-identical whatever the ring order.
+    int rc = api->group_start();
+    if (rc == 0) rc = api->all_reduce(h->d_acc, h->d_acc, h->acc_words, kNcclInt64, kNcclSum, nccl_comm, h->stream);
+    if (rc == 0 && h->extra.maps) {
+        const size_t nmap = 3 * (size_t)h->plan.n_acc * h->map_nx * h->map_ny;
+        rc = api->all_reduce(h->d_map_sums, h->d_map_sums, nmap, kNcclInt64, kNcclSum, nccl_comm, h->stream);
+        if (rc == 0) rc = api->all_reduce(h->d_map_cnts, h->d_map_cnts, nmap, kNcclInt64, kNcclSum, nccl_comm, h->stream);
+    }
+    const int rc_end = api->group_end();
+    if (rc == 0) rc = rc_end;
+    if (rc != 0) return fail(h, GORDER_ERR_DEVICE, rccl_error(api, "ncclAllReduce", rc));
+    return GORDER_OK;
+}
+
 uint64_t gorder_hip_last_error_index(const gorder_hip_handle *h) { return h ? h->err_index : 0; }
 const char *gorder_hip_last_error_message(const gorder_hip_handle *h) { return h ? h->err_msg.c_str() : ""; }
 
 int gorder_hip_kernel_time(gorder_hip_handle *h, double *ms, uint64_t *launches, int reset) {
     if (!h) return GORDER_ERR_INVALID_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->device));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    for (auto &ev : h->timing) {
-        float t = 0.0f;
-        HIP_TRY(h, hipEventElapsedTime(&t, ev.first, ev.second));
-        h->timing_ms += t;
-        (void)hipEventDestroy(ev.first);
-        (void)hipEventDestroy(ev.second);
+    h->timing_on = true;   // the first call switches the event pairs on (submits before it are not timed)
+    while (h->timing_count) {
+        const int st = timing_drain_oldest(h);
+        if (st != GORDER_OK) return st;
     }
-    h->timing.clear();
     if (ms) *ms = h->timing_ms;
     if (launches) *launches = h->timing_launches;
     if (reset) { h->timing_ms = 0.0; h->timing_launches = 0; }
@@ -1252,3 +1513,5 @@ int gorder_hip_kernel_time(gorder_hip_handle *h, double *ms, uint64_t *launches,
 }
 
 }  // extern "C"
+
+#include "trajectory_driver.h"

@@ -6,6 +6,7 @@
 namespace {
 
 // ---- one bond sample (bond.rs:407-443) -----------------------------------------------------
+constexpr uint32_t kNoNan = 0xffffffffu;   // "this sample has met no undefined position yet"
 struct SampleAcc {
     long long s_tot = 0, s_up = 0;
     uint32_t n_tot = 0, n_up = 0;
@@ -106,7 +107,7 @@ struct TiledStage {
     template <int NF>
     static __device__ __forceinline__ void compute_core(const FrameArgs &a, const Tile &t, const Item &it,
                                                         uint32_t f0, const float (&P)[NF][6], SampleAcc &acc,
-                                                        int &bad, uint32_t &nan_atom, uint32_t &nan_frame) {
+                                                        int &bad, uint32_t &nan_which, uint32_t &nan_frame) {
         int tick[NF];
         uint8_t fl[NF];
         float bx[NF], by[NF], bz[NF];
@@ -162,9 +163,9 @@ struct TiledStage {
                 }
                 const float sch = gm_calc_sch<ACOS_COS>(vx, vy, vz, a.nx, a.ny, a.nz, a.n2, a.n2sq);
                 tick[k] = gm_tick(sch);
-                if (sch != sch) {
-                    if (P[k][0] != P[k][0]) { nan_atom = t.atom0 + it.li; nan_frame = f0 + k; }
-                    else if (P[k][3] != P[k][3]) { nan_atom = t.atom0 + it.lj; nan_frame = f0 + k; }
+                if (sch != sch && nan_frame == kNoNan) {   // the FIRST undefined position this sample meets (bond.rs:410-416)
+                    if (P[k][0] != P[k][0]) { nan_which = 0; nan_frame = f0 + k; }
+                    else if (P[k][3] != P[k][3]) { nan_which = 1; nan_frame = f0 + k; }
                 }
             }
         }
@@ -186,7 +187,7 @@ struct TiledStage {
     // LDS-staged variant: pick my two atoms out of the staged windows
     static __device__ __forceinline__ void compute(const FrameArgs &a, const Tile &t, const Item &it, uint32_t f0,
                                                    const float *lds, uint32_t lw, SampleAcc &acc, int &bad,
-                                                   uint32_t &nan_atom, uint32_t &nan_frame) {
+                                                   uint32_t &nan_which, uint32_t &nan_frame) {
         // NF frames at a time: NF independent dependency chains interleave; fewer live registers than all G at once
         constexpr int NF = GORDER_COMPUTE_NF < G ? GORDER_COMPUTE_NF : G;
 #pragma unroll
@@ -199,13 +200,13 @@ struct TiledStage {
                 P[k][0] = w[3u * it.li]; P[k][1] = w[3u * it.li + 1]; P[k][2] = w[3u * it.li + 2];
                 P[k][3] = w[3u * it.lj]; P[k][4] = w[3u * it.lj + 1]; P[k][5] = w[3u * it.lj + 2];
             }
-            compute_core<NF>(a, t, it, f0 + h, P, acc, bad, nan_atom, nan_frame);
+            compute_core<NF>(a, t, it, f0 + h, P, acc, bad, nan_which, nan_frame);
         }
     }
     // partial last stage: frames f0 .. f_end-1, one at a time (not performance relevant)
     static __device__ __forceinline__ void compute_tail(const FrameArgs &a, const Tile &t, const Item &it,
                                                         uint32_t f0, uint32_t f_end, const float *lds, uint32_t lw,
-                                                        SampleAcc &acc, int &bad, uint32_t &nan_atom,
+                                                        SampleAcc &acc, int &bad, uint32_t &nan_which,
                                                         uint32_t &nan_frame) {
 #pragma unroll 1
         for (uint32_t f = f0; f < f_end; f++) {
@@ -213,9 +214,9 @@ struct TiledStage {
             const float *w = lds + (size_t)(f - f0) * lw + sh;
             const float p1x = w[3u * it.li], p1y = w[3u * it.li + 1], p1z = w[3u * it.li + 2];
             const float p2x = w[3u * it.lj], p2y = w[3u * it.lj + 1], p2z = w[3u * it.lj + 2];
-            if (bond_sample<ACOS_COS>(a, f, p1x, p1y, p1z, p2x, p2y, p2z, it.mol, acc, bad)) {
-                if (p1x != p1x) { nan_atom = t.atom0 + it.li; nan_frame = f; }
-                else if (p2x != p2x) { nan_atom = t.atom0 + it.lj; nan_frame = f; }
+            if (bond_sample<ACOS_COS>(a, f, p1x, p1y, p1z, p2x, p2y, p2z, it.mol, acc, bad) && nan_frame == kNoNan) {
+                if (p1x != p1x) { nan_which = 0; nan_frame = f; }
+                else if (p2x != p2x) { nan_which = 1; nan_frame = f; }
             }
         }
     }
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(kBlock, GORDER_TILED_MIN_WAVES) void k_bonds_tiled(
 
     SampleAcc acc;
     int bad = 0;
-    uint32_t nan_atom = 0xffffffffu, nan_frame = 0;
+    uint32_t nan_which = 0, nan_frame = kNoNan;
     v4f pre[NPF];
 
     if (f_begin < f_full) S::template load<false>(a, t, f_begin, f_end, sk, si, pre);
@@ -262,19 +263,20 @@ __global__ __launch_bounds__(kBlock, GORDER_TILED_MIN_WAVES) void k_bonds_tiled(
         S::template store<false>(a, t, f0, f_end, sk, si, pre, lds, lw);
         __syncthreads();
         if (f0 + G < f_full) S::template load<false>(a, t, f0 + G, f_end, sk, si, pre);   // next stage in flight
-        if (active) S::compute(a, t, it, f0, lds, lw, acc, bad, nan_atom, nan_frame);
+        if (active) S::compute(a, t, it, f0, lds, lw, acc, bad, nan_which, nan_frame);
         __syncthreads();
     }
     if (f_full < f_end) {   // last, partial stage of the batch
         S::template load<true>(a, t, f_full, f_end, sk, si, pre);
         S::template store<true>(a, t, f_full, f_end, sk, si, pre, lds, lw);
         __syncthreads();
-        if (active) S::compute_tail(a, t, it, f_full, f_end, lds, lw, acc, bad, nan_atom, nan_frame);
+        if (active) S::compute_tail(a, t, it, f_full, f_end, lds, lw, acc, bad, nan_which, nan_frame);
         __syncthreads();
     }
 
-    if (nan_atom != 0xffffffffu) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, nan_atom, nan_frame);
-    if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f_begin);
+    if (nan_frame != kNoNan)
+        raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, nan_frame, kStageTypes, tile_slots[t.slot0 + it.lslot], 1, it.mol, nan_which);
+    if (bad) raise_box_range(a.err, f_begin);
 
     // ---- epilogue: fold the block's samples per accumulator slot in LDS, then one global atomic
     // per (slot, field).  Integer sums: the result does not depend on the order (order.rs:44-60).
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(kBlock) void k_bonds_gather(FrameArgs a_in, const f
 
     SampleAcc acc;
     int bad = 0;
-    uint32_t nan_atom = 0xffffffffu, nan_frame = 0;
+    uint32_t nan_which = 0, nan_frame = kNoNan;
     float cur[G][6], nxt[G][6];
     auto fetch = [&](float (&P)[G][6], uint32_t f0) {
 #pragma unroll
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(kBlock) void k_bonds_gather(FrameArgs a_in, const f
         for (uint32_t f0 = f_begin; f0 < f_full; f0 += G) {
             const bool more = f0 + G < f_full;
             if (more) fetch(nxt, f0 + G);
-            S::template compute_core<G>(a, t, it, f0, cur, acc, bad, nan_atom, nan_frame);
+            S::template compute_core<G>(a, t, it, f0, cur, acc, bad, nan_which, nan_frame);
             if (more) {
 #pragma unroll
                 for (int k = 0; k < G; k++)
@@ -368,14 +370,15 @@ __global__ __launch_bounds__(kBlock) void k_bonds_gather(FrameArgs a_in, const f
         for (uint32_t f = f_full; f < f_end; f++) {
             const float *q1 = pi + (size_t)f * fstride, *q2 = pj + (size_t)f * fstride;
             const float p1x = q1[0], p1y = q1[1], p1z = q1[2], p2x = q2[0], p2y = q2[1], p2z = q2[2];
-            if (bond_sample<ACOS_COS>(a, f, p1x, p1y, p1z, p2x, p2y, p2z, it.mol, acc, bad)) {
-                if (p1x != p1x) { nan_atom = t.atom0 + it.li; nan_frame = f; }
-                else if (p2x != p2x) { nan_atom = t.atom0 + it.lj; nan_frame = f; }
+            if (bond_sample<ACOS_COS>(a, f, p1x, p1y, p1z, p2x, p2y, p2z, it.mol, acc, bad) && nan_frame == kNoNan) {
+                if (p1x != p1x) { nan_which = 0; nan_frame = f; }
+                else if (p2x != p2x) { nan_which = 1; nan_frame = f; }
             }
         }
     }
-    if (nan_atom != 0xffffffffu) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, nan_atom, nan_frame);
-    if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f_begin);
+    if (nan_frame != kNoNan)
+        raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, nan_frame, kStageTypes, tile_slots[t.slot0 + it.lslot], 1, it.mol, nan_which);
+    if (bad) raise_box_range(a.err, f_begin);
 
     l_s[tid] = 0; l_s[kBlock + tid] = 0; l_n[tid] = 0; l_n[kBlock + tid] = 0;
     __syncthreads();
@@ -423,11 +426,11 @@ __global__ __launch_bounds__(256) void k_bonds_direct(FrameArgs a, const DirectI
         const float p1x = p1[0], p1y = p1[1], p1z = p1[2];
         const float p2x = p2[0], p2y = p2[1], p2z = p2[2];
         if (__builtin_expect(bond_sample<ACOS_COS>(a, f, p1x, p1y, p1z, p2x, p2y, p2z, it.mol, acc, bad), 0)) {
-            if (p1x != p1x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, it.i, f);
-            else if (p2x != p2x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, it.j, f);
+            if (p1x != p1x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, f, kStageTypes, it.slot, 1, it.mol, 0);
+            else if (p2x != p2x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, f, kStageTypes, it.slot, 1, it.mol, 1);
         }
     }
-    if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f_begin);
+    if (bad) raise_box_range(a.err, f_begin);
     if (acc.n_tot) {
         atomicAdd(&a.acc[it.slot], (unsigned long long)acc.s_tot);
         atomicAdd(&a.acc[2u * a.n_acc + it.slot], (unsigned long long)acc.n_tot);

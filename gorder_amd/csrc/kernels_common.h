@@ -6,7 +6,7 @@
 namespace {
 
 constexpr int kFramesPerStage = 4;   // G: frames staged in LDS per barrier pair (= waves per block)
-constexpr uint32_t kErrWords = 4;    // device error record: code, payload, frame, spare
+constexpr uint32_t kErrWords = 2;    // device error record: one 64-bit key (raise_error)
 
 struct FrameArgs {
     const float *xyz;        // [n_frames][n_atoms][3]
@@ -28,11 +28,36 @@ struct FrameArgs {
     uint32_t *err;
 };
 
-__device__ __forceinline__ void raise_error(uint32_t *err, uint32_t code, uint32_t payload, uint32_t frame) {
-    if (atomicCAS(&err[0], 0u, code) == 0u) {
-        err[1] = payload;
-        err[2] = frame;
-    }
+// ---- device error record --------------------------------------------------------------------------
+// ONE 64-bit key, lowered with atomicMin: the smallest key of a batch wins, and keys ascend in the order in which
+// the reference's single-threaded walk would meet the errors — frame by frame (common.rs:201-235: box check, then
+// the system-level leaflet step), then molecule type by molecule type (molecule.rs:54-95: leaflet assignment of the
+// type, then bond type -> molecule, bond.rs:406-417 / united atom -> molecule, uaorder.rs:400-437).  Which error a
+// batch reports therefore does not depend on the launch geometry or on which wave gets there first.
+//   [63]    0 = an error of the reference (errors.rs:121-168), 1 = GORDER_ERR_BOX_RANGE: the library's own range
+//           check (where the reference would spin) never hides an error the reference would have returned
+//   [62:40] frame in batch (clamped to 2^23 - 1)      [39:38] stage (ErrStage)
+//   [37:24] accumulator slot (first slot of the type for its leaflet assignment; clamped to 2^14 - 1)
+//   [23]    0 = leaflet assignment of the type, 1 = order sample
+//   [22:6]  global molecule id (clamped to 2^17 - 1)   [5:4] detail (which atom of the sample / cloud size)
+//   [3:0]   code: gorder_status_t 1..7, 8 = GORDER_ERR_BOX_RANGE
+// The payload of gorder_hip_last_error_index (an atom index) is resolved on the host from (slot, molecule, detail).
+constexpr unsigned long long kErrNone = ~0ull;
+enum ErrStage : uint32_t { kStageBox = 0, kStageSystem = 1, kStageTypes = 2, kStageEnd = 3 };
+__device__ __forceinline__ void raise_error(uint32_t *err, uint32_t code, uint32_t frame, uint32_t stage,
+                                            uint32_t slot = 0, uint32_t sample = 0, uint32_t mol = 0,
+                                            uint32_t detail = 0) {
+    const unsigned long long key =
+        ((unsigned long long)(code == GORDER_ERR_BOX_RANGE ? 1u : 0u) << 63) |
+        ((unsigned long long)min(frame, 0x7fffffu) << 40) | ((unsigned long long)(stage & 3u) << 38) |
+        ((unsigned long long)min(slot, 0x3fffu) << 24) | ((unsigned long long)(sample & 1u) << 23) |
+        ((unsigned long long)min(mol, 0x1ffffu) << 6) | ((unsigned long long)(detail & 3u) << 4) |
+        (unsigned long long)(code == GORDER_ERR_BOX_RANGE ? 8u : (code & 15u));
+    atomicMin(reinterpret_cast<unsigned long long *>(err), key);
+}
+// the library's own range error (a coordinate so far outside the box that the reference would spin): end of frame
+__device__ __forceinline__ void raise_box_range(uint32_t *err, uint32_t frame) {
+    raise_error(err, GORDER_ERR_BOX_RANGE, frame, kStageEnd);
 }
 
 // ---- check_box (common.rs:186-198), one thread per frame -----------------------------------
@@ -42,13 +67,13 @@ __global__ void k_check_box(const float *__restrict__ box9, uint32_t n_frames, u
     const float *b = box9 + 9 * (size_t)f;
     bool all_nan = true;
     for (int i = 0; i < 9; i++) all_nan = all_nan && (b[i] != b[i]);
-    if (all_nan) { raise_error(err, GORDER_ERR_UNDEFINED_BOX, 0, f); return; }
+    if (all_nan) { raise_error(err, GORDER_ERR_UNDEFINED_BOX, f, kStageBox); return; }
     if (b[1] != 0.0f || b[2] != 0.0f || b[3] != 0.0f || b[5] != 0.0f || b[6] != 0.0f || b[7] != 0.0f) {
-        raise_error(err, GORDER_ERR_NOT_ORTHOGONAL_BOX, 0, f);
+        raise_error(err, GORDER_ERR_NOT_ORTHOGONAL_BOX, f, kStageBox);
         return;
     }
-    if (b[0] == 0.0f && b[4] == 0.0f && b[8] == 0.0f) { raise_error(err, GORDER_ERR_ZERO_BOX, 0, f); return; }
-    if (!(b[0] > 0.0f) || !(b[4] > 0.0f) || !(b[8] > 0.0f)) raise_error(err, GORDER_ERR_BOX_RANGE, 0, f);
+    if (b[0] == 0.0f && b[4] == 0.0f && b[8] == 0.0f) { raise_error(err, GORDER_ERR_ZERO_BOX, f, kStageBox); return; }
+    if (!(b[0] > 0.0f) || !(b[4] > 0.0f) || !(b[8] > 0.0f)) raise_error(err, GORDER_ERR_BOX_RANGE, f, kStageBox);
 }
 
 // total_frames (topology/mod.rs:141-144) lives in the last word of the accumulator block so that a

@@ -201,8 +201,8 @@ __global__ __launch_bounds__(kBlock) void k_bonds_extras(FrameArgs a_in, ExtraAr
                 vy = gm_min_image(vy, b[4], bad);
                 vz = gm_min_image(vz, b[8], bad);
             }
-            if (p1x != p1x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, t.atom0 + it.li, f);
-            else if (p2x != p2x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, t.atom0 + it.lj, f);
+            if (p1x != p1x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, f, kStageTypes, gslot, 1, it.mol, 0);
+            else if (p2x != p2x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, f, kStageTypes, gslot, 1, it.mol, 1);
             // bond position = p1 + v / 2 (bond.rs:422); geometry filter (bond.rs:424-426)
             const float mx = p1x + vx / 2.0f, my = p1y + vy / 2.0f, mz = p1z + vz / 2.0f;
             bool in = true;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(kBlock) void k_bonds_extras(FrameArgs a_in, ExtraAr
                 float sch;
                 if (!MAPS_ONLY && e.dyn) {   // the molecule's own normal of this frame, fetched after the geometry test (bond.rs:429-431)
                     const float4 n = e.dyn[(size_t)f * a.n_mol_total + it.mol];
-                    if (n.w < 3.0f) raise_error(a.err, GORDER_ERR_DYNAMIC_NORMAL, (uint32_t)n.w, f);
+                    if (n.w < 3.0f) raise_error(a.err, GORDER_ERR_DYNAMIC_NORMAL, f, kStageTypes, gslot, 1, it.mol, (uint32_t)n.w);
                     const float n2sq = (n.x * n.x + n.y * n.y) + n.z * n.z;
                     sch = gm_calc_sch<ACOS_COS>(vx, vy, vz, n.x, n.y, n.z, __builtin_sqrtf(n2sq), n2sq);
                 } else {
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(kBlock) void k_bonds_extras(FrameArgs a_in, ExtraAr
             __syncthreads();
         }
     }
-    if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f_begin);
+    if (bad) raise_box_range(a.err, f_begin);
     l_s[tid] = 0; l_s[kBlock + tid] = 0; l_n[tid] = 0; l_n[kBlock + tid] = 0;
     __syncthreads();
     if (active && acc.n_tot) {
@@ -493,10 +493,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             const UaCarbon c = fetch(f);
             V3 bx3{1.0f, 1.0f, 1.0f};
             if (pbc) { const float *b = a.box9 + 9 * (size_t)f; bx3 = {b[0], b[4], b[8]}; }
-            if (c.p0.x != c.p0.x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, t.atom0 + it.l[0], f);
-            if (c.p1.x != c.p1.x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, t.atom0 + it.l[1], f);
-            if (c.p2.x != c.p2.x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, t.atom0 + it.l[2], f);
-            if (c.p3.x != c.p3.x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, t.atom0 + it.l[3], f);
+            // the atoms are checked in index order (uaorder.rs:400-437 via get_position of each helper); the smallest key wins
+            if (c.p0.x != c.p0.x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, f, kStageTypes, gslot0, 1, it.mol, 0);
+            else if (c.p1.x != c.p1.x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, f, kStageTypes, gslot0, 1, it.mol, 1);
+            else if (c.p2.x != c.p2.x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, f, kStageTypes, gslot0, 1, it.mol, 2);
+            else if (c.p3.x != c.p3.x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, f, kStageTypes, gslot0, 1, it.mol, 3);
             PbcStep ps{bx3, pbc};
             UaBonds ub = ua_carbon(kind, c, uc, ps);
             if (__builtin_expect(ps.slow, 0)) {
@@ -508,7 +509,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             float nrx = a.nx, nry = a.ny, nrz = a.nz, nr2 = a.n2, nr2sq = a.n2sq;
             if (GENERAL && e.dyn) {   // fetched for every molecule, before the geometry test (uaorder.rs:412-413)
                 const float4 n = e.dyn[(size_t)f * a.n_mol_total + it.mol];
-                if (n.w < 3.0f) raise_error(a.err, GORDER_ERR_DYNAMIC_NORMAL, (uint32_t)n.w, f);
+                if (n.w < 3.0f) raise_error(a.err, GORDER_ERR_DYNAMIC_NORMAL, f, kStageTypes, gslot0, 1, it.mol, (uint32_t)n.w);
                 nrx = n.x; nry = n.y; nrz = n.z;
                 nr2sq = (n.x * n.x + n.y * n.y) + n.z * n.z;
                 nr2 = __builtin_sqrtf(nr2sq);
@@ -554,7 +555,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             __syncthreads();
         }
     }
-    if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f_begin);
+    if (bad) raise_box_range(a.err, f_begin);
     if (active) {
 #pragma unroll
         for (int k = 0; k < 3; k++) {

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void k_geom_shapes(GeomArgs g) {
         if (g.pbc) for (int d = 0; d < 3; d++) sh[d] = gm_wrap(sh[d], shape_box[d], bad);
         for (int k = 0; k < 8; k++) g.shapes[8 * (size_t)f + k] = sh[k];
     }
-    if (bad) raise_error(g.err, GORDER_ERR_BOX_RANGE, 0, f);
+    if (bad) raise_box_range(g.err, f);
 }
 
 // One block per assignment frame: refined Bai-Breen centre of the membrane group
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(1024) void k_leaflets_global(LeafletArgs a) {
         float c = est + (float)(tot / (double)a.n_membrane);
         if (a.pbc) c = gm_wrap(c, L, bad);
         if (c != c || nf != 0.0 || a.n_membrane == 0) {
-            raise_error(a.err, GORDER_ERR_INVALID_GLOBAL_MEMBRANE_CENTER, 0, f);
+            raise_error(a.err, GORDER_ERR_INVALID_GLOBAL_MEMBRANE_CENTER, f, kStageSystem);
             c = __builtin_nanf("");
         }
         s_center = c;
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(1024) void k_leaflets_global(LeafletArgs a) {
         row[m] = (uint8_t)((d >= 0.0f ? 0 : 1) ^ (a.flip ? 1 : 0));
         if (last && a.adist) a.adist[m] = d;
     }
-    if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f);
+    if (bad) raise_box_range(a.err, f);
 }
 
 // The same classifier for the usual case that the membrane group is EVERY atom of the frame, in order (all
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void k_leaflets_global_contig(LeafletArgs a) {
     }
     if (threadIdx.x == 0) {
         if (center != center || nf != 0.0 || a.n_atoms == 0) {
-            raise_error(a.err, GORDER_ERR_INVALID_GLOBAL_MEMBRANE_CENTER, 0, f);
+            raise_error(a.err, GORDER_ERR_INVALID_GLOBAL_MEMBRANE_CENTER, f, kStageSystem);
             center = __builtin_nanf("");
         }
         s_center = center;
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256) void k_leaflets_global_contig(LeafletArgs a) {
         row[m] = (uint8_t)((d >= 0.0f ? 0 : 1) ^ (a.flip ? 1 : 0));
         if (last && a.adist) a.adist[m] = d;
     }
-    if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f);
+    if (bad) raise_box_range(a.err, f);
 }
 
 // grid = (ceil(n_mol/256), n_assign).  IndividualClassification::identify_leaflet, leaflets.rs:777-801:
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256) void k_leaflets_individual(LeafletArgs a) {
     a.aflags[(size_t)(a.row0 + blockIdx.y) * a.n_mol_total + m] =
         (uint8_t)((total >= 0.0f ? 0 : 1) ^ (a.flip ? 1 : 0));
     if (blockIdx.y + 1 == gridDim.y && a.adist) a.adist[m] = total;
-    if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f);
+    if (bad) raise_box_range(a.err, f);
 }
 
 // ---- Local leaflets (LocalClassification, leaflets.rs:661-675 -> PBC3D::calc_local_membrane_centers,
@@ -487,6 +487,7 @@ struct LocalArgs {
     int write_dist_frame;       // slab-local index whose distances go to adist (-1: none)
     uint32_t n_mol_total;
     const uint32_t *heads;
+    const uint32_t *mol_slot0;  // [n_mol_total] first accumulator slot of the molecule's type (error key only; may be null)
     const uint32_t *membrane;
     uint32_t n_membrane;
     uint4 *grid;                // [n_slab] (cells along a, cells along b, reach ka, reach kb) of each slab frame, written by
@@ -557,7 +558,7 @@ __device__ __forceinline__ uint32_t local_cell_of(const LocalArgs &a, uint32_t s
     }
     const uint32_t c = ca * ncb + cb;
     a.cell_of[(size_t)s * a.n_membrane + i] = c;
-    if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f);
+    if (bad) raise_box_range(a.err, f);
     return c;
 }
 
@@ -893,7 +894,7 @@ __global__ __launch_bounds__(256) void k_local_flags(LocalArgs a) {
     }
     const double tcnt = wave_total((double)cnt);
     if (tcnt == 0.0 || __any(nf != 0u)) {
-        if (lane == 0) raise_error(a.err, GORDER_ERR_INVALID_LOCAL_MEMBRANE_CENTER, a.heads[m], f);
+        if (lane == 0) raise_error(a.err, GORDER_ERR_INVALID_LOCAL_MEMBRANE_CENTER, f, kStageTypes, a.mol_slot0 ? a.mol_slot0[m] : 0u, 0, m);
         return;
     }
     float center;
@@ -929,7 +930,7 @@ __global__ __launch_bounds__(256) void k_local_flags(LocalArgs a) {
     }
     if (lane == 0) {
         if (center != center) {
-            raise_error(a.err, GORDER_ERR_INVALID_LOCAL_MEMBRANE_CENTER, a.heads[m], f);
+            raise_error(a.err, GORDER_ERR_INVALID_LOCAL_MEMBRANE_CENTER, f, kStageTypes, a.mol_slot0 ? a.mol_slot0[m] : 0u, 0, m);
             return;
         }
         float d = hn_pos - center;
@@ -937,7 +938,7 @@ __global__ __launch_bounds__(256) void k_local_flags(LocalArgs a) {
         a.aflags[(size_t)(a.row0 + s) * a.n_mol_total + m] = (uint8_t)((d >= 0.0f ? 0 : 1) ^ (a.flip ? 1 : 0));
         if ((int)s == a.write_dist_frame && a.adist) a.adist[m] = d;
     }
-    if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f);
+    if (bad) raise_box_range(a.err, f);
 }
 
 }  // namespace

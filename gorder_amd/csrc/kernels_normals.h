@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void k_dyn_normals(LocalArgs a, float4 *__rest
     const float *hp = x + 3u * (size_t)a.heads[m];
     const float hx = hp[0], hy = hp[1], hz = hp[2];
     if (hx != hx) {
-        if (lane == 0) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, a.heads[m], f);
+        if (lane == 0) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, f, kStageSystem, 0, 0, m);
         return;
     }
     int bad = 0;
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void k_dyn_normals(LocalArgs a, float4 *__rest
         }
         out[(size_t)f * a.n_mol_total + m] = o;
     }
-    if (bad) raise_error(a.err, GORDER_ERR_BOX_RANGE, 0, f);
+    if (bad) raise_box_range(a.err, f);
 }
 
 }  // namespace

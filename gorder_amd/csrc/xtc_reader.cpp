@@ -8,6 +8,8 @@
 // The bit stream packs each atom's three integers (coordinate * precision, offset by minint) either
 // in full width or, for runs of neighbouring atoms, as small differences in a mixed-radix number
 // whose radix comes from the `magicints` table.
+#include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -549,6 +551,224 @@ int gorder_xtc_next(gorder_xtc_reader *r, float *xyz, float *box9, int64_t *step
     }
     return GORDER_XTC_OK;
 }
+
+}  // extern "C"
+
+// ---- writer ------------------------------------------------------------------------------------------
+// The compression side of the same published format (xdr3dcoord): coordinates become integers
+// (round-half-away of x * precision in f32), the frame stores their bounding box, and atoms go out either at full
+// width (one mixed-radix number of `bitsize` bits) or, for runs of up to 8 neighbours closer than `smallnum` grid
+// steps, as small offsets from their predecessor; the size of "small" adapts by one table step per atom group.
+// Tooling only: the reference never writes trajectories.  It exists so that tests and the end-to-end benchmark can
+// produce multi-frame XTC input for the reader -> GPU pipeline without any file the checkout does not hold.
+namespace {
+struct BitWriter {
+    std::vector<uint8_t> out;
+    uint32_t lastbyte = 0;
+    int lastbits = 0;
+    void bits(int nbits, uint32_t num) {          // MSB first
+        while (nbits >= 8) {
+            lastbyte = (lastbyte << 8) | ((num >> (nbits - 8)) & 0xffu);
+            out.push_back((uint8_t)(lastbyte >> lastbits));
+            nbits -= 8;
+        }
+        if (nbits > 0) {
+            lastbyte = (lastbyte << nbits) | (num & ((1u << nbits) - 1u));
+            lastbits += nbits;
+            if (lastbits >= 8) {
+                lastbits -= 8;
+                out.push_back((uint8_t)(lastbyte >> lastbits));
+            }
+        }
+    }
+    // three integers as one mixed-radix number, least significant byte first, `nbits` bits in all
+    void ints(int nbits, const uint32_t sizes[3], const uint32_t nums[3]) {
+        unsigned __int128 v = nums[0];
+        v = v * sizes[1] + nums[1];
+        v = v * sizes[2] + nums[2];
+        uint8_t bytes[16];
+        int nbytes = 0;
+        do { bytes[nbytes++] = (uint8_t)(v & 0xff); v >>= 8; } while (v != 0);
+        if (nbits >= nbytes * 8) {
+            for (int i = 0; i < nbytes; i++) bits(8, bytes[i]);
+            int pad = nbits - nbytes * 8;
+            while (pad > 0) { const int k = pad > 24 ? 24 : pad; bits(k, 0); pad -= k; }
+        } else {
+            for (int i = 0; i < nbytes - 1; i++) bits(8, bytes[i]);
+            bits(nbits - (nbytes - 1) * 8, bytes[nbytes - 1]);
+        }
+    }
+    void finish() {
+        if (lastbits > 0) out.push_back((uint8_t)(lastbyte << (8 - lastbits)));
+    }
+};
+void put32(std::vector<uint8_t> &o, uint32_t v) { o.push_back(v >> 24); o.push_back(v >> 16); o.push_back(v >> 8); o.push_back(v); }
+void putf(std::vector<uint8_t> &o, float f) { uint32_t u; memcpy(&u, &f, 4); put32(o, u); }
+}  // namespace
+
+struct gorder_xtc_writer {
+    FILE *fp = nullptr;
+    uint32_t natoms = 0;
+    float precision = 1000.0f;
+    std::vector<int> ints;
+    std::vector<uint8_t> head;
+};
+
+extern "C" {
+
+int gorder_xtc_writer_open(const char *path, uint32_t n_atoms, float precision, gorder_xtc_writer **out) {
+    if (!path || !out || n_atoms == 0 || !(precision > 0.0f)) return GORDER_XTC_ERR_ARGUMENT;
+    *out = nullptr;
+    FILE *fp = fopen(path, "wb");
+    if (!fp) return GORDER_XTC_ERR_OPEN;
+    gorder_xtc_writer *w = new gorder_xtc_writer();
+    w->fp = fp;
+    w->natoms = n_atoms;
+    w->precision = precision;
+    *out = w;
+    return GORDER_XTC_OK;
+}
+
+void gorder_xtc_writer_close(gorder_xtc_writer *w) {
+    if (!w) return;
+    if (w->fp) fclose(w->fp);
+    delete w;
+}
+
+int gorder_xtc_writer_add(gorder_xtc_writer *w, const float *xyz, const float *box9, int64_t step, float time_ps) {
+    if (!w || !w->fp || !xyz || !box9) return GORDER_XTC_ERR_ARGUMENT;
+    const uint32_t natoms = w->natoms;
+    std::vector<uint8_t> &o = w->head;
+    o.clear();
+    put32(o, 1995u);
+    put32(o, natoms);
+    put32(o, (uint32_t)(int32_t)step);
+    putf(o, time_ps);
+    for (int k = 0; k < 9; k++) putf(o, box9[k]);
+    put32(o, natoms);
+    if (natoms <= 9) {
+        for (size_t k = 0; k < (size_t)natoms * 3; k++) putf(o, xyz[k]);
+        return fwrite(o.data(), 1, o.size(), w->fp) == o.size() ? GORDER_XTC_OK : GORDER_XTC_ERR_OPEN;
+    }
+    // ---- integers, their bounding box, the smallest step between consecutive atoms
+    w->ints.resize((size_t)natoms * 3);
+    int *ip = w->ints.data();
+    int minint[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, maxint[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+    int mindiff = INT32_MAX;
+    int old[3] = {0, 0, 0};
+    for (uint32_t a = 0; a < natoms; a++) {
+        int cur[3];
+        for (int c = 0; c < 3; c++) {
+            const float x = xyz[3 * (size_t)a + c];
+            const float lf = x >= 0.0f ? x * w->precision + 0.5f : x * w->precision - 0.5f;
+            if (!(std::fabs(lf) < 2147483520.0f)) return GORDER_XTC_ERR_ARGUMENT;     // does not fit an int (or NaN)
+            cur[c] = (int)lf;
+            if (cur[c] < minint[c]) minint[c] = cur[c];
+            if (cur[c] > maxint[c]) maxint[c] = cur[c];
+            ip[3 * (size_t)a + c] = cur[c];
+        }
+        const int64_t diff = (int64_t)std::abs((int64_t)old[0] - cur[0]) + std::abs((int64_t)old[1] - cur[1]) +
+                             std::abs((int64_t)old[2] - cur[2]);
+        if (a > 0 && diff < mindiff) mindiff = (int)diff;
+        old[0] = cur[0]; old[1] = cur[1]; old[2] = cur[2];
+    }
+    uint32_t sizeint[3];
+    int bitsizeint[3] = {0, 0, 0};
+    for (int c = 0; c < 3; c++) {
+        const int64_t sz = (int64_t)maxint[c] - (int64_t)minint[c] + 1;
+        if (sz > 0xffffffffll) return GORDER_XTC_ERR_ARGUMENT;
+        sizeint[c] = (uint32_t)sz;
+    }
+    int bitsize;
+    if ((sizeint[0] | sizeint[1] | sizeint[2]) > 0xffffff) {
+        for (int c = 0; c < 3; c++) bitsizeint[c] = size_of_int(sizeint[c]);
+        bitsize = 0;
+    } else {
+        bitsize = size_of_ints(sizeint);
+    }
+    int smallidx = kFirstIdx;
+    while (smallidx < kLastIdx - 1 && kMagicInts[smallidx] < mindiff) smallidx++;
+    putf(o, w->precision);
+    for (int c = 0; c < 3; c++) put32(o, (uint32_t)minint[c]);
+    for (int c = 0; c < 3; c++) put32(o, (uint32_t)maxint[c]);
+    put32(o, (uint32_t)smallidx);
+    const int maxidx = std::min(kLastIdx - 1, smallidx + 8), minidx = maxidx - 8;
+    int smaller = kMagicInts[std::max(kFirstIdx, smallidx - 1)] / 2;
+    int smallnum = kMagicInts[smallidx] / 2;
+    uint32_t sizesmall[3] = {(uint32_t)kMagicInts[smallidx], (uint32_t)kMagicInts[smallidx], (uint32_t)kMagicInts[smallidx]};
+    const int larger = kMagicInts[maxidx] / 2;
+    BitWriter bw;
+    bw.out.reserve((size_t)natoms * 5);
+    int prevcoord[3] = {0, 0, 0};
+    int prevrun = -1;
+    uint32_t i = 0;
+    auto near = [](const int *p, const int *q, int lim) {
+        return std::abs(p[0] - q[0]) < lim && std::abs(p[1] - q[1]) < lim && std::abs(p[2] - q[2]) < lim;
+    };
+    while (i < natoms) {
+        int *thiscoord = ip + 3 * (size_t)i;
+        bool is_small = false;
+        int is_smaller;
+        if (smallidx < maxidx && i >= 1 && near(thiscoord, prevcoord, larger)) is_smaller = 1;
+        else if (smallidx > minidx) is_smaller = -1;
+        else is_smaller = 0;
+        if (i + 1 < natoms && near(thiscoord, thiscoord + 3, smallnum)) {
+            // the first atom of a run is stored after the second (water: the oxygen between its hydrogens)
+            for (int c = 0; c < 3; c++) std::swap(thiscoord[c], thiscoord[3 + c]);
+            is_small = true;
+        }
+        const uint32_t big[3] = {(uint32_t)(thiscoord[0] - minint[0]), (uint32_t)(thiscoord[1] - minint[1]),
+                                 (uint32_t)(thiscoord[2] - minint[2])};
+        if (bitsize == 0) for (int c = 0; c < 3; c++) bw.bits(bitsizeint[c], big[c]);
+        else bw.ints(bitsize, sizeint, big);
+        for (int c = 0; c < 3; c++) prevcoord[c] = thiscoord[c];
+        thiscoord += 3;
+        i++;
+        int run = 0;
+        uint32_t small[24];
+        if (!is_small && is_smaller == -1) is_smaller = 0;
+        while (is_small && run < 8 * 3) {
+            if (is_smaller == -1) {
+                const int64_t d0 = thiscoord[0] - prevcoord[0], d1 = thiscoord[1] - prevcoord[1], d2 = thiscoord[2] - prevcoord[2];
+                if (d0 * d0 + d1 * d1 + d2 * d2 >= (int64_t)smaller * smaller) is_smaller = 0;
+            }
+            for (int c = 0; c < 3; c++) small[run++] = (uint32_t)(thiscoord[c] - prevcoord[c] + smallnum);
+            for (int c = 0; c < 3; c++) prevcoord[c] = thiscoord[c];
+            i++;
+            thiscoord += 3;
+            is_small = i < natoms && near(thiscoord, prevcoord, smallnum);
+        }
+        if (run != prevrun || is_smaller != 0) {
+            prevrun = run;
+            bw.bits(1, 1);
+            bw.bits(5, (uint32_t)(run + is_smaller + 1));
+        } else {
+            bw.bits(1, 0);
+        }
+        for (int k = 0; k < run; k += 3) bw.ints(smallidx, sizesmall, small + k);
+        if (is_smaller != 0) {
+            smallidx += is_smaller;
+            if (is_smaller < 0) {
+                smallnum = smaller;
+                smaller = kMagicInts[smallidx - 1] / 2;
+            } else {
+                smaller = smallnum;
+                smallnum = kMagicInts[smallidx] / 2;
+            }
+            sizesmall[0] = sizesmall[1] = sizesmall[2] = (uint32_t)kMagicInts[smallidx];
+        }
+    }
+    bw.finish();
+    put32(o, (uint32_t)bw.out.size());
+    while (bw.out.size() % 4) bw.out.push_back(0);
+    if (fwrite(o.data(), 1, o.size(), w->fp) != o.size()) return GORDER_XTC_ERR_OPEN;
+    if (fwrite(bw.out.data(), 1, bw.out.size(), w->fp) != bw.out.size()) return GORDER_XTC_ERR_OPEN;
+    return GORDER_XTC_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
 
 int64_t gorder_xtc_read_window(gorder_xtc_reader *r, float begin_ps, float end_ps, uint32_t step, uint64_t *state,
                                double *last_time, float *xyz, float *box9, float *time_ps, uint64_t capacity) {

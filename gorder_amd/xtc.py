@@ -30,8 +30,34 @@ def _lib():
         lib.gorder_xtc_read_window_mt.argtypes = [vp, C.c_float, C.c_float, C.c_uint32, C.POINTER(C.c_uint64),
                                                   C.POINTER(C.c_double), vp, vp, vp, C.c_uint64, C.c_uint32]
         lib.gorder_xtc_read_window_mt.restype = C.c_int64
+        lib.gorder_xtc_writer_open.argtypes = [C.c_char_p, C.c_uint32, C.c_float, C.POINTER(vp)]
+        lib.gorder_xtc_writer_add.argtypes = [vp, vp, vp, C.c_int64, C.c_float]
+        lib.gorder_xtc_writer_close.argtypes = [vp]
+        lib.gorder_xtc_writer_close.restype = None
         _bound = True
     return lib
+
+
+def write_trajectory(path: str, xyz: np.ndarray, box: np.ndarray, times: Optional[Sequence[float]] = None,
+                     precision: float = 1000.0, append_to=None):
+    """Write frames [F, N, 3] (+ boxes [F, 3, 3], times in ps) as a compressed XTC file (tooling: tests, end-to-end
+    benchmark).  Reading it back gives round(x * precision) / precision."""
+    lib = _lib()
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+    box = np.ascontiguousarray(box, dtype=np.float32).reshape(xyz.shape[0], 9)
+    if times is None:
+        times = np.arange(xyz.shape[0], dtype=np.float32)
+    w = C.c_void_p()
+    st = lib.gorder_xtc_writer_open(path.encode(), xyz.shape[1], precision, C.byref(w))
+    if st != 0:
+        raise IOError(f"cannot create {path}: status {st}")
+    try:
+        for f in range(xyz.shape[0]):
+            st = lib.gorder_xtc_writer_add(w, xyz[f].ctypes.data, box[f].ctypes.data, f, float(times[f]))
+            if st != 0:
+                raise IOError(f"{path}: XTC write error {st} in frame {f}")
+    finally:
+        lib.gorder_xtc_writer_close(w)
 
 
 def read_trajectory(paths: Sequence[str], group: Optional[np.ndarray] = None, begin: float = 0.0, end: float = -1.0,

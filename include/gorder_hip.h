@@ -18,8 +18,9 @@
  *                                                            u64 counts which add element-wise
  *                                                            (order.rs:160-176, ordermap.rs:116-138);
  *                                                            on a multi-GPU node one RCCL all-reduce
- *                                                            over the packed buffer of
- *                                                            gorder_hip_accumulators_device()
+ *                                                            (gorder_hip_allreduce, or the host's own
+ *                                                            over gorder_hip_accumulators_device())
+ *   read_trajectory (common.rs:239-342)                    -> gorder_hip_run_trajectory
  *   Result<(), AnalysisError> (errors.rs:121-168)          -> gorder_status_t + gorder_hip_last_error_index
  *
  * Plain pointers and sizes only.  No allocation ownership crosses the boundary: every input
@@ -58,7 +59,8 @@ typedef enum {
                                          terminate in 8 iterations (the reference would spin) */
     GORDER_ERR_LEAFLETS_NOT_PRIMED = 104, /* first submitted frame is not an assignment frame and no
                                              earlier assignment is known: call gorder_hip_prime_leaflets */
-    GORDER_ERR_OVERFLOW = 105         /* i64 accumulator overflow (reference panics, order.rs:44-60) */
+    GORDER_ERR_OVERFLOW = 105         /* a batch was refused because frames x molecules would reach 2^63 / 1e6: an i64
+                                         order sum could then overflow (the reference panics, order.rs:44-60) */
 } gorder_status_t;
 
 /* ---- leaflets -------------------------------------------------------------------------------- */
@@ -156,13 +158,15 @@ typedef struct {
                                box-centre / group references are rebuilt with each frame's box */
 } gorder_geometry_t;
 
-/* How cos(theta) of calc_sch (mod.rs:78-82) is evaluated.
- * Default (0): cos(theta) = clamp(v.n / (|v||n|), -1, 1) taken DIRECTLY.  The reference evaluates
- *   `angle = acos(clamp(..))` and then `angle.cos()` in f32; that round trip returns the same number
- *   up to +-2 ulp of rounding noise.  Measured against the libm round trip: 3.3 % of samples move by
- *   one 1e-6 tick, never more, mean shift 3e-10 — four orders below the 1e-6 parity tolerance.
- * GORDER_FLAG_TRIG_ACOS_COS: evaluate the acos -> cos round trip like the reference (own f32
- *   polynomial kernels, < 1 ulp each; 1.6 % of samples move by one tick vs glibc 2.35). */
+/* How P2(cos theta) of calc_sch (mod.rs:78-82) is evaluated.
+ * Default (0): from the SQUARED cosine, q = (v.n)^2 / (|v|^2 |n|^2), S = 1.5 q - 0.5: one IEEE division, no square
+ *   root, no acos -> cos round trip.  The reference evaluates `angle = acos(clamp(v.n / (|v||n|)))` and then
+ *   `angle.cos()` in f32 — mathematically the same number plus <= 2 ulp of rounding noise.  Measured against the
+ *   reference pipeline with glibc's acosf / cosf (tools/trig_fidelity.c): 5.9 % of samples move by one 1e-6 tick, never
+ *   more, mean shift 2.6e-10 — inside the 1e-6 parity tolerance but NOT bit-identical to the reference.  The squared
+ *   form also has half the exponent range (|v| below ~1e-19 nm or above ~1e19 nm is no longer the reference's value).
+ * GORDER_FLAG_TRIG_ACOS_COS: evaluate the literal acos -> cos round trip like the reference (own f32 polynomial
+ *   kernels, < 1 ulp each; 1.6 % of samples move by one tick vs glibc 2.35). */
 typedef enum {
     GORDER_FLAG_TRIG_ACOS_COS = 1u
 } gorder_flags_t;
@@ -208,9 +212,47 @@ int gorder_hip_set_stream(gorder_hip_handle *h, void *hip_stream);
 int gorder_hip_submit_device(gorder_hip_handle *h, const float *d_xyz, const float *d_box,
                              const uint64_t *frame_index, uint32_t n_frames);
 
-/* Same, from host memory (pinned or pageable); stages through an internal device buffer. */
+/* Same, from host memory (pinned or pageable).  Double-buffered: the batch is copied on a copy stream into one of
+ * two internal device buffers while the kernels of the previous batch may still be running; the call returns once
+ * the copy has left the host buffer (the caller may refill it at once), NOT once the kernels are done.  A host that
+ * decodes batch k+1 between two calls therefore overlaps decoding, the PCIe copy and the kernels. */
 int gorder_hip_submit_host(gorder_hip_handle *h, const float *xyz, const float *box,
                            const uint64_t *frame_index, uint32_t n_frames);
+
+/* ---- trajectory driver: `read_trajectory` (src/analysis/common.rs:239-342) --------------------------------------
+ * Reads one trajectory (XTC, TRR or multi-frame GRO; several files = one concatenated trajectory with the duplicate
+ * boundary frames dropped), applies the time window and the step, and feeds the frames to the handle batch by batch
+ * through a pipeline: `n_threads` host threads decode batch k+2 into pinned memory while batch k+1 is copied on a
+ * copy stream and batch k is analysed (see gorder_amd/csrc/trajectory_driver.h).  The k-th analysed frame gets the
+ * global frame index first_frame_index + k * step (SystemTopology::frame, topology/mod.rs:141-144).
+ * Returns after the last batch has been analysed (synchronised); results are read with gorder_hip_finish.
+ * The first error — of the reader or of the analysis — ends the run (common.rs:248). */
+typedef struct {
+    const char *const *paths;
+    uint32_t n_paths;
+    const uint32_t *group;       /* atoms of the file that make up a submitted frame, in order (the "Master" group,
+                                    common.rs:283-304); NULL = every atom */
+    uint32_t n_group;
+    float begin_ps, end_ps;      /* inclusive window on the frame time; end_ps < 0 = to the end */
+    uint32_t step;               /* analyse every step-th frame of the window (>= 1) */
+    uint32_t n_threads;          /* decoder threads; 0 = all hardware threads */
+    uint32_t batch_frames;       /* frames per device batch; 0 = about 128 MB of coordinates */
+    uint64_t first_frame_index;  /* 0 for a whole trajectory; a rank that reads a later window passes where it starts */
+} gorder_trajectory_t;
+
+typedef struct {
+    uint64_t n_frames;               /* frames analysed */
+    uint64_t n_batches;
+    uint64_t bytes_h2d;              /* coordinate + box bytes copied to the device */
+    double seconds_total;            /* wall time of the call */
+    double seconds_decode;           /* wall time inside the decoder (overlaps with copies and kernels) */
+    double seconds_reader_stalled;   /* the reader waited for a free staging slot: copies / kernels are the bottleneck */
+    double seconds_gpu_starved;      /* the submitter waited for a decoded batch: the decoder is the bottleneck */
+    uint32_t batch_frames, decoder_threads;   /* what was used */
+} gorder_trajectory_stats_t;
+
+int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_trajectory_t *trajectory,
+                              gorder_trajectory_stats_t *stats /* may be NULL */);
 
 /* Compute (only) the leaflet assignment of ONE frame that precedes a rank's frame range
  * (replaces the cross-thread spin-wait of leaflets.rs:1529-1565). */
@@ -254,11 +296,32 @@ int gorder_hip_set_normals(gorder_hip_handle *h, const float *normals, uint32_t 
  * (what NormalsStorage keeps per frame, normal.rs:460-520).  Requires tables.dynamic_normal.enabled. */
 int gorder_hip_normals(gorder_hip_handle *h, float *normals, uint32_t *n_points);
 
-/* Device pointer + element count of the packed u64 accumulator block
- * {i64 sums[3][n_acc], u64 counts[3][n_acc], u64 total_frames, (maps...)} so that a host can issue
- * ONE RCCL all-reduce (ncclUint64 / ncclSum) over it — the multi-GPU form of
- * SystemTopology::reduce (topology/mod.rs:256-272). */
+/* Device pointer + element count of the packed 64-bit accumulator block, n_u64 = 4 * n_acc + 1 words:
+ *   { i64 sum_total[n_acc], i64 sum_upper[n_acc], u64 count_total[n_acc], u64 count_upper[n_acc], u64 total_frames }
+ * (lower = total - upper: every sample is upper or lower, bond.rs:199-213; gorder_hip_finish derives it), so that
+ * a host can issue ONE RCCL all-reduce (ncclInt64 / ncclSum) over it — the multi-GPU form of
+ * SystemTopology::reduce (topology/mod.rs:256-272).  Ordermaps are NOT part of the block: see
+ * gorder_hip_export_maps / gorder_hip_allreduce. */
 int gorder_hip_accumulators_device(gorder_hip_handle *h, void **d_ptr, uint64_t *n_u64);
+
+/* ---- multi-GPU reduce inside the library (for hosts without a collective library of their own) -------------------
+ * gorder_hip_allreduce sums, in place and across the ranks of an initialised RCCL communicator (`ncclComm_t`, passed
+ * as void *), everything SystemTopology::add sums (topology/mod.rs:236-254): the packed accumulator block (order sums,
+ * counts, total_frames) and, with ordermaps, the maps — ONE group of ncclAllReduce(ncclInt64, ncclSum) calls on the
+ * handle's stream, over xGMI on an MI355X node.  Call it once, after the rank's last batch; every rank then reads the
+ * whole-trajectory result with gorder_hip_finish.  Per-frame timewise rows and leaflet flags are per-rank data and are
+ * not touched (the host concatenates them by frame index).  RCCL is bound at the first call (librccl.so.1).
+ * The communicator can come from the host's own RCCL calls or from the two helpers below:
+ *   rank 0: gorder_hip_comm_unique_id(id) -> the host ships the 128 bytes to the other ranks (any channel) ->
+ *   every rank: gorder_hip_comm_create(handle, id, n_ranks, rank, &comm) on its handle's device. */
+int gorder_hip_comm_unique_id(uint8_t id[128]);
+int gorder_hip_comm_create(gorder_hip_handle *h, const uint8_t id[128], int n_ranks, int rank, void **comm_out);
+void gorder_hip_comm_destroy(void *comm);
+int gorder_hip_allreduce(gorder_hip_handle *h, void *nccl_comm);
+
+/* Forget everything accumulated so far (sums, counts, maps, timewise rows, frame count, leaflet carry, error
+ * state): the handle is a fresh `SystemTopology` on the same tables.  Stream-ordered. */
+int gorder_hip_reset(gorder_hip_handle *h);
 
 /* Ordermaps for the same reduction: copies the folded maps, i64 sums and u64 counts laid out
  * [3][n_acc][nx*ny] (n_u64 = 3 * n_acc * nx * ny words each, see gorder_hip_ordermap_dims), into caller-owned

@@ -66,6 +66,16 @@ int64_t gorder_xtc_read_window_mt(gorder_xtc_reader *r, float begin_ps, float en
                                   uint64_t *state, double *last_time, float *xyz, float *box9, float *time_ps,
                                   uint64_t capacity, uint32_t n_threads);
 
+/* ---- writer (tooling) --------------------------------------------------------------------------------
+ * The compression side of the same format, so that tests and the end-to-end benchmark can produce multi-frame
+ * XTC input for the reader -> GPU pipeline (the reference itself never writes trajectories).  Frames of up to
+ * 9 atoms are stored as raw floats, larger ones compressed with `precision` grid steps per nm (GROMACS default
+ * 1000).  A frame written here and read back through gorder_xtc_next gives round(x * precision) / precision. */
+typedef struct gorder_xtc_writer gorder_xtc_writer;
+int gorder_xtc_writer_open(const char *path, uint32_t n_atoms, float precision, gorder_xtc_writer **out);
+int gorder_xtc_writer_add(gorder_xtc_writer *w, const float *xyz, const float *box9, int64_t step, float time_ps);
+void gorder_xtc_writer_close(gorder_xtc_writer *w);
+
 #ifdef __cplusplus
 }
 #endif

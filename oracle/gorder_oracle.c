@@ -974,7 +974,8 @@ typedef struct {
     o_acc acc;
     int64_t *tw_s; uint64_t *tw_n; /* batch timewise rows (shared, disjoint rows per thread) */
     const float *manual;           /* manual normals of the batch or NULL */
-    int status; uint64_t err_index;
+    int status; uint64_t err_index; uint32_t err_frame;
+    int range_bad;   /* GORDER_ERR_BOX_RANGE met (the library's own range check): reported only if nothing else fails */
 } o_job;
 
 static void *worker(void *arg) {
@@ -987,14 +988,16 @@ static void *worker(void *arg) {
         float box3[3] = {0, 0, 0};
         if (h->pbc) {
             const int st = check_box(j->box + 9 * (size_t)f, box3);
-            if (st != GORDER_OK) { j->status = st; break; }
+            if (st == GORDER_ERR_BOX_RANGE) { j->range_bad = 1; continue; }   /* a frame the reference could not walk */
+            if (st != GORDER_OK) { j->status = st; j->err_frame = f; break; }
         }
         const int st = analyze_frame_orders(
             h, &j->acc, j->tw_s ? j->tw_s + row * f : NULL, j->tw_n ? j->tw_n + row * f : NULL,
             j->xyz + 3 * (size_t)h->n_atoms * f, box3,
             j->frame_flags ? j->frame_flags + (size_t)h->n_mol_total * f : NULL, &j->err_index, normals,
             j->manual ? j->manual + 3 * (size_t)h->n_mol_total * f : NULL);
-        if (st != GORDER_OK) { j->status = st; break; }
+        if (st == GORDER_ERR_BOX_RANGE) j->range_bad = 1;
+        else if (st != GORDER_OK) { j->status = st; j->err_frame = f; break; }
         if (normals && f + 1 == j->n_frames) memcpy(h->last_normals, normals, 4 * sizeof(float) * (size_t)h->n_mol_total);
     }
     free(normals);
@@ -1008,6 +1011,13 @@ int gorder_oracle_submit(gorder_oracle_handle *h, const float *xyz, const float 
     const size_t row = 3 * (size_t)h->n_acc;
     uint8_t *frame_flags = NULL;
     int status = GORDER_OK;
+    /* The error a batch reports is the one the reference's single-threaded walk meets first: frame by frame, inside a
+     * frame the box check, the leaflet assignment, then the order loop (common.rs:201-235, molecule.rs:54-95).  The
+     * leaflet pass below runs ahead of the order pass, so an error it finds in frame f only stands if the order pass
+     * over the frames before f is clean. */
+    int lf_status = GORDER_OK, range_bad = 0;
+    uint32_t lf_err_frame = n_frames;
+    uint64_t lf_err_index = 0;
     /* pass 1: leaflet flags per frame (sequential; molecule.rs:61-70) */
     if (h->lf.method != GORDER_LEAFLETS_NONE) {
         frame_flags = (uint8_t *)malloc((size_t)h->n_mol_total * n_frames);
@@ -1016,11 +1026,13 @@ int gorder_oracle_submit(gorder_oracle_handle *h, const float *xyz, const float 
             if (h->lf.method != GORDER_LEAFLETS_MANUAL && should_assign(h->lf.frequency, g)) {
                 float box3[3] = {0, 0, 0};
                 if (h->pbc) {
-                    status = check_box(box + 9 * (size_t)f, box3);
-                    if (status != GORDER_OK) goto done;
+                    lf_status = check_box(box + 9 * (size_t)f, box3);
+                    if (lf_status == GORDER_ERR_BOX_RANGE) { lf_status = GORDER_OK; range_bad = 1; box3[0] = box3[1] = box3[2] = 1.0f; }
+                    if (lf_status != GORDER_OK) { lf_err_frame = f; break; }
                 }
-                status = assign_leaflets(h, xyz + 3 * (size_t)h->n_atoms * f, box3, h->flags, h->flag_dist);
-                if (status != GORDER_OK) goto done;
+                lf_status = assign_leaflets(h, xyz + 3 * (size_t)h->n_atoms * f, box3, h->flags, h->flag_dist);
+                if (lf_status == GORDER_ERR_BOX_RANGE) { lf_status = GORDER_OK; range_bad = 1; }
+                if (lf_status != GORDER_OK) { lf_err_frame = f; lf_err_index = h->err_index; break; }
                 h->have_flags = 1;
                 h->flags_frame = g;
             }
@@ -1042,13 +1054,15 @@ int gorder_oracle_submit(gorder_oracle_handle *h, const float *xyz, const float 
         memset(tw_n, 0, row * n_frames * sizeof(uint64_t));
     }
     {
+        const uint32_t n_run = lf_err_frame;   /* frames the order pass may look at (all of them without a leaflet error) */
         uint32_t nthr = (uint32_t)h->n_threads;
-        if (nthr > n_frames) nthr = n_frames;
+        if (nthr > n_run) nthr = n_run;
+        uint32_t err_frame = n_frames;
         o_job *jobs = (o_job *)calloc(nthr, sizeof(o_job));
         pthread_t *th = (pthread_t *)calloc(nthr, sizeof(pthread_t));
         for (uint32_t t = 0; t < nthr; t++) {
             jobs[t].h = h; jobs[t].xyz = xyz; jobs[t].box = box; jobs[t].frame_flags = frame_flags;
-            jobs[t].n_frames = n_frames; jobs[t].tid = t; jobs[t].nthr = nthr;
+            jobs[t].n_frames = n_run; jobs[t].tid = t; jobs[t].nthr = nthr;
             jobs[t].manual = (h->manual_frames == n_frames) ? h->manual_normals : NULL;
             jobs[t].tw_s = tw_s; jobs[t].tw_n = tw_n; jobs[t].status = GORDER_OK;
             acc_alloc(h, &jobs[t].acc);
@@ -1058,8 +1072,10 @@ int gorder_oracle_submit(gorder_oracle_handle *h, const float *xyz, const float 
         const size_t ntile = (size_t)h->nx * h->ny;
         for (uint32_t t = 0; t < nthr; t++) {
             if (nthr > 1) pthread_join(th[t], NULL);
-            if (jobs[t].status != GORDER_OK && status == GORDER_OK) {
-                status = jobs[t].status;
+            if (jobs[t].range_bad) range_bad = 1;
+            if (jobs[t].status != GORDER_OK && (status == GORDER_OK || jobs[t].err_frame < err_frame)) {
+                status = jobs[t].status;          /* the error of the earliest frame */
+                err_frame = jobs[t].err_frame;
                 h->err_index = jobs[t].err_index;
             }
             /* SystemTopology::add, topology/mod.rs:236-254 */
@@ -1077,6 +1093,8 @@ int gorder_oracle_submit(gorder_oracle_handle *h, const float *xyz, const float 
         }
         free(jobs); free(th);
     }
+    if (status == GORDER_OK && lf_status != GORDER_OK) { status = lf_status; h->err_index = lf_err_index; }
+    if (status == GORDER_OK && range_bad) status = GORDER_ERR_BOX_RANGE;
     if (status == GORDER_OK) h->n_frames += n_frames;
 done:
     h->manual_frames = 0;   /* manual normals apply to one submit call */

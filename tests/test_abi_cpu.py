@@ -27,6 +27,15 @@ def test_library_exports_every_declared_symbol(built):
     assert set(names) == set(abi._EXPORTS)
 
 
+def test_reader_library_exports_every_declared_symbol(built):
+    lib = abi.load_library()
+    src = open(os.path.join(ROOT, "include", "gorder_xtc.h")).read()
+    names = sorted(set(re.findall(r"\b(gorder_xtc_[a-z_]+)\s*\(", src)))
+    assert len(names) >= 10
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/gorder_xtc.h but not exported"
+
+
 def test_strerror(built):
     lib = abi.load_library()
     assert lib.gorder_hip_strerror(0) == b"ok"

@@ -7,6 +7,7 @@ from gorder_amd import HipEngine, abi
 from gorder_amd import structure as st
 from oracle import oracle
 from golden_util import METHODS, Fixture, aa_setup, cg_setup, expected, ua_setup
+from leaflet_check import assert_sums_given_device_flags
 
 pytestmark = pytest.mark.gpu
 
@@ -68,6 +69,8 @@ def test_aa_order_leaflets(pcpepg, method):
     oflags, odist, _ = o.leaflets()
     diff = flags != oflags
     assert not diff.any() or np.abs(odist[diff]).max() < 1e-4   # only a lipid ON the mid-plane may differ
+    # the integer sums are compared in every case: equal to the oracle run with the device's own assignment
+    assert_sums_given_device_flags(tables, xyz, box, res, fi)
     if not diff.any():
         np.testing.assert_array_equal(res.sums, want.sums)
         np.testing.assert_array_equal(res.counts, want.counts)

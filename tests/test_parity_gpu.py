@@ -12,6 +12,7 @@ from gorder_amd import HipEngine, abi, synthetic
 from gorder_amd.abi import (LEAFLETS_GLOBAL, LEAFLETS_INDIVIDUAL, LEAFLETS_LOCAL, LEAFLETS_MANUAL,
                             LEAFLETS_NONE, MolType, Tables)
 from oracle import oracle
+from leaflet_check import assert_sums_given_device_flags
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-6   # BASELINE.json north_star: "every per-bond order parameter within 1e-6 of the reference"
@@ -128,6 +129,9 @@ def test_local_leaflets(built, radius, n_lipids, pbc):
     assert not diff.any() or np.abs(odist[diff]).max() < 1e-4
     np.testing.assert_allclose(eng.leaflet_distances()[~diff], odist[~diff], atol=5e-5)
     assert 0 < flags.sum() < len(flags)
+    # sums are compared whatever the flags did: EQUAL to the oracle fed with the device's own assignment, and the
+    # assignments differ in at most a few lipids that sit on the mid-plane
+    assert_sums_given_device_flags(system.tables, xyz, box, got)
     if not diff.any():
         np.testing.assert_array_equal(got.sums, want.sums)
         np.testing.assert_array_equal(got.counts, want.counts)
@@ -320,6 +324,53 @@ def test_errors_mirror_the_reference(built):
     assert e.value.status == abi.ERR_LEAFLETS_NOT_PRIMED
 
 
+@pytest.mark.parametrize("mode", ["tiled", "direct", "timewise", "gather", "ua"])
+def test_first_error_in_reference_order(built, monkeypatch, mode):
+    """Several undefined atoms in one batch: the status payload is the one the reference's single-threaded walk meets
+    first — lowest frame, then bond type, then molecule, first atom before second (bond.rs:406-417; united atoms:
+    uaorder.rs:400-437) — whichever wave of which kernel gets there first (64-bit error key + atomicMin)."""
+    torch_cuda()
+    if mode == "direct":
+        monkeypatch.setenv("GORDER_HIP_FORCE_DIRECT", "1")
+    if mode == "gather":
+        monkeypatch.setenv("GORDER_HIP_KERNEL", "gather")
+    if mode == "ua":
+        system = synthetic.ua_membrane(24)
+        apl = 52
+    else:
+        system = synthetic.cg_membrane(40, n_types=2, timewise=(mode == "timewise"))
+        apl = 12
+    n = 9
+    xyz = system.frames(n, seed=3)
+    box = system.box9(n)
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        x = xyz.copy()
+        # a handful of undefined atoms: several in the first bad frame (different lipids, beads that belong to early
+        # and late bond types, a lower atom index that comes LATER in the walk), more in later frames
+        f0 = int(rng.integers(1, n - 2))
+        lo, hi = (10, 42) if mode == "ua" else (0, apl)      # atoms that the order walk really reads
+        for f in (f0, f0, f0, f0 + 1, n - 1):
+            x[f, int(rng.integers(0, system.n_atoms // apl)) * apl + int(rng.integers(lo, hi)), 0] = np.nan
+        if trial == 0 and mode != "ua":      # bead 11 of lipid 1 (atom 23, last bond type) against bead 0 of lipid 2 (atom 24, first)
+            x = xyz.copy()
+            x[4, 23, 0] = np.nan
+            x[4, 24, 0] = np.nan
+            x[6, 0, 0] = np.nan
+        o = oracle.OracleEngine(system.tables, trig=oracle.TRIG_DIRECT)
+        with pytest.raises(oracle.OracleError) as oe:
+            o.submit(x, box)
+        for batches in (1, 3):
+            eng = HipEngine(system.tables)
+            edges = np.linspace(0, n, batches + 1).astype(int)
+            with pytest.raises(abi.GorderHipError) as e:
+                for a, b in zip(edges[:-1], edges[1:]):
+                    eng.submit_host(x[a:b], box[a:b], np.arange(a, b))
+                    eng.synchronize()
+            assert e.value.status == oe.value.status == abi.ERR_UNDEFINED_POSITION
+            assert e.value.index == oe.value.index, (mode, trial, batches)
+
+
 def test_priming_replaces_cross_thread_wait(built):
     # rank r starts at frame 6 with Every(5): it needs the assignment of frame 5 (leaflets.rs:1437-1472)
     torch = torch_cuda()
@@ -447,6 +498,7 @@ def test_global_leaflet_kernels(built, monkeypatch, variant):
     assert not diff.any() or np.abs(odist[diff]).max() < 1e-4
     np.testing.assert_allclose(eng.leaflet_distances()[~diff], odist[~diff], atol=5e-5)
     assert 0 < flags.sum() < len(flags)
+    assert_sums_given_device_flags(system.tables, xyz, system.box9(n), got)
     if not diff.any():
         np.testing.assert_array_equal(got.sums, want.sums)
         np.testing.assert_array_equal(got.counts, want.counts)
@@ -468,6 +520,7 @@ def test_local_leaflets_membrane_thicker_than_half_the_box(built):
     assert not diff.any() or np.abs(odist[diff]).max() < 1e-4
     np.testing.assert_allclose(eng.leaflet_distances()[~diff], odist[~diff], atol=5e-5)
     assert 0 < flags.sum() < len(flags)
+    assert_sums_given_device_flags(system.tables, xyz, system.box9(n), got)
     if not diff.any():
         np.testing.assert_array_equal(got.sums, want.sums)
 
@@ -497,3 +550,55 @@ def test_independent_handles_interleaved_and_threaded(built):
         _, want = run_oracle(s, data[k][0], data[k][1])
         np.testing.assert_array_equal(results[k].sums, want.sums)
         np.testing.assert_array_equal(results[k].counts, want.counts)
+
+
+@pytest.mark.parametrize("method", [LEAFLETS_GLOBAL, LEAFLETS_LOCAL, LEAFLETS_INDIVIDUAL])
+@pytest.mark.parametrize("frequency", [4, 0])
+def test_primed_shards_equal_one_handle(built, method, frequency):
+    """Frame-sharded ranks with a leaflet frequency other than every frame: a shard that starts between
+    two assignment frames is primed ON THE DEVICE with the one frame it depends on (gorder_hip_prime_leaflets:
+    carry row, flag buffer (re)allocation, the Local method's slab path) — shards cut at non-assignment frames,
+    added up, equal the single-handle run bit for bit, flags of the last assignment included."""
+    torch = torch_cuda()
+    system = synthetic.cg_membrane(96, leaflets=method, frequency=frequency, radius=2.0, n_types=2)
+    n = 22
+    xyz = system.frames(n, seed=31)
+    for f in range(n):                       # lipids change sides over time: which assignment a frame uses matters
+        k = 12 * (3 * f)
+        xyz[f:, k:k + 36, 2] = system.box[2] - xyz[f:, k:k + 36, 2]
+    box = system.box9(n)
+    d_xyz, d_box = torch.from_numpy(xyz).cuda(), torch.from_numpy(box).cuda()
+    whole = HipEngine(system.tables)
+    whole.submit_device(d_xyz, d_box)
+    want = whole.finish()
+    wflags, wframe = whole.leaflets()
+    assert want.counts[1].sum() > 0 and want.counts[2].sum() > 0
+    for cuts in ([0, 10, n], [0, 5, 13, n], [0, 1, 2, 3, n]):
+        sums, counts, last = 0, 0, None
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            eng = HipEngine(system.tables)
+            assign = 0 if frequency == 0 else (a // frequency) * frequency      # floor(frame / n) * n, leaflets.rs:1437-1472
+            if assign != a:
+                eng.prime_leaflets_device(d_xyz[assign], d_box[assign], assign)
+                f0, fr = eng.leaflets()
+                assert fr == assign
+            eng.submit_device(d_xyz[a:b].contiguous(), d_box[a:b].contiguous(), np.arange(a, b))
+            r = eng.finish()
+            assert r.n_frames == b - a
+            sums, counts, last = sums + r.sums, counts + r.counts, eng
+        np.testing.assert_array_equal(sums, want.sums)
+        np.testing.assert_array_equal(counts, want.counts)
+        lflags, lframe = last.leaflets()
+        assert lframe == wframe
+        np.testing.assert_array_equal(lflags, wflags)
+    # the priming frame goes through the same checks as an analysed frame
+    eng = HipEngine(system.tables)
+    with pytest.raises(abi.GorderHipError) as e:
+        eng.prime_leaflets_device(d_xyz[0], None, 0)
+    assert e.value.status == abi.ERR_INVALID_ARGUMENT
+    bad = d_box[0].clone()
+    bad[0, 1] = 0.3
+    eng.prime_leaflets_device(d_xyz[0], bad, 0)
+    with pytest.raises(abi.GorderHipError) as e:
+        eng.synchronize()
+    assert e.value.status == abi.ERR_NOT_ORTHOGONAL_BOX

@@ -165,3 +165,40 @@ def test_gro_triclinic_box_and_truncation(tmp_path, built):
     open(cut, "w").write(data[: len(data) - 60])            # the second frame loses its box line and last atom
     with pytest.raises(IOError):
         xtc.read_trajectory([cut])
+
+
+def test_writer_round_trip_and_reference_bytes(tmp_path, cg):
+    """The repo's own XTC encoder (tooling for the reader -> GPU pipeline tests): what it writes decodes to
+    round(x * precision) / precision, for compressed frames with runs, for boxes wide enough to need per-dimension
+    bit fields, and for tiny uncompressed frames; and re-encoding a frame of the reference's own file reproduces that
+    file byte for byte (same algorithm as the GROMACS writer that produced it)."""
+    rng = np.random.default_rng(3)
+    # a membrane-like system: neighbours close together (runs of small offsets), wrapped into the box
+    n, f = 5000, 4
+    base = np.cumsum(rng.normal(0, 0.08, (n, 3)), axis=0) % np.array([9.0, 9.0, 8.0])
+    xyz = (base[None] + rng.normal(0, 0.02, (f, n, 3))).astype(np.float32)
+    box = np.zeros((f, 3, 3), np.float32)
+    box[:, 0, 0], box[:, 1, 1], box[:, 2, 2] = 9.0, 9.0, 8.0
+    path = str(tmp_path / "w.xtc")
+    for prec in (1000.0, 100.0):
+        xtc.write_trajectory(path, xyz, box, times=np.arange(f) * 10.0, precision=prec)
+        back, bback, t, p = xtc.read_trajectory([path], return_precision=True)
+        assert p == prec and np.array_equal(t, np.arange(f, dtype=np.float32) * 10.0)
+        np.testing.assert_array_equal(bback, box)
+        want = (np.where(xyz >= 0, np.float32(prec) * xyz + np.float32(0.5), np.float32(prec) * xyz - np.float32(0.5))
+                .astype(np.int32).astype(np.float32) * (np.float32(1.0) / np.float32(prec)))
+        np.testing.assert_array_equal(back, want)
+        assert os.path.getsize(path) < 0.55 * xyz.nbytes            # the small-offset runs do compress
+    # coordinates spread over > 2^24 grid steps: per-dimension bit fields instead of one mixed-radix number
+    far = (rng.random((2, 300, 3)) * np.array([20000.0, 5.0, 5.0])).astype(np.float32)
+    xtc.write_trajectory(path, far, box[:2])
+    back = xtc.read_trajectory([path])[0]
+    np.testing.assert_allclose(back, far, atol=2e-3, rtol=1e-6)
+    # <= 9 atoms: raw floats
+    xtc.write_trajectory(path, xyz[:, :7], box)
+    np.testing.assert_array_equal(xtc.read_trajectory([path])[0], xyz[:, :7])
+    # the reference's frame, re-encoded: identical bytes
+    rx, rb, rt, rp = xtc.read_trajectory([CG3], return_precision=True)
+    xtc.write_trajectory(path, rx, rb, times=rt, precision=rp)
+    ours, theirs = open(path, "rb").read(), open(CG3, "rb").read()
+    assert ours[:8] == theirs[:8] and ours[12:] == theirs[12:]    # all but the step number, which the reader does not return
