@@ -1,26 +1,32 @@
 #!/usr/bin/env python3
 """bench.py — trajectory frames/s of the per-frame order-parameter path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload aa256|cg3k|cg1m] [--frames F]
+    python bench.py --gpus N --steps K --warmup W [--workload NAME] [--frames F] [--scaling strong|weak]
 
-A "step" is one pass of the hot path (gorder_hip_submit_device: box check + P2 kernels + leaflet
-kernels if enabled) over one batch of F synthetic frames that are ALREADY resident in HBM.
-Default workload = BASELINE.json configs[1]: AAOrder, 256-lipid membrane (25 088 selected atoms,
-16 384 C-H bonds per frame), 10 000 frames per step, one GPU.
-With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank analyses its own shard of
-F frames per step (frames are independent units: weak scaling, no data-path collective) and the ranks'
-i64 accumulators are summed by ONE RCCL all-reduce at the end of the timed region
-(= SystemTopology::reduce, /root/reference/src/analysis/topology/mod.rs:256-272).
+A "step" is one pass of the hot path (gorder_hip_submit_device: box check + P2 kernels + leaflet kernels if
+enabled) over one batch of synthetic frames that are ALREADY resident in HBM.
 
-Rank 0 prints ONE JSON line.  `roofline` is computed live from HIP events recorded on the launch
-stream around the per-frame kernels; `cpu_baseline` is the oracle (C restatement of the reference
-algorithm, libm trig exactly like the Rust code) timed on this box's host cores on a bounded sample.
+N = 1 (default): BASELINE.json configs[1] — AAOrder, 256-lipid membrane (25 088 selected atoms, 16 384 C-H bonds per
+  frame), 10 000 frames per step.  The JSON line also carries
+    roofline          the dominant kernel against the HBM roofline (HIP events on the launch stream),
+    cpu_baseline      the oracle (C restatement of the reference algorithm, libm trig like the Rust code) on this box's
+                      host cores, at 1 thread and at all cores,
+    end_to_end        the same workload from an XTC FILE: reader threads -> pinned staging -> copy stream -> kernels
+                      (gorder_hip_run_trajectory): frames/s from file, decoder threads, PCIe GB/s,
+    scaling_reference the north_star scaling job (CG-1M, 10 000 frames) on this one GPU: the N = 1 point of the curve
+                      that `--gpus N` continues.
+N > 1 (launched by torch.distributed.run, one rank per GPU): the north_star scaling experiment — STRONG scaling of
+  the 10 000-frame, 1 000 008-bead trajectory: rank r owns the contiguous frame shard [r F/N, (r+1) F/N), a step is the
+  whole job (reset, the rank's shard, ONE RCCL all-reduce of the packed i64 accumulators = SystemTopology::reduce,
+  /root/reference/src/analysis/topology/mod.rs:256-272), value = F / (max-over-ranks time per step).
+  `--scaling weak` keeps per-GPU work fixed instead (F frames per GPU and step, one all-reduce at the end).
 """
 import argparse
 import glob
 import json
 import os
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -30,6 +36,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+MIN_WARMUP_S = 0.03     # the chip needs ~20-30 ms of launches to settle its clocks, whatever --warmup says
 
 
 def make_system(name):
@@ -63,41 +70,153 @@ def make_system(name):
     raise SystemExit(f"unknown workload {name}")
 
 
-def cpu_baseline(system, seconds_target=12.0):
-    """Oracle (kind 'port') on the host cores: reference-faithful libm trig, one accumulator clone per
-    thread + ordered reduce like groan_rs' traj_iter_map_reduce."""
-    from oracle import oracle
+def host_cores():
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))   # a one-GPU box grants a 16-core CPU share
+    return max(1, min(cores, 16))   # a one-GPU box grants a 16-core CPU share
+
+
+def cpu_baseline(system, seconds_target=8.0):
+    """Oracle (kind 'port') on the host cores: reference-faithful libm trig, one accumulator clone per thread +
+    ordered reduce like groan_rs' traj_iter_map_reduce.  Timed at 1 thread and at all cores."""
+    from oracle import oracle
+    cores = host_cores()
     n_sample = max(cores * 4, min(512, int(2e8 // max(1, system.n_atoms * 12))))
     xyz = system.frames(n_sample, seed=99)
     box = system.box9(n_sample)
-    eng = oracle.OracleEngine(system.tables, trig=oracle.TRIG_LIBM, n_threads=cores)
-    t0 = time.perf_counter()
-    eng.submit(xyz, box)
-    t1 = time.perf_counter() - t0
-    reps = int(max(1, min(200, seconds_target / max(t1, 1e-6))))
-    t0 = time.perf_counter()
-    for _ in range(reps):
+
+    def timed(threads):
+        eng = oracle.OracleEngine(system.tables, trig=oracle.TRIG_LIBM, n_threads=threads)
+        t0 = time.perf_counter()
         eng.submit(xyz, box)
+        t1 = time.perf_counter() - t0
+        reps = int(max(1, min(200, seconds_target / max(t1, 1e-6))))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            eng.submit(xyz, box)
+        return reps * n_sample / (time.perf_counter() - t0), reps
+
+    all_cores, reps = timed(cores)
+    one, reps1 = timed(1)
+    return {"value": all_cores, "unit": "frames/s", "cores": cores, "kind": "port",
+            "value_1_thread": one,
+            "sample": f"{n_sample} synthetic frames of the same workload x {reps} passes on {cores} threads "
+                      f"(x {reps1} passes on 1 thread); libm trig, frame-interleaved threads + ordered reduce"}
+
+
+def warm_up(step, sync, n_steps, agree=None):
+    """At least n_steps passes AND at least MIN_WARMUP_S of launches.  With several ranks `agree(flag)` returns the OR
+    of the ranks' flags, so that every rank runs the same number of passes (the passes may contain collectives)."""
+    t0 = time.perf_counter()
+    done = 0
+    for _ in range(n_steps):
+        step()
+        done += 1
+    sync()
+    while True:
+        more = time.perf_counter() - t0 < MIN_WARMUP_S
+        if agree is not None:
+            more = agree(more)
+        if not more:
+            break
+        for _ in range(8):
+            step()
+            done += 1
+        sync()
+    return done
+
+
+def end_to_end(system, device_index, n_unique=500, repeats=40):
+    """The workload from an XTC FILE through gorder_hip_run_trajectory: the repo's encoder writes n_unique synthetic
+    frames (precision 1000 like GROMACS), the file is read `repeats` times as one concatenated trajectory."""
+    from gorder_amd import HipEngine, xtc
+    cores = host_cores()
+    xyz = system.frames(n_unique, seed=4242)
+    box = system.box9(n_unique)
+    with tempfile.TemporaryDirectory(prefix="gorder_bench_") as tmp:
+        path = os.path.join(tmp, "traj.xtc")
+        t0 = time.perf_counter()
+        xtc.write_trajectory(path, xyz, box, times=np.arange(n_unique, dtype=np.float32) * 10.0, precision=1000.0)
+        t_write = time.perf_counter() - t0
+        size = os.path.getsize(path)
+        system.tables.device = device_index
+        eng = HipEngine(system.tables)
+        eng.run_trajectory([path], threads=cores)            # warm: page cache, pinned pools, kernels
+        eng.reset()
+        stats = eng.run_trajectory([path] * repeats, threads=cores)
+        res = eng.finish()
+        eng.close()
+    n = stats["n_frames"]
+    assert n == n_unique * repeats == res.n_frames
+    sec = stats["seconds_total"]
+    return {"value": n / sec, "unit": "frames/s", "frames": n, "decoder_threads": stats["decoder_threads"],
+            "batch_frames": stats["batch_frames"], "batches": stats["n_batches"],
+            "pcie_GBps": stats["bytes_h2d"] / sec / 1e9, "file_MB": size * repeats / 1e6,
+            "file_read_MBps": size * repeats / sec / 1e6,
+            "seconds": {"total": sec, "decoding": stats["seconds_decode"],
+                        "reader_waiting_for_gpu": stats["seconds_reader_stalled"],
+                        "gpu_waiting_for_reader": stats["seconds_gpu_starved"]},
+            "bottleneck": "decoder" if stats["seconds_gpu_starved"] > stats["seconds_reader_stalled"] else "copy/kernels",
+            "path": "XTC file (repo encoder, precision 1000, %d frames read %d x as one concatenated trajectory, "
+                    "encoded in %.1f s) -> gorder_xtc_read_window_mt -> pinned staging x3 -> hipMemcpyAsync on a copy "
+                    "stream -> kernels (gorder_hip_run_trajectory)" % (n_unique, repeats, t_write)}
+
+
+def scaling_reference(device, steps=5):
+    """The north_star scaling job on ONE GPU: CG-1M, 10 000 resident frames (120 GB), one pass per step."""
+    import torch
+    from gorder_amd import HipEngine
+    system, workload = make_system("cg1m")
+    frames = 10000
+    system.tables.device = device.index
+    d_xyz, d_box = system.frames_device(frames, seed=1000, device=str(device))
+    eng = HipEngine(system.tables)
+    eng.use_torch_stream()
+    fidx = np.arange(frames, dtype=np.uint64)
+
+    def step():
+        eng.reset()
+        eng.submit_device(d_xyz, d_box, fidx)
+        eng.flush()
+
+    warm_up(step, eng.synchronize, 2)
+    eng.kernel_time(reset=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    eng.synchronize()
     dt = time.perf_counter() - t0
-    frames = reps * n_sample
-    return {"value": frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{n_sample} synthetic frames of the same workload x {reps} passes, "
-                      f"{cores} threads (libm trig, frame-interleaved threads + ordered reduce)"}
+    kernel_ms, launches = eng.kernel_time()
+    res = eng.finish()
+    ok = bool((res.counts[0] == frames * 83334).all()) and res.n_frames == frames
+    avg = kernel_ms / 1e3 / max(1, launches)
+    del d_xyz, d_box
+    eng.close()
+    torch.cuda.empty_cache()
+    return {"workload": workload + ", 10000 frames resident (120 GB), one job per step", "value": frames * steps / dt,
+            "unit": "frames/s", "n_gpus": 1, "steps": steps, "ms_per_step": dt / steps * 1e3,
+            "roofline_frac": system.bytes_per_frame * frames / avg / 1e9 / HBM_PEAK_GBS if avg > 0 else None,
+            "result_ok": ok}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=40)   # ~20 ms: the chip needs that long to settle its clocks
-    ap.add_argument("--workload", default="aa256")
-    ap.add_argument("--frames", type=int, default=0, help="frames per step per GPU (default: 10000, cg1m: 1000)")
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--workload", default=None, help="default: aa256 on one GPU, cg1m on several")
+    ap.add_argument("--frames", type=int, default=0,
+                    help="strong scaling: frames of the whole trajectory (default 10000); weak / one GPU: frames per "
+                         "step and GPU (default 10000, cg1m: 1000)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default=None, help="N > 1 only; default strong")
+    ap.add_argument("--collective", choices=["lib", "torch"], default="lib",
+                    help="N > 1: gorder_hip_allreduce (RCCL called by the library) or torch.distributed.all_reduce")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-scaling-reference", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -116,40 +235,96 @@ def main():
     rehearsal = os.environ.get("GORDER_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
+        args.collective = "torch"
     torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    # ONE stream for everything that touches the results: the handle's launches, torch's collectives and the timing
+    # events.  (torch's default stream is the NULL stream, which gorder_hip_set_stream reads as "use your own": the
+    # handle's launches would then not be ordered with torch.distributed's collectives.)
+    torch.cuda.set_stream(torch.cuda.Stream(device))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=device)
     if rank == 0:
         entry.build()          # no-op when the in-tree libraries are current
     if world > 1:
         dist.barrier()         # nobody loads the library while rank 0 may still be linking it
 
     from gorder_amd import HipEngine
-    system, workload = make_system(args.workload)
-    frames = args.frames or (1000 if args.workload == "cg1m" else 10000)
+    strong = world > 1 and (args.scaling or "strong") == "strong"
+    name = args.workload or ("cg1m" if world > 1 else "aa256")
+    system, workload = make_system(name)
     system.tables.device = local_rank
+    if strong:
+        total = args.frames or 10000
+        edges = np.linspace(0, total, world + 1).astype(np.int64)      # contiguous frame shards
+        first, frames = int(edges[rank]), int(edges[rank + 1] - edges[rank])
+    else:
+        frames = args.frames or (1000 if name == "cg1m" else 10000)
+        total = frames * world
+        first = rank * frames   # global frame indices of this rank's shard (topology/mod.rs:141-144)
 
     # synthetic frames, resident in HBM before the timed region; each rank owns its own shard
-    d_xyz, d_box = system.frames_device(frames, seed=1000 + rank, device=f"cuda:{local_rank}")
+    d_xyz, d_box = system.frames_device(frames, seed=1000 + rank, device=str(device))
     eng = HipEngine(system.tables)
     eng.use_torch_stream()
-    acc = torch.zeros(eng.accumulator_words(), dtype=torch.int64, device=f"cuda:{local_rank}")
+    acc = torch.zeros(eng.accumulator_words(), dtype=torch.int64, device=device)
     eng.bind_accumulators(acc)
-
-    first = rank * frames   # global frame indices of this rank's shard (topology/mod.rs:141-144)
     fidx = np.arange(first, first + frames, dtype=np.uint64)
 
-    def step():
-        eng.submit_device(d_xyz, d_box, fidx)
+    # ---- the collective: one all-reduce of the packed accumulators (+ ordermap grids when they are on)
+    comm, collective = None, None
+    if world > 1:
+        if args.collective == "lib":
+            try:      # the C-ABI route a non-Python host takes: RCCL called from inside the library
+                ids = [HipEngine.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                comm = eng.comm_create(ids[0], world, rank)
+                collective = "gorder_hip_allreduce: ncclAllReduce(int64, sum) issued by the library on the handle's stream"
+            except Exception as e:   # noqa: BLE001 — plumbing only: fall back to torch's RCCL binding
+                comm = None
+                print(f"[rank {rank}] library collective unavailable ({e}); using torch.distributed", file=sys.stderr)
+        ok = torch.tensor([1 if comm is not None else 0], device=device if not rehearsal else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if comm is not None:
+                eng.comm_destroy(comm)
+            comm = None
+            collective = "torch.distributed.all_reduce (%s)" % ("gloo, rehearsal" if rehearsal else "RCCL")
+    maps_on = bool(system.tables.ordermap.enabled)
 
-    for _ in range(args.warmup):
-        step()
-    eng.synchronize()
-    if world > 1:   # untimed: RCCL sets up its communicator and buffers on the first collective of a size
+    def reduce_results():
+        if comm is not None:
+            eng.allreduce(comm)              # accumulators and maps, in place, stream-ordered
+            return
+        eng.flush()   # fold the kernel's accumulator replicas into the packed block (stream-ordered, tiny)
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        if maps_on:   # ... plus the ordermap grids (Map::add)
+            n_map = 3 * eng.tables.n_acc * int(np.prod(eng.ordermap_dims()))
+            ms = torch.zeros(n_map, dtype=torch.int64, device=device)
+            mc = torch.zeros_like(ms)
+            eng.export_maps(ms, mc)
+            dist.all_reduce(ms, op=dist.ReduceOp.SUM)
+            dist.all_reduce(mc, op=dist.ReduceOp.SUM)
+
+    def step():
+        if strong:               # one step = the whole job: fresh accumulators, the rank's shard, the reduce
+            eng.reset()
+            eng.submit_device(d_xyz, d_box, fidx)
+            reduce_results()
+        else:
+            eng.submit_device(d_xyz, d_box, fidx)
+
+    def agree(flag):
+        f = torch.tensor([1 if flag else 0], device=device if not rehearsal else "cpu")
+        dist.all_reduce(f, op=dist.ReduceOp.MAX)
+        return bool(f.item())
+
+    n_warm = warm_up(step, eng.synchronize, args.warmup, agree if world > 1 else None)
+    if world > 1 and not strong:   # untimed: RCCL sets up its buffers on the first collective of a size
         dist.all_reduce(torch.zeros_like(acc), op=dist.ReduceOp.SUM)
         torch.cuda.synchronize()
     eng.kernel_time(reset=True)
@@ -163,66 +338,105 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    eng.flush()   # fold the kernel's accumulator replicas into the packed block (stream-ordered, tiny)
-    if world > 1:
-        dist.all_reduce(acc, op=dist.ReduceOp.SUM)   # RCCL over xGMI: the only collective of the path
-        if system.tables.ordermap.enabled:           # ... plus the ordermap grids when they are on (Map::add)
-            n_map = 3 * eng.tables.n_acc * int(np.prod(eng.ordermap_dims()))
-            ms = torch.zeros(n_map, dtype=torch.int64, device=f"cuda:{local_rank}")
-            mc = torch.zeros_like(ms)
-            eng.export_maps(ms, mc)
-            dist.all_reduce(ms, op=dist.ReduceOp.SUM)
-            dist.all_reduce(mc, op=dist.ReduceOp.SUM)
+    if world > 1 and not strong:
+        reduce_results()           # weak scaling: the only collective of the path, once at the end
+    elif world == 1:
+        eng.flush()
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([dt], dtype=torch.float64, device=device if not rehearsal else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     kernel_ms, launches = eng.kernel_time()
     res = eng.finish()
-    expect_frames = (args.steps + args.warmup) * frames * world   # warmup passes accumulate too
-    ok_counts = int(res.counts[0].min()) > 0
+    allreduce_ms = None
+    if world > 1:                  # the collective alone, after the timed region (what a step pays for it)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            reduce_results()
+        torch.cuda.synchronize()
+        allreduce_ms = (time.perf_counter() - t1) / 10 * 1e3
+    if strong:
+        expect_frames = total                                   # every step starts from fresh accumulators
+        # every slot holds total x (molecules of its type) samples after the last step's reduce
+        ok_counts = int(res.counts[0].min()) > 0 and bool((res.counts[0] % np.uint64(total) == 0).all())
+    else:
+        expect_frames = (args.steps + n_warm) * frames * world   # warm-up passes accumulate too
+        ok_counts = int(res.counts[0].min()) > 0
+    per_rank = None
+    if world > 1:                  # per-rank fraction of the HBM roofline on the rank's own shard
+        avg = kernel_ms / 1e3 / max(1, launches)
+        mine = torch.tensor([system.bytes_per_frame * frames / avg / 1e9 / HBM_PEAK_GBS if avg > 0 else 0.0],
+                            dtype=torch.float64, device=device if not rehearsal else "cpu")
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        per_rank = [float(g.item()) for g in gathered]
 
     if rank == 0:
         # HBM traffic of the dominant kernel comes from PMC counters, which need their own rocprofv3 passes
         # (tools/pmc.sh); the committed summary for this workload and launch size is reported, else null
         traffic, traffic_src = None, None
-        prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-        for cand in sorted(glob.glob(os.path.join(prof_dir, f"r*_pmc_{args.workload}_k_bonds_tiled.json")), reverse=True):
+        prof_dir = os.path.join(ROOT, "profiles")
+        for cand in sorted(glob.glob(os.path.join(prof_dir, f"r*_pmc_{name}_k_bonds_tiled.json")), reverse=True):
             with open(cand) as fh:
                 pmc = json.load(fh)
             if pmc.get("algorithmic_bytes_per_launch") == system.bytes_per_frame * frames and \
                     "hbm_traffic_bytes_per_launch" in pmc:
-                traffic, traffic_src = pmc["hbm_traffic_bytes_per_launch"], os.path.relpath(cand, os.path.dirname(prof_dir))
+                traffic, traffic_src = pmc["hbm_traffic_bytes_per_launch"], os.path.relpath(cand, ROOT)
                 break
-        total_frames = args.steps * frames * world
+        total_frames = args.steps * total
         value = total_frames / dt
         per_launch_bytes = system.bytes_per_frame * frames
         avg_launch_s = (kernel_ms / 1e3) / max(1, launches)
         achieved = per_launch_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        if world == 1:
+            parallelism = "single GPU"
+        elif strong:
+            parallelism = (f"strong scaling: {total} frames cut into {world} contiguous shards, every step = reset + shard "
+                           f"+ one all-reduce of {eng.accumulator_words()} int64 words")
+        else:
+            parallelism = f"weak scaling: frame-sharded x{world}, one int64 all-reduce at the end"
         out = {
             "metric": "trajectory frames/sec", "value": value, "unit": "frames/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": workload, "frames_per_step_per_gpu": frames, "atoms": system.n_atoms,
-                       "bonds_per_frame": system.tables.n_samples_per_frame,
-                       "parallelism": f"frame-sharded x{world}, one RCCL int64 all-reduce at the end"
-                       if world > 1 else "single GPU", "plan": eng.plan()},
+            "config": {"workload": workload, "frames_per_step_per_gpu": frames, "frames_per_step": total,
+                       "atoms": system.n_atoms, "bonds_per_frame": system.tables.n_samples_per_frame,
+                       "parallelism": parallelism, "collective": collective, "warmup_steps_run": n_warm,
+                       "plan": eng.plan()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
                          "traffic_source": traffic_src,
                          "kernel": "k_bonds_tiled", "launches": launches, "avg_launch_ms": avg_launch_s * 1e3,
-                         "algorithmic_bytes_per_launch": per_launch_bytes},
+                         "algorithmic_bytes_per_launch": per_launch_bytes, "frac_per_rank": per_rank},
             "sanity": {"frames_accumulated": res.n_frames, "expected": expect_frames, "counts_ok": ok_counts},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if allreduce_ms is not None:
+            out["allreduce_ms"] = allreduce_ms
+    if world == 1:
+        # release the headline workload's frames before the secondary measurements
+        del d_xyz, d_box
+        eng.close()
+        torch.cuda.empty_cache()
+        if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(system)
+        if not args.no_end_to_end:
+            out["end_to_end"] = end_to_end(system, local_rank)
+        if not args.no_scaling_reference and name == "aa256" and not args.frames:
+            free_b, _ = torch.cuda.mem_get_info(device)
+            if free_b > 150 * (1 << 30):
+                out["scaling_reference"] = scaling_reference(device)
+    if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
+        if comm is not None:
+            eng.comm_destroy(comm)
         dist.destroy_process_group()
 
 

@@ -466,6 +466,9 @@ class HipEngine:
         self._check(self.lib.gorder_hip_set_stream(self._h, C.c_void_p(stream_ptr)))
 
     def use_torch_stream(self):
+        """Launch on torch's CURRENT stream, so that torch ops (and torch.distributed collectives) issued on it are
+        ordered with the handle's work.  torch's default stream is the NULL stream, which the C ABI reads as "the
+        handle's own stream": make a torch.cuda.Stream current first if that ordering matters."""
         import torch
         self.set_stream(torch.cuda.current_stream().cuda_stream)
 

@@ -229,7 +229,7 @@ int check_device_error(gorder_hip_handle *h) {
     } else if (status == GORDER_ERR_DYNAMIC_NORMAL) {
         h->err_index = detail;                                                             // NotEnoughPoints(n)
     }
-    char buf[160];
+    char buf[200];
     snprintf(buf, sizeof(buf), "device raised %s (payload %llu) in batch frame %u", gorder_hip_strerror(status),
              (unsigned long long)h->err_index, frame);
     h->err_msg = buf;

@@ -81,6 +81,53 @@ struct UaSample {
     uint32_t slot0, kind, mol, type;
 };
 
+// Which lane of the workgroup evaluates which sample of a tile is free (the samples read their atoms from the LDS
+// window, not from memory), and it decides the LDS bank conflicts of K1's per-sample reads: a `ds_read_b32` is served
+// in two groups of 32 lanes over 32 banks (bank = dword address mod 32), a sample reads w[3 * atom + c], and
+// 3 (a - b) = 0 mod 32 only for a = b mod 32 — so two lanes of one half-wave collide exactly when their atoms differ by
+// a multiple of 32 (equal atoms broadcast).  Lanes in atom order put 35-50 consecutive atoms on every half-wave, and
+// with them such pairs (measured: 21 % of the LDS cycles on the all-atom, 37 % on the coarse-grained membranes).
+// Greedy repair: hand the samples, in atom order, to the first half-wave in which neither of their two atoms meets
+// another atom of its residue class; a sample that fits nowhere takes the emptiest half-wave.
+inline void spread_over_banks(Item *items, uint32_t n) {
+    constexpr uint32_t kHalf = 32, kBins = kBlock / kHalf;
+    if (n <= kHalf) return;
+    struct Bin {
+        int32_t at_i[kHalf], at_j[kHalf];     // residue -> the atom that owns it in this half-wave (-1: free)
+        std::vector<Item> got;
+    };
+    std::vector<Bin> bins(kBins);
+    for (Bin &b : bins) { std::fill(b.at_i, b.at_i + kHalf, -1); std::fill(b.at_j, b.at_j + kHalf, -1); }
+    const uint32_t n_bins = (n + kHalf - 1) / kHalf;      // the tile's lanes 0 .. n-1 are the active ones
+    auto cap = [&](uint32_t b) { return b + 1 < n_bins ? kHalf : n - kHalf * (n_bins - 1); };
+    std::vector<Item> late;
+    for (uint32_t q = 0; q < n; q++) {
+        const Item it = items[q];
+        bool placed = false;
+        for (uint32_t b = 0; b < n_bins && !placed; b++) {
+            Bin &bin = bins[b];
+            if (bin.got.size() >= cap(b)) continue;
+            const int32_t oi = bin.at_i[it.li % kHalf], oj = bin.at_j[it.lj % kHalf];
+            if ((oi >= 0 && oi != (int32_t)it.li) || (oj >= 0 && oj != (int32_t)it.lj)) continue;
+            bin.at_i[it.li % kHalf] = it.li;
+            bin.at_j[it.lj % kHalf] = it.lj;
+            bin.got.push_back(it);
+            placed = true;
+        }
+        if (!placed) late.push_back(it);
+    }
+    for (const Item &it : late) {                         // whatever is left: the emptiest half-wave
+        uint32_t best = 0;
+        size_t room = 0;
+        for (uint32_t b = 0; b < n_bins; b++)
+            if (cap(b) - std::min<size_t>(cap(b), bins[b].got.size()) > room) { room = cap(b) - bins[b].got.size(); best = b; }
+        bins[best].got.push_back(it);
+    }
+    uint32_t q = 0;
+    for (uint32_t b = 0; b < n_bins; b++)
+        for (const Item &it : bins[b].got) items[q++] = it;
+}
+
 // Returns GORDER_OK or GORDER_ERR_INVALID_ARGUMENT (index out of range, self bond, ...).
 inline int build_plan(const gorder_tables_t &t, bool force_direct, Plan &p) {
     p = Plan();
@@ -254,6 +301,7 @@ inline int build_plan(const gorder_tables_t &t, bool force_direct, Plan &p) {
         tile.n_slots = (uint32_t)slots.size();
         p.tile_slots.insert(p.tile_slots.end(), slots.begin(), slots.end());
         p.max_window = std::max(p.max_window, tile.n_window);
+        spread_over_banks(p.items.data() + tile.item0, tile.n_items);
         p.tiles.push_back(tile);
     }
     {   // slot-ordered copy of the tile items + the runs of every slot (see MapRun)

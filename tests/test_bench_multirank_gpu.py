@@ -12,19 +12,37 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("workload,frames", [("aa256", 600), ("ua256-maps", 200)])
-def test_two_ranks_on_one_gpu(built, workload, frames):
+def launch(extra, port):
     env = dict(os.environ, GORDER_BENCH_REHEARSAL="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
-           "--warmup", "2", "--frames", str(frames), "--workload", workload]
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "2"] + extra
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=280)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1                                     # rank 0 prints ONE JSON line
-    out = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("workload,frames", [("aa256", 600), ("ua256-maps", 200)])
+def test_two_ranks_on_one_gpu_weak(built, workload, frames):
+    out = launch(["--frames", str(frames), "--workload", workload, "--scaling", "weak"], 29533)
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["unit"] == "frames/s"
     # every frame of both ranks' shards (warm-up passes included) arrived in the reduced accumulators
-    assert out["sanity"]["frames_accumulated"] == out["sanity"]["expected"] == (3 + 2) * frames * 2
+    n_warm = out["config"]["warmup_steps_run"]
+    assert n_warm >= 2
+    assert out["sanity"]["frames_accumulated"] == out["sanity"]["expected"] == (3 + n_warm) * frames * 2
     assert out["sanity"]["counts_ok"]
     assert out["value"] > 0 and "cpu_baseline" not in out      # the CPU baseline is an N = 1 thing
+
+
+def test_two_ranks_strong_scaling_default(built):
+    """`--gpus N` with N > 1 runs the north_star experiment: STRONG scaling of one CG-1M trajectory cut into contiguous
+    frame shards, every step = reset + shard + one all-reduce (here 301 frames instead of 10 000: 151 + 150)."""
+    out = launch(["--frames", "301"], 29534)
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong"
+    assert "1M-bead" in out["config"]["workload"] and out["config"]["frames_per_step"] == 301
+    assert out["config"]["frames_per_step_per_gpu"] in (150, 151)
+    assert out["sanity"]["frames_accumulated"] == out["sanity"]["expected"] == 301    # the job, not the warm-up
+    assert out["sanity"]["counts_ok"] and out["value"] > 0
+    assert len(out["roofline"]["frac_per_rank"]) == 2 and out["allreduce_ms"] > 0

@@ -602,3 +602,42 @@ def test_primed_shards_equal_one_handle(built, method, frequency):
     with pytest.raises(abi.GorderHipError) as e:
         eng.synchronize()
     assert e.value.status == abi.ERR_NOT_ORTHOGONAL_BOX
+
+
+def test_library_allreduce_and_reset(built):
+    """gorder_hip_allreduce: RCCL called from inside the library over the packed accumulators and the ordermaps — with
+    a single-rank communicator (all one GPU can host) the reduce is the identity, which pins the plumbing: RCCL binding,
+    communicator helpers, in-place ncclInt64 sums on the handle's stream, maps included.  gorder_hip_reset then gives a
+    fresh SystemTopology: the same batch again reproduces the same results, not twice the sums."""
+    torch = torch_cuda()
+    om = abi.OrderMap(enabled=True, plane=0, span_x=(0.0, 6.0), span_y=(0.0, 6.0), bin=(0.5, 0.5))
+    system = synthetic.cg_membrane(90, leaflets=LEAFLETS_GLOBAL, n_types=2, ordermap=om, timewise=True)
+    n = 11
+    xyz = system.frames(n, seed=12)
+    box = system.box9(n)
+    plain = HipEngine(system.tables)
+    plain.submit_host(xyz, box)
+    want = plain.finish()
+    eng = HipEngine(system.tables)
+    uid = HipEngine.comm_unique_id()
+    assert len(uid) == 128
+    comm = eng.comm_create(uid, 1, 0)
+    eng.submit_host(xyz, box)
+    eng.allreduce(comm)
+    got = eng.finish()
+    for a, b in ((got.sums, want.sums), (got.counts, want.counts), (got.map_sums, want.map_sums),
+                 (got.map_counts, want.map_counts)):
+        np.testing.assert_array_equal(a, b)
+    assert got.n_frames == n
+    eng.reset()
+    assert eng.finish().n_frames == 0 and eng.finish().counts.sum() == 0
+    eng.submit_host(xyz, box)
+    eng.allreduce(comm)
+    again = eng.finish()
+    np.testing.assert_array_equal(again.sums, want.sums)
+    np.testing.assert_array_equal(again.map_counts, want.map_counts)
+    tw_s, tw_c = eng.timewise(n)
+    pw_s, pw_c = plain.timewise(n)
+    np.testing.assert_array_equal(tw_s, pw_s)
+    np.testing.assert_array_equal(tw_c, pw_c)
+    eng.comm_destroy(comm)
