@@ -417,6 +417,127 @@ __device__ __forceinline__ UaBonds ua_carbon(uint32_t kind, UaCarbon c, UaConsts
     r.bad = pb.bad;
     return r;
 }
+// ---- the same constructions with PAIRS of vectors in packed registers (v_pk_mul / v_pk_add / v_pk_fma_f32 do two
+// f32 operations per lane and instruction).  A methylene carbon does everything twice — two helper vectors are made
+// periodic and normalised, two hydrogens are rotated (by +- the same angle about the same axis), shifted, wrapped and
+// turned into bond vectors — and a methyl carbon does so for its second and third hydrogen.  Lane 0 / lane 1 of an `f2`
+// hold the two instances; every component goes through exactly the operations of the scalar code above (IEEE
+// multiplication is sign-symmetric, so u * (-s) = -(u * s) and a - (-b) = a + b bit for bit), hence the same bits.
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef int i2 __attribute__((ext_vector_type(2)));
+struct V3P { f2 x, y, z; };
+__device__ __forceinline__ f2 f2_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 f2_splat(float v) { return f2{v, v}; }
+__device__ __forceinline__ V3 v3p_lane0(V3P a) { return {a.x.x, a.y.x, a.z.x}; }
+__device__ __forceinline__ V3 v3p_lane1(V3P a) { return {a.x.y, a.y.y, a.z.y}; }
+struct PbcStep2 {       // PbcStep on pairs
+    V3 box;
+    bool pbc;
+    i2 slow2 = {0, 0};       // the "one shift was not enough" conditions, OR-ed per lane; reduced once by slow()
+    __device__ __forceinline__ bool slow() const { return (slow2.x | slow2.y) != 0; }
+    __device__ __forceinline__ f2 mi(f2 d, float L) {
+        if (!pbc) return d;
+        const f2 Lv = f2_splat(L), half = Lv / 2.0f;
+        const f2 r = __builtin_elementwise_abs(d) > half ? d - __builtin_elementwise_copysign(Lv, d) : d;
+        slow2 |= __builtin_elementwise_abs(r) > half;
+        return r;
+    }
+    __device__ __forceinline__ f2 wr(f2 x, float L) {
+        if (!pbc) return x;
+        const f2 Lv = f2_splat(L), zero = f2_splat(0.0f);
+        const f2 r = x > Lv ? x - Lv : (x < zero ? x + Lv : x);
+        slow2 |= (r > Lv) | (r < zero);
+        return r;
+    }
+    __device__ __forceinline__ V3P unit(V3P a) {       // PbcStep::unit, twice
+        const f2 s2 = (a.x * a.x + a.y * a.y) + a.z * a.z;
+        slow2 |= ~((s2 >= f2_splat(0x1p-40f)) & (s2 <= f2_splat(0x1p+40f)));
+        const f2 s = f2{__builtin_amdgcn_sqrtf(s2.x), __builtin_amdgcn_sqrtf(s2.y)};      // gm_sqrt_core
+        const i2 si = __builtin_bit_cast(i2, s);
+        const f2 sm = __builtin_bit_cast(f2, si - 1), sp = __builtin_bit_cast(f2, si + 1);
+        const f2 rm = f2_fma(-sm, s, s2), rp = f2_fma(-sp, s, s2);
+        f2 n = rm <= f2_splat(0.0f) ? sm : s;
+        n = rp > f2_splat(0.0f) ? sp : n;
+        f2 r = f2{__builtin_amdgcn_rcpf(n.x), __builtin_amdgcn_rcpf(n.y)};
+        r = f2_fma(f2_fma(-n, r, f2_splat(1.0f)), r, r);
+        auto quot = [&](f2 c) {
+            f2 q = c * r;
+            q = f2_fma(f2_fma(-n, q, c), r, q);
+            return f2_fma(f2_fma(-n, q, c), r, q);
+        };
+        return {quot(a.x), quot(a.y), quot(a.z)};
+    }
+};
+// target -> the two points (p, q), periodic
+__device__ __forceinline__ V3P v3p_to(V3 t, V3 p, V3 q, PbcStep2 &pb) {
+    return {pb.mi(f2{p.x, q.x} - f2_splat(t.x), pb.box.x), pb.mi(f2{p.y, q.y} - f2_splat(t.y), pb.box.y),
+            pb.mi(f2{p.z, q.z} - f2_splat(t.z), pb.box.z)};
+}
+__device__ __forceinline__ V3P v3p_to(V3 t, V3P h, PbcStep2 &pb) {
+    return {pb.mi(h.x - f2_splat(t.x), pb.box.x), pb.mi(h.y - f2_splat(t.y), pb.box.y), pb.mi(h.z - f2_splat(t.z), pb.box.z)};
+}
+// v rotated about the unit axis u by +angle (lane 0) and -angle (lane 1): v3_rotate with s = (+s, -s)
+__device__ __forceinline__ V3P v3p_rotate_pm(V3 u, float s, float c, V3 v) {
+    const float sqx = u.x * u.x, sqy = u.y * u.y, sqz = u.z * u.z, omc = 1.0f - c;
+    const f2 sv = f2{s, -s};
+    const f2 uxs = f2_splat(u.x) * sv, uys = f2_splat(u.y) * sv, uzs = f2_splat(u.z) * sv;
+    const float xy = u.x * u.y * omc, xz = u.x * u.z * omc, yz = u.y * u.z * omc;
+    const float m11 = sqx + (1.0f - sqx) * c, m22 = sqy + (1.0f - sqy) * c, m33 = sqz + (1.0f - sqz) * c;
+    const f2 m12 = f2_splat(xy) - uzs, m13 = f2_splat(xz) + uys;
+    const f2 m21 = f2_splat(xy) + uzs, m23 = f2_splat(yz) - uxs;
+    const f2 m31 = f2_splat(xz) - uys, m32 = f2_splat(yz) + uxs;
+    const f2 vx = f2_splat(v.x), vy = f2_splat(v.y), vz = f2_splat(v.z);
+    return {(f2_splat(m11) * vx + m12 * vy) + m13 * vz, (m21 * vx + f2_splat(m22) * vy) + m23 * vz,
+            (m31 * vx + m32 * vy) + f2_splat(m33) * vz};
+}
+__device__ __forceinline__ V3P v3p_shift_wrap(V3 t, V3P dir, PbcStep2 &pb) {
+    const V3P u = pb.unit(dir);
+    return {pb.wr(f2_splat(t.x) + u.x * 0.109f, pb.box.x), pb.wr(f2_splat(t.y) + u.y * 0.109f, pb.box.y),
+            pb.wr(f2_splat(t.z) + u.z * 0.109f, pb.box.z)};   // BOND_LENGTH
+}
+// CH2 and CH3 carbons by pairs; `slow` comes back raised when a literal-loop evaluation is needed instead
+__device__ __forceinline__ UaBonds ua_carbon_pairs(uint32_t kind, UaCarbon c, UaConsts e, V3 box, bool pbc, bool &slow) {
+    const V3 zero{0.0f, 0.0f, 0.0f};
+    const V3 target = c.p1;
+    PbcStep ps{box, pbc};
+    PbcStep2 pp{box, pbc};
+    UaBonds r;
+    r.v2 = r.b2 = zero;
+    V3P h;                                   // CH2: hydrogens 0, 1; CH3: hydrogens 1, 2
+    if (kind == GORDER_UA_CH2) {            // uaorder.rs:985-1020
+        const V3P th = pp.unit(v3p_to(target, c.p0, c.p2, pp));
+        const V3 th1 = v3p_lane0(th), th2 = v3p_lane1(th);
+        const V3 pn = v3_cross(th2, th1);
+        const V3 ra = ps.unit(V3{th1.x - th2.x, th1.y - th2.y, th1.z - th2.z});
+        const V3 rv = v3_cross(pn, ra);
+        const V3 ura = ps.unit(ra);
+        h = v3p_shift_wrap(target, v3p_rotate_pm(ura, e.sin_half, e.cos_half, rv), pp);
+    } else {                                // CH3, uaorder.rs:947-981
+        const V3P th = v3p_to(target, c.p0, c.p2, pp);
+        const V3 th1 = v3p_lane0(th), th2 = v3p_lane1(th);
+        const V3 ua = ps.unit(v3_cross(th2, th1));
+        const V3 hv1 = v3_rotate(ua, e.sin_tet, e.cos_tet, th1);
+        const V3 h0 = v3_shift_wrap(target, hv1, ps);
+        const V3 n1 = ps.unit(th1);
+        h = v3p_shift_wrap(target, v3p_rotate_pm(n1, e.sin_ch3, e.cos_ch3, hv1), pp);
+        r.v0 = v3_to(target, h0, ps);
+        r.b0 = {h0.x + r.v0.x / 2.0f, h0.y + r.v0.y / 2.0f, h0.z + r.v0.z / 2.0f};
+    }
+    // bond vectors target -> H and bond positions H + v / 2 (UAAtom::calculate_sch, uaorder.rs:375-397)
+    const V3P v = v3p_to(target, h, pp);
+    const V3P b = {h.x + v.x / 2.0f, h.y + v.y / 2.0f, h.z + v.z / 2.0f};
+    if (kind == GORDER_UA_CH2) {
+        r.v0 = v3p_lane0(v); r.b0 = v3p_lane0(b);
+        r.v1 = v3p_lane1(v); r.b1 = v3p_lane1(b);
+    } else {
+        r.v1 = v3p_lane0(v); r.b1 = v3p_lane0(b);
+        r.v2 = v3p_lane1(v); r.b2 = v3p_lane1(b);
+    }
+    r.bad = 0;
+    slow = ps.slow || pp.slow();
+    return r;
+}
+
 // the literal-loop variant, kept out of line: it runs only for carbons more than 1.5 box lengths away
 // from a helper
 __device__ __noinline__ UaBonds ua_carbon_slow(uint32_t kind, UaCarbon c, UaConsts e, V3 box, bool pbc) {
@@ -498,9 +619,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             else if (c.p1.x != c.p1.x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, f, kStageTypes, gslot0, 1, it.mol, 1);
             else if (c.p2.x != c.p2.x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, f, kStageTypes, gslot0, 1, it.mol, 2);
             else if (c.p3.x != c.p3.x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, f, kStageTypes, gslot0, 1, it.mol, 3);
-            PbcStep ps{bx3, pbc};
-            UaBonds ub = ua_carbon(kind, c, uc, ps);
-            if (__builtin_expect(ps.slow, 0)) {
+            bool slow = false;
+            UaBonds ub;
+            if (kind == GORDER_UA_CH2 || kind == GORDER_UA_CH3) {       // the two common kinds: paired arithmetic
+                ub = ua_carbon_pairs(kind, c, uc, bx3, pbc, slow);
+            } else {
+                PbcStep ps{bx3, pbc};
+                ub = ua_carbon(kind, c, uc, ps);
+                slow = ps.slow;
+            }
+            if (__builtin_expect(slow, 0)) {
                 ub = ua_carbon_slow(kind, c, uc, bx3, pbc);
                 bad |= ub.bad;
             }

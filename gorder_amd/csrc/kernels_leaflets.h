@@ -468,7 +468,7 @@ constexpr uint32_t kLocalMaxCells1D = 128;
 // 36 864-bead membrane gains 10 % from 32 -> 128 frames, nothing beyond: the small binning kernels get amortised)
 constexpr uint32_t kLocalSlabMax = 128;
 inline uint32_t local_slab_frames(size_t n_membrane) {
-    const size_t per_frame = n_membrane * 24u + (size_t)2 * kLocalMaxCells1D * kLocalMaxCells1D * 4u + 8u;
+    const size_t per_frame = n_membrane * 24u + (size_t)(2 * 4u + 32u) * kLocalMaxCells1D * kLocalMaxCells1D + 8u;
     const size_t n = ((size_t)256 << 20) / per_frame;
     return (uint32_t)(n < 4 ? 4 : (n > kLocalSlabMax ? kLocalSlabMax : n));
 }
@@ -502,6 +502,7 @@ struct LocalArgs {
     float *rsn;                 // [n_slab][n_membrane] sin of the normal angle, cell order
     uint32_t *cell_count;       // [n_slab][kLocalMaxCells1D^2 + 1] counts -> starts
     uint32_t *cell_fill;        // [n_slab][kLocalMaxCells1D^2]
+    float4 *agg;                // [n_slab][kLocalMaxCells1D^2][2] per-cell sums (k_local_cellsums) for k_local_flags, or null
     uint32_t *err;
 };
 
@@ -672,6 +673,55 @@ __global__ __launch_bounds__(256) void k_local_scatter(LocalArgs a) {
     a.rsn[q] = sn;
 }
 
+// Per cell: what the members' sums need from a cell ALL of whose atoms are members (k_local_flags takes such a cell
+// as a whole instead of atom by atom): agg[2c] = (sum cos, sum sin, sum z, count), agg[2c + 1] = (z min, z max, -, -).
+// A non-finite coordinate poisons the z sum (NaN) and so, as before, the centre of every head that includes the cell.
+// A quarter wave per cell: its 16 lanes read the cell's records as contiguous 256-byte pieces and fold them with DPP
+// row shifts (a row IS 16 lanes), in a fixed order.  Launched with a fixed number of blocks per frame (the grid of a
+// frame is only known on the device), each taking every gridDim.x-th group of 16 cells.
+template <int CTRL>
+__device__ __forceinline__ float row_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ float row_shifted(float v) {      // out-of-row lanes keep their own value
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__global__ __launch_bounds__(256) void k_local_cellsums(LocalArgs a) {
+    const uint32_t s = blockIdx.y, sub = threadIdx.x & 15u;
+    const uint4 g = a.grid[s];
+    const uint32_t ncell = g.x * g.y;
+    const uint32_t *cstart = a.cell_count + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u);
+    const float4 *rec = reinterpret_cast<const float4 *>(a.trig) + (size_t)s * a.n_membrane;
+    const float *rsn = a.rsn + (size_t)s * a.n_membrane;
+    float4 *out = a.agg + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D) * 2u;
+    for (uint32_t c = blockIdx.x * 16u + (threadIdx.x >> 4); c < ncell; c += gridDim.x * 16u) {
+        const uint32_t q0 = cstart[c], q1 = cstart[c + 1u];
+        float sc = 0.0f, ss = 0.0f, sz = 0.0f, zlo = 3.0e38f, zhi = -3.0e38f;
+        for (uint32_t q = q0 + sub; q < q1; q += 16u) {
+            const float4 r = rec[q];
+            sc += r.w;
+            ss += rsn[q];
+            sz += r.z;
+            zlo = fminf(zlo, r.z);
+            zhi = fmaxf(zhi, r.z);
+        }
+        // Hillis-Steele over the row: lane 15 ends with the row's total / extrema
+        sc = row_add<0x111>(sc); ss = row_add<0x111>(ss); sz = row_add<0x111>(sz);
+        zlo = fminf(zlo, row_shifted<0x111>(zlo)); zhi = fmaxf(zhi, row_shifted<0x111>(zhi));
+        sc = row_add<0x112>(sc); ss = row_add<0x112>(ss); sz = row_add<0x112>(sz);
+        zlo = fminf(zlo, row_shifted<0x112>(zlo)); zhi = fmaxf(zhi, row_shifted<0x112>(zhi));
+        sc = row_add<0x114>(sc); ss = row_add<0x114>(ss); sz = row_add<0x114>(sz);
+        zlo = fminf(zlo, row_shifted<0x114>(zlo)); zhi = fmaxf(zhi, row_shifted<0x114>(zhi));
+        sc = row_add<0x118>(sc); ss = row_add<0x118>(ss); sz = row_add<0x118>(sz);
+        zlo = fminf(zlo, row_shifted<0x118>(zlo)); zhi = fmaxf(zhi, row_shifted<0x118>(zhi));
+        if (sub == 15u) {
+            out[2u * c] = make_float4(sc, ss, sz, (float)(q1 - q0));
+            out[2u * c + 1u] = make_float4(zlo, zhi, 0.0f, 0.0f);
+        }
+    }
+}
+
 // `sqrt(d2) < radius` (groan_rs Cylinder::inside) is evaluated as `d2 < thr` with thr = the smallest float
 // whose correctly rounded square root reaches the radius: sqrt is monotonic, so the two tests select
 // exactly the same atoms.  Computed once on the host; k_local_flags gets it as LocalArgs::radius_thr.
@@ -773,9 +823,127 @@ __global__ __launch_bounds__(256) void k_local_flags(LocalArgs a) {
     // Every load address of the passes below then comes from a lane read-out instead of a chain of
     // dependent cell-table loads, so the loads of several iterations are in flight together — this
     // kernel is bound by load latency, not by arithmetic.
+    float sc = 0.0f, ss = 0.0f, sp = 0.0f, su = 0.0f, ulo = 3.0e38f, uhi = -3.0e38f;
+    uint32_t cnt = 0, nf = 0;
+    bool done = false;
+    // ---- cells instead of atoms where a whole cell lies inside the cylinder -------------------------------------
+    // The head's (2ka+1) x (2kb+1) cells, one per lane: a cell whose farthest corner is closer than the radius holds
+    // members only — its precomputed sums (k_local_cellsums) are added as a block; a cell whose nearest point is
+    // farther holds none; only the ring of cells the circle crosses is looked at atom by atom, FOUR cells per wave
+    // iteration (a cell holds about as many atoms as a quarter wave has lanes).  Membership itself stays the exact
+    // distance test; the margins only decide who is tested.  Every periodic image of a neighbourhood cell other than
+    // the direct one lies beyond the radius (at least k cells of >= 1.0001 r / k away, local_axis), so the direct
+    // displacement is the minimum image here — unless a coordinate sits outside the box, which the flag `redo` catches.
+    constexpr uint32_t kRingChunks = 4, kRingCap = 128u * kRingChunks;
+    __shared__ uint2 l_ring[4][kRingCap];
+    if (pbc && a.agg && a.grid && n_rows * n_cols <= 128u && ka >= 1u && kb >= 1u) {
+        const float halfn = Ln / 2.0f;
+        const float ca = La / (float)nca, cb = Lb / (float)ncb;            // cell edges
+        // the head inside its cell, from its wrapped coordinates (what the cells were made from)
+        const float fa = gm_wrap(ha_pos, La, bad) - (float)ha * ca, fb = gm_wrap(hb_pos, Lb, bad) - (float)hb * cb;
+        const float r_in = thr * (1.0f - 4e-4f), r_out = thr * (1.0f + 4e-4f);
+        const float4 *agg = a.agg + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D) * 2u;
+        uint2 *ring = l_ring[threadIdx.x >> 6];
+        uint32_t n_ring = 0;
+        bool redo = false;
+        const uint32_t inv_cols = n_cols == 9u ? 7282u : (65536u + n_cols - 1u) / n_cols;
+        for (uint32_t c0 = 0; c0 < n_rows * n_cols; c0 += 64u) {
+            const uint32_t ci = c0 + lane;
+            const bool valid = ci < n_rows * n_cols;
+            // ci / n_cols for ci < 128, n_cols <= 128 by one multiplication: floor(ci * ceil(2^16 / n) / 2^16) is exact there
+            const uint32_t ia = valid ? (ci * inv_cols) >> 16 : 0u, ib = valid ? ci - ia * n_cols : 0u;
+            // the cell's rectangle relative to the head
+            const float a_lo = ((float)ia - (float)ka) * ca - fa, a_hi = a_lo + ca;
+            const float b_lo = ((float)ib - (float)kb) * cb - fb, b_hi = b_lo + cb;
+            const float fa_far = fmaxf(fabsf(a_lo), fabsf(a_hi)), fb_far = fmaxf(fabsf(b_lo), fabsf(b_hi));
+            const float fa_near = (a_lo <= 0.0f && a_hi >= 0.0f) ? 0.0f : fminf(fabsf(a_lo), fabsf(a_hi));
+            const float fb_near = (b_lo <= 0.0f && b_hi >= 0.0f) ? 0.0f : fminf(fabsf(b_lo), fabsf(b_hi));
+            const bool inner = valid && (fa_far * fa_far + fb_far * fb_far < r_in);
+            const bool outer = !valid || (fa_near * fa_near + fb_near * fb_near > r_out);
+            uint32_t ra = a0 + ia, rb = b0 + ib;
+            ra -= ra >= nca ? nca : 0u;
+            rb -= rb >= ncb ? ncb : 0u;
+            const uint32_t cell = ra * ncb + rb;
+            bool ring_cell = !inner && !outer;
+            // every load of this round goes out before the first use: sums of inner cells, runs of the others
+            const float4 g0 = inner ? agg[2u * cell] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            const float4 g1 = inner ? agg[2u * cell + 1u] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            const uint32_t q0 = outer ? 0u : cstart[cell], q1 = outer ? 0u : cstart[cell + 1u];
+            if (inner && g0.w > 0.0f) {
+                // the block sum of u = MI(z - z_head) is sum z - n z_head when no atom of the cell needs a shift
+                if (!(g1.x - hn_pos >= -halfn && g1.y - hn_pos <= halfn && g0.z - g0.z == 0.0f)) {
+                    ring_cell = true;                               // atom by atom instead (also carries a NaN on)
+                } else {
+                    cnt += (uint32_t)g0.w;
+                    sc += g0.x;
+                    ss += g0.y;
+                    su += g0.z - g0.w * hn_pos;
+                    ulo = fminf(ulo, g1.x - hn_pos);
+                    uhi = fmaxf(uhi, g1.y - hn_pos);
+                }
+            }
+            // ring cells go to the wave's list in pieces of <= 16 records (one quarter wave each)
+            const uint32_t n_at = ring_cell ? q1 - q0 : 0u;
+            redo |= n_at > 16u * kRingChunks;                      // an overfull cell: the general code
+#pragma unroll
+            for (uint32_t j = 0; j < kRingChunks; j++) {
+                const bool has = n_at > 16u * j;
+                const uint64_t mask = __ballot(has);
+                if (!mask) break;                                  // (wave-uniform) no cell has a j-th piece
+                if (has) ring[n_ring + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] =
+                             make_uint2(q0 + 16u * j, min(q1, q0 + 16u * j + 16u));
+                n_ring += (uint32_t)__popcll(mask);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // the ring: group g = lane / 16 of iteration t takes piece 4 t + g, one record per lane; the records of four
+        // iterations are fetched together
+        const uint32_t grp = lane >> 4, sub = lane & 15u;
+        const float halfa = La / 2.0f, halfb = Lb / 2.0f;
+        for (uint32_t t = 0; t < n_ring; t += 16u) {
+            float4 r[4];
+            float sn[4];
+            bool v[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; u++) {
+                const uint32_t e = t + 4u * u + grp;
+                uint2 run = make_uint2(0u, 0u);
+                if (e < n_ring) run = ring[e];
+                const uint32_t q = run.x + sub;
+                v[u] = q < run.y;
+                const uint32_t qc = v[u] ? q : 0u;
+                r[u] = rec[qc];
+                sn[u] = rsn[qc];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; u++) {
+                const float ea = __builtin_fabsf(r[u].x - ha_pos), eb = __builtin_fabsf(r[u].y - hb_pos);
+                const float ta = La - ea, tb = Lb - eb;
+                const float ma = ea > halfa ? ta : ea, mb = eb > halfb ? tb : eb;
+                const bool in = v[u] & (ma * ma + mb * mb < thr);
+                redo |= v[u] & ((ta < 0.0f) | (tb < 0.0f));
+                if (in) {
+                    const float dz = r[u].z - hn_pos;
+                    const float uz = __builtin_fabsf(dz) > halfn ? dz - __builtin_copysignf(Ln, dz) : dz;
+                    redo |= __builtin_fabsf(uz) > halfn;
+                    cnt += 1u;
+                    nf |= (r[u].z - r[u].z == 0.0f) ? 0u : 1u;
+                    sc += r[u].w;
+                    ss += sn[u];
+                    su += uz;
+                    ulo = __builtin_fminf(ulo, uz);
+                    uhi = __builtin_fmaxf(uhi, uz);
+                }
+            }
+        }
+        // a head outside the box, or coordinates more than a box length apart: the general code below decides
+        redo |= !(fa >= -1e-4f * ca && fa <= ca * 1.0001f && fb >= -1e-4f * cb && fb <= cb * 1.0001f);
+        done = !__any(redo);
+        if (!done) { sc = ss = sp = su = 0.0f; ulo = 3.0e38f; uhi = -3.0e38f; cnt = 0; nf = 0; }
+    }
     const uint32_t n_runs = 2u * n_rows;
     uint32_t rq0 = 0, rq1 = 0;
-    if (lane < n_runs) {
+    if (!done && lane < n_runs) {       // (the run table serves the general passes only)
         uint32_t ra = a0 + (lane >> 1);
         ra -= ra >= nca ? nca : 0u;
         const uint32_t row = ra * ncb;
@@ -785,7 +953,7 @@ __global__ __launch_bounds__(256) void k_local_flags(LocalArgs a) {
     // Every run overwrites the lanes from its first iteration on (a later run then overwrites its own); the lanes
     // past the last iteration are cleared at the end.  The second run of a row is empty unless the columns wrap.
     uint32_t n_it = 0, it_base = 0, it_end = 0;
-    for (uint32_t r = 0; r < n_runs; r += (b2 ? 1u : 2u)) {
+    for (uint32_t r = 0; !done && r < n_runs; r += (b2 ? 1u : 2u)) {
         const uint32_t q0 = __builtin_amdgcn_readlane(rq0, r), q1 = __builtin_amdgcn_readlane(rq1, r);
         const bool from_here = lane >= n_it;
         it_base = from_here ? q0 + 64u * (lane - n_it) : it_base;
@@ -801,8 +969,6 @@ __global__ __launch_bounds__(256) void k_local_flags(LocalArgs a) {
     // u = MI(z - z_head), with its minimum and maximum over the members.  If, once the estimate is known, every
     // member's image around the head is also its image around the estimate, then sum MI(z - est) = sum u +
     // n MI(z_head - est) and pass 2 is not needed (k_leaflets_global_contig explains the argument).
-    float sc = 0.0f, ss = 0.0f, sp = 0.0f, su = 0.0f, ulo = 3.0e38f, uhi = -3.0e38f;
-    uint32_t cnt = 0, nf = 0;
     auto take = [&](const float4 r, const float sn) {
         if (inside(r.x, r.y)) {
             cnt += 1;
@@ -822,8 +988,7 @@ __global__ __launch_bounds__(256) void k_local_flags(LocalArgs a) {
     // per candidate: the in-plane test only squares its components, so magnitudes do (|dx - copysign(L, dx)| =
     // |L - |dx|| bit for bit), membership becomes a select mask, and whatever would need the literal image loops is
     // only FLAGGED; if any lane raised the flag the sums are thrown away and the general code below runs instead.
-    bool done = false;
-    if (flat && pbc) {
+    if (!done && flat && pbc) {
         const float halfa = La / 2.0f, halfb = Lb / 2.0f, halfn = Ln / 2.0f;
         bool redo = false;
         for (uint32_t it0 = 0; it0 < n_it; it0 += 4u) {

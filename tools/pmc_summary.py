@@ -18,7 +18,8 @@ def main():
     for path in sorted(glob.glob(os.path.join(out_dir, "p*/*/*counter_collection.csv"))):
         for r in csv.DictReader(open(path)):
             if kernel in r["Kernel_Name"]:
-                names.add(r["Kernel_Name"].split("(")[0].replace("void (anonymous namespace)::", ""))
+                name = r["Kernel_Name"].replace("void ", "", 1).replace("(anonymous namespace)::", "")
+                names.add(name.split("(")[0])          # template arguments kept, the parameter list dropped
                 a = agg[r["Counter_Name"]]
                 a[0] += 1
                 a[1] += float(r["Counter_Value"])
