@@ -214,6 +214,9 @@ def main():
     ap.add_argument("--scaling", choices=["strong", "weak"], default=None, help="N > 1 only; default strong")
     ap.add_argument("--collective", choices=["lib", "torch"], default="lib",
                     help="N > 1: gorder_hip_allreduce (RCCL called by the library) or torch.distributed.all_reduce")
+    ap.add_argument("--trig", choices=["squared", "acos"], default="squared",
+                    help="squared: P2 from the squared cosine (library default); acos: the reference's literal acos -> cos "
+                         "round trip (GORDER_FLAG_TRIG_ACOS_COS)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--no-scaling-reference", action="store_true")
@@ -258,6 +261,10 @@ def main():
     name = args.workload or ("cg1m" if world > 1 else "aa256")
     system, workload = make_system(name)
     system.tables.device = local_rank
+    if args.trig == "acos":
+        from gorder_amd.abi import FLAG_TRIG_ACOS_COS
+        system.tables.flags |= FLAG_TRIG_ACOS_COS
+        workload += " [acos -> cos round trip like the reference]"
     if strong:
         total = args.frames or 10000
         edges = np.linspace(0, total, world + 1).astype(np.int64)      # contiguous frame shards
@@ -427,7 +434,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(system)
         if not args.no_end_to_end:
             out["end_to_end"] = end_to_end(system, local_rank)
-        if not args.no_scaling_reference and name == "aa256" and not args.frames:
+        if not args.no_scaling_reference and name == "aa256" and not args.frames and args.trig == "squared":
             free_b, _ = torch.cuda.mem_get_info(device)
             if free_b > 150 * (1 << 30):
                 out["scaling_reference"] = scaling_reference(device)

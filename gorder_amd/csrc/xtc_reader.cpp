@@ -59,7 +59,8 @@ struct BitReader {
     // stored in chunks of 8 bits, FIRST chunk least significant (the last, partial chunk is the top): for up to 64
     // bits that is a byte swap of the stream bits, then two 64-bit divisions; wider numbers (boxes beyond ~2 million
     // grid steps per edge) take the byte-wise long division of the original algorithm.
-    void ints(int nbits, const uint32_t sizes[3], int out[3]) {
+    // recip[k] = floor(2^64 / sizes[k]) (reciprocal_of), k = 1, 2
+    void ints(int nbits, const uint32_t sizes[3], const uint64_t recip[3], int out[3]) {
         if (nbits <= 64) {
             const int m = (nbits - 1) / 8, rem = nbits - 8 * m;      // m full chunks, then `rem` (1..8) bits
             uint64_t v = 0;
@@ -70,11 +71,20 @@ struct BitReader {
                 v = __builtin_bswap64(w << (64 - lo_bits));
             }
             v |= bits57(rem) << (8 * m);
+            // two divisions by the radices — as multiplications by their precomputed reciprocals (a 64-bit hardware
+            // division costs several times the rest of the atom): q = floor(v * floor(2^64 / s) / 2^64) is at most
+            // two short of floor(v / s), the remainder test repairs it
             const uint64_t s2 = sizes[2], s1 = sizes[1];
-            const uint64_t q2 = v / s2;
-            out[2] = (int)(v - q2 * s2);
-            const uint64_t q1 = q2 / s1;
-            out[1] = (int)(q2 - q1 * s1);
+            uint64_t q2 = (uint64_t)(((unsigned __int128)v * recip[2]) >> 64);
+            uint64_t r2 = v - q2 * s2;
+            if (r2 >= s2) { r2 -= s2; q2++; }
+            if (r2 >= s2) { r2 -= s2; q2++; }
+            out[2] = (int)r2;
+            uint64_t q1 = (uint64_t)(((unsigned __int128)q2 * recip[1]) >> 64);
+            uint64_t r1 = q2 - q1 * s1;
+            if (r1 >= s1) { r1 -= s1; q1++; }
+            if (r1 >= s1) { r1 -= s1; q1++; }
+            out[1] = (int)r1;
             out[0] = (int)(uint32_t)q1;
             return;
         }
@@ -99,6 +109,16 @@ struct BitReader {
         out[0] = (int)(bytes[0] | (bytes[1] << 8) | (bytes[2] << 16) | (bytes[3] << 24));
     }
 };
+
+inline uint64_t reciprocal_of(uint32_t s) {      // floor(2^64 / s); s = 1 saturates (then q = v - 1 short by one: repaired)
+    return s <= 1u ? ~0ull : (uint64_t)((((unsigned __int128)1) << 64) / s);
+}
+// the reciprocals of the "magic" radices of the small-offset runs, made once
+struct MagicRecips {
+    uint64_t r[kLastIdx];
+    MagicRecips() { for (int i = 0; i < kLastIdx; i++) r[i] = kMagicInts[i] > 0 ? reciprocal_of((uint32_t)kMagicInts[i]) : 0; }
+};
+const MagicRecips kMagicRecips;
 
 int size_of_int(uint32_t size) {
     uint32_t num = 1;
@@ -195,6 +215,8 @@ int decode_ints(gorder_xtc_reader *r, const int minint[3], const int maxint[3], 
     int smaller = kMagicInts[smallidx > kFirstIdx ? smallidx - 1 : kFirstIdx] / 2;
     int smallnum = kMagicInts[smallidx] / 2;
     uint32_t sizesmall[3] = {(uint32_t)kMagicInts[smallidx], (uint32_t)kMagicInts[smallidx], (uint32_t)kMagicInts[smallidx]};
+    const uint64_t recip_big[3] = {reciprocal_of(sizeint[0]), reciprocal_of(sizeint[1]), reciprocal_of(sizeint[2])};
+    uint64_t recip_small[3] = {kMagicRecips.r[smallidx], kMagicRecips.r[smallidx], kMagicRecips.r[smallidx]};
 
     BitReader br{data, nbytes};
     int *out = r->ints.data();
@@ -205,7 +227,7 @@ int decode_ints(gorder_xtc_reader *r, const int minint[3], const int maxint[3], 
         if (bitsize == 0) {
             for (int k = 0; k < 3; k++) cur[k] = (int)br.bits(bitsizeint[k]);
         } else {
-            br.ints(bitsize, sizeint, cur);
+            br.ints(bitsize, sizeint, recip_big, cur);
         }
         i++;
         for (int k = 0; k < 3; k++) cur[k] += minint[k];
@@ -222,7 +244,7 @@ int decode_ints(gorder_xtc_reader *r, const int minint[3], const int maxint[3], 
             if (i + (uint32_t)(run / 3) > natoms) return GORDER_XTC_ERR_FORMAT;
             for (int k = 0; k < run; k += 3) {
                 int d[3];
-                br.ints(smallidx, sizesmall, d);
+                br.ints(smallidx, sizesmall, recip_small, d);
                 i++;
                 for (int c = 0; c < 3; c++) cur[c] = d[c] + prev[c] - smallnum;
                 if (k == 0) {
@@ -250,6 +272,7 @@ int decode_ints(gorder_xtc_reader *r, const int minint[3], const int maxint[3], 
             smallnum = kMagicInts[smallidx] / 2;
         }
         sizesmall[0] = sizesmall[1] = sizesmall[2] = (uint32_t)kMagicInts[smallidx];
+        recip_small[0] = recip_small[1] = recip_small[2] = kMagicRecips.r[smallidx];
         if (br.overrun) return GORDER_XTC_ERR_FORMAT;
     }
     if (br.bitpos > 8 * nbytes) return GORDER_XTC_ERR_FORMAT;     // read into the padding: truncated block

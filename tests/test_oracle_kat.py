@@ -148,3 +148,61 @@ def test_predicted_hydrogen_positions(built, kind, atoms, want):
         # each hydrogen sits BOND_LENGTH = 0.109 nm from its carbon
         target = pos[3] if kind == "CH1_SAT" else pos[1]
         np.testing.assert_allclose(np.linalg.norm(out[:n] - target, axis=1), 0.109, atol=1e-6)
+
+
+# ---- the reference's leaflet unit tests by ATOM INDEX (leaflets.rs:1603-1685, 1858-1960) ----------------------
+import functools
+
+
+@functools.lru_cache(maxsize=1)
+def _pcpepg_frame():
+    """tests/files/pcpepg.gro (the 1e-3-nm twin of the .tpr the reference's tests load): the lipid atoms keep the
+    indices they have in the full system, so the reference's literal atom numbers apply."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from golden_util import GOLDEN, Fixture
+    fx = Fixture("pcpepg")
+    z = np.load(os.path.join(GOLDEN, "pcpepg_structure_frame.npz"))
+    xyz = (z["ints"].astype(np.float32) * np.float32(0.001)).astype(np.float32)
+    box = np.zeros((1, 3, 3), dtype=np.float32)
+    box[0, 0, 0], box[0, 1, 1], box[0, 2, 2] = z["box"]
+    return fx, np.ascontiguousarray(xyz[None]), box
+
+
+def leaflet_kat_tables(fx, method):
+    """Two molecules with the heads / methyls of test_{global,local,individual}_assign_to_leaflet
+    (leaflets.rs:1858-1960): heads 1385 and 11885, methyls [1453, 1496] and [11953, 11996]; the membrane group is
+    every lipid atom (`@membrane`)."""
+    from gorder_amd.abi import Leaflets, MolType, Tables
+    heads = np.array([1385, 11885], dtype=np.uint32)
+    methyls = np.array([[1453, 1496], [11953, 11996]], dtype=np.uint32)
+    bonds = np.stack([heads, methyls[:, 0]], axis=1)[None].astype(np.uint32)       # any bond: the flags are the point
+    n = fx.structure.n_atoms
+    lf = Leaflets(method=method, normal_dim=2, frequency=1, radius=2.5, membrane=np.arange(n, dtype=np.uint32))
+    return Tables(n_atoms=n, molecule_types=[MolType(n_molecules=2, bonds=bonds, heads=heads, methyls=methyls)], leaflets=lf)
+
+
+def test_leaflet_heads_and_methyls_by_atom_index(built):
+    """`name P` / `name C218 C316` of residues 7, 144 and 264 are atoms 760 / 18002 / 34047 and [828, 871] /
+    [18070, 18113] / [34115, 34158] (leaflets.rs:1603-1685): the selection language and the atom numbering."""
+    from gorder_amd.select import select
+    fx, _, _ = _pcpepg_frame()
+    heads = np.flatnonzero(select(fx.structure, "resid 7 144 264 and name P"))
+    assert heads.tolist() == [760, 18002, 34047]
+    methyls = np.flatnonzero(select(fx.structure, "resid 7 144 264 and name C218 C316"))
+    assert methyls.reshape(3, 2).tolist() == [[828, 871], [18070, 18113], [34115, 34158]]
+
+
+@pytest.mark.parametrize("method", ["global", "local", "individual"])
+def test_assign_to_leaflet_kat(built, method):
+    """Head 1385 is in the UPPER leaflet, head 11885 in the LOWER one — for the global centre, the local centres
+    (radius 2.5 nm) and the head-to-methyl distances alike (leaflets.rs:1858-1960); Upper = 0, Lower = 1."""
+    from gorder_amd.abi import LEAFLETS_GLOBAL, LEAFLETS_INDIVIDUAL, LEAFLETS_LOCAL
+    fx, xyz, box = _pcpepg_frame()
+    tables = leaflet_kat_tables(fx, {"global": LEAFLETS_GLOBAL, "local": LEAFLETS_LOCAL, "individual": LEAFLETS_INDIVIDUAL}[method])
+    eng = oracle.OracleEngine(tables, trig=oracle.TRIG_LIBM)
+    eng.submit(xyz, box, [0])
+    flags, dist, frame = eng.leaflets()
+    assert flags.tolist() == [0, 1] and frame == 0
+    assert dist[0] > 0.5 and dist[1] < -0.5          # well away from the mid-plane: the sign is not a rounding matter

@@ -641,3 +641,39 @@ def test_library_allreduce_and_reset(built):
     np.testing.assert_array_equal(tw_s, pw_s)
     np.testing.assert_array_equal(tw_c, pw_c)
     eng.comm_destroy(comm)
+
+
+@pytest.mark.parametrize("method", ["global", "local", "individual"])
+def test_reference_leaflet_kat_on_the_device(built, method):
+    """The reference's own leaflet unit tests through the C ABI: atoms 1385 / 11885 of the all-atom membrane are
+    Upper / Lower under every classifier (leaflets.rs:1858-1960); distances equal to the oracle's."""
+    torch_cuda()
+    from test_oracle_kat import _pcpepg_frame, leaflet_kat_tables
+    fx, xyz, box = _pcpepg_frame()
+    tables = leaflet_kat_tables(fx, {"global": LEAFLETS_GLOBAL, "local": LEAFLETS_LOCAL, "individual": LEAFLETS_INDIVIDUAL}[method])
+    eng = HipEngine(tables)
+    eng.submit_host(xyz, box, np.arange(1))
+    res = eng.finish()
+    flags, frame = eng.leaflets()
+    assert flags.tolist() == [0, 1] and frame == 0
+    assert res.counts[1, 0] == 1 and res.counts[2, 0] == 1
+    o = oracle.OracleEngine(tables, trig=oracle.TRIG_DIRECT)
+    o.submit(xyz, box, [0])
+    _, odist, _ = o.leaflets()
+    np.testing.assert_allclose(eng.leaflet_distances(), odist, atol=5e-5)
+    np.testing.assert_array_equal(res.sums, o.finish().sums)
+
+
+def test_global_leaflets_with_unwrapped_coordinates(built):
+    """Molecules that have drifted whole box lengths away ('nojump' trajectories): the minimum-image loops of the centre
+    and of the head distances take several steps — same flags and sums as the oracle."""
+    system = synthetic.cg_membrane(120, leaflets=LEAFLETS_GLOBAL, n_types=2)
+    n = 21
+    xyz = system.frames(n, seed=3)
+    xyz[3:, 12 * 7:12 * 9, 2] += 2 * system.box[2]          # two lipids two boxes up, from frame 3 on
+    xyz[10:, 12 * 40:12 * 41, 2] -= 3 * system.box[2]       # one lipid three boxes down
+    xyz[:, 12 * 60:12 * 62, 0] += 4 * system.box[0]         # in-plane shifts do not matter to the centre
+    box = system.box9(n)
+    _, got = run_gpu(system, xyz, box, batches=2)
+    assert got.counts[1].sum() > 0 and got.counts[2].sum() > 0
+    assert_sums_given_device_flags(system.tables, xyz, box, got)

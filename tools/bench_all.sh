@@ -3,9 +3,10 @@
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=${1:-$ROOT/gpurun_out/bench_all.jsonl}
 : > $OUT
-run() { python3 $ROOT/bench.py --no-cpu-baseline --workload $1 --frames $2 --steps $3 --warmup $4 | grep '^{' >> $OUT; }
+run() { python3 $ROOT/bench.py --no-cpu-baseline --no-end-to-end --no-scaling-reference --workload $1 --frames $2 --steps $3 --warmup $4 $5 $6 | grep '^{' >> $OUT; }
 # warm-up launches cover >= 20 ms: the chip needs that long to settle its clocks
 run aa256 10000 100 40
+run aa256 10000 100 40 --trig acos
 run aa256-leaflets 4000 50 40
 run aa256-maps 3000 50 40
 run cg3k 4000 100 60
