@@ -212,8 +212,9 @@ def main():
                     help="strong scaling: frames of the whole trajectory (default 10000); weak / one GPU: frames per "
                          "step and GPU (default 10000, cg1m: 1000)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default=None, help="N > 1 only; default strong")
-    ap.add_argument("--collective", choices=["lib", "torch"], default="lib",
-                    help="N > 1: gorder_hip_allreduce (RCCL called by the library) or torch.distributed.all_reduce")
+    ap.add_argument("--collective", choices=["lib", "torch"], default="torch",
+                    help="N > 1: torch.distributed.all_reduce on the handle's stream (default), or gorder_hip_allreduce — "
+                         "RCCL called by the library itself, the route of a host without a collective library")
     ap.add_argument("--trig", choices=["squared", "acos"], default="squared",
                     help="squared: P2 from the squared cosine (library default); acos: the reference's literal acos -> cos "
                          "round trip (GORDER_FLAG_TRIG_ACOS_COS)")

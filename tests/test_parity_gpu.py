@@ -677,3 +677,21 @@ def test_global_leaflets_with_unwrapped_coordinates(built):
     _, got = run_gpu(system, xyz, box, batches=2)
     assert got.counts[1].sum() > 0 and got.counts[2].sum() > 0
     assert_sums_given_device_flags(system.tables, xyz, box, got)
+
+
+def test_eight_frames_per_stage_falls_back_on_wide_windows(built, monkeypatch):
+    """GORDER_HIP_FRAMES_PER_STAGE=8 with an atom window of ~860 atoms would need 82 KB of LDS per workgroup, more than
+    a launch gets without opting in: the handle then stages 4 frames (48 KB at the widest window) instead of failing."""
+    monkeypatch.setenv("GORDER_HIP_FRAMES_PER_STAGE", "8")
+    rng = np.random.default_rng(4)
+    n_atoms, n_mol = 3000, 60
+    wide = np.stack([np.arange(n_mol), np.arange(n_mol) + 800], axis=1)
+    near = np.stack([np.arange(1500, 1500 + n_mol), np.arange(1501, 1501 + n_mol)], axis=1)
+    t = Tables(n_atoms=n_atoms, molecule_types=[MolType(n_molecules=n_mol, bonds=np.stack([wide, near]).astype(np.uint32))])
+    box = np.array([7.0, 8.0, 9.0], dtype=np.float32)
+    system = synthetic.System("wide", t, (rng.random((n_atoms, 3)) * box).astype(np.float32), box, 0.05)
+    xyz = system.frames(19, seed=2)
+    eng, _ = assert_parity(system, xyz, system.box9(19))
+    plan = eng.plan()
+    assert plan["max_window_atoms"] > 700 and plan["n_direct_items"] == 0
+    assert plan["frames_per_stage"] == 4 and plan["lds_bytes"] <= 64 * 1024
