@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -565,10 +566,9 @@ struct RcclApi {
 constexpr int kNcclInt64 = 4, kNcclSum = 0;   // ncclDataType_t / ncclRedOp_t values of rccl.h
 RcclApi *rccl_api(std::string *why) {
     static RcclApi api;
-    static bool tried = false;
+    static std::once_flag once;
     static std::string err;
-    if (!tried) {
-        tried = true;
+    std::call_once(once, [&]() {
         const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char *n : names)
             if ((api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
@@ -588,7 +588,7 @@ RcclApi *rccl_api(std::string *why) {
                 api.lib = nullptr;
             }
         }
-    }
+    });
     if (!api.lib) { if (why) *why = err; return nullptr; }
     return &api;
 }

@@ -184,6 +184,8 @@ struct gorder_xtc_reader {
     uint32_t natoms = 0;
     std::vector<uint32_t> group;      // atoms to convert (empty = all)
     std::vector<int32_t> slot_of;     // atom -> output slot or -1 (only when group given)
+    uint32_t n_needed = 0;            // atoms to decompress per frame: up to the last atom of the group (the bit stream is
+                                      // sequential, but nothing after that atom is wanted — e.g. the water behind the lipids)
     std::vector<uint8_t> buf;
     std::vector<int> ints;            // decoded integer coordinates of one frame
 };
@@ -222,7 +224,8 @@ int decode_ints(gorder_xtc_reader *r, const int minint[3], const int maxint[3], 
     int *out = r->ints.data();
     uint32_t i = 0;
     int run = 0;
-    while (i < natoms) {
+    const uint32_t n_stop = r->n_needed ? std::min(r->n_needed, natoms) : natoms;
+    while (i < n_stop) {
         int cur[3];
         if (bitsize == 0) {
             for (int k = 0; k < 3; k++) cur[k] = (int)br.bits(bitsizeint[k]);
@@ -276,7 +279,7 @@ int decode_ints(gorder_xtc_reader *r, const int minint[3], const int maxint[3], 
         if (br.overrun) return GORDER_XTC_ERR_FORMAT;
     }
     if (br.bitpos > 8 * nbytes) return GORDER_XTC_ERR_FORMAT;     // read into the padding: truncated block
-    return GORDER_XTC_OK;
+    return GORDER_XTC_OK;                                         // (a run may have carried `out` past n_stop: the buffer holds all atoms)
 }
 
 // ---- TRR ------------------------------------------------------------------------------------------
@@ -494,6 +497,7 @@ int gorder_xtc_open(const char *path, const uint32_t *group, uint32_t n_group, g
                 return GORDER_XTC_ERR_ARGUMENT;
             }
             r->slot_of[group[k]] = (int32_t)k;
+            r->n_needed = std::max(r->n_needed, group[k] + 1u);
         }
     }
     *out = r;

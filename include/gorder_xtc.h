@@ -36,7 +36,9 @@ typedef enum {
  * reference reads through groan_rs' TrrReader (common.rs:306-320); a file with neither magic number is read as a
  * multi-frame GRO text trajectory (GroReader, common.rs:322-333: time from "t=" in the title line, positions in
  * three equal-width columns from column 20, 3- or 9-value box line).  `group` (may be NULL = all atoms) lists the n_group atom indices to convert;
- * decoded frames hold exactly those atoms, in that order (the "Master" group of common.rs:283-304). */
+ * decoded frames hold exactly those atoms, in that order (the "Master" group of common.rs:283-304).  The compressed
+ * stream of a frame is only decompressed up to the last atom of the group: a group of lipids in front of the water
+ * costs the lipids' share of the frame. */
 int gorder_xtc_open(const char *path, const uint32_t *group, uint32_t n_group, gorder_xtc_reader **out);
 void gorder_xtc_close(gorder_xtc_reader *r);
 uint32_t gorder_xtc_n_atoms_file(const gorder_xtc_reader *r);   /* atoms per frame in the file */
