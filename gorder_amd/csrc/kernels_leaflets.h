@@ -759,6 +759,44 @@ __device__ __forceinline__ double wave_total(double v) {
 }
 
 
+// The same row-shift reductions for values whose last digits do not reach the result (the circular sums only make the
+// ESTIMATE, the member count is an integer): one DPP-modified add / min / max per step instead of three for an f64.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add_f32(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+}
+__device__ __forceinline__ float wave_total_f32(float v) {
+    v = dpp_add_f32<0x111, 0xf>(v); v = dpp_add_f32<0x112, 0xf>(v); v = dpp_add_f32<0x114, 0xf>(v); v = dpp_add_f32<0x118, 0xf>(v);
+    v = dpp_add_f32<0x142, 0xa>(v); v = dpp_add_f32<0x143, 0xc>(v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_add_u32(uint32_t v) {
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
+}
+__device__ __forceinline__ uint32_t wave_total_u32(uint32_t v) {
+    v = dpp_add_u32<0x111, 0xf>(v); v = dpp_add_u32<0x112, 0xf>(v); v = dpp_add_u32<0x114, 0xf>(v); v = dpp_add_u32<0x118, 0xf>(v);
+    v = dpp_add_u32<0x142, 0xa>(v); v = dpp_add_u32<0x143, 0xc>(v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// minimum / maximum over the wave: lanes without a source keep their own value (bound_ctrl off, old = the value itself)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_keep_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_min_f32(float v) {
+    v = fminf(v, dpp_keep_f32<0x111, 0xf>(v)); v = fminf(v, dpp_keep_f32<0x112, 0xf>(v));
+    v = fminf(v, dpp_keep_f32<0x114, 0xf>(v)); v = fminf(v, dpp_keep_f32<0x118, 0xf>(v));
+    v = fminf(v, dpp_keep_f32<0x142, 0xa>(v)); v = fminf(v, dpp_keep_f32<0x143, 0xc>(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+    v = fmaxf(v, dpp_keep_f32<0x111, 0xf>(v)); v = fmaxf(v, dpp_keep_f32<0x112, 0xf>(v));
+    v = fmaxf(v, dpp_keep_f32<0x114, 0xf>(v)); v = fmaxf(v, dpp_keep_f32<0x118, 0xf>(v));
+    v = fmaxf(v, dpp_keep_f32<0x142, 0xa>(v)); v = fmaxf(v, dpp_keep_f32<0x143, 0xc>(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 // block = 256 threads = 4 waves = 4 heads; grid = (ceil(n_mol / 4), n_slab).  A head's candidates are
 // the records of the (2ka+1) x (2kb+1) cells around its own: per row of cells ONE contiguous run of
 // records (two when the run wraps around the box), lanes over the run.
@@ -1057,7 +1095,7 @@ __global__ __launch_bounds__(256) void k_local_flags(LocalArgs a) {
             }
         }
     }
-    const double tcnt = wave_total((double)cnt);
+    const double tcnt = (double)wave_total_u32(cnt);
     if (tcnt == 0.0 || __any(nf != 0u)) {
         if (lane == 0) raise_error(a.err, GORDER_ERR_INVALID_LOCAL_MEMBRANE_CENTER, f, kStageTypes, a.mol_slot0 ? a.mol_slot0[m] : 0u, 0, m);
         return;
@@ -1066,12 +1104,10 @@ __global__ __launch_bounds__(256) void k_local_flags(LocalArgs a) {
     if (!pbc) {
         center = (float)(wave_total((double)sp) / tcnt);
     } else {
-        const double tc = wave_total((double)sc), ts = wave_total((double)ss);
-        const float est = (atan2f(-(float)ts, -(float)tc) + 3.1415927f) / (6.2831855f / Ln);
-        for (int off = 32; off > 0; off >>= 1) {
-            ulo = fminf(ulo, __shfl_xor(ulo, off, 64));
-            uhi = fmaxf(uhi, __shfl_xor(uhi, off, 64));
-        }
+        const float tc = wave_total_f32(sc), ts = wave_total_f32(ss);        // the estimate only anchors the image choice
+        const float est = (atan2f(-ts, -tc) + 3.1415927f) / (6.2831855f / Ln);
+        ulo = wave_min_f32(ulo);
+        uhi = wave_max_f32(uhi);
         const float shift = gm_min_image(hn_pos - est, Ln, bad), half = Ln / 2.0f, margin = 1e-4f * Ln;
         const bool one_pass = ulo + shift > -half + margin && uhi + shift < half - margin;   // wave-uniform
         // pass 2 (only for a membrane thicker than half the box): refine with the mean minimum-image displacement
