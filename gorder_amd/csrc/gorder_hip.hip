@@ -77,6 +77,7 @@ struct gorder_hip_handle {
     uint32_t *d_item_run = nullptr, *d_ua_item_run = nullptr;
     uint4 *d_lgrid = nullptr;       // per slab frame: the cell grid of the local-leaflet kernels
     float4 *d_lagg = nullptr;       // per slab frame and cell: the sums of k_local_cellsums
+    uint2 *d_ltodo = nullptr;       // {count}, then the (slab frame, head) pairs left to the general passes
     bool map_staged = false;       // the packed map of one slot fits LDS: stage + accumulate instead of one atomic per sample
     uint64_t map_pending = 0;      // upper bound of the samples one packed word may hold since the last fold
     uint64_t map_fold_limit = kMapFoldLimit;   // GORDER_HIP_MAP_FOLD_LIMIT lowers it (tests)
@@ -932,8 +933,10 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
             HIP_TRY(h, hipMalloc((void **)&h->d_lcell_count, sl * (ncell + 1) * sizeof(uint32_t)));
             HIP_TRY(h, hipMalloc((void **)&h->d_lcell_fill, sl * ncell * sizeof(uint32_t)));
             HIP_TRY(h, hipMalloc((void **)&h->d_lgrid, sl * sizeof(uint4)));
-            if (!env_flag("GORDER_HIP_LOCAL_ATOMS_ONLY"))      // A/B switch: every candidate atom by atom, as before
+            if (!env_flag("GORDER_HIP_LOCAL_ATOMS_ONLY")) {    // A/B switch: every candidate atom by atom, as before
                 HIP_TRY(h, hipMalloc((void **)&h->d_lagg, sl * ncell * 2 * sizeof(float4)));
+                HIP_TRY(h, hipMalloc((void **)&h->d_ltodo, (1 + sl * (size_t)(p.n_mol_total ? p.n_mol_total : 1)) * sizeof(uint2)));
+            }
         }
         HIP_TRY(h, hipMalloc((void **)&h->d_adist, sizeof(float) * (p.n_mol_total ? p.n_mol_total : 1)));
     }
@@ -957,7 +960,7 @@ void gorder_hip_destroy(gorder_hip_handle *h) {
     (void)hipFree(h->d_geom_group); (void)hipFree(h->d_shapes);
     (void)hipFree(h->d_map_rec); (void)hipFree(h->d_ua_runs); (void)hipFree(h->d_ua_run_begin);
     (void)hipFree(h->d_runs); (void)hipFree(h->d_run_begin); (void)hipFree(h->d_items_by_slot);
-    (void)hipFree(h->d_item_run); (void)hipFree(h->d_ua_item_run); (void)hipFree(h->d_lgrid); (void)hipFree(h->d_lagg);
+    (void)hipFree(h->d_item_run); (void)hipFree(h->d_ua_item_run); (void)hipFree(h->d_lgrid); (void)hipFree(h->d_lagg); (void)hipFree(h->d_ltodo);
     (void)hipFree(h->d_dyn_cloud); (void)hipFree(h->d_dyn_heads); (void)hipFree(h->d_dyn_cell_of); (void)hipFree(h->d_dyn_count);
     (void)hipFree(h->d_dyn_rec); (void)hipFree(h->d_dyn_rsn); (void)hipFree(h->d_dyn_normals);
     if (!h->acc_external) (void)hipFree(h->d_acc);
@@ -1058,6 +1061,7 @@ static int run_leaflets(gorder_hip_handle *h, const float *d_xyz, const float *d
         lo.cell_fill = h->d_lcell_fill; lo.rsn = reinterpret_cast<float *>(h->d_lcell_atoms); lo.err = h->d_err;
         lo.grid = h->d_lgrid;
         lo.agg = h->d_lagg;
+        lo.todo = h->d_ltodo;
         for (size_t done = 0; done < aframes.size(); done += h->local_slab) {
             const uint32_t ns = (uint32_t)std::min<size_t>(aframes.size() - done, h->local_slab);
             lo.aframes = h->d_aframes + done;
@@ -1072,7 +1076,12 @@ static int run_leaflets(gorder_hip_handle *h, const float *d_xyz, const float *d
             hipLaunchKernelGGL(k_local_scatter, ga, dim3(256), 0, h->stream, lo);
             if (lo.agg)
                 hipLaunchKernelGGL(k_local_cellsums, dim3(64, ns), dim3(256), 0, h->stream, lo);
-            hipLaunchKernelGGL(k_local_flags, dim3((lo.n_mol_total + 3) / 4, ns), dim3(256), 0, h->stream, lo);
+            if (lo.agg && lo.pbc) {
+                hipLaunchKernelGGL(k_local_flags_rows, dim3((lo.n_mol_total + 15) / 16, ns), dim3(256), 0, h->stream, lo);
+                // the heads the rows left over (normally none: the grid finds an empty list and leaves)
+                hipLaunchKernelGGL(k_local_flags_todo, dim3(512), dim3(256), 0, h->stream, lo);
+            } else
+                hipLaunchKernelGGL(k_local_flags, dim3((lo.n_mol_total + 3) / 4, ns), dim3(256), 0, h->stream, lo);
         }
     }
     HIP_TRY(h, hipGetLastError());

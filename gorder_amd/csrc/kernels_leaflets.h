@@ -468,6 +468,7 @@ constexpr uint32_t kLocalMaxCells1D = 128;
 // 36 864-bead membrane gains 10 % from 32 -> 128 frames, nothing beyond: the small binning kernels get amortised)
 constexpr uint32_t kLocalSlabMax = 128;
 inline uint32_t local_slab_frames(size_t n_membrane) {
+    // (the heads' to-do list, 8 bytes per head and frame, is on top: heads are a fraction of the membrane atoms)
     const size_t per_frame = n_membrane * 24u + (size_t)(2 * 4u + 32u) * kLocalMaxCells1D * kLocalMaxCells1D + 8u;
     const size_t n = ((size_t)256 << 20) / per_frame;
     return (uint32_t)(n < 4 ? 4 : (n > kLocalSlabMax ? kLocalSlabMax : n));
@@ -503,6 +504,8 @@ struct LocalArgs {
     uint32_t *cell_count;       // [n_slab][kLocalMaxCells1D^2 + 1] counts -> starts
     uint32_t *cell_fill;        // [n_slab][kLocalMaxCells1D^2]
     float4 *agg;                // [n_slab][kLocalMaxCells1D^2][2] per-cell sums (k_local_cellsums) for k_local_flags, or null
+    uint2 *todo;                // [1 + n_slab * n_mol_total] with agg: {count, -} then the (slab frame, head) pairs
+                                // k_local_flags_rows leaves to k_local_flags_todo
     uint32_t *err;
 };
 
@@ -695,6 +698,7 @@ __global__ __launch_bounds__(256) void k_local_cellsums(LocalArgs a) {
     const float4 *rec = reinterpret_cast<const float4 *>(a.trig) + (size_t)s * a.n_membrane;
     const float *rsn = a.rsn + (size_t)s * a.n_membrane;
     float4 *out = a.agg + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D) * 2u;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.todo[0] = make_uint2(0u, 0u);   // this slab's list starts empty
     for (uint32_t c = blockIdx.x * 16u + (threadIdx.x >> 4); c < ncell; c += gridDim.x * 16u) {
         const uint32_t q0 = cstart[c], q1 = cstart[c + 1u];
         float sc = 0.0f, ss = 0.0f, sz = 0.0f, zlo = 3.0e38f, zhi = -3.0e38f;
@@ -800,11 +804,9 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 // block = 256 threads = 4 waves = 4 heads; grid = (ceil(n_mol / 4), n_slab).  A head's candidates are
 // the records of the (2ka+1) x (2kb+1) cells around its own: per row of cells ONE contiguous run of
 // records (two when the run wraps around the box), lanes over the run.
-__global__ __launch_bounds__(256) void k_local_flags(LocalArgs a) {
+// The general passes for ONE head by ONE wave (all 64 lanes must be here).
+__device__ __noinline__ void local_flags_head(const LocalArgs &a, uint32_t s, uint32_t m) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t m = blockIdx.x * 4u + (threadIdx.x >> 6);
-    const uint32_t s = blockIdx.y;
-    if (m >= a.n_mol_total) return;
     const uint32_t f = a.aframes ? a.aframes[s] : a.frame0 + s;
     float box[3];
     frame_box(a, f, box);
@@ -864,121 +866,6 @@ __global__ __launch_bounds__(256) void k_local_flags(LocalArgs a) {
     float sc = 0.0f, ss = 0.0f, sp = 0.0f, su = 0.0f, ulo = 3.0e38f, uhi = -3.0e38f;
     uint32_t cnt = 0, nf = 0;
     bool done = false;
-    // ---- cells instead of atoms where a whole cell lies inside the cylinder -------------------------------------
-    // The head's (2ka+1) x (2kb+1) cells, one per lane: a cell whose farthest corner is closer than the radius holds
-    // members only — its precomputed sums (k_local_cellsums) are added as a block; a cell whose nearest point is
-    // farther holds none; only the ring of cells the circle crosses is looked at atom by atom, FOUR cells per wave
-    // iteration (a cell holds about as many atoms as a quarter wave has lanes).  Membership itself stays the exact
-    // distance test; the margins only decide who is tested.  Every periodic image of a neighbourhood cell other than
-    // the direct one lies beyond the radius (at least k cells of >= 1.0001 r / k away, local_axis), so the direct
-    // displacement is the minimum image here — unless a coordinate sits outside the box, which the flag `redo` catches.
-    constexpr uint32_t kRingChunks = 4, kRingCap = 128u * kRingChunks;
-    __shared__ uint2 l_ring[4][kRingCap];
-    if (pbc && a.agg && a.grid && n_rows * n_cols <= 128u && ka >= 1u && kb >= 1u) {
-        const float halfn = Ln / 2.0f;
-        const float ca = La / (float)nca, cb = Lb / (float)ncb;            // cell edges
-        // the head inside its cell, from its wrapped coordinates (what the cells were made from)
-        const float fa = gm_wrap(ha_pos, La, bad) - (float)ha * ca, fb = gm_wrap(hb_pos, Lb, bad) - (float)hb * cb;
-        const float r_in = thr * (1.0f - 4e-4f), r_out = thr * (1.0f + 4e-4f);
-        const float4 *agg = a.agg + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D) * 2u;
-        uint2 *ring = l_ring[threadIdx.x >> 6];
-        uint32_t n_ring = 0;
-        bool redo = false;
-        const uint32_t inv_cols = n_cols == 9u ? 7282u : (65536u + n_cols - 1u) / n_cols;
-        for (uint32_t c0 = 0; c0 < n_rows * n_cols; c0 += 64u) {
-            const uint32_t ci = c0 + lane;
-            const bool valid = ci < n_rows * n_cols;
-            // ci / n_cols for ci < 128, n_cols <= 128 by one multiplication: floor(ci * ceil(2^16 / n) / 2^16) is exact there
-            const uint32_t ia = valid ? (ci * inv_cols) >> 16 : 0u, ib = valid ? ci - ia * n_cols : 0u;
-            // the cell's rectangle relative to the head
-            const float a_lo = ((float)ia - (float)ka) * ca - fa, a_hi = a_lo + ca;
-            const float b_lo = ((float)ib - (float)kb) * cb - fb, b_hi = b_lo + cb;
-            const float fa_far = fmaxf(fabsf(a_lo), fabsf(a_hi)), fb_far = fmaxf(fabsf(b_lo), fabsf(b_hi));
-            const float fa_near = (a_lo <= 0.0f && a_hi >= 0.0f) ? 0.0f : fminf(fabsf(a_lo), fabsf(a_hi));
-            const float fb_near = (b_lo <= 0.0f && b_hi >= 0.0f) ? 0.0f : fminf(fabsf(b_lo), fabsf(b_hi));
-            const bool inner = valid && (fa_far * fa_far + fb_far * fb_far < r_in);
-            const bool outer = !valid || (fa_near * fa_near + fb_near * fb_near > r_out);
-            uint32_t ra = a0 + ia, rb = b0 + ib;
-            ra -= ra >= nca ? nca : 0u;
-            rb -= rb >= ncb ? ncb : 0u;
-            const uint32_t cell = ra * ncb + rb;
-            bool ring_cell = !inner && !outer;
-            // every load of this round goes out before the first use: sums of inner cells, runs of the others
-            const float4 g0 = inner ? agg[2u * cell] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            const float4 g1 = inner ? agg[2u * cell + 1u] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            const uint32_t q0 = outer ? 0u : cstart[cell], q1 = outer ? 0u : cstart[cell + 1u];
-            if (inner && g0.w > 0.0f) {
-                // the block sum of u = MI(z - z_head) is sum z - n z_head when no atom of the cell needs a shift
-                if (!(g1.x - hn_pos >= -halfn && g1.y - hn_pos <= halfn && g0.z - g0.z == 0.0f)) {
-                    ring_cell = true;                               // atom by atom instead (also carries a NaN on)
-                } else {
-                    cnt += (uint32_t)g0.w;
-                    sc += g0.x;
-                    ss += g0.y;
-                    su += g0.z - g0.w * hn_pos;
-                    ulo = fminf(ulo, g1.x - hn_pos);
-                    uhi = fmaxf(uhi, g1.y - hn_pos);
-                }
-            }
-            // ring cells go to the wave's list in pieces of <= 16 records (one quarter wave each)
-            const uint32_t n_at = ring_cell ? q1 - q0 : 0u;
-            redo |= n_at > 16u * kRingChunks;                      // an overfull cell: the general code
-#pragma unroll
-            for (uint32_t j = 0; j < kRingChunks; j++) {
-                const bool has = n_at > 16u * j;
-                const uint64_t mask = __ballot(has);
-                if (!mask) break;                                  // (wave-uniform) no cell has a j-th piece
-                if (has) ring[n_ring + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] =
-                             make_uint2(q0 + 16u * j, min(q1, q0 + 16u * j + 16u));
-                n_ring += (uint32_t)__popcll(mask);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        // the ring: group g = lane / 16 of iteration t takes piece 4 t + g, one record per lane; the records of four
-        // iterations are fetched together
-        const uint32_t grp = lane >> 4, sub = lane & 15u;
-        const float halfa = La / 2.0f, halfb = Lb / 2.0f;
-        for (uint32_t t = 0; t < n_ring; t += 16u) {
-            float4 r[4];
-            float sn[4];
-            bool v[4];
-#pragma unroll
-            for (uint32_t u = 0; u < 4u; u++) {
-                const uint32_t e = t + 4u * u + grp;
-                uint2 run = make_uint2(0u, 0u);
-                if (e < n_ring) run = ring[e];
-                const uint32_t q = run.x + sub;
-                v[u] = q < run.y;
-                const uint32_t qc = v[u] ? q : 0u;
-                r[u] = rec[qc];
-                sn[u] = rsn[qc];
-            }
-#pragma unroll
-            for (uint32_t u = 0; u < 4u; u++) {
-                const float ea = __builtin_fabsf(r[u].x - ha_pos), eb = __builtin_fabsf(r[u].y - hb_pos);
-                const float ta = La - ea, tb = Lb - eb;
-                const float ma = ea > halfa ? ta : ea, mb = eb > halfb ? tb : eb;
-                const bool in = v[u] & (ma * ma + mb * mb < thr);
-                redo |= v[u] & ((ta < 0.0f) | (tb < 0.0f));
-                if (in) {
-                    const float dz = r[u].z - hn_pos;
-                    const float uz = __builtin_fabsf(dz) > halfn ? dz - __builtin_copysignf(Ln, dz) : dz;
-                    redo |= __builtin_fabsf(uz) > halfn;
-                    cnt += 1u;
-                    nf |= (r[u].z - r[u].z == 0.0f) ? 0u : 1u;
-                    sc += r[u].w;
-                    ss += sn[u];
-                    su += uz;
-                    ulo = __builtin_fminf(ulo, uz);
-                    uhi = __builtin_fmaxf(uhi, uz);
-                }
-            }
-        }
-        // a head outside the box, or coordinates more than a box length apart: the general code below decides
-        redo |= !(fa >= -1e-4f * ca && fa <= ca * 1.0001f && fb >= -1e-4f * cb && fb <= cb * 1.0001f);
-        done = !__any(redo);
-        if (!done) { sc = ss = sp = su = 0.0f; ulo = 3.0e38f; uhi = -3.0e38f; cnt = 0; nf = 0; }
-    }
     const uint32_t n_runs = 2u * n_rows;
     uint32_t rq0 = 0, rq1 = 0;
     if (!done && lane < n_runs) {       // (the run table serves the general passes only)
@@ -1140,6 +1027,247 @@ __global__ __launch_bounds__(256) void k_local_flags(LocalArgs a) {
         if ((int)s == a.write_dist_frame && a.adist) a.adist[m] = d;
     }
     if (bad) raise_box_range(a.err, f);
+}
+
+// block = 256 threads = 4 waves = 4 heads; grid = (ceil(n_mol / 4), n_slab): the general passes for every head
+// (no cell sums: NoPBC, or GORDER_HIP_LOCAL_ATOMS_ONLY)
+__global__ __launch_bounds__(256) void k_local_flags(LocalArgs a) {
+    const uint32_t m = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (m >= a.n_mol_total) return;
+    local_flags_head(a, blockIdx.y, m);
+}
+
+// ---- cells instead of atoms where a whole cell lies inside the cylinder; a head per ROW of 16 lanes ----------------
+// A head's (2ka+1) x (2kb+1) cells are classified against the cylinder with the head's true position inside its cell:
+// a cell whose farthest corner is closer than the radius holds members only — its precomputed sums (k_local_cellsums)
+// are added as a block; a cell whose nearest point is farther holds none; only the ring of cells the circle crosses is
+// looked at atom by atom, in pieces of <= 16 records.  Membership itself stays the exact distance test; the margins
+// only decide who is tested.  Every periodic image of a neighbourhood cell other than the direct one lies beyond the
+// radius (at least k cells of >= 1.0001 r / k away, local_axis), so the direct displacement is the minimum image here —
+// unless a coordinate sits outside the box, which the flag `redo` catches.
+// FOUR heads per wave, one per DPP row: a piece of the ring is as long as a row, the 81 cells of a head take 6 rounds of
+// 16 lanes (84 % of the lanes busy; 63 % in two rounds of 64), and everything that is per head — the head's cell, the
+// sums over the lanes (row shifts only), the centre, atan2f — is paid once per four heads.  A head the cells cannot
+// decide (thick membrane, coordinates outside the box, an overfull cell or list) is handed, wave by wave, to the
+// general passes (local_flags_head).
+// block = 256 threads = 4 waves = 16 heads; grid = (ceil(n_mol / 16), n_slab).  Periodic boxes only.
+constexpr uint32_t kRowRing = 96;              // ring pieces a head may list (typically ~48)
+template <int CTRL>
+__device__ __forceinline__ double row_add_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return v + __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ uint32_t row_add_u32(uint32_t v) {
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+__global__ __launch_bounds__(256) void k_local_flags_rows(LocalArgs a) {
+    __shared__ uint2 l_ring[16][kRowRing];
+    const uint32_t lane = threadIdx.x & 63u, row = lane >> 4, sub = lane & 15u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t s = blockIdx.y;
+    const uint32_t m_raw = (blockIdx.x * 4u + wave) * 4u + row;
+    if ((blockIdx.x * 4u + wave) * 4u >= a.n_mol_total) return;           // the whole wave is past the last head
+    const bool head_ok = m_raw < a.n_mol_total;
+    const uint32_t m = head_ok ? m_raw : a.n_mol_total - 1u;              // idle rows shadow the last head, write nothing
+    const uint32_t f = a.aframes ? a.aframes[s] : a.frame0 + s;
+    float box[3];
+    frame_box(a, f, box);
+    const uint4 g = a.grid[s];
+    const uint32_t nca = g.x, ncb = g.y, ka = g.z, kb = g.w;
+    const int da = (int)((a.dim + 1u) % 3u), db = (int)((a.dim + 2u) % 3u), dn = (int)a.dim;
+    const float La = box[da], Lb = box[db], Ln = box[dn];
+    const float halfa = La / 2.0f, halfb = Lb / 2.0f, halfn = Ln / 2.0f;
+    const float thr = a.radius_thr;
+    const uint32_t n_rows = 2u * ka + 1u, n_cols = 2u * kb + 1u, n_cells = n_rows * n_cols;
+    const uint32_t *cstart = a.cell_count + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u);
+    const float4 *rec = reinterpret_cast<const float4 *>(a.trig) + (size_t)s * a.n_membrane;
+    const float *rsn = a.rsn + (size_t)s * a.n_membrane;
+    const float4 *agg = a.agg + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D) * 2u;
+    bool fail = !(ka >= 1u && kb >= 1u && n_cells <= 128u);               // (uniform) grids the cells do not handle
+
+    // ---- the head of this row
+    const float *hp = a.xyz + ((size_t)f * a.n_atoms + a.heads[m]) * 3u;
+    const float ha_pos = hp[da], hb_pos = hp[db], hn_pos = hp[dn];
+    int bad = 0;
+    const float wa = gm_wrap(ha_pos, La, bad), wb = gm_wrap(hb_pos, Lb, bad);
+    const float ca = La / (float)nca, cb = Lb / (float)ncb;                // cell edges
+    const uint32_t ha = (uint32_t)fminf(fmaxf(floorf(wa / La * (float)nca), 0.0f), (float)(nca - 1u));
+    const uint32_t hb = (uint32_t)fminf(fmaxf(floorf(wb / Lb * (float)ncb), 0.0f), (float)(ncb - 1u));
+    const float fa = wa - (float)ha * ca, fb = wb - (float)hb * cb;        // the head inside its cell
+    uint32_t a0 = ha + nca - ka, b0 = hb + ncb - kb;
+    a0 -= a0 >= nca ? nca : 0u;
+    b0 -= b0 >= ncb ? ncb : 0u;
+    // a head outside the box by more than rounding, or not where its cell says: the general passes decide
+    bool redo = !(fa >= -1e-4f * ca && fa <= ca * 1.0001f && fb >= -1e-4f * cb && fb <= cb * 1.0001f);
+
+    // ---- the cells, 16 per round and row
+    float sc = 0.0f, ss = 0.0f, su = 0.0f, ulo = 3.0e38f, uhi = -3.0e38f;
+    uint32_t cnt = 0, nf = 0, n_ring = 0;
+    const float r_in = thr * (1.0f - 4e-4f), r_out = thr * (1.0f + 4e-4f);
+    const uint32_t inv_cols = n_cols == 9u ? 7282u : (65536u + n_cols - 1u) / n_cols;
+    uint2 *ring = l_ring[wave * 4u + row];
+    // two rounds of 16 cells per trip to memory: the loads of both (sums of inner cells, runs of the others) go out
+    // before the first use — with four heads per wave there are few waves, and a wave that waits for one round at a
+    // time leaves the SIMD idle
+    struct CellRound {
+        float4 g0, g1;
+        uint32_t q0, q1;
+        bool inner, ring_cell;
+    };
+    auto classify = [&](uint32_t c0, CellRound &cr) {
+        const uint32_t ci = c0 + sub;
+        const bool valid = ci < n_cells;
+        // ci / n_cols for ci < 128, n_cols <= 128 by one multiplication: floor(ci * ceil(2^16 / n) / 2^16) is exact there
+        const uint32_t ia = valid ? (ci * inv_cols) >> 16 : 0u, ib = valid ? ci - ia * n_cols : 0u;
+        const float a_lo = ((float)ia - (float)ka) * ca - fa, a_hi = a_lo + ca;      // the cell's rectangle relative to the head
+        const float b_lo = ((float)ib - (float)kb) * cb - fb, b_hi = b_lo + cb;
+        const float fa_far = fmaxf(fabsf(a_lo), fabsf(a_hi)), fb_far = fmaxf(fabsf(b_lo), fabsf(b_hi));
+        const float fa_near = (a_lo <= 0.0f && a_hi >= 0.0f) ? 0.0f : fminf(fabsf(a_lo), fabsf(a_hi));
+        const float fb_near = (b_lo <= 0.0f && b_hi >= 0.0f) ? 0.0f : fminf(fabsf(b_lo), fabsf(b_hi));
+        cr.inner = valid && (fa_far * fa_far + fb_far * fb_far < r_in);
+        const bool outer = !valid || (fa_near * fa_near + fb_near * fb_near > r_out);
+        uint32_t ra = a0 + ia, rb = b0 + ib;
+        ra -= ra >= nca ? nca : 0u;
+        rb -= rb >= ncb ? ncb : 0u;
+        const uint32_t cell = ra * ncb + rb;
+        cr.ring_cell = !cr.inner && !outer;
+        cr.g0 = cr.inner ? agg[2u * cell] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        cr.g1 = cr.inner ? agg[2u * cell + 1u] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        cr.q0 = outer ? 0u : cstart[cell];
+        cr.q1 = outer ? 0u : cstart[cell + 1u];
+    };
+    auto absorb = [&](CellRound &cr) {
+        if (cr.inner && cr.g0.w > 0.0f) {
+            // the block sum of u = MI(z - z_head) is sum z - n z_head when no atom of the cell needs a shift
+            if (!(cr.g1.x - hn_pos >= -halfn && cr.g1.y - hn_pos <= halfn && cr.g0.z - cr.g0.z == 0.0f)) {
+                cr.ring_cell = true;                               // atom by atom instead (also carries a NaN on)
+            } else {
+                cnt += (uint32_t)cr.g0.w;
+                sc += cr.g0.x;
+                ss += cr.g0.y;
+                su += cr.g0.z - cr.g0.w * hn_pos;
+                ulo = fminf(ulo, cr.g1.x - hn_pos);
+                uhi = fmaxf(uhi, cr.g1.y - hn_pos);
+            }
+        }
+        // ring cells go to the row's list in pieces of <= 16 records
+        const uint32_t n_at = cr.ring_cell ? cr.q1 - cr.q0 : 0u;
+        redo |= n_at > 64u;                                    // an overfull cell: the general passes
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; j++) {
+            const bool has = n_at > 16u * j;
+            const uint64_t mask = __ballot(has);
+            if (!mask) break;                                  // (wave-uniform) no cell of any row has a j-th piece
+            const uint32_t mine = (uint32_t)(mask >> (16u * row)) & 0xffffu;          // this row's lanes
+            const uint32_t pos = n_ring + (uint32_t)__popc(mine & ((1u << sub) - 1u));
+            if (has && pos < kRowRing) ring[pos] = make_uint2(cr.q0 + 16u * j, min(cr.q1, cr.q0 + 16u * j + 16u));
+            n_ring += (uint32_t)__popc(mine);
+        }
+    };
+    for (uint32_t c0 = 0; !fail && c0 < n_cells; c0 += 32u) {
+        CellRound ra_, rb_;
+        classify(c0, ra_);
+        classify(c0 + 16u, rb_);           // (past the last cell: every lane invalid -> outer, nothing loaded)
+        absorb(ra_);
+        absorb(rb_);
+    }
+    redo |= n_ring > kRowRing;                                  // the list ran over: the general passes
+    __builtin_amdgcn_wave_barrier();
+    // ---- the ring: one piece per row and iteration, one record per lane; the records of eight iterations together
+    uint32_t n_max = max(max((uint32_t)__builtin_amdgcn_readlane((int)n_ring, 0), (uint32_t)__builtin_amdgcn_readlane((int)n_ring, 16)),
+                         max((uint32_t)__builtin_amdgcn_readlane((int)n_ring, 32), (uint32_t)__builtin_amdgcn_readlane((int)n_ring, 48)));
+    n_max = min(n_max, kRowRing);
+    for (uint32_t t = 0; !fail && t < n_max; t += 8u) {
+        float4 r[8];
+        float sn[8];
+        bool v[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; u++) {
+            const uint32_t e = t + u;
+            uint2 run = make_uint2(0u, 0u);
+            if (e < min(n_ring, kRowRing)) run = ring[e];
+            const uint32_t q = run.x + sub;
+            v[u] = q < run.y;
+            const uint32_t qc = v[u] ? q : 0u;
+            r[u] = rec[qc];
+            sn[u] = rsn[qc];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; u++) {
+            const float ea = __builtin_fabsf(r[u].x - ha_pos), eb = __builtin_fabsf(r[u].y - hb_pos);
+            const float ta = La - ea, tb = Lb - eb;
+            const float ma = ea > halfa ? ta : ea, mb = eb > halfb ? tb : eb;
+            const bool in = v[u] & (ma * ma + mb * mb < thr);
+            redo |= v[u] & ((ta < 0.0f) | (tb < 0.0f));
+            if (in) {
+                const float dz = r[u].z - hn_pos;
+                const float uz = __builtin_fabsf(dz) > halfn ? dz - __builtin_copysignf(Ln, dz) : dz;
+                redo |= __builtin_fabsf(uz) > halfn;
+                cnt += 1u;
+                nf |= (r[u].z - r[u].z == 0.0f) ? 0u : 1u;
+                sc += r[u].w;
+                ss += sn[u];
+                su += uz;
+                ulo = __builtin_fminf(ulo, uz);
+                uhi = __builtin_fmaxf(uhi, uz);
+            }
+        }
+    }
+    // ---- per row: totals in lane 15 of the row (row shifts only), then the centre as in the general passes
+    double tu = (double)su;
+    tu = row_add_f64<0x111>(tu); tu = row_add_f64<0x112>(tu); tu = row_add_f64<0x114>(tu); tu = row_add_f64<0x118>(tu);
+    sc = row_add<0x111>(sc); ss = row_add<0x111>(ss); cnt = row_add_u32<0x111>(cnt);
+    sc = row_add<0x112>(sc); ss = row_add<0x112>(ss); cnt = row_add_u32<0x112>(cnt);
+    sc = row_add<0x114>(sc); ss = row_add<0x114>(ss); cnt = row_add_u32<0x114>(cnt);
+    sc = row_add<0x118>(sc); ss = row_add<0x118>(ss); cnt = row_add_u32<0x118>(cnt);
+    ulo = fminf(ulo, row_shifted<0x111>(ulo)); uhi = fmaxf(uhi, row_shifted<0x111>(uhi));
+    ulo = fminf(ulo, row_shifted<0x112>(ulo)); uhi = fmaxf(uhi, row_shifted<0x112>(uhi));
+    ulo = fminf(ulo, row_shifted<0x114>(ulo)); uhi = fmaxf(uhi, row_shifted<0x114>(uhi));
+    ulo = fminf(ulo, row_shifted<0x118>(ulo)); uhi = fmaxf(uhi, row_shifted<0x118>(uhi));
+    // any lane of the row: redo / non-finite member
+    const uint64_t redo_mask = __ballot(redo), nf_mask = __ballot(nf != 0u);
+    const bool row_redo = ((redo_mask >> (16u * row)) & 0xffffull) != 0ull;
+    const bool row_nf = ((nf_mask >> (16u * row)) & 0xffffull) != 0ull;
+    bool general = fail || row_redo;
+    if (sub == 15u && head_ok && !general) {
+        if (cnt == 0u || row_nf) {
+            raise_error(a.err, GORDER_ERR_INVALID_LOCAL_MEMBRANE_CENTER, f, kStageTypes, a.mol_slot0 ? a.mol_slot0[m] : 0u, 0, m);
+        } else {
+            const float est = (atan2f(-ss, -sc) + 3.1415927f) / (6.2831855f / Ln);
+            const float shift = gm_min_image(hn_pos - est, Ln, bad), margin = 1e-4f * Ln;
+            if (ulo + shift > -halfn + margin && uhi + shift < halfn - margin) {
+                const float center = gm_wrap((est + shift) + (float)(tu / (double)cnt), Ln, bad);
+                if (center != center) {
+                    raise_error(a.err, GORDER_ERR_INVALID_LOCAL_MEMBRANE_CENTER, f, kStageTypes, a.mol_slot0 ? a.mol_slot0[m] : 0u, 0, m);
+                } else {
+                    const float d = gm_min_image(hn_pos - center, Ln, bad);
+                    a.aflags[(size_t)(a.row0 + s) * a.n_mol_total + m] = (uint8_t)((d >= 0.0f ? 0 : 1) ^ (a.flip ? 1 : 0));
+                    if ((int)s == a.write_dist_frame && a.adist) a.adist[m] = d;
+                }
+            } else {
+                general = true;          // a membrane thicker than half the box: the second pass of the general code
+            }
+        }
+    }
+    if (bad) raise_box_range(a.err, f);
+    // ---- heads the cells could not decide go on the list of k_local_flags_todo (calling the general passes from here
+    // would cost this kernel their registers and a stack: 102 VGPRs and 4 waves per SIMD instead of what the rows need)
+    if (general && head_ok && sub == 15u) {
+        const uint32_t at = atomicAdd(&a.todo[0].x, 1u);
+        a.todo[1u + at] = make_uint2(s, m);
+    }
+}
+
+// The general passes for the heads k_local_flags_rows listed; one wave per head, a fixed grid walks the list.
+__global__ __launch_bounds__(256) void k_local_flags_todo(LocalArgs a) {
+    const uint32_t n = a.todo[0].x;
+    for (uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6); i < n; i += gridDim.x * 4u) {
+        const uint2 e = a.todo[1u + i];
+        local_flags_head(a, (uint32_t)__builtin_amdgcn_readfirstlane((int)e.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)e.y));
+    }
 }
 
 }  // namespace
