@@ -11,8 +11,8 @@ N = 1 (default): BASELINE.json configs[1] — AAOrder, 256-lipid membrane (25 08
     roofline          the dominant kernel against the HBM roofline (HIP events on the launch stream),
     cpu_baseline      the oracle (C restatement of the reference algorithm, libm trig like the Rust code) on this box's
                       host cores, at 1 thread and at all cores,
-    end_to_end        the same workload from an XTC FILE: reader threads -> pinned staging -> copy stream -> kernels
-                      (gorder_hip_run_trajectory): frames/s from file, decoder threads, PCIe GB/s,
+    end_to_end        the same workload from an XTC FILE (gorder_hip_run_trajectory): frames/s from file with the frames
+                      decompressed on the device (value) and by host threads (host_decode), PCIe GB/s,
     scaling_reference the north_star scaling job (CG-1M, 10 000 frames) on this one GPU: the N = 1 point of the curve
                       that `--gpus N` continues.
 N > 1 (launched by torch.distributed.run, one rank per GPU): the north_star scaling experiment — STRONG scaling of
@@ -128,7 +128,7 @@ def warm_up(step, sync, n_steps, agree=None):
     return done
 
 
-def end_to_end(system, device_index, n_unique=500, repeats=40):
+def end_to_end(system, device_index, n_unique=500, repeats=200):
     """The workload from an XTC FILE through gorder_hip_run_trajectory: the repo's encoder writes n_unique synthetic
     frames (precision 1000 like GROMACS), the file is read `repeats` times as one concatenated trajectory."""
     from gorder_amd import HipEngine, xtc
@@ -143,25 +143,37 @@ def end_to_end(system, device_index, n_unique=500, repeats=40):
         size = os.path.getsize(path)
         system.tables.device = device_index
         eng = HipEngine(system.tables)
-        eng.run_trajectory([path], threads=cores)            # warm: page cache, pinned pools, kernels
-        eng.reset()
-        stats = eng.run_trajectory([path] * repeats, threads=cores)
-        res = eng.finish()
+        runs = {}
+        for route, dev in (("host_decode", False), ("device_decode", True)):
+            eng.reset()
+            eng.run_trajectory([path] * 2, threads=cores, device_decode=dev)     # warm: page cache, pinned pools, kernels
+            eng.reset()
+            stats = eng.run_trajectory([path] * repeats, threads=cores, device_decode=dev)
+            res = eng.finish()
+            assert stats["n_frames"] == n_unique * repeats == res.n_frames and stats["device_decode"] == int(dev)
+            runs[route] = (stats, res)
         eng.close()
-    n = stats["n_frames"]
-    assert n == n_unique * repeats == res.n_frames
-    sec = stats["seconds_total"]
-    return {"value": n / sec, "unit": "frames/s", "frames": n, "decoder_threads": stats["decoder_threads"],
-            "batch_frames": stats["batch_frames"], "batches": stats["n_batches"],
-            "pcie_GBps": stats["bytes_h2d"] / sec / 1e9, "file_MB": size * repeats / 1e6,
-            "file_read_MBps": size * repeats / sec / 1e6,
-            "seconds": {"total": sec, "decoding": stats["seconds_decode"],
-                        "reader_waiting_for_gpu": stats["seconds_reader_stalled"],
-                        "gpu_waiting_for_reader": stats["seconds_gpu_starved"]},
-            "bottleneck": "decoder" if stats["seconds_gpu_starved"] > stats["seconds_reader_stalled"] else "copy/kernels",
-            "path": "XTC file (repo encoder, precision 1000, %d frames read %d x as one concatenated trajectory, "
-                    "encoded in %.1f s) -> gorder_xtc_read_window_mt -> pinned staging x3 -> hipMemcpyAsync on a copy "
-                    "stream -> kernels (gorder_hip_run_trajectory)" % (n_unique, repeats, t_write)}
+    np.testing.assert_array_equal(runs["host_decode"][1].sums, runs["device_decode"][1].sums)   # same coordinates, same sums
+
+    def block(stats):
+        n, sec = stats["n_frames"], stats["seconds_total"]
+        return {"value": n / sec, "unit": "frames/s", "frames": n, "host_threads": stats["decoder_threads"],
+                "batch_frames": stats["batch_frames"], "batches": stats["n_batches"],
+                "pcie_GBps": stats["bytes_h2d"] / sec / 1e9, "file_read_MBps": size * repeats / sec / 1e6,
+                "seconds": {"total": sec, "setup": stats["seconds_setup"], "host_reader": stats["seconds_decode"],
+                            "reader_waiting_for_gpu": stats["seconds_reader_stalled"],
+                            "gpu_waiting_for_reader": stats["seconds_gpu_starved"]},
+                "bottleneck": "host reader" if stats["seconds_gpu_starved"] > stats["seconds_reader_stalled"] else "copy/kernels"}
+
+    out = block(runs["device_decode"][0])
+    out["host_decode"] = block(runs["host_decode"][0])
+    out["file_MB"] = size * repeats / 1e6
+    out["path"] = ("XTC file (repo encoder, precision 1000, %d frames read %d x as one concatenated trajectory, encoded in "
+                   "%.1f s) -> gorder_hip_run_trajectory.  value: device_decode = host threads copy the compressed blocks "
+                   "(gorder_xtc_pack_window) -> pinned staging x3 -> hipMemcpyAsync -> k_xtc_decode (one frame per lane) "
+                   "-> kernels.  host_decode: gorder_xtc_read_window_mt on the same threads -> pinned -> hipMemcpyAsync "
+                   "-> kernels.  Both routes give identical sums (checked)." % (n_unique, repeats, t_write))
+    return out
 
 
 def scaling_reference(device, steps=5):

@@ -86,13 +86,22 @@ class CTables(C.Structure):
 class CTrajectory(C.Structure):
     _fields_ = [("paths", C.POINTER(C.c_char_p)), ("n_paths", C.c_uint32), ("group", _u32p), ("n_group", C.c_uint32),
                 ("begin_ps", C.c_float), ("end_ps", C.c_float), ("step", C.c_uint32), ("n_threads", C.c_uint32),
-                ("batch_frames", C.c_uint32), ("first_frame_index", C.c_uint64)]
+                ("batch_frames", C.c_uint32), ("first_frame_index", C.c_uint64), ("device_decode", C.c_uint32),
+                ("reserved", C.c_uint32)]
 
 
 class CTrajectoryStats(C.Structure):
     _fields_ = [("n_frames", C.c_uint64), ("n_batches", C.c_uint64), ("bytes_h2d", C.c_uint64),
                 ("seconds_total", C.c_double), ("seconds_decode", C.c_double), ("seconds_reader_stalled", C.c_double),
-                ("seconds_gpu_starved", C.c_double), ("batch_frames", C.c_uint32), ("decoder_threads", C.c_uint32)]
+                ("seconds_gpu_starved", C.c_double), ("batch_frames", C.c_uint32), ("decoder_threads", C.c_uint32),
+                ("device_decode", C.c_uint32), ("reserved", C.c_uint32), ("seconds_setup", C.c_double)]
+
+
+class CXtcFrame(C.Structure):
+    """gorder_xtc_frame_t (include/gorder_xtc.h): one still-compressed frame for the device decoder."""
+    _fields_ = [("offset", C.c_uint64), ("recip1", C.c_uint64), ("recip2", C.c_uint64), ("n_bytes", C.c_uint32),
+                ("kind", C.c_uint32), ("minint", C.c_int32 * 3), ("sizeint", C.c_uint32 * 3), ("smallidx", C.c_int32),
+                ("inv_precision", C.c_float), ("bitsize", C.c_uint32), ("bitsizeint", C.c_uint32)]
 
 
 class CPlan(C.Structure):
@@ -298,7 +307,7 @@ _EXPORTS = [
     "gorder_hip_last_error_message", "gorder_hip_strerror", "gorder_hip_kernel_time", "gorder_hip_plan",
     "gorder_hip_plan_tables", "gorder_hip_selftest_arithmetic", "gorder_hip_run_trajectory",
     "gorder_hip_comm_unique_id", "gorder_hip_comm_create", "gorder_hip_comm_destroy", "gorder_hip_allreduce",
-    "gorder_hip_reset",
+    "gorder_hip_reset", "gorder_hip_xtc_decode",
 ]
 
 _lib = None
@@ -370,6 +379,7 @@ def load_library() -> C.CDLL:
     lib.gorder_hip_comm_destroy.restype = None
     lib.gorder_hip_allreduce.argtypes = [vp, vp]
     lib.gorder_hip_reset.argtypes = [vp]
+    lib.gorder_hip_xtc_decode.argtypes = [vp, vp, u64, vp, u32, u32, vp, u32, vp, u32]
     _lib = lib
     return lib
 
@@ -506,10 +516,11 @@ class HipEngine:
                                                     fi.ctypes.data_as(C.c_void_p), n_frames))
 
     def run_trajectory(self, paths, group=None, begin: float = 0.0, end: float = -1.0, step: int = 1, threads: int = 0,
-                       batch_frames: int = 0, first_frame_index: int = 0) -> dict:
+                       batch_frames: int = 0, first_frame_index: int = 0, device_decode: bool = False) -> dict:
         """The reference's `read_trajectory` (common.rs:239-342) as one library call: read (and concatenate) the
         files, apply the time window / step, decode on `threads` host threads and analyse batch by batch with copies
-        and kernels overlapped (gorder_hip_run_trajectory).  -> the pipeline's statistics."""
+        and kernels overlapped (gorder_hip_run_trajectory).  `device_decode`: the host threads only copy the compressed
+        XTC blocks, the device unpacks them (one frame per lane).  -> the pipeline's statistics."""
         arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
         grp = None if group is None else np.ascontiguousarray(group, dtype=np.uint32)
         t = CTrajectory()
@@ -519,9 +530,17 @@ class HipEngine:
         t.n_group = 0 if grp is None else grp.size
         t.begin_ps, t.end_ps, t.step = begin, end, step
         t.n_threads, t.batch_frames, t.first_frame_index = threads, batch_frames, first_frame_index
+        t.device_decode = 1 if device_decode else 0
         stats = CTrajectoryStats()
         self._check(self.lib.gorder_hip_run_trajectory(self._h, C.byref(t), C.byref(stats)))
         return {name: getattr(stats, name) for name, _ in CTrajectoryStats._fields_}
+
+    def xtc_decode(self, d_blob: int, blob_bytes: int, d_frames: int, n_frames: int, n_atoms_file: int, d_slot_of: int,
+                   n_stop: int, d_xyz: int, n_atoms_out: int):
+        """Decompress packed XTC frames on the device (gorder_hip_xtc_decode); all pointers are device addresses
+        (d_slot_of may be 0).  Asynchronous on the handle's stream."""
+        self._check(self.lib.gorder_hip_xtc_decode(self._h, d_blob, blob_bytes, d_frames, n_frames, n_atoms_file,
+                                                   d_slot_of or None, n_stop, d_xyz, n_atoms_out))
 
     def reset(self):
         """A fresh SystemTopology on the same tables (gorder_hip_reset)."""

@@ -46,6 +46,7 @@ using gorder::Tile;
 #include "kernels_extras.h"
 #include "kernels_leaflets.h"
 #include "kernels_normals.h"
+#include "kernels_xtc.h"
 
 // ============================================================================================
 // host side
@@ -221,7 +222,7 @@ int check_device_error(gorder_hip_handle *h) {
     const uint32_t code = (uint32_t)(key & 15u), detail = (uint32_t)(key >> 4) & 3u, mol = (uint32_t)(key >> 6) & 0x1ffffu;
     const uint32_t sample = (uint32_t)(key >> 23) & 1u, slot = (uint32_t)(key >> 24) & 0x3fffu;
     const uint32_t stage = (uint32_t)(key >> 38) & 3u, frame = (uint32_t)(key >> 40) & 0x7fffffu;
-    const int status = code == 8u ? (int)GORDER_ERR_BOX_RANGE : (int)code;
+    const int status = code == 8u ? (int)GORDER_ERR_BOX_RANGE : (code == 9u ? (int)GORDER_ERR_TRAJECTORY_FORMAT : (int)code);
     h->err_frame = frame;
     h->err_index = 0;
     if (status == GORDER_ERR_UNDEFINED_POSITION) {
@@ -617,6 +618,7 @@ const char *gorder_hip_strerror(int status) {
         case GORDER_ERR_BOX_RANGE: return "box edge <= 0 or coordinate too far outside the box";
         case GORDER_ERR_LEAFLETS_NOT_PRIMED: return "leaflet assignment missing for the first frame";
         case GORDER_ERR_OVERFLOW: return "order accumulator overflowed";
+        case GORDER_ERR_TRAJECTORY_FORMAT: return "corrupt or truncated trajectory frame";
         default: return "unknown status";
     }
 }
@@ -1525,6 +1527,29 @@ int gorder_hip_kernel_time(gorder_hip_handle *h, double *ms, uint64_t *launches,
     if (launches) *launches = h->timing_launches;
     if (reset) { h->timing_ms = 0.0; h->timing_launches = 0; }
     return GORDER_OK;
+}
+
+// ---- XTC frames decompressed on the device (kernels_xtc.h) ---------------------------------------------------------
+int xtc_decode_on(gorder_hip_handle *h, hipStream_t stream, const uint8_t *d_blob, uint64_t blob_bytes,
+                  const gorder_xtc_frame_t *d_frames, uint32_t n_frames, uint32_t n_atoms_file, const int32_t *d_slot_of,
+                  uint32_t n_stop, float *d_xyz, uint32_t n_atoms_out) {
+    if (!h || !d_blob || !d_frames || !d_xyz || blob_bytes < 32 || n_atoms_file == 0 || n_atoms_out == 0 ||
+        n_stop > n_atoms_file || (!d_slot_of && n_atoms_out < n_stop))
+        return fail(h, GORDER_ERR_INVALID_ARGUMENT, "gorder_hip_xtc_decode: bad arguments");
+    if (n_frames == 0) return GORDER_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_xtc_decode, dim3((n_frames + 63u) / 64u), dim3(64), 0, stream, d_blob,
+                       (unsigned long long)blob_bytes, d_frames, n_frames, n_atoms_file, d_slot_of, n_stop, d_xyz,
+                       n_atoms_out, h->d_err);
+    HIP_TRY(h, hipGetLastError());
+    return GORDER_OK;
+}
+int gorder_hip_xtc_decode(gorder_hip_handle *h, const uint8_t *d_blob, uint64_t blob_bytes,
+                          const gorder_xtc_frame_t *d_frames, uint32_t n_frames, uint32_t n_atoms_file,
+                          const int32_t *d_slot_of, uint32_t n_stop, float *d_xyz, uint32_t n_atoms_out) {
+    if (!h) return GORDER_ERR_INVALID_ARGUMENT;
+    return xtc_decode_on(h, h->stream, d_blob, blob_bytes, d_frames, n_frames, n_atoms_file, d_slot_of, n_stop, d_xyz,
+                         n_atoms_out);
 }
 
 }  // extern "C"

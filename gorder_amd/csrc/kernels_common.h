@@ -40,7 +40,7 @@ struct FrameArgs {
 //   [37:24] accumulator slot (first slot of the type for its leaflet assignment; clamped to 2^14 - 1)
 //   [23]    0 = leaflet assignment of the type, 1 = order sample
 //   [22:6]  global molecule id (clamped to 2^17 - 1)   [5:4] detail (which atom of the sample / cloud size)
-//   [3:0]   code: gorder_status_t 1..7, 8 = GORDER_ERR_BOX_RANGE
+//   [3:0]   code: gorder_status_t 1..7, 8 = GORDER_ERR_BOX_RANGE, 9 = GORDER_ERR_TRAJECTORY_FORMAT (k_xtc_decode)
 // The payload of gorder_hip_last_error_index (an atom index) is resolved on the host from (slot, molecule, detail).
 constexpr unsigned long long kErrNone = ~0ull;
 enum ErrStage : uint32_t { kStageBox = 0, kStageSystem = 1, kStageTypes = 2, kStageEnd = 3 };
@@ -52,7 +52,7 @@ __device__ __forceinline__ void raise_error(uint32_t *err, uint32_t code, uint32
         ((unsigned long long)min(frame, 0x7fffffu) << 40) | ((unsigned long long)(stage & 3u) << 38) |
         ((unsigned long long)min(slot, 0x3fffu) << 24) | ((unsigned long long)(sample & 1u) << 23) |
         ((unsigned long long)min(mol, 0x1ffffu) << 6) | ((unsigned long long)(detail & 3u) << 4) |
-        (unsigned long long)(code == GORDER_ERR_BOX_RANGE ? 8u : (code & 15u));
+        (unsigned long long)(code == GORDER_ERR_BOX_RANGE ? 8u : (code == GORDER_ERR_TRAJECTORY_FORMAT ? 9u : (code & 15u)));
     atomicMin(reinterpret_cast<unsigned long long *>(err), key);
 }
 // the library's own range error (a coordinate so far outside the box that the reference would spin): end of frame

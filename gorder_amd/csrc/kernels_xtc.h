@@ -1,0 +1,276 @@
+// kernels_xtc.h — k_xtc_decode: GROMACS xdr3dcoord bit streams -> f32 coordinates of the analysed atoms, on the device.
+// Part of the single translation unit gorder_hip.hip; device code for gfx950 only.
+//
+// What it replaces: the decoding half of the reference's reader (groan_rs GroupXtcReader -> molly 0.5.0, reached from
+// common.rs:283-304) — "the reference's true bottleneck" (SURVEY §6, §8f row 1).  The host only copies the compressed
+// blocks (gorder_xtc_pack_window); the bit stream of a frame is strictly sequential (every field's position and the
+// adaptive `smallidx` depend on everything before it), so the parallel axis is the FRAME: one lane decodes one frame,
+// a wave 64 frames, a window of thousands of frames a few hundred waves.  Same integers, same `int * (1 / precision)`
+// as gorder_xtc_next (xtc_reader.cpp): the two decoders are compared bit for bit in tests/test_xtc_device_gpu.py.
+//
+// Shape of the loop.  The reference algorithm is "one full-width atom, then a run of 0..8 small atoms"; here every
+// iteration of every lane decodes exactly ONE atom — full-width or small, by the lane's own state — so the atom
+// counter is wave-uniform (the slot lookups are scalar loads, the stores of a wave go to the same atom of 64 frames)
+// and the trip count is the number of atoms up to the last analysed one, not a data-dependent quantity.
+// The bit reader keeps 128 bits of the stream in registers and the next 64 prefetched, so no load is on the
+// dependency chain of a field; every lane reads its own stream with aligned 8-byte loads.
+#pragma once
+
+#include "../../include/gorder_xtc.h"
+
+namespace {
+
+constexpr int kXtcFirstIdx = 9, kXtcLastIdx = 73;
+constexpr uint32_t kXtcGroup = 16;     // atoms written out together (see k_xtc_decode)
+constexpr uint32_t kXtcPitch = 65;     // floats per (atom, coordinate) row of the LDS staging: 64 frames + 1 (bank spread)
+__device__ const uint32_t kXtcMagic[kXtcLastIdx] = {
+    0,       0,       0,       0,       0,       0,       0,       0,       0,       8,        10,       12,
+    16,      20,      25,      32,      40,      50,      64,      80,      101,     128,      161,      203,
+    256,     322,     406,     512,     645,     812,     1024,    1290,    1625,    2048,     2580,     3250,
+    4096,    5060,    6501,    8192,    10321,   13003,   16384,   20642,   26007,   32768,    41285,    52015,
+    65536,   82570,   104031,  131072,  165140,  208063,  262144,  330280,  416127,  524287,   660561,   832255,
+    1048576, 1321122, 1664510, 2097152, 2642245, 3329021, 4194304, 5284491, 6658042, 8388607,  10568983, 13316085,
+    16777216};
+
+struct XtcBits {
+    const unsigned long long *src, *end;   // next word to prefetch; one past the last readable word
+    unsigned long long w0, w1, pre;        // w0:w1 = the next 128 bits of the stream, MSB first; pre = the raw word behind them
+    uint32_t off;                          // bits of w0 already taken
+    unsigned long long taken;              // bits taken in all
+    __device__ __forceinline__ void open(const uint8_t *p, const uint8_t *p_end) {   // >= 24 readable bytes
+        src = reinterpret_cast<const unsigned long long *>(p);
+        end = reinterpret_cast<const unsigned long long *>(p_end);
+        w0 = __builtin_bswap64(src[0]);
+        w1 = __builtin_bswap64(src[1]);
+        pre = src[2];
+        src += 3;
+        off = 0;
+        taken = 0;
+    }
+    __device__ __forceinline__ unsigned long long take(uint32_t n) {   // 0 <= n <= 64
+        const unsigned long long next = off ? (w0 << off) | (w1 >> (64u - off)) : w0;
+        const unsigned long long v = n ? next >> (64u - n) : 0ull;
+        off += n;
+        taken += n;
+        if (off >= 64u) {
+            off -= 64u;
+            w0 = w1;
+            w1 = __builtin_bswap64(pre);
+            pre = src < end ? *src : 0ull;      // a corrupt stream runs into zeros, never out of the block
+            src++;
+        }
+        return v;
+    }
+};
+
+// v / s by the precomputed floor(2^64 / s): the estimate is at most two short (xtc_reader.cpp BitReader::ints)
+__device__ __forceinline__ unsigned long long xtc_div(unsigned long long v, uint32_t s, unsigned long long recip, uint32_t &rem) {
+    unsigned long long q = __umul64hi(v, recip);
+    unsigned long long r = v - q * s;
+    if (r >= s) { r -= s; q++; }
+    if (r >= s) { r -= s; q++; }
+    rem = (uint32_t)r;
+    return q;
+}
+
+// Three integers packed as one mixed-radix number of nbits (1..72) bits with radices (-, s1, s2).  The number is
+// stored in chunks of 8 bits, first chunk least significant, the last (partial) chunk on top.
+__device__ __forceinline__ void xtc_ints(XtcBits &b, uint32_t nbits, uint32_t s1, uint32_t s2, unsigned long long r1,
+                                         unsigned long long r2, int (&out)[3]) {
+    uint32_t c1, c2;
+    if (nbits <= 32u) {
+        // the usual small-offset atom (and full atoms of tiny boxes): everything in 32 bits — a 64 x 64 -> 128
+        // multiplication is seven quarter-rate integer multiplications on this hardware, this path has four in all.
+        // floor(2^32 / s) = floor(2^64 / s) >> 32; the estimate is at most one short (two repairs as above).
+        const uint32_t m = (nbits - 1u) >> 3, rem = nbits - 8u * m;
+        const uint32_t x = (uint32_t)b.take(nbits);
+        uint32_t v = (x & ((1u << rem) - 1u)) << (8u * m);
+        if (m) v |= __builtin_bswap32((x >> rem) << (32u - 8u * m));
+        auto div32 = [](uint32_t n, uint32_t s, uint32_t recip, uint32_t &r) {
+            uint32_t q = __umulhi(n, recip);
+            r = n - q * s;
+            if (r >= s) { r -= s; q++; }
+            if (r >= s) { r -= s; q++; }
+            return q;
+        };
+        const uint32_t q2 = div32(v, s2, (uint32_t)(r2 >> 32), c2);
+        out[0] = (int)div32(q2, s1, (uint32_t)(r1 >> 32), c1);
+    } else if (nbits <= 64u) {
+        const uint32_t m = (nbits - 1u) >> 3, rem = nbits - 8u * m;     // m full chunks, then rem (1..8) bits
+        const unsigned long long x = b.take(nbits);
+        unsigned long long v = (x & ((1ull << rem) - 1ull)) << (8u * m);
+        if (m) v |= __builtin_bswap64((x >> rem) << (64u - 8u * m));
+        const unsigned long long q2 = xtc_div(v, s2, r2, c2);
+        const unsigned long long q1 = xtc_div(q2, s1, r1, c1);
+        out[0] = (int)(uint32_t)q1;
+    } else {
+        // 65..72 bits (boxes beyond ~2 million grid steps per edge): long division over 32-bit limbs
+        uint32_t l0 = __builtin_bswap32((uint32_t)b.take(32)), l1 = __builtin_bswap32((uint32_t)b.take(32));
+        uint32_t l2 = (uint32_t)b.take(nbits - 64u);
+        auto div96 = [&](uint32_t s, unsigned long long recip) {
+            uint32_t r;
+            l2 = (uint32_t)xtc_div(l2, s, recip, r);
+            l1 = (uint32_t)xtc_div(((unsigned long long)r << 32) | l1, s, recip, r);
+            l0 = (uint32_t)xtc_div(((unsigned long long)r << 32) | l0, s, recip, r);
+            return r;
+        };
+        c2 = div96(s2, r2);
+        c1 = div96(s1, r1);
+        out[0] = (int)l0;
+    }
+    out[1] = (int)c1;
+    out[2] = (int)c2;
+}
+
+// grid = ceil(n_frames / 64) blocks of ONE wave; lane = frame.
+//   blob, frames : what gorder_xtc_pack_window produced (device copies)
+//   natoms       : atoms per frame in the file;  n_stop: atoms to go through (up to the last analysed one)
+//   slot_of      : [natoms] output slot of an atom or -1 (null: every atom, slot = atom)
+//   out          : [n_frames][n_out][3]
+__global__ __launch_bounds__(64) void k_xtc_decode(const uint8_t *__restrict__ blob, unsigned long long blob_bytes,
+                                                   const gorder_xtc_frame_t *__restrict__ frames, uint32_t n_frames,
+                                                   uint32_t natoms, const int32_t *__restrict__ slot_of, uint32_t n_stop,
+                                                   float *__restrict__ out, uint32_t n_out, uint32_t *err) {
+    __shared__ uint32_t l_magic[kXtcLastIdx];
+    __shared__ unsigned long long l_recip[kXtcLastIdx];
+    for (uint32_t k = threadIdx.x; k < (uint32_t)kXtcLastIdx; k += 64u) {
+        const uint32_t m = kXtcMagic[k];
+        l_magic[k] = m;
+        // floor(2^64 / m): a power of two divides 2^64 exactly, for anything else it is floor((2^64 - 1) / m)
+        l_recip[k] = m == 0u ? 0ull : ((m & (m - 1u)) == 0u ? 1ull << (64 - __builtin_ctz(m)) : ~0ull / m);
+    }
+    __syncthreads();
+    const uint32_t fr = blockIdx.x * 64u + threadIdx.x;
+    const bool live = fr < n_frames;
+    const gorder_xtc_frame_t d = frames[live ? fr : n_frames - 1u];
+    float *o = out + (size_t)(live ? fr : 0u) * n_out * 3u;      // (the raw path below)
+    const float inv_p = d.inv_precision;
+    const unsigned long long padded = ((unsigned long long)d.n_bytes + 7ull) & ~7ull;
+    bool bad = (d.offset & 7ull) != 0ull || d.offset + padded + 32ull > blob_bytes;
+    const uint8_t *p = blob + (bad ? 0ull : d.offset);
+
+    // Decoded atoms go through LDS: a lane writing its frame's atom straight to memory is one 4-byte piece in each of
+    // 64 cache lines per store instruction.  Instead a lane parks atom i at l_atoms[i mod 32] and, once 16 consecutive
+    // atoms are final, the wave writes them frame by frame: 48 lanes = 16 atoms x 3 coordinates = one contiguous
+    // 192-byte piece of a frame when the analysed atoms are consecutive in the file (any other order is still correct,
+    // only less coalesced): 48 x fewer memory transactions.  (The kernel's time did not change with it — 0.9 us per
+    // atom and wave before and after: a wave is bound by the ~500 instructions of an iteration, one issue per 4 cycles,
+    // not by memory — but it keeps thousands of concurrent waves from flooding the memory pipeline with partial lines.)
+    __shared__ float l_atoms[2u * kXtcGroup * 3u * kXtcPitch];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n_live = min(64u, n_frames - blockIdx.x * 64u);
+    auto put = [&](const int (&c)[3], uint32_t idx) {        // idx is wave-uniform
+        float *q = l_atoms + (idx & (2u * kXtcGroup - 1u)) * 3u * kXtcPitch + lane;
+        q[0] = (float)c[0] * inv_p;
+        q[kXtcPitch] = (float)c[1] * inv_p;
+        q[2u * kXtcPitch] = (float)c[2] * inv_p;
+    };
+    auto flush = [&](uint32_t first_atom) {                  // atoms first_atom .. first_atom + 15, all final
+        __syncthreads();                                     // (one wave per block: orders the LDS writes before the reads)
+        const uint32_t j = lane / 3u, c = lane - 3u * j, idx = first_atom + j;
+        int32_t slot = -1;
+        if (lane < 3u * kXtcGroup && idx < n_stop) slot = slot_of ? slot_of[idx] : (int32_t)idx;
+        if (slot >= 0 && (uint32_t)slot < n_out) {
+            const float *q = l_atoms + ((idx & (2u * kXtcGroup - 1u)) * 3u + c) * kXtcPitch;
+            float *dst = out + ((size_t)blockIdx.x * 64u * n_out + (uint32_t)slot) * 3u + c;
+#pragma unroll 4
+            for (uint32_t f = 0; f < n_live; f++) dst[(size_t)f * n_out * 3u] = q[f];
+        }
+    };
+
+    if (natoms <= 9u) {      // uncompressed small systems: big-endian floats
+        for (uint32_t t = 0; t < n_stop; t++) {
+            const int32_t slot = slot_of ? slot_of[t] : (int32_t)t;
+            if (slot < 0 || (uint32_t)slot >= n_out || !live || bad || d.n_bytes < 12u * natoms) continue;
+            const uint32_t *w = reinterpret_cast<const uint32_t *>(p) + 3u * t;
+            for (int c = 0; c < 3; c++) o[3u * (size_t)slot + c] = __uint_as_float(__builtin_bswap32(w[c]));
+        }
+        if (bad && live) raise_error(err, GORDER_ERR_TRAJECTORY_FORMAT, fr, kStageBox);
+        return;
+    }
+
+    XtcBits b;
+    if (bad) b.open(blob, blob);                // (blob holds at least one frame: >= 32 readable bytes) nothing is used
+    else b.open(p, p + padded + 32ull);
+    int smallidx = d.smallidx;
+    if (smallidx < kXtcFirstIdx || smallidx >= kXtcLastIdx) { bad = true; smallidx = kXtcFirstIdx; }
+    uint32_t sizesmall = l_magic[smallidx];
+    unsigned long long rsmall = l_recip[smallidx];
+    int smallnum = (int)(sizesmall / 2u);
+    int smaller = (int)(l_magic[smallidx > kXtcFirstIdx ? smallidx - 1 : kXtcFirstIdx] / 2u);
+    auto adapt = [&](int is_smaller) {           // the table step after an atom group (xtc_reader.cpp decode_ints)
+        if (is_smaller == 0) return;
+        smallidx += is_smaller;
+        if (smallidx < kXtcFirstIdx || smallidx >= kXtcLastIdx) { bad = true; smallidx = kXtcFirstIdx; }
+        if (is_smaller < 0) {
+            smallnum = smaller;
+            smaller = smallidx > kXtcFirstIdx ? (int)(l_magic[smallidx - 1] / 2u) : 0;
+        } else {
+            smaller = smallnum;
+            smallnum = (int)(l_magic[smallidx] / 2u);
+        }
+        sizesmall = l_magic[smallidx];
+        rsmall = l_recip[smallidx];
+    };
+    int run = 0, pend = 0;
+    uint32_t run_left = 0;          // small atoms of the current run still to come
+    bool first = false;             // the next small atom is the first of its run (it swaps places with its predecessor)
+    int prev[3] = {0, 0, 0};
+    // an atom is final one iteration after it was read (the swap): one iteration past the last analysed atom
+    const uint32_t n_iter = min(natoms, n_stop + 1u);
+    uint32_t flushed = 0;           // atoms written out so far (a multiple of kXtcGroup)
+    for (uint32_t t = 0; t < n_iter; t++) {
+        if (t == flushed + kXtcGroup + 1u) {     // atoms < t - 1 are final
+            flush(flushed);
+            flushed += kXtcGroup;
+        }
+        if (run_left == 0u) {
+            int cur[3];
+            if (d.bitsize == 0u) {
+                cur[0] = (int)(uint32_t)b.take(d.bitsizeint & 0xffu);
+                cur[1] = (int)(uint32_t)b.take((d.bitsizeint >> 8) & 0xffu);
+                cur[2] = (int)(uint32_t)b.take((d.bitsizeint >> 16) & 0xffu);
+            } else {
+                xtc_ints(b, d.bitsize, d.sizeint[1], d.sizeint[2], d.recip1, d.recip2, cur);
+            }
+            cur[0] += d.minint[0]; cur[1] += d.minint[1]; cur[2] += d.minint[2];
+            int is_smaller = 0;
+            if (b.take(1)) {
+                run = (int)b.take(5);
+                is_smaller = run % 3;
+                run -= is_smaller;
+                is_smaller--;
+            }
+            prev[0] = cur[0]; prev[1] = cur[1]; prev[2] = cur[2];
+            if (run > 0) {
+                run_left = (uint32_t)run / 3u;
+                first = true;
+                pend = is_smaller;
+                if (t + 1u + run_left > natoms) { bad = true; run_left = 0; }
+            } else {
+                put(cur, t);
+                adapt(is_smaller);
+            }
+        } else {
+            int dd[3], cur[3];
+            xtc_ints(b, (uint32_t)smallidx, sizesmall, sizesmall, rsmall, rsmall, dd);
+            cur[0] = dd[0] + prev[0] - smallnum;
+            cur[1] = dd[1] + prev[1] - smallnum;
+            cur[2] = dd[2] + prev[2] - smallnum;
+            if (first) {             // stored AFTER the second atom of the run (water: O after H)
+                put(cur, t - 1u);
+                put(prev, t);
+                first = false;
+            } else {
+                put(cur, t);
+            }
+            prev[0] = cur[0]; prev[1] = cur[1]; prev[2] = cur[2];
+            if (--run_left == 0u) adapt(pend);
+        }
+    }
+    for (; flushed < n_stop; flushed += kXtcGroup) flush(flushed);
+    if (b.taken > 8ull * d.n_bytes) bad = true;          // read into the padding: a truncated block
+    if (bad && live) raise_error(err, GORDER_ERR_TRAJECTORY_FORMAT, fr, kStageBox);
+}
+
+}  // namespace

@@ -10,6 +10,9 @@
 //                    batch k+2 overlap the kernels of batch k.
 // A slot's host buffer is refilled once its copy has completed, its device buffer is overwritten once the kernels
 // that read it have completed (the copy stream waits for that event) — no stream-wide synchronisation anywhere.
+// With gorder_trajectory_t::device_decode the host threads only COPY the compressed blocks (gorder_xtc_pack_window),
+// the slot's own stream carries blob + frame table + boxes to the device and runs k_xtc_decode (one frame per lane)
+// into the slot's coordinate buffer; the handle's stream waits for that kernel instead of for a copy.
 #pragma once
 
 #include <chrono>
@@ -25,14 +28,20 @@ namespace {
 struct TrajSlot {
     float *h_xyz = nullptr, *h_box = nullptr, *h_time = nullptr;   // pinned
     float *d_xyz = nullptr, *d_box = nullptr;
-    hipEvent_t copied = nullptr, computed = nullptr;
+    // device decode: the compressed blocks and their table, pinned and on the device, and the slot's own stream
+    uint8_t *h_blob = nullptr, *d_blob = nullptr;
+    gorder_xtc_frame_t *h_frames = nullptr, *d_frames = nullptr;
+    float *d_box_in = nullptr;      // the boxes land here first: d_box may still be read by the kernels of the slot's last batch
+    uint64_t blob_bytes = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t staged = nullptr, copied = nullptr, computed = nullptr;   // host buffers read; device buffers ready; kernels done
     bool copy_issued = false, compute_issued = false;
     uint32_t n = 0;
     std::vector<uint64_t> fidx;
 };
 
 struct TrajPipe {
-    static constexpr int kSlots = 3;
+    static constexpr int kSlots = 4;     // the host-decode route uses three of them
     TrajSlot slot[kSlots];
     std::mutex mu;
     std::condition_variable cv;
@@ -40,7 +49,7 @@ struct TrajPipe {
     bool reader_done = false, stop = false;
     int reader_status = GORDER_XTC_OK;
     std::string reader_msg;
-    double decode_s = 0.0, reader_stalled_s = 0.0;
+    double decode_s = 0.0, reader_stalled_s = 0.0, setup_s = 0.0;
 };
 
 double seconds_since(std::chrono::steady_clock::time_point t0) {
@@ -52,8 +61,15 @@ void traj_free(gorder_hip_handle *h, TrajPipe &p) {
         if (s.h_xyz) (void)hipHostFree(s.h_xyz);
         if (s.h_box) (void)hipHostFree(s.h_box);
         if (s.h_time) (void)hipHostFree(s.h_time);
+        if (s.h_blob) (void)hipHostFree(s.h_blob);
+        if (s.h_frames) (void)hipHostFree(s.h_frames);
         (void)hipFree(s.d_xyz);
         (void)hipFree(s.d_box);
+        (void)hipFree(s.d_blob);
+        (void)hipFree(s.d_frames);
+        (void)hipFree(s.d_box_in);
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+        if (s.staged) (void)hipEventDestroy(s.staged);
         if (s.copied) (void)hipEventDestroy(s.copied);
         if (s.computed) (void)hipEventDestroy(s.computed);
     }
@@ -69,19 +85,43 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
     const auto t_start = std::chrono::steady_clock::now();
     const uint32_t n_atoms = h->plan.n_atoms;
     uint32_t n_threads = tr->n_threads ? tr->n_threads : std::max(1u, std::thread::hardware_concurrency());
+    // device decode: every file must be XTC (TRR / GRO have nothing to decompress); the atoms per frame of the
+    // first file size the blob
+    bool dev = tr->device_decode != 0;
+    uint32_t n_file_atoms = 0, n_stop = 0;
+    std::vector<int32_t> slot_of;
+    for (uint32_t f = 0; dev && f < tr->n_paths; f++) {
+        gorder_xtc_reader *r = nullptr;
+        if (gorder_xtc_open(tr->paths[f], tr->group, tr->n_group, &r) != GORDER_XTC_OK) { dev = false; break; }   // (the reader thread reports it)
+        if (!gorder_xtc_is_xtc(r)) dev = false;
+        if (f == 0) { n_file_atoms = gorder_xtc_n_atoms_file(r); n_stop = gorder_xtc_n_atoms_needed(r); }
+        else if (gorder_xtc_n_atoms_file(r) != n_file_atoms) dev = false;
+        gorder_xtc_close(r);
+    }
+    if (dev && tr->group && tr->n_group) {
+        slot_of.assign(n_file_atoms, -1);
+        for (uint32_t k = 0; k < tr->n_group; k++) slot_of[tr->group[k]] = (int32_t)k;     // (gorder_xtc_open checked the range)
+    }
     // frames per batch: ~128 MB of coordinates per slot unless the host asks otherwise (>= 16 so that the launches
-    // amortise; a batch is also what one decoder pass spreads over its threads)
+    // amortise; a batch is also what one decoder pass spreads over its threads).  The device decoder works one frame
+    // per lane: its batches are as large as 1 GiB of coordinates allows, up to 16384 frames, and there are four slots
+    // (the decoding of two batches overlaps the packing and the copy of the next ones).
     uint32_t batch = tr->batch_frames;
-    if (batch == 0) batch = (uint32_t)std::min<size_t>(4096, std::max<size_t>(16, ((size_t)128 << 20) / ((size_t)n_atoms * 12u)));
+    if (batch == 0 && !dev) batch = (uint32_t)std::min<size_t>(4096, std::max<size_t>(16, ((size_t)128 << 20) / ((size_t)n_atoms * 12u)));
+    if (batch == 0 && dev) batch = (uint32_t)std::min<size_t>(16384, std::max<size_t>(64, ((size_t)1 << 30) / ((size_t)n_atoms * 12u)));
     const size_t xyz_bytes = (size_t)batch * n_atoms * 3u * sizeof(float), box_bytes = (size_t)batch * 9u * sizeof(float);
-
+    // a compressed atom takes 3-5 bytes at the usual precision, never more than 10: 6 per atom and frame on average,
+    // and room for one worst-case frame
+    const size_t blob_cap = dev ? std::max<size_t>((size_t)batch * n_file_atoms * 6u, (size_t)n_file_atoms * 12u + 4096u) + 4096u : 0;
     TrajPipe pipe;
     hipStream_t copy_stream = nullptr;
+    int32_t *d_slot_of = nullptr;
     unsigned long long *h_err = nullptr;   // pinned mirror of the device error key: lets the loop stop at the first error
     auto cleanup = [&]() {
         traj_free(h, pipe);
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
         if (h_err) (void)hipHostFree(h_err);
+        (void)hipFree(d_slot_of);
     };
 #define TRAJ_TRY(expr)                                                                              \
     do {                                                                                            \
@@ -94,16 +134,58 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
     TRAJ_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
     TRAJ_TRY(hipHostMalloc((void **)&h_err, sizeof(unsigned long long), hipHostMallocDefault));
     *h_err = kErrNone;
-    for (TrajSlot &s : pipe.slot) {
-        TRAJ_TRY(hipHostMalloc((void **)&s.h_xyz, xyz_bytes, hipHostMallocDefault));
-        TRAJ_TRY(hipHostMalloc((void **)&s.h_box, box_bytes, hipHostMallocDefault));
-        TRAJ_TRY(hipHostMalloc((void **)&s.h_time, (size_t)batch * sizeof(float), hipHostMallocDefault));
-        TRAJ_TRY(hipMalloc((void **)&s.d_xyz, xyz_bytes));
-        TRAJ_TRY(hipMalloc((void **)&s.d_box, box_bytes));
-        TRAJ_TRY(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
-        TRAJ_TRY(hipEventCreateWithFlags(&s.computed, hipEventDisableTiming));
+    if (dev && !slot_of.empty()) {
+        TRAJ_TRY(hipMalloc((void **)&d_slot_of, slot_of.size() * sizeof(int32_t)));
+        TRAJ_TRY(hipMemcpy(d_slot_of, slot_of.data(), slot_of.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
-    for (int k = 0; k < TrajPipe::kSlots; k++) pipe.free_q.push_back(k);
+    // Pinning a gigabyte takes tens of milliseconds: only the first slot's share of that stands before the first frame
+    // is read, the other slots are made ready by a thread of their own.
+    auto alloc_slot = [&](TrajSlot &s) -> hipError_t {
+        hipError_t e = hipSuccess;
+        auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
+        if (dev) {
+            ok(hipHostMalloc((void **)&s.h_blob, blob_cap, hipHostMallocDefault));
+            ok(hipHostMalloc((void **)&s.h_frames, (size_t)batch * sizeof(gorder_xtc_frame_t), hipHostMallocDefault));
+            ok(hipMalloc((void **)&s.d_blob, blob_cap));
+            ok(hipMalloc((void **)&s.d_frames, (size_t)batch * sizeof(gorder_xtc_frame_t)));
+            ok(hipMalloc((void **)&s.d_box_in, box_bytes));
+            ok(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        } else {
+            ok(hipHostMalloc((void **)&s.h_xyz, xyz_bytes, hipHostMallocDefault));
+        }
+        ok(hipHostMalloc((void **)&s.h_box, box_bytes, hipHostMallocDefault));
+        ok(hipHostMalloc((void **)&s.h_time, (size_t)batch * sizeof(float), hipHostMallocDefault));
+        ok(hipMalloc((void **)&s.d_xyz, xyz_bytes));
+        ok(hipMalloc((void **)&s.d_box, box_bytes));
+        ok(hipEventCreateWithFlags(&s.staged, hipEventDisableTiming));
+        ok(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
+        ok(hipEventCreateWithFlags(&s.computed, hipEventDisableTiming));
+        return e;
+    };
+    const int n_slots = dev ? TrajPipe::kSlots : 3;
+    // slot 0 here, the others by a thread of their own while the reader already fills slot 0
+    {
+        const hipError_t e0 = alloc_slot(pipe.slot[0]);
+        if (e0 != hipSuccess) TRAJ_TRY(e0);
+    }
+    pipe.free_q.push_back(0);
+    std::thread allocator([&, n_slots]() {
+        (void)hipSetDevice(h->device);
+        for (int k = 1; k < n_slots; k++) {
+            {
+                std::lock_guard<std::mutex> lk(pipe.mu);
+                if (pipe.stop) return;
+            }
+            const auto t0 = std::chrono::steady_clock::now();
+            const hipError_t e = alloc_slot(pipe.slot[k]);
+            std::lock_guard<std::mutex> lk(pipe.mu);
+            pipe.setup_s += seconds_since(t0);
+            if (e != hipSuccess) return;          // the run goes on with the slots there are
+            pipe.free_q.push_back(k);
+            pipe.cv.notify_all();
+        }
+    });
+    const double setup_s = seconds_since(t_start);
 
     // ---- reader thread: the sequential part of read_trajectory (time window, step, concatenation) + decoding
     const int device = h->device;
@@ -111,57 +193,88 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
         (void)hipSetDevice(device);
         uint64_t state = 0, analysed = 0;
         double last_time = -INFINITY;
-        for (uint32_t f = 0; f < tr->n_paths; f++) {
-            gorder_xtc_reader *r = nullptr;
-            int st = gorder_xtc_open(tr->paths[f], tr->group, tr->n_group, &r);
-            if (st == GORDER_XTC_OK && gorder_xtc_n_atoms_out(r) != n_atoms) st = GORDER_XTC_ERR_ARGUMENT;
-            if (st != GORDER_XTC_OK) {
-                std::lock_guard<std::mutex> lk(pipe.mu);
-                pipe.reader_status = st;
-                pipe.reader_msg = std::string("cannot read ") + tr->paths[f] +
-                                  (st == GORDER_XTC_ERR_ARGUMENT ? ": atoms per frame differ from the tables" : "");
-                if (r) gorder_xtc_close(r);
-                break;
-            }
-            for (;;) {
-                int k = -1;
-                {
-                    const auto t0 = std::chrono::steady_clock::now();
-                    std::unique_lock<std::mutex> lk(pipe.mu);
-                    pipe.cv.wait(lk, [&] { return pipe.stop || !pipe.free_q.empty(); });
-                    pipe.reader_stalled_s += seconds_since(t0);
-                    if (pipe.stop) break;
-                    k = pipe.free_q.front();
-                    pipe.free_q.pop_front();
-                }
-                TrajSlot &s = pipe.slot[k];
-                if (s.copy_issued) (void)hipEventSynchronize(s.copied);   // the previous batch has left the host buffer
+        uint32_t f = 0;                       // next file to open
+        gorder_xtc_reader *r = nullptr;       // the open one
+        bool done = false;
+        auto give_up = [&](int st, const std::string &msg) {
+            std::lock_guard<std::mutex> lk(pipe.mu);
+            pipe.reader_status = st;
+            pipe.reader_msg = msg;
+            done = true;
+        };
+        while (!done) {
+            int k = -1;
+            {
                 const auto t0 = std::chrono::steady_clock::now();
-                const int64_t got = gorder_xtc_read_window_mt(r, tr->begin_ps, tr->end_ps, tr->step, &state, &last_time,
-                                                              s.h_xyz, s.h_box, s.h_time, batch, n_threads);
-                const double dt = seconds_since(t0);
+                std::unique_lock<std::mutex> lk(pipe.mu);
+                pipe.cv.wait(lk, [&] { return pipe.stop || !pipe.free_q.empty(); });
+                pipe.reader_stalled_s += seconds_since(t0);
+                if (pipe.stop) break;
+                k = pipe.free_q.front();
+                pipe.free_q.pop_front();
+            }
+            TrajSlot &s = pipe.slot[k];
+            const auto t_wait = std::chrono::steady_clock::now();
+            if (s.copy_issued) (void)hipEventSynchronize(s.staged);   // the previous batch has left the host buffers
+            const auto t1 = std::chrono::steady_clock::now();
+            {
                 std::lock_guard<std::mutex> lk(pipe.mu);
-                pipe.decode_s += dt;
-                if (got <= 0) {
-                    pipe.free_q.push_front(k);
-                    if (got < 0) {
-                        pipe.reader_status = (int)got;
-                        pipe.reader_msg = std::string("read error in ") + tr->paths[f];
+                pipe.reader_stalled_s += std::chrono::duration<double>(t1 - t_wait).count();
+            }
+            // a batch is filled across file boundaries: a trajectory split into many short files still makes full batches
+            s.n = 0;
+            s.blob_bytes = 0;
+            while (!done && s.n < batch) {
+                if (!r) {
+                    if (f == tr->n_paths) { done = true; break; }
+                    int st = gorder_xtc_open(tr->paths[f], tr->group, tr->n_group, &r);
+                    if (st == GORDER_XTC_OK && gorder_xtc_n_atoms_out(r) != n_atoms) st = GORDER_XTC_ERR_ARGUMENT;
+                    if (st != GORDER_XTC_OK) {
+                        give_up(st, std::string("cannot read ") + tr->paths[f] +
+                                        (st == GORDER_XTC_ERR_ARGUMENT ? ": atoms per frame differ from the tables" : ""));
+                        break;
                     }
+                }
+                uint64_t used = 0;
+                const int64_t got =
+                    dev ? gorder_xtc_pack_window(r, tr->begin_ps, tr->end_ps, tr->step, &state, &last_time,
+                                                 s.h_blob + s.blob_bytes, blob_cap - s.blob_bytes, &used, s.h_frames + s.n,
+                                                 s.h_box + 9u * (size_t)s.n, s.h_time + s.n, batch - s.n, n_threads)
+                        : gorder_xtc_read_window_mt(r, tr->begin_ps, tr->end_ps, tr->step, &state, &last_time,
+                                                    s.h_xyz + (size_t)s.n * n_atoms * 3u, s.h_box + 9u * (size_t)s.n,
+                                                    s.h_time + s.n, batch - s.n, n_threads);
+                if (dev && got == GORDER_XTC_ERR_ARGUMENT && s.n > 0) break;      // the blob is full: this batch is complete
+                if (got < 0) {
+                    give_up((int)got, std::string("read error in ") + tr->paths[f]);
                     break;
                 }
-                s.n = (uint32_t)got;
-                s.fidx.resize((size_t)got);
-                // SystemTopology::frame of the k-th analysed frame = k * step (topology/mod.rs:141-144)
-                for (int64_t q = 0; q < got; q++) s.fidx[(size_t)q] = tr->first_frame_index + (analysed + (uint64_t)q) * tr->step;
-                analysed += (uint64_t)got;
-                pipe.filled_q.push_back(k);
-                pipe.cv.notify_all();
+                if (got == 0) {                                                   // end of this file
+                    gorder_xtc_close(r);
+                    r = nullptr;
+                    f++;
+                    continue;
+                }
+                if (dev) {
+                    for (int64_t q = 0; q < got; q++) s.h_frames[s.n + (size_t)q].offset += s.blob_bytes;
+                    s.blob_bytes += used;
+                }
+                s.n += (uint32_t)got;
             }
-            gorder_xtc_close(r);
+            const double dt = seconds_since(t1);
             std::lock_guard<std::mutex> lk(pipe.mu);
-            if (pipe.stop || pipe.reader_status != GORDER_XTC_OK) break;
+            pipe.decode_s += dt;
+            if (s.n == 0 || pipe.reader_status != GORDER_XTC_OK) {
+                pipe.free_q.push_front(k);
+                break;
+            }
+            s.fidx.resize((size_t)s.n);
+            // SystemTopology::frame of the k-th analysed frame = k * step (topology/mod.rs:141-144)
+            for (uint32_t q = 0; q < s.n; q++) s.fidx[q] = tr->first_frame_index + (analysed + q) * tr->step;
+            analysed += s.n;
+            pipe.filled_q.push_back(k);
+            pipe.cv.notify_all();
         }
+        if (r) gorder_xtc_close(r);
         std::lock_guard<std::mutex> lk(pipe.mu);
         pipe.reader_done = true;
         pipe.cv.notify_all();
@@ -186,10 +299,30 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
         TrajSlot &s = pipe.slot[k];
         const size_t nx = (size_t)s.n * n_atoms * 3u * sizeof(float), nb = (size_t)s.n * 9u * sizeof(float);
         hipError_t e = hipSuccess;
-        if (s.compute_issued) e = hipStreamWaitEvent(copy_stream, s.computed, 0);   // kernels of the slot's last batch
-        if (e == hipSuccess) e = hipMemcpyAsync(s.d_xyz, s.h_xyz, nx, hipMemcpyHostToDevice, copy_stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(s.d_box, s.h_box, nb, hipMemcpyHostToDevice, copy_stream);
-        if (e == hipSuccess) e = hipEventRecord(s.copied, copy_stream);
+        const hipStream_t feed = dev ? s.stream : copy_stream;
+        // the slot's coordinate buffer is free once the kernels of its last batch are done; the compressed blocks go
+        // to a buffer of their own and need not wait for that
+        if (s.compute_issued && !dev) e = hipStreamWaitEvent(feed, s.computed, 0);
+        size_t moved = nb;
+        if (dev) {
+            const size_t nf = (size_t)s.n * sizeof(gorder_xtc_frame_t);
+            moved += (size_t)s.blob_bytes + nf;
+            if (e == hipSuccess) e = hipMemcpyAsync(s.d_blob, s.h_blob, (size_t)s.blob_bytes, hipMemcpyHostToDevice, feed);
+            if (e == hipSuccess) e = hipMemcpyAsync(s.d_frames, s.h_frames, nf, hipMemcpyHostToDevice, feed);
+            if (e == hipSuccess) e = hipMemcpyAsync(s.d_box_in, s.h_box, nb, hipMemcpyHostToDevice, feed);
+            if (e == hipSuccess) e = hipEventRecord(s.staged, feed);
+            if (e == hipSuccess && s.compute_issued) e = hipStreamWaitEvent(feed, s.computed, 0);
+            if (e == hipSuccess) e = hipMemcpyAsync(s.d_box, s.d_box_in, nb, hipMemcpyDeviceToDevice, feed);
+            if (e == hipSuccess && status == GORDER_OK)
+                status = xtc_decode_on(h, feed, s.d_blob, s.blob_bytes, s.d_frames, s.n, n_file_atoms, d_slot_of, n_stop,
+                                       s.d_xyz, n_atoms);
+        } else {
+            moved += nx;
+            if (e == hipSuccess) e = hipMemcpyAsync(s.d_xyz, s.h_xyz, nx, hipMemcpyHostToDevice, feed);
+            if (e == hipSuccess) e = hipMemcpyAsync(s.d_box, s.h_box, nb, hipMemcpyHostToDevice, feed);
+            if (e == hipSuccess) e = hipEventRecord(s.staged, feed);
+        }
+        if (e == hipSuccess) e = hipEventRecord(s.copied, feed);
         if (e == hipSuccess) { s.copy_issued = true; e = hipStreamWaitEvent(h->stream, s.copied, 0); }
         if (e != hipSuccess) { status = GORDER_ERR_DEVICE; hip_msg = std::string("trajectory copy: ") + hipGetErrorString(e); }
         if (status == GORDER_OK)
@@ -201,7 +334,7 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
             s.compute_issued = true;
             frames += s.n;
             batches++;
-            bytes += nx + nb;
+            bytes += moved;
         }
         const bool device_error = *reinterpret_cast<volatile unsigned long long *>(h_err) != kErrNone;
         {
@@ -218,7 +351,10 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
         pipe.cv.notify_all();
     }
     reader.join();
+    allocator.join();
     (void)hipStreamSynchronize(copy_stream);
+    for (TrajSlot &s : pipe.slot)
+        if (s.stream) (void)hipStreamSynchronize(s.stream);
     const int sync_status = gorder_hip_synchronize(h);      // surfaces device errors
     if (status == GORDER_OK) status = sync_status;
     else if (!hip_msg.empty()) h->err_msg = hip_msg;
@@ -236,6 +372,9 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
         stats->seconds_gpu_starved = starved_s;
         stats->batch_frames = batch;
         stats->decoder_threads = n_threads;
+        stats->device_decode = dev ? 1u : 0u;
+        stats->reserved = 0;
+        stats->seconds_setup = setup_s + pipe.setup_s;
     }
     cleanup();
 #undef TRAJ_TRY

@@ -17,6 +17,7 @@
 #include <string>
 #include <string>
 #include <thread>
+#include <unistd.h>
 #include <vector>
 
 #include "../../include/gorder_xtc.h"
@@ -866,6 +867,131 @@ int64_t gorder_xtc_read_window_mt(gorder_xtc_reader *r, float begin_ps, float en
     for (auto &th : pool) th.join();
     for (int st : status)
         if (st != GORDER_XTC_OK) return st == GORDER_XTC_EOF ? GORDER_XTC_ERR_FORMAT : st;
+    return (int64_t)n;
+}
+
+}  // extern "C"
+
+// ---- packing for the device decoder ------------------------------------------------------------------
+extern "C" {
+
+int gorder_xtc_is_xtc(const gorder_xtc_reader *r) { return (r && !r->trr && !r->gro) ? 1 : 0; }
+uint32_t gorder_xtc_n_atoms_needed(const gorder_xtc_reader *r) {
+    return r ? (r->n_needed ? std::min(r->n_needed, r->natoms) : r->natoms) : 0;
+}
+
+int64_t gorder_xtc_pack_window(gorder_xtc_reader *r, float begin_ps, float end_ps, uint32_t step, uint64_t *state,
+                               double *last_time, uint8_t *blob, uint64_t blob_capacity, uint64_t *blob_bytes,
+                               gorder_xtc_frame_t *frames, float *box9, float *time_ps, uint64_t capacity,
+                               uint32_t n_threads) {
+    if (!r || !r->fp || r->trr || r->gro || !state || !last_time || !blob || !blob_bytes || !frames || !box9 || step == 0)
+        return GORDER_XTC_ERR_ARGUMENT;
+    *blob_bytes = 0;
+    // pass 1 (sequential): the headers — which frames, where their blocks lie, what the decoder needs to know.
+    // One pread of 92 bytes per frame, the position kept here (the FILE is moved once, at the end).
+    struct Src { off_t pos; uint32_t n; };
+    std::vector<Src> src;
+    uint64_t used = 0;
+    const uint32_t natoms = r->natoms;
+    const int fd = fileno(r->fp);
+    off_t pos = (off_t)ftell(r->fp);
+    bool to_end = false;
+    while (src.size() < capacity) {
+        const off_t pos0 = pos;
+        uint8_t head[56 + 36];
+        const ssize_t got = pread(fd, head, sizeof(head), pos0);
+        if (got == 0) break;
+        if (got < 56 || be32(head) != 1995u || be32(head + 4) != natoms || be32(head + 52) != natoms)
+            return GORDER_XTC_ERR_FORMAT;
+        const float t = bef(head + 12);
+        gorder_xtc_frame_t fr{};
+        uint32_t block = 0;       // bytes of the coordinate block in the file
+        off_t pos_block;
+        if (natoms <= 9) {
+            fr.kind = 1;
+            fr.n_bytes = block = natoms * 12u;
+            pos_block = pos0 + 56;
+        } else {
+            if (got != (ssize_t)sizeof(head)) return GORDER_XTC_ERR_FORMAT;
+            const uint8_t *h2 = head + 56;
+            for (int k = 0; k < 3; k++) {
+                const int minint = (int32_t)be32(h2 + 4 + 4 * k), maxint = (int32_t)be32(h2 + 16 + 4 * k);
+                const int64_t sz = (int64_t)maxint - (int64_t)minint + 1;
+                if (sz <= 0 || sz > 0xffffffffll) return GORDER_XTC_ERR_FORMAT;
+                fr.minint[k] = minint;
+                fr.sizeint[k] = (uint32_t)sz;
+            }
+            if ((fr.sizeint[0] | fr.sizeint[1] | fr.sizeint[2]) > 0xffffff) {
+                fr.bitsize = 0;
+                for (int k = 0; k < 3; k++) fr.bitsizeint |= (uint32_t)size_of_int(fr.sizeint[k]) << (8 * k);
+            } else {
+                fr.bitsize = (uint32_t)size_of_ints(fr.sizeint);
+            }
+            fr.recip1 = reciprocal_of(fr.sizeint[1]);
+            fr.recip2 = reciprocal_of(fr.sizeint[2]);
+            fr.smallidx = (int32_t)be32(h2 + 28);
+            if (fr.smallidx < kFirstIdx || fr.smallidx >= kLastIdx) return GORDER_XTC_ERR_FORMAT;
+            fr.inv_precision = 1.0f / bef(h2);
+            block = (uint32_t)(((size_t)be32(h2 + 32) + 3) & ~(size_t)3);
+            fr.n_bytes = block;
+            pos_block = pos0 + (off_t)sizeof(head);
+        }
+        pos = pos_block + (off_t)block;
+        // selection: as in gorder_xtc_read_window
+        if ((double)t == *last_time) continue;             // duplicate frame at a file boundary
+        const double time_before = *last_time;
+        *last_time = (double)t;
+        if (t < begin_ps) continue;
+        if (end_ps >= 0.0f && t > end_ps) { to_end = true; break; }
+        const uint64_t k = (*state)++;
+        if (k % step != 0) continue;
+        const uint64_t need = (((uint64_t)block + 7u) & ~7ull) + 32u;
+        if (used + need > blob_capacity) {                 // does not fit any more: this frame opens the next window
+            if (src.empty()) return GORDER_XTC_ERR_ARGUMENT;
+            (*state)--;
+            *last_time = time_before;
+            pos = pos0;
+            break;
+        }
+        const size_t i = src.size();
+        fr.offset = used;
+        used += need;
+        frames[i] = fr;
+        for (int q = 0; q < 9; q++) box9[9 * i + q] = bef(head + 16 + 4 * q);
+        if (time_ps) time_ps[i] = t;
+        src.push_back({pos_block, block});
+    }
+    if (to_end ? fseek(r->fp, 0, SEEK_END) != 0 : fseeko(r->fp, pos, SEEK_SET) != 0) return GORDER_XTC_ERR_FORMAT;
+    // pass 2: the blocks, by n_threads readers at once (pread does not move the file position)
+    const size_t n = src.size();
+    if (n == 0) return 0;
+    const uint32_t nt = (uint32_t)std::min<size_t>(std::max(1u, n_threads), n);
+    std::vector<int> status(nt, GORDER_XTC_OK);
+    auto work = [&](uint32_t w) {
+        // contiguous shares: every thread streams one piece of the file
+        const size_t i0 = n * w / nt, i1 = n * (w + 1) / nt;
+        for (size_t i = i0; i < i1; i++) {
+            uint8_t *dst = blob + frames[i].offset;
+            size_t done = 0;
+            while (done < src[i].n) {
+                const ssize_t g = pread(fd, dst + done, src[i].n - done, src[i].pos + (off_t)done);
+                if (g <= 0) { status[w] = GORDER_XTC_ERR_FORMAT; return; }
+                done += (size_t)g;
+            }
+            const size_t end = (size_t)((((uint64_t)src[i].n + 7u) & ~7ull) + 32u);
+            memset(dst + src[i].n, 0, end - src[i].n);
+        }
+    };
+    if (nt == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (uint32_t w = 0; w < nt; w++) pool.emplace_back(work, w);
+        for (auto &th : pool) th.join();
+    }
+    for (int st : status)
+        if (st != GORDER_XTC_OK) return st;
+    *blob_bytes = used;
     return (int64_t)n;
 }
 

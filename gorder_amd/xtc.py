@@ -30,6 +30,13 @@ def _lib():
         lib.gorder_xtc_read_window_mt.argtypes = [vp, C.c_float, C.c_float, C.c_uint32, C.POINTER(C.c_uint64),
                                                   C.POINTER(C.c_double), vp, vp, vp, C.c_uint64, C.c_uint32]
         lib.gorder_xtc_read_window_mt.restype = C.c_int64
+        lib.gorder_xtc_pack_window.argtypes = [vp, C.c_float, C.c_float, C.c_uint32, C.POINTER(C.c_uint64),
+                                               C.POINTER(C.c_double), vp, C.c_uint64, C.POINTER(C.c_uint64), vp, vp, vp,
+                                               C.c_uint64, C.c_uint32]
+        lib.gorder_xtc_pack_window.restype = C.c_int64
+        lib.gorder_xtc_is_xtc.argtypes = [vp]
+        lib.gorder_xtc_n_atoms_needed.argtypes = [vp]
+        lib.gorder_xtc_n_atoms_needed.restype = C.c_uint32
         lib.gorder_xtc_writer_open.argtypes = [C.c_char_p, C.c_uint32, C.c_float, C.POINTER(vp)]
         lib.gorder_xtc_writer_add.argtypes = [vp, vp, vp, C.c_int64, C.c_float]
         lib.gorder_xtc_writer_close.argtypes = [vp]
@@ -106,3 +113,50 @@ def read_trajectory(paths: Sequence[str], group: Optional[np.ndarray] = None, be
     else:
         out = (np.concatenate(xs), np.concatenate(bs), np.concatenate(ts))
     return out + (prec,) if return_precision else out
+
+
+def pack_trajectory(paths: Sequence[str], group: Optional[np.ndarray] = None, begin: float = 0.0, end: float = -1.0,
+                    step: int = 1, chunk: int = 64, blob_capacity: int = 0, threads: int = 1):
+    """The frames `read_trajectory` would return, still compressed: windows of at most `chunk` frames as
+    gorder_xtc_pack_window packs them for the device decoder (gorder_hip_xtc_decode).
+    -> list of dicts {blob: uint8 [bytes], frames: structured array of CXtcFrame, box [n, 3, 3], time [n],
+                      n_atoms_file, n_stop, slot_of (int32 [n_atoms_file] or None)}."""
+    from .abi import CXtcFrame
+    lib = _lib()
+    grp = None if group is None else np.ascontiguousarray(group, dtype=np.uint32)
+    state, last = C.c_uint64(0), C.c_double(float("-inf"))
+    out = []
+    for path in paths:
+        r = C.c_void_p()
+        st = lib.gorder_xtc_open(path.encode(), None if grp is None else grp.ctypes.data, 0 if grp is None else grp.size,
+                                 C.byref(r))
+        if st != 0:
+            raise IOError(f"cannot open {path}: status {st}")
+        try:
+            if not lib.gorder_xtc_is_xtc(r):
+                raise IOError(f"{path}: not an XTC file")
+            n_file, n_stop = lib.gorder_xtc_n_atoms_file(r), lib.gorder_xtc_n_atoms_needed(r)
+            slot_of = None
+            if grp is not None:
+                slot_of = np.full(n_file, -1, dtype=np.int32)
+                slot_of[grp] = np.arange(grp.size, dtype=np.int32)
+            cap = blob_capacity or (chunk * (n_file * 12 + 128) + 4096)
+            while True:
+                blob = np.empty(cap, dtype=np.uint8)
+                frames = (CXtcFrame * chunk)()
+                b = np.empty((chunk, 3, 3), dtype=np.float32)
+                t = np.empty(chunk, dtype=np.float32)
+                used = C.c_uint64(0)
+                got = lib.gorder_xtc_pack_window(r, begin, end, step, C.byref(state), C.byref(last), blob.ctypes.data, cap,
+                                                 C.byref(used), C.cast(frames, C.c_void_p), b.ctypes.data, t.ctypes.data,
+                                                 chunk, threads)
+                if got < 0:
+                    raise IOError(f"{path}: XTC pack error {got}")
+                if got == 0:
+                    break
+                fr = np.frombuffer(frames, dtype=np.dtype(CXtcFrame))[:got].copy()
+                out.append({"blob": blob[:used.value].copy(), "frames": fr, "box": b[:got].copy(), "time": t[:got].copy(),
+                            "n_atoms_file": n_file, "n_stop": n_stop, "slot_of": slot_of})
+        finally:
+            lib.gorder_xtc_close(r)
+    return out

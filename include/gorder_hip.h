@@ -34,6 +34,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "gorder_xtc.h"   /* gorder_xtc_frame_t for gorder_hip_xtc_decode */
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -59,8 +61,10 @@ typedef enum {
                                          terminate in 8 iterations (the reference would spin) */
     GORDER_ERR_LEAFLETS_NOT_PRIMED = 104, /* first submitted frame is not an assignment frame and no
                                              earlier assignment is known: call gorder_hip_prime_leaflets */
-    GORDER_ERR_OVERFLOW = 105         /* a batch was refused because frames x molecules would reach 2^63 / 1e6: an i64
+    GORDER_ERR_OVERFLOW = 105,        /* a batch was refused because frames x molecules would reach 2^63 / 1e6: an i64
                                          order sum could then overflow (the reference panics, order.rs:44-60) */
+    GORDER_ERR_TRAJECTORY_FORMAT = 106 /* gorder_hip_xtc_decode met a corrupt or truncated XTC frame (the reference:
+                                         a read error of the trajectory iterator, common.rs:248) */
 } gorder_status_t;
 
 /* ---- leaflets -------------------------------------------------------------------------------- */
@@ -236,8 +240,14 @@ typedef struct {
     float begin_ps, end_ps;      /* inclusive window on the frame time; end_ps < 0 = to the end */
     uint32_t step;               /* analyse every step-th frame of the window (>= 1) */
     uint32_t n_threads;          /* decoder threads; 0 = all hardware threads */
-    uint32_t batch_frames;       /* frames per device batch; 0 = about 128 MB of coordinates */
+    uint32_t batch_frames;       /* frames per device batch; 0 = about 128 MB of coordinates (1 GiB with device_decode) */
     uint64_t first_frame_index;  /* 0 for a whole trajectory; a rank that reads a later window passes where it starts */
+    uint32_t device_decode;      /* 1: XTC files are decompressed ON THE DEVICE — the host threads only copy the compressed
+                                    blocks into pinned memory (gorder_xtc_pack_window), the copy engine moves those
+                                    (about a third of the decoded bytes) and gorder_hip_xtc_decode unpacks one frame
+                                    per lane.  Same coordinates bit for bit.  A run with a TRR or GRO file in it
+                                    falls back to the host decoder for the whole run.  0: host decoder threads */
+    uint32_t reserved;
 } gorder_trajectory_t;
 
 typedef struct {
@@ -249,10 +259,24 @@ typedef struct {
     double seconds_reader_stalled;   /* the reader waited for a free staging slot: copies / kernels are the bottleneck */
     double seconds_gpu_starved;      /* the submitter waited for a decoded batch: the decoder is the bottleneck */
     uint32_t batch_frames, decoder_threads;   /* what was used */
+    uint32_t device_decode, reserved;         /* 1: the frames were decompressed on the device */
+    double seconds_setup;            /* time spent allocating the pinned and device staging buffers (all but the first slot's
+                                        share overlaps with reading) */
 } gorder_trajectory_stats_t;
 
 int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_trajectory_t *trajectory,
                               gorder_trajectory_stats_t *stats /* may be NULL */);
+
+/* Decompress XTC frames on the device (the decoding half of groan_rs' GroupXtcReader, common.rs:283-304):
+ * `d_blob` / `d_frames` are device copies of what gorder_xtc_pack_window produced (blob_bytes >= 32), `d_slot_of`
+ * [n_atoms_file] maps a file atom to its place in the output frame or -1 (NULL: every atom, in order), `n_stop` is
+ * the number of atoms to go through (gorder_xtc_n_atoms_needed), `d_xyz` [n_frames][n_atoms_out][3] receives exactly
+ * what gorder_xtc_next would have written, bit for bit.  Asynchronous on the handle's stream; a corrupt frame is
+ * reported as GORDER_ERR_TRAJECTORY_FORMAT by the next synchronising call.  One lane decodes one frame (a frame's bit
+ * stream is sequential), so throughput grows with n_frames up to ~64 k frames per call. */
+int gorder_hip_xtc_decode(gorder_hip_handle *h, const uint8_t *d_blob, uint64_t blob_bytes,
+                          const gorder_xtc_frame_t *d_frames, uint32_t n_frames, uint32_t n_atoms_file,
+                          const int32_t *d_slot_of, uint32_t n_stop, float *d_xyz, uint32_t n_atoms_out);
 
 /* Compute (only) the leaflet assignment of ONE frame that precedes a rank's frame range
  * (replaces the cross-thread spin-wait of leaflets.rs:1529-1565). */

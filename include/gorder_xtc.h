@@ -68,6 +68,38 @@ int64_t gorder_xtc_read_window_mt(gorder_xtc_reader *r, float begin_ps, float en
                                   uint64_t *state, double *last_time, float *xyz, float *box9, float *time_ps,
                                   uint64_t capacity, uint32_t n_threads);
 
+/* ---- frames for the device-side decoder (gorder_hip_xtc_decode, include/gorder_hip.h) -----------------------------
+ * Decoding the bit stream is the dominant cost of reading a trajectory ("optional GPU bit-unpack
+ * later").  Instead of decoding, gorder_xtc_pack_window copies the still-compressed coordinate blocks of the selected
+ * frames into one caller buffer (`blob`, meant to be pinned host memory) and describes each with a gorder_xtc_frame_t;
+ * the device decodes one frame per lane.  Frame selection (time window, step, duplicate boundary frame), `state`,
+ * `last_time`, box and time outputs are exactly those of gorder_xtc_read_window.  XTC only (not TRR / GRO). */
+typedef struct {
+    uint64_t offset;         /* of the frame's bit stream in the blob: a multiple of 8, followed by >= 32 zero bytes */
+    uint64_t recip1, recip2; /* floor(2^64 / sizeint[1]), floor(2^64 / sizeint[2]) (all ones for a size of 1) */
+    uint32_t n_bytes;        /* length of the bit stream, padded to a multiple of 4 as in the file */
+    uint32_t kind;           /* 0: compressed; 1: raw big-endian floats (files of <= 9 atoms) */
+    int32_t minint[3];
+    uint32_t sizeint[3];     /* maxint - minint + 1 */
+    int32_t smallidx;
+    float inv_precision;     /* 1 / precision, in f32 like gorder_xtc_next */
+    uint32_t bitsize;        /* width of a full atom as ONE mixed-radix number; 0: three fields of bitsizeint bits */
+    uint32_t bitsizeint;     /* the three field widths, 8 bits each (x lowest) */
+} gorder_xtc_frame_t;
+
+/* Returns the number of frames packed (0 at the end of the file), fewer than `capacity` also when the next frame
+ * would not fit `blob_capacity` (a later call continues with that frame), or a negative gorder_xtc_status_t
+ * (GORDER_XTC_ERR_ARGUMENT also when ONE frame alone does not fit the blob, or for a TRR / GRO reader).
+ * `*blob_bytes` receives the bytes of the blob in use.  The blocks are read by `n_threads` threads (pread). */
+int64_t gorder_xtc_pack_window(gorder_xtc_reader *r, float begin_ps, float end_ps, uint32_t step, uint64_t *state,
+                               double *last_time, uint8_t *blob, uint64_t blob_capacity, uint64_t *blob_bytes,
+                               gorder_xtc_frame_t *frames, float *box9, float *time_ps, uint64_t capacity,
+                               uint32_t n_threads);
+/* 1 when the reader's file is an XTC file (what gorder_xtc_pack_window accepts), else 0 */
+int gorder_xtc_is_xtc(const gorder_xtc_reader *r);
+/* atoms of a frame the decoder has to go through: up to the last atom of the group (all atoms without a group) */
+uint32_t gorder_xtc_n_atoms_needed(const gorder_xtc_reader *r);
+
 /* ---- writer (tooling) --------------------------------------------------------------------------------
  * The compression side of the same format, so that tests and the end-to-end benchmark can produce multi-frame
  * XTC input for the reader -> GPU pipeline (the reference itself never writes trajectories).  Frames of up to

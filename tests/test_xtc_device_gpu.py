@@ -1,0 +1,184 @@
+"""k_xtc_decode (XTC frames decompressed on the device, one frame per lane) against the host decoder
+gorder_xtc_next, bit for bit — reference files, files of the repo's encoder at several precisions and box sizes
+(every field-width path of the format), groups with early stop, corrupt blocks — and the trajectory driver with
+device_decode against the host-decode route."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gorder_amd import HipEngine, abi, xtc
+from golden_util import GOLDEN, METHODS, Fixture, cg_setup
+
+pytestmark = pytest.mark.gpu
+CG3 = os.path.join(GOLDEN, "cg3.xtc")
+
+
+@pytest.fixture(scope="module")
+def cg(built):
+    return Fixture("cg")
+
+
+@pytest.fixture(scope="module")
+def engine(built):
+    mt = abi.MolType(n_molecules=1, bonds=np.array([[[0, 1]]], dtype=np.uint32))
+    return HipEngine(abi.Tables(n_atoms=2, molecule_types=[mt]))
+
+
+def device_decode(engine, paths, group=None, chunk=64, **kw):
+    """-> xyz [F, n_out, 3] decoded by the device from packed windows"""
+    out = []
+    for w in xtc.pack_trajectory(paths, group=group, chunk=chunk, threads=2, **kw):
+        n = len(w["time"])
+        n_out = w["n_atoms_file"] if group is None else len(group)
+        blob = torch.from_numpy(w["blob"]).cuda()
+        frames = torch.from_numpy(w["frames"].view(np.uint8).reshape(-1).copy()).cuda()
+        slot = None if w["slot_of"] is None else torch.from_numpy(w["slot_of"]).cuda()
+        xyz = torch.full((n, n_out, 3), float("nan"), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        engine.xtc_decode(blob.data_ptr(), blob.numel(), frames.data_ptr(), n, w["n_atoms_file"],
+                          0 if slot is None else slot.data_ptr(), w["n_stop"], xyz.data_ptr(), n_out)
+        engine.synchronize()
+        out.append(xyz.cpu().numpy())
+    return np.concatenate(out) if out else np.zeros((0, 0, 3), np.float32)
+
+
+def same_bits(a, b):
+    assert a.shape == b.shape
+    np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def clustered(rng, n_atoms, n_frames, span, sigma=0.04, jitter=0.02):
+    """triplets of atoms close together (water-like: the encoder's runs of small offsets) + slow motion"""
+    centres = rng.uniform(0.0, span, size=(n_atoms // 3 + 1, 1, 3))
+    x0 = (centres + rng.normal(0.0, sigma, size=(n_atoms // 3 + 1, 3, 3))).reshape(-1, 3)[:n_atoms]
+    return (x0[None] + rng.normal(0.0, jitter, size=(n_frames, n_atoms, 3))).astype(np.float32)
+
+
+def write(tmp_path, name, xyz, span, precision):
+    box = np.tile(np.eye(3, dtype=np.float32) * np.float32(span), (xyz.shape[0], 1, 1))
+    path = str(tmp_path / name)
+    xtc.write_trajectory(path, xyz, box, times=np.arange(xyz.shape[0], dtype=np.float32), precision=precision)
+    return path
+
+
+def test_reference_file(engine):
+    host = xtc.read_trajectory([CG3])[0]
+    same_bits(device_decode(engine, [CG3]), host)
+    group = np.arange(100, 6000, 7, dtype=np.uint32)
+    same_bits(device_decode(engine, [CG3], group=group), xtc.read_trajectory([CG3], group=group)[0])
+
+
+@pytest.mark.parametrize("precision", [10.0, 100.0, 1000.0, 12345.0])
+def test_encoder_files(engine, tmp_path, precision):
+    rng = np.random.default_rng(int(precision))
+    xyz = clustered(rng, 4001, 150, 7.5)                     # 150 frames: three waves, the last one partly idle
+    path = write(tmp_path, "p.xtc", xyz, 7.5, precision)
+    host = xtc.read_trajectory([path], threads=4)[0]
+    same_bits(device_decode(engine, [path], chunk=150), host)
+    same_bits(device_decode(engine, [path], chunk=37, begin=10.0, end=120.0, step=3),
+              xtc.read_trajectory([path], begin=10.0, end=120.0, step=3)[0])
+
+
+def test_every_field_width(engine, tmp_path):
+    """one mixed-radix number of <= 64 bits (the usual case), of 65..72 bits (edges beyond ~2 million grid steps),
+    and three separate fields (an edge beyond 2^24 grid steps); gases (no runs) and dense clusters (long runs);
+    smallidx walking up and down"""
+    rng = np.random.default_rng(77)
+    cases = {
+        "wide": (clustered(rng, 900, 70, 5000.0), 5000.0, 1000.0),            # 5e6 steps per edge: 3 x 22.3 bits = 67
+        "split": (clustered(rng, 900, 70, 20000.0), 20000.0, 1000.0),         # 2e7 steps > 0xffffff
+        "gas": (rng.uniform(0, 30.0, size=(70, 1500, 3)).astype(np.float32), 30.0, 1000.0),
+        "dense": (clustered(rng, 3000, 70, 2.0, sigma=0.003, jitter=0.001), 2.0, 1000.0),
+        "mixed": (np.concatenate([clustered(rng, 600, 70, 8.0, sigma=0.2), clustered(rng, 600, 70, 8.0, sigma=0.002),
+                                  rng.uniform(0, 8.0, size=(70, 300, 3)).astype(np.float32)], axis=1), 8.0, 1000.0),
+        "negative": (clustered(rng, 900, 70, 6.0) - 40.0, 6.0, 500.0),        # minint < 0
+    }
+    for name, (xyz, span, prec) in cases.items():
+        path = write(tmp_path, name + ".xtc", xyz, span, prec)
+        host = xtc.read_trajectory([path])[0]
+        packed = xtc.pack_trajectory([path], chunk=70)[0]["frames"]
+        if name == "wide":
+            assert packed["bitsize"].min() > 64
+        if name == "split":
+            assert packed["bitsize"].max() == 0 and packed["bitsizeint"].min() > 0
+        same_bits(device_decode(engine, [path], chunk=70), host)
+
+
+def test_small_systems_are_raw_floats(engine, tmp_path):
+    rng = np.random.default_rng(5)
+    xyz = rng.normal(0, 3, size=(9, 7, 3)).astype(np.float32)
+    path = write(tmp_path, "tiny.xtc", xyz, 4.0, 1000.0)
+    got = device_decode(engine, [path])
+    same_bits(got, xtc.read_trajectory([path])[0])
+    same_bits(got, xyz)                                       # raw frames are exact
+    group = np.array([6, 1], dtype=np.uint32)
+    same_bits(device_decode(engine, [path], group=group), xyz[:, group])
+
+
+def test_group_order_and_early_stop(engine, tmp_path):
+    rng = np.random.default_rng(11)
+    xyz = clustered(rng, 3000, 80, 6.0)
+    path = write(tmp_path, "g.xtc", xyz, 6.0, 1000.0)
+    for group in (np.array([2999], np.uint32), np.array([0], np.uint32), rng.permutation(3000)[:500].astype(np.uint32),
+                  np.arange(1200, dtype=np.uint32)[::-1].copy()):
+        same_bits(device_decode(engine, [path], group=group, chunk=80), xtc.read_trajectory([path], group=group)[0])
+
+
+def test_corrupt_block_is_reported(built, tmp_path):
+    rng = np.random.default_rng(13)
+    path = write(tmp_path, "c.xtc", clustered(rng, 2000, 5, 6.0), 6.0, 1000.0)
+    w = xtc.pack_trajectory([path])[0]
+    for damage in ("truncated", "smallidx", "offset"):
+        mt = abi.MolType(n_molecules=1, bonds=np.array([[[0, 1]]], dtype=np.uint32))
+        eng = HipEngine(abi.Tables(n_atoms=2, molecule_types=[mt]))
+        fr = w["frames"].copy()
+        if damage == "truncated":
+            fr["n_bytes"][3] = 400                          # the stream ends long before the last atom
+        elif damage == "smallidx":
+            fr["smallidx"][3] = 80
+        else:
+            fr["offset"][3] = w["blob"].size                # outside the blob: nothing may be read
+        blob = torch.from_numpy(w["blob"]).cuda()
+        frames = torch.from_numpy(fr.view(np.uint8).reshape(-1).copy()).cuda()
+        out = torch.zeros((5, 2000, 3), dtype=torch.float32, device="cuda")
+        eng.xtc_decode(blob.data_ptr(), blob.numel(), frames.data_ptr(), 5, 2000, 0, 2000, out.data_ptr(), 2000)
+        with pytest.raises(abi.GorderHipError) as ei:
+            eng.synchronize()
+        assert ei.value.status == 106
+        assert "frame 3" in str(ei.value)
+
+
+@pytest.mark.parametrize("batch_frames,threads", [(0, 4), (16, 2), (1, 1)])
+def test_driver_device_decode_matches_host_decode(cg, tmp_path, batch_frames, threads):
+    """the whole pipeline (pack -> copy -> k_xtc_decode -> analysis) against the host-decode pipeline: 101 CG frames
+    in two files with a duplicate boundary frame, a time window and a step"""
+    tables, labels, midx = cg_setup(cg, leaflets=METHODS["global"])
+    a, b = str(tmp_path / "a.xtc"), str(tmp_path / "b.xtc")
+    xtc.write_trajectory(a, cg.xyz[:60], cg.boxes[:60], times=cg.times[:60], precision=100.0)
+    xtc.write_trajectory(b, cg.xyz[59:], cg.boxes[59:], times=cg.times[59:], precision=100.0)
+    for kw in (dict(), dict(begin=float(cg.times[7]), end=float(cg.times[90]), step=4)):
+        host = HipEngine(tables)
+        s0 = host.run_trajectory([a, b], group=midx, threads=threads, batch_frames=batch_frames, **kw)
+        dev = HipEngine(tables)
+        s1 = dev.run_trajectory([a, b], group=midx, threads=threads, batch_frames=batch_frames, device_decode=True, **kw)
+        assert s0["device_decode"] == 0 and s1["device_decode"] == 1
+        assert s0["n_frames"] == s1["n_frames"] and s1["n_frames"] in (101, 21)
+        assert s1["bytes_h2d"] < s0["bytes_h2d"]
+        r0, r1 = host.finish(), dev.finish()
+        assert r0.n_frames == r1.n_frames
+        np.testing.assert_array_equal(r0.sums, r1.sums)
+        np.testing.assert_array_equal(r0.counts, r1.counts)
+
+
+def test_driver_falls_back_for_other_formats(cg, tmp_path):
+    """device_decode with a reference XTC file whose group is the Master group, and the fallback to the host decoder
+    is silent for non-XTC input (nothing to decompress there)"""
+    tables, labels, midx = cg_setup(cg, leaflets=METHODS["global"])
+    eng = HipEngine(tables)
+    stats = eng.run_trajectory([CG3], group=midx, device_decode=True)
+    assert stats["n_frames"] == 1 and stats["device_decode"] == 1
+    ref = HipEngine(tables)
+    ref.run_trajectory([CG3], group=midx)
+    np.testing.assert_array_equal(eng.finish().sums, ref.finish().sums)

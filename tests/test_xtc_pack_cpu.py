@@ -1,0 +1,97 @@
+"""gorder_xtc_pack_window (host half of the device decoder): the frames it selects, their boxes and times are those of
+gorder_xtc_read_window; the blob is laid out as include/gorder_xtc.h says.  No GPU: the decoding itself is compared in
+tests/test_xtc_device_gpu.py."""
+import os
+
+import numpy as np
+import pytest
+
+from gorder_amd import xtc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CG3 = os.path.join(HERE, "golden", "cg3.xtc")
+
+
+def synthetic(tmp_path, n_atoms=700, n_frames=23, precision=1000.0, span=6.0, seed=3, name="s.xtc"):
+    rng = np.random.default_rng(seed)
+    base = rng.uniform(0.0, span, size=(n_atoms // 3 + 1, 1, 3)) + rng.normal(0.0, 0.05, size=(n_atoms // 3 + 1, 3, 3))
+    x0 = base.reshape(-1, 3)[:n_atoms]
+    xyz = (x0[None] + rng.normal(0.0, 0.02, size=(n_frames, n_atoms, 3))).astype(np.float32)
+    box = np.zeros((n_frames, 3, 3), np.float32)
+    box[:, 0, 0] = box[:, 1, 1] = box[:, 2, 2] = span
+    path = str(tmp_path / name)
+    xtc.write_trajectory(path, xyz, box, times=np.arange(n_frames, dtype=np.float32) * 10.0, precision=precision)
+    return path
+
+
+def check_layout(w):
+    fr = w["frames"]
+    assert np.all(fr["offset"] % 8 == 0)
+    ends = fr["offset"] + ((fr["n_bytes"].astype(np.uint64) + 7) // 8) * 8 + 32
+    assert np.all(ends[:-1] <= fr["offset"][1:]) and ends[-1] <= w["blob"].size
+    for f in fr:      # the padding behind a block is zero
+        pad = w["blob"][int(f["offset"]) + int(f["n_bytes"]):int(f["offset"]) + ((int(f["n_bytes"]) + 7) // 8) * 8 + 32]
+        assert not pad.any()
+    assert np.all(fr["n_bytes"] % 4 == 0)
+
+
+def test_pack_selects_what_read_selects(built, tmp_path):
+    path = synthetic(tmp_path)
+    for kw in (dict(), dict(begin=30.0, end=170.0, step=3), dict(step=5), dict(begin=1e9)):
+        x, b, t = xtc.read_trajectory([path], **kw)
+        ws = xtc.pack_trajectory([path], chunk=7, threads=3, **kw)
+        n = sum(len(w["time"]) for w in ws)
+        assert n == len(t)
+        if n:
+            np.testing.assert_array_equal(np.concatenate([w["time"] for w in ws]), t)
+            np.testing.assert_array_equal(np.concatenate([w["box"] for w in ws]), b)
+            for w in ws:
+                check_layout(w)
+                assert w["n_atoms_file"] == 700 and w["n_stop"] == 700 and w["slot_of"] is None
+
+
+def test_pack_continues_when_the_blob_is_full(built, tmp_path):
+    path = synthetic(tmp_path, n_frames=11)
+    one = xtc.pack_trajectory([path], chunk=64)
+    assert len(one) == 1 and len(one[0]["time"]) == 11
+    per_frame = int(one[0]["frames"]["offset"][1])
+    small = xtc.pack_trajectory([path], chunk=64, blob_capacity=int(one[0]["frames"]["offset"][3]), threads=2)
+    assert len(small[0]["time"]) == 3 and len(small) >= 4 and sum(len(w["time"]) for w in small) == 11
+    np.testing.assert_array_equal(np.concatenate([w["time"] for w in small]), one[0]["time"])
+    # the same bytes, whatever the windowing
+    def blocks(ws):
+        return [bytes(w["blob"][int(f["offset"]):int(f["offset"]) + int(f["n_bytes"])]) for w in ws for f in w["frames"]]
+    assert blocks(small) == blocks(one)
+    with pytest.raises(IOError):      # not even one frame fits
+        xtc.pack_trajectory([path], chunk=64, blob_capacity=per_frame // 2)
+
+
+def test_pack_concatenation_and_group(built, tmp_path):
+    a = synthetic(tmp_path, n_frames=6, name="a.xtc")
+    # the second file starts with the last time of the first (a duplicate boundary frame, CHANGELOG.md:64)
+    rng = np.random.default_rng(9)
+    xyz = rng.uniform(0, 6, size=(4, 700, 3)).astype(np.float32)
+    box = np.tile(np.eye(3, dtype=np.float32) * 6.0, (4, 1, 1))
+    b = str(tmp_path / "b.xtc")
+    xtc.write_trajectory(b, xyz, box, times=np.array([50.0, 60.0, 70.0, 80.0], np.float32))
+    group = np.array([5, 17, 300, 311], dtype=np.uint32)
+    x, bx, t = xtc.read_trajectory([a, b], group=group)
+    ws = xtc.pack_trajectory([a, b], group=group, chunk=4)
+    np.testing.assert_array_equal(np.concatenate([w["time"] for w in ws]), t)
+    assert len(t) == 9
+    w = ws[0]
+    assert w["n_stop"] == 312 and w["slot_of"].shape == (700,)
+    assert list(np.flatnonzero(w["slot_of"] >= 0)) == [5, 17, 300, 311]
+
+
+def test_pack_reference_file(built):
+    """tests/golden/cg3.xtc (the reference's tests/files/split/cg3.xtc): header fields as the format defines them."""
+    ws = xtc.pack_trajectory([CG3])
+    assert len(ws) == 1 and len(ws[0]["time"]) == 1
+    f = ws[0]["frames"][0]
+    assert f["kind"] == 0 and 9 <= f["smallidx"] < 73 and f["bitsize"] > 0
+    assert f["inv_precision"] == np.float32(1.0) / np.float32(1.0 / f["inv_precision"])
+    assert int(f["n_bytes"]) + 92 == os.path.getsize(CG3)      # one frame: header + block
+    for k in (1, 2):
+        s = int(f["sizeint"][k])
+        assert int(f[f"recip{k}"]) == (2 ** 64 // s if s > 1 else 2 ** 64 - 1)
