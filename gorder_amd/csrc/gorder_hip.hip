@@ -302,6 +302,22 @@ int fold_maps(gorder_hip_handle *h) {
     return GORDER_OK;
 }
 
+// the cell list of `ns` slab frames (k_local_build, or bin / scan / scatter for very large atom sets); `counts` are the
+// lo.cell_count and lo.cell_fill words the three-kernel form needs zeroed
+int launch_cell_list(gorder_hip_handle *h, const LocalArgs &lo, uint32_t ns, uint32_t n_list, void *counts, size_t count_bytes) {
+    static const bool three = env_flag("GORDER_HIP_LOCAL_THREE_KERNELS");      // A/B switch
+    if (n_list <= kLocalBuildMax && !three) {
+        hipLaunchKernelGGL(k_local_build, dim3(ns), dim3(1024), kLocalBuildLds, h->stream, lo);
+        return GORDER_OK;
+    }
+    HIP_TRY(h, hipMemsetAsync(counts, 0, count_bytes, h->stream));
+    const dim3 ga((n_list + 255) / 256, ns);
+    hipLaunchKernelGGL(k_local_bin, ga, dim3(256), 0, h->stream, lo);
+    hipLaunchKernelGGL(k_local_scan, dim3(ns), dim3(1024), 0, h->stream, lo);
+    hipLaunchKernelGGL(k_local_scatter, ga, dim3(256), 0, h->stream, lo);
+    return GORDER_OK;
+}
+
 // normals of every molecule for the frames of this batch -> h->d_dyn_normals [n_frames][n_mol_total]
 int run_dynamic_normals(gorder_hip_handle *h, const FrameArgs &a) {
     int st;
@@ -320,11 +336,8 @@ int run_dynamic_normals(gorder_hip_handle *h, const FrameArgs &a) {
         const uint32_t ns = std::min(a.n_frames - done, h->dyn_slab);
         lo.frame0 = done;
         lo.n_slab = ns;
-        HIP_TRY(h, hipMemsetAsync(h->d_dyn_count, 0, (size_t)h->dyn_slab * (2 * ncell + 1) * sizeof(uint32_t), h->stream));
-        const dim3 ga((dn.n_cloud + 255) / 256, ns);
-        hipLaunchKernelGGL(k_local_bin, ga, dim3(256), 0, h->stream, lo);
-        hipLaunchKernelGGL(k_local_scan, dim3(ns), dim3(1024), 0, h->stream, lo);
-        hipLaunchKernelGGL(k_local_scatter, ga, dim3(256), 0, h->stream, lo);
+        if ((st = launch_cell_list(h, lo, ns, dn.n_cloud, h->d_dyn_count,
+                                   (size_t)h->dyn_slab * (2 * ncell + 1) * sizeof(uint32_t))) != GORDER_OK) return st;
         hipLaunchKernelGGL(k_dyn_normals, dim3((n_mol + 3) / 4, ns), dim3(256), 0, h->stream, lo, h->d_dyn_normals);
     }
     HIP_TRY(h, hipGetLastError());
@@ -875,6 +888,8 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
         h->host_dyn_heads = nheads;
         const size_t nm = dn.n_cloud, ncell = (size_t)kLocalMaxCells1D * kLocalMaxCells1D;
         const size_t sl = h->dyn_slab = local_slab_frames(nm);
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_local_build), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)kLocalBuildLds));
         HIP_TRY(h, hipMalloc((void **)&h->d_dyn_cell_of, sl * nm * sizeof(uint32_t)));
         HIP_TRY(h, hipMalloc((void **)&h->d_dyn_rsn, sl * nm * sizeof(float)));
         HIP_TRY(h, hipMalloc((void **)&h->d_dyn_rec, sl * nm * 4 * sizeof(float)));
@@ -929,6 +944,8 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
         if (lf.method == GORDER_LEAFLETS_LOCAL) {
             const size_t nm = lf.n_membrane, ncell = (size_t)kLocalMaxCells1D * kLocalMaxCells1D;
             const size_t sl = h->local_slab = local_slab_frames(nm);
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_local_build),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLocalBuildLds));
             HIP_TRY(h, hipMalloc((void **)&h->d_lcell_of, sl * nm * sizeof(uint32_t)));
             HIP_TRY(h, hipMalloc((void **)&h->d_lcell_atoms, sl * nm * sizeof(float)));   // sin column
             HIP_TRY(h, hipMalloc((void **)&h->d_ltrig, sl * nm * 4 * sizeof(float)));
@@ -1070,12 +1087,10 @@ static int run_leaflets(gorder_hip_handle *h, const float *d_xyz, const float *d
             lo.n_slab = ns;
             lo.row0 = row0 + (uint32_t)done;
             lo.write_dist_frame = (done + ns == aframes.size()) ? (int)ns - 1 : -1;
-            HIP_TRY(h, hipMemsetAsync(h->d_lcell_count, 0, ns * (ncell + 1) * sizeof(uint32_t), h->stream));
-            HIP_TRY(h, hipMemsetAsync(h->d_lcell_fill, 0, ns * ncell * sizeof(uint32_t), h->stream));
-            const dim3 ga((lf.n_membrane + 255) / 256, ns);
-            hipLaunchKernelGGL(k_local_bin, ga, dim3(256), 0, h->stream, lo);
-            hipLaunchKernelGGL(k_local_scan, dim3(ns), dim3(1024), 0, h->stream, lo);
-            hipLaunchKernelGGL(k_local_scatter, ga, dim3(256), 0, h->stream, lo);
+            if (lf.n_membrane > kLocalBuildMax || env_flag("GORDER_HIP_LOCAL_THREE_KERNELS"))
+                HIP_TRY(h, hipMemsetAsync(h->d_lcell_fill, 0, ns * ncell * sizeof(uint32_t), h->stream));
+            const int cst = launch_cell_list(h, lo, ns, lf.n_membrane, h->d_lcell_count, ns * (ncell + 1) * sizeof(uint32_t));
+            if (cst != GORDER_OK) return cst;
             if (lo.agg)
                 hipLaunchKernelGGL(k_local_cellsums, dim3(64, ns), dim3(256), 0, h->stream, lo);
             if (lo.agg && lo.pbc) {

@@ -464,13 +464,13 @@ __global__ __launch_bounds__(256) void k_leaflets_individual(LeafletArgs a) {
 //   k_local_scatter : per (slab frame, membrane atom): cell-ordered record (coordinates + cos/sin)
 //   k_local_flags   : one wave per (slab frame, head): two passes over the 3x3 neighbour cells
 constexpr uint32_t kLocalMaxCells1D = 128;
-// assignment frames processed per launch group: as many as fit 256 MiB of cell-list scratch, at most 128 (a
-// 36 864-bead membrane gains 10 % from 32 -> 128 frames, nothing beyond: the small binning kernels get amortised)
-constexpr uint32_t kLocalSlabMax = 128;
+// assignment frames processed per launch group: as many as fit 512 MiB of cell-list scratch, at most 256 (one block of
+// k_local_build per frame then fills the 256 CUs)
+constexpr uint32_t kLocalSlabMax = 256;
 inline uint32_t local_slab_frames(size_t n_membrane) {
     // (the heads' to-do list, 8 bytes per head and frame, is on top: heads are a fraction of the membrane atoms)
     const size_t per_frame = n_membrane * 24u + (size_t)(2 * 4u + 32u) * kLocalMaxCells1D * kLocalMaxCells1D + 8u;
-    const size_t n = ((size_t)256 << 20) / per_frame;
+    const size_t n = ((size_t)512 << 20) / per_frame;
     return (uint32_t)(n < 4 ? 4 : (n > kLocalSlabMax ? kLocalSlabMax : n));
 }
 
@@ -674,6 +674,110 @@ __global__ __launch_bounds__(256) void k_local_scatter(LocalArgs a) {
     const size_t q = (size_t)s * a.n_membrane + start + rank;
     reinterpret_cast<float4 *>(a.trig)[q] = make_float4(p[da], p[db], p[dn], cs);
     a.rsn[q] = sn;
+}
+
+// bin + scan + scatter in ONE kernel, one block per slab frame (membranes of up to kLocalBuildMax atoms: the slab then has
+// enough frames to fill the chip with one block each).  The cell counts live in LDS (no global atomics, no memsets,
+// no cell_of round trip): pass 1 counts, an in-block scan turns the counts into the starts (kept in LDS and written to
+// cell_count for the kernels that follow), pass 2 recomputes an atom's cell — the same arithmetic on the same
+// coordinates, now an L2 hit — takes its rank from a second LDS counter and writes the record.
+// dynamic LDS: 2 x kLocalMaxCells1D^2 words.
+constexpr uint32_t kLocalBuildMax = 65536;
+constexpr uint32_t kLocalBuildLds = 2u * kLocalMaxCells1D * kLocalMaxCells1D * (uint32_t)sizeof(uint32_t);
+__global__ __launch_bounds__(1024) void k_local_build(LocalArgs a) {
+    extern __shared__ uint32_t l_build[];
+    __shared__ uint32_t l_wave[16];
+    uint32_t *l_start = l_build, *l_fill = l_build + kLocalMaxCells1D * kLocalMaxCells1D;
+    const uint32_t s = blockIdx.x, tid = threadIdx.x;
+    const uint32_t f = a.aframes ? a.aframes[s] : a.frame0 + s;
+    float box[3];
+    frame_box(a, f, box);
+    uint32_t nca, ncb, ka, kb;
+    int da, db;
+    local_grid(a, box, nca, ncb, da, db, ka, kb);
+    const uint32_t ncell = nca * ncb;
+    const int dn = (int)a.dim;
+    for (uint32_t k = tid; k < ncell; k += 1024u) { l_start[k] = 0; l_fill[k] = 0; }
+    __syncthreads();
+    const float *x = a.xyz + (size_t)f * a.n_atoms * 3u;
+    int bad = 0;
+    auto cell_ab = [&](float xa, float xb) -> uint32_t {
+        if (!a.pbc) return 0u;
+        const float wa = gm_wrap(xa, box[da], bad), wb = gm_wrap(xb, box[db], bad);
+        const uint32_t ca = (uint32_t)fminf(fmaxf(floorf(wa / box[da] * (float)nca), 0.0f), (float)(nca - 1u));
+        const uint32_t cb = (uint32_t)fminf(fmaxf(floorf(wb / box[db] * (float)ncb), 0.0f), (float)(ncb - 1u));
+        return ca * ncb + cb;
+    };
+    // eight atoms per trip: the index and coordinate loads of all of them go out before the first is used (a thread walks
+    // ~36 atoms; one dependent load pair per atom would leave the 16 waves of the block waiting most of the time)
+    constexpr uint32_t U = 8;
+    for (uint32_t i0 = tid; i0 < a.n_membrane; i0 += U * 1024u) {
+        uint32_t at[U];
+        float pa[U], pb[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) at[u] = a.membrane[min(i0 + u * 1024u, a.n_membrane - 1u)];
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) { pa[u] = x[3u * (size_t)at[u] + da]; pb[u] = x[3u * (size_t)at[u] + db]; }
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++)
+            if (i0 + u * 1024u < a.n_membrane) atomicAdd(&l_start[cell_ab(pa[u], pb[u])], 1u);
+    }
+    __syncthreads();
+    // exclusive scan: 16 consecutive cells per thread, wave scan of the thread sums, then the waves' totals
+    {
+        constexpr uint32_t PER = kLocalMaxCells1D * kLocalMaxCells1D / 1024u;
+        const uint32_t c0 = tid * PER;
+        uint32_t cnt[PER], sum = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+            cnt[k] = c0 + k < ncell ? l_start[c0 + k] : 0u;
+            sum += cnt[k];
+        }
+        uint32_t incl = sum;
+#pragma unroll
+        for (uint32_t off = 1; off < 64u; off <<= 1) {
+            const uint32_t v = __shfl_up(incl, off, 64);
+            if ((tid & 63u) >= off) incl += v;
+        }
+        if ((tid & 63u) == 63u) l_wave[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t run = incl - sum;
+        for (uint32_t w = 0; w < (tid >> 6); w++) run += l_wave[w];
+        uint32_t *cstart = a.cell_count + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u);
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+            if (c0 + k <= ncell) {              // (entry ncell = the number of atoms)
+                cstart[c0 + k] = run;
+                if (c0 + k < ncell) l_start[c0 + k] = run;
+            }
+            run += cnt[k];
+        }
+    }
+    if (tid == 0 && a.grid) a.grid[s] = make_uint4(nca, ncb, ka, kb);
+    __syncthreads();
+    float4 *rec = reinterpret_cast<float4 *>(a.trig) + (size_t)s * a.n_membrane;
+    float *rsn = a.rsn + (size_t)s * a.n_membrane;
+    for (uint32_t i0 = tid; i0 < a.n_membrane; i0 += U * 1024u) {
+        uint32_t at[U];
+        float pa[U], pb[U], pn[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) at[u] = a.membrane[min(i0 + u * 1024u, a.n_membrane - 1u)];
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) {
+            pa[u] = x[3u * (size_t)at[u] + da]; pb[u] = x[3u * (size_t)at[u] + db]; pn[u] = x[3u * (size_t)at[u] + dn];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) {
+            if (i0 + u * 1024u >= a.n_membrane) continue;
+            const uint32_t c = cell_ab(pa[u], pb[u]);
+            const uint32_t q = l_start[c] + atomicAdd(&l_fill[c], 1u);
+            float sn = 0.0f, cs = 0.0f;
+            if (a.pbc) fast_sincos_rev(gm_wrap(pn[u], box[dn], bad) / box[dn], &sn, &cs);
+            rec[q] = make_float4(pa[u], pb[u], pn[u], cs);
+            rsn[q] = sn;
+        }
+    }
+    if (bad) raise_box_range(a.err, f);
 }
 
 // Per cell: what the members' sums need from a cell ALL of whose atoms are members (k_local_flags takes such a cell
