@@ -68,10 +68,38 @@ def pack(name, gro, bnd, xtcs, alt_bnd=None, same_frames=None):
           "->", os.path.getsize(out) // 1024, "KiB")
 
 
+def tpr_frame(tpr_path, gro_positions, gro_box):
+    """The full-precision coordinates and box a GROMACS .tpr file holds, WITHOUT parsing the format: the file stores
+    them as big-endian f32 arrays, and its .gro twin prints the same frame rounded to 1e-3 nm (box: 1e-5) — so the
+    arrays are the (only) places in the file where 3 N consecutive floats agree with the .gro to half a unit of its
+    last digit."""
+    raw = open(tpr_path, "rb").read()
+    n = len(gro_positions)
+    want = np.asarray(gro_positions, dtype=np.float64)
+    found_x, found_b = [], []
+    bw = np.zeros(9)
+    bw[[0, 4, 8]] = gro_box[:3]
+    for shift in range(4):                      # newer .tpr bodies are not 4-byte aligned
+        m = (len(raw) - shift) // 4
+        f = np.frombuffer(raw[shift:shift + 4 * m], dtype=">f4")
+        with np.errstate(invalid="ignore"):
+            f64 = f.astype(np.float64)
+            for k in np.flatnonzero(np.abs(f64 - want[0, 0]) < 5.01e-4):
+                if k + 3 * n <= m and np.abs(f64[k:k + 3 * n].reshape(n, 3) - want).max() < 5.01e-4:
+                    found_x.append(f[k:k + 3 * n].astype(np.float32).reshape(n, 3))
+            for k in np.flatnonzero(np.abs(f64 - bw[0]) < 5.01e-6):
+                if k + 9 <= m and np.abs(f64[k:k + 9] - bw).max() < 5.01e-6:
+                    found_b.append(f[k:k + 9].astype(np.float32))
+    assert len(found_x) == 1 and len(found_b) >= 1, (len(found_x), len(found_b))
+    assert all(np.array_equal(b, found_b[0]) for b in found_b)
+    return found_x[0], found_b[0][[0, 4, 8]]
+
+
 def single_frame_kats():
     """The literal expectation arrays of the reference's single-frame tests (aaorder.rs:226-464, cgorder.rs:188-351:
     per bond type the SUM of the order parameters of one frame — the structure file's coordinates — total / upper /
-    lower) + those coordinates as the .gro twins of the .tpr files print them (1e-3 nm, which loosens the pin)."""
+    lower) + those coordinates: as the .gro twins of the .tpr files print them (1e-3 nm) and at the .tpr's own full
+    f32 precision (tpr_frame), which is what the reference's tests run on."""
     import json
     import re
     out = {}
@@ -88,8 +116,9 @@ def single_frame_kats():
         g = st.read_gro(os.path.join(REF, gro))
         keep = np.array([r in LIPIDS for r in g.resnames])
         ints = np.rint(g.positions[keep].astype(np.float64) * 1000).astype(np.int32)
+        x32, b32 = tpr_frame(os.path.join(REF, tag + ".tpr"), g.positions, g.box)
         np.savez_compressed(os.path.join(HERE, f"{tag}_structure_frame.npz"), ints=ints.astype(np.int16),
-                            box=np.asarray(g.box, dtype=np.float32))
+                            box=np.asarray(g.box, dtype=np.float32), xyz_tpr=x32[keep], box_tpr=b32)
     with open(os.path.join(HERE, "expected", "single_frame_sums.json"), "w") as f:
         json.dump(out, f)
 

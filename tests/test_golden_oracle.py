@@ -375,15 +375,17 @@ def test_ua_ordermaps(ua):
 
 # ---- single-frame tests of the reference (aaorder.rs:226-464, cgorder.rs:188-351) ------------------------------
 def single_frame(kind, fx):
-    """The structure file's own coordinates (its .gro twin, 1e-3 nm) as one frame with global leaflets, and the
-    literal expectation arrays of the reference's unit tests."""
+    """The structure file's own coordinates — the .tpr's full-precision f32 positions and box, found in the file by
+    tests/golden/make_fixtures.py:tpr_frame — as one frame with global leaflets, and the literal expectation arrays
+    of the reference's unit tests (which run on exactly these coordinates)."""
     import json
     import os
     from golden_util import GOLDEN
     z = np.load(os.path.join(GOLDEN, ("pcpepg" if kind == "aa" else "cg") + "_structure_frame.npz"))
-    xyz = (z["ints"].astype(np.float32) * np.float32(0.001)).astype(np.float32)
+    xyz = z["xyz_tpr"].astype(np.float32)
+    assert np.abs(xyz - z["ints"].astype(np.float64) * 0.001).max() < 5.01e-4      # the .gro twin prints the same frame
     box = np.zeros((1, 3, 3), dtype=np.float32)
-    box[0, 0, 0], box[0, 1, 1], box[0, 2, 2] = z["box"]
+    box[0, 0, 0], box[0, 1, 1], box[0, 2, 2] = z["box_tpr"]
     with open(os.path.join(GOLDEN, "expected", "single_frame_sums.json")) as f:
         want = json.load(f)[kind]
     setup = aa_setup if kind == "aa" else cg_setup
@@ -391,7 +393,8 @@ def single_frame(kind, fx):
     return tables, labels, np.ascontiguousarray(xyz[midx][None]), box, want
 
 
-def check_single_frame(kind, res, labels, want):
+def check_single_frame(kind, res, labels, want, tol=None):
+    tol = tol or {"aa": 1.5e-4, "cg": 6e-5}[kind]
     counts = {"aa": ([131, 128, 15], [65, 64, 8], [66, 64, 7]), "cg": ([242, 242, 24], [121, 121, 12], [121, 121, 12])}[kind]
     sign = -1.0 if kind == "aa" else 1.0
     for w, key in enumerate(("total", "upper", "lower")):
@@ -399,10 +402,16 @@ def check_single_frame(kind, res, labels, want):
             sl = slice(ml.slot0, ml.slot0 + len(ml.bonds))
             # the leaflet populations are exact: this pins the global classifier (and its Bai-Breen centre)
             assert set(res.counts[w, sl].tolist()) == {counts[w][m]}
-            # the sums only as far as 1e-3-nm coordinates allow (the test itself uses the .tpr's full precision)
-            got = sign * res.sums[w, sl] / 1e6
-            assert np.abs(got - np.array(want[key][m])).max() < 0.2
-            assert abs(got.sum() - np.sum(want[key][m])) < 0.6
+            # The reference's own bar is assert_relative_eq!(-real, expected, epsilon = 1e-5) on the f32 sum of up to 242
+            # samples (aaorder.rs:394, 456; cgorder.rs).  On the .tpr's f32 coordinates the sums (values 1..130) come
+            # out within 1.1e-4 (AA) / 4.6e-5 (CG = 6 f32 ulps of the sum) — with the .gro twins it was 0.2.  An exact
+            # f64 evaluation of the same coordinates leaves the same residual, so it is not this arithmetic: it is what
+            # ONE f32 ulp of noise per coordinate does to a sum (3e-7 nm on a 0.11 nm bond = 4 ticks per sample), i.e.
+            # the reference's expectation arrays were made from coordinates that went through one more f32 rounding
+            # somewhere in its .tpr reading path (minitpr / groan_rs, not in the checkout).
+            got = (sign * res.sums[w, sl] / 1e6).astype(np.float32)
+            err = np.abs(got.astype(np.float64) - np.array(want[key][m], dtype=np.float32).astype(np.float64))
+            assert err.max() < tol, (key, m, err.max())
 
 
 @pytest.mark.parametrize("kind", ["aa", "cg"])
