@@ -133,6 +133,21 @@ __device__ __forceinline__ void extras_flush_tw(const FrameArgs &a, const ExtraA
 constexpr uint32_t kRecFrames = 4;               // frames per block of the bond tiles' staging layout
 constexpr uint32_t kRecPitch = kBlock + 4;       // LDS row pitch in words (the flush reads columns)
 
+// The staged samples of one block of <= kRecFrames frames (frames f_first .. f_first + c) from LDS to the blocked layout
+// described at ExtraArgs::map_rec: whole rows, the runs of a slot contiguous.  l_rec[frame in block][lane], l_run[lane].
+__device__ __forceinline__ void rec_flush(const ExtraArgs &e, uint32_t tile_id, uint32_t f_first, uint32_t c, uint32_t tid,
+                                          const unsigned long long *l_rec, const uint32_t *l_run) {
+    unsigned long long *row = e.map_rec + (size_t)tile_id * kBlock * e.rec_stride +
+                              (size_t)((f_first - e.rec_frame0) / kRecFrames) * (kRecFrames * kBlock);
+#pragma unroll
+    for (uint32_t m = 0; m < kRecFrames; m++) {
+        const uint32_t w = tid + kBlock * m, run = l_run[w / kRecFrames];
+        const uint32_t tid0 = run >> 16, n = run & 0xffffu, rem = w - kRecFrames * tid0;
+        const uint32_t cc = (rem >= n ? 1u : 0u) + (rem >= 2u * n ? 1u : 0u) + (rem >= 3u * n ? 1u : 0u);
+        row[w] = cc <= c ? l_rec[cc * kRecPitch + tid0 + (rem - cc * n)] : kMapNoSample;
+    }
+}
+
 // MAPS_ONLY: staged ordermap samples and nothing else (no geometry selection, timewise rows, per-molecule normals)
 template <bool ACOS_COS, bool MAPS_ONLY>
 __global__ __launch_bounds__(kBlock) void k_bonds_extras(FrameArgs a_in, ExtraArgs e, const float *__restrict__ xyz,
@@ -236,15 +251,7 @@ __global__ __launch_bounds__(kBlock) void k_bonds_extras(FrameArgs a_in, ExtraAr
             l_rec[c * kRecPitch + tid] = rec;
             if (c == kRecFrames - 1 || f + 1 == f_end) {
                 __syncthreads();
-                unsigned long long *row = e.map_rec + (size_t)tile_id * kBlock * e.rec_stride +
-                                          (size_t)((f - c - e.rec_frame0) / kRecFrames) * (kRecFrames * kBlock);
-#pragma unroll
-                for (uint32_t m = 0; m < kRecFrames; m++) {
-                    const uint32_t w = tid + kBlock * m, run = l_run[w / kRecFrames];
-                    const uint32_t tid0 = run >> 16, n = run & 0xffffu, rem = w - kRecFrames * tid0;
-                    const uint32_t cc = (rem >= n ? 1u : 0u) + (rem >= 2u * n ? 1u : 0u) + (rem >= 3u * n ? 1u : 0u);
-                    row[w] = cc <= c ? l_rec[cc * kRecPitch + tid0 + (rem - cc * n)] : kMapNoSample;
-                }
+                rec_flush(e, tile_id, f - c, c, tid, l_rec, l_run);
                 __syncthreads();
             }
         }
