@@ -34,6 +34,7 @@ ERR_NO_DEVICE = 102
 ERR_BOX_RANGE = 103
 ERR_LEAFLETS_NOT_PRIMED = 104
 ERR_OVERFLOW = 105
+ERR_TRAJECTORY_FORMAT = 106
 
 LEAFLETS_NONE, LEAFLETS_GLOBAL, LEAFLETS_LOCAL, LEAFLETS_INDIVIDUAL, LEAFLETS_MANUAL = range(5)
 FLAG_TRIG_ACOS_COS = 1

@@ -359,7 +359,8 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
     if (status == GORDER_OK) status = sync_status;
     else if (!hip_msg.empty()) h->err_msg = hip_msg;
     if (status == GORDER_OK && pipe.reader_status != GORDER_XTC_OK) {
-        status = GORDER_ERR_INVALID_ARGUMENT;
+        // a corrupt or truncated file is the same error whichever side decodes it
+        status = pipe.reader_status == GORDER_XTC_ERR_FORMAT ? GORDER_ERR_TRAJECTORY_FORMAT : GORDER_ERR_INVALID_ARGUMENT;
         h->err_msg = pipe.reader_msg + " (reader status " + std::to_string(pipe.reader_status) + ")";
     }
     if (stats) {

@@ -63,8 +63,9 @@ typedef enum {
                                              earlier assignment is known: call gorder_hip_prime_leaflets */
     GORDER_ERR_OVERFLOW = 105,        /* a batch was refused because frames x molecules would reach 2^63 / 1e6: an i64
                                          order sum could then overflow (the reference panics, order.rs:44-60) */
-    GORDER_ERR_TRAJECTORY_FORMAT = 106 /* gorder_hip_xtc_decode met a corrupt or truncated XTC frame (the reference:
-                                         a read error of the trajectory iterator, common.rs:248) */
+    GORDER_ERR_TRAJECTORY_FORMAT = 106 /* a corrupt or truncated trajectory frame, met by gorder_hip_xtc_decode on the device or
+                                         by the host reader inside gorder_hip_run_trajectory (the reference: a read error
+                                         of the trajectory iterator, common.rs:248) */
 } gorder_status_t;
 
 /* ---- leaflets -------------------------------------------------------------------------------- */

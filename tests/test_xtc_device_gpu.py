@@ -146,7 +146,7 @@ def test_corrupt_block_is_reported(built, tmp_path):
         eng.xtc_decode(blob.data_ptr(), blob.numel(), frames.data_ptr(), 5, 2000, 0, 2000, out.data_ptr(), 2000)
         with pytest.raises(abi.GorderHipError) as ei:
             eng.synchronize()
-        assert ei.value.status == 106
+        assert ei.value.status == abi.ERR_TRAJECTORY_FORMAT
         assert "frame 3" in str(ei.value)
 
 
@@ -182,3 +182,26 @@ def test_driver_falls_back_for_other_formats(cg, tmp_path):
     ref = HipEngine(tables)
     ref.run_trajectory([CG3], group=midx)
     np.testing.assert_array_equal(eng.finish().sums, ref.finish().sums)
+
+
+@pytest.mark.parametrize("damage", ["zeros", "truncated"])
+def test_driver_reports_corrupt_files_on_both_routes(cg, tmp_path, damage):
+    """a frame whose bit stream is all zeros (every atom at full width: the block is too short for that) and a file cut
+    in the middle of a frame: GORDER_ERR_TRAJECTORY_FORMAT whichever side decodes"""
+    tables, labels, midx = cg_setup(cg, leaflets=METHODS["global"])
+    path = str(tmp_path / "bad.xtc")
+    xtc.write_trajectory(path, cg.xyz[:12], cg.boxes[:12], times=cg.times[:12], precision=100.0)
+    w = xtc.pack_trajectory([path])[0]
+    raw = bytearray(open(path, "rb").read())
+    sizes = [92 + int(f["n_bytes"]) for f in w["frames"]]
+    start7 = sum(sizes[:7])
+    if damage == "zeros":
+        raw[start7 + 92:start7 + sizes[7]] = bytes(sizes[7] - 92)
+    else:
+        raw = raw[:start7 + sizes[7] // 2]
+    open(path, "wb").write(bytes(raw))
+    for dev in (False, True):
+        eng = HipEngine(tables)
+        with pytest.raises(abi.GorderHipError) as ei:
+            eng.run_trajectory([path], group=midx, threads=2, device_decode=dev)
+        assert ei.value.status == abi.ERR_TRAJECTORY_FORMAT, (dev, str(ei.value))
