@@ -308,7 +308,7 @@ _EXPORTS = [
     "gorder_hip_last_error_message", "gorder_hip_strerror", "gorder_hip_kernel_time", "gorder_hip_plan",
     "gorder_hip_plan_tables", "gorder_hip_selftest_arithmetic", "gorder_hip_run_trajectory",
     "gorder_hip_comm_unique_id", "gorder_hip_comm_create", "gorder_hip_comm_destroy", "gorder_hip_allreduce",
-    "gorder_hip_reset", "gorder_hip_xtc_decode",
+    "gorder_hip_reset", "gorder_hip_xtc_decode", "gorder_hip_release_staging",
 ]
 
 _lib = None
@@ -381,6 +381,8 @@ def load_library() -> C.CDLL:
     lib.gorder_hip_allreduce.argtypes = [vp, vp]
     lib.gorder_hip_reset.argtypes = [vp]
     lib.gorder_hip_xtc_decode.argtypes = [vp, vp, u64, vp, u32, u32, vp, u32, vp, u32]
+    lib.gorder_hip_release_staging.argtypes = [vp]
+    lib.gorder_hip_release_staging.restype = None
     _lib = lib
     return lib
 
@@ -542,6 +544,10 @@ class HipEngine:
         (d_slot_of may be 0).  Asynchronous on the handle's stream."""
         self._check(self.lib.gorder_hip_xtc_decode(self._h, d_blob, blob_bytes, d_frames, n_frames, n_atoms_file,
                                                    d_slot_of or None, n_stop, d_xyz, n_atoms_out))
+
+    def release_staging(self):
+        """Give back the staging buffers run_trajectory keeps between calls (gorder_hip_release_staging)."""
+        self.lib.gorder_hip_release_staging(self._h)
 
     def reset(self):
         """A fresh SystemTopology on the same tables (gorder_hip_reset)."""

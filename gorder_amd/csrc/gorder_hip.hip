@@ -53,6 +53,9 @@ using gorder::Tile;
 // ============================================================================================
 
 struct gorder_hip_handle {
+    // staging buffers of gorder_hip_run_trajectory, kept between calls (trajectory_driver.h: TrajCache)
+    void *traj_cache = nullptr;
+    void (*traj_cache_free)(gorder_hip_handle *) = nullptr;
     Plan plan;
     gorder_tables_t tables{};           // scalar copy (pointers inside are NOT kept)
     int device = 0;
@@ -968,6 +971,7 @@ void gorder_hip_destroy(gorder_hip_handle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->traj_cache_free) h->traj_cache_free(h);
     for (auto &pair : h->timing_ev)
         for (hipEvent_t ev : pair)
             if (ev) (void)hipEventDestroy(ev);

@@ -40,9 +40,21 @@ struct TrajSlot {
     std::vector<uint64_t> fidx;
 };
 
-struct TrajPipe {
+// The staging buffers of a handle's trajectory runs.  They are kept by the handle between calls (and freed with it):
+// pinning gigabytes of host memory costs ~0.1 s, which a second trajectory analysed with the same handle need not pay.
+struct TrajCache {
     static constexpr int kSlots = 4;     // the host-decode route uses three of them
     TrajSlot slot[kSlots];
+    bool dev = false;
+    uint32_t batch = 0;
+    size_t blob_cap = 0, xyz_bytes = 0;
+    hipStream_t copy_stream = nullptr;
+    unsigned long long *h_err = nullptr;     // pinned mirror of the device error key
+};
+
+struct TrajPipe {
+    static constexpr int kSlots = TrajCache::kSlots;
+    TrajSlot *slot = nullptr;            // the cache's
     std::mutex mu;
     std::condition_variable cv;
     std::deque<int> free_q, filled_q;
@@ -50,14 +62,17 @@ struct TrajPipe {
     int reader_status = GORDER_XTC_OK;
     std::string reader_msg;
     double decode_s = 0.0, reader_stalled_s = 0.0, setup_s = 0.0;
+    bool alloc_failed = false;
 };
 
 double seconds_since(std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
-void traj_free(gorder_hip_handle *h, TrajPipe &p) {
-    for (TrajSlot &s : p.slot) {
+void traj_cache_free(gorder_hip_handle *h) {
+    TrajCache *c = static_cast<TrajCache *>(h->traj_cache);
+    if (!c) return;
+    for (TrajSlot &s : c->slot) {
         if (s.h_xyz) (void)hipHostFree(s.h_xyz);
         if (s.h_box) (void)hipHostFree(s.h_box);
         if (s.h_time) (void)hipHostFree(s.h_time);
@@ -73,10 +88,19 @@ void traj_free(gorder_hip_handle *h, TrajPipe &p) {
         if (s.copied) (void)hipEventDestroy(s.copied);
         if (s.computed) (void)hipEventDestroy(s.computed);
     }
-    (void)h;
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->h_err) (void)hipHostFree(c->h_err);
+    delete c;
+    h->traj_cache = nullptr;
 }
 
 }  // namespace
+
+extern "C" void gorder_hip_release_staging(gorder_hip_handle *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    traj_cache_free(h);
+}
 
 extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_trajectory_t *tr,
                                          gorder_trajectory_stats_t *stats) {
@@ -91,12 +115,20 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
     uint32_t n_file_atoms = 0, n_stop = 0;
     std::vector<int32_t> slot_of;
     for (uint32_t f = 0; dev && f < tr->n_paths; f++) {
-        gorder_xtc_reader *r = nullptr;
-        if (gorder_xtc_open(tr->paths[f], tr->group, tr->n_group, &r) != GORDER_XTC_OK) { dev = false; break; }   // (the reader thread reports it)
-        if (!gorder_xtc_is_xtc(r)) dev = false;
-        if (f == 0) { n_file_atoms = gorder_xtc_n_atoms_file(r); n_stop = gorder_xtc_n_atoms_needed(r); }
-        else if (gorder_xtc_n_atoms_file(r) != n_file_atoms) dev = false;
-        gorder_xtc_close(r);
+        uint32_t na = 0;
+        if (gorder_xtc_probe(tr->paths[f], &na) != 1) { dev = false; break; }     // (an unreadable file: the reader thread reports it)
+        if (f == 0) n_file_atoms = na;
+        else if (na != n_file_atoms) dev = false;
+    }
+    if (dev) {
+        n_stop = n_file_atoms;
+        if (tr->group && tr->n_group) {
+            n_stop = 0;
+            for (uint32_t k = 0; k < tr->n_group; k++) {
+                if (tr->group[k] >= n_file_atoms) return fail(h, GORDER_ERR_INVALID_ARGUMENT, "group index beyond the atoms of the file");
+                n_stop = std::max(n_stop, tr->group[k] + 1u);
+            }
+        }
     }
     if (dev && tr->group && tr->n_group) {
         slot_of.assign(n_file_atoms, -1);
@@ -113,16 +145,23 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
     // a compressed atom takes 3-5 bytes at the usual precision, never more than 10: 6 per atom and frame on average,
     // and room for one worst-case frame
     const size_t blob_cap = dev ? std::max<size_t>((size_t)batch * n_file_atoms * 6u, (size_t)n_file_atoms * 12u + 4096u) + 4096u : 0;
+    TrajCache *cache = static_cast<TrajCache *>(h->traj_cache);
+    if (cache && !(cache->dev == dev && cache->batch == batch && cache->blob_cap == blob_cap && cache->xyz_bytes == xyz_bytes)) {
+        traj_cache_free(h);            // another shape of run: start over
+        cache = nullptr;
+    }
+    if (!cache) {
+        cache = new (std::nothrow) TrajCache();
+        if (!cache) return fail(h, GORDER_ERR_DEVICE, "out of host memory");
+        cache->dev = dev; cache->batch = batch; cache->blob_cap = blob_cap; cache->xyz_bytes = xyz_bytes;
+        h->traj_cache = cache;
+        h->traj_cache_free = &traj_cache_free;
+    }
     TrajPipe pipe;
-    hipStream_t copy_stream = nullptr;
+    pipe.slot = cache->slot;
+    for (int k = 0; k < TrajPipe::kSlots; k++) { pipe.slot[k].copy_issued = pipe.slot[k].compute_issued = false; }   // (the last run ended synchronised)
     int32_t *d_slot_of = nullptr;
-    unsigned long long *h_err = nullptr;   // pinned mirror of the device error key: lets the loop stop at the first error
-    auto cleanup = [&]() {
-        traj_free(h, pipe);
-        if (copy_stream) (void)hipStreamDestroy(copy_stream);
-        if (h_err) (void)hipHostFree(h_err);
-        (void)hipFree(d_slot_of);
-    };
+    auto cleanup = [&]() { (void)hipFree(d_slot_of); };
 #define TRAJ_TRY(expr)                                                                              \
     do {                                                                                            \
         hipError_t e_ = (expr);                                                                     \
@@ -131,8 +170,10 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
             return fail(h, GORDER_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));   \
         }                                                                                           \
     } while (0)
-    TRAJ_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
-    TRAJ_TRY(hipHostMalloc((void **)&h_err, sizeof(unsigned long long), hipHostMallocDefault));
+    if (!cache->copy_stream) TRAJ_TRY(hipStreamCreateWithFlags(&cache->copy_stream, hipStreamNonBlocking));
+    if (!cache->h_err) TRAJ_TRY(hipHostMalloc((void **)&cache->h_err, sizeof(unsigned long long), hipHostMallocDefault));
+    const hipStream_t copy_stream = cache->copy_stream;
+    unsigned long long *h_err = cache->h_err;   // lets the loop stop at the first error
     *h_err = kErrNone;
     if (dev && !slot_of.empty()) {
         TRAJ_TRY(hipMalloc((void **)&d_slot_of, slot_of.size() * sizeof(int32_t)));
@@ -141,10 +182,11 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
     // Pinning a gigabyte takes tens of milliseconds: only the first slot's share of that stands before the first frame
     // is read, the other slots are made ready by a thread of their own.
     auto alloc_slot = [&](TrajSlot &s) -> hipError_t {
+        if (s.computed) return hipSuccess;           // kept from an earlier call
         hipError_t e = hipSuccess;
         auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
         if (dev) {
-            ok(hipHostMalloc((void **)&s.h_blob, blob_cap, hipHostMallocDefault));
+            ok(hipHostMalloc((void **)&s.h_blob, blob_cap, hipHostMallocDefault));   // (write-combined: no faster, measured)
             ok(hipHostMalloc((void **)&s.h_frames, (size_t)batch * sizeof(gorder_xtc_frame_t), hipHostMallocDefault));
             ok(hipMalloc((void **)&s.d_blob, blob_cap));
             ok(hipMalloc((void **)&s.d_frames, (size_t)batch * sizeof(gorder_xtc_frame_t)));
@@ -166,7 +208,10 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
     // slot 0 here, the others by a thread of their own while the reader already fills slot 0
     {
         const hipError_t e0 = alloc_slot(pipe.slot[0]);
-        if (e0 != hipSuccess) TRAJ_TRY(e0);
+        if (e0 != hipSuccess) {
+            traj_cache_free(h);        // (a slot that is only partly there)
+            TRAJ_TRY(e0);
+        }
     }
     pipe.free_q.push_back(0);
     std::thread allocator([&, n_slots]() {
@@ -180,7 +225,7 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
             const hipError_t e = alloc_slot(pipe.slot[k]);
             std::lock_guard<std::mutex> lk(pipe.mu);
             pipe.setup_s += seconds_since(t0);
-            if (e != hipSuccess) return;          // the run goes on with the slots there are
+            if (e != hipSuccess) { pipe.alloc_failed = true; return; }   // the run goes on with the slots there are
             pipe.free_q.push_back(k);
             pipe.cv.notify_all();
         }
@@ -353,8 +398,8 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
     reader.join();
     allocator.join();
     (void)hipStreamSynchronize(copy_stream);
-    for (TrajSlot &s : pipe.slot)
-        if (s.stream) (void)hipStreamSynchronize(s.stream);
+    for (int k = 0; k < TrajPipe::kSlots; k++)
+        if (pipe.slot[k].stream) (void)hipStreamSynchronize(pipe.slot[k].stream);
     const int sync_status = gorder_hip_synchronize(h);      // surfaces device errors
     if (status == GORDER_OK) status = sync_status;
     else if (!hip_msg.empty()) h->err_msg = hip_msg;
@@ -378,6 +423,7 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
         stats->seconds_setup = setup_s + pipe.setup_s;
     }
     cleanup();
+    if (pipe.alloc_failed) traj_cache_free(h);      // (a slot that is only partly there)
 #undef TRAJ_TRY
     return status;
 }

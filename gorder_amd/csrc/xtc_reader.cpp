@@ -875,6 +875,18 @@ int64_t gorder_xtc_read_window_mt(gorder_xtc_reader *r, float begin_ps, float en
 // ---- packing for the device decoder ------------------------------------------------------------------
 extern "C" {
 
+int gorder_xtc_probe(const char *path, uint32_t *n_atoms) {
+    if (!path) return GORDER_XTC_ERR_ARGUMENT;
+    FILE *fp = fopen(path, "rb");
+    if (!fp) return GORDER_XTC_ERR_OPEN;
+    uint8_t head[8];
+    const bool ok = read_exact(fp, head, 8);
+    fclose(fp);
+    if (!ok) return GORDER_XTC_ERR_FORMAT;
+    if (be32(head) != 1995u) return 0;
+    if (n_atoms) *n_atoms = be32(head + 4);
+    return 1;
+}
 int gorder_xtc_is_xtc(const gorder_xtc_reader *r) { return (r && !r->trr && !r->gro) ? 1 : 0; }
 uint32_t gorder_xtc_n_atoms_needed(const gorder_xtc_reader *r) {
     return r ? (r->n_needed ? std::min(r->n_needed, r->natoms) : r->natoms) : 0;

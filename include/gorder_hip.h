@@ -267,6 +267,11 @@ typedef struct {
 
 int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_trajectory_t *trajectory,
                               gorder_trajectory_stats_t *stats /* may be NULL */);
+/* The pinned host buffers and device buffers of gorder_hip_run_trajectory (with device_decode: 4 slots of a pinned
+ * blob + its device copy + 1 GiB of coordinates) stay with the handle after the call, so that the next trajectory
+ * analysed with it does not pay for pinning again (~0.1 s per GB); a run of a different shape (route, batch size)
+ * replaces them, gorder_hip_destroy frees them — and so does this call, for a host that wants the memory back. */
+void gorder_hip_release_staging(gorder_hip_handle *h);
 
 /* Decompress XTC frames on the device (the decoding half of groan_rs' GroupXtcReader, common.rs:283-304):
  * `d_blob` / `d_frames` are device copies of what gorder_xtc_pack_window produced (blob_bytes >= 32), `d_slot_of`

@@ -95,6 +95,9 @@ int64_t gorder_xtc_pack_window(gorder_xtc_reader *r, float begin_ps, float end_p
                                double *last_time, uint8_t *blob, uint64_t blob_capacity, uint64_t *blob_bytes,
                                gorder_xtc_frame_t *frames, float *box9, float *time_ps, uint64_t capacity,
                                uint32_t n_threads);
+/* Look at a file's first bytes only: 1 = XTC (and *n_atoms = atoms per frame), 0 = something else (TRR, GRO, ...),
+ * negative = cannot be opened / too short. */
+int gorder_xtc_probe(const char *path, uint32_t *n_atoms);
 /* 1 when the reader's file is an XTC file (what gorder_xtc_pack_window accepts), else 0 */
 int gorder_xtc_is_xtc(const gorder_xtc_reader *r);
 /* atoms of a frame the decoder has to go through: up to the last atom of the group (all atoms without a group) */

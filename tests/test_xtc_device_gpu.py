@@ -172,6 +172,28 @@ def test_driver_device_decode_matches_host_decode(cg, tmp_path, batch_frames, th
         np.testing.assert_array_equal(r0.counts, r1.counts)
 
 
+def test_staging_is_kept_and_released(cg, tmp_path):
+    """a handle's second run finds its staging buffers (no setup to speak of), runs of another shape and
+    release_staging start over; results do not depend on any of it"""
+    tables, labels, midx = cg_setup(cg, leaflets=METHODS["global"])
+    path = str(tmp_path / "c.xtc")
+    xtc.write_trajectory(path, cg.xyz, cg.boxes, times=cg.times, precision=100.0)
+    eng = HipEngine(tables)
+    want = None
+    for kw in (dict(device_decode=True), dict(device_decode=True), dict(device_decode=False), dict(device_decode=True, batch_frames=9),
+               dict(device_decode=True, batch_frames=9), "release", dict(device_decode=True, batch_frames=9)):
+        if kw == "release":
+            eng.release_staging()
+            continue
+        eng.reset()
+        stats = eng.run_trajectory([path], group=midx, threads=2, **kw)
+        res = eng.finish()
+        assert stats["n_frames"] == 101
+        if want is None:
+            want = res.sums.copy()
+        np.testing.assert_array_equal(res.sums, want)
+
+
 def test_driver_falls_back_for_other_formats(cg, tmp_path):
     """device_decode with a reference XTC file whose group is the Master group, and the fallback to the host decoder
     is silent for non-XTC input (nothing to decompress there)"""
