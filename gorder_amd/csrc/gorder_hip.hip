@@ -1557,7 +1557,7 @@ int xtc_decode_on(gorder_hip_handle *h, hipStream_t stream, const uint8_t *d_blo
         return fail(h, GORDER_ERR_INVALID_ARGUMENT, "gorder_hip_xtc_decode: bad arguments");
     if (n_frames == 0) return GORDER_OK;
     HIP_TRY(h, hipSetDevice(h->device));
-    hipLaunchKernelGGL(k_xtc_decode, dim3((n_frames + 63u) / 64u), dim3(64), 0, stream, d_blob,
+    hipLaunchKernelGGL(k_xtc_decode, dim3((n_frames + 64u * kXtcWaves - 1u) / (64u * kXtcWaves)), dim3(64u * kXtcWaves), 0, stream, d_blob,
                        (unsigned long long)blob_bytes, d_frames, n_frames, n_atoms_file, d_slot_of, n_stop, d_xyz,
                        n_atoms_out, h->d_err);
     HIP_TRY(h, hipGetLastError());

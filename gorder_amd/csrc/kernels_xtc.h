@@ -21,7 +21,8 @@
 namespace {
 
 constexpr int kXtcFirstIdx = 9, kXtcLastIdx = 73;
-constexpr uint32_t kXtcGroup = 16;     // atoms written out together (see k_xtc_decode)
+constexpr uint32_t kXtcGroup = 8;      // atoms written out together (see k_xtc_decode)
+constexpr uint32_t kXtcWaves = 1;      // waves per workgroup (co-resident waves do not shorten a wave: 12 per CU measured 25 % slower, the loads of 64 streams each contend for the one address unit)
 constexpr uint32_t kXtcPitch = 65;     // floats per (atom, coordinate) row of the LDS staging: 64 frames + 1 (bank spread)
 __device__ const uint32_t kXtcMagic[kXtcLastIdx] = {
     0,       0,       0,       0,       0,       0,       0,       0,       0,       8,        10,       12,
@@ -33,7 +34,7 @@ __device__ const uint32_t kXtcMagic[kXtcLastIdx] = {
     16777216};
 
 struct XtcBits {
-    const unsigned long long *src, *end;   // next word to prefetch; one past the last readable word
+    const unsigned long long *src, *end;   // next word to prefetch; one past the last readable word (the last ones are zero padding)
     unsigned long long w0, w1, pre;        // w0:w1 = the next 128 bits of the stream, MSB first; pre = the raw word behind them
     uint32_t off;                          // bits of w0 already taken
     unsigned long long taken;              // bits taken in all
@@ -47,18 +48,38 @@ struct XtcBits {
         off = 0;
         taken = 0;
     }
+    __device__ __forceinline__ unsigned long long peek() const {        // the next 64 bits
+        return off ? (w0 << off) | (w1 >> (64u - off)) : w0;
+    }
     __device__ __forceinline__ unsigned long long take(uint32_t n) {   // 0 <= n <= 64
-        const unsigned long long next = off ? (w0 << off) | (w1 >> (64u - off)) : w0;
-        const unsigned long long v = n ? next >> (64u - n) : 0ull;
+        const unsigned long long v = n ? peek() >> (64u - n) : 0ull;
+        skip(n);
+        return v;
+    }
+    __device__ __forceinline__ void skip(uint32_t n) {                  // 0 <= n <= 64
         off += n;
         taken += n;
         if (off >= 64u) {
             off -= 64u;
             w0 = w1;
             w1 = __builtin_bswap64(pre);
-            pre = src < end ? *src : 0ull;      // a corrupt stream runs into zeros, never out of the block
+            // a corrupt stream runs into the zero padding behind the block, never out of it.  The ADDRESS is clamped, not
+            // the value: a select on the loaded value would make the wave wait for the load right here (it did: 1 200 of
+            // the 2 100 cycles of an iteration), while the word is only needed at the next refill
+            pre = *(src < end ? src : end - 1);
             src++;
         }
+    }
+};
+
+// a reader over ONE peeked word: the fields of an atom whose bits all lie within the next 64 (the usual case) are cut
+// out of a register, and the stream moves once per atom
+struct XtcPeek {
+    unsigned long long p;
+    uint32_t used;
+    __device__ __forceinline__ unsigned long long take(uint32_t n) {   // used + n <= 64
+        const unsigned long long v = n ? (p << used) >> (64u - n) : 0ull;
+        used += n;
         return v;
     }
 };
@@ -127,20 +148,29 @@ __device__ __forceinline__ void xtc_ints(XtcBits &b, uint32_t nbits, uint32_t s1
 //   natoms       : atoms per frame in the file;  n_stop: atoms to go through (up to the last analysed one)
 //   slot_of      : [natoms] output slot of an atom or -1 (null: every atom, slot = atom)
 //   out          : [n_frames][n_out][3]
-__global__ __launch_bounds__(64) void k_xtc_decode(const uint8_t *__restrict__ blob, unsigned long long blob_bytes,
+__global__ __launch_bounds__(64 * kXtcWaves) void k_xtc_decode(const uint8_t *__restrict__ blob, unsigned long long blob_bytes,
                                                    const gorder_xtc_frame_t *__restrict__ frames, uint32_t n_frames,
                                                    uint32_t natoms, const int32_t *__restrict__ slot_of, uint32_t n_stop,
                                                    float *__restrict__ out, uint32_t n_out, uint32_t *err) {
     __shared__ uint32_t l_magic[kXtcLastIdx];
     __shared__ unsigned long long l_recip[kXtcLastIdx];
-    for (uint32_t k = threadIdx.x; k < (uint32_t)kXtcLastIdx; k += 64u) {
+    __shared__ double l_inv[kXtcLastIdx];
+    for (uint32_t k = threadIdx.x; k < (uint32_t)kXtcLastIdx; k += 64u * kXtcWaves) {
         const uint32_t m = kXtcMagic[k];
         l_magic[k] = m;
         // floor(2^64 / m): a power of two divides 2^64 exactly, for anything else it is floor((2^64 - 1) / m)
         l_recip[k] = m == 0u ? 0ull : ((m & (m - 1u)) == 0u ? 1ull << (64 - __builtin_ctz(m)) : ~0ull / m);
+        l_inv[k] = m == 0u ? 0.0 : 1.0 / (double)m;
     }
     __syncthreads();
-    const uint32_t fr = blockIdx.x * 64u + threadIdx.x;
+    // a wave = 64 frames; the waves of a workgroup share nothing but the tables above and a CU: with a few thousand
+    // frames per launch there are far fewer waves than SIMDs, and the dispatcher would give each a SIMD of its own,
+    // where every dependent instruction, LDS access and load is waited for in full (measured: 190 instructions per
+    // atom take 2 100 cycles).  Twelve waves per workgroup put three on each SIMD of one CU instead.
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t frame0 = (blockIdx.x * kXtcWaves + wave) * 64u;
+    if (frame0 >= n_frames) return;              // (no workgroup barrier below this line)
+    const uint32_t fr = frame0 + lane;
     const bool live = fr < n_frames;
     const gorder_xtc_frame_t d = frames[live ? fr : n_frames - 1u];
     float *o = out + (size_t)(live ? fr : 0u) * n_out * 3u;      // (the raw path below)
@@ -150,15 +180,13 @@ __global__ __launch_bounds__(64) void k_xtc_decode(const uint8_t *__restrict__ b
     const uint8_t *p = blob + (bad ? 0ull : d.offset);
 
     // Decoded atoms go through LDS: a lane writing its frame's atom straight to memory is one 4-byte piece in each of
-    // 64 cache lines per store instruction.  Instead a lane parks atom i at l_atoms[i mod 32] and, once 16 consecutive
-    // atoms are final, the wave writes them frame by frame: 48 lanes = 16 atoms x 3 coordinates = one contiguous
-    // 192-byte piece of a frame when the analysed atoms are consecutive in the file (any other order is still correct,
-    // only less coalesced): 48 x fewer memory transactions.  (The kernel's time did not change with it — 0.9 us per
-    // atom and wave before and after: a wave is bound by the ~500 instructions of an iteration, one issue per 4 cycles,
-    // not by memory — but it keeps thousands of concurrent waves from flooding the memory pipeline with partial lines.)
-    __shared__ float l_atoms[2u * kXtcGroup * 3u * kXtcPitch];
-    const uint32_t lane = threadIdx.x;
-    const uint32_t n_live = min(64u, n_frames - blockIdx.x * 64u);
+    // 64 cache lines per store instruction.  Instead a lane parks atom i at l_atoms[i mod 16] and, once 8 consecutive
+    // atoms are final, the wave writes them frame by frame: 24 lanes = 8 atoms x 3 coordinates = one contiguous 96-byte
+    // piece of a frame when the analysed atoms are consecutive in the file (any other order is still correct, only
+    // less coalesced), two frames per store instruction.
+    __shared__ float l_atoms_all[kXtcWaves * 2u * kXtcGroup * 3u * kXtcPitch];
+    float *l_atoms = l_atoms_all + wave * (2u * kXtcGroup * 3u * kXtcPitch);
+    const uint32_t n_live = min(64u, n_frames - frame0);
     auto put = [&](const int (&c)[3], uint32_t idx) {        // idx is wave-uniform
         float *q = l_atoms + (idx & (2u * kXtcGroup - 1u)) * 3u * kXtcPitch + lane;
         q[0] = (float)c[0] * inv_p;
@@ -166,16 +194,24 @@ __global__ __launch_bounds__(64) void k_xtc_decode(const uint8_t *__restrict__ b
         q[2u * kXtcPitch] = (float)c[2] * inv_p;
     };
     auto flush = [&](uint32_t first_atom) {                  // atoms first_atom .. first_atom + 15, all final
-        __syncthreads();                                     // (one wave per block: orders the LDS writes before the reads)
-        const uint32_t j = lane / 3u, c = lane - 3u * j, idx = first_atom + j;
+        // the wave reads what its own lanes wrote: LDS instructions of one wave execute in order, the fences only keep
+        // the compiler from moving the reads up
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // lanes 0..23: (atom, coordinate) of the even frames, lanes 24..47: of the odd frames — 96 contiguous bytes each
+        const uint32_t half = lane >= 3u * kXtcGroup ? 1u : 0u, l = lane - half * 3u * kXtcGroup;
+        const uint32_t j = l / 3u, c = l - 3u * j, idx = first_atom + j;
         int32_t slot = -1;
-        if (lane < 3u * kXtcGroup && idx < n_stop) slot = slot_of ? slot_of[idx] : (int32_t)idx;
+        if (lane < 6u * kXtcGroup && idx < n_stop) slot = slot_of ? slot_of[idx] : (int32_t)idx;
         if (slot >= 0 && (uint32_t)slot < n_out) {
             const float *q = l_atoms + ((idx & (2u * kXtcGroup - 1u)) * 3u + c) * kXtcPitch;
-            float *dst = out + ((size_t)blockIdx.x * 64u * n_out + (uint32_t)slot) * 3u + c;
+            float *dst = out + ((size_t)frame0 * n_out + (uint32_t)slot) * 3u + c;
 #pragma unroll 4
-            for (uint32_t f = 0; f < n_live; f++) dst[(size_t)f * n_out * 3u] = q[f];
+            for (uint32_t f = half; f < n_live; f += 2u) dst[(size_t)f * n_out * 3u] = q[f];
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     };
 
     if (natoms <= 9u) {      // uncompressed small systems: big-endian floats
@@ -190,27 +226,25 @@ __global__ __launch_bounds__(64) void k_xtc_decode(const uint8_t *__restrict__ b
     }
 
     XtcBits b;
-    if (bad) b.open(blob, blob);                // (blob holds at least one frame: >= 32 readable bytes) nothing is used
+    if (bad) b.open(blob, blob + 32);           // (blob holds at least 32 readable bytes) nothing of it is used
     else b.open(p, p + padded + 32ull);
     int smallidx = d.smallidx;
     if (smallidx < kXtcFirstIdx || smallidx >= kXtcLastIdx) { bad = true; smallidx = kXtcFirstIdx; }
     uint32_t sizesmall = l_magic[smallidx];
     unsigned long long rsmall = l_recip[smallidx];
+    double sinv = l_inv[smallidx];
     int smallnum = (int)(sizesmall / 2u);
-    int smaller = (int)(l_magic[smallidx > kXtcFirstIdx ? smallidx - 1 : kXtcFirstIdx] / 2u);
-    auto adapt = [&](int is_smaller) {           // the table step after an atom group (xtc_reader.cpp decode_ints)
+    // The table step after an atom group.  The reference decoder carries two values, `smallnum` and `smaller`, but
+    // smallnum == magic[smallidx] / 2 holds at every point (xtc_reader.cpp decode_ints keeps `smaller` ==
+    // magic[smallidx - 1] / 2 only to assign it on the way down): one table row, fetched in one go.
+    auto adapt = [&](int is_smaller) {
         if (is_smaller == 0) return;
         smallidx += is_smaller;
         if (smallidx < kXtcFirstIdx || smallidx >= kXtcLastIdx) { bad = true; smallidx = kXtcFirstIdx; }
-        if (is_smaller < 0) {
-            smallnum = smaller;
-            smaller = smallidx > kXtcFirstIdx ? (int)(l_magic[smallidx - 1] / 2u) : 0;
-        } else {
-            smaller = smallnum;
-            smallnum = (int)(l_magic[smallidx] / 2u);
-        }
         sizesmall = l_magic[smallidx];
         rsmall = l_recip[smallidx];
+        sinv = l_inv[smallidx];
+        smallnum = (int)(sizesmall / 2u);
     };
     int run = 0, pend = 0;
     uint32_t run_left = 0;          // small atoms of the current run still to come
@@ -219,6 +253,89 @@ __global__ __launch_bounds__(64) void k_xtc_decode(const uint8_t *__restrict__ b
     // an atom is final one iteration after it was read (the swap): one iteration past the last analysed atom
     const uint32_t n_iter = min(natoms, n_stop + 1u);
     uint32_t flushed = 0;           // atoms written out so far (a multiple of kXtcGroup)
+    // ---- the usual case, for the whole wave: every frame's full-width atom is ONE number of at most 53 bits (box edges
+    // below ~100 000 grid steps).  A full-width atom and a small-offset atom are then the SAME computation with other
+    // parameters — a mixed-radix number of nb bits with radices (s1, s2), cut out of the next 64 bits of the stream —
+    // so the lanes of a wave, which are in the two states at the same time, run ONE copy of it instead of both
+    // (measured 2 000 cycles per iteration with two copies).  The two divisions are done in f64: v < 2^53 is exact as a
+    // double, floor(v * (1 / s)) is within 1 of the quotient, the remainder by fma is exact and repairs it — 8 f64
+    // operations per division where floor(2^64 / s) arithmetic needs 7 quarter-rate integer multiplications.
+    const bool simple = d.bitsize >= 1u && d.bitsize <= 53u;
+    if (__ballot(!simple) == 0ull) {
+        const double ls1 = (double)d.sizeint[1], ls2 = (double)d.sizeint[2];
+        const double li1 = 1.0 / ls1, li2 = 1.0 / ls2;
+        for (uint32_t t = 0; t < n_iter; t++) {
+            if (t == flushed + kXtcGroup + 1u) {     // atoms < t - 1 are final
+                flush(flushed);
+                flushed += kXtcGroup;
+            }
+            const bool large = run_left == 0u;
+            const uint32_t nb = large ? d.bitsize : (uint32_t)smallidx;
+            const unsigned long long P = b.peek();
+            uint32_t used = nb;
+            int c3[3];
+            if (nb <= 53u) {
+                const double s1 = large ? ls1 : (double)sizesmall, s2 = large ? ls2 : (double)sizesmall;
+                const double i1 = large ? li1 : sinv, i2 = large ? li2 : sinv;
+                const uint32_t m = (nb - 1u) >> 3, rem = nb - 8u * m;      // m whole chunks (first lowest), rem bits on top
+                const unsigned long long x = P >> (64u - nb);
+                unsigned long long v = (x & ((1ull << rem) - 1ull)) << (8u * m);
+                if (m) v |= __builtin_bswap64((x >> rem) << (64u - 8u * m));
+                const double vd = (double)v;
+                double q2 = __builtin_floor(vd * i2);
+                double r2 = __builtin_fma(-q2, s2, vd);
+                if (r2 < 0.0) { q2 -= 1.0; r2 += s2; } else if (r2 >= s2) { q2 += 1.0; r2 -= s2; }
+                double q1 = __builtin_floor(q2 * i1);
+                double r1 = __builtin_fma(-q1, s1, q2);
+                if (r1 < 0.0) { q1 -= 1.0; r1 += s1; } else if (r1 >= s1) { q1 += 1.0; r1 -= s1; }
+                c3[0] = (int)(uint32_t)q1;
+                c3[1] = (int)(uint32_t)r1;
+                c3[2] = (int)(uint32_t)r2;
+            } else {      // small offsets beyond 2^17 grid steps (never seen; valid): the general unpacking, from the stream
+                xtc_ints(b, nb, sizesmall, sizesmall, rsmall, rsmall, c3);
+                used = 0;
+            }
+            if (large) {
+                c3[0] += d.minint[0]; c3[1] += d.minint[1]; c3[2] += d.minint[2];
+                int is_smaller = 0;
+                used += 1u;
+                if ((P >> (63u - nb)) & 1ull) {
+                    run = (int)((P >> (58u - nb)) & 31ull);
+                    used += 5u;
+                    is_smaller = run % 3;
+                    run -= is_smaller;
+                    is_smaller--;
+                }
+                b.skip(used);
+                prev[0] = c3[0]; prev[1] = c3[1]; prev[2] = c3[2];
+                if (run > 0) {
+                    run_left = (uint32_t)run / 3u;
+                    first = true;
+                    pend = is_smaller;
+                    if (t + 1u + run_left > natoms) { bad = true; run_left = 0; }
+                } else {
+                    put(c3, t);
+                    adapt(is_smaller);
+                }
+            } else {
+                b.skip(used);
+                int cur[3];
+                cur[0] = c3[0] + prev[0] - smallnum;
+                cur[1] = c3[1] + prev[1] - smallnum;
+                cur[2] = c3[2] + prev[2] - smallnum;
+                if (first) {             // stored AFTER the second atom of the run (water: O after H)
+                    put(cur, t - 1u);
+                    put(prev, t);
+                    first = false;
+                } else {
+                    put(cur, t);
+                }
+                prev[0] = cur[0]; prev[1] = cur[1]; prev[2] = cur[2];
+                if (--run_left == 0u) adapt(pend);
+            }
+        }
+    } else
+    // ---- every form of the format (edges beyond 2^24 grid steps, numbers of 54..72 bits): field by field
     for (uint32_t t = 0; t < n_iter; t++) {
         if (t == flushed + kXtcGroup + 1u) {     // atoms < t - 1 are final
             flush(flushed);

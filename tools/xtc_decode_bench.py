@@ -2,7 +2,7 @@
 """Throughput of k_xtc_decode (XTC frames decompressed on the device, one frame per lane) against the window size,
 next to the host decoder on all cores.
 
-    python tools/xtc_decode_bench.py [workload] [unique_frames]
+    python tools/xtc_decode_bench.py [workload] [unique_frames] [window,window,...]
 
 The repo's encoder writes `unique_frames` synthetic frames of the workload (precision 1000); the packed window is
 repeated on the device to the sizes measured (the frame table is tiled, the blob is shared)."""
@@ -43,7 +43,8 @@ def main():
     blob = torch.from_numpy(w["blob"]).cuda()
     out = {"workload": f"{name}: {desc}", "atoms_per_frame": n_atoms, "compressed_bytes_per_frame": size / n_unique,
            "host_decoder": {"frames_per_s": host_fps, "threads": cores}, "device": []}
-    for window in (256, 1024, 4096, 16384):
+    windows = [int(w) for w in sys.argv[3].split(",")] if len(sys.argv) > 3 else [256, 1024, 4096, 16384]
+    for window in windows:
         reps = (window + n_unique - 1) // n_unique
         table = np.tile(w["frames"], reps)[:window]
         frames = torch.from_numpy(table.view(np.uint8).reshape(-1).copy()).cuda()
