@@ -1552,7 +1552,7 @@ int gorder_hip_kernel_time(gorder_hip_handle *h, double *ms, uint64_t *launches,
 int xtc_decode_on(gorder_hip_handle *h, hipStream_t stream, const uint8_t *d_blob, uint64_t blob_bytes,
                   const gorder_xtc_frame_t *d_frames, uint32_t n_frames, uint32_t n_atoms_file, const int32_t *d_slot_of,
                   uint32_t n_stop, float *d_xyz, uint32_t n_atoms_out) {
-    if (!h || !d_blob || !d_frames || !d_xyz || blob_bytes < 32 || n_atoms_file == 0 || n_atoms_out == 0 ||
+    if (!h || !d_blob || !d_frames || !d_xyz || blob_bytes < 64 || (reinterpret_cast<uintptr_t>(d_blob) & 63u) != 0 || n_atoms_file == 0 || n_atoms_out == 0 ||
         n_stop > n_atoms_file || (!d_slot_of && n_atoms_out < n_stop))
         return fail(h, GORDER_ERR_INVALID_ARGUMENT, "gorder_hip_xtc_decode: bad arguments");
     if (n_frames == 0) return GORDER_OK;

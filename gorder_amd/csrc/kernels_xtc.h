@@ -23,6 +23,8 @@ namespace {
 constexpr int kXtcFirstIdx = 9, kXtcLastIdx = 73;
 constexpr uint32_t kXtcGroup = 8;      // atoms written out together (see k_xtc_decode)
 constexpr uint32_t kXtcWaves = 1;      // waves per workgroup (co-resident waves do not shorten a wave: 12 per CU measured 25 % slower, the loads of 64 streams each contend for the one address unit)
+constexpr uint32_t kXtcRingWords = 32;  // a lane's input ring in LDS: 256 bytes of its stream, refilled 64 bytes at a time
+constexpr uint32_t kXtcRingPitch = 33;  // words per lane (bank spread)
 constexpr uint32_t kXtcPitch = 65;     // floats per (atom, coordinate) row of the LDS staging: 64 frames + 1 (bank spread)
 __device__ const uint32_t kXtcMagic[kXtcLastIdx] = {
     0,       0,       0,       0,       0,       0,       0,       0,       0,       8,        10,       12,
@@ -34,17 +36,17 @@ __device__ const uint32_t kXtcMagic[kXtcLastIdx] = {
     16777216};
 
 struct XtcBits {
-    const unsigned long long *src, *end;   // next word to prefetch; one past the last readable word (the last ones are zero padding)
+    const unsigned long long *ring;        // this lane's ring of kXtcRingWords stream words in LDS (k_xtc_decode keeps it filled)
+    uint32_t rd;                           // words of the stream handed to the window so far
     unsigned long long w0, w1, pre;        // w0:w1 = the next 128 bits of the stream, MSB first; pre = the raw word behind them
     uint32_t off;                          // bits of w0 already taken
     unsigned long long taken;              // bits taken in all
-    __device__ __forceinline__ void open(const uint8_t *p, const uint8_t *p_end) {   // >= 24 readable bytes
-        src = reinterpret_cast<const unsigned long long *>(p);
-        end = reinterpret_cast<const unsigned long long *>(p_end);
-        w0 = __builtin_bswap64(src[0]);
-        w1 = __builtin_bswap64(src[1]);
-        pre = src[2];
-        src += 3;
+    __device__ __forceinline__ void open(const unsigned long long *lane_ring) {   // the first 3 words are in the ring
+        ring = lane_ring;
+        w0 = __builtin_bswap64(ring[0]);
+        w1 = __builtin_bswap64(ring[1]);
+        pre = ring[2];
+        rd = 3;
         off = 0;
         taken = 0;
     }
@@ -63,11 +65,8 @@ struct XtcBits {
             off -= 64u;
             w0 = w1;
             w1 = __builtin_bswap64(pre);
-            // a corrupt stream runs into the zero padding behind the block, never out of it.  The ADDRESS is clamped, not
-            // the value: a select on the loaded value would make the wave wait for the load right here (it did: 1 200 of
-            // the 2 100 cycles of an iteration), while the word is only needed at the next refill
-            pre = *(src < end ? src : end - 1);
-            src++;
+            pre = ring[rd & (kXtcRingWords - 1u)];      // an LDS read, waited for at the next refill only
+            rd++;
         }
     }
 };
@@ -175,9 +174,11 @@ __global__ __launch_bounds__(64 * kXtcWaves) void k_xtc_decode(const uint8_t *__
     const gorder_xtc_frame_t d = frames[live ? fr : n_frames - 1u];
     float *o = out + (size_t)(live ? fr : 0u) * n_out * 3u;      // (the raw path below)
     const float inv_p = d.inv_precision;
-    const unsigned long long padded = ((unsigned long long)d.n_bytes + 7ull) & ~7ull;
-    bool bad = (d.offset & 7ull) != 0ull || d.offset + padded + 32ull > blob_bytes;
+    // the frame's region of the blob: the block rounded up to whole 64-byte pieces plus one piece of zeros
+    const unsigned long long region = (((unsigned long long)d.n_bytes + 63ull) & ~63ull) + 64ull;
+    bool bad = (d.offset & 63ull) != 0ull || d.offset + region > blob_bytes;
     const uint8_t *p = blob + (bad ? 0ull : d.offset);
+    const unsigned long long last_piece = bad ? 0ull : region - 64ull;      // (a bad frame reads the blob's first piece, harmlessly)
 
     // Decoded atoms go through LDS: a lane writing its frame's atom straight to memory is one 4-byte piece in each of
     // 64 cache lines per store instruction.  Instead a lane parks atom i at l_atoms[i mod 16] and, once 8 consecutive
@@ -193,17 +194,22 @@ __global__ __launch_bounds__(64 * kXtcWaves) void k_xtc_decode(const uint8_t *__
         q[kXtcPitch] = (float)c[1] * inv_p;
         q[2u * kXtcPitch] = (float)c[2] * inv_p;
     };
-    auto flush = [&](uint32_t first_atom) {                  // atoms first_atom .. first_atom + 15, all final
+    // the output slot of the (atom, coordinate) this lane writes in the flush of the group that starts at first_atom
+    const uint32_t fl_half = lane >= 3u * kXtcGroup ? 1u : 0u, fl_l = lane - fl_half * 3u * kXtcGroup;
+    const uint32_t fl_j = fl_l / 3u, fl_c = fl_l - 3u * fl_j;
+    auto slot_for = [&](uint32_t first_atom) -> int32_t {
+        const uint32_t idx = first_atom + fl_j;
+        if (lane >= 6u * kXtcGroup || idx >= n_stop) return -1;
+        return slot_of ? slot_of[idx] : (int32_t)idx;
+    };
+    auto flush = [&](uint32_t first_atom, int32_t slot) {    // atoms first_atom .. first_atom + 7, all final
         // the wave reads what its own lanes wrote: LDS instructions of one wave execute in order, the fences only keep
         // the compiler from moving the reads up
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // lanes 0..23: (atom, coordinate) of the even frames, lanes 24..47: of the odd frames — 96 contiguous bytes each
-        const uint32_t half = lane >= 3u * kXtcGroup ? 1u : 0u, l = lane - half * 3u * kXtcGroup;
-        const uint32_t j = l / 3u, c = l - 3u * j, idx = first_atom + j;
-        int32_t slot = -1;
-        if (lane < 6u * kXtcGroup && idx < n_stop) slot = slot_of ? slot_of[idx] : (int32_t)idx;
+        const uint32_t half = fl_half, c = fl_c, idx = first_atom + fl_j;
         if (slot >= 0 && (uint32_t)slot < n_out) {
             const float *q = l_atoms + ((idx & (2u * kXtcGroup - 1u)) * 3u + c) * kXtcPitch;
             float *dst = out + ((size_t)frame0 * n_out + (uint32_t)slot) * 3u + c;
@@ -225,9 +231,54 @@ __global__ __launch_bounds__(64 * kXtcWaves) void k_xtc_decode(const uint8_t *__
         return;
     }
 
+    // ---- the input side: each lane's stream goes through a 256-byte ring in LDS, refilled in 64-byte pieces at the
+    // same points where the output is flushed.  A piece is REQUESTED at one service point (global loads into registers)
+    // and LANDED in the ring at the next one, eight atoms later: no instruction of the loop ever waits for memory, and
+    // the wait for the loads no longer waits for the flush's stores either (gfx9 counts both in vmcnt) — they are all
+    // one service point old by then.  A lane uses at most 78 bytes between two service points (8 atoms of 72 + 6 bits)
+    // and gets up to 128, a corrupt stream just runs into the region's zero piece (the piece ADDRESS is clamped).
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    __shared__ unsigned long long l_in_all[kXtcWaves * 64u * kXtcRingPitch];
+    unsigned long long *ring = l_in_all + (wave * 64u + lane) * kXtcRingPitch;
+    uint32_t wr = 0;                 // bytes of the stream landed in the ring (a multiple of 64)
+    uint32_t n_req = 0;              // pieces requested at the last service point (0..2)
+    u32x4 pc[8];
+    auto piece_at = [&](uint32_t off) {
+        return reinterpret_cast<const u32x4 *>(p + (off < last_piece ? (unsigned long long)off : last_piece));
+    };
+    auto land = [&](const u32x4 *v) {           // one piece into the ring at stream offset wr (8-byte stores: odd pitch)
+        unsigned long long *dst = ring + ((wr >> 3) & (kXtcRingWords - 1u));
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            dst[2 * k] = (unsigned long long)v[k].x | ((unsigned long long)v[k].y << 32);
+            dst[2 * k + 1] = (unsigned long long)v[k].z | ((unsigned long long)v[k].w << 32);
+        }
+        wr += 64u;
+    };
+    {   // the first four pieces, straight in
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; k++) {
+            const u32x4 *src = piece_at(64u * k);
+            pc[0] = src[0]; pc[1] = src[1]; pc[2] = src[2]; pc[3] = src[3];
+            land(pc);
+        }
+    }
     XtcBits b;
-    if (bad) b.open(blob, blob + 32);           // (blob holds at least 32 readable bytes) nothing of it is used
-    else b.open(p, p + padded + 32ull);
+    b.open(ring);
+    // A service point, every kXtcGroup atoms: land what was requested at the last one, flush the finished atoms, request
+    // the next pieces and the output slots of the next flush.  Every global load is consumed one service point after it
+    // was issued, so the only waits on memory are for operations eight atoms old.
+    int32_t slot_next = slot_for(0);
+    auto service = [&](uint32_t first_atom) {
+        if (n_req >= 1u) land(pc);
+        if (n_req == 2u) land(pc + 4);
+        flush(first_atom, slot_next);
+        slot_next = slot_for(first_atom + kXtcGroup);
+        const uint32_t room = 8u * kXtcRingWords - (wr - 8u * b.rd);        // bytes of the ring not holding unread stream
+        n_req = min(2u, room / 64u);
+        if (n_req >= 1u) { const u32x4 *src = piece_at(wr); pc[0] = src[0]; pc[1] = src[1]; pc[2] = src[2]; pc[3] = src[3]; }
+        if (n_req == 2u) { const u32x4 *src = piece_at(wr + 64u); pc[4] = src[0]; pc[5] = src[1]; pc[6] = src[2]; pc[7] = src[3]; }
+    };
     int smallidx = d.smallidx;
     if (smallidx < kXtcFirstIdx || smallidx >= kXtcLastIdx) { bad = true; smallidx = kXtcFirstIdx; }
     uint32_t sizesmall = l_magic[smallidx];
@@ -266,7 +317,7 @@ __global__ __launch_bounds__(64 * kXtcWaves) void k_xtc_decode(const uint8_t *__
         const double li1 = 1.0 / ls1, li2 = 1.0 / ls2;
         for (uint32_t t = 0; t < n_iter; t++) {
             if (t == flushed + kXtcGroup + 1u) {     // atoms < t - 1 are final
-                flush(flushed);
+                service(flushed);
                 flushed += kXtcGroup;
             }
             const bool large = run_left == 0u;
@@ -338,7 +389,7 @@ __global__ __launch_bounds__(64 * kXtcWaves) void k_xtc_decode(const uint8_t *__
     // ---- every form of the format (edges beyond 2^24 grid steps, numbers of 54..72 bits): field by field
     for (uint32_t t = 0; t < n_iter; t++) {
         if (t == flushed + kXtcGroup + 1u) {     // atoms < t - 1 are final
-            flush(flushed);
+            service(flushed);
             flushed += kXtcGroup;
         }
         if (run_left == 0u) {
@@ -385,7 +436,7 @@ __global__ __launch_bounds__(64 * kXtcWaves) void k_xtc_decode(const uint8_t *__
             if (--run_left == 0u) adapt(pend);
         }
     }
-    for (; flushed < n_stop; flushed += kXtcGroup) flush(flushed);
+    for (; flushed < n_stop; flushed += kXtcGroup) flush(flushed, slot_for(flushed));
     if (b.taken > 8ull * d.n_bytes) bad = true;          // read into the padding: a truncated block
     if (bad && live) raise_error(err, GORDER_ERR_TRAJECTORY_FORMAT, fr, kStageBox);
 }

@@ -957,7 +957,7 @@ int64_t gorder_xtc_pack_window(gorder_xtc_reader *r, float begin_ps, float end_p
         if (end_ps >= 0.0f && t > end_ps) { to_end = true; break; }
         const uint64_t k = (*state)++;
         if (k % step != 0) continue;
-        const uint64_t need = (((uint64_t)block + 7u) & ~7ull) + 32u;
+        const uint64_t need = (((uint64_t)block + 63u) & ~63ull) + 64u;     // whole 64-byte pieces + one piece of zeros
         if (used + need > blob_capacity) {                 // does not fit any more: this frame opens the next window
             if (src.empty()) return GORDER_XTC_ERR_ARGUMENT;
             (*state)--;
@@ -990,7 +990,7 @@ int64_t gorder_xtc_pack_window(gorder_xtc_reader *r, float begin_ps, float end_p
                 if (g <= 0) { status[w] = GORDER_XTC_ERR_FORMAT; return; }
                 done += (size_t)g;
             }
-            const size_t end = (size_t)((((uint64_t)src[i].n + 7u) & ~7ull) + 32u);
+            const size_t end = (size_t)((((uint64_t)src[i].n + 63u) & ~63ull) + 64u);
             memset(dst + src[i].n, 0, end - src[i].n);
         }
     };

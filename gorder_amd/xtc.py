@@ -141,7 +141,7 @@ def pack_trajectory(paths: Sequence[str], group: Optional[np.ndarray] = None, be
             if grp is not None:
                 slot_of = np.full(n_file, -1, dtype=np.int32)
                 slot_of[grp] = np.arange(grp.size, dtype=np.int32)
-            cap = blob_capacity or (chunk * (n_file * 12 + 128) + 4096)
+            cap = blob_capacity or (chunk * (n_file * 12 + 256) + 4096)
             while True:
                 blob = np.empty(cap, dtype=np.uint8)
                 frames = (CXtcFrame * chunk)()

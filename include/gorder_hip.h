@@ -274,7 +274,7 @@ int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_trajectory_t *t
 void gorder_hip_release_staging(gorder_hip_handle *h);
 
 /* Decompress XTC frames on the device (the decoding half of groan_rs' GroupXtcReader, common.rs:283-304):
- * `d_blob` / `d_frames` are device copies of what gorder_xtc_pack_window produced (blob_bytes >= 32), `d_slot_of`
+ * `d_blob` / `d_frames` are device copies of what gorder_xtc_pack_window produced (d_blob 64-byte aligned, blob_bytes >= 64), `d_slot_of`
  * [n_atoms_file] maps a file atom to its place in the output frame or -1 (NULL: every atom, in order), `n_stop` is
  * the number of atoms to go through (gorder_xtc_n_atoms_needed), `d_xyz` [n_frames][n_atoms_out][3] receives exactly
  * what gorder_xtc_next would have written, bit for bit.  Asynchronous on the handle's stream; a corrupt frame is

@@ -75,7 +75,8 @@ int64_t gorder_xtc_read_window_mt(gorder_xtc_reader *r, float begin_ps, float en
  * the device decodes one frame per lane.  Frame selection (time window, step, duplicate boundary frame), `state`,
  * `last_time`, box and time outputs are exactly those of gorder_xtc_read_window.  XTC only (not TRR / GRO). */
 typedef struct {
-    uint64_t offset;         /* of the frame's bit stream in the blob: a multiple of 8, followed by >= 32 zero bytes */
+    uint64_t offset;         /* of the frame's bit stream in the blob: a multiple of 64; the stream is followed by zeros up to
+                                the next multiple of 64 and by 64 more (the device reads whole 64-byte pieces) */
     uint64_t recip1, recip2; /* floor(2^64 / sizeint[1]), floor(2^64 / sizeint[2]) (all ones for a size of 1) */
     uint32_t n_bytes;        /* length of the bit stream, padded to a multiple of 4 as in the file */
     uint32_t kind;           /* 0: compressed; 1: raw big-endian floats (files of <= 9 atoms) */

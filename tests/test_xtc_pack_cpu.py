@@ -26,11 +26,11 @@ def synthetic(tmp_path, n_atoms=700, n_frames=23, precision=1000.0, span=6.0, se
 
 def check_layout(w):
     fr = w["frames"]
-    assert np.all(fr["offset"] % 8 == 0)
-    ends = fr["offset"] + ((fr["n_bytes"].astype(np.uint64) + 7) // 8) * 8 + 32
+    assert np.all(fr["offset"] % 64 == 0)
+    ends = fr["offset"] + ((fr["n_bytes"].astype(np.uint64) + 63) // 64) * 64 + 64
     assert np.all(ends[:-1] <= fr["offset"][1:]) and ends[-1] <= w["blob"].size
     for f in fr:      # the padding behind a block is zero
-        pad = w["blob"][int(f["offset"]) + int(f["n_bytes"]):int(f["offset"]) + ((int(f["n_bytes"]) + 7) // 8) * 8 + 32]
+        pad = w["blob"][int(f["offset"]) + int(f["n_bytes"]):int(f["offset"]) + ((int(f["n_bytes"]) + 63) // 64) * 64 + 64]
         assert not pad.any()
     assert np.all(fr["n_bytes"] % 4 == 0)
 
