@@ -169,6 +169,10 @@ if __name__ == "__main__":
             shutil.copy(src, os.path.join(HERE, "expected", f))
     # one small trajectory file as it is, for the reader's own tests (1 frame, 16 769 beads, 62 KB)
     shutil.copy(os.path.join(REF, "split", "cg3.xtc"), os.path.join(HERE, "cg3.xtc"))
+    # two more of the reference's trajectory files, as data for the decoders (device against host, bit for bit): one
+    # all-atom frame with its water (long runs of small offsets) and a small multi-frame system
+    shutil.copy(os.path.join(REF, "split", "pcpepg4.xtc"), os.path.join(HERE, "pcpepg4.xtc"))
+    shutil.copy(os.path.join(REF, "multiple_resid_same_name.xtc"), os.path.join(HERE, "multiple_resid_same_name.xtc"))
     # the 12 united-atom ordermaps compared by tests_ua.rs:351-410 (made from ua.xtc)
     os.makedirs(os.path.join(HERE, "expected", "ordermaps_ua"), exist_ok=True)
     for f in sorted(os.listdir(os.path.join(REF, "ordermaps_ua"))):

@@ -70,6 +70,19 @@ def test_reference_file(engine):
     same_bits(device_decode(engine, [CG3], group=group), xtc.read_trajectory([CG3], group=group)[0])
 
 
+@pytest.mark.parametrize("name", ["pcpepg4.xtc", "multiple_resid_same_name.xtc"])
+def test_more_reference_files(engine, name):
+    """an all-atom frame with its water (68 375 atoms, long runs of small offsets) and a small multi-frame system, both
+    from the reference's tests/files: whole frames and a scattered group"""
+    path = os.path.join(GOLDEN, name)
+    host = xtc.read_trajectory([path])[0]
+    assert host.shape[0] >= 1
+    same_bits(device_decode(engine, [path]), host)
+    n = host.shape[1]
+    group = np.unique(np.random.default_rng(4).integers(0, n, size=max(3, n // 7))).astype(np.uint32)[::-1].copy()
+    same_bits(device_decode(engine, [path], group=group), xtc.read_trajectory([path], group=group)[0])
+
+
 @pytest.mark.parametrize("precision", [10.0, 100.0, 1000.0, 12345.0])
 def test_encoder_files(engine, tmp_path, precision):
     rng = np.random.default_rng(int(precision))
