@@ -88,14 +88,15 @@ class CTrajectory(C.Structure):
     _fields_ = [("paths", C.POINTER(C.c_char_p)), ("n_paths", C.c_uint32), ("group", _u32p), ("n_group", C.c_uint32),
                 ("begin_ps", C.c_float), ("end_ps", C.c_float), ("step", C.c_uint32), ("n_threads", C.c_uint32),
                 ("batch_frames", C.c_uint32), ("first_frame_index", C.c_uint64), ("device_decode", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("shard_index", C.c_uint32), ("shard_count", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class CTrajectoryStats(C.Structure):
     _fields_ = [("n_frames", C.c_uint64), ("n_batches", C.c_uint64), ("bytes_h2d", C.c_uint64),
                 ("seconds_total", C.c_double), ("seconds_decode", C.c_double), ("seconds_reader_stalled", C.c_double),
                 ("seconds_gpu_starved", C.c_double), ("batch_frames", C.c_uint32), ("decoder_threads", C.c_uint32),
-                ("device_decode", C.c_uint32), ("reserved", C.c_uint32), ("seconds_setup", C.c_double)]
+                ("device_decode", C.c_uint32), ("reserved", C.c_uint32), ("shard_first", C.c_uint64),
+                ("shard_frames_total", C.c_uint64), ("seconds_setup", C.c_double)]
 
 
 class CXtcFrame(C.Structure):
@@ -519,11 +520,13 @@ class HipEngine:
                                                     fi.ctypes.data_as(C.c_void_p), n_frames))
 
     def run_trajectory(self, paths, group=None, begin: float = 0.0, end: float = -1.0, step: int = 1, threads: int = 0,
-                       batch_frames: int = 0, first_frame_index: int = 0, device_decode: bool = False) -> dict:
+                       batch_frames: int = 0, first_frame_index: int = 0, device_decode: bool = False,
+                       shard=None) -> dict:
         """The reference's `read_trajectory` (common.rs:239-342) as one library call: read (and concatenate) the
         files, apply the time window / step, decode on `threads` host threads and analyse batch by batch with copies
         and kernels overlapped (gorder_hip_run_trajectory).  `device_decode`: the host threads only copy the compressed
-        XTC blocks, the device unpacks them (one frame per lane).  -> the pipeline's statistics."""
+        XTC blocks, the device unpacks them (one frame per lane).  `shard` = (i, n): analyse only the i-th of n
+        contiguous shares of the selected frames (one rank of a multi-GPU run).  -> the pipeline's statistics."""
         arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
         grp = None if group is None else np.ascontiguousarray(group, dtype=np.uint32)
         t = CTrajectory()
@@ -534,6 +537,8 @@ class HipEngine:
         t.begin_ps, t.end_ps, t.step = begin, end, step
         t.n_threads, t.batch_frames, t.first_frame_index = threads, batch_frames, first_frame_index
         t.device_decode = 1 if device_decode else 0
+        if shard is not None:          # (index, count): this rank's contiguous share of the selected frames
+            t.shard_index, t.shard_count = shard
         stats = CTrajectoryStats()
         self._check(self.lib.gorder_hip_run_trajectory(self._h, C.byref(t), C.byref(stats)))
         return {name: getattr(stats, name) for name, _ in CTrajectoryStats._fields_}

@@ -134,6 +134,26 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
         slot_of.assign(n_file_atoms, -1);
         for (uint32_t k = 0; k < tr->n_group; k++) slot_of[tr->group[k]] = (int32_t)k;     // (gorder_xtc_open checked the range)
     }
+    // contiguous frame shards: count what the window selects, headers only, and take this rank's share
+    uint64_t shard_lo = 0, shard_n = UINT64_MAX, shard_total = 0;
+    if (tr->shard_count > 1) {
+        if (tr->shard_index >= tr->shard_count) return fail(h, GORDER_ERR_INVALID_ARGUMENT, "shard_index >= shard_count");
+        uint64_t state = 0;
+        double last_time = -INFINITY;
+        for (uint32_t f = 0; f < tr->n_paths; f++) {
+            gorder_xtc_reader *r = nullptr;
+            int st = gorder_xtc_open(tr->paths[f], nullptr, 0, &r);
+            int64_t n = st;
+            if (st == GORDER_XTC_OK) n = gorder_xtc_skip_window(r, tr->begin_ps, tr->end_ps, tr->step, &state, &last_time, UINT64_MAX);
+            if (r) gorder_xtc_close(r);
+            if (n < 0)
+                return fail(h, n == GORDER_XTC_ERR_FORMAT ? GORDER_ERR_TRAJECTORY_FORMAT : GORDER_ERR_INVALID_ARGUMENT,
+                            std::string("cannot read ") + tr->paths[f] + " (reader status " + std::to_string(n) + ")");
+            shard_total += (uint64_t)n;
+        }
+        shard_lo = shard_total * tr->shard_index / tr->shard_count;
+        shard_n = shard_total * (tr->shard_index + 1ull) / tr->shard_count - shard_lo;
+    }
     // frames per batch: ~128 MB of coordinates per slot unless the host asks otherwise (>= 16 so that the launches
     // amortise; a batch is also what one decoder pass spreads over its threads).  The device decoder works one frame
     // per lane: its batches are as large as 1 GiB of coordinates allows, up to 16384 frames, and there are four slots
@@ -236,11 +256,12 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
     const int device = h->device;
     std::thread reader([&, device]() {
         (void)hipSetDevice(device);
-        uint64_t state = 0, analysed = 0;
+        uint64_t state = 0, analysed = shard_lo;   // (frames are numbered as in the whole trajectory)
         double last_time = -INFINITY;
         uint32_t f = 0;                       // next file to open
         gorder_xtc_reader *r = nullptr;       // the open one
-        bool done = false;
+        bool done = shard_n == 0;
+        uint64_t to_skip = shard_lo, left = shard_n;      // frames before this rank's shard; frames of it still to read
         auto give_up = [&](int st, const std::string &msg) {
             std::lock_guard<std::mutex> lk(pipe.mu);
             pipe.reader_status = st;
@@ -270,6 +291,7 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
             s.n = 0;
             s.blob_bytes = 0;
             while (!done && s.n < batch) {
+                if (left == 0) { done = true; break; }
                 if (!r) {
                     if (f == tr->n_paths) { done = true; break; }
                     int st = gorder_xtc_open(tr->paths[f], tr->group, tr->n_group, &r);
@@ -280,14 +302,26 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
                         break;
                     }
                 }
+                if (to_skip) {                           // pass over the frames of the ranks before this one
+                    const int64_t sk = gorder_xtc_skip_window(r, tr->begin_ps, tr->end_ps, tr->step, &state, &last_time, to_skip);
+                    if (sk < 0) { give_up((int)sk, std::string("read error in ") + tr->paths[f]); break; }
+                    to_skip -= (uint64_t)sk;
+                    if (to_skip) {                       // this file ended inside the part to pass over
+                        gorder_xtc_close(r);
+                        r = nullptr;
+                        f++;
+                        continue;
+                    }
+                }
+                const uint64_t want = std::min<uint64_t>(batch - s.n, left);
                 uint64_t used = 0;
                 const int64_t got =
                     dev ? gorder_xtc_pack_window(r, tr->begin_ps, tr->end_ps, tr->step, &state, &last_time,
                                                  s.h_blob + s.blob_bytes, blob_cap - s.blob_bytes, &used, s.h_frames + s.n,
-                                                 s.h_box + 9u * (size_t)s.n, s.h_time + s.n, batch - s.n, n_threads)
+                                                 s.h_box + 9u * (size_t)s.n, s.h_time + s.n, want, n_threads)
                         : gorder_xtc_read_window_mt(r, tr->begin_ps, tr->end_ps, tr->step, &state, &last_time,
                                                     s.h_xyz + (size_t)s.n * n_atoms * 3u, s.h_box + 9u * (size_t)s.n,
-                                                    s.h_time + s.n, batch - s.n, n_threads);
+                                                    s.h_time + s.n, want, n_threads);
                 if (dev && got == GORDER_XTC_ERR_ARGUMENT && s.n > 0) break;      // the blob is full: this batch is complete
                 if (got < 0) {
                     give_up((int)got, std::string("read error in ") + tr->paths[f]);
@@ -304,6 +338,7 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
                     s.blob_bytes += used;
                 }
                 s.n += (uint32_t)got;
+                left -= (uint64_t)got;
             }
             const double dt = seconds_since(t1);
             std::lock_guard<std::mutex> lk(pipe.mu);
@@ -421,6 +456,8 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
         stats->device_decode = dev ? 1u : 0u;
         stats->reserved = 0;
         stats->seconds_setup = setup_s + pipe.setup_s;
+        stats->shard_first = shard_lo;
+        stats->shard_frames_total = tr->shard_count > 1 ? shard_total : frames;
     }
     cleanup();
     if (pipe.alloc_failed) traj_cache_free(h);      // (a slot that is only partly there)

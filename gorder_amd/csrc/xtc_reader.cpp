@@ -825,6 +825,26 @@ int64_t gorder_xtc_read_window(gorder_xtc_reader *r, float begin_ps, float end_p
     return (int64_t)written;
 }
 
+int64_t gorder_xtc_skip_window(gorder_xtc_reader *r, float begin_ps, float end_ps, uint32_t step, uint64_t *state,
+                               double *last_time, uint64_t max_frames) {
+    if (!r || !state || !last_time || step == 0) return GORDER_XTC_ERR_ARGUMENT;
+    uint64_t passed = 0;
+    while (passed < max_frames) {
+        float t = 0.0f;
+        const int st = gorder_xtc_next(r, nullptr, nullptr, nullptr, &t, nullptr);
+        if (st == GORDER_XTC_EOF) break;
+        if (st != GORDER_XTC_OK) return st;
+        if ((double)t == *last_time) continue;             // duplicate frame at a file boundary
+        *last_time = (double)t;
+        if (t < begin_ps) continue;
+        if (end_ps >= 0.0f && t > end_ps) { fseek(r->fp, 0, SEEK_END); break; }
+        const uint64_t k = (*state)++;
+        if (k % step != 0) continue;
+        passed++;
+    }
+    return (int64_t)passed;
+}
+
 int64_t gorder_xtc_read_window_mt(gorder_xtc_reader *r, float begin_ps, float end_ps, uint32_t step,
                                   uint64_t *state, double *last_time, float *xyz, float *box9, float *time_ps,
                                   uint64_t capacity, uint32_t n_threads) {

@@ -34,6 +34,9 @@ def _lib():
                                                C.POINTER(C.c_double), vp, C.c_uint64, C.POINTER(C.c_uint64), vp, vp, vp,
                                                C.c_uint64, C.c_uint32]
         lib.gorder_xtc_pack_window.restype = C.c_int64
+        lib.gorder_xtc_skip_window.argtypes = [vp, C.c_float, C.c_float, C.c_uint32, C.POINTER(C.c_uint64),
+                                               C.POINTER(C.c_double), C.c_uint64]
+        lib.gorder_xtc_skip_window.restype = C.c_int64
         lib.gorder_xtc_is_xtc.argtypes = [vp]
         lib.gorder_xtc_probe.argtypes = [C.c_char_p, C.POINTER(C.c_uint32)]
         lib.gorder_xtc_n_atoms_needed.argtypes = [vp]
@@ -161,3 +164,23 @@ def pack_trajectory(paths: Sequence[str], group: Optional[np.ndarray] = None, be
         finally:
             lib.gorder_xtc_close(r)
     return out
+
+
+def count_frames(paths: Sequence[str], begin: float = 0.0, end: float = -1.0, step: int = 1) -> int:
+    """How many frames `read_trajectory` would return, from the headers alone (gorder_xtc_skip_window)."""
+    lib = _lib()
+    state, last = C.c_uint64(0), C.c_double(float("-inf"))
+    total = 0
+    for path in paths:
+        r = C.c_void_p()
+        st = lib.gorder_xtc_open(path.encode(), None, 0, C.byref(r))
+        if st != 0:
+            raise IOError(f"cannot open {path}: status {st}")
+        try:
+            n = lib.gorder_xtc_skip_window(r, begin, end, step, C.byref(state), C.byref(last), 2 ** 64 - 1)
+            if n < 0:
+                raise IOError(f"{path}: XTC read error {n}")
+            total += n
+        finally:
+            lib.gorder_xtc_close(r)
+    return total

@@ -248,6 +248,13 @@ typedef struct {
                                     (about a third of the decoded bytes) and gorder_hip_xtc_decode unpacks one frame
                                     per lane.  Same coordinates bit for bit.  A run with a TRR or GRO file in it
                                     falls back to the host decoder for the whole run.  0: host decoder threads */
+    uint32_t shard_index;        /* SURVEY 8e, contiguous frame shards: with shard_count = n > 1 the call first counts the F frames */
+    uint32_t shard_count;        /* the window selects (headers only), then analyses frames [i F / n, (i + 1) F / n) of them,
+                                    numbered as in the whole trajectory (first_frame_index + k * step for the k-th selected
+                                    frame).  Every rank passes the same trajectory and its own i; gorder_hip_allreduce (or the
+                                    host's own reduction) then gives SystemTopology::reduce's result.  With a leaflet frequency
+                                    other than every frame the rank still primes its shard's first assignment itself
+                                    (gorder_hip_prime_leaflets).  0 or 1: the whole trajectory */
     uint32_t reserved;
 } gorder_trajectory_t;
 
@@ -261,6 +268,7 @@ typedef struct {
     double seconds_gpu_starved;      /* the submitter waited for a decoded batch: the decoder is the bottleneck */
     uint32_t batch_frames, decoder_threads;   /* what was used */
     uint32_t device_decode, reserved;         /* 1: the frames were decompressed on the device */
+    uint64_t shard_first, shard_frames_total;   /* with shards: ordinal of this shard's first frame among the F selected; F */
     double seconds_setup;            /* time spent allocating the pinned and device staging buffers (all but the first slot's
                                         share overlaps with reading) */
 } gorder_trajectory_stats_t;

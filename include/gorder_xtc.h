@@ -60,6 +60,13 @@ int64_t gorder_xtc_read_window(gorder_xtc_reader *r, float begin_ps, float end_p
                                uint64_t *state, double *last_time, float *xyz, float *box9, float *time_ps,
                                uint64_t capacity);
 
+/* Pass over up to `max_frames` frames the window selects WITHOUT decoding them (headers only; any format): same
+ * selection, `state` and `last_time` bookkeeping as gorder_xtc_read_window.  Returns how many were passed over (fewer
+ * than max_frames: the file ended) or a negative status.  With max_frames = UINT64_MAX it counts the selected frames of
+ * a file; with a smaller number it positions a reader at the start of a rank's shard of the trajectory. */
+int64_t gorder_xtc_skip_window(gorder_xtc_reader *r, float begin_ps, float end_ps, uint32_t step, uint64_t *state,
+                               double *last_time, uint64_t max_frames);
+
 /* The same with `n_threads` decoder threads: the frame headers are scanned sequentially (cheap), the selected
  * frames are then decompressed in parallel, each worker through a file handle of its own.  Output, state and
  * return value are identical to gorder_xtc_read_window for every n_threads (the reference decodes one reader

@@ -147,3 +147,36 @@ def test_submit_host_is_double_buffered(cg):
     _, many = npz_route(tables, cg, midx, frames, frames, batches=37)
     _, one = npz_route(tables, cg, midx, frames, frames, batches=1)
     assert_same(many, one)
+
+
+@pytest.mark.parametrize("device_decode", [False, True])
+def test_frame_shards_add_up_to_the_whole_trajectory(cg, tmp_path, device_decode):
+    """SURVEY 8e through the driver: n ranks pass the same files and (i, n); each analyses a contiguous share of the
+    frames the window selects, and the shares' accumulators add up to the single-handle result exactly (what
+    gorder_hip_allreduce / SystemTopology::reduce then does across GPUs)."""
+    tables, labels, midx = cg_setup(cg, leaflets=METHODS["global"])
+    a, b = str(tmp_path / "a.xtc"), str(tmp_path / "b.xtc")
+    xtc.write_trajectory(a, cg.xyz[:37], cg.boxes[:37], times=cg.times[:37], precision=100.0)
+    xtc.write_trajectory(b, cg.xyz[36:], cg.boxes[36:], times=cg.times[36:], precision=100.0)     # duplicate boundary frame
+    for kw, total in ((dict(), 101), (dict(begin=float(cg.times[5]), end=float(cg.times[95]), step=3), 31)):
+        whole = HipEngine(tables)
+        st = whole.run_trajectory([a, b], group=midx, threads=2, device_decode=device_decode, **kw)
+        want = whole.finish()
+        assert st["n_frames"] == total == want.n_frames
+        for n in (2, 3, 7):
+            sums = np.zeros_like(want.sums)
+            counts = np.zeros_like(want.counts)
+            first = 0
+            for i in range(n):
+                eng = HipEngine(tables)
+                st = eng.run_trajectory([a, b], group=midx, threads=2, device_decode=device_decode, batch_frames=8,
+                                        shard=(i, n), **kw)
+                assert st["shard_frames_total"] == total and st["shard_first"] == first == total * i // n
+                assert st["n_frames"] == total * (i + 1) // n - first
+                first += st["n_frames"]
+                got = eng.finish()
+                sums += got.sums
+                counts += got.counts
+            assert first == total
+            np.testing.assert_array_equal(sums, want.sums)
+            np.testing.assert_array_equal(counts, want.counts)

@@ -50,6 +50,14 @@ def test_pack_selects_what_read_selects(built, tmp_path):
                 assert w["n_atoms_file"] == 700 and w["n_stop"] == 700 and w["slot_of"] is None
 
 
+def test_skip_counts_what_read_returns(built, tmp_path):
+    a = synthetic(tmp_path, n_frames=13, name="a.xtc")
+    b = synthetic(tmp_path, n_frames=9, seed=8, name="b.xtc")       # times 0..80: overlaps a's, only later ones are new
+    for kw in (dict(), dict(begin=25.0, end=95.0, step=2), dict(step=4), dict(begin=1e9)):
+        assert xtc.count_frames([a, b], **kw) == len(xtc.read_trajectory([a, b], **kw)[2])
+    assert xtc.count_frames([CG3]) == 1
+
+
 def test_pack_continues_when_the_blob_is_full(built, tmp_path):
     path = synthetic(tmp_path, n_frames=11)
     one = xtc.pack_trajectory([path], chunk=64)
