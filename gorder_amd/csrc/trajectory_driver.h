@@ -154,6 +154,44 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
         shard_lo = shard_total * tr->shard_index / tr->shard_count;
         shard_n = shard_total * (tr->shard_index + 1ull) / tr->shard_count - shard_lo;
     }
+    // A shard that begins between two assignment frames (leaflet frequency Every(n) / Once) depends on ONE frame of an
+    // earlier rank's share: fetch it (host decoder, one frame) and prime the handle with it, so that sharded ranks need
+    // nothing from the host beyond (i, n) — the cross-thread wait of leaflets.rs:1529-1565 becomes one extra frame read.
+    {
+        const gorder_leaflets_t &lf = h->tables.leaflets;
+        const uint64_t f_first = tr->first_frame_index + shard_lo * tr->step;
+        const uint64_t f_assign = lf.frequency == 0 ? tr->first_frame_index
+                                                    : f_first / lf.frequency * lf.frequency;
+        if (tr->shard_count > 1 && shard_n > 0 && lf.method != GORDER_LEAFLETS_NONE && lf.method != GORDER_LEAFLETS_MANUAL &&
+            f_assign != f_first && f_assign >= tr->first_frame_index && (f_assign - tr->first_frame_index) % tr->step == 0) {
+            uint64_t to_skip = (f_assign - tr->first_frame_index) / tr->step, state = 0;
+            double last_time = -INFINITY;
+            std::vector<float> x((size_t)n_atoms * 3u), bx(9);
+            float t_ps = 0.0f;
+            int64_t got = 0;
+            for (uint32_t f = 0; f < tr->n_paths && got == 0; f++) {
+                gorder_xtc_reader *r = nullptr;
+                if (gorder_xtc_open(tr->paths[f], tr->group, tr->n_group, &r) != GORDER_XTC_OK) break;
+                const int64_t sk = gorder_xtc_skip_window(r, tr->begin_ps, tr->end_ps, tr->step, &state, &last_time, to_skip);
+                if (sk >= 0) to_skip -= (uint64_t)sk;
+                if (sk >= 0 && to_skip == 0 && gorder_xtc_n_atoms_out(r) == n_atoms)
+                    got = gorder_xtc_read_window(r, tr->begin_ps, tr->end_ps, tr->step, &state, &last_time, x.data(), bx.data(), &t_ps, 1);
+                gorder_xtc_close(r);
+                if (sk < 0) break;
+            }
+            if (got != 1) return fail(h, GORDER_ERR_INVALID_ARGUMENT, "cannot read the leaflet assignment frame that precedes this shard");
+            float *d_x = nullptr, *d_b = nullptr;
+            HIP_TRY(h, hipMalloc((void **)&d_x, x.size() * sizeof(float)));
+            HIP_TRY(h, hipMalloc((void **)&d_b, 9 * sizeof(float)));
+            hipError_t e = hipMemcpy(d_x, x.data(), x.size() * sizeof(float), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(d_b, bx.data(), 9 * sizeof(float), hipMemcpyHostToDevice);
+            int st = e == hipSuccess ? gorder_hip_prime_leaflets(h, d_x, h->tables.handle_pbc ? d_b : nullptr, f_assign) : GORDER_ERR_DEVICE;
+            if (st == GORDER_OK) st = gorder_hip_synchronize(h);       // (the buffers go away below)
+            (void)hipFree(d_x);
+            (void)hipFree(d_b);
+            if (st != GORDER_OK) return st;
+        }
+    }
     // frames per batch: ~128 MB of coordinates per slot unless the host asks otherwise (>= 16 so that the launches
     // amortise; a batch is also what one decoder pass spreads over its threads).  The device decoder works one frame
     // per lane: its batches are as large as 1 GiB of coordinates allows, up to 16384 frames, and there are four slots

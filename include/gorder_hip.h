@@ -253,8 +253,9 @@ typedef struct {
                                     numbered as in the whole trajectory (first_frame_index + k * step for the k-th selected
                                     frame).  Every rank passes the same trajectory and its own i; gorder_hip_allreduce (or the
                                     host's own reduction) then gives SystemTopology::reduce's result.  With a leaflet frequency
-                                    other than every frame the rank still primes its shard's first assignment itself
-                                    (gorder_hip_prime_leaflets).  0 or 1: the whole trajectory */
+                                    other than every frame a shard that begins between two assignment frames reads the one
+                                    frame it depends on itself and primes the handle with it (gorder_hip_prime_leaflets).
+                                    0 or 1: the whole trajectory */
     uint32_t reserved;
 } gorder_trajectory_t;
 

@@ -180,3 +180,37 @@ def test_frame_shards_add_up_to_the_whole_trajectory(cg, tmp_path, device_decode
             assert first == total
             np.testing.assert_array_equal(sums, want.sums)
             np.testing.assert_array_equal(counts, want.counts)
+
+
+@pytest.mark.parametrize("method,frequency", [("global", 5), ("individual", 0), ("local", 3)])
+def test_frame_shards_prime_their_leaflets(cg, tmp_path, method, frequency):
+    """a leaflet frequency other than every frame: a shard that begins between two assignment frames fetches the one
+    frame it depends on itself (the cross-thread wait of leaflets.rs:1529-1565 as one extra frame read); lipids are
+    made to change sides over the trajectory so that WHICH assignment a frame uses shows in the result"""
+    tables, labels, midx = cg_setup(cg, leaflets=METHODS[method], frequency=frequency)
+    xyz = cg.xyz[:40].copy()
+    zmid = float(cg.boxes[0][2, 2]) / 2.0
+    heads = np.asarray(tables.molecule_types[0].heads)
+    per = int(np.diff(np.sort(heads))[0]) if len(heads) > 1 else 12
+    for f in range(40):                 # from frame f on, lipid f of the first type is mirrored through the mid-plane
+        a0 = int(midx[np.sort(heads)[f]])
+        sl = slice(a0, a0 + per)
+        xyz[f:, sl, 2] = 2.0 * zmid - xyz[f:, sl, 2]
+    path = str(tmp_path / "flip.xtc")
+    xtc.write_trajectory(path, xyz, cg.boxes[:40], times=cg.times[:40], precision=100.0)
+    whole = HipEngine(tables)
+    whole.run_trajectory([path], group=midx, threads=2)
+    want = whole.finish()
+    every = HipEngine(cg_setup(cg, leaflets=METHODS[method], frequency=1)[0])
+    every.run_trajectory([path], group=midx, threads=2)
+    assert not np.array_equal(every.finish().sums, want.sums)          # the frequency matters on this trajectory
+    for n in (2, 3, 7):
+        sums, counts = np.zeros_like(want.sums), np.zeros_like(want.counts)
+        for i in range(n):
+            eng = HipEngine(tables)
+            eng.run_trajectory([path], group=midx, threads=2, device_decode=bool(i % 2), batch_frames=8, shard=(i, n))
+            got = eng.finish()
+            sums += got.sums
+            counts += got.counts
+        np.testing.assert_array_equal(sums, want.sums)
+        np.testing.assert_array_equal(counts, want.counts)
