@@ -308,7 +308,7 @@ int fold_maps(gorder_hip_handle *h) {
 // the cell list of `ns` slab frames (k_local_build, or bin / scan / scatter for very large atom sets); `counts` are the
 // lo.cell_count and lo.cell_fill words the three-kernel form needs zeroed
 int launch_cell_list(gorder_hip_handle *h, const LocalArgs &lo, uint32_t ns, uint32_t n_list, void *counts, size_t count_bytes) {
-    static const bool three = env_flag("GORDER_HIP_LOCAL_THREE_KERNELS");      // A/B switch
+    const bool three = env_flag("GORDER_HIP_LOCAL_THREE_KERNELS");   // A/B switch; also what membranes beyond kLocalBuildMax take
     if (n_list <= kLocalBuildMax && !three) {
         hipLaunchKernelGGL(k_local_build, dim3(ns), dim3(1024), kLocalBuildLds, h->stream, lo);
         return GORDER_OK;

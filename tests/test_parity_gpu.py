@@ -109,11 +109,18 @@ def test_cg_global_leaflets_mixed_types(built, flags):
     np.testing.assert_allclose(eng.leaflet_distances(), odist, atol=2e-5)
 
 
+@pytest.mark.parametrize("cell_list", ["one kernel", "three kernels", "atoms only"])
 @pytest.mark.parametrize("pbc", [True, False])
 @pytest.mark.parametrize("radius,n_lipids", [(2.5, 800), (1.2, 300), (30.0, 120), (6.0, 1000)])
-def test_local_leaflets(built, radius, n_lipids, pbc):
+def test_local_leaflets(built, monkeypatch, radius, n_lipids, pbc, cell_list):
     """Local classification (leaflets.rs:661-675 + pbc.rs:273-318): cylinder membership is restated with
-    identical f32 operations, so flags must agree unless a head sits within 1e-4 nm of its local centre."""
+    identical f32 operations, so flags must agree unless a head sits within 1e-4 nm of its local centre.
+    Every way the device builds and walks the cell list: k_local_build (default), bin / scan / scatter (what membranes
+    beyond 65 536 atoms take), and without the per-cell sums (every candidate atom by atom)."""
+    if cell_list == "three kernels":
+        monkeypatch.setenv("GORDER_HIP_LOCAL_THREE_KERNELS", "1")
+    if cell_list == "atoms only":
+        monkeypatch.setenv("GORDER_HIP_LOCAL_ATOMS_ONLY", "1")
     system = synthetic.cg_membrane(n_lipids, leaflets=LEAFLETS_LOCAL, radius=radius, n_types=2, handle_pbc=pbc)
     n = 7
     xyz = system.frames(n, seed=17)
