@@ -181,11 +181,12 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
             }
             if (got != 1) return fail(h, GORDER_ERR_INVALID_ARGUMENT, "cannot read the leaflet assignment frame that precedes this shard");
             float *d_x = nullptr, *d_b = nullptr;
-            HIP_TRY(h, hipMalloc((void **)&d_x, x.size() * sizeof(float)));
-            HIP_TRY(h, hipMalloc((void **)&d_b, 9 * sizeof(float)));
-            hipError_t e = hipMemcpy(d_x, x.data(), x.size() * sizeof(float), hipMemcpyHostToDevice);
+            hipError_t e = hipMalloc((void **)&d_x, x.size() * sizeof(float));
+            if (e == hipSuccess) e = hipMalloc((void **)&d_b, 9 * sizeof(float));
+            if (e == hipSuccess) e = hipMemcpy(d_x, x.data(), x.size() * sizeof(float), hipMemcpyHostToDevice);
             if (e == hipSuccess) e = hipMemcpy(d_b, bx.data(), 9 * sizeof(float), hipMemcpyHostToDevice);
-            int st = e == hipSuccess ? gorder_hip_prime_leaflets(h, d_x, h->tables.handle_pbc ? d_b : nullptr, f_assign) : GORDER_ERR_DEVICE;
+            int st = e == hipSuccess ? gorder_hip_prime_leaflets(h, d_x, h->tables.handle_pbc ? d_b : nullptr, f_assign)
+                                     : fail(h, GORDER_ERR_DEVICE, std::string("priming frame: ") + hipGetErrorString(e));
             if (st == GORDER_OK) st = gorder_hip_synchronize(h);       // (the buffers go away below)
             (void)hipFree(d_x);
             (void)hipFree(d_b);
