@@ -291,6 +291,10 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
     });
     const double setup_s = seconds_since(t_start);
 
+    // the device route's block copies go to a pool that outlives a window: the header scan of the next file or window
+    // runs while the blocks of this one are still being copied
+    gorder_xtc_pool *pool = nullptr;
+    if (dev && gorder_xtc_pool_create(n_threads, &pool) != GORDER_XTC_OK) pool = nullptr;
     // ---- reader thread: the sequential part of read_trajectory (time window, step, concatenation) + decoding
     const int device = h->device;
     std::thread reader([&, device]() {
@@ -355,9 +359,12 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
                 const uint64_t want = std::min<uint64_t>(batch - s.n, left);
                 uint64_t used = 0;
                 const int64_t got =
-                    dev ? gorder_xtc_pack_window(r, tr->begin_ps, tr->end_ps, tr->step, &state, &last_time,
-                                                 s.h_blob + s.blob_bytes, blob_cap - s.blob_bytes, &used, s.h_frames + s.n,
-                                                 s.h_box + 9u * (size_t)s.n, s.h_time + s.n, want, n_threads)
+                    dev ? (pool ? gorder_xtc_pack_window_pool(r, tr->begin_ps, tr->end_ps, tr->step, &state, &last_time,
+                                                              s.h_blob + s.blob_bytes, blob_cap - s.blob_bytes, &used,
+                                                              s.h_frames + s.n, s.h_box + 9u * (size_t)s.n, s.h_time + s.n, want, pool)
+                                 : gorder_xtc_pack_window(r, tr->begin_ps, tr->end_ps, tr->step, &state, &last_time,
+                                                          s.h_blob + s.blob_bytes, blob_cap - s.blob_bytes, &used, s.h_frames + s.n,
+                                                          s.h_box + 9u * (size_t)s.n, s.h_time + s.n, want, n_threads))
                         : gorder_xtc_read_window_mt(r, tr->begin_ps, tr->end_ps, tr->step, &state, &last_time,
                                                     s.h_xyz + (size_t)s.n * n_atoms * 3u, s.h_box + 9u * (size_t)s.n,
                                                     s.h_time + s.n, want, n_threads);
@@ -378,6 +385,11 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
                 }
                 s.n += (uint32_t)got;
                 left -= (uint64_t)got;
+            }
+            if (pool) {                                  // the slot's blocks are complete only now
+                const int cst = gorder_xtc_pool_wait(pool);
+                if (cst != GORDER_XTC_OK && !done) give_up(cst, "read error while copying the compressed blocks");
+                else if (cst != GORDER_XTC_OK) { std::lock_guard<std::mutex> lk(pipe.mu); if (pipe.reader_status == GORDER_XTC_OK) { pipe.reader_status = cst; pipe.reader_msg = "read error while copying the compressed blocks"; } }
             }
             const double dt = seconds_since(t1);
             std::lock_guard<std::mutex> lk(pipe.mu);
@@ -471,6 +483,7 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
     }
     reader.join();
     allocator.join();
+    if (pool) gorder_xtc_pool_destroy(pool);
     (void)hipStreamSynchronize(copy_stream);
     for (int k = 0; k < TrajPipe::kSlots; k++)
         if (pipe.slot[k].stream) (void)hipStreamSynchronize(pipe.slot[k].stream);

@@ -16,6 +16,12 @@
 #include <cstring>
 #include <string>
 #include <string>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <unistd.h>
 #include <vector>
@@ -893,7 +899,65 @@ int64_t gorder_xtc_read_window_mt(gorder_xtc_reader *r, float begin_ps, float en
 }  // extern "C"
 
 // ---- packing for the device decoder ------------------------------------------------------------------
+// A pool of copying threads that outlives one window: gorder_xtc_pack_window_pool hands the block copies of a window
+// to it and returns as soon as the headers are scanned, so that the (sequential) header scan of the next file or window
+// runs while the blocks of this one are still being copied (scan 0.28 ms + copy 0.83 ms per 500 V-AA frames, measured).
+struct gorder_xtc_pool {
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_idle;
+    std::deque<std::function<int()>> jobs;
+    size_t running = 0;
+    int status = GORDER_XTC_OK;      // first failure since the last wait
+    bool stop = false;
+    void loop() {
+        for (;;) {
+            std::function<int()> job;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return stop || !jobs.empty(); });
+                if (jobs.empty()) return;
+                job = std::move(jobs.front());
+                jobs.pop_front();
+                running++;
+            }
+            const int st = job();
+            std::lock_guard<std::mutex> lk(mu);
+            if (st != GORDER_XTC_OK && status == GORDER_XTC_OK) status = st;
+            running--;
+            if (jobs.empty() && running == 0) cv_idle.notify_all();
+        }
+    }
+};
+
 extern "C" {
+
+int gorder_xtc_pool_create(uint32_t n_threads, gorder_xtc_pool **out) {
+    if (!out) return GORDER_XTC_ERR_ARGUMENT;
+    gorder_xtc_pool *p = new gorder_xtc_pool();
+    for (uint32_t w = 0; w < std::max(1u, n_threads); w++) p->workers.emplace_back([p] { p->loop(); });
+    *out = p;
+    return GORDER_XTC_OK;
+}
+int gorder_xtc_pool_wait(gorder_xtc_pool *p) {
+    if (!p) return GORDER_XTC_ERR_ARGUMENT;
+    std::unique_lock<std::mutex> lk(p->mu);
+    p->cv_idle.wait(lk, [&] { return p->jobs.empty() && p->running == 0; });
+    const int st = p->status;
+    p->status = GORDER_XTC_OK;
+    return st;
+}
+void gorder_xtc_pool_destroy(gorder_xtc_pool *p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->stop = true;
+    }
+    p->cv_work.notify_all();
+    for (auto &t : p->workers) t.join();
+    delete p;
+}
+
 
 int gorder_xtc_probe(const char *path, uint32_t *n_atoms) {
     if (!path) return GORDER_XTC_ERR_ARGUMENT;
@@ -912,17 +976,37 @@ uint32_t gorder_xtc_n_atoms_needed(const gorder_xtc_reader *r) {
     return r ? (r->n_needed ? std::min(r->n_needed, r->natoms) : r->natoms) : 0;
 }
 
-int64_t gorder_xtc_pack_window(gorder_xtc_reader *r, float begin_ps, float end_ps, uint32_t step, uint64_t *state,
-                               double *last_time, uint8_t *blob, uint64_t blob_capacity, uint64_t *blob_bytes,
-                               gorder_xtc_frame_t *frames, float *box9, float *time_ps, uint64_t capacity,
-                               uint32_t n_threads) {
+}  // extern "C"
+
+namespace {
+struct PackSrc { off_t pos; uint32_t n; uint64_t dst; };
+// the blocks [i0, i1) of a window into the blob (pread does not move the file position)
+int pack_copy(int fd, const PackSrc *src, size_t i0, size_t i1, uint8_t *blob) {
+    for (size_t i = i0; i < i1; i++) {
+        uint8_t *dst = blob + src[i].dst;
+        size_t done = 0;
+        while (done < src[i].n) {
+            const ssize_t g = pread(fd, dst + done, src[i].n - done, src[i].pos + (off_t)done);
+            if (g <= 0) return GORDER_XTC_ERR_FORMAT;
+            done += (size_t)g;
+        }
+        const size_t end = (size_t)((((uint64_t)src[i].n + 63u) & ~63ull) + 64u);
+        memset(dst + src[i].n, 0, end - src[i].n);
+    }
+    return GORDER_XTC_OK;
+}
+
+int64_t pack_window_impl(gorder_xtc_reader *r, float begin_ps, float end_ps, uint32_t step, uint64_t *state,
+                         double *last_time, uint8_t *blob, uint64_t blob_capacity, uint64_t *blob_bytes,
+                         gorder_xtc_frame_t *frames, float *box9, float *time_ps, uint64_t capacity,
+                         uint32_t n_threads, gorder_xtc_pool *pool) {
     if (!r || !r->fp || r->trr || r->gro || !state || !last_time || !blob || !blob_bytes || !frames || !box9 || step == 0)
         return GORDER_XTC_ERR_ARGUMENT;
     *blob_bytes = 0;
+    const auto t_scan0 = std::chrono::steady_clock::now();
     // pass 1 (sequential): the headers — which frames, where their blocks lie, what the decoder needs to know.
     // One pread of 92 bytes per frame, the position kept here (the FILE is moved once, at the end).
-    struct Src { off_t pos; uint32_t n; };
-    std::vector<Src> src;
+    std::vector<PackSrc> src;
     uint64_t used = 0;
     const uint32_t natoms = r->natoms;
     const int fd = fileno(r->fp);
@@ -991,40 +1075,76 @@ int64_t gorder_xtc_pack_window(gorder_xtc_reader *r, float begin_ps, float end_p
         frames[i] = fr;
         for (int q = 0; q < 9; q++) box9[9 * i + q] = bef(head + 16 + 4 * q);
         if (time_ps) time_ps[i] = t;
-        src.push_back({pos_block, block});
+        src.push_back({pos_block, block, fr.offset});
     }
     if (to_end ? fseek(r->fp, 0, SEEK_END) != 0 : fseeko(r->fp, pos, SEEK_SET) != 0) return GORDER_XTC_ERR_FORMAT;
-    // pass 2: the blocks, by n_threads readers at once (pread does not move the file position)
+    // pass 2: the blocks, by several readers at once
     const size_t n = src.size();
     if (n == 0) return 0;
+    const auto t_copy0 = std::chrono::steady_clock::now();
+    if (pool) {
+        // asynchronously: contiguous shares of the window, one job per worker; the descriptor is duplicated so that
+        // the reader may be closed before the copies are done
+        const size_t nj = std::min<size_t>(pool->workers.size(), n);
+        auto shared = std::make_shared<std::vector<PackSrc>>(std::move(src));
+        const int fd2 = dup(fd);
+        if (fd2 < 0) return GORDER_XTC_ERR_OPEN;
+        auto left = std::make_shared<std::atomic<size_t>>(nj);
+        {
+            std::lock_guard<std::mutex> lk(pool->mu);
+            for (size_t w = 0; w < nj; w++) {
+                const size_t i0 = n * w / nj, i1 = n * (w + 1) / nj;
+                pool->jobs.emplace_back([shared, fd2, left, i0, i1, blob]() {
+                    const int st = pack_copy(fd2, shared->data(), i0, i1, blob);
+                    if (left->fetch_sub(1) == 1) close(fd2);
+                    return st;
+                });
+            }
+        }
+        pool->cv_work.notify_all();
+        *blob_bytes = used;
+        return (int64_t)n;
+    }
     const uint32_t nt = (uint32_t)std::min<size_t>(std::max(1u, n_threads), n);
     std::vector<int> status(nt, GORDER_XTC_OK);
-    auto work = [&](uint32_t w) {
-        // contiguous shares: every thread streams one piece of the file
-        const size_t i0 = n * w / nt, i1 = n * (w + 1) / nt;
-        for (size_t i = i0; i < i1; i++) {
-            uint8_t *dst = blob + frames[i].offset;
-            size_t done = 0;
-            while (done < src[i].n) {
-                const ssize_t g = pread(fd, dst + done, src[i].n - done, src[i].pos + (off_t)done);
-                if (g <= 0) { status[w] = GORDER_XTC_ERR_FORMAT; return; }
-                done += (size_t)g;
-            }
-            const size_t end = (size_t)((((uint64_t)src[i].n + 63u) & ~63ull) + 64u);
-            memset(dst + src[i].n, 0, end - src[i].n);
-        }
-    };
+    auto work = [&](uint32_t w) { status[w] = pack_copy(fd, src.data(), n * w / nt, n * (w + 1) / nt, blob); };
     if (nt == 1) {
         work(0);
     } else {
-        std::vector<std::thread> pool;
-        for (uint32_t w = 0; w < nt; w++) pool.emplace_back(work, w);
-        for (auto &th : pool) th.join();
+        std::vector<std::thread> threads;
+        for (uint32_t w = 0; w < nt; w++) threads.emplace_back(work, w);
+        for (auto &th : threads) th.join();
     }
     for (int st : status)
         if (st != GORDER_XTC_OK) return st;
+    if (getenv("GORDER_XTC_PACK_TIMING")) {     // development aid: where a window's time goes
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "pack_window: %zu frames, scan %.3f ms, copy %.3f ms (%u threads, %.1f MB)\n", n,
+                std::chrono::duration<double, std::milli>(t_copy0 - t_scan0).count(),
+                std::chrono::duration<double, std::milli>(t1 - t_copy0).count(), nt, used / 1e6);
+    }
     *blob_bytes = used;
     return (int64_t)n;
+}
+}  // namespace
+
+extern "C" {
+
+int64_t gorder_xtc_pack_window(gorder_xtc_reader *r, float begin_ps, float end_ps, uint32_t step, uint64_t *state,
+                               double *last_time, uint8_t *blob, uint64_t blob_capacity, uint64_t *blob_bytes,
+                               gorder_xtc_frame_t *frames, float *box9, float *time_ps, uint64_t capacity,
+                               uint32_t n_threads) {
+    return pack_window_impl(r, begin_ps, end_ps, step, state, last_time, blob, blob_capacity, blob_bytes, frames, box9,
+                            time_ps, capacity, n_threads, nullptr);
+}
+
+int64_t gorder_xtc_pack_window_pool(gorder_xtc_reader *r, float begin_ps, float end_ps, uint32_t step, uint64_t *state,
+                                    double *last_time, uint8_t *blob, uint64_t blob_capacity, uint64_t *blob_bytes,
+                                    gorder_xtc_frame_t *frames, float *box9, float *time_ps, uint64_t capacity,
+                                    gorder_xtc_pool *pool) {
+    if (!pool) return GORDER_XTC_ERR_ARGUMENT;
+    return pack_window_impl(r, begin_ps, end_ps, step, state, last_time, blob, blob_capacity, blob_bytes, frames, box9,
+                            time_ps, capacity, 1, pool);
 }
 
 }  // extern "C"

@@ -37,6 +37,14 @@ def _lib():
         lib.gorder_xtc_skip_window.argtypes = [vp, C.c_float, C.c_float, C.c_uint32, C.POINTER(C.c_uint64),
                                                C.POINTER(C.c_double), C.c_uint64]
         lib.gorder_xtc_skip_window.restype = C.c_int64
+        lib.gorder_xtc_pool_create.argtypes = [C.c_uint32, C.POINTER(vp)]
+        lib.gorder_xtc_pool_wait.argtypes = [vp]
+        lib.gorder_xtc_pool_destroy.argtypes = [vp]
+        lib.gorder_xtc_pool_destroy.restype = None
+        lib.gorder_xtc_pack_window_pool.argtypes = [vp, C.c_float, C.c_float, C.c_uint32, C.POINTER(C.c_uint64),
+                                                    C.POINTER(C.c_double), vp, C.c_uint64, C.POINTER(C.c_uint64), vp, vp, vp,
+                                                    C.c_uint64, vp]
+        lib.gorder_xtc_pack_window_pool.restype = C.c_int64
         lib.gorder_xtc_is_xtc.argtypes = [vp]
         lib.gorder_xtc_probe.argtypes = [C.c_char_p, C.POINTER(C.c_uint32)]
         lib.gorder_xtc_n_atoms_needed.argtypes = [vp]
@@ -120,9 +128,11 @@ def read_trajectory(paths: Sequence[str], group: Optional[np.ndarray] = None, be
 
 
 def pack_trajectory(paths: Sequence[str], group: Optional[np.ndarray] = None, begin: float = 0.0, end: float = -1.0,
-                    step: int = 1, chunk: int = 64, blob_capacity: int = 0, threads: int = 1):
+                    step: int = 1, chunk: int = 64, blob_capacity: int = 0, threads: int = 1, pool: bool = False):
     """The frames `read_trajectory` would return, still compressed: windows of at most `chunk` frames as
     gorder_xtc_pack_window packs them for the device decoder (gorder_hip_xtc_decode).
+    `pool`: the block copies go through a pool of `threads` copying threads (gorder_xtc_pack_window_pool), waited for
+    after every window.
     -> list of dicts {blob: uint8 [bytes], frames: structured array of CXtcFrame, box [n, 3, 3], time [n],
                       n_atoms_file, n_stop, slot_of (int32 [n_atoms_file] or None)}."""
     from .abi import CXtcFrame
@@ -130,6 +140,19 @@ def pack_trajectory(paths: Sequence[str], group: Optional[np.ndarray] = None, be
     grp = None if group is None else np.ascontiguousarray(group, dtype=np.uint32)
     state, last = C.c_uint64(0), C.c_double(float("-inf"))
     out = []
+    cpool = C.c_void_p()
+    if pool and lib.gorder_xtc_pool_create(threads, C.byref(cpool)) != 0:
+        raise IOError("cannot create the copy pool")
+    try:
+        return _pack_files(lib, paths, grp, begin, end, step, chunk, blob_capacity, threads, cpool if pool else None, state,
+                           last, out)
+    finally:
+        if pool:
+            lib.gorder_xtc_pool_destroy(cpool)
+
+
+def _pack_files(lib, paths, grp, begin, end, step, chunk, blob_capacity, threads, cpool, state, last, out):
+    from .abi import CXtcFrame
     for path in paths:
         r = C.c_void_p()
         st = lib.gorder_xtc_open(path.encode(), None if grp is None else grp.ctypes.data, 0 if grp is None else grp.size,
@@ -151,9 +174,16 @@ def pack_trajectory(paths: Sequence[str], group: Optional[np.ndarray] = None, be
                 b = np.empty((chunk, 3, 3), dtype=np.float32)
                 t = np.empty(chunk, dtype=np.float32)
                 used = C.c_uint64(0)
-                got = lib.gorder_xtc_pack_window(r, begin, end, step, C.byref(state), C.byref(last), blob.ctypes.data, cap,
-                                                 C.byref(used), C.cast(frames, C.c_void_p), b.ctypes.data, t.ctypes.data,
-                                                 chunk, threads)
+                if cpool is not None:
+                    got = lib.gorder_xtc_pack_window_pool(r, begin, end, step, C.byref(state), C.byref(last), blob.ctypes.data,
+                                                          cap, C.byref(used), C.cast(frames, C.c_void_p), b.ctypes.data,
+                                                          t.ctypes.data, chunk, cpool)
+                    if got >= 0 and lib.gorder_xtc_pool_wait(cpool) != 0:
+                        got = -2
+                else:
+                    got = lib.gorder_xtc_pack_window(r, begin, end, step, C.byref(state), C.byref(last), blob.ctypes.data,
+                                                     cap, C.byref(used), C.cast(frames, C.c_void_p), b.ctypes.data,
+                                                     t.ctypes.data, chunk, threads)
                 if got < 0:
                     raise IOError(f"{path}: XTC pack error {got}")
                 if got == 0:

@@ -103,6 +103,19 @@ int64_t gorder_xtc_pack_window(gorder_xtc_reader *r, float begin_ps, float end_p
                                double *last_time, uint8_t *blob, uint64_t blob_capacity, uint64_t *blob_bytes,
                                gorder_xtc_frame_t *frames, float *box9, float *time_ps, uint64_t capacity,
                                uint32_t n_threads);
+/* The same with the block copies handed to a pool of copying threads: the call returns when the headers are scanned
+ * (frames, boxes, times and *blob_bytes are final), the blob's bytes are complete once gorder_xtc_pool_wait has
+ * returned (its status: the first copy failure since the last wait).  The sequential header scan of the next file
+ * or window then overlaps these copies.  The reader may be closed before the wait. */
+typedef struct gorder_xtc_pool gorder_xtc_pool;
+int gorder_xtc_pool_create(uint32_t n_threads, gorder_xtc_pool **out);
+int gorder_xtc_pool_wait(gorder_xtc_pool *pool);
+void gorder_xtc_pool_destroy(gorder_xtc_pool *pool);
+int64_t gorder_xtc_pack_window_pool(gorder_xtc_reader *r, float begin_ps, float end_ps, uint32_t step, uint64_t *state,
+                                    double *last_time, uint8_t *blob, uint64_t blob_capacity, uint64_t *blob_bytes,
+                                    gorder_xtc_frame_t *frames, float *box9, float *time_ps, uint64_t capacity,
+                                    gorder_xtc_pool *pool);
+
 /* Look at a file's first bytes only: 1 = XTC (and *n_atoms = atoms per frame), 0 = something else (TRR, GRO, ...),
  * negative = cannot be opened / too short. */
 int gorder_xtc_probe(const char *path, uint32_t *n_atoms);

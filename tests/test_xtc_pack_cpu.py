@@ -74,6 +74,18 @@ def test_pack_continues_when_the_blob_is_full(built, tmp_path):
         xtc.pack_trajectory([path], chunk=64, blob_capacity=per_frame // 2)
 
 
+def test_pool_copies_the_same_bytes(built, tmp_path):
+    a = synthetic(tmp_path, n_frames=29, name="a.xtc")
+    b = synthetic(tmp_path, n_frames=11, seed=5, n_atoms=700, name="b.xtc")
+    plain = xtc.pack_trajectory([a, b, CG3] if False else [a, b], chunk=8, threads=3)
+    pooled = xtc.pack_trajectory([a, b], chunk=8, threads=3, pool=True)
+    assert len(plain) == len(pooled)
+    for x, y in zip(plain, pooled):
+        assert bytes(x["blob"]) == bytes(y["blob"]) and x["frames"].tobytes() == y["frames"].tobytes()
+        np.testing.assert_array_equal(x["time"], y["time"])
+        check_layout(y)
+
+
 def test_pack_concatenation_and_group(built, tmp_path):
     a = synthetic(tmp_path, n_frames=6, name="a.xtc")
     # the second file starts with the last time of the first (a duplicate boundary frame, CHANGELOG.md:64)
