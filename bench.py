@@ -150,7 +150,8 @@ def end_to_end(system, device_index, n_unique=500, repeats=200):
             eng.reset()
             stats = eng.run_trajectory([path] * repeats, threads=cores, device_decode=dev)
             res = eng.finish()
-            assert stats["n_frames"] == n_unique * repeats == res.n_frames and stats["device_decode"] == int(dev)
+            assert stats["n_frames"] == n_unique * repeats == res.n_frames
+            assert stats["device_decode"] <= int(dev)      # (frames too large for one-lane-per-frame decoding: host decoder)
             stats["first_call_setup"] = first["seconds_setup"]
             runs[route] = (stats, res)
         eng.close()
@@ -159,7 +160,7 @@ def end_to_end(system, device_index, n_unique=500, repeats=200):
     def block(stats):
         n, sec = stats["n_frames"], stats["seconds_total"]
         return {"value": n / sec, "unit": "frames/s", "frames": n, "host_threads": stats["decoder_threads"],
-                "batch_frames": stats["batch_frames"], "batches": stats["n_batches"],
+                "batch_frames": stats["batch_frames"], "batches": stats["n_batches"], "decoded_on": "device" if stats["device_decode"] else "host",
                 "pcie_GBps": stats["bytes_h2d"] / sec / 1e9, "file_read_MBps": size * repeats / sec / 1e6,
                 "seconds": {"total": sec, "setup": stats["seconds_setup"],
                             "setup_of_the_handles_first_call": stats["first_call_setup"], "host_reader": stats["seconds_decode"],

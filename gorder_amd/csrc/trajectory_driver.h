@@ -199,7 +199,17 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
     // (the decoding of two batches overlaps the packing and the copy of the next ones).
     uint32_t batch = tr->batch_frames;
     if (batch == 0 && !dev) batch = (uint32_t)std::min<size_t>(4096, std::max<size_t>(16, ((size_t)128 << 20) / ((size_t)n_atoms * 12u)));
-    if (batch == 0 && dev) batch = (uint32_t)std::min<size_t>(16384, std::max<size_t>(64, ((size_t)1 << 30) / ((size_t)n_atoms * 12u)));
+    if (batch == 0 && dev) {
+        // One lane decodes one frame, so a launch takes (atoms per frame) x 0.6 us whatever its size: below a few hundred
+        // frames per launch the host's decoder threads are faster.  Large systems get a larger budget (4 GiB of
+        // coordinates per slot; HBM has the room), and beyond that (about a million atoms per frame) the run uses
+        // the host decoder.
+        size_t b = std::min<size_t>(16384, ((size_t)1 << 30) / ((size_t)n_atoms * 12u));
+        if (b < 512) b = std::min<size_t>(512, ((size_t)4 << 30) / ((size_t)n_atoms * 12u));
+        if (b < 512) dev = false;
+        else batch = (uint32_t)b;
+    }
+    if (batch == 0) batch = (uint32_t)std::min<size_t>(4096, std::max<size_t>(16, ((size_t)128 << 20) / ((size_t)n_atoms * 12u)));
     const size_t xyz_bytes = (size_t)batch * n_atoms * 3u * sizeof(float), box_bytes = (size_t)batch * 9u * sizeof(float);
     // a compressed atom takes 3-5 bytes at the usual precision, never more than 10: 6 per atom and frame on average,
     // and room for one worst-case frame
