@@ -213,7 +213,10 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
     const size_t xyz_bytes = (size_t)batch * n_atoms * 3u * sizeof(float), box_bytes = (size_t)batch * 9u * sizeof(float);
     // a compressed atom takes 3-5 bytes at the usual precision, never more than 10: 6 per atom and frame on average,
     // and room for one worst-case frame
-    const size_t blob_cap = dev ? std::max<size_t>((size_t)batch * n_file_atoms * 6u, (size_t)n_file_atoms * 12u + 4096u) + 4096u : 0;
+    // (a file with much more in it than the analysed atoms — water — would ask for gigabytes: at most 1 GiB per slot,
+    // a batch then simply ends when its blob is full)
+    const size_t blob_cap = dev ? std::max<size_t>(std::min<size_t>((size_t)batch * n_file_atoms * 6u, (size_t)1 << 30),
+                                                   (size_t)n_file_atoms * 12u + 4096u) + 4096u : 0;
     TrajCache *cache = static_cast<TrajCache *>(h->traj_cache);
     if (cache && !(cache->dev == dev && cache->batch == batch && cache->blob_cap == blob_cap && cache->xyz_bytes == xyz_bytes)) {
         traj_cache_free(h);            // another shape of run: start over
