@@ -1063,9 +1063,9 @@ int64_t pack_window_impl(gorder_xtc_reader *r, float begin_ps, float end_ps, uin
         if (k % step != 0) continue;
         const uint64_t need = (((uint64_t)block + 63u) & ~63ull) + 64u;     // whole 64-byte pieces + one piece of zeros
         if (used + need > blob_capacity) {                 // does not fit any more: this frame opens the next window
-            if (src.empty()) return GORDER_XTC_ERR_ARGUMENT;
-            (*state)--;
+            (*state)--;                                    // (nothing of it has happened: a later call meets it again)
             *last_time = time_before;
+            if (src.empty()) return GORDER_XTC_ERR_ARGUMENT;
             pos = pos0;
             break;
         }

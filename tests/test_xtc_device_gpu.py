@@ -185,6 +185,28 @@ def test_driver_device_decode_matches_host_decode(cg, tmp_path, batch_frames, th
         np.testing.assert_array_equal(r0.counts, r1.counts)
 
 
+def test_driver_batches_that_end_because_the_blob_is_full(built, tmp_path):
+    """frames that compress worse than the blob is sized for (a gas at high precision: 6.5 bytes per atom): a batch
+    ends when its blob is full, the frame that did not fit opens the next one — none is lost, none taken twice"""
+    rng = np.random.default_rng(21)
+    n_atoms, n_frames = 2000, 50
+    xyz = rng.uniform(0.0, 30.0, size=(n_frames, n_atoms, 3)).astype(np.float32)
+    path = write(tmp_path, "gas.xtc", xyz, 30.0, 5000.0)
+    assert os.path.getsize(path) > n_frames * n_atoms * 6.3
+    bonds = np.arange(n_atoms, dtype=np.uint32).reshape(1, n_atoms // 2, 2)
+    tables = abi.Tables(n_atoms=n_atoms, molecule_types=[abi.MolType(n_molecules=n_atoms // 2, bonds=bonds)])
+    res = {}
+    for dev in (False, True):
+        eng = HipEngine(tables)
+        st = eng.run_trajectory([path, path], threads=2, batch_frames=16, device_decode=dev, end=1e9)
+        assert st["n_frames"] == 2 * n_frames and st["device_decode"] == int(dev)
+        if dev:
+            assert st["n_batches"] > (2 * n_frames + 15) // 16                      # batches were cut short by the blob
+        res[dev] = eng.finish()
+    np.testing.assert_array_equal(res[False].sums, res[True].sums)
+    np.testing.assert_array_equal(res[False].counts, res[True].counts)
+
+
 def test_staging_is_kept_and_released(cg, tmp_path):
     """a handle's second run finds its staging buffers (no setup to speak of), runs of another shape and
     release_staging start over; results do not depend on any of it"""

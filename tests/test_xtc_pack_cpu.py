@@ -74,6 +74,28 @@ def test_pack_continues_when_the_blob_is_full(built, tmp_path):
         xtc.pack_trajectory([path], chunk=64, blob_capacity=per_frame // 2)
 
 
+def test_a_frame_that_does_not_fit_is_met_again(built, tmp_path):
+    """the driver's case: a batch's blob is partly full, the next file's FIRST frame does not fit what is left — the call
+    refuses (nothing packed) and must leave the selection state untouched, so that the same frame opens the next batch"""
+    import ctypes as C
+    from gorder_amd.abi import CXtcFrame
+    path = synthetic(tmp_path, n_frames=6)
+    lib = xtc._lib()
+    r = C.c_void_p()
+    assert lib.gorder_xtc_open(path.encode(), None, 0, C.byref(r)) == 0
+    state, last, used = C.c_uint64(0), C.c_double(float("-inf")), C.c_uint64(0)
+    blob = np.empty(1 << 20, np.uint8)
+    frames = (CXtcFrame * 8)()
+    box, t = np.empty((8, 9), np.float32), np.empty(8, np.float32)
+    args = lambda cap: (r, 0.0, -1.0, 2, C.byref(state), C.byref(last), blob.ctypes.data, cap, C.byref(used),
+                        C.cast(frames, C.c_void_p), box.ctypes.data, t.ctypes.data, 8, 1)
+    assert lib.gorder_xtc_pack_window(*args(100)) == -3           # refused: not one frame fits 100 bytes
+    assert state.value == 0 and last.value == float("-inf")
+    assert lib.gorder_xtc_pack_window(*args(1 << 20)) == 3        # every second of 6 frames, the first one included
+    np.testing.assert_array_equal(t[:3], [0.0, 20.0, 40.0])
+    lib.gorder_xtc_close(r)
+
+
 def test_pool_copies_the_same_bytes(built, tmp_path):
     a = synthetic(tmp_path, n_frames=29, name="a.xtc")
     b = synthetic(tmp_path, n_frames=11, seed=5, n_atoms=700, name="b.xtc")
