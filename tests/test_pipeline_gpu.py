@@ -214,3 +214,23 @@ def test_frame_shards_prime_their_leaflets(cg, tmp_path, method, frequency):
             counts += got.counts
         np.testing.assert_array_equal(sums, want.sums)
         np.testing.assert_array_equal(counts, want.counts)
+
+
+@pytest.mark.parametrize("device_decode", [False, True])
+def test_empty_selections(cg, tmp_path, device_decode):
+    """a window that selects nothing, and more shards than frames: zero frames analysed, no error, results all zero"""
+    tables, labels, midx = cg_setup(cg, leaflets=METHODS["global"])
+    path = str(tmp_path / "c.xtc")
+    write_fixture(cg, path, frames=np.arange(5))
+    eng = HipEngine(tables)
+    st = eng.run_trajectory([path], group=midx, threads=2, device_decode=device_decode, begin=1e9)
+    assert st["n_frames"] == 0 and eng.finish().n_frames == 0
+    total = 0
+    for i in range(8):                      # 5 frames over 8 shards: three of them are empty
+        eng = HipEngine(tables)
+        st = eng.run_trajectory([path], group=midx, threads=2, device_decode=device_decode, shard=(i, 8))
+        assert st["n_frames"] in (0, 1) and st["shard_frames_total"] == 5
+        total += eng.finish().n_frames
+    assert total == 5
+    with pytest.raises(abi.GorderHipError):
+        HipEngine(tables).run_trajectory([path], group=midx, shard=(8, 8))
