@@ -119,6 +119,25 @@ def test_every_field_width(engine, tmp_path):
         same_bits(device_decode(engine, [path], chunk=70), host)
 
 
+def test_many_shapes(engine, tmp_path):
+    """sizes around every boundary of the kernel: atoms per frame just above the raw-float limit and around the flush
+    group of 8, frames per launch around a wave of 64, groups whose last atom (= where decoding stops, one atom past
+    it for the swap) sits at every position of a flush group, with and without runs of small offsets"""
+    rng = np.random.default_rng(2024)
+    for k in range(28):
+        n_atoms = int(rng.choice([10, 11, 15, 16, 17, 23, 24, 25, 31, 33, 63, 64, 65, 100, 257]))
+        n_frames = int(rng.choice([1, 2, 63, 64, 65, 130]))
+        span = float(rng.choice([1.5, 6.0, 40.0]))
+        xyz = clustered(rng, n_atoms, n_frames, span, sigma=float(rng.choice([0.002, 0.05, 0.5])))
+        path = write(tmp_path, f"s{k}.xtc", xyz, span, float(rng.choice([50.0, 1000.0])))
+        host = xtc.read_trajectory([path])[0]
+        same_bits(device_decode(engine, [path], chunk=n_frames), host)
+        last = int(rng.integers(0, n_atoms))
+        group = np.unique(np.concatenate([rng.integers(0, last + 1, size=max(1, last // 3)), [last]])).astype(np.uint32)
+        rng.shuffle(group)
+        same_bits(device_decode(engine, [path], group=group, chunk=n_frames), xtc.read_trajectory([path], group=group)[0])
+
+
 def test_small_systems_are_raw_floats(engine, tmp_path):
     rng = np.random.default_rng(5)
     xyz = rng.normal(0, 3, size=(9, 7, 3)).astype(np.float32)
