@@ -95,7 +95,7 @@ class CTrajectoryStats(C.Structure):
     _fields_ = [("n_frames", C.c_uint64), ("n_batches", C.c_uint64), ("bytes_h2d", C.c_uint64),
                 ("seconds_total", C.c_double), ("seconds_decode", C.c_double), ("seconds_reader_stalled", C.c_double),
                 ("seconds_gpu_starved", C.c_double), ("batch_frames", C.c_uint32), ("decoder_threads", C.c_uint32),
-                ("device_decode", C.c_uint32), ("reserved", C.c_uint32), ("shard_first", C.c_uint64),
+                ("device_decode", C.c_uint32), ("frames_decoded_by_host", C.c_uint32), ("shard_first", C.c_uint64),
                 ("shard_frames_total", C.c_uint64), ("seconds_setup", C.c_double)]
 
 

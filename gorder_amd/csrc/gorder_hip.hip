@@ -1551,7 +1551,7 @@ int gorder_hip_kernel_time(gorder_hip_handle *h, double *ms, uint64_t *launches,
 // ---- XTC frames decompressed on the device (kernels_xtc.h) ---------------------------------------------------------
 int xtc_decode_on(gorder_hip_handle *h, hipStream_t stream, const uint8_t *d_blob, uint64_t blob_bytes,
                   const gorder_xtc_frame_t *d_frames, uint32_t n_frames, uint32_t n_atoms_file, const int32_t *d_slot_of,
-                  uint32_t n_stop, float *d_xyz, uint32_t n_atoms_out) {
+                  uint32_t n_stop, float *d_xyz, uint32_t n_atoms_out, uint32_t *d_stat = nullptr, uint32_t *d_short = nullptr) {
     if (!h || !d_blob || !d_frames || !d_xyz || blob_bytes < 64 || (reinterpret_cast<uintptr_t>(d_blob) & 63u) != 0 || n_atoms_file == 0 || n_atoms_out == 0 ||
         n_stop > n_atoms_file || (!d_slot_of && n_atoms_out < n_stop))
         return fail(h, GORDER_ERR_INVALID_ARGUMENT, "gorder_hip_xtc_decode: bad arguments");
@@ -1559,7 +1559,7 @@ int xtc_decode_on(gorder_hip_handle *h, hipStream_t stream, const uint8_t *d_blo
     HIP_TRY(h, hipSetDevice(h->device));
     hipLaunchKernelGGL(k_xtc_decode, dim3((n_frames + 64u * kXtcWaves - 1u) / (64u * kXtcWaves)), dim3(64u * kXtcWaves), 0, stream, d_blob,
                        (unsigned long long)blob_bytes, d_frames, n_frames, n_atoms_file, d_slot_of, n_stop, d_xyz,
-                       n_atoms_out, h->d_err);
+                       n_atoms_out, h->d_err, d_stat, d_short);
     HIP_TRY(h, hipGetLastError());
     return GORDER_OK;
 }

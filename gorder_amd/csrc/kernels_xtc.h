@@ -147,10 +147,12 @@ __device__ __forceinline__ void xtc_ints(XtcBits &b, uint32_t nbits, uint32_t s1
 //   natoms       : atoms per frame in the file;  n_stop: atoms to go through (up to the last analysed one)
 //   slot_of      : [natoms] output slot of an atom or -1 (null: every atom, slot = atom)
 //   out          : [n_frames][n_out][3]
+//   stat, short_list : null, or 2 words (zeroed by the caller) + [n_frames] words: see the end of the kernel
 __global__ __launch_bounds__(64 * kXtcWaves) void k_xtc_decode(const uint8_t *__restrict__ blob, unsigned long long blob_bytes,
                                                    const gorder_xtc_frame_t *__restrict__ frames, uint32_t n_frames,
                                                    uint32_t natoms, const int32_t *__restrict__ slot_of, uint32_t n_stop,
-                                                   float *__restrict__ out, uint32_t n_out, uint32_t *err) {
+                                                   float *__restrict__ out, uint32_t n_out, uint32_t *err,
+                                                   uint32_t *stat, uint32_t *short_list) {
     __shared__ uint32_t l_magic[kXtcLastIdx];
     __shared__ unsigned long long l_recip[kXtcLastIdx];
     __shared__ double l_inv[kXtcLastIdx];
@@ -437,8 +439,18 @@ __global__ __launch_bounds__(64 * kXtcWaves) void k_xtc_decode(const uint8_t *__
         }
     }
     for (; flushed < n_stop; flushed += kXtcGroup) flush(flushed, slot_for(flushed));
-    if (b.taken > 8ull * d.n_bytes) bad = true;          // read into the padding: a truncated block
-    if (bad && live) raise_error(err, GORDER_ERR_TRAJECTORY_FORMAT, fr, kStageBox);
+    // Read into the padding?  A frame of which only a leading part was copied (bit 1 of kind) is then SHORT, not corrupt
+    // (whatever else went wrong while it decoded zeros): it goes on the caller's list and is decoded elsewhere.
+    // stat[0] = short frames, stat[1] = max over frames of bytes needed / bytes given, in units of 2^-16.
+    const bool over = b.taken > 8ull * d.n_bytes;
+    if (live) {
+        if (stat) {
+            const unsigned long long q16 = (((b.taken + 7ull) >> 3) << 16) / (d.n_bytes ? d.n_bytes : 1u);
+            atomicMax(&stat[1], (uint32_t)(q16 > 0xffffffffull ? 0xffffffffull : q16));
+        }
+        if (over && (d.kind & 2u) && stat && short_list) short_list[atomicAdd(&stat[0], 1u)] = fr;
+        else if (bad || over) raise_error(err, GORDER_ERR_TRAJECTORY_FORMAT, fr, kStageBox);
+    }
 }
 
 }  // namespace

@@ -15,6 +15,7 @@
 // into the slot's coordinate buffer; the handle's stream waits for that kernel instead of for a copy.
 #pragma once
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -32,6 +33,13 @@ struct TrajSlot {
     uint8_t *h_blob = nullptr, *d_blob = nullptr;
     gorder_xtc_frame_t *h_frames = nullptr, *d_frames = nullptr;
     float *d_box_in = nullptr;      // the boxes land here first: d_box may still be read by the kernels of the slot's last batch
+    // what the decoder reports back (2 words: short frames, largest need in 2^-16 of the bytes given; then the list of
+    // the short frames), on the device and pinned; where every frame of the batch lies in which file
+    uint32_t *d_stat = nullptr, *d_short = nullptr, *h_stat = nullptr, *h_short = nullptr;
+    std::vector<int64_t> file_pos;
+    std::vector<uint32_t> file_idx;
+    uint32_t prefix_q16 = 65536;    // the part of every block this batch was packed with
+    size_t moved = 0;               // bytes copied to the device for this batch
     uint64_t blob_bytes = 0;
     hipStream_t stream = nullptr;
     hipEvent_t staged = nullptr, copied = nullptr, computed = nullptr;   // host buffers read; device buffers ready; kernels done
@@ -50,6 +58,7 @@ struct TrajCache {
     size_t blob_cap = 0, xyz_bytes = 0;
     hipStream_t copy_stream = nullptr;
     unsigned long long *h_err = nullptr;     // pinned mirror of the device error key
+    float *h_fix = nullptr;                  // pinned: one frame + its box, for the frames the host decodes after all
 };
 
 struct TrajPipe {
@@ -62,6 +71,7 @@ struct TrajPipe {
     int reader_status = GORDER_XTC_OK;
     std::string reader_msg;
     double decode_s = 0.0, reader_stalled_s = 0.0, setup_s = 0.0;
+    std::atomic<uint32_t> prefix_q16{65536};   // the leading part of every block the reader copies (device route)
     bool alloc_failed = false;
 };
 
@@ -83,6 +93,10 @@ void traj_cache_free(gorder_hip_handle *h) {
         (void)hipFree(s.d_blob);
         (void)hipFree(s.d_frames);
         (void)hipFree(s.d_box_in);
+        (void)hipFree(s.d_stat);
+        (void)hipFree(s.d_short);
+        if (s.h_stat) (void)hipHostFree(s.h_stat);
+        if (s.h_short) (void)hipHostFree(s.h_short);
         if (s.stream) (void)hipStreamDestroy(s.stream);
         if (s.staged) (void)hipEventDestroy(s.staged);
         if (s.copied) (void)hipEventDestroy(s.copied);
@@ -90,6 +104,7 @@ void traj_cache_free(gorder_hip_handle *h) {
     }
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->h_err) (void)hipHostFree(c->h_err);
+    if (c->h_fix) (void)hipHostFree(c->h_fix);
     delete c;
     h->traj_cache = nullptr;
 }
@@ -249,6 +264,7 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
     } while (0)
     if (!cache->copy_stream) TRAJ_TRY(hipStreamCreateWithFlags(&cache->copy_stream, hipStreamNonBlocking));
     if (!cache->h_err) TRAJ_TRY(hipHostMalloc((void **)&cache->h_err, sizeof(unsigned long long), hipHostMallocDefault));
+    if (dev && !cache->h_fix) TRAJ_TRY(hipHostMalloc((void **)&cache->h_fix, ((size_t)n_atoms * 3u + 9u) * sizeof(float), hipHostMallocDefault));
     const hipStream_t copy_stream = cache->copy_stream;
     unsigned long long *h_err = cache->h_err;   // lets the loop stop at the first error
     *h_err = kErrNone;
@@ -268,6 +284,12 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
             ok(hipMalloc((void **)&s.d_blob, blob_cap));
             ok(hipMalloc((void **)&s.d_frames, (size_t)batch * sizeof(gorder_xtc_frame_t)));
             ok(hipMalloc((void **)&s.d_box_in, box_bytes));
+            ok(hipMalloc((void **)&s.d_stat, 2 * sizeof(uint32_t)));
+            ok(hipMalloc((void **)&s.d_short, (size_t)batch * sizeof(uint32_t)));
+            ok(hipHostMalloc((void **)&s.h_stat, 2 * sizeof(uint32_t), hipHostMallocDefault));
+            ok(hipHostMalloc((void **)&s.h_short, (size_t)batch * sizeof(uint32_t), hipHostMallocDefault));
+            s.file_pos.resize(batch);
+            s.file_idx.resize(batch);
             ok(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
         } else {
             ok(hipHostMalloc((void **)&s.h_xyz, xyz_bytes, hipHostMallocDefault));
@@ -351,6 +373,7 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
             // a batch is filled across file boundaries: a trajectory split into many short files still makes full batches
             s.n = 0;
             s.blob_bytes = 0;
+            s.prefix_q16 = pipe.prefix_q16.load();
             while (!done && s.n < batch) {
                 if (left == 0) { done = true; break; }
                 if (!r) {
@@ -377,12 +400,10 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
                 const uint64_t want = std::min<uint64_t>(batch - s.n, left);
                 uint64_t used = 0;
                 const int64_t got =
-                    dev ? (pool ? gorder_xtc_pack_window_pool(r, tr->begin_ps, tr->end_ps, tr->step, &state, &last_time,
-                                                              s.h_blob + s.blob_bytes, blob_cap - s.blob_bytes, &used,
-                                                              s.h_frames + s.n, s.h_box + 9u * (size_t)s.n, s.h_time + s.n, want, pool)
-                                 : gorder_xtc_pack_window(r, tr->begin_ps, tr->end_ps, tr->step, &state, &last_time,
-                                                          s.h_blob + s.blob_bytes, blob_cap - s.blob_bytes, &used, s.h_frames + s.n,
-                                                          s.h_box + 9u * (size_t)s.n, s.h_time + s.n, want, n_threads))
+                    dev ? gorder_xtc_pack_window_ex(r, tr->begin_ps, tr->end_ps, tr->step, &state, &last_time,
+                                                    s.h_blob + s.blob_bytes, blob_cap - s.blob_bytes, &used, s.h_frames + s.n,
+                                                    s.h_box + 9u * (size_t)s.n, s.h_time + s.n, want, n_threads, pool,
+                                                    s.prefix_q16, s.file_pos.data() + s.n)
                         : gorder_xtc_read_window_mt(r, tr->begin_ps, tr->end_ps, tr->step, &state, &last_time,
                                                     s.h_xyz + (size_t)s.n * n_atoms * 3u, s.h_box + 9u * (size_t)s.n,
                                                     s.h_time + s.n, want, n_threads);
@@ -398,7 +419,10 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
                     continue;
                 }
                 if (dev) {
-                    for (int64_t q = 0; q < got; q++) s.h_frames[s.n + (size_t)q].offset += s.blob_bytes;
+                    for (int64_t q = 0; q < got; q++) {
+                        s.h_frames[s.n + (size_t)q].offset += s.blob_bytes;
+                        s.file_idx[s.n + (size_t)q] = f;
+                    }
                     s.blob_bytes += used;
                 }
                 s.n += (uint32_t)got;
@@ -430,21 +454,23 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
     });
 
     // ---- submitter (this thread)
+    // Two stages per batch.  A: as soon as a batch is filled, its copies (and, on the device route, its decode kernel
+    // and the decoder's report) are queued on the slot's stream.  B: once that has finished — the device route looks
+    // at the report first: frames of which too short a part was copied are decoded by the host after all, and the part
+    // copied of later batches follows what the decoder needed — the analysis is queued on the handle's stream.
+    // Batches are analysed in the order they were read.
     int status = GORDER_OK;
-    uint64_t frames = 0, batches = 0, bytes = 0;
+    uint64_t frames = 0, batches = 0, bytes = 0, frames_fixed = 0;
     double starved_s = 0.0;
     std::string hip_msg;
-    for (;;) {
-        int k = -1;
-        {
-            const auto t0 = std::chrono::steady_clock::now();
-            std::unique_lock<std::mutex> lk(pipe.mu);
-            pipe.cv.wait(lk, [&] { return !pipe.filled_q.empty() || pipe.reader_done; });
-            starved_s += seconds_since(t0);
-            if (pipe.filled_q.empty()) break;     // reader done and nothing left
-            k = pipe.filled_q.front();
-            pipe.filled_q.pop_front();
-        }
+    const char *forced_prefix = getenv("GORDER_HIP_PREFIX_Q16");          // test switch: a fixed part, whatever it leads to
+    const bool adapt_prefix = dev && !forced_prefix && !env_flag("GORDER_HIP_NO_PREFIX") && n_stop < n_file_atoms;
+    if (dev && forced_prefix) pipe.prefix_q16.store((uint32_t)std::max(1l, std::min(65536l, atol(forced_prefix))));
+    // only a run that copies parts of blocks has anything to look at between the two stages; any other queues stage B
+    // right behind stage A and never waits for the device
+    const bool verify = dev && (adapt_prefix || forced_prefix);
+    uint32_t need_q16 = 0;                                                   // the largest part of a block a frame needed so far
+    auto stage_a = [&](int k) {
         TrajSlot &s = pipe.slot[k];
         const size_t nx = (size_t)s.n * n_atoms * 3u * sizeof(float), nb = (size_t)s.n * 9u * sizeof(float);
         hipError_t e = hipSuccess;
@@ -452,10 +478,11 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
         // the slot's coordinate buffer is free once the kernels of its last batch are done; the compressed blocks go
         // to a buffer of their own and need not wait for that
         if (s.compute_issued && !dev) e = hipStreamWaitEvent(feed, s.computed, 0);
-        size_t moved = nb;
+        s.moved = nb;
         if (dev) {
             const size_t nf = (size_t)s.n * sizeof(gorder_xtc_frame_t);
-            moved += (size_t)s.blob_bytes + nf;
+            s.moved += (size_t)s.blob_bytes + nf;
+            if (e == hipSuccess) e = hipMemsetAsync(s.d_stat, 0, 2 * sizeof(uint32_t), feed);
             if (e == hipSuccess) e = hipMemcpyAsync(s.d_blob, s.h_blob, (size_t)s.blob_bytes, hipMemcpyHostToDevice, feed);
             if (e == hipSuccess) e = hipMemcpyAsync(s.d_frames, s.h_frames, nf, hipMemcpyHostToDevice, feed);
             if (e == hipSuccess) e = hipMemcpyAsync(s.d_box_in, s.h_box, nb, hipMemcpyHostToDevice, feed);
@@ -464,16 +491,65 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
             if (e == hipSuccess) e = hipMemcpyAsync(s.d_box, s.d_box_in, nb, hipMemcpyDeviceToDevice, feed);
             if (e == hipSuccess && status == GORDER_OK)
                 status = xtc_decode_on(h, feed, s.d_blob, s.blob_bytes, s.d_frames, s.n, n_file_atoms, d_slot_of, n_stop,
-                                       s.d_xyz, n_atoms);
+                                       s.d_xyz, n_atoms, s.d_stat, s.d_short);
+            if (e == hipSuccess) e = hipMemcpyAsync(s.h_stat, s.d_stat, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, feed);
+            if (e == hipSuccess) e = hipMemcpyAsync(s.h_short, s.d_short, (size_t)s.n * sizeof(uint32_t), hipMemcpyDeviceToHost, feed);
         } else {
-            moved += nx;
+            s.moved += nx;
             if (e == hipSuccess) e = hipMemcpyAsync(s.d_xyz, s.h_xyz, nx, hipMemcpyHostToDevice, feed);
             if (e == hipSuccess) e = hipMemcpyAsync(s.d_box, s.h_box, nb, hipMemcpyHostToDevice, feed);
             if (e == hipSuccess) e = hipEventRecord(s.staged, feed);
         }
         if (e == hipSuccess) e = hipEventRecord(s.copied, feed);
-        if (e == hipSuccess) { s.copy_issued = true; e = hipStreamWaitEvent(h->stream, s.copied, 0); }
+        if (e == hipSuccess) s.copy_issued = true;
         if (e != hipSuccess) { status = GORDER_ERR_DEVICE; hip_msg = std::string("trajectory copy: ") + hipGetErrorString(e); }
+    };
+    // the frames of a batch the decoder could not finish with the part it was given: decoded here, one by one
+    auto fix_short_frames = [&](TrajSlot &s, uint32_t n_short) {
+        gorder_xtc_reader *r = nullptr;
+        uint32_t open_idx = UINT32_MAX;
+        float *fx = cache->h_fix, *fb = cache->h_fix + (size_t)n_atoms * 3u;
+        for (uint32_t q = 0; q < n_short && status == GORDER_OK; q++) {
+            const uint32_t fr = s.h_short[q];
+            if (fr >= s.n) { status = fail(h, GORDER_ERR_DEVICE, "decoder report out of range"); break; }
+            if (s.file_idx[fr] != open_idx) {
+                if (r) gorder_xtc_close(r);
+                r = nullptr;
+                open_idx = s.file_idx[fr];
+                if (gorder_xtc_open(tr->paths[open_idx], tr->group, tr->n_group, &r) != GORDER_XTC_OK) r = nullptr;
+            }
+            const int st = r ? gorder_xtc_read_at(r, s.file_pos[fr], fx, fb) : GORDER_XTC_ERR_OPEN;
+            if (st != GORDER_XTC_OK) {
+                status = fail(h, st == GORDER_XTC_ERR_FORMAT ? GORDER_ERR_TRAJECTORY_FORMAT : GORDER_ERR_INVALID_ARGUMENT,
+                              std::string("cannot decode a frame of ") + tr->paths[open_idx] + " (reader status " + std::to_string(st) + ")");
+                break;
+            }
+            const hipError_t e = hipMemcpy(s.d_xyz + (size_t)fr * n_atoms * 3u, fx, (size_t)n_atoms * 3u * sizeof(float), hipMemcpyHostToDevice);
+            if (e != hipSuccess) status = fail(h, GORDER_ERR_DEVICE, std::string("trajectory copy: ") + hipGetErrorString(e));
+        }
+        if (r) gorder_xtc_close(r);
+        frames_fixed += n_short;
+    };
+    auto stage_b = [&](int k) {
+        TrajSlot &s = pipe.slot[k];
+        hipError_t e = hipSuccess;
+        if (verify && status == GORDER_OK) {
+            e = hipEventSynchronize(s.copied);
+            if (e == hipSuccess) {
+                const uint32_t n_short = s.h_stat[0], q = s.h_stat[1];
+                if (n_short) fix_short_frames(s, std::min(n_short, s.n));
+                if (adapt_prefix) {
+                    // what this batch needed, as a part of the whole block; the next batches get an eighth and 1 % more
+                    // (nothing less than nine tenths is worth the trouble), and more at once when frames came out short
+                    need_q16 = std::max<uint32_t>(need_q16, (uint32_t)std::min<uint64_t>(65536u, ((uint64_t)q * s.prefix_q16) >> 16));
+                    uint32_t next = need_q16 + need_q16 / 8u + 656u;
+                    if (n_short) next = std::max<uint32_t>(next, s.prefix_q16 + s.prefix_q16 / 4u);
+                    pipe.prefix_q16.store(next >= 58982u ? 65536u : next);
+                }
+            }
+        }
+        if (e == hipSuccess && status == GORDER_OK) e = hipStreamWaitEvent(h->stream, s.copied, 0);
+        if (e != hipSuccess && status == GORDER_OK) { status = GORDER_ERR_DEVICE; hip_msg = std::string("trajectory copy: ") + hipGetErrorString(e); }
         if (status == GORDER_OK)
             status = gorder_hip_submit_device(h, s.d_xyz, h->tables.handle_pbc ? s.d_box : nullptr, s.fidx.data(), s.n);
         if (status == GORDER_OK) {
@@ -483,16 +559,54 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
             s.compute_issued = true;
             frames += s.n;
             batches++;
-            bytes += moved;
+            bytes += s.moved;
         }
         const bool device_error = *reinterpret_cast<volatile unsigned long long *>(h_err) != kErrNone;
+        std::lock_guard<std::mutex> lk(pipe.mu);
+        pipe.free_q.push_back(k);
+        if (status != GORDER_OK || device_error) pipe.stop = true;   // first error aborts the iteration (common.rs:248)
+        pipe.cv.notify_all();
+        return status == GORDER_OK && !device_error;
+    };
+    std::deque<int> decoding;            // batches past stage A whose decoder report is still to come, oldest first
+    for (bool go = true; go;) {
+        // stage A for every batch the reader has filled
+        std::vector<int> fresh;
+        bool finished = false;
         {
-            std::lock_guard<std::mutex> lk(pipe.mu);
-            pipe.free_q.push_back(k);
-            if (status != GORDER_OK || device_error) pipe.stop = true;   // first error aborts the iteration (common.rs:248)
-            pipe.cv.notify_all();
+            const auto t0 = std::chrono::steady_clock::now();
+            std::unique_lock<std::mutex> lk(pipe.mu);
+            if (decoding.empty()) {      // nothing of ours in flight: wait for the reader
+                pipe.cv.wait(lk, [&] { return !pipe.filled_q.empty() || pipe.reader_done; });
+                starved_s += seconds_since(t0);
+            }
+            while (!pipe.filled_q.empty()) {
+                fresh.push_back(pipe.filled_q.front());
+                pipe.filled_q.pop_front();
+            }
+            finished = pipe.reader_done && fresh.empty() && decoding.empty();
         }
-        if (status != GORDER_OK || device_error) break;
+        if (finished) break;
+        for (int k : fresh) {
+            if (!go) break;
+            stage_a(k);
+            if (verify) decoding.push_back(k);
+            else go = stage_b(k);
+        }
+        // stage B for the batches whose report has arrived; with nothing fresh and nothing ready, sleep a little
+        // (the copies of the batches behind are queued already: nothing idles while this thread does)
+        bool any = !fresh.empty();
+        while (go && !decoding.empty() &&
+               (status != GORDER_OK || hipEventQuery(pipe.slot[decoding.front()].copied) == hipSuccess)) {
+            const int front = decoding.front();
+            decoding.pop_front();
+            go = stage_b(front);
+            any = true;
+        }
+        if (go && !any && !decoding.empty()) {
+            std::unique_lock<std::mutex> lk(pipe.mu);
+            pipe.cv.wait_for(lk, std::chrono::microseconds(100), [&] { return !pipe.filled_q.empty(); });
+        }
     }
     {
         std::lock_guard<std::mutex> lk(pipe.mu);
@@ -524,7 +638,7 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
         stats->batch_frames = batch;
         stats->decoder_threads = n_threads;
         stats->device_decode = dev ? 1u : 0u;
-        stats->reserved = 0;
+        stats->frames_decoded_by_host = (uint32_t)std::min<uint64_t>(frames_fixed, UINT32_MAX);
         stats->seconds_setup = setup_s + pipe.setup_s;
         stats->shard_first = shard_lo;
         stats->shard_frames_total = tr->shard_count > 1 ? shard_total : frames;

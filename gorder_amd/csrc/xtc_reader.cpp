@@ -999,7 +999,7 @@ int pack_copy(int fd, const PackSrc *src, size_t i0, size_t i1, uint8_t *blob) {
 int64_t pack_window_impl(gorder_xtc_reader *r, float begin_ps, float end_ps, uint32_t step, uint64_t *state,
                          double *last_time, uint8_t *blob, uint64_t blob_capacity, uint64_t *blob_bytes,
                          gorder_xtc_frame_t *frames, float *box9, float *time_ps, uint64_t capacity,
-                         uint32_t n_threads, gorder_xtc_pool *pool) {
+                         uint32_t n_threads, gorder_xtc_pool *pool, uint32_t prefix_q16 = 65536u, int64_t *file_pos = nullptr) {
     if (!r || !r->fp || r->trr || r->gro || !state || !last_time || !blob || !blob_bytes || !frames || !box9 || step == 0)
         return GORDER_XTC_ERR_ARGUMENT;
     *blob_bytes = 0;
@@ -1052,6 +1052,13 @@ int64_t pack_window_impl(gorder_xtc_reader *r, float begin_ps, float end_ps, uin
             fr.n_bytes = block;
             pos_block = pos0 + (off_t)sizeof(head);
         }
+        // only the leading part of the block (the analysed atoms come first in the frame and the decoder stops behind
+        // them): `copy` bytes are copied and described, bit 1 of `kind` says that the block goes on in the file
+        uint32_t copy = block;
+        if (prefix_q16 < 65536u && natoms > 9) {
+            const uint64_t c = (((uint64_t)block * prefix_q16 >> 16) + 2048u + 3u) & ~3ull;
+            if (c < block) { copy = (uint32_t)c; fr.kind |= 2u; fr.n_bytes = copy; }
+        }
         pos = pos_block + (off_t)block;
         // selection: as in gorder_xtc_read_window
         if ((double)t == *last_time) continue;             // duplicate frame at a file boundary
@@ -1061,7 +1068,7 @@ int64_t pack_window_impl(gorder_xtc_reader *r, float begin_ps, float end_ps, uin
         if (end_ps >= 0.0f && t > end_ps) { to_end = true; break; }
         const uint64_t k = (*state)++;
         if (k % step != 0) continue;
-        const uint64_t need = (((uint64_t)block + 63u) & ~63ull) + 64u;     // whole 64-byte pieces + one piece of zeros
+        const uint64_t need = (((uint64_t)copy + 63u) & ~63ull) + 64u;      // whole 64-byte pieces + one piece of zeros
         if (used + need > blob_capacity) {                 // does not fit any more: this frame opens the next window
             (*state)--;                                    // (nothing of it has happened: a later call meets it again)
             *last_time = time_before;
@@ -1075,7 +1082,8 @@ int64_t pack_window_impl(gorder_xtc_reader *r, float begin_ps, float end_ps, uin
         frames[i] = fr;
         for (int q = 0; q < 9; q++) box9[9 * i + q] = bef(head + 16 + 4 * q);
         if (time_ps) time_ps[i] = t;
-        src.push_back({pos_block, block, fr.offset});
+        if (file_pos) file_pos[i] = (int64_t)pos0;
+        src.push_back({pos_block, copy, fr.offset});
     }
     if (to_end ? fseek(r->fp, 0, SEEK_END) != 0 : fseeko(r->fp, pos, SEEK_SET) != 0) return GORDER_XTC_ERR_FORMAT;
     // pass 2: the blocks, by several readers at once
@@ -1136,6 +1144,20 @@ int64_t gorder_xtc_pack_window(gorder_xtc_reader *r, float begin_ps, float end_p
                                uint32_t n_threads) {
     return pack_window_impl(r, begin_ps, end_ps, step, state, last_time, blob, blob_capacity, blob_bytes, frames, box9,
                             time_ps, capacity, n_threads, nullptr);
+}
+
+int64_t gorder_xtc_pack_window_ex(gorder_xtc_reader *r, float begin_ps, float end_ps, uint32_t step, uint64_t *state,
+                                  double *last_time, uint8_t *blob, uint64_t blob_capacity, uint64_t *blob_bytes,
+                                  gorder_xtc_frame_t *frames, float *box9, float *time_ps, uint64_t capacity,
+                                  uint32_t n_threads, gorder_xtc_pool *pool, uint32_t prefix_q16, int64_t *file_pos) {
+    return pack_window_impl(r, begin_ps, end_ps, step, state, last_time, blob, blob_capacity, blob_bytes, frames, box9,
+                            time_ps, capacity, n_threads ? n_threads : 1, pool, prefix_q16 ? prefix_q16 : 65536u, file_pos);
+}
+
+int gorder_xtc_read_at(gorder_xtc_reader *r, int64_t file_pos, float *xyz, float *box9) {
+    if (!r || !r->fp || !xyz) return GORDER_XTC_ERR_ARGUMENT;
+    if (fseeko(r->fp, (off_t)file_pos, SEEK_SET) != 0) return GORDER_XTC_ERR_FORMAT;
+    return gorder_xtc_next(r, xyz, box9, nullptr, nullptr, nullptr);
 }
 
 int64_t gorder_xtc_pack_window_pool(gorder_xtc_reader *r, float begin_ps, float end_ps, uint32_t step, uint64_t *state,

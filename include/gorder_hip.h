@@ -271,7 +271,9 @@ typedef struct {
     double seconds_reader_stalled;   /* the reader waited for a free staging slot: copies / kernels are the bottleneck */
     double seconds_gpu_starved;      /* the submitter waited for a decoded batch: the decoder is the bottleneck */
     uint32_t batch_frames, decoder_threads;   /* what was used */
-    uint32_t device_decode, reserved;         /* 1: the frames were decompressed on the device */
+    uint32_t device_decode;          /* 1: the frames were decompressed on the device */
+    uint32_t frames_decoded_by_host; /* device route: frames of which too short a leading part had been copied (see
+                                        gorder_xtc_pack_window_ex) and which the host decoded after all */
     uint64_t shard_first, shard_frames_total;   /* with shards: ordinal of this shard's first frame among the F selected; F */
     double seconds_setup;            /* time spent allocating the pinned and device staging buffers (all but the first slot's
                                         share overlaps with reading) */

@@ -86,7 +86,8 @@ typedef struct {
                                 the next multiple of 64 and by 64 more (the device reads whole 64-byte pieces) */
     uint64_t recip1, recip2; /* floor(2^64 / sizeint[1]), floor(2^64 / sizeint[2]) (all ones for a size of 1) */
     uint32_t n_bytes;        /* length of the bit stream, padded to a multiple of 4 as in the file */
-    uint32_t kind;           /* 0: compressed; 1: raw big-endian floats (files of <= 9 atoms) */
+    uint32_t kind;           /* bit 0: raw big-endian floats (files of <= 9 atoms) instead of a compressed block;
+                                bit 1: only a leading part of the block was copied (gorder_xtc_pack_window_ex) */
     int32_t minint[3];
     uint32_t sizeint[3];     /* maxint - minint + 1 */
     int32_t smallidx;
@@ -115,6 +116,19 @@ int64_t gorder_xtc_pack_window_pool(gorder_xtc_reader *r, float begin_ps, float 
                                     double *last_time, uint8_t *blob, uint64_t blob_capacity, uint64_t *blob_bytes,
                                     gorder_xtc_frame_t *frames, float *box9, float *time_ps, uint64_t capacity,
                                     gorder_xtc_pool *pool);
+
+/* The general form.  `pool` may be NULL (then `n_threads` copying threads, synchronously).  `prefix_q16` < 65536 copies
+ * only the leading prefix_q16 / 65536 of every block (+ 2 KB): the analysed atoms come first in a frame and the decoder
+ * stops behind them, so the tail — the solvent — need not travel; such a frame has bit 1 of `kind` set and `n_bytes` =
+ * the bytes copied, and a decoder that runs past them must report the frame as SHORT, not as corrupt (k_xtc_decode
+ * does; the trajectory driver then decodes that frame on the host from `file_pos`).  `file_pos` (may be NULL)
+ * receives the file offset of every packed frame's header, for gorder_xtc_read_at. */
+int64_t gorder_xtc_pack_window_ex(gorder_xtc_reader *r, float begin_ps, float end_ps, uint32_t step, uint64_t *state,
+                                  double *last_time, uint8_t *blob, uint64_t blob_capacity, uint64_t *blob_bytes,
+                                  gorder_xtc_frame_t *frames, float *box9, float *time_ps, uint64_t capacity,
+                                  uint32_t n_threads, gorder_xtc_pool *pool, uint32_t prefix_q16, int64_t *file_pos);
+/* Decode the frame whose header starts at `file_pos` (as reported by gorder_xtc_pack_window_ex); moves the reader. */
+int gorder_xtc_read_at(gorder_xtc_reader *r, int64_t file_pos, float *xyz, float *box9);
 
 /* Look at a file's first bytes only: 1 = XTC (and *n_atoms = atoms per frame), 0 = something else (TRR, GRO, ...),
  * negative = cannot be opened / too short. */

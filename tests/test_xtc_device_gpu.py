@@ -226,6 +226,82 @@ def test_driver_batches_that_end_because_the_blob_is_full(built, tmp_path):
     np.testing.assert_array_equal(res[False].counts, res[True].counts)
 
 
+def _membrane_with_water(tmp_path, n_frames=150, seed=5):
+    """a 'membrane' of 600 bonded atoms in front of 4 200 'water' atoms: decoding stops a seventh into every frame"""
+    rng = np.random.default_rng(seed)
+    n_sel, n_w = 600, 4200
+    xyz = np.concatenate([clustered(rng, n_sel, n_frames, 6.0, sigma=0.05), clustered(rng, n_w, n_frames, 6.0, sigma=0.04)], axis=1)
+    path = write(tmp_path, "mw.xtc", xyz, 6.0, 1000.0)
+    bonds = np.arange(n_sel, dtype=np.uint32).reshape(1, n_sel // 2, 2)
+    tables = abi.Tables(n_atoms=n_sel, molecule_types=[abi.MolType(n_molecules=n_sel // 2, bonds=bonds)])
+    return path, tables, np.arange(n_sel, dtype=np.uint32)
+
+
+@pytest.mark.parametrize("mode", ["adaptive", "forced tiny", "forced half", "off"])
+def test_driver_copies_only_the_part_of_a_frame_it_needs(built, tmp_path, monkeypatch, mode):
+    """The analysed atoms come first in a frame and the decoder stops behind them: after the first batches the driver
+    copies only the leading part of every block that the decoder reported it needed (+ margin).  A frame for which
+    that was too little is reported SHORT and decoded by the host — forced here with a fixed, far too small part — and
+    whatever happens the result is the host route's, bit for bit."""
+    path, tables, group = _membrane_with_water(tmp_path)
+    host = HipEngine(tables)
+    s0 = host.run_trajectory([path] * 6, group=group, threads=2, batch_frames=40)
+    want = host.finish()
+    if mode == "forced tiny":
+        monkeypatch.setenv("GORDER_HIP_PREFIX_Q16", "2000")        # 3 % of a block: every frame comes out short
+    if mode == "forced half":
+        monkeypatch.setenv("GORDER_HIP_PREFIX_Q16", "32768")       # plenty: the analysed atoms end a seventh into the frame
+    if mode == "off":
+        monkeypatch.setenv("GORDER_HIP_NO_PREFIX", "1")
+    eng = HipEngine(tables)
+    s1 = eng.run_trajectory([path] * 6, group=group, threads=2, batch_frames=40, device_decode=True)
+    got = eng.finish()
+    assert s1["device_decode"] == 1 and s1["n_frames"] == s0["n_frames"] == 900
+    np.testing.assert_array_equal(got.sums, want.sums)
+    np.testing.assert_array_equal(got.counts, want.counts)
+    full = os.path.getsize(path) * 6
+    if mode == "forced tiny":
+        assert s1["frames_decoded_by_host"] == 900
+    elif mode == "forced half":
+        assert s1["frames_decoded_by_host"] == 0 and s1["bytes_h2d"] < 0.62 * full
+    elif mode == "off":
+        assert s1["frames_decoded_by_host"] == 0 and s1["bytes_h2d"] > 0.95 * full
+    else:
+        assert s1["frames_decoded_by_host"] == 0 and s1["bytes_h2d"] < 0.75 * full      # the first batches travel whole
+
+
+def test_short_frames_through_the_plain_call_are_errors(engine, tmp_path):
+    """gorder_hip_xtc_decode has no list to put a short frame on: a frame packed with too small a part is reported
+    like a truncated one"""
+    path, tables, group = _membrane_with_water(tmp_path, n_frames=3)
+    lib = xtc._lib()
+    import ctypes as C
+    r = C.c_void_p()
+    assert lib.gorder_xtc_open(path.encode(), None, 0, C.byref(r)) == 0
+    state, last, used = C.c_uint64(0), C.c_double(float("-inf")), C.c_uint64(0)
+    blob = np.zeros(1 << 20, np.uint8)
+    frames = (abi.CXtcFrame * 3)()
+    box, t, pos = np.empty((3, 9), np.float32), np.empty(3, np.float32), np.zeros(3, np.int64)
+    lib.gorder_xtc_pack_window_ex.restype = C.c_int64
+    lib.gorder_xtc_pack_window_ex.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_uint32, C.POINTER(C.c_uint64),
+                                              C.POINTER(C.c_double), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+    got = lib.gorder_xtc_pack_window_ex(r, 0.0, -1.0, 1, C.byref(state), C.byref(last), blob.ctypes.data, blob.size, C.byref(used),
+                                        C.cast(frames, C.c_void_p), box.ctypes.data, t.ctypes.data, 3, 1, None, 1000, pos.ctypes.data)
+    lib.gorder_xtc_close(r)
+    assert got == 3 and all(f.kind & 2 for f in frames) and pos[0] == 0 and pos[1] > 0
+    fr = np.frombuffer(frames, dtype=np.dtype(abi.CXtcFrame)).copy()
+    d_blob = torch.from_numpy(blob[:used.value].copy()).cuda()
+    d_frames = torch.from_numpy(fr.view(np.uint8).reshape(-1).copy()).cuda()
+    out = torch.zeros((3, 4800, 3), dtype=torch.float32, device="cuda")
+    mt = abi.MolType(n_molecules=1, bonds=np.array([[[0, 1]]], dtype=np.uint32))
+    eng = HipEngine(abi.Tables(n_atoms=2, molecule_types=[mt]))
+    eng.xtc_decode(d_blob.data_ptr(), d_blob.numel(), d_frames.data_ptr(), 3, 4800, 0, 4800, out.data_ptr(), 4800)
+    with pytest.raises(abi.GorderHipError) as ei:
+        eng.synchronize()
+    assert ei.value.status == abi.ERR_TRAJECTORY_FORMAT
+
+
 def test_staging_is_kept_and_released(cg, tmp_path):
     """a handle's second run finds its staging buffers (no setup to speak of), runs of another shape and
     release_staging start over; results do not depend on any of it"""
