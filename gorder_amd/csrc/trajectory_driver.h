@@ -72,6 +72,7 @@ struct TrajPipe {
     std::string reader_msg;
     double decode_s = 0.0, reader_stalled_s = 0.0, setup_s = 0.0;
     std::atomic<uint32_t> prefix_q16{65536};   // the leading part of every block the reader copies (device route)
+    uint32_t reports = 0;                      // batches whose decoder report the submitter has seen (under mu)
     bool alloc_failed = false;
 };
 
@@ -145,11 +146,6 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
             }
         }
     }
-    // The device route copies whole compressed frames (where in a block the analysed atoms end is only known after
-    // decoding) while the host decoder stops at the last analysed atom: with the analysed atoms in the first sixth of a
-    // frame (a solute in front of its solvent) the host route moves and decodes so much less that it wins
-    // (measured at one quarter: 63 k against 48 k frames/s, still in favour of the device).
-    if (dev && tr->batch_frames == 0 && (uint64_t)n_stop * 6u < n_file_atoms) dev = false;
     if (dev && tr->group && tr->n_group) {
         slot_of.assign(n_file_atoms, -1);
         for (uint32_t k = 0; k < tr->n_group; k++) slot_of[tr->group[k]] = (int32_t)k;     // (gorder_xtc_open checked the range)
@@ -335,6 +331,12 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
     // runs while the blocks of this one are still being copied
     gorder_xtc_pool *pool = nullptr;
     if (dev && gorder_xtc_pool_create(n_threads, &pool) != GORDER_XTC_OK) pool = nullptr;
+    const char *forced_prefix = getenv("GORDER_HIP_PREFIX_Q16");          // test switch: a fixed part, whatever it leads to
+    const bool adapt_prefix = dev && !forced_prefix && !env_flag("GORDER_HIP_NO_PREFIX") && n_stop < n_file_atoms;
+    if (dev && forced_prefix) pipe.prefix_q16.store((uint32_t)std::max(1l, std::min(65536l, atol(forced_prefix))));
+    // only a run that copies parts of blocks has anything to look at between the two stages; any other queues stage B
+    // right behind stage A and never waits for the device
+    const bool verify = dev && (adapt_prefix || forced_prefix);
     // ---- reader thread: the sequential part of read_trajectory (time window, step, concatenation) + decoding
     const int device = h->device;
     std::thread reader([&, device]() {
@@ -344,6 +346,7 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
         uint32_t f = 0;                       // next file to open
         gorder_xtc_reader *r = nullptr;       // the open one
         bool done = shard_n == 0;
+        uint32_t n_filled = 0;                // batches this thread has started to fill
         uint64_t to_skip = shard_lo, left = shard_n;      // frames before this rank's shard; frames of it still to read
         auto give_up = [&](int st, const std::string &msg) {
             std::lock_guard<std::mutex> lk(pipe.mu);
@@ -373,8 +376,21 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
             // a batch is filled across file boundaries: a trajectory split into many short files still makes full batches
             s.n = 0;
             s.blob_bytes = 0;
+            // A run that will copy only parts of blocks learns the part from the decoder's first report: its first
+            // two batches are short (256 and 1024 frames) and the third waits for that report, so that no more than
+            // ~1 300 frames travel whole.
+            uint32_t fill = batch;
+            if (adapt_prefix && tr->batch_frames == 0) {
+                if (n_filled == 0) fill = std::min(batch, 256u);
+                else if (n_filled == 1) fill = std::min(batch, 1024u);
+                else if (n_filled == 2) {
+                    std::unique_lock<std::mutex> lk(pipe.mu);
+                    pipe.cv.wait(lk, [&] { return pipe.stop || pipe.reports > 0; });
+                }
+            }
+            n_filled++;
             s.prefix_q16 = pipe.prefix_q16.load();
-            while (!done && s.n < batch) {
+            while (!done && s.n < fill) {
                 if (left == 0) { done = true; break; }
                 if (!r) {
                     if (f == tr->n_paths) { done = true; break; }
@@ -397,7 +413,7 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
                         continue;
                     }
                 }
-                const uint64_t want = std::min<uint64_t>(batch - s.n, left);
+                const uint64_t want = std::min<uint64_t>(fill - s.n, left);
                 uint64_t used = 0;
                 const int64_t got =
                     dev ? gorder_xtc_pack_window_ex(r, tr->begin_ps, tr->end_ps, tr->step, &state, &last_time,
@@ -463,12 +479,6 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
     uint64_t frames = 0, batches = 0, bytes = 0, frames_fixed = 0;
     double starved_s = 0.0;
     std::string hip_msg;
-    const char *forced_prefix = getenv("GORDER_HIP_PREFIX_Q16");          // test switch: a fixed part, whatever it leads to
-    const bool adapt_prefix = dev && !forced_prefix && !env_flag("GORDER_HIP_NO_PREFIX") && n_stop < n_file_atoms;
-    if (dev && forced_prefix) pipe.prefix_q16.store((uint32_t)std::max(1l, std::min(65536l, atol(forced_prefix))));
-    // only a run that copies parts of blocks has anything to look at between the two stages; any other queues stage B
-    // right behind stage A and never waits for the device
-    const bool verify = dev && (adapt_prefix || forced_prefix);
     uint32_t need_q16 = 0;                                                   // the largest part of a block a frame needed so far
     auto stage_a = [&](int k) {
         TrajSlot &s = pipe.slot[k];
@@ -546,6 +556,9 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
                     if (n_short) next = std::max<uint32_t>(next, s.prefix_q16 + s.prefix_q16 / 4u);
                     pipe.prefix_q16.store(next >= 58982u ? 65536u : next);
                 }
+                std::lock_guard<std::mutex> lk(pipe.mu);
+                pipe.reports++;
+                pipe.cv.notify_all();
             }
         }
         if (e == hipSuccess && status == GORDER_OK) e = hipStreamWaitEvent(h->stream, s.copied, 0);

@@ -248,9 +248,10 @@ typedef struct {
                                     (about a third of the decoded bytes) and gorder_hip_xtc_decode unpacks one frame
                                     per lane.  Same coordinates bit for bit.  A run with a TRR or GRO file in it, or of frames
                                     so large that fewer than 512 fit a 4-GiB batch (about 700 000 analysed atoms; a launch
-                                    takes 0.6 us per atom whatever its size), or whose analysed atoms end within the first
-                                    sixth of a frame (the host decoder stops there, the device route copies whole frames),
-                                    uses the host decoder.  0: host decoder threads */
+                                    takes 0.6 us per atom whatever its size), uses the host decoder.  When the analysed
+                                    atoms end before the frame does, only the leading part of every compressed block the
+                                    decoder needs is copied (learned from the first batches; a frame that needs more is
+                                    decoded by the host).  0: host decoder threads */
     uint32_t shard_index;        /* SURVEY 8e, contiguous frame shards: with shard_count = n > 1 the call first counts the F frames */
     uint32_t shard_count;        /* the window selects (headers only), then analyses frames [i F / n, (i + 1) F / n) of them,
                                     numbered as in the whole trajectory (first_frame_index + k * step for the k-th selected
