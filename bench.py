@@ -12,7 +12,8 @@ N = 1 (default): BASELINE.json configs[1] — AAOrder, 256-lipid membrane (25 08
     cpu_baseline      the oracle (C restatement of the reference algorithm, libm trig like the Rust code) on this box's
                       host cores, at 1 thread and at all cores,
     end_to_end        the same workload from an XTC FILE (gorder_hip_run_trajectory): frames/s from file with the frames
-                      decompressed on the device (value) and by host threads (host_decode), PCIe GB/s,
+                      decompressed on the device (value) and by host threads (host_decode), PCIe GB/s; `solvated`:
+                      the same with three times as many solvent atoms behind the analysed ones in every frame,
     scaling_reference the north_star scaling job (CG-1M, 10 000 frames) on this one GPU: the N = 1 point of the curve
                       that `--gpus N` continues.
 N > 1 (launched by torch.distributed.run, one rank per GPU): the north_star scaling experiment — STRONG scaling of
@@ -176,6 +177,44 @@ def end_to_end(system, device_index, n_unique=500, repeats=200):
                    "(gorder_xtc_pack_window) -> pinned staging x3 -> hipMemcpyAsync -> k_xtc_decode (one frame per lane) "
                    "-> kernels.  host_decode: gorder_xtc_read_window_mt on the same threads -> pinned -> hipMemcpyAsync "
                    "-> kernels.  Both routes give identical sums (checked)." % (n_unique, repeats, t_write))
+    return out
+
+
+def end_to_end_solvated(system, device_index, n_unique=100, repeats=200, water_per_atom=3):
+    """The same workload as a real membrane simulation stores it: the analysed atoms in front of `water_per_atom` times
+    as many solvent atoms.  The host decoder stops at the last analysed atom; the device route learns from the decoder's
+    first report which leading part of every compressed block it needs and copies only that."""
+    from gorder_amd import HipEngine, xtc
+    cores = host_cores()
+    rng = np.random.default_rng(7)
+    n_sel = system.n_atoms
+    n_w = water_per_atom * n_sel
+    span = float(system.box[0])
+    centres = rng.uniform(0.0, span, size=(n_w // 3, 1, 3))
+    w0 = (centres + rng.normal(0.0, 0.05, size=(n_w // 3, 3, 3))).reshape(-1, 3)
+    water = (w0[None] + rng.normal(0.0, 0.03, size=(n_unique, n_w, 3))).astype(np.float32)
+    xyz = np.concatenate([system.frames(n_unique, seed=11), water], axis=1)
+    group = np.arange(n_sel, dtype=np.uint32)
+    out = {"atoms_in_file": int(xyz.shape[1]), "atoms_analysed": int(n_sel), "frames": n_unique * repeats}
+    with tempfile.TemporaryDirectory(prefix="gorder_bench_") as tmp:
+        path = os.path.join(tmp, "solvated.xtc")
+        xtc.write_trajectory(path, xyz, system.box9(n_unique), precision=1000.0)
+        out["compressed_bytes_per_frame"] = os.path.getsize(path) / n_unique
+        system.tables.device = device_index
+        eng = HipEngine(system.tables)
+        sums = {}
+        for route, dev in (("host_decode", False), ("device_decode", True)):
+            eng.reset()
+            eng.run_trajectory([path] * 2, group=group, threads=cores, device_decode=dev)
+            eng.reset()
+            st = eng.run_trajectory([path] * repeats, group=group, threads=cores, device_decode=dev)
+            sums[route] = eng.finish().sums
+            out[route] = {"value": st["n_frames"] / st["seconds_total"], "unit": "frames/s",
+                          "pcie_GBps": st["bytes_h2d"] / st["seconds_total"] / 1e9,
+                          "decoded_on": "device" if st["device_decode"] else "host",
+                          "frames_decoded_by_host_after_all": st["frames_decoded_by_host"]}
+        eng.close()
+    np.testing.assert_array_equal(sums["host_decode"], sums["device_decode"])
     return out
 
 
@@ -450,6 +489,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(system)
         if not args.no_end_to_end:
             out["end_to_end"] = end_to_end(system, local_rank)
+            if name == "aa256":
+                out["end_to_end"]["solvated"] = end_to_end_solvated(system, local_rank)
         if not args.no_scaling_reference and name == "aa256" and not args.frames and args.trig == "squared":
             free_b, _ = torch.cuda.mem_get_info(device)
             if free_b > 150 * (1 << 30):
