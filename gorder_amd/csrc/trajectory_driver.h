@@ -124,7 +124,8 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
     HIP_TRY(h, hipSetDevice(h->device));
     const auto t_start = std::chrono::steady_clock::now();
     const uint32_t n_atoms = h->plan.n_atoms;
-    uint32_t n_threads = tr->n_threads ? tr->n_threads : std::max(1u, std::thread::hardware_concurrency());
+    // (0: the machine's threads, at most 16 — the copies and the decoder saturate there, and a node runs one rank per GPU)
+    uint32_t n_threads = tr->n_threads ? tr->n_threads : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     // device decode: every file must be XTC (TRR / GRO have nothing to decompress); the atoms per frame of the
     // first file size the blob
     bool dev = tr->device_decode != 0;

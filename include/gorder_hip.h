@@ -240,7 +240,7 @@ typedef struct {
     uint32_t n_group;
     float begin_ps, end_ps;      /* inclusive window on the frame time; end_ps < 0 = to the end */
     uint32_t step;               /* analyse every step-th frame of the window (>= 1) */
-    uint32_t n_threads;          /* decoder threads; 0 = all hardware threads */
+    uint32_t n_threads;          /* decoder / copying threads; 0 = the hardware threads, at most 16 */
     uint32_t batch_frames;       /* frames per device batch; 0 = about 128 MB of coordinates (1 GiB with device_decode) */
     uint64_t first_frame_index;  /* 0 for a whole trajectory; a rank that reads a later window passes where it starts */
     uint32_t device_decode;      /* 1: XTC files are decompressed ON THE DEVICE — the host threads only copy the compressed
