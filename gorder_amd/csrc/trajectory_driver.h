@@ -129,11 +129,15 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
     // device decode: every file must be XTC (TRR / GRO have nothing to decompress); the atoms per frame of the
     // first file size the blob
     bool dev = tr->device_decode != 0;
-    uint32_t n_file_atoms = 0, n_stop = 0;
+    uint32_t n_file_atoms = 0, n_stop = 0, first_frame_bytes = 0;
+    uint64_t total_file_bytes = 0;
     std::vector<int32_t> slot_of;
     for (uint32_t f = 0; dev && f < tr->n_paths; f++) {
-        uint32_t na = 0;
-        if (gorder_xtc_probe(tr->paths[f], &na) != 1) { dev = false; break; }     // (an unreadable file: the reader thread reports it)
+        uint32_t na = 0, first = 0;
+        uint64_t fbytes = 0;
+        if (gorder_xtc_probe(tr->paths[f], &na, &fbytes, &first) != 1) { dev = false; break; }     // (an unreadable file: the reader thread reports it)
+        total_file_bytes += fbytes;
+        if (f == 0) first_frame_bytes = first;
         if (f == 0) n_file_atoms = na;
         else if (na != n_file_atoms) dev = false;
     }
@@ -225,6 +229,12 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
         if (b < 512) b = std::min<size_t>(512, ((size_t)4 << 30) / ((size_t)n_atoms * 12u));
         if (b < 512) dev = false;
         else batch = (uint32_t)b;
+        // A short trajectory does not need (and should not pay for pinning) four full-size slots: about a third of its
+        // frames per batch, estimated from the files' sizes and the first frame's
+        if (dev && first_frame_bytes) {
+            const uint64_t est_frames = total_file_bytes / first_frame_bytes + 1u;
+            batch = (uint32_t)std::min<uint64_t>(batch, std::max<uint64_t>(256u, (est_frames + 2u) / 3u + 16u));
+        }
     }
     if (batch == 0) batch = (uint32_t)std::min<size_t>(4096, std::max<size_t>(16, ((size_t)128 << 20) / ((size_t)n_atoms * 12u)));
     const size_t xyz_bytes = (size_t)batch * n_atoms * 3u * sizeof(float), box_bytes = (size_t)batch * 9u * sizeof(float);

@@ -959,16 +959,26 @@ void gorder_xtc_pool_destroy(gorder_xtc_pool *p) {
 }
 
 
-int gorder_xtc_probe(const char *path, uint32_t *n_atoms) {
+int gorder_xtc_probe(const char *path, uint32_t *n_atoms, uint64_t *file_bytes, uint32_t *first_frame_bytes) {
     if (!path) return GORDER_XTC_ERR_ARGUMENT;
     FILE *fp = fopen(path, "rb");
     if (!fp) return GORDER_XTC_ERR_OPEN;
-    uint8_t head[8];
-    const bool ok = read_exact(fp, head, 8);
+    uint8_t head[92];
+    const size_t got = fread(head, 1, sizeof(head), fp);
+    if (file_bytes) {
+        *file_bytes = 0;
+        if (fseeko(fp, 0, SEEK_END) == 0) *file_bytes = (uint64_t)ftello(fp);
+    }
     fclose(fp);
-    if (!ok) return GORDER_XTC_ERR_FORMAT;
+    if (got < 8) return GORDER_XTC_ERR_FORMAT;
     if (be32(head) != 1995u) return 0;
-    if (n_atoms) *n_atoms = be32(head + 4);
+    const uint32_t na = be32(head + 4);
+    if (n_atoms) *n_atoms = na;
+    if (first_frame_bytes) {       // header + coordinate block of the first frame (0: the file is too short to tell)
+        *first_frame_bytes = 0;
+        if (na <= 9 && got >= 56) *first_frame_bytes = 56u + 12u * na;
+        else if (na > 9 && got == sizeof(head)) *first_frame_bytes = 92u + ((be32(head + 88) + 3u) & ~3u);
+    }
     return 1;
 }
 int gorder_xtc_is_xtc(const gorder_xtc_reader *r) { return (r && !r->trr && !r->gro) ? 1 : 0; }

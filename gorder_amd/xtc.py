@@ -46,7 +46,7 @@ def _lib():
                                                     C.c_uint64, vp]
         lib.gorder_xtc_pack_window_pool.restype = C.c_int64
         lib.gorder_xtc_is_xtc.argtypes = [vp]
-        lib.gorder_xtc_probe.argtypes = [C.c_char_p, C.POINTER(C.c_uint32)]
+        lib.gorder_xtc_probe.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
         lib.gorder_xtc_n_atoms_needed.argtypes = [vp]
         lib.gorder_xtc_n_atoms_needed.restype = C.c_uint32
         lib.gorder_xtc_writer_open.argtypes = [C.c_char_p, C.c_uint32, C.c_float, C.POINTER(vp)]

@@ -130,9 +130,10 @@ int64_t gorder_xtc_pack_window_ex(gorder_xtc_reader *r, float begin_ps, float en
 /* Decode the frame whose header starts at `file_pos` (as reported by gorder_xtc_pack_window_ex); moves the reader. */
 int gorder_xtc_read_at(gorder_xtc_reader *r, int64_t file_pos, float *xyz, float *box9);
 
-/* Look at a file's first bytes only: 1 = XTC (and *n_atoms = atoms per frame), 0 = something else (TRR, GRO, ...),
- * negative = cannot be opened / too short. */
-int gorder_xtc_probe(const char *path, uint32_t *n_atoms);
+/* Look at a file's first bytes only: 1 = XTC (and *n_atoms = atoms per frame, *file_bytes = size of the file,
+ * *first_frame_bytes = header + coordinate block of its first frame; each may be NULL), 0 = something else
+ * (TRR, GRO, ...), negative = cannot be opened / too short. */
+int gorder_xtc_probe(const char *path, uint32_t *n_atoms, uint64_t *file_bytes, uint32_t *first_frame_bytes);
 /* 1 when the reader's file is an XTC file (what gorder_xtc_pack_window accepts), else 0 */
 int gorder_xtc_is_xtc(const gorder_xtc_reader *r);
 /* atoms of a frame the decoder has to go through: up to the last atom of the group (all atoms without a group) */

@@ -12,7 +12,8 @@ int main() {
     const char *files[] = {GOLDEN "/multiple_resid_same_name.xtc", GOLDEN "/cg3.xtc", GOLDEN "/pcpepg4.xtc"};
     for (const char *path : files) {
         uint32_t na = 0;
-        if (gorder_xtc_probe(path, &na) != 1) return 1;
+        uint64_t fbytes = 0; uint32_t first = 0;
+        if (gorder_xtc_probe(path, &na, &fbytes, &first) != 1 || first == 0 || first > fbytes) return 1;
         std::vector<uint32_t> group;
         for (uint32_t i = 0; i < na; i += 3) group.push_back(i);
         for (int g = 0; g < 2; g++) {
