@@ -147,20 +147,22 @@ def end_to_end(system, device_index, n_unique=500, repeats=200):
         runs = {}
         for route, dev in (("host_decode", False), ("device_decode", True)):
             eng.reset()
-            first = eng.run_trajectory([path] * 2, threads=cores, device_decode=dev)   # warm: page cache, staging buffers, kernels
+            # warm: page cache, kernels, and the handle's staging buffers (sized to the trajectory: the same file list)
+            first = eng.run_trajectory([path] * repeats, threads=cores, device_decode=dev)
             eng.reset()
             stats = eng.run_trajectory([path] * repeats, threads=cores, device_decode=dev)
             res = eng.finish()
             assert stats["n_frames"] == n_unique * repeats == res.n_frames
             assert stats["device_decode"] <= int(dev)      # (frames too large for one-lane-per-frame decoding: host decoder)
             stats["first_call_setup"] = first["seconds_setup"]
+            stats["first_call_value"] = first["n_frames"] / first["seconds_total"]
             runs[route] = (stats, res)
         eng.close()
     np.testing.assert_array_equal(runs["host_decode"][1].sums, runs["device_decode"][1].sums)   # same coordinates, same sums
 
     def block(stats):
         n, sec = stats["n_frames"], stats["seconds_total"]
-        return {"value": n / sec, "unit": "frames/s", "frames": n, "host_threads": stats["decoder_threads"],
+        return {"value": n / sec, "unit": "frames/s", "first_call_value": stats["first_call_value"], "frames": n, "host_threads": stats["decoder_threads"],
                 "batch_frames": stats["batch_frames"], "batches": stats["n_batches"], "decoded_on": "device" if stats["device_decode"] else "host",
                 "pcie_GBps": stats["bytes_h2d"] / sec / 1e9, "file_read_MBps": size * repeats / sec / 1e6,
                 "seconds": {"total": sec, "setup": stats["seconds_setup"],
@@ -205,11 +207,11 @@ def end_to_end_solvated(system, device_index, n_unique=100, repeats=200, water_p
         sums = {}
         for route, dev in (("host_decode", False), ("device_decode", True)):
             eng.reset()
-            eng.run_trajectory([path] * 2, group=group, threads=cores, device_decode=dev)
+            first = eng.run_trajectory([path] * repeats, group=group, threads=cores, device_decode=dev)     # warm, same shape
             eng.reset()
             st = eng.run_trajectory([path] * repeats, group=group, threads=cores, device_decode=dev)
             sums[route] = eng.finish().sums
-            out[route] = {"value": st["n_frames"] / st["seconds_total"], "unit": "frames/s",
+            out[route] = {"first_call_value": first["n_frames"] / first["seconds_total"], "value": st["n_frames"] / st["seconds_total"], "unit": "frames/s",
                           "pcie_GBps": st["bytes_h2d"] / st["seconds_total"] / 1e9,
                           "decoded_on": "device" if st["device_decode"] else "host",
                           "frames_decoded_by_host_after_all": st["frames_decoded_by_host"]}
