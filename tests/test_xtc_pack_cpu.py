@@ -126,6 +126,21 @@ def test_pack_concatenation_and_group(built, tmp_path):
     assert list(np.flatnonzero(w["slot_of"] >= 0)) == [5, 17, 300, 311]
 
 
+def test_probe(built, tmp_path):
+    import ctypes as C
+    lib = xtc._lib()
+    n, size, first = C.c_uint32(), C.c_uint64(), C.c_uint32()
+    assert lib.gorder_xtc_probe(CG3.encode(), C.byref(n), C.byref(size), C.byref(first)) == 1
+    assert n.value == 16769 and size.value == os.path.getsize(CG3) == first.value        # one frame: the file IS that frame
+    path = synthetic(tmp_path, n_frames=4)
+    assert lib.gorder_xtc_probe(path.encode(), C.byref(n), C.byref(size), C.byref(first)) == 1
+    assert n.value == 700 and 0 < first.value < size.value == os.path.getsize(path)
+    other = str(tmp_path / "not.xtc")
+    open(other, "wb").write(b"title\n   12\n" + bytes(100))
+    assert lib.gorder_xtc_probe(other.encode(), None, None, None) == 0
+    assert lib.gorder_xtc_probe(str(tmp_path / "missing.xtc").encode(), None, None, None) < 0
+
+
 def test_pack_reference_file(built):
     """tests/golden/cg3.xtc (the reference's tests/files/split/cg3.xtc): header fields as the format defines them."""
     ws = xtc.pack_trajectory([CG3])
