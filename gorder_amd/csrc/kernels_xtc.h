@@ -12,8 +12,9 @@
 // iteration of every lane decodes exactly ONE atom — full-width or small, by the lane's own state — so the atom
 // counter is wave-uniform (the slot lookups are scalar loads, the stores of a wave go to the same atom of 64 frames)
 // and the trip count is the number of atoms up to the last analysed one, not a data-dependent quantity.
-// The bit reader keeps 128 bits of the stream in registers and the next 64 prefetched, so no load is on the
-// dependency chain of a field; every lane reads its own stream with aligned 8-byte loads.
+// The bit reader keeps 128 bits of the stream in registers and the next 64 prefetched from the lane's ring in LDS, which
+// is refilled in 64-byte pieces at the service points of the loop (see k_xtc_decode): no load is on the dependency
+// chain of a field, and no instruction of the loop waits for memory.
 #pragma once
 
 #include "../../include/gorder_xtc.h"
@@ -22,7 +23,7 @@ namespace {
 
 constexpr int kXtcFirstIdx = 9, kXtcLastIdx = 73;
 constexpr uint32_t kXtcGroup = 8;      // atoms written out together (see k_xtc_decode)
-constexpr uint32_t kXtcWaves = 1;      // waves per workgroup (co-resident waves do not shorten a wave: 12 per CU measured 25 % slower, the loads of 64 streams each contend for the one address unit)
+constexpr uint32_t kXtcWaves = 1;      // waves per workgroup (co-resident waves do not shorten a wave; 12 per CU measured 25 % slower)
 constexpr uint32_t kXtcRingWords = 32;  // a lane's input ring in LDS: 256 bytes of its stream, refilled 64 bytes at a time
 constexpr uint32_t kXtcRingPitch = 33;  // words per lane (bank spread)
 constexpr uint32_t kXtcPitch = 65;     // floats per (atom, coordinate) row of the LDS staging: 64 frames + 1 (bank spread)
