@@ -71,12 +71,19 @@ def make_system(name):
     raise SystemExit(f"unknown workload {name}")
 
 
-def host_cores():
+def cores_available():
     try:
-        cores = len(os.sched_getaffinity(0))
+        return max(1, len(os.sched_getaffinity(0)))
     except AttributeError:
-        cores = os.cpu_count() or 1
-    return max(1, min(cores, 16))   # a one-GPU box grants a 16-core CPU share
+        return max(1, os.cpu_count() or 1)
+
+
+def host_cores():
+    """Threads the CPU-side measurements use: every core this process may run on, up to GORDER_BENCH_MAX_THREADS
+    (default 64: the oracle's frame-interleaved threads and the reader's copy threads stop scaling long before that;
+    both numbers are reported — `cores` and `cores_available` — so a cap is never silent)."""
+    cap = int(os.environ.get("GORDER_BENCH_MAX_THREADS", "64"))
+    return max(1, min(cores_available(), cap))
 
 
 def cpu_baseline(system, seconds_target=8.0):
@@ -101,7 +108,7 @@ def cpu_baseline(system, seconds_target=8.0):
 
     all_cores, reps = timed(cores)
     one, reps1 = timed(1)
-    return {"value": all_cores, "unit": "frames/s", "cores": cores, "kind": "port",
+    return {"value": all_cores, "unit": "frames/s", "cores": cores, "cores_available": cores_available(), "kind": "port",
             "value_1_thread": one,
             "sample": f"{n_sample} synthetic frames of the same workload x {reps} passes on {cores} threads "
                       f"(x {reps1} passes on 1 thread); libm trig, frame-interleaved threads + ordered reduce"}
@@ -217,6 +224,78 @@ def end_to_end_solvated(system, device_index, n_unique=100, repeats=200, water_p
                           "frames_decoded_by_host_after_all": st["frames_decoded_by_host"]}
         eng.close()
     np.testing.assert_array_equal(sums["host_decode"], sums["device_decode"])
+    return out
+
+
+def end_to_end_sharded(dist, rank, world, local_rank, device, rehearsal, n_unique=500, repeats_per_rank=40):
+    """N > 1: the path a multi-GPU host really takes from a FILE.  Every rank opens the SAME trajectory and calls
+    gorder_hip_run_trajectory with shard_index = rank, shard_count = world (contiguous shares of the selected frames,
+    SURVEY §8e; frames decompressed on the device), then ONE all-reduce of the packed accumulators
+    (SystemTopology::reduce, topology/mod.rs:256-278).  Timed between barriers, max over ranks; afterwards rank 0
+    analyses the whole trajectory on one handle and the reduced sums must equal that bit for bit."""
+    import shutil
+    import torch
+    from gorder_amd import HipEngine, xtc
+    system, workload = make_system("aa256")
+    system.tables.device = local_rank
+    cpu = torch.device("cpu")
+    tdev = cpu if rehearsal else device
+    box = [None]
+    if rank == 0:
+        tmp = tempfile.mkdtemp(prefix="gorder_bench_shards_")
+        path = os.path.join(tmp, "traj.xtc")
+        xtc.write_trajectory(path, system.frames(n_unique, seed=4242), system.box9(n_unique),
+                             times=np.arange(n_unique, dtype=np.float32) * 10.0, precision=1000.0)
+        box[0] = path
+    dist.broadcast_object_list(box, src=0)          # one node: every rank sees rank 0's file
+    path = box[0]
+    repeats = repeats_per_rank * world
+    paths = [path] * repeats
+    threads = max(1, min(16, cores_available() // world))
+    eng = HipEngine(system.tables)
+    eng.use_torch_stream()
+    acc = torch.zeros(eng.accumulator_words(), dtype=torch.int64, device=device)
+    eng.bind_accumulators(acc)
+    eng.run_trajectory(paths, threads=threads, device_decode=True, shard=(rank, world))      # warm: staging, page cache
+    eng.reset()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stats = eng.run_trajectory(paths, threads=threads, device_decode=True, shard=(rank, world))
+    t_run = time.perf_counter() - t0
+    eng.flush()
+    dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt, t_run, float(stats["n_frames"]), float(stats["shard_first"])], dtype=torch.float64, device=tdev)
+    rows = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(rows, t)
+    rows = [[float(x) for x in r.tolist()] for r in rows]
+    out = None
+    if rank == 0:
+        total = n_unique * repeats
+        reduced = acc.cpu().numpy().copy()
+        one = HipEngine(system.tables)
+        one.run_trajectory(paths, threads=threads, device_decode=True)
+        want = one.finish()
+        n_acc = system.tables.n_acc
+        same = bool(np.array_equal(reduced[:n_acc], want.sums[0]) and np.array_equal(reduced[2 * n_acc:3 * n_acc].astype(np.uint64), want.counts[0])
+                    and int(reduced[4 * n_acc]) == want.n_frames == total)
+        one.close()
+        out = {"value": total / max(r[0] for r in rows), "unit": "frames/s", "frames": total, "workload": workload,
+               "path": "one XTC trajectory (%d frames: %d unique x %d), every rank: gorder_hip_run_trajectory(shard_index = rank, "
+                       "shard_count = %d, device_decode) -> one all-reduce of the packed accumulators" % (total, n_unique, repeats, world),
+               "host_threads_per_rank": threads,
+               "per_rank": [{"seconds_run_trajectory": r[1], "frames": int(r[2]), "first_frame_of_shard": int(r[3])} for r in rows],
+               "frames_of_all_shards": int(sum(r[2] for r in rows)),
+               "equal_to_one_handle": same}
+        assert same, "sharded ranks + all-reduce differ from one handle over the whole trajectory"
+        assert out["frames_of_all_shards"] == total
+    eng.close()
+    dist.barrier()
+    if rank == 0:
+        shutil.rmtree(os.path.dirname(path), ignore_errors=True)
     return out
 
 
@@ -414,6 +493,7 @@ def main():
         dt = float(t.item())
 
     kernel_ms, launches = eng.kernel_time()
+    kernel_names = eng.kernel_names()      # what the timed region really launched (gorder_hip_kernel_time_names)
     res = eng.finish()
     allreduce_ms = None
     if world > 1:                  # the collective alone, after the timed region (what a step pays for it)
@@ -431,27 +511,37 @@ def main():
     else:
         expect_frames = (args.steps + n_warm) * frames * world   # warm-up passes accumulate too
         ok_counts = int(res.counts[0].min()) > 0
-    per_rank = None
+    per_rank = per_rank_ms = per_rank_dev = None
     if world > 1:                  # per-rank fraction of the HBM roofline on the rank's own shard
         avg = kernel_ms / 1e3 / max(1, launches)
-        mine = torch.tensor([system.bytes_per_frame * frames / avg / 1e9 / HBM_PEAK_GBS if avg > 0 else 0.0],
+        mine = torch.tensor([system.bytes_per_frame * frames / avg / 1e9 / HBM_PEAK_GBS if avg > 0 else 0.0,
+                             avg * 1e3, float(torch.cuda.current_device())],
                             dtype=torch.float64, device=device if not rehearsal else "cpu")
         gathered = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine)
-        per_rank = [float(g.item()) for g in gathered]
+        per_rank = [float(g[0].item()) for g in gathered]
+        per_rank_ms = [float(g[1].item()) for g in gathered]
+        per_rank_dev = [int(g[2].item()) for g in gathered]
 
     if rank == 0:
         # HBM traffic of the dominant kernel comes from PMC counters, which need their own rocprofv3 passes
         # (tools/pmc.sh); the committed summary for this workload and launch size is reported, else null
         traffic, traffic_src = None, None
         prof_dir = os.path.join(ROOT, "profiles")
-        for cand in sorted(glob.glob(os.path.join(prof_dir, f"r*_pmc_{name}_k_bonds_tiled.json")), reverse=True):
+        first_kernel = kernel_names.split(" + ")[0] if kernel_names else "k_bonds_tiled"
+        for cand in sorted(glob.glob(os.path.join(prof_dir, f"r*_pmc_{name}_{first_kernel}*.json")), reverse=True):
             with open(cand) as fh:
                 pmc = json.load(fh)
-            if pmc.get("algorithmic_bytes_per_launch") == system.bytes_per_frame * frames and \
-                    "hbm_traffic_bytes_per_launch" in pmc:
+            if not pmc.get("algorithmic_bytes_per_launch") or "hbm_traffic_bytes_per_launch" not in pmc:
+                continue
+            if pmc["algorithmic_bytes_per_launch"] == system.bytes_per_frame * frames:
                 traffic, traffic_src = pmc["hbm_traffic_bytes_per_launch"], os.path.relpath(cand, ROOT)
-                break
+            else:   # another launch size: the kernel streams, its traffic per algorithmic byte does not depend on the size
+                ratio = pmc["hbm_traffic_bytes_per_launch"] / pmc["algorithmic_bytes_per_launch"]
+                traffic = ratio * system.bytes_per_frame * frames
+                traffic_src = "%s, measured at %d bytes per launch (x %.4f of the algorithmic bytes), scaled to this launch" % (
+                    os.path.relpath(cand, ROOT), pmc["algorithmic_bytes_per_launch"], ratio)
+            break
         total_frames = args.steps * total
         value = total_frames / dt
         per_launch_bytes = system.bytes_per_frame * frames
@@ -476,12 +566,21 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
                          "traffic_source": traffic_src,
-                         "kernel": "k_bonds_tiled", "launches": launches, "avg_launch_ms": avg_launch_s * 1e3,
+                         "kernel": kernel_names, "launches": launches, "avg_launch_ms": avg_launch_s * 1e3,
                          "algorithmic_bytes_per_launch": per_launch_bytes, "frac_per_rank": per_rank},
             "sanity": {"frames_accumulated": res.n_frames, "expected": expect_frames, "counts_ok": ok_counts},
         }
         if allreduce_ms is not None:
             out["allreduce_ms"] = allreduce_ms
+        if world > 1:      # what the collective backend itself says about the job, so that the line explains itself
+            try:
+                nccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:   # noqa: BLE001
+                nccl_version = None
+            out["ranks"] = {"launched": world, "rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                            "rccl_version": nccl_version, "collective_issued_by": "library (gorder_hip_allreduce)" if comm is not None
+                            else "torch.distributed", "kernel_ms_per_step_per_rank": per_rank_ms, "device_per_rank": per_rank_dev,
+                            "rehearsal_on_one_gpu": rehearsal}
     if world == 1:
         # release the headline workload's frames before the secondary measurements
         del d_xyz, d_box
@@ -497,6 +596,12 @@ def main():
             free_b, _ = torch.cuda.mem_get_info(device)
             if free_b > 150 * (1 << 30):
                 out["scaling_reference"] = scaling_reference(device)
+    if world > 1 and not args.no_end_to_end:
+        del d_xyz, d_box
+        torch.cuda.empty_cache()
+        e2e = end_to_end_sharded(dist, rank, world, local_rank, device, rehearsal)
+        if rank == 0:
+            out["end_to_end"] = e2e
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -109,7 +109,8 @@ class CXtcFrame(C.Structure):
 class CPlan(C.Structure):
     _fields_ = [("n_tiles", C.c_uint32), ("block_threads", C.c_uint32),
                 ("max_window_atoms", C.c_uint32), ("n_direct_items", C.c_uint32),
-                ("frames_per_stage", C.c_uint32), ("lds_bytes", C.c_uint32)]
+                ("frames_per_stage", C.c_uint32), ("lds_bytes", C.c_uint32),
+                ("map_staged", C.c_uint32), ("map_lds_bytes", C.c_uint32)]
 
 
 # ---- python-side description of the tables ----------------------------------------------------
@@ -305,7 +306,7 @@ _EXPORTS = [
     "gorder_hip_prime_leaflets", "gorder_hip_set_manual_leaflets", "gorder_hip_synchronize",
     "gorder_hip_finish", "gorder_hip_timewise", "gorder_hip_leaflets", "gorder_hip_leaflet_distances",
     "gorder_hip_normals", "gorder_hip_export_maps", "gorder_hip_set_normals",
-    "gorder_hip_accumulators_device", "gorder_hip_bind_accumulators", "gorder_hip_last_error_index",
+    "gorder_hip_accumulators_device", "gorder_hip_bind_accumulators", "gorder_hip_last_error_index", "gorder_hip_last_error_frame", "gorder_hip_kernel_time_names",
     "gorder_hip_last_error_message", "gorder_hip_strerror", "gorder_hip_kernel_time", "gorder_hip_plan",
     "gorder_hip_plan_tables", "gorder_hip_selftest_arithmetic", "gorder_hip_run_trajectory",
     "gorder_hip_comm_unique_id", "gorder_hip_comm_create", "gorder_hip_comm_destroy", "gorder_hip_allreduce",
@@ -316,9 +317,10 @@ _lib = None
 
 
 class GorderHipError(RuntimeError):
-    def __init__(self, status: int, message: str = "", index: int = 0):
+    def __init__(self, status: int, message: str = "", index: int = 0, frame: int = 0):
         self.status = status
         self.index = index
+        self.frame = frame      # SystemTopology::frame of the first device error (gorder_hip_last_error_frame)
         super().__init__(f"gorder_hip status {status}: {message}")
 
 
@@ -366,6 +368,10 @@ def load_library() -> C.CDLL:
     lib.gorder_hip_bind_accumulators.argtypes = [vp, vp, u64]
     lib.gorder_hip_last_error_index.argtypes = [vp]
     lib.gorder_hip_last_error_index.restype = u64
+    lib.gorder_hip_kernel_time_names.argtypes = [vp]
+    lib.gorder_hip_kernel_time_names.restype = C.c_char_p
+    lib.gorder_hip_last_error_frame.argtypes = [vp]
+    lib.gorder_hip_last_error_frame.restype = u64
     lib.gorder_hip_last_error_message.argtypes = [vp]
     lib.gorder_hip_last_error_message.restype = C.c_char_p
     lib.gorder_hip_strerror.argtypes = [i32]
@@ -474,7 +480,8 @@ class HipEngine:
         if st != OK:
             msg = self.lib.gorder_hip_strerror(st).decode() + ": " + \
                 self.lib.gorder_hip_last_error_message(self._h).decode()
-            raise GorderHipError(st, msg, self.lib.gorder_hip_last_error_index(self._h))
+            raise GorderHipError(st, msg, self.lib.gorder_hip_last_error_index(self._h),
+                                 self.lib.gorder_hip_last_error_frame(self._h))
 
     def set_stream(self, stream_ptr: int):
         self._check(self.lib.gorder_hip_set_stream(self._h, C.c_void_p(stream_ptr)))
@@ -679,6 +686,10 @@ class HipEngine:
         ms, n = C.c_double(), C.c_uint64()
         self._check(self.lib.gorder_hip_kernel_time(self._h, C.byref(ms), C.byref(n), 1 if reset else 0))
         return ms.value, int(n.value)
+
+    def kernel_names(self) -> str:
+        """The kernels inside the region gorder_hip_kernel_time measured on the last batch."""
+        return self.lib.gorder_hip_kernel_time_names(self._h).decode()
 
     def plan(self) -> dict:
         p = CPlan()

@@ -27,6 +27,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <deque>
 #include <vector>
 
 #include "../../include/gorder_hip.h"
@@ -82,6 +83,7 @@ struct gorder_hip_handle {
     uint4 *d_lgrid = nullptr;       // per slab frame: the cell grid of the local-leaflet kernels
     float4 *d_lagg = nullptr;       // per slab frame and cell: the sums of k_local_cellsums
     uint2 *d_ltodo = nullptr;       // {count}, then the (slab frame, head) pairs left to the general passes
+    size_t map_lds_bytes = 0;
     bool map_staged = false;       // the packed map of one slot fits LDS: stage + accumulate instead of one atomic per sample
     uint64_t map_pending = 0;      // upper bound of the samples one packed word may hold since the last fold
     uint64_t map_fold_limit = kMapFoldLimit;   // GORDER_HIP_MAP_FOLD_LIMIT lowers it (tests)
@@ -154,10 +156,19 @@ struct gorder_hip_handle {
     uint32_t timing_head = 0, timing_count = 0;   // pairs [head - count, head) are recorded and not yet read
     double timing_ms = 0.0;
     uint64_t timing_launches = 0;
+    std::string timed_kernels;                    // what the last timed region launched (gorder_hip_kernel_time_names)
     // host copies behind the payload of gorder_hip_last_error_index
     std::vector<uint32_t> host_heads, host_dyn_heads;
     uint32_t *d_mol_slot0 = nullptr;
     uint64_t err_frame = 0;
+    // frame indices of the batches submitted since the last clean synchronisation (ordinal -> SystemTopology::frame of
+    // its frames), so that a device error names the frame of the TRAJECTORY; arithmetic progressions are kept as three
+    // numbers, at most kBatchLog batches are remembered
+    struct BatchLog { uint64_t ordinal, first, stride; std::vector<uint64_t> list; };
+    static constexpr size_t kBatchLog = 4096;
+    std::deque<BatchLog> batch_log;
+    uint64_t n_submits = 0;
+    const unsigned long long *decoder_key = nullptr;   // gorder_hip_run_trajectory: the slot's decoder record, for the next submit only
 };
 
 namespace {
@@ -219,14 +230,28 @@ uint32_t sample_atom(const Plan &p, uint32_t slot, uint32_t mol, uint32_t which)
 
 // Decode the device's error key (kernels_common.h, raise_error): status, frame, payload.
 int check_device_error(gorder_hip_handle *h) {
-    unsigned long long key = kErrNone;
-    HIP_TRY(h, hipMemcpy(&key, h->d_err, sizeof(key), hipMemcpyDeviceToHost));
-    if (key == kErrNone) return GORDER_OK;
+    unsigned long long rec[3] = {kErrNone, kErrNone, 0};
+    HIP_TRY(h, hipMemcpy(rec, h->d_err, sizeof(rec), hipMemcpyDeviceToHost));
+    // [1]: latched at the end of a batch; [0]: raised outside a batch (priming frame, stand-alone decode) and not committed yet
+    const bool latched = rec[1] != kErrNone;
+    const unsigned long long key = latched ? rec[1] : rec[0];
+    if (key == kErrNone) { h->batch_log.clear(); return GORDER_OK; }
     const uint32_t code = (uint32_t)(key & 15u), detail = (uint32_t)(key >> 4) & 3u, mol = (uint32_t)(key >> 6) & 0x1ffffu;
     const uint32_t sample = (uint32_t)(key >> 23) & 1u, slot = (uint32_t)(key >> 24) & 0x3fffu;
     const uint32_t stage = (uint32_t)(key >> 38) & 3u, frame = (uint32_t)(key >> 40) & 0x7fffffu;
     const int status = code == 8u ? (int)GORDER_ERR_BOX_RANGE : (code == 9u ? (int)GORDER_ERR_TRAJECTORY_FORMAT : (int)code);
     h->err_frame = frame;
+    char where[96];
+    snprintf(where, sizeof(where), "frame %u of a batch", frame);
+    if (latched)
+        for (const auto &b : h->batch_log)
+            if (b.ordinal == rec[2]) {
+                if (b.list.empty()) h->err_frame = b.first + (uint64_t)frame * b.stride;
+                else if (frame < b.list.size()) h->err_frame = b.list[frame];
+                snprintf(where, sizeof(where), "frame %llu of the trajectory (frame %u of batch %llu)",
+                         (unsigned long long)h->err_frame, frame, (unsigned long long)rec[2]);
+                break;
+            }
     h->err_index = 0;
     if (status == GORDER_ERR_UNDEFINED_POSITION) {
         if (stage == kStageTypes && sample) h->err_index = sample_atom(h->plan, slot, mol, detail);
@@ -237,8 +262,8 @@ int check_device_error(gorder_hip_handle *h) {
         h->err_index = detail;                                                             // NotEnoughPoints(n)
     }
     char buf[200];
-    snprintf(buf, sizeof(buf), "device raised %s (payload %llu) in batch frame %u", gorder_hip_strerror(status),
-             (unsigned long long)h->err_index, frame);
+    snprintf(buf, sizeof(buf), "device raised %s (payload %llu) in %s", gorder_hip_strerror(status),
+             (unsigned long long)h->err_index, where);
     h->err_msg = buf;
     return status;
 }
@@ -360,7 +385,15 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
         if (st0 != GORDER_OK) return st0;
     }
     const bool extras = h->extra.maps || h->extra.tw || h->extra.geom_kind || h->dyn || h->manual_active;
+    const bool naming = tslot >= 0;
+    if (naming) h->timed_kernels.clear();
+    auto name = [&](const char *k) {
+        if (!naming || h->timed_kernels.find(k) != std::string::npos) return;
+        if (!h->timed_kernels.empty()) h->timed_kernels += " + ";
+        h->timed_kernels += k;
+    };
     if (h->dyn && !h->manual_active) {
+        name("k_dyn_normals");
         const int st2 = run_dynamic_normals(h, a);
         if (st2 != GORDER_OK) return st2;
     }
@@ -377,6 +410,7 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
         ga.shapes = h->d_shapes; ga.err = h->d_err;
         hipLaunchKernelGGL(k_geom_shapes, dim3(a.n_frames), dim3(256), 0, h->stream, ga);
         HIP_TRY(h, hipGetLastError());
+        name("k_geom_shapes");
     }
     if (n_tiles && !extras) {
         // enough workgroups to fill 256 CUs x 8 blocks, frames split into chunks of whole stages
@@ -438,6 +472,7 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
                 default: GORDER_LAUNCH_GATHER_V(G_, true, true, true); break;                               \
             }                                                                                               \
         } while (0)
+        name(h->use_gather ? "k_bonds_gather" : "k_bonds_tiled");
         if (h->use_gather) {
             GORDER_LAUNCH_GATHER(4);
         } else {
@@ -507,6 +542,7 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
     hipLaunchKernelGGL((k_bonds_extras<AC, MO>), g, blk, 0, h->stream, b, e, b.xyz, b.box9, b.aflags, b.arow,       \
                        h->d_tiles, items, h->d_tile_slots, nt)
                     const bool maps_only = staged && !e.tw && !e.geom_kind && !e.dyn;
+                    name("k_bonds_extras");
                     if (maps_only) { if (ac) GORDER_LAUNCH_BONDS(true, true); else GORDER_LAUNCH_BONDS(false, true); }
                     else { if (ac) GORDER_LAUNCH_BONDS(true, false); else GORDER_LAUNCH_BONDS(false, false); }
 #undef GORDER_LAUNCH_BONDS
@@ -516,6 +552,7 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
                        h->d_ua_tiles, h->d_ua_items, h->d_ua_tile_slots, nt)
                     // staged ordermap samples and nothing else: the lean kernel
                     const bool maps_only = extras && staged && !e.tw && !e.geom_kind && !e.dyn;
+                    name("k_ua_extras");
                     if (maps_only) { if (ac) GORDER_LAUNCH_UA(true, 1); else GORDER_LAUNCH_UA(false, 1); }
                     else if (extras) { if (ac) GORDER_LAUNCH_UA(true, 2); else GORDER_LAUNCH_UA(false, 2); }
                     else { if (ac) GORDER_LAUNCH_UA(true, 0); else GORDER_LAUNCH_UA(false, 0); }
@@ -530,6 +567,7 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
                         mchunks = std::min(mchunks, std::max(1u, nf / 16u));
                         const uint32_t mfpc = ((nf + mchunks - 1) / mchunks + 15u) / 16u * 16u;   // whole frame blocks
                         mchunks = (nf + mfpc - 1) / mfpc;
+                        name("k_map_accumulate");
                         hipLaunchKernelGGL(k_map_accumulate, dim3(p.n_acc * mchunks), dim3(1024),
                                            n_words * sizeof(unsigned long long), h->stream, h->d_map_rec,
                                            pass == 0 ? h->d_runs : h->d_ua_runs, pass == 0 ? h->d_run_begin : h->d_ua_run_begin,
@@ -551,6 +589,7 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
         n_chunks = (a.n_frames + fpc - 1) / fpc;
         FrameArgs b = a;
         b.frames_per_chunk = fpc;
+        name("k_bonds_direct");
         if (h->tables.flags & GORDER_FLAG_TRIG_ACOS_COS)
             hipLaunchKernelGGL(k_bonds_direct<true>, dim3(bpc * n_chunks), dim3(kBlock), 0, h->stream, b, h->d_direct,
                                n_items, bpc);
@@ -710,6 +749,8 @@ int gorder_hip_plan_tables(const gorder_tables_t *tables, gorder_hip_plan_t *out
     size_t lds = (size_t)kFramesPerStage * lw * sizeof(float);
     if (lds < (size_t)kBlock * 24) lds = (size_t)kBlock * 24;
     out->lds_bytes = (uint32_t)lds;
+    out->map_staged = 0;         // decided at gorder_hip_create (device LDS size, GORDER_HIP_MAP_DIRECT)
+    out->map_lds_bytes = 0;
     if (selfcheck) *selfcheck = gorder::selfcheck_plan(*tables, p);
     return GORDER_OK;
 }
@@ -771,6 +812,7 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
             HIP_TRY(h, hipMemset(h->d_map_packed, 0, npk * sizeof(unsigned long long)));
             // united atoms: stage + accumulate in LDS when one slot's packed map (x2 with leaflets) fits
             const size_t lds_bytes = npk / p.n_acc * sizeof(unsigned long long);
+            h->map_lds_bytes = lds_bytes;
             if (lds_bytes <= 150u * 1024u && !env_flag("GORDER_HIP_MAP_DIRECT")) {
                 if ((st = upload(h, &h->d_ua_runs, p.ua_runs)) != GORDER_OK) return st;
                 if ((st = upload(h, &h->d_ua_run_begin, p.ua_run_begin)) != GORDER_OK) return st;
@@ -1026,6 +1068,8 @@ int gorder_hip_plan(const gorder_hip_handle *h, gorder_hip_plan_t *plan) {
     plan->n_direct_items = (uint32_t)h->plan.direct.size();
     plan->frames_per_stage = (uint32_t)h->frames_per_stage;
     plan->lds_bytes = (uint32_t)h->lds_bytes;
+    plan->map_staged = h->map_staged ? 1u : 0u;
+    plan->map_lds_bytes = (uint32_t)h->map_lds_bytes;
     return GORDER_OK;
 }
 
@@ -1221,6 +1265,18 @@ int gorder_hip_submit_device(gorder_hip_handle *h, const float *d_xyz, const flo
     if (n_new_rows) {   // newest assignment becomes the carry row of the next batch
         HIP_TRY(h, hipMemcpyAsync(h->d_aflags, h->d_aflags + n_new_rows * (size_t)p.n_mol_total, p.n_mol_total,
                                   hipMemcpyDeviceToDevice, h->stream));
+    }
+    // the batch's error key (if any) becomes the run's unless an earlier batch had one
+    {
+        gorder_hip_handle::BatchLog rec{h->n_submits, frame_index[0], n_frames > 1 ? frame_index[1] - frame_index[0] : 0, {}};
+        for (uint32_t f = 1; f < n_frames; f++)
+            if (frame_index[f] != rec.first + (uint64_t)f * rec.stride) { rec.list.assign(frame_index, frame_index + n_frames); break; }
+        if (h->batch_log.size() >= gorder_hip_handle::kBatchLog) h->batch_log.pop_front();
+        h->batch_log.push_back(std::move(rec));
+        hipLaunchKernelGGL(k_err_commit, dim3(1), dim3(1), 0, h->stream, reinterpret_cast<unsigned long long *>(h->d_err),
+                           (unsigned long long)h->n_submits, h->decoder_key);
+        HIP_TRY(h, hipGetLastError());
+        h->n_submits++;
     }
     h->n_frames += n_frames;
     return GORDER_OK;
@@ -1468,6 +1524,7 @@ int gorder_hip_reset(gorder_hip_handle *h) {
         HIP_TRY(h, hipMemsetAsync(h->d_tw_cnts, 0, n, h->stream));
     }
     HIP_TRY(h, hipMemsetAsync(h->d_err, 0xff, kErrWords * sizeof(uint32_t), h->stream));
+    h->batch_log.clear();
     h->n_frames = 0;
     h->have_assignment = false;
     h->assignment_frame = 0;
@@ -1532,6 +1589,8 @@ int gorder_hip_allreduce(gorder_hip_handle *h, void *nccl_comm) {
 }
 
 uint64_t gorder_hip_last_error_index(const gorder_hip_handle *h) { return h ? h->err_index : 0; }
+uint64_t gorder_hip_last_error_frame(const gorder_hip_handle *h) { return h ? h->err_frame : 0; }
+const char *gorder_hip_kernel_time_names(const gorder_hip_handle *h) { return h ? h->timed_kernels.c_str() : ""; }
 const char *gorder_hip_last_error_message(const gorder_hip_handle *h) { return h ? h->err_msg.c_str() : ""; }
 
 int gorder_hip_kernel_time(gorder_hip_handle *h, double *ms, uint64_t *launches, int reset) {
@@ -1551,7 +1610,8 @@ int gorder_hip_kernel_time(gorder_hip_handle *h, double *ms, uint64_t *launches,
 // ---- XTC frames decompressed on the device (kernels_xtc.h) ---------------------------------------------------------
 int xtc_decode_on(gorder_hip_handle *h, hipStream_t stream, const uint8_t *d_blob, uint64_t blob_bytes,
                   const gorder_xtc_frame_t *d_frames, uint32_t n_frames, uint32_t n_atoms_file, const int32_t *d_slot_of,
-                  uint32_t n_stop, float *d_xyz, uint32_t n_atoms_out, uint32_t *d_stat = nullptr, uint32_t *d_short = nullptr) {
+                  uint32_t n_stop, float *d_xyz, uint32_t n_atoms_out, uint32_t *d_stat = nullptr, uint32_t *d_short = nullptr,
+                  uint32_t *d_err_key = nullptr) {
     if (!h || !d_blob || !d_frames || !d_xyz || blob_bytes < 64 || (reinterpret_cast<uintptr_t>(d_blob) & 63u) != 0 || n_atoms_file == 0 || n_atoms_out == 0 ||
         n_stop > n_atoms_file || (!d_slot_of && n_atoms_out < n_stop))
         return fail(h, GORDER_ERR_INVALID_ARGUMENT, "gorder_hip_xtc_decode: bad arguments");
@@ -1559,7 +1619,7 @@ int xtc_decode_on(gorder_hip_handle *h, hipStream_t stream, const uint8_t *d_blo
     HIP_TRY(h, hipSetDevice(h->device));
     hipLaunchKernelGGL(k_xtc_decode, dim3((n_frames + 64u * kXtcWaves - 1u) / (64u * kXtcWaves)), dim3(64u * kXtcWaves), 0, stream, d_blob,
                        (unsigned long long)blob_bytes, d_frames, n_frames, n_atoms_file, d_slot_of, n_stop, d_xyz,
-                       n_atoms_out, h->d_err, d_stat, d_short);
+                       n_atoms_out, d_err_key ? d_err_key : h->d_err, d_stat, d_short);
     HIP_TRY(h, hipGetLastError());
     return GORDER_OK;
 }

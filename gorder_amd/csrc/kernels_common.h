@@ -6,7 +6,8 @@
 namespace {
 
 constexpr int kFramesPerStage = 4;   // G: frames staged in LDS per barrier pair (= waves per block)
-constexpr uint32_t kErrWords = 2;    // device error record: one 64-bit key (raise_error)
+constexpr uint32_t kErrWords = 8;    // device error record, four 64-bit words: [0] key of the batch in flight (raise_error),
+                                     // [1] the FIRST batch key that was not kErrNone, [2] that batch's ordinal (k_err_commit)
 
 struct FrameArgs {
     const float *xyz;        // [n_frames][n_atoms][3]
@@ -58,6 +59,21 @@ __device__ __forceinline__ void raise_error(uint32_t *err, uint32_t code, uint32
 // the library's own range error (a coordinate so far outside the box that the reference would spin): end of frame
 __device__ __forceinline__ void raise_box_range(uint32_t *err, uint32_t frame) {
     raise_error(err, GORDER_ERR_BOX_RANGE, frame, kStageEnd);
+}
+
+// End of a batch (stream-ordered behind its kernels): the batch's key — and the key its frames' decoder left in a
+// record of its own (k_xtc_decode of a slot of gorder_hip_run_trajectory runs on another stream, beside the kernels
+// of the batch before) — becomes THE error of the run if no earlier batch had one.  Keys order errors inside a batch
+// only (frame IN BATCH is their leading field); across batches the order of submission decides, which is the order
+// of the trajectory: the first error as the reference's sequential walk meets it (common.rs:248).
+__global__ void k_err_commit(unsigned long long *err, unsigned long long ordinal, const unsigned long long *decoder_key) {
+    unsigned long long cur = err[0];
+    if (decoder_key && *decoder_key < cur) cur = *decoder_key;
+    if (err[1] == kErrNone && cur != kErrNone) {
+        err[1] = cur;
+        err[2] = ordinal;
+    }
+    err[0] = kErrNone;
 }
 
 // ---- check_box (common.rs:186-198), one thread per frame -----------------------------------

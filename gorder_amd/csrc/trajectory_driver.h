@@ -153,7 +153,14 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
     }
     if (dev && tr->group && tr->n_group) {
         slot_of.assign(n_file_atoms, -1);
-        for (uint32_t k = 0; k < tr->n_group; k++) slot_of[tr->group[k]] = (int32_t)k;     // (gorder_xtc_open checked the range)
+        for (uint32_t k = 0; k < tr->n_group && dev; k++) {                                 // (gorder_xtc_open checked the range)
+            // an atom listed twice has two output slots but one entry here: the device decoder would leave the first
+            // slot unwritten.  The host decoder fills every slot (gorder_xtc_next walks the group), so such a group
+            // takes the host route for the whole run.
+            if (slot_of[tr->group[k]] >= 0) dev = false;
+            slot_of[tr->group[k]] = (int32_t)k;
+        }
+        if (!dev) slot_of.clear();
     }
     // contiguous frame shards: count what the window selects, headers only, and take this rank's share
     uint64_t shard_lo = 0, shard_n = UINT64_MAX, shard_total = 0;
@@ -291,7 +298,7 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
             ok(hipMalloc((void **)&s.d_blob, blob_cap));
             ok(hipMalloc((void **)&s.d_frames, (size_t)batch * sizeof(gorder_xtc_frame_t)));
             ok(hipMalloc((void **)&s.d_box_in, box_bytes));
-            ok(hipMalloc((void **)&s.d_stat, 2 * sizeof(uint32_t)));
+            ok(hipMalloc((void **)&s.d_stat, 4 * sizeof(uint32_t)));      // [0..1] the decoder's report, [2..3] its error key
             ok(hipMalloc((void **)&s.d_short, (size_t)batch * sizeof(uint32_t)));
             ok(hipHostMalloc((void **)&s.h_stat, 2 * sizeof(uint32_t), hipHostMallocDefault));
             ok(hipHostMalloc((void **)&s.h_short, (size_t)batch * sizeof(uint32_t), hipHostMallocDefault));
@@ -434,7 +441,11 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
                         : gorder_xtc_read_window_mt(r, tr->begin_ps, tr->end_ps, tr->step, &state, &last_time,
                                                     s.h_xyz + (size_t)s.n * n_atoms * 3u, s.h_box + 9u * (size_t)s.n,
                                                     s.h_time + s.n, want, n_threads);
-                if (dev && got == GORDER_XTC_ERR_ARGUMENT && s.n > 0) break;      // the blob is full: this batch is complete
+                if (dev && got == GORDER_XTC_ERR_NO_SPACE) {
+                    if (s.n > 0) break;                                           // the blob is full: this batch is complete
+                    give_up(GORDER_XTC_ERR_ARGUMENT, std::string("a single frame of ") + tr->paths[f] + " does not fit the staging blob");
+                    break;
+                }
                 if (got < 0) {
                     give_up((int)got, std::string("read error in ") + tr->paths[f]);
                     break;
@@ -504,6 +515,7 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
             const size_t nf = (size_t)s.n * sizeof(gorder_xtc_frame_t);
             s.moved += (size_t)s.blob_bytes + nf;
             if (e == hipSuccess) e = hipMemsetAsync(s.d_stat, 0, 2 * sizeof(uint32_t), feed);
+            if (e == hipSuccess) e = hipMemsetAsync(s.d_stat + 2, 0xff, 2 * sizeof(uint32_t), feed);      // kErrNone
             if (e == hipSuccess) e = hipMemcpyAsync(s.d_blob, s.h_blob, (size_t)s.blob_bytes, hipMemcpyHostToDevice, feed);
             if (e == hipSuccess) e = hipMemcpyAsync(s.d_frames, s.h_frames, nf, hipMemcpyHostToDevice, feed);
             if (e == hipSuccess) e = hipMemcpyAsync(s.d_box_in, s.h_box, nb, hipMemcpyHostToDevice, feed);
@@ -512,7 +524,7 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
             if (e == hipSuccess) e = hipMemcpyAsync(s.d_box, s.d_box_in, nb, hipMemcpyDeviceToDevice, feed);
             if (e == hipSuccess && status == GORDER_OK)
                 status = xtc_decode_on(h, feed, s.d_blob, s.blob_bytes, s.d_frames, s.n, n_file_atoms, d_slot_of, n_stop,
-                                       s.d_xyz, n_atoms, s.d_stat, s.d_short);
+                                       s.d_xyz, n_atoms, s.d_stat, s.d_short, s.d_stat + 2);
             if (e == hipSuccess) e = hipMemcpyAsync(s.h_stat, s.d_stat, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, feed);
             if (e == hipSuccess) e = hipMemcpyAsync(s.h_short, s.d_short, (size_t)s.n * sizeof(uint32_t), hipMemcpyDeviceToHost, feed);
         } else {
@@ -574,11 +586,16 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
         }
         if (e == hipSuccess && status == GORDER_OK) e = hipStreamWaitEvent(h->stream, s.copied, 0);
         if (e != hipSuccess && status == GORDER_OK) { status = GORDER_ERR_DEVICE; hip_msg = std::string("trajectory copy: ") + hipGetErrorString(e); }
-        if (status == GORDER_OK)
+        if (status == GORDER_OK) {
+            // a frame the decoder could not make sense of is an error of THIS batch, ordered with the errors its analysis
+            // raises (the frame's number leads the key) and behind those of the batches before (k_err_commit)
+            h->decoder_key = dev ? reinterpret_cast<const unsigned long long *>(s.d_stat + 2) : nullptr;
             status = gorder_hip_submit_device(h, s.d_xyz, h->tables.handle_pbc ? s.d_box : nullptr, s.fidx.data(), s.n);
+            h->decoder_key = nullptr;
+        }
         if (status == GORDER_OK) {
             e = hipEventRecord(s.computed, h->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(h_err, h->d_err, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(h_err, reinterpret_cast<unsigned long long *>(h->d_err) + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream);
             if (e != hipSuccess) { status = GORDER_ERR_DEVICE; hip_msg = std::string("trajectory submit: ") + hipGetErrorString(e); }
             s.compute_issued = true;
             frames += s.n;

@@ -23,6 +23,7 @@
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <vector>
 
@@ -1020,8 +1021,12 @@ int64_t pack_window_impl(gorder_xtc_reader *r, float begin_ps, float end_ps, uin
     uint64_t used = 0;
     const uint32_t natoms = r->natoms;
     const int fd = fileno(r->fp);
-    off_t pos = (off_t)ftell(r->fp);
+    off_t pos = (off_t)ftello(r->fp);
     bool to_end = false;
+    const uint64_t state_at_entry = *state;        // a call that returns NO_SPACE leaves reader AND selection state untouched
+    const double last_time_at_entry = *last_time;
+    struct stat sb;
+    const off_t file_end = fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) ? sb.st_size : (off_t)-1;
     while (src.size() < capacity) {
         const off_t pos0 = pos;
         uint8_t head[56 + 36];
@@ -1070,6 +1075,7 @@ int64_t pack_window_impl(gorder_xtc_reader *r, float begin_ps, float end_ps, uin
             if (c < block) { copy = (uint32_t)c; fr.kind |= 2u; fr.n_bytes = copy; }
         }
         pos = pos_block + (off_t)block;
+        if (file_end >= 0 && pos > file_end) return GORDER_XTC_ERR_FORMAT;     // a byte count the file cannot hold
         // selection: as in gorder_xtc_read_window
         if ((double)t == *last_time) continue;             // duplicate frame at a file boundary
         const double time_before = *last_time;
@@ -1080,9 +1086,13 @@ int64_t pack_window_impl(gorder_xtc_reader *r, float begin_ps, float end_ps, uin
         if (k % step != 0) continue;
         const uint64_t need = (((uint64_t)copy + 63u) & ~63ull) + 64u;      // whole 64-byte pieces + one piece of zeros
         if (used + need > blob_capacity) {                 // does not fit any more: this frame opens the next window
+            if (src.empty()) {                             // not even one frame: the FILE is still where it was at entry,
+                *state = state_at_entry;                   // so the frames passed over so far (stepped over, the duplicate at
+                *last_time = last_time_at_entry;           // a file boundary) must not be counted either
+                return GORDER_XTC_ERR_NO_SPACE;
+            }
             (*state)--;                                    // (nothing of it has happened: a later call meets it again)
             *last_time = time_before;
-            if (src.empty()) return GORDER_XTC_ERR_ARGUMENT;
             pos = pos0;
             break;
         }

@@ -45,6 +45,10 @@ def _lib():
                                                     C.POINTER(C.c_double), vp, C.c_uint64, C.POINTER(C.c_uint64), vp, vp, vp,
                                                     C.c_uint64, vp]
         lib.gorder_xtc_pack_window_pool.restype = C.c_int64
+        lib.gorder_xtc_pack_window_ex.argtypes = [vp, C.c_float, C.c_float, C.c_uint32, C.POINTER(C.c_uint64),
+                                                  C.POINTER(C.c_double), vp, C.c_uint64, C.POINTER(C.c_uint64), vp, vp, vp,
+                                                  C.c_uint64, C.c_uint32, vp, C.c_uint32, vp]
+        lib.gorder_xtc_pack_window_ex.restype = C.c_int64
         lib.gorder_xtc_is_xtc.argtypes = [vp]
         lib.gorder_xtc_probe.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
         lib.gorder_xtc_n_atoms_needed.argtypes = [vp]

@@ -381,12 +381,19 @@ int gorder_hip_bind_accumulators(gorder_hip_handle *h, void *d_ptr, uint64_t n_u
 
 /* Payload of the last UndefinedPosition / InvalidLocalMembraneCenter error (atom index). */
 uint64_t gorder_hip_last_error_index(const gorder_hip_handle *h);
+/* The frame (SystemTopology::frame, i.e. the frame_index the host passed) in which the last device error was raised:
+ * the first error of the run in trajectory order — batches in the order of submission, inside a batch the order of the
+ * reference's sequential walk (common.rs:201-235, 248). */
+uint64_t gorder_hip_last_error_frame(const gorder_hip_handle *h);
 const char *gorder_hip_last_error_message(const gorder_hip_handle *h);
 const char *gorder_hip_strerror(int status);
 
 /* Device time (ms, HIP events on the launch stream) and launch count of the dominant per-frame
  * kernel since the last call with reset != 0. */
 int gorder_hip_kernel_time(gorder_hip_handle *h, double *ms, uint64_t *launches, int reset);
+/* The kernels inside the timed region of the LAST timed batch, e.g. "k_bonds_tiled" or
+ * "k_ua_extras + k_map_accumulate" ("" before the first timed batch); valid until the next submit. */
+const char *gorder_hip_kernel_time_names(const gorder_hip_handle *h);
 
 /* Introspection for tests / DESIGN.md: how the bond table was tiled. */
 typedef struct {
@@ -396,6 +403,8 @@ typedef struct {
     uint32_t n_direct_items;     /* samples that did not fit an LDS window (direct-gather kernel) */
     uint32_t frames_per_stage;
     uint32_t lds_bytes;
+    uint32_t map_staged;         /* 1: ordermap samples go through the staging buffer + k_map_accumulate (LDS) */
+    uint32_t map_lds_bytes;      /* packed map of one accumulator slot (x2 with leaflets) = k_map_accumulate's LDS */
 } gorder_hip_plan_t;
 int gorder_hip_plan(const gorder_hip_handle *h, gorder_hip_plan_t *plan);
 /* Same, without touching a device (host logic only); *selfcheck = 0 when every sample of the

@@ -28,7 +28,9 @@ typedef enum {
     GORDER_XTC_EOF = 1,            /* clean end of file */
     GORDER_XTC_ERR_OPEN = -1,
     GORDER_XTC_ERR_FORMAT = -2,    /* bad magic / truncated frame / corrupt bit stream */
-    GORDER_XTC_ERR_ARGUMENT = -3
+    GORDER_XTC_ERR_ARGUMENT = -3,
+    GORDER_XTC_ERR_NO_SPACE = -4   /* gorder_xtc_pack_window*: the next selected frame does not fit what is left of the blob;
+                                    * reader, *state and *last_time are as they were before the call */
 } gorder_xtc_status_t;
 
 /* Open one file: XTC, or — recognised by its magic number 1993 — a GROMACS TRR file (uncompressed single- or
@@ -98,7 +100,9 @@ typedef struct {
 
 /* Returns the number of frames packed (0 at the end of the file), fewer than `capacity` also when the next frame
  * would not fit `blob_capacity` (a later call continues with that frame), or a negative gorder_xtc_status_t
- * (GORDER_XTC_ERR_ARGUMENT also when ONE frame alone does not fit the blob, or for a TRR / GRO reader).
+ * (GORDER_XTC_ERR_NO_SPACE when not even ONE frame fits the blob — nothing has happened then: file position, *state
+ * and *last_time are those of the call's entry; GORDER_XTC_ERR_ARGUMENT for a TRR / GRO reader; GORDER_XTC_ERR_FORMAT
+ * also for a block whose byte count runs past the end of the file).
  * `*blob_bytes` receives the bytes of the blob in use.  The blocks are read by `n_threads` threads (pread). */
 int64_t gorder_xtc_pack_window(gorder_xtc_reader *r, float begin_ps, float end_ps, uint32_t step, uint64_t *state,
                                double *last_time, uint8_t *blob, uint64_t blob_capacity, uint64_t *blob_bytes,

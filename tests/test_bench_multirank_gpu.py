@@ -17,7 +17,7 @@ def launch(extra, port):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
            "--warmup", "2"] + extra
-    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=280)
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=420)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1                                     # rank 0 prints ONE JSON line
@@ -34,6 +34,8 @@ def test_two_ranks_on_one_gpu_weak(built, workload, frames):
     assert out["sanity"]["frames_accumulated"] == out["sanity"]["expected"] == (3 + n_warm) * frames * 2
     assert out["sanity"]["counts_ok"]
     assert out["value"] > 0 and "cpu_baseline" not in out      # the CPU baseline is an N = 1 thing
+    assert out["ranks"]["rccl_ranks"] == out["ranks"]["launched"] == 2 and out["ranks"]["backend"] == "gloo"
+    assert len(out["ranks"]["kernel_ms_per_step_per_rank"]) == 2 and min(out["ranks"]["kernel_ms_per_step_per_rank"]) > 0
 
 
 def test_two_ranks_strong_scaling_default(built):
@@ -46,3 +48,9 @@ def test_two_ranks_strong_scaling_default(built):
     assert out["sanity"]["frames_accumulated"] == out["sanity"]["expected"] == 301    # the job, not the warm-up
     assert out["sanity"]["counts_ok"] and out["value"] > 0
     assert len(out["roofline"]["frac_per_rank"]) == 2 and out["allreduce_ms"] > 0
+    assert out["roofline"]["kernel"] == "k_bonds_tiled"
+    # the same sharding from a FILE: every rank ran gorder_hip_run_trajectory on its share, one all-reduce, and the
+    # result equals one handle over the whole trajectory
+    e2e = out["end_to_end"]
+    assert e2e["equal_to_one_handle"] and e2e["frames_of_all_shards"] == e2e["frames"] == 500 * 80
+    assert [r["frames"] for r in e2e["per_rank"]] == [20000, 20000] and e2e["per_rank"][1]["first_frame_of_shard"] == 20000

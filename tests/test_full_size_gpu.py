@@ -120,3 +120,99 @@ def test_cg1m_one_launch_beyond_32_bit_offsets(cg1m):
     np.testing.assert_array_equal(got.counts, want.counts)
     s = whole.order()[0]
     assert np.all(s >= -0.5 - 1e-6) and np.all(s <= 1.0 + 1e-6)
+
+
+# ---- configs[3]: UAOrder + 2-D ordermap scatter at its own size ----------------------------------------------
+def _vua(leaflets):
+    from gorder_amd.abi import OrderMap
+    om = OrderMap(enabled=True, plane=0, span_x=(0.0, 9.0), span_y=(0.0, 9.0), bin=(0.1, 0.1))     # bench.py's ua256-maps
+    return synthetic.ua_membrane(256, leaflets=leaflets, ordermap=om)
+
+
+def _unsaturated_slots(system):
+    from gorder_amd import abi
+    out, slot = np.zeros(system.tables.n_acc, dtype=bool), 0
+    for kind, _ in system.tables.molecule_types[0].ua_atoms:
+        nh = abi.UA_N_H[int(kind)]
+        out[slot:slot + nh] = int(kind) == abi.UA_CH1_UNSAT
+        slot += nh
+    return out
+
+
+@pytest.mark.parametrize("direct", [False, True])
+@pytest.mark.parametrize("leaflets", [0, LEAFLETS_GLOBAL])
+def test_vua_ordermaps_at_full_size(built, monkeypatch, leaflets, direct):
+    """configs[3] (V-UA): 256 united-atom lipids x 62 virtual C-H, 91 x 91 tiles per slot (ordermap.rs:100-113;
+    GridMap: round(9.0 / 0.1) + 1 tiles).  One slot's packed map is 66 KB (> 64 KB: the dynamic-LDS branch of
+    k_map_accumulate), 132 KB with leaflets (upper + lower planes).  Staged route (default) and one atomic per
+    sample (GORDER_HIP_MAP_DIRECT=1), several batches so that the staging buffer is reused, against the oracle:
+    sums, counts, map sums and map counts EQUAL, except the unsaturated CH slots (device sincos / acos vs host
+    libm): at most one tick per sample."""
+    torch_cuda()
+    if direct:
+        monkeypatch.setenv("GORDER_HIP_MAP_DIRECT", "1")
+    system = _vua(leaflets)
+    assert system.n_atoms == 13312 and system.tables.n_samples_per_frame == 256 * 62
+    n = 6
+    xyz, box = system.frames(n, seed=17), system.box9(n)
+    eng = HipEngine(system.tables)
+    o = oracle.OracleEngine(system.tables, trig=oracle.TRIG_DIRECT, n_threads=2)
+    for a, b in ((0, 1), (1, 4), (4, n)):
+        eng.submit_host(xyz[a:b], box[a:b], np.arange(a, b))
+        o.submit(xyz[a:b], box[a:b], np.arange(a, b))
+    got, want = eng.finish(), o.finish()
+    assert eng.ordermap_dims() == (91, 91) and got.map_sums.shape == want.map_sums.shape == (3, 62, 91, 91)
+    plan = eng.plan()
+    assert plan["map_staged"] == int(not direct)                # which route really ran
+    assert plan["map_lds_bytes"] == (2 if leaflets else 1) * 91 * 91 * 8 > 64 * 1024
+    un = _unsaturated_slots(system)
+    assert un.sum() == 2
+    np.testing.assert_array_equal(got.counts, want.counts)
+    assert (got.counts[0] == 256 * n).all()
+    np.testing.assert_array_equal(got.map_counts, want.map_counts)
+    np.testing.assert_array_equal(got.sums[:, ~un], want.sums[:, ~un])
+    np.testing.assert_array_equal(got.map_sums[:, ~un], want.map_sums[:, ~un])
+    assert np.abs(got.sums[:, un] - want.sums[:, un]).max() <= 256 * n
+    assert (np.abs(got.map_sums[:, un] - want.map_sums[:, un]) <= got.map_counts[:, un].astype(np.int64)).all()
+    # every sample of a frame lands in one tile (hydrogens are wrapped into the box, uaorder.rs:979-1104; the bond
+    # position H + v/2 may leave it by half a bond: those are dropped by the reference as well)
+    tot = got.map_counts[0].sum(axis=(1, 2))
+    assert (tot <= got.counts[0]).all() and tot.sum() > 0.97 * got.counts[0].sum()
+    if leaflets:
+        np.testing.assert_array_equal(got.map_counts[0], got.map_counts[1] + got.map_counts[2])
+        np.testing.assert_array_equal(got.map_sums[0], got.map_sums[1] + got.map_sums[2])
+        assert got.map_counts[1].sum() > 0 and got.map_counts[2].sum() > 0
+    else:
+        assert got.map_counts[1:].sum() == 0
+    # within 1e-6 of the reference-faithful (libm) arithmetic
+    libm = oracle.OracleEngine(system.tables, trig=oracle.TRIG_LIBM, n_threads=2)
+    libm.submit(xyz, box)
+    assert np.abs(got.order_ticks() - libm.finish().order_ticks()).max() <= 1
+
+
+def test_vua_maps_many_frames_linearity(built):
+    """The same workload on enough frames that k_map_accumulate cuts its frame ranges (600 frames), through
+    size-independent properties: two halves add up to the whole (maps included), total = upper + lower,
+    every slot counts 256 samples per frame."""
+    torch = torch_cuda()
+    system = _vua(LEAFLETS_GLOBAL)
+    n = 600
+    d_xyz, d_box = system.frames_device(n, seed=23)
+    whole = HipEngine(system.tables)
+    whole.use_torch_stream()
+    whole.submit_device(d_xyz, d_box, np.arange(n))
+    w = whole.finish()
+    assert (w.counts[0] == 256 * n).all()
+    parts = []
+    for a, b in ((0, 173), (173, n)):
+        e = HipEngine(system.tables)
+        e.use_torch_stream()
+        e.submit_device(d_xyz[a:b], d_box[a:b], np.arange(a, b))
+        parts.append(e.finish())
+    np.testing.assert_array_equal(parts[0].sums + parts[1].sums, w.sums)
+    np.testing.assert_array_equal(parts[0].map_sums + parts[1].map_sums, w.map_sums)
+    np.testing.assert_array_equal(parts[0].map_counts + parts[1].map_counts, w.map_counts)
+    np.testing.assert_array_equal(w.map_counts[0], w.map_counts[1] + w.map_counts[2])
+    np.testing.assert_array_equal(w.map_sums[0], w.map_sums[1] + w.map_sums[2])
+    assert w.map_counts[0].sum() > 0.97 * w.counts[0].sum()
+    del torch

@@ -378,6 +378,43 @@ def test_first_error_in_reference_order(built, monkeypatch, mode):
             assert e.value.index == oe.value.index, (mode, trial, batches)
 
 
+def test_first_error_across_batches_in_flight(built):
+    """Batches queued WITHOUT a synchronisation in between (what gorder_hip_run_trajectory does): the error reported is
+    the one of the earliest batch, although a later batch has one in an earlier frame of ITS batch — keys order errors
+    inside a batch, k_err_commit latches the first batch that had one (common.rs:248: the first Err ends the iteration) —
+    and the frame reported is the frame of the trajectory (SystemTopology::frame), not the frame in the batch."""
+    torch_cuda()
+    system = synthetic.cg_membrane(40, n_types=2)
+    n = 12
+    xyz, box = system.frames(n, seed=3), system.box9(n)
+    x = xyz.copy()
+    x[7, 5 * 12 + 3, 1] = np.nan          # batch 1 (frames 4..7), last frame of the batch
+    x[8, 2 * 12 + 0, 0] = np.nan          # batch 2 (frames 8..11), FIRST frame of its batch: a smaller key
+    o = oracle.OracleEngine(system.tables, trig=oracle.TRIG_DIRECT)
+    with pytest.raises(oracle.OracleError) as oe:
+        o.submit(x, box, np.arange(100, 100 + 3 * n, 3))
+    eng = HipEngine(system.tables)
+    with pytest.raises(abi.GorderHipError) as e:
+        for a in (0, 4, 8):
+            eng.submit_host(x[a:a + 4], box[a:a + 4], np.arange(100 + 3 * a, 100 + 3 * (a + 4), 3))
+        eng.finish()
+    assert e.value.status == oe.value.status == abi.ERR_UNDEFINED_POSITION
+    assert e.value.index == oe.value.index == 5 * 12 + 3
+    assert e.value.frame == 100 + 3 * 7
+    assert "frame 121 of the trajectory (frame 3 of batch 1)" in str(e.value)
+    # an irregular list of frame indices is remembered as such
+    eng = HipEngine(system.tables)
+    with pytest.raises(abi.GorderHipError) as e:
+        eng.submit_host(x[:4], box[:4], np.array([5, 6, 9, 40]))
+        eng.submit_host(x[4:8], box[4:8], np.array([41, 50, 51, 77]))
+        eng.finish()
+    assert e.value.frame == 77 and e.value.index == 5 * 12 + 3
+    # after gorder_hip_reset the handle is clean again
+    eng.reset()
+    eng.submit_host(xyz[:4], box[:4], np.arange(4))
+    assert eng.finish().n_frames == 4
+
+
 def test_priming_replaces_cross_thread_wait(built):
     # rank r starts at frame 6 with Every(5): it needs the assignment of frame 5 (leaflets.rs:1437-1472)
     torch = torch_cuda()

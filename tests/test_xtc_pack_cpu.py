@@ -89,11 +89,76 @@ def test_a_frame_that_does_not_fit_is_met_again(built, tmp_path):
     box, t = np.empty((8, 9), np.float32), np.empty(8, np.float32)
     args = lambda cap: (r, 0.0, -1.0, 2, C.byref(state), C.byref(last), blob.ctypes.data, cap, C.byref(used),
                         C.cast(frames, C.c_void_p), box.ctypes.data, t.ctypes.data, 8, 1)
-    assert lib.gorder_xtc_pack_window(*args(100)) == -3           # refused: not one frame fits 100 bytes
+    assert lib.gorder_xtc_pack_window(*args(100)) == -4           # GORDER_XTC_ERR_NO_SPACE: not one frame fits 100 bytes
     assert state.value == 0 and last.value == float("-inf")
     assert lib.gorder_xtc_pack_window(*args(1 << 20)) == 3        # every second of 6 frames, the first one included
     np.testing.assert_array_equal(t[:3], [0.0, 20.0, 40.0])
     lib.gorder_xtc_close(r)
+
+
+@pytest.mark.parametrize("step", [1, 2, 3, 4])
+@pytest.mark.parametrize("blob_frames", [1.5, 2.5, 3.2])
+def test_batches_filled_across_files_select_what_read_window_selects(built, tmp_path, step, blob_frames):
+    """gorder_hip_run_trajectory's reader (trajectory_driver.h): ONE blob per batch, filled across file boundaries with
+    the capacity that is left; a call that cannot place its first selected frame returns NO_SPACE and the batch ends.
+    Frames passed over before that frame (stepped over, or the duplicate frame at a file boundary, CHANGELOG.md:64) must
+    not be counted twice when the next batch meets them again: the selection equals gorder_xtc_read_window's."""
+    import ctypes as C
+    from gorder_amd.abi import CXtcFrame
+    rng = np.random.default_rng(3)
+    paths, t0 = [], 0.0
+    for k, nf in enumerate((4, 6, 3, 5)):           # every file starts with the last time of the one before
+        xyz = rng.uniform(0, 6, size=(nf, 700, 3)).astype(np.float32)
+        box = np.tile(np.eye(3, dtype=np.float32) * 6.0, (nf, 1, 1))
+        p = str(tmp_path / f"part{k}.xtc")
+        xtc.write_trajectory(p, xyz, box, times=(t0 + 10.0 * np.arange(nf)).astype(np.float32))
+        t0 += 10.0 * (nf - 1)
+        paths.append(p)
+    want = xtc.read_trajectory(paths, step=step)[2]
+    lib = xtc._lib()
+    per_frame = int(xtc.pack_trajectory([paths[0]], chunk=4)[0]["frames"]["offset"][1])
+    cap = int(per_frame * blob_frames)
+    state, last = C.c_uint64(0), C.c_double(float("-inf"))
+    got_times, batches = [], []
+    f, r = 0, None
+    while f < len(paths):
+        blob = np.empty(cap, np.uint8)
+        frames = (CXtcFrame * 8)()
+        box, t = np.empty((8, 9), np.float32), np.empty(8, np.float32)
+        n, filled = 0, 0
+        while f < len(paths) and n < 8:
+            if r is None:
+                r = C.c_void_p()
+                assert lib.gorder_xtc_open(paths[f].encode(), None, 0, C.byref(r)) == 0
+            used = C.c_uint64(0)
+            got = lib.gorder_xtc_pack_window_ex(r, 0.0, -1.0, step, C.byref(state), C.byref(last), blob.ctypes.data + filled,
+                                                cap - filled, C.byref(used), C.addressof(frames) + n * C.sizeof(CXtcFrame),
+                                                box.ctypes.data + 36 * n, t.ctypes.data + 4 * n, 8 - n, 1, None, 0, None)
+            if got == -4:
+                assert n > 0, "a frame must fit an empty blob"
+                break
+            assert got >= 0, got
+            if got == 0:
+                lib.gorder_xtc_close(r)
+                r = None
+                f += 1
+                continue
+            n += got
+            filled += used.value
+        got_times += list(t[:n])
+        batches.append(n)
+    np.testing.assert_array_equal(np.array(got_times, np.float32), want)
+    assert max(batches) <= int(blob_frames) + 1 and len(batches) > 1
+
+
+def test_a_block_longer_than_the_file_is_a_format_error(built, tmp_path):
+    path = synthetic(tmp_path, n_frames=3)
+    raw = bytearray(open(path, "rb").read())
+    raw[88:92] = (1 << 30).to_bytes(4, "big")          # byte count of the first frame's bit stream
+    bad = str(tmp_path / "bad.xtc")
+    open(bad, "wb").write(bytes(raw))
+    with pytest.raises(IOError, match="-2"):
+        xtc.pack_trajectory([bad], chunk=4, blob_capacity=1 << 20)
 
 
 def test_pool_copies_the_same_bytes(built, tmp_path):
