@@ -161,6 +161,18 @@ __device__ __forceinline__ float gm_cosf(float t) {
     return mid ? ks : (lo ? kc : -kc);   // t = NaN: rc = NaN -> NaN
 }
 
+// sin on [0, pi] from the same two kernels (the rotation angle of the unsaturated-CH hydrogen, pi - gamma / 2,
+// uaorder.rs:1024-1045, lies in [pi/2, pi]); restated by oracle/gorder_oracle.c (gorder_oracle_mirror_sinf).
+__device__ __forceinline__ float gm_sinf_0pi(float t) {
+    const bool lo = t < GM_PIO4;
+    const bool mid = !lo && (t <= GM_3PIO4);
+    const float rs = lo ? t : (GM_PI_HI - t) + GM_PI_LO;
+    const float rc = (t - GM_PIO2_HI) - GM_PIO2_LO;
+    const float ks = gm_ksin(rs);
+    const float kc = gm_kcos(rc);
+    return mid ? kc : ks;                // t = NaN: NaN
+}
+
 // P2 of the angle between the bond vector v and the membrane normal n (calc_sch, mod.rs:78-82).
 //   n2 = |n|, n2sq = |n|^2, both precomputed on the host with nalgebra's f32 sequence.
 //

@@ -399,8 +399,8 @@ __device__ __forceinline__ UaBonds ua_carbon(uint32_t kind, UaCarbon c, UaConsts
             gamma = gm_acosf(cs);
         }
         const float ang = 3.14159265358979323846f - (gamma / 2.0f);
-        float sn, cs;
-        sincosf(ang, &sn, &cs);
+        // own sin / cos kernels (gm_math.h), restated by the oracle's non-libm modes: the hydrogen is the same bits there
+        const float sn = gm_sinf_0pi(ang), cs = gm_cosf(ang);
         const V3 ua = pb.unit(v3_cross(th1, th2));
         h0 = v3_shift_wrap(target, ang == 0.0f ? th2 : v3_rotate(ua, sn, cs, th2), pb);
     } else {                                // CH1 saturated, uaorder.rs:1087-1104 (h1, h2, h3, target)

@@ -136,6 +136,14 @@ float gorder_oracle_mirror_cosf(float t) {
     return -m_kcos((M_PI_HI - t) + M_PI_LO);
 }
 
+/* sin on [0, pi], the device's sequence (gm_math.h: gm_sinf_0pi) */
+float gorder_oracle_mirror_sinf(float t) {
+    if (t < M_PIO4) return m_ksin(t);
+    if (t <= M_3PIO4) return m_kcos((t - M_PIO2_HI) - M_PIO2_LO);
+    if (t != t) return t;
+    return m_ksin((M_PI_HI - t) + M_PI_LO);
+}
+
 /* [3rd-party] nalgebra Matrix::angle, reached through groan_rs Vector3D::angle (mod.rs:79):
  * 0 if either norm is 0, else acos(clamp(a.b / (|a||b|), -1, 1)); clamp lets NaN through.
  * `*cosine` receives the clamped cosine (1 for the zero-norm case, = cos(0)). */
@@ -274,11 +282,13 @@ static inline void unit3(const float *a, float *o) {
 }
 /* [3rd-party] nalgebra Rotation3::from_axis_angle(unit axis, angle) applied to v
  * (groan_rs Vector3D::rotate = matrix * vector, column-accumulated). */
-static void rotate_axis_angle(const float *u, float angle, const float *v, float *o) {
+static void rotate_axis_angle_mode(const float *u, float angle, const float *v, float *o, int mirror) {
     if (angle == 0.0f) { o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; return; }
     const float ux = u[0], uy = u[1], uz = u[2];
     const float sqx = ux * ux, sqy = uy * uy, sqz = uz * uz;
-    const float s = sinf(angle), c = cosf(angle);
+    /* mirror: the device's own sin / cos kernels (angle in [0, pi]); else libm like Rust's f32::sin_cos */
+    const float s = mirror ? gorder_oracle_mirror_sinf(angle) : sinf(angle);
+    const float c = mirror ? gorder_oracle_mirror_cosf(angle) : cosf(angle);
     const float omc = 1.0f - c;
     const float m11 = sqx + (1.0f - sqx) * c;
     const float m12 = ux * uy * omc - uz * s;
@@ -293,6 +303,9 @@ static void rotate_axis_angle(const float *u, float angle, const float *v, float
     o[1] = (m21 * v[0] + m22 * v[1]) + m23 * v[2];
     o[2] = (m31 * v[0] + m32 * v[1]) + m33 * v[2];
 }
+static void rotate_axis_angle(const float *u, float angle, const float *v, float *o) {
+    rotate_axis_angle_mode(u, angle, v, o, 0);
+}
 /* [3rd-party] groan_rs Vector3D::shift(direction, distance): move along the normalised direction;
  * then PBCHandler::wrap (pbc.rs:388-390; no-op for NoPBC, pbc.rs:193) */
 static int shift_wrap(const float *target, const float *dir, const float *box, int pbc, float *h) {
@@ -306,8 +319,11 @@ static int shift_wrap(const float *target, const float *dir, const float *box, i
     return bad;
 }
 
-int gorder_oracle_predict_hydrogens(uint32_t kind, const float pos[4][3], const float box[3],
-                                    int pbc, float out[3][3]) {
+/* trig: GORDER_ORACLE_TRIG_LIBM = the reference's arithmetic (acosf / sinf / cosf of the host libm, like Rust's f32
+ * methods); any other mode restates the DEVICE's kernels for the one data-dependent angle of the construction (the
+ * unsaturated CH), so that the device's hydrogens can be compared bit for bit. */
+static int predict_hydrogens_mode(uint32_t kind, const float pos[4][3], const float box[3], int pbc, int trig,
+                                  float out[3][3]) {
     int bad = 0;
     if (kind == GORDER_UA_CH3) { /* uaorder.rs:947-981; indices helper1,target,helper2 */
         const float *h1 = pos[0], *t = pos[1], *h2 = pos[2];
@@ -348,10 +364,11 @@ int gorder_oracle_predict_hydrogens(uint32_t kind, const float pos[4][3], const 
         float th1[3], th2[3], axis[3], ua[3], hv[3];
         bad |= vector_to(t, h1, box, pbc, th1);
         bad |= vector_to(t, h2, box, pbc, th2);
-        const float gamma = angle3(th1, th2, GORDER_ORACLE_TRIG_LIBM, NULL);
+        const int mirror = trig != GORDER_ORACLE_TRIG_LIBM;
+        const float gamma = angle3(th1, th2, mirror ? GORDER_ORACLE_TRIG_MIRROR : GORDER_ORACLE_TRIG_LIBM, NULL);
         cross3(th1, th2, axis);
         unit3(axis, ua);
-        rotate_axis_angle(ua, 3.14159265358979323846f - (gamma / 2.0f), th2, hv);
+        rotate_axis_angle_mode(ua, 3.14159265358979323846f - (gamma / 2.0f), th2, hv, mirror);
         bad |= shift_wrap(t, hv, box, pbc, out[0]);
         return bad ? -1 : 1;
     }
@@ -366,6 +383,10 @@ int gorder_oracle_predict_hydrogens(uint32_t kind, const float pos[4][3], const 
         return bad ? -1 : 1;
     }
     return -2;
+}
+int gorder_oracle_predict_hydrogens(uint32_t kind, const float pos[4][3], const float box[3],
+                                    int pbc, float out[3][3]) {
+    return predict_hydrogens_mode(kind, pos, box, pbc, GORDER_ORACLE_TRIG_LIBM, out);
 }
 
 /* ---- geometry selection ----------------------------------------------------------------------
@@ -942,7 +963,7 @@ static int analyze_frame_orders(const gorder_oracle_handle *h, o_acc *a, int64_t
                     pos[k][0] = p[0]; pos[k][1] = p[1]; pos[k][2] = p[2];
                 }
                 float hy[3][3];
-                const int nh = gorder_oracle_predict_hydrogens(kind, pos, box, h->pbc, hy);
+                const int nh = predict_hydrogens_mode(kind, pos, box, h->pbc, h->trig, hy);
                 if (nh < 0) { bad = 1; continue; }
                 for (int k = 0; k < nh; k++) {
                     /* UAAtom::calculate_sch, uaorder.rs:375-397: vec = target->H, pos = H + vec/2 (sic) */

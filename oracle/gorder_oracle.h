@@ -70,6 +70,7 @@ float gorder_oracle_calc_order(int64_t sum, uint64_t n, uint64_t min_samples);
 /* mirror-mode primitives */
 float gorder_oracle_mirror_acosf(float x);
 float gorder_oracle_mirror_cosf(float x);
+float gorder_oracle_mirror_sinf(float x);   /* x in [0, pi] */
 /* UA hydrogen construction (uaorder.rs:947-1104); pos = [4][3] in the order of `indices`;
  * out = [n_h][3]; returns n_h */
 int gorder_oracle_predict_hydrogens(uint32_t kind, const float pos[4][3], const float box[3],

@@ -60,6 +60,8 @@ def load():
     lib.gorder_oracle_mirror_acosf.restype = f32
     lib.gorder_oracle_mirror_cosf.argtypes = [f32]
     lib.gorder_oracle_mirror_cosf.restype = f32
+    lib.gorder_oracle_mirror_sinf.argtypes = [f32]
+    lib.gorder_oracle_mirror_sinf.restype = f32
     lib.gorder_oracle_predict_hydrogens.argtypes = [u32, vp, vp, i32, vp]
     lib.gorder_oracle_estimate_error.argtypes = [vp, vp, u64, u64]
     lib.gorder_oracle_estimate_error.restype = f32
@@ -111,6 +113,10 @@ def mirror_acosf(x):
 
 def mirror_cosf(x):
     return float(np.float32(load().gorder_oracle_mirror_cosf(float(np.float32(x)))))
+
+
+def mirror_sinf(x):
+    return float(np.float32(load().gorder_oracle_mirror_sinf(float(np.float32(x)))))
 
 
 def predict_hydrogens(kind, positions, box, pbc=True):

@@ -146,7 +146,8 @@ def test_united_atoms(built, leaflets, pbc):
     exact = np.array(exact)
     assert exact.size == got.sums.shape[1] == 62
     np.testing.assert_array_equal(got.sums[:, exact], want.sums[:, exact])
-    assert np.abs(got.order_ticks()[:, ~exact] - want.order_ticks()[:, ~exact]).max() <= 1
+    # ... and so is the unsaturated CH since the device evaluates its angle with kernels the oracle restates
+    np.testing.assert_array_equal(got.sums[:, ~exact], want.sums[:, ~exact])
     # and everything within 1e-6 of the libm (reference-faithful) oracle
     ref = oracle.OracleEngine(system.tables, trig=oracle.TRIG_LIBM)
     ref.submit(xyz, box)
@@ -335,7 +336,7 @@ def test_united_atom_ordermaps_staged_and_direct(built, monkeypatch, leaflets, d
         ch1u[slot:slot + nh] = int(kind) == abi.UA_CH1_UNSAT
         slot += nh
     np.testing.assert_array_equal(got.map_sums[:, ~ch1u], want.map_sums[:, ~ch1u])
-    assert np.abs(got.map_sums[:, ch1u] - want.map_sums[:, ch1u]).max() <= got.map_counts[:, ch1u].max()   # <= 1 tick a sample
+    np.testing.assert_array_equal(got.map_sums[:, ch1u], want.map_sums[:, ch1u])
     assert got.map_counts.sum() > 0
 
 

@@ -146,8 +146,9 @@ def test_vua_ordermaps_at_full_size(built, monkeypatch, leaflets, direct):
     GridMap: round(9.0 / 0.1) + 1 tiles).  One slot's packed map is 66 KB (> 64 KB: the dynamic-LDS branch of
     k_map_accumulate), 132 KB with leaflets (upper + lower planes).  Staged route (default) and one atomic per
     sample (GORDER_HIP_MAP_DIRECT=1), several batches so that the staging buffer is reused, against the oracle:
-    sums, counts, map sums and map counts EQUAL, except the unsaturated CH slots (device sincos / acos vs host
-    libm): at most one tick per sample."""
+    sums, counts, map sums and map counts EQUAL in all 62 slots (the oracle's DIRECT mode restates the device's
+    arithmetic, the sin / cos / acos kernels of the unsaturated CH included); every order parameter within 1e-6 of
+    the libm (reference-faithful) mode."""
     torch_cuda()
     if direct:
         monkeypatch.setenv("GORDER_HIP_MAP_DIRECT", "1")
@@ -170,10 +171,9 @@ def test_vua_ordermaps_at_full_size(built, monkeypatch, leaflets, direct):
     np.testing.assert_array_equal(got.counts, want.counts)
     assert (got.counts[0] == 256 * n).all()
     np.testing.assert_array_equal(got.map_counts, want.map_counts)
-    np.testing.assert_array_equal(got.sums[:, ~un], want.sums[:, ~un])
-    np.testing.assert_array_equal(got.map_sums[:, ~un], want.map_sums[:, ~un])
-    assert np.abs(got.sums[:, un] - want.sums[:, un]).max() <= 256 * n
-    assert (np.abs(got.map_sums[:, un] - want.map_sums[:, un]) <= got.map_counts[:, un].astype(np.int64)).all()
+    np.testing.assert_array_equal(got.sums, want.sums)
+    np.testing.assert_array_equal(got.map_sums, want.map_sums)
+    assert (got.counts[0, un] == 256 * n).all()
     # every sample of a frame lands in one tile (hydrogens are wrapped into the box, uaorder.rs:979-1104; the bond
     # position H + v/2 may leave it by half a bond: those are dropped by the reference as well)
     tot = got.map_counts[0].sum(axis=(1, 2))

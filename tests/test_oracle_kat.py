@@ -56,6 +56,9 @@ def test_mirror_trig_accuracy(built):
     c = np.array([oracle.mirror_cosf(t) for t in ts])
     refc = np.cos(ts.astype(np.float64))
     assert np.max(np.abs(c - refc)) < 1.2e-7
+    sn = np.array([oracle.mirror_sinf(t) for t in ts])
+    assert np.max(np.abs(sn - np.sin(ts.astype(np.float64)))) < 1.2e-7
+    assert oracle.mirror_sinf(0.0) == 0.0 and np.isnan(oracle.mirror_sinf(float("nan")))
     assert np.isnan(oracle.mirror_acosf(1.5)) and np.isnan(oracle.mirror_cosf(float("nan")))
     assert oracle.mirror_acosf(1.0) == 0.0 and oracle.mirror_cosf(0.0) == 1.0
 
