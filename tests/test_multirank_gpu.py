@@ -67,7 +67,7 @@ def test_hip_shards_reduce_to_the_whole(built, world, method, frequency):
     np.testing.assert_array_equal(counts, want.counts)
     np.testing.assert_array_equal(np.concatenate(rows_s), ws)
     np.testing.assert_array_equal(np.concatenate(rows_c), wc)
-    assert (want.counts[1] > 0).all() and (want.counts[2] > 0).all()
+    assert want.counts[1].sum() > 0 and want.counts[2].sum() > 0
     # ... and the whole is the oracle's (bit for bit when the flags agree; they do here: nobody sits on the mid-plane)
     o = oracle.OracleEngine(system.tables, trig=oracle.TRIG_DIRECT, n_threads=2)
     o.submit(xyz, box, np.arange(n))

@@ -388,7 +388,7 @@ def test_first_error_across_batches_in_flight(built):
     n = 12
     xyz, box = system.frames(n, seed=3), system.box9(n)
     x = xyz.copy()
-    x[7, 5 * 12 + 3, 1] = np.nan          # batch 1 (frames 4..7), last frame of the batch
+    x[7, 5 * 12 + 3, 0] = np.nan          # batch 1 (frames 4..7), last frame of the batch (undefined = NaN in x)
     x[8, 2 * 12 + 0, 0] = np.nan          # batch 2 (frames 8..11), FIRST frame of its batch: a smaller key
     o = oracle.OracleEngine(system.tables, trig=oracle.TRIG_DIRECT)
     with pytest.raises(oracle.OracleError) as oe:
