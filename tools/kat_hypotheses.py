@@ -88,7 +88,15 @@ def c_centered(x, L):               # positions relative to the box centre and b
     return ((x - h).astype(f32) + h).astype(f32)
 
 
-COORDS = {"tpr f32 as stored": c_tpr, "x*10/10 (f32)": c_times10_div10, "x*10*0.1 (f32)": c_times10_times01,
+def c_round6(x, L):                 # six decimals (a text format with %.6f)
+    return (np.rint(x.astype(np.float64) * 1e6) / 1e6).astype(f32)
+
+
+def c_round7(x, L):
+    return (np.rint(x.astype(np.float64) * 1e7) / 1e7).astype(f32)
+
+
+COORDS = {"tpr f32 as stored": c_tpr, "6 decimals": c_round6, "7 decimals": c_round7, "x*10/10 (f32)": c_times10_div10, "x*10*0.1 (f32)": c_times10_times01,
           "x/10*10 (f32)": c_div10_times10, "x*10/10 in f64": c_f64_round_trip, ".gro twin (1e-3 nm)": c_gro,
           "int*(1/1000) f32": c_xtc1000_mul, "int/1000 f32": c_xtc1000_div, "(x+L)-L (f32)": c_plus_box_minus_box,
           "(x-L/2)+L/2 (f32)": c_centered}
@@ -221,6 +229,25 @@ def main():
         print(f"{'coordinates':<22}{'vector':<32}{'cosine':<28}{'max |err|':>11}{'rms':>11}{'> 1e-5':>8}")
         for r in rows[:12] + [{"coordinates": "...", "vector": "", "cosine": "", "max_abs_err": float("nan"), "rms_err": float("nan"), "values_outside_1e-5": -1}] + rows[-4:]:
             print(f"{r['coordinates']:<22}{r['vector']:<32}{r['cosine']:<28}{r['max_abs_err']:>11.2e}{r['rms_err']:>11.2e}{r['values_outside_1e-5']:>8}")
+        # how large a perturbation of the coordinates explains the residual: uniform noise of +- a nm added to every
+        # coordinate of the stored frame raises the rms error from r0 to sqrt(r0^2 + (k a)^2); the a at which the
+        # added part equals r0 is the size of the difference between these coordinates and the reference's
+        base = next(r for r in rows if r["coordinates"] == "tpr f32 as stored" and r["vector"] == "while loops on p2-p1" and r["cosine"].startswith("acosf"))
+        rng = np.random.default_rng(1)
+        calib = []
+        for amp in (1e-7, 2e-7, 3e-7, 5e-7, 1e-6):
+            rms = []
+            for _ in range(4):
+                xn = (x.astype(np.float64) + rng.uniform(-amp, amp, size=x.shape)).astype(f32)
+                got = sign * sums(xn, L, pairs, owner, n_types, v_while, s_f64) / 1e6
+                rms.append(float(np.sqrt(((got.astype(f32).astype(np.float64) - expected) ** 2).mean())))
+            added = float(np.sqrt(max(0.0, np.mean(rms) ** 2 - base["rms_err"] ** 2)))
+            calib.append({"uniform_noise_nm": amp, "rms_err": float(np.mean(rms)), "added_rms": added})
+        k = np.mean([c["added_rms"] / c["uniform_noise_nm"] for c in calib[2:]])
+        report["systems"][kind]["noise_calibration"] = calib
+        report["systems"][kind]["residual_equals_uniform_noise_of_nm"] = float(base["rms_err"] / k)
+        print("residual of the stored frame = what uniform noise of +-%.1e nm per coordinate adds (f32 ulp of these coordinates: 2.4e-7 .. 9.5e-7)"
+              % (base["rms_err"] / k))
         best = rows[0]
         report["systems"][kind]["verdict"] = (
             "a combination reproduces the reference's arrays to its tolerance" if best["values_outside_1e-5"] == 0 else
