@@ -117,23 +117,37 @@ __device__ __forceinline__ float gm_asin_r(float z) {
     return p;
 }
 
+__device__ __forceinline__ float gm_div_core(float n, float d);
+__device__ __forceinline__ float gm_sqrt_core(float x);
+
 // Branch-free (a wave almost always holds lanes of every range); the arithmetic of each range is
 // exactly the sequence restated in oracle/gorder_oracle.c (gorder_oracle_mirror_acosf).
-__device__ __forceinline__ float gm_acosf(float x) {
+// CORES: the square root and the division of the |x| > 1/2 range by their Newton cores (gm_sqrt_core / gm_div_core
+// below).  Same bits: there z = (1 - |x|) / 2 is 0 or lies in [2^-25, 1/4) — inside the cores' guarded range, and
+// gm_sqrt_core(0) = 0 —, the divisor s + s in [2^-12, 1], and the numerator z - s^2 is 0 or at least 2^-74 in
+// magnitude (a multiple of ulp(s)^2); for |x| <= 1/2 both results are computed and discarded.
+template <bool CORES = false>
+__device__ __forceinline__ float gm_acosf_t(float x) {
     const float ax = __builtin_fabsf(x);
     // both argument reductions share the polynomial: z = x^2 (|x| <= 1/2) or (1-|x|)/2
     const bool small = ax <= 0.5f;
     const float z = small ? x * x : (1.0f - ax) * 0.5f;
     const float r = z * gm_asin_r(z);
     const float r_small = GM_PIO2_HI - (x - (GM_PIO2_LO - x * r));
-    const float s = __builtin_sqrtf(z);
-    const float c = (s > 0.0f) ? __builtin_fmaf(-s, s, z) / (s + s) : 0.0f;
+    const float s = CORES ? gm_sqrt_core(z) : __builtin_sqrtf(z);
+    const float quo = CORES ? gm_div_core(__builtin_fmaf(-s, s, z), s + s) : __builtin_fmaf(-s, s, z) / (s + s);
+    const float c = (s > 0.0f) ? quo : 0.0f;
     const float w = __builtin_fmaf(s, r, c);
     const float r_pos = 2.0f * (s + w);
     const float r_neg = 2.0f * (GM_PIO2_HI - (s + (w - GM_PIO2_LO)));
-    float res = small ? r_small : (x > 0.0f ? r_pos : r_neg);
+    float r_large = x > 0.0f ? r_pos : r_neg;
+    // (the streaming kernel evaluates several frames as interleaved straight-line chains: keep the compiler from
+    // sinking this range's arithmetic into a branch on `small` — a wave always has lanes of both ranges)
+    if (CORES) asm volatile("" : "+v"(r_large));
+    float res = small ? r_small : r_large;
     return (ax <= 1.0f) ? res : __builtin_nanf("");
 }
+__device__ __forceinline__ float gm_acosf(float x) { return gm_acosf_t<false>(x); }
 
 __device__ __forceinline__ float gm_kcos(float r) {
     const float z = r * r;
@@ -255,6 +269,23 @@ __device__ __forceinline__ float gm_sch_axis(float vx, float vy, float vz, bool 
     const float prod = AXIS == 0 ? vx : (AXIS == 1 ? vy : vz);
     rare = rare || !(s2 >= 0x1p-40f && s2 <= 0x1p+40f);
     return (1.5f * gm_div_core(prod * prod, s2)) - 0.5f;
+}
+// The reference's LITERAL evaluation (GORDER_FLAG_TRIG_ACOS_COS) for a static normal along a coordinate axis, with the
+// same trims as gm_sch_axis: gm_calc_sch<true> computes c = clamp(v.n / (|v| |n|)), angle = acos(c), S = 1.5 cos^2 - 0.5.
+// With n the unit vector of AXIS and a FINITE v:  v.n = (vx*0 + vy*0) + v_AXIS*1 = v_AXIS (a -0 instead of +0 gives the
+// same angle, see gm_acosf_t's |x| <= 1/2 range), |n| = 1 so |v| |n| = |v|, and |v_AXIS| <= RN(sqrt(s2)) because
+// s2 >= v_AXIS^2 and both roundings are monotonic — the quotient cannot leave [-1, 1], no clamp.  |v|^2 outside
+// [2^-40, 2^40] (0, inf, NaN included) raises `rare` and the caller recomputes the sample with the general routine;
+// inside, square root and division are their cores (|v| in [2^-20, 2^20], |v_AXIS| <= |v|; a numerator so small that
+// v_div_fixup would matter gives a quotient below 2^-63, and acos of that is pi/2 whatever its last bit).
+template <int AXIS>
+__device__ __forceinline__ float gm_sch_axis_acos(float vx, float vy, float vz, bool &rare) {
+    const float s2 = (vx * vx + vy * vy) + vz * vz;
+    const float prod = AXIS == 0 ? vx : (AXIS == 1 ? vy : vz);
+    rare = rare || !(s2 >= 0x1p-40f && s2 <= 0x1p+40f);
+    const float c = gm_div_core(prod, gm_sqrt_core(s2));
+    const float co = gm_cosf(gm_acosf_t<true>(c));
+    return (1.5f * co * co) - 0.5f;
 }
 // gm_tick for a sample that is known not to be NaN (the caller's rare path takes those)
 __device__ __forceinline__ int gm_tick_finite(float s) {

@@ -436,9 +436,9 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
                            h->lw)
 #define GORDER_LAUNCH_TILED_V(G_, NPF_, AC_, PBC_, LF_)                                                    \
         do {                                                                                                \
-            if (!(AC_) && h->axis == 2) GORDER_LAUNCH_TILED_A(G_, NPF_, AC_, PBC_, LF_, 2);                 \
-            else if (!(AC_) && h->axis == 1) GORDER_LAUNCH_TILED_A(G_, NPF_, AC_, PBC_, LF_, 1);            \
-            else if (!(AC_) && h->axis == 0) GORDER_LAUNCH_TILED_A(G_, NPF_, AC_, PBC_, LF_, 0);            \
+            if (h->axis == 2) GORDER_LAUNCH_TILED_A(G_, NPF_, AC_, PBC_, LF_, 2);                           \
+            else if (h->axis == 1) GORDER_LAUNCH_TILED_A(G_, NPF_, AC_, PBC_, LF_, 1);                      \
+            else if (h->axis == 0) GORDER_LAUNCH_TILED_A(G_, NPF_, AC_, PBC_, LF_, 0);                      \
             else GORDER_LAUNCH_TILED_A(G_, NPF_, AC_, PBC_, LF_, -1);                                       \
         } while (0)
 #define GORDER_LAUNCH_TILED(G_, NPF_)                                                                       \
@@ -708,6 +708,15 @@ __global__ void k_selftest_arithmetic(uint64_t n, uint64_t seed, unsigned long l
         if (__float_as_uint(q_core) != __float_as_uint(q_ieee)) bad_div++;
         const float s_core = gm_sqrt_core(d), s_ieee = __builtin_sqrtf(d);
         if (__float_as_uint(s_core) != __float_as_uint(s_ieee)) bad_sqrt++;
+        // acos with the cores inside against acos with the IEEE operations: arguments over the whole of [-1, 1]
+        // (every exponent down to 2^-60, both ends, the ties of the range split)
+        float xa = make(-60, -1, true);
+        if (i % 16u == 0) xa = __builtin_copysignf(1.0f - __uint_as_float(0x33800000u) * (float)(next() & 0xffffu), xa);   // 1 - k 2^-24
+        if (i % 4096u == 1) xa = 1.0f;
+        if (i % 4096u == 2) xa = -1.0f;
+        if (i % 4096u == 3) xa = 0.5f;
+        if (i % 4096u == 4) xa = 0.0f;
+        if (__float_as_uint(gm_acosf_t<true>(xa)) != __float_as_uint(gm_acosf_t<false>(xa))) bad_sqrt++;
     }
     if (bad_div) atomicAdd(&mismatches[0], (unsigned long long)bad_div);
     if (bad_sqrt) atomicAdd(&mismatches[1], (unsigned long long)bad_sqrt);

@@ -144,6 +144,10 @@ struct TiledStage {
                 const float sch = gm_sch_axis<AXIS>(vx, vy, vz, slow);
                 rare |= (slow ? 1u : 0u) << k;
                 tick[k] = gm_tick_finite(sch);
+            } else if (AXIS >= 0) {           // the same normal, the reference's literal acos -> cos round trip
+                const float sch = gm_sch_axis_acos<AXIS>(vx, vy, vz, slow);
+                rare |= (slow ? 1u : 0u) << k;
+                tick[k] = gm_tick_finite(sch);
             } else {
                 bool nonfinite = false;
                 const float sch = gm_calc_sch<ACOS_COS, AXIS>(vx, vy, vz, a.nx, a.ny, a.nz, a.n2, a.n2sq, &nonfinite);

@@ -415,7 +415,8 @@ int gorder_hip_plan_tables(const gorder_tables_t *tables, gorder_hip_plan_t *pla
  * ranges (gm_div_core / gm_sqrt_core in gm_math.h; DESIGN.md, K1 arithmetic).  This runs both forms on `n` pseudo-random
  * operand sets on the device — divisors and radicands log-uniform over the guarded range [2^-40, 2^40], numerators of
  * either sign from 2^-100 to 2^60 and exact zeros — and returns how many results differ in any bit:
- * mismatches[0] division, mismatches[1] square root.  Both must be 0. */
+ * mismatches[0] division, mismatches[1] square root and the acos kernel with the cores inside against the same kernel
+ * with IEEE operations (arguments over all of [-1, 1]).  Both must be 0. */
 int gorder_hip_selftest_arithmetic(int device, uint64_t n, uint64_t seed, uint64_t mismatches[2]);
 
 #ifdef __cplusplus
