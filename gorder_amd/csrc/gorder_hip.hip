@@ -81,7 +81,8 @@ struct gorder_hip_handle {
     Item *d_items_by_slot = nullptr;
     uint32_t *d_item_run = nullptr, *d_ua_item_run = nullptr;
     uint4 *d_lgrid = nullptr;       // per slab frame: the cell grid of the local-leaflet kernels
-    float4 *d_lagg = nullptr;       // per slab frame and cell: the sums of k_local_cellsums
+    LocalRowPre *d_lrowpre = nullptr;   // per slab frame: prefix sums along the rows of cells (k_local_rowprefix)
+    float4 *d_lfinfo = nullptr;     // per slab frame: extrema of the membrane's normal coordinate, finite flag
     uint2 *d_ltodo = nullptr;       // {count}, then the (slab frame, head) pairs left to the general passes
     size_t map_lds_bytes = 0;
     bool map_staged = false;       // the packed map of one slot fits LDS: stage + accumulate instead of one atomic per sample
@@ -95,6 +96,10 @@ struct gorder_hip_handle {
     float *d_shapes = nullptr;
     // dynamic membrane normals: cloud + per-molecule heads, cell-list scratch (dyn_slab frames), normals of the batch
     uint32_t dyn_slab = 4, local_slab = 4;
+    bool local_halo = false;           // local leaflets: rows of cells with a halo + prefix sums (k_local_flags_rows)
+    size_t local_rec_stride = 0;       // records per slab frame the local-leaflet record arrays hold
+    XtcCheckpoint *d_xtc_cp = nullptr; // gorder_hip_xtc_decode: where the chunks of the frames start (k_xtc_scan -> k_xtc_chunks)
+    size_t xtc_cp_cap = 0;
     bool dyn = false;
     uint32_t *d_dyn_cloud = nullptr, *d_dyn_heads = nullptr;
     uint32_t *d_dyn_cell_of = nullptr, *d_dyn_count = nullptr;
@@ -357,6 +362,7 @@ int run_dynamic_normals(gorder_hip_handle *h, const FrameArgs &a) {
     lo.xyz = a.xyz; lo.box9 = a.box9; lo.n_atoms = a.n_atoms;
     lo.n_mol_total = n_mol; lo.heads = h->d_dyn_heads; lo.membrane = h->d_dyn_cloud; lo.n_membrane = dn.n_cloud;
     lo.dim = 2; lo.pbc = a.pbc; lo.radius = dn.radius; lo.radius_thr = local_radius_threshold(dn.radius);
+    lo.halo = 0; lo.rec_stride = dn.n_cloud;
     lo.cell_of = h->d_dyn_cell_of; lo.trig = h->d_dyn_rec; lo.rsn = h->d_dyn_rsn;
     lo.cell_count = h->d_dyn_count; lo.cell_fill = h->d_dyn_count + h->dyn_slab * (ncell + 1);
     lo.err = h->d_err; lo.aframes = nullptr; lo.write_dist_frame = -1;
@@ -1000,14 +1006,19 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
             const size_t sl = h->local_slab = local_slab_frames(nm);
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_local_build),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLocalBuildLds));
+            // rows of cells with a halo (periodic boxes, k_local_flags_rows): the first cells of a row are there twice,
+            // records included — room for twice the membrane
+            h->local_halo = t->handle_pbc && !env_flag("GORDER_HIP_LOCAL_ATOMS_ONLY");
+            h->local_rec_stride = (h->local_halo ? 2u : 1u) * nm;
             HIP_TRY(h, hipMalloc((void **)&h->d_lcell_of, sl * nm * sizeof(uint32_t)));
-            HIP_TRY(h, hipMalloc((void **)&h->d_lcell_atoms, sl * nm * sizeof(float)));   // sin column
-            HIP_TRY(h, hipMalloc((void **)&h->d_ltrig, sl * nm * 4 * sizeof(float)));
+            HIP_TRY(h, hipMalloc((void **)&h->d_lcell_atoms, sl * h->local_rec_stride * sizeof(float)));   // sin column
+            HIP_TRY(h, hipMalloc((void **)&h->d_ltrig, sl * h->local_rec_stride * 4 * sizeof(float)));
             HIP_TRY(h, hipMalloc((void **)&h->d_lcell_count, sl * (ncell + 1) * sizeof(uint32_t)));
             HIP_TRY(h, hipMalloc((void **)&h->d_lcell_fill, sl * ncell * sizeof(uint32_t)));
             HIP_TRY(h, hipMalloc((void **)&h->d_lgrid, sl * sizeof(uint4)));
-            if (!env_flag("GORDER_HIP_LOCAL_ATOMS_ONLY")) {    // A/B switch: every candidate atom by atom, as before
-                HIP_TRY(h, hipMalloc((void **)&h->d_lagg, sl * ncell * 2 * sizeof(float4)));
+            if (h->local_halo) {    // (GORDER_HIP_LOCAL_ATOMS_ONLY, an A/B switch: every candidate atom by atom, the general passes)
+                HIP_TRY(h, hipMalloc((void **)&h->d_lrowpre, sl * (size_t)kLocalMaxCells1D * (kLocalMaxCells1D + 1u) * sizeof(LocalRowPre)));
+                HIP_TRY(h, hipMalloc((void **)&h->d_lfinfo, sl * sizeof(float4)));
                 HIP_TRY(h, hipMalloc((void **)&h->d_ltodo, (1 + sl * (size_t)(p.n_mol_total ? p.n_mol_total : 1)) * sizeof(uint2)));
             }
         }
@@ -1028,13 +1039,13 @@ void gorder_hip_destroy(gorder_hip_handle *h) {
             if (ev) (void)hipEventDestroy(ev);
     (void)hipFree(h->d_mol_slot0);
     (void)hipFree(h->d_tiles); (void)hipFree(h->d_items); (void)hipFree(h->d_tile_slots);
-    (void)hipFree(h->d_direct); (void)hipFree(h->d_err);
+    (void)hipFree(h->d_direct); (void)hipFree(h->d_err); (void)hipFree(h->d_xtc_cp);
     (void)hipFree(h->d_ua_tiles); (void)hipFree(h->d_ua_items); (void)hipFree(h->d_ua_tile_slots);
     (void)hipFree(h->d_map_sums); (void)hipFree(h->d_map_cnts); (void)hipFree(h->d_map_packed); (void)hipFree(h->d_tw_sums); (void)hipFree(h->d_tw_cnts);
     (void)hipFree(h->d_geom_group); (void)hipFree(h->d_shapes);
     (void)hipFree(h->d_map_rec); (void)hipFree(h->d_ua_runs); (void)hipFree(h->d_ua_run_begin);
     (void)hipFree(h->d_runs); (void)hipFree(h->d_run_begin); (void)hipFree(h->d_items_by_slot);
-    (void)hipFree(h->d_item_run); (void)hipFree(h->d_ua_item_run); (void)hipFree(h->d_lgrid); (void)hipFree(h->d_lagg); (void)hipFree(h->d_ltodo);
+    (void)hipFree(h->d_item_run); (void)hipFree(h->d_ua_item_run); (void)hipFree(h->d_lgrid); (void)hipFree(h->d_lrowpre); (void)hipFree(h->d_lfinfo); (void)hipFree(h->d_ltodo);
     (void)hipFree(h->d_dyn_cloud); (void)hipFree(h->d_dyn_heads); (void)hipFree(h->d_dyn_cell_of); (void)hipFree(h->d_dyn_count);
     (void)hipFree(h->d_dyn_rec); (void)hipFree(h->d_dyn_rsn); (void)hipFree(h->d_dyn_normals);
     if (!h->acc_external) (void)hipFree(h->d_acc);
@@ -1136,7 +1147,10 @@ static int run_leaflets(gorder_hip_handle *h, const float *d_xyz, const float *d
         lo.cell_of = h->d_lcell_of; lo.trig = h->d_ltrig; lo.cell_count = h->d_lcell_count;
         lo.cell_fill = h->d_lcell_fill; lo.rsn = reinterpret_cast<float *>(h->d_lcell_atoms); lo.err = h->d_err;
         lo.grid = h->d_lgrid;
-        lo.agg = h->d_lagg;
+        lo.halo = h->local_halo ? 1 : 0;
+        lo.rec_stride = (uint32_t)h->local_rec_stride;
+        lo.rowpre = h->d_lrowpre;
+        lo.finfo = h->d_lfinfo;
         lo.todo = h->d_ltodo;
         for (size_t done = 0; done < aframes.size(); done += h->local_slab) {
             const uint32_t ns = (uint32_t)std::min<size_t>(aframes.size() - done, h->local_slab);
@@ -1148,10 +1162,10 @@ static int run_leaflets(gorder_hip_handle *h, const float *d_xyz, const float *d
                 HIP_TRY(h, hipMemsetAsync(h->d_lcell_fill, 0, ns * ncell * sizeof(uint32_t), h->stream));
             const int cst = launch_cell_list(h, lo, ns, lf.n_membrane, h->d_lcell_count, ns * (ncell + 1) * sizeof(uint32_t));
             if (cst != GORDER_OK) return cst;
-            if (lo.agg)
-                hipLaunchKernelGGL(k_local_cellsums, dim3(64, ns), dim3(256), 0, h->stream, lo);
-            if (lo.agg && lo.pbc) {
-                hipLaunchKernelGGL(k_local_flags_rows, dim3((lo.n_mol_total + 15) / 16, ns), dim3(256), 0, h->stream, lo);
+            if (lo.halo) {
+                hipLaunchKernelGGL(k_local_rowprefix, dim3(kLocalMaxCells1D / 4u, ns), dim3(256), 0, h->stream, lo);
+                lo.rows_groups = (lo.n_mol_total + 15u) / 16u;
+                hipLaunchKernelGGL(k_local_flags_rows, dim3(lo.rows_groups * ((ns + 7u) / 8u * 8u)), dim3(256), 0, h->stream, lo);
                 // the heads the rows left over (normally none: the grid finds an empty list and leaves)
                 hipLaunchKernelGGL(k_local_flags_todo, dim3(512), dim3(256), 0, h->stream, lo);
             } else
@@ -1617,18 +1631,36 @@ int gorder_hip_kernel_time(gorder_hip_handle *h, double *ms, uint64_t *launches,
 }
 
 // ---- XTC frames decompressed on the device (kernels_xtc.h) ---------------------------------------------------------
+// checkpoints a batch needs between its two kernels
+size_t xtc_checkpoints(uint32_t n_frames, uint32_t n_stop) {
+    return (size_t)n_frames * ((std::max(n_stop, 1u) + kXtcChunk - 1u) / kXtcChunk + 1u);
+}
 int xtc_decode_on(gorder_hip_handle *h, hipStream_t stream, const uint8_t *d_blob, uint64_t blob_bytes,
                   const gorder_xtc_frame_t *d_frames, uint32_t n_frames, uint32_t n_atoms_file, const int32_t *d_slot_of,
                   uint32_t n_stop, float *d_xyz, uint32_t n_atoms_out, uint32_t *d_stat = nullptr, uint32_t *d_short = nullptr,
-                  uint32_t *d_err_key = nullptr) {
+                  uint32_t *d_err_key = nullptr, XtcCheckpoint *d_cp = nullptr) {
     if (!h || !d_blob || !d_frames || !d_xyz || blob_bytes < 64 || (reinterpret_cast<uintptr_t>(d_blob) & 63u) != 0 || n_atoms_file == 0 || n_atoms_out == 0 ||
         n_stop > n_atoms_file || (!d_slot_of && n_atoms_out < n_stop))
         return fail(h, GORDER_ERR_INVALID_ARGUMENT, "gorder_hip_xtc_decode: bad arguments");
     if (n_frames == 0) return GORDER_OK;
     HIP_TRY(h, hipSetDevice(h->device));
-    hipLaunchKernelGGL(k_xtc_decode, dim3((n_frames + 64u * kXtcWaves - 1u) / (64u * kXtcWaves)), dim3(64u * kXtcWaves), 0, stream, d_blob,
-                       (unsigned long long)blob_bytes, d_frames, n_frames, n_atoms_file, d_slot_of, n_stop, d_xyz,
-                       n_atoms_out, d_err_key ? d_err_key : h->d_err, d_stat, d_short);
+    // two kernels (kernels_xtc.h): where the chunks of ~kXtcChunk atoms start in every frame's stream (one lane per
+    // frame, no decoding), then the chunks (one lane per frame and chunk).  The checkpoints between them live in the
+    // caller's buffer (a slot of gorder_hip_run_trajectory has its own: several batches decode at once) or the handle's.
+    const uint32_t n_chunks = (std::max(n_stop, 1u) + kXtcChunk - 1u) / kXtcChunk;
+    if (!d_cp) {
+        const int st = ensure(h, &h->d_xtc_cp, &h->xtc_cp_cap, xtc_checkpoints(n_frames, n_stop));
+        if (st != GORDER_OK) return st;
+        d_cp = h->d_xtc_cp;
+    }
+    hipLaunchKernelGGL(k_xtc_scan, dim3((n_frames + 3u) / 4u), dim3(256), 0, stream, d_blob, (unsigned long long)blob_bytes,
+                       d_frames, n_frames, n_atoms_file, d_slot_of, n_stop, d_xyz, n_atoms_out,
+                       d_err_key ? d_err_key : h->d_err, d_stat, d_short, d_cp, n_chunks);
+    const unsigned long long items = (unsigned long long)n_frames * n_chunks;
+    if (items + 63ull > 64ull * 0x7fffffffull) return fail(h, GORDER_ERR_INVALID_ARGUMENT, "gorder_hip_xtc_decode: batch too large");
+    hipLaunchKernelGGL(k_xtc_chunks, dim3((uint32_t)((items + 63ull) / 64ull)), dim3(64), 0, stream, d_blob,
+                       (unsigned long long)blob_bytes, d_frames, n_frames, n_atoms_file, d_slot_of, n_stop, d_xyz, n_atoms_out,
+                       d_cp, n_chunks);
     HIP_TRY(h, hipGetLastError());
     return GORDER_OK;
 }

@@ -469,10 +469,14 @@ constexpr uint32_t kLocalMaxCells1D = 128;
 constexpr uint32_t kLocalSlabMax = 256;
 inline uint32_t local_slab_frames(size_t n_membrane) {
     // (the heads' to-do list, 8 bytes per head and frame, is on top: heads are a fraction of the membrane atoms)
-    const size_t per_frame = n_membrane * 24u + (size_t)(2 * 4u + 32u) * kLocalMaxCells1D * kLocalMaxCells1D + 8u;
+    // (records and their sin column twice — the halo copies —, the cell of every atom, two tables of cell counts, the rows'
+    // prefix sums)
+    const size_t per_frame = n_membrane * (2u * 20u + 4u) + (size_t)(2 * 4u + 16u) * kLocalMaxCells1D * (kLocalMaxCells1D + 1u) + 32u;
     const size_t n = ((size_t)512 << 20) / per_frame;
     return (uint32_t)(n < 4 ? 4 : (n > kLocalSlabMax ? kLocalSlabMax : n));
 }
+
+struct LocalRowPre { float sc, ss; double sz; };   // sum cos, sum sin, sum of the normal coordinate: cells before this one in its row
 
 struct LocalArgs {
     const float *xyz;
@@ -503,7 +507,15 @@ struct LocalArgs {
     float *rsn;                 // [n_slab][n_membrane] sin of the normal angle, cell order
     uint32_t *cell_count;       // [n_slab][kLocalMaxCells1D^2 + 1] counts -> starts
     uint32_t *cell_fill;        // [n_slab][kLocalMaxCells1D^2]
-    float4 *agg;                // [n_slab][kLocalMaxCells1D^2][2] per-cell sums (k_local_cellsums) for k_local_flags, or null
+    // rows of cells with a HALO (local leaflets in a periodic box): a row of the grid carries, behind its ncb cells,
+    // copies of its first 2 kb cells (records included), so that the (2 kb + 1) cells a head looks at in a row are one
+    // contiguous run of cells — and of records — wherever the head stands; rows are `ncb + 2 kb` cells apart
+    int halo;
+    uint32_t rows_groups;       // k_local_flags_rows: workgroups per frame (16 heads each)
+    uint32_t rec_stride;        // records per slab frame the record arrays have room for (>= n_membrane; 2 x with halo)
+    LocalRowPre *rowpre;        // [n_slab][kLocalMaxCells1D * (kLocalMaxCells1D + 1)] prefix sums along each row of cells
+                                // (k_local_rowprefix) for k_local_flags_rows, or null
+    float4 *finfo;              // [n_slab] (min, max of the membrane's normal coordinate, 1 if every coordinate is finite, -)
     uint2 *todo;                // [1 + n_slab * n_mol_total] with agg: {count, -} then the (slab frame, head) pairs
                                 // k_local_flags_rows leaves to k_local_flags_todo
     uint32_t *err;
@@ -515,13 +527,16 @@ struct LocalArgs {
 // cut the candidates per head from 9 r^2 (k = 1) towards the disk area pi r^2: k = 4 gives 5.1 r^2.
 // The grid is this engine's own pruning device — membership itself is the exact distance test.
 constexpr uint32_t kLocalFine = 4;
-__device__ __forceinline__ void local_axis(float L, float radius, uint32_t &nc, uint32_t &k) {
+// with a halo (k_local_flags_rows): cells of radius / 7 — the 15 rows of cells around a head are the lanes of one DPP row
+constexpr uint32_t kLocalFineRows = 7;
+__device__ __forceinline__ void local_axis(float L, float radius, uint32_t &nc, uint32_t &k, uint32_t k_max = kLocalFine,
+                                           uint32_t nc_max = kLocalMaxCells1D) {
     nc = 1; k = 0;
-    for (uint32_t kk = kLocalFine; kk >= 1u; kk--) {
+    for (uint32_t kk = k_max; kk >= 1u; kk--) {
         // cells are at least 1.0001 radius / kk wide (floor + margin), so +-kk cells reach one radius even
         // when the wrapped coordinates the cells are made from are off by a rounding error
         const float fine = floorf(L / (radius / (float)kk) * 0.9999f);
-        if (fine >= (float)(2u * kk + 1u) && fine <= (float)kLocalMaxCells1D) { nc = (uint32_t)fine; k = kk; return; }
+        if (fine >= (float)(2u * kk + 1u) && fine <= (float)nc_max) { nc = (uint32_t)fine; k = kk; return; }
     }
 }
 __device__ __forceinline__ void local_grid(const LocalArgs &a, const float *box, uint32_t &nca, uint32_t &ncb,
@@ -531,9 +546,15 @@ __device__ __forceinline__ void local_grid(const LocalArgs &a, const float *box,
     nca = ncb = 1;   // no periodic images to prune with: one cell holds every atom
     ka = kb = 0;
     if (a.pbc) {
-        local_axis(box[da], a.radius, nca, ka);
-        local_axis(box[db], a.radius, ncb, kb);
+        const uint32_t k_max = a.halo ? kLocalFineRows : kLocalFine;
+        local_axis(box[da], a.radius, nca, ka, k_max);
+        // (with the halo a row is ncb + 2 kb cells long and must still fit the tables of kLocalMaxCells1D^2 cells)
+        local_axis(box[db], a.radius, ncb, kb, k_max, a.halo ? kLocalMaxCells1D - 2u * kLocalFineRows : kLocalMaxCells1D);
     }
+}
+// cells between the starts of two rows of the grid
+__device__ __forceinline__ uint32_t local_row_stride(const LocalArgs &a, uint32_t ncb, uint32_t kb) {
+    return a.halo ? ncb + 2u * kb : ncb;
 }
 __device__ __forceinline__ void local_grid(const LocalArgs &a, const float *box, uint32_t &nca, uint32_t &ncb,
                                            int &da, int &db) {
@@ -541,6 +562,19 @@ __device__ __forceinline__ void local_grid(const LocalArgs &a, const float *box,
     local_grid(a, box, nca, ncb, da, db, ka, kb);
 }
 
+// ordered-integer image of a float (monotonic for every non-NaN value): atomicMin / atomicMax on floats of either sign
+__device__ __forceinline__ uint32_t local_float_key(float v) {
+    const uint32_t b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float local_key_float(uint32_t k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+// finfo[s] as the kernels keep it while it is being made: (key of the minimum, key of the maximum, 1 if a coordinate is
+// not finite, -); set to (max key, 0, 0, 0) by whoever writes grid[s]
+__device__ __forceinline__ void local_finfo_init(const LocalArgs &a, uint32_t s) {
+    if (a.finfo) reinterpret_cast<uint4 *>(a.finfo)[s] = make_uint4(0xffffffffu, 0u, 0u, 0u);
+}
 __device__ __forceinline__ void frame_box(const LocalArgs &a, uint32_t f, float *box) {
     box[0] = box[1] = box[2] = 1.0f;
     if (a.pbc) {
@@ -549,9 +583,9 @@ __device__ __forceinline__ void frame_box(const LocalArgs &a, uint32_t f, float 
     }
 }
 
-// in-plane cell of membrane atom i in slab frame s (also stored in cell_of)
+// in-plane cell of membrane atom i in slab frame s (also stored in cell_of); rows are `ncs` cells apart
 __device__ __forceinline__ uint32_t local_cell_of(const LocalArgs &a, uint32_t s, uint32_t f, uint32_t i,
-                                                  const float *box, uint32_t nca, uint32_t ncb, int da, int db) {
+                                                  const float *box, uint32_t nca, uint32_t ncb, uint32_t ncs, int da, int db) {
     const float *p = a.xyz + ((size_t)f * a.n_atoms + a.membrane[i]) * 3u;
     int bad = 0;
     uint32_t ca = 0, cb = 0;
@@ -560,7 +594,7 @@ __device__ __forceinline__ uint32_t local_cell_of(const LocalArgs &a, uint32_t s
         ca = (uint32_t)fminf(fmaxf(floorf(wa / box[da] * (float)nca), 0.0f), (float)(nca - 1u));
         cb = (uint32_t)fminf(fmaxf(floorf(wb / box[db] * (float)ncb), 0.0f), (float)(ncb - 1u));
     }
-    const uint32_t c = ca * ncb + cb;
+    const uint32_t c = ca * ncs + cb;
     a.cell_of[(size_t)s * a.n_membrane + i] = c;
     if (bad) raise_box_range(a.err, f);
     return c;
@@ -575,10 +609,10 @@ __global__ __launch_bounds__(256) void k_local_bin(LocalArgs a) {
     const uint32_t f = a.aframes ? a.aframes[s] : a.frame0 + s;
     float box[3];
     frame_box(a, f, box);
-    uint32_t nca, ncb;
+    uint32_t nca, ncb, ka, kb;
     int da, db;
-    local_grid(a, box, nca, ncb, da, db);
-    const uint32_t ncell = nca * ncb;
+    local_grid(a, box, nca, ncb, da, db, ka, kb);
+    const uint32_t ncs = local_row_stride(a, ncb, kb), ncell = nca * ncs;
     uint32_t *count = a.cell_count + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u);
     const bool lds = ncell <= kLocalLdsCells;   // uniform
     if (lds) {
@@ -586,9 +620,13 @@ __global__ __launch_bounds__(256) void k_local_bin(LocalArgs a) {
         __syncthreads();
     }
     if (i < a.n_membrane) {
-        const uint32_t c = local_cell_of(a, s, f, i, box, nca, ncb, da, db);
+        const uint32_t c = local_cell_of(a, s, f, i, box, nca, ncb, ncs, da, db);
         if (lds) atomicAdd(&hist[c], 1u);
         else atomicAdd(&count[c], 1u);
+        if (a.halo && c % ncs < 2u * kb) {          // the first 2 kb cells of a row appear again behind its last cell
+            if (lds) atomicAdd(&hist[c + ncb], 1u);
+            else atomicAdd(&count[c + ncb], 1u);
+        }
     }
     if (lds) {   // one global atomic per cell the block touched (neighbouring atoms share cells)
         __syncthreads();
@@ -629,6 +667,7 @@ __global__ __launch_bounds__(1024) void k_local_scan(LocalArgs a) {
         int da, db;
         local_grid(a, box, nca, ncb, da, db, ka, kb);
         a.grid[s] = make_uint4(nca, ncb, ka, kb);
+        local_finfo_init(a, s);
     }
 }
 
@@ -643,10 +682,10 @@ __global__ __launch_bounds__(256) void k_local_scatter(LocalArgs a) {
     const uint32_t f = a.aframes ? a.aframes[s] : a.frame0 + s;
     float box[3];
     frame_box(a, f, box);
-    uint32_t nca, ncb;
+    uint32_t nca, ncb, ka, kb;
     int da, db;
-    local_grid(a, box, nca, ncb, da, db);
-    const uint32_t ncell = nca * ncb;
+    local_grid(a, box, nca, ncb, da, db, ka, kb);
+    const uint32_t ncs = local_row_stride(a, ncb, kb), ncell = nca * ncs;
     const int dn = (int)a.dim;
     const bool lds = ncell <= kLocalLdsCells;   // uniform
     uint32_t *fill = a.cell_fill + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D);
@@ -671,22 +710,54 @@ __global__ __launch_bounds__(256) void k_local_scatter(LocalArgs a) {
     int bad = 0;
     float sn = 0.0f, cs = 0.0f;
     if (a.pbc) fast_sincos_rev(gm_wrap(p[dn], box[dn], bad) / box[dn], &sn, &cs);
-    const size_t q = (size_t)s * a.n_membrane + start + rank;
+    const size_t q = (size_t)s * a.rec_stride + start + rank;
     reinterpret_cast<float4 *>(a.trig)[q] = make_float4(p[da], p[db], p[dn], cs);
     a.rsn[q] = sn;
+    if (a.halo && c % ncs < 2u * kb) {              // the copy in the row's halo
+        const uint32_t c2 = c + ncb;
+        const size_t q2 = (size_t)s * a.rec_stride + a.cell_count[(size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u) + c2] +
+                          atomicAdd(&fill[c2], 1u);
+        reinterpret_cast<float4 *>(a.trig)[q2] = make_float4(p[da], p[db], p[dn], cs);
+        a.rsn[q2] = sn;
+    }
 }
 
+template <int CTRL>
+__device__ __forceinline__ float row_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ float row_shifted(float v) {      // out-of-row lanes keep their own value
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ double row_add_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return v + __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ uint32_t row_add_u32(uint32_t v) {
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
 // bin + scan + scatter in ONE kernel, one block per slab frame (membranes of up to kLocalBuildMax atoms: the slab then has
 // enough frames to fill the chip with one block each).  The cell counts live in LDS (no global atomics, no memsets,
-// no cell_of round trip): pass 1 counts, an in-block scan turns the counts into the starts (kept in LDS and written to
+// no cell_of round trip): pass 1 counts — the counting atomic's return value is the atom's place inside its cell, which
+// the thread keeps (a byte per atom) —, an in-block scan turns the counts into the starts (kept in LDS and written to
 // cell_count for the kernels that follow), pass 2 recomputes an atom's cell — the same arithmetic on the same
-// coordinates, now an L2 hit — takes its rank from a second LDS counter and writes the record.
+// coordinates, now an L2 hit — and writes the record at start + place.  LDS atomics are served one LANE per cycle on
+// this hardware (PMC: the LDS busy 56 % of a version with five atomics per atom, 64 cycles per instruction), so their
+// number is what the kernel costs: one per atom and one per halo copy here.  A cell with more than 255 atoms (a place
+// that does not fit its byte) makes pass 2 take the places from a second LDS counter instead.
 // dynamic LDS: 2 x kLocalMaxCells1D^2 words.
 constexpr uint32_t kLocalBuildMax = 65536;
 constexpr uint32_t kLocalBuildLds = 2u * kLocalMaxCells1D * kLocalMaxCells1D * (uint32_t)sizeof(uint32_t);
+constexpr uint32_t kLocalBuildTrips = kLocalBuildMax / (8u * 1024u);       // trips of eight atoms a thread makes at most
 __global__ __launch_bounds__(1024) void k_local_build(LocalArgs a) {
     extern __shared__ uint32_t l_build[];
     __shared__ uint32_t l_wave[16];
+    __shared__ uint32_t l_over;
     uint32_t *l_start = l_build, *l_fill = l_build + kLocalMaxCells1D * kLocalMaxCells1D;
     const uint32_t s = blockIdx.x, tid = threadIdx.x;
     const uint32_t f = a.aframes ? a.aframes[s] : a.frame0 + s;
@@ -695,23 +766,34 @@ __global__ __launch_bounds__(1024) void k_local_build(LocalArgs a) {
     uint32_t nca, ncb, ka, kb;
     int da, db;
     local_grid(a, box, nca, ncb, da, db, ka, kb);
-    const uint32_t ncell = nca * ncb;
+    const uint32_t ncs = local_row_stride(a, ncb, kb), ncell = nca * ncs;
+    const uint32_t n_halo = a.halo ? 2u * kb : 0u;     // columns of a row that appear again behind its last cell
     const int dn = (int)a.dim;
     for (uint32_t k = tid; k < ncell; k += 1024u) { l_start[k] = 0; l_fill[k] = 0; }
+    if (tid == 0) l_over = 0;
     __syncthreads();
     const float *x = a.xyz + (size_t)f * a.n_atoms * 3u;
     int bad = 0;
+    bool in_halo = false;
     auto cell_ab = [&](float xa, float xb) -> uint32_t {
+        in_halo = false;
         if (!a.pbc) return 0u;
         const float wa = gm_wrap(xa, box[da], bad), wb = gm_wrap(xb, box[db], bad);
         const uint32_t ca = (uint32_t)fminf(fmaxf(floorf(wa / box[da] * (float)nca), 0.0f), (float)(nca - 1u));
         const uint32_t cb = (uint32_t)fminf(fmaxf(floorf(wb / box[db] * (float)ncb), 0.0f), (float)(ncb - 1u));
-        return ca * ncb + cb;
+        in_halo = cb < n_halo;
+        return ca * ncs + cb;
     };
     // eight atoms per trip: the index and coordinate loads of all of them go out before the first is used (a thread walks
     // ~36 atoms; one dependent load pair per atom would leave the 16 waves of the block waiting most of the time)
     constexpr uint32_t U = 8;
-    for (uint32_t i0 = tid; i0 < a.n_membrane; i0 += U * 1024u) {
+    uint32_t place[kLocalBuildTrips][2], place2[kLocalBuildTrips][2];       // a byte per atom: its place in its cell / in the halo cell
+    bool over = false;
+#pragma unroll
+    for (uint32_t trip = 0; trip < kLocalBuildTrips; trip++) {
+        const uint32_t i0 = tid + trip * U * 1024u;
+        place[trip][0] = place[trip][1] = place2[trip][0] = place2[trip][1] = 0u;
+        if (trip * U * 1024u >= a.n_membrane) continue;                     // (uniform)
         uint32_t at[U];
         float pa[U], pb[U];
 #pragma unroll
@@ -720,9 +802,21 @@ __global__ __launch_bounds__(1024) void k_local_build(LocalArgs a) {
         for (uint32_t u = 0; u < U; u++) { pa[u] = x[3u * (size_t)at[u] + da]; pb[u] = x[3u * (size_t)at[u] + db]; }
 #pragma unroll
         for (uint32_t u = 0; u < U; u++)
-            if (i0 + u * 1024u < a.n_membrane) atomicAdd(&l_start[cell_ab(pa[u], pb[u])], 1u);
+            if (i0 + u * 1024u < a.n_membrane) {
+                const uint32_t c = cell_ab(pa[u], pb[u]);
+                const uint32_t r = atomicAdd(&l_start[c], 1u);
+                over |= r > 255u;
+                place[trip][u >> 2] |= (r & 255u) << (8u * (u & 3u));
+                if (in_halo) {
+                    const uint32_t r2 = atomicAdd(&l_start[c + ncb], 1u);
+                    over |= r2 > 255u;
+                    place2[trip][u >> 2] |= (r2 & 255u) << (8u * (u & 3u));
+                }
+            }
     }
+    if (over) l_over = 1u;
     __syncthreads();
+    const bool use_fill = l_over != 0u;                 // (uniform) some cell holds more atoms than a byte counts
     // exclusive scan: 16 consecutive cells per thread, wave scan of the thread sums, then the waves' totals
     {
         constexpr uint32_t PER = kLocalMaxCells1D * kLocalMaxCells1D / 1024u;
@@ -753,11 +847,14 @@ __global__ __launch_bounds__(1024) void k_local_build(LocalArgs a) {
             run += cnt[k];
         }
     }
-    if (tid == 0 && a.grid) a.grid[s] = make_uint4(nca, ncb, ka, kb);
+    if (tid == 0 && a.grid) { a.grid[s] = make_uint4(nca, ncb, ka, kb); local_finfo_init(a, s); }
     __syncthreads();
-    float4 *rec = reinterpret_cast<float4 *>(a.trig) + (size_t)s * a.n_membrane;
-    float *rsn = a.rsn + (size_t)s * a.n_membrane;
-    for (uint32_t i0 = tid; i0 < a.n_membrane; i0 += U * 1024u) {
+    float4 *rec = reinterpret_cast<float4 *>(a.trig) + (size_t)s * a.rec_stride;
+    float *rsn = a.rsn + (size_t)s * a.rec_stride;
+#pragma unroll
+    for (uint32_t trip = 0; trip < kLocalBuildTrips; trip++) {
+        const uint32_t i0 = tid + trip * U * 1024u;
+        if (trip * U * 1024u >= a.n_membrane) continue;                     // (uniform)
         uint32_t at[U];
         float pa[U], pb[U], pn[U];
 #pragma unroll
@@ -770,63 +867,129 @@ __global__ __launch_bounds__(1024) void k_local_build(LocalArgs a) {
         for (uint32_t u = 0; u < U; u++) {
             if (i0 + u * 1024u >= a.n_membrane) continue;
             const uint32_t c = cell_ab(pa[u], pb[u]);
-            const uint32_t q = l_start[c] + atomicAdd(&l_fill[c], 1u);
+            const uint32_t q = l_start[c] + (use_fill ? atomicAdd(&l_fill[c], 1u) : (place[trip][u >> 2] >> (8u * (u & 3u))) & 255u);
             float sn = 0.0f, cs = 0.0f;
             if (a.pbc) fast_sincos_rev(gm_wrap(pn[u], box[dn], bad) / box[dn], &sn, &cs);
             rec[q] = make_float4(pa[u], pb[u], pn[u], cs);
             rsn[q] = sn;
+            if (in_halo) {
+                const uint32_t q2 = l_start[c + ncb] + (use_fill ? atomicAdd(&l_fill[c + ncb], 1u) : (place2[trip][u >> 2] >> (8u * (u & 3u))) & 255u);
+                rec[q2] = make_float4(pa[u], pb[u], pn[u], cs);
+                rsn[q2] = sn;
+            }
         }
     }
     if (bad) raise_box_range(a.err, f);
 }
 
-// Per cell: what the members' sums need from a cell ALL of whose atoms are members (k_local_flags takes such a cell
-// as a whole instead of atom by atom): agg[2c] = (sum cos, sum sin, sum z, count), agg[2c + 1] = (z min, z max, -, -).
-// A non-finite coordinate poisons the z sum (NaN) and so, as before, the centre of every head that includes the cell.
-// A quarter wave per cell: its 16 lanes read the cell's records as contiguous 256-byte pieces and fold them with DPP
-// row shifts (a row IS 16 lanes), in a fixed order.  Launched with a fixed number of blocks per frame (the grid of a
-// frame is only known on the device), each taking every gridDim.x-th group of 16 cells.
-template <int CTRL>
-__device__ __forceinline__ float row_add(float v) {
-    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-template <int CTRL>
-__device__ __forceinline__ float row_shifted(float v) {      // out-of-row lanes keep their own value
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false));
-}
-__global__ __launch_bounds__(256) void k_local_cellsums(LocalArgs a) {
-    const uint32_t s = blockIdx.y, sub = threadIdx.x & 15u;
+// Per row of cells: running sums along the row (the halo cells continue it), so that k_local_flags_rows takes the
+// cells of a row that lie wholly inside a head's cylinder — always one span of consecutive cells — as the difference
+// of two entries:  rowpre[ra (ncs + 1) + j] = sums over the cells 0 .. j-1 of row ra (cos and sin of the normal angle
+// in f32: they only make the estimate that anchors the image choice; the normal coordinate itself in f64).
+// (k_local_rowprefix, below: a scan over the row's RECORDS, read off at the cells' first records.)  The same pass makes the frame's record for the rows kernel: finfo[s] = (min, max of the normal
+// coordinate over the membrane, whether a coordinate of a record is not finite), kept as ordered integers.
+// block = 256 threads = 4 waves = 4 rows of cells, a wave per row; grid = (ceil(kLocalMaxCells1D / 4), n_slab).
+// The wave streams its row's records (contiguous: the row's cells one after the other, halo copies included) 512 at a
+// time with coalesced loads — all eight loads of a piece in flight together —, scans them (inclusive scan over the 64
+// lanes by row shifts + the totals of the 16-lane rows before, carried from load to load), parks the exclusive sums in
+// LDS, and then gives every cell of the row the sum parked at its first record.  (A lane per CELL summing its own
+// handful of records took 140 us per 256 frames: 64 short gathers per load instruction.)
+constexpr uint32_t kRowPrefixPiece = 512;
+__global__ __launch_bounds__(256) void k_local_rowprefix(LocalArgs a) {
+    __shared__ float l_c[4][kRowPrefixPiece + 1], l_s[4][kRowPrefixPiece + 1];
+    __shared__ double l_z[4][kRowPrefixPiece + 1];
+    const uint32_t s = blockIdx.y, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, ra = blockIdx.x * 4u + wave;
     const uint4 g = a.grid[s];
-    const uint32_t ncell = g.x * g.y;
+    const uint32_t nca = g.x, ncs = local_row_stride(a, g.y, g.w);
+    if (blockIdx.x == 0 && s == 0 && threadIdx.x == 0) a.todo[0] = make_uint2(0u, 0u);        // this slab's list starts empty
+    if (ra >= nca) return;                                                                       // (uniform per wave; no workgroup barrier below)
     const uint32_t *cstart = a.cell_count + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u);
-    const float4 *rec = reinterpret_cast<const float4 *>(a.trig) + (size_t)s * a.n_membrane;
-    const float *rsn = a.rsn + (size_t)s * a.n_membrane;
-    float4 *out = a.agg + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D) * 2u;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.todo[0] = make_uint2(0u, 0u);   // this slab's list starts empty
-    for (uint32_t c = blockIdx.x * 16u + (threadIdx.x >> 4); c < ncell; c += gridDim.x * 16u) {
-        const uint32_t q0 = cstart[c], q1 = cstart[c + 1u];
-        float sc = 0.0f, ss = 0.0f, sz = 0.0f, zlo = 3.0e38f, zhi = -3.0e38f;
-        for (uint32_t q = q0 + sub; q < q1; q += 16u) {
-            const float4 r = rec[q];
-            sc += r.w;
-            ss += rsn[q];
-            sz += r.z;
-            zlo = fminf(zlo, r.z);
-            zhi = fmaxf(zhi, r.z);
+    const float4 *rec = reinterpret_cast<const float4 *>(a.trig) + (size_t)s * a.rec_stride;
+    const float *rsn = a.rsn + (size_t)s * a.rec_stride;
+    LocalRowPre *out = a.rowpre + (size_t)s * (kLocalMaxCells1D * (kLocalMaxCells1D + 1u)) + (size_t)ra * (ncs + 1u);
+    const uint32_t qa = cstart[ra * ncs], qb = cstart[(ra + 1u) * ncs];
+    float zlo = 3.0e38f, zhi = -3.0e38f;
+    uint32_t nf = 0;
+    float carry_c = 0.0f, carry_s = 0.0f;
+    double carry_z = 0.0;
+    float *pc = l_c[wave], *ps = l_s[wave];
+    double *pz = l_z[wave];
+    for (uint32_t base = qa; base < qb || base == qa; base += kRowPrefixPiece) {
+        const uint32_t n_here = min(kRowPrefixPiece, qb - base);
+        float4 r[8];
+        float sn[8];
+#pragma unroll
+        for (uint32_t t = 0; t < 8u; t++) {
+            const uint32_t q = base + 64u * t + lane;
+            const uint32_t qc = q < qb ? q : (qb ? qb - 1u : 0u);
+            r[t] = rec[qc];
+            sn[t] = rsn[qc];
         }
-        // Hillis-Steele over the row: lane 15 ends with the row's total / extrema
-        sc = row_add<0x111>(sc); ss = row_add<0x111>(ss); sz = row_add<0x111>(sz);
-        zlo = fminf(zlo, row_shifted<0x111>(zlo)); zhi = fmaxf(zhi, row_shifted<0x111>(zhi));
-        sc = row_add<0x112>(sc); ss = row_add<0x112>(ss); sz = row_add<0x112>(sz);
-        zlo = fminf(zlo, row_shifted<0x112>(zlo)); zhi = fmaxf(zhi, row_shifted<0x112>(zhi));
-        sc = row_add<0x114>(sc); ss = row_add<0x114>(ss); sz = row_add<0x114>(sz);
-        zlo = fminf(zlo, row_shifted<0x114>(zlo)); zhi = fmaxf(zhi, row_shifted<0x114>(zhi));
-        sc = row_add<0x118>(sc); ss = row_add<0x118>(ss); sz = row_add<0x118>(sz);
-        zlo = fminf(zlo, row_shifted<0x118>(zlo)); zhi = fmaxf(zhi, row_shifted<0x118>(zhi));
-        if (sub == 15u) {
-            out[2u * c] = make_float4(sc, ss, sz, (float)(q1 - q0));
-            out[2u * c + 1u] = make_float4(zlo, zhi, 0.0f, 0.0f);
+#pragma unroll
+        for (uint32_t t = 0; t < 8u; t++) {
+            if (64u * t >= n_here) break;                                   // (uniform)
+            const bool valid = base + 64u * t + lane < qb;
+            const float vc = valid ? r[t].w : 0.0f, vs = valid ? sn[t] : 0.0f;
+            const double vz = valid ? (double)r[t].z : 0.0;
+            if (valid) {
+                zlo = fminf(zlo, r[t].z);
+                zhi = fmaxf(zhi, r[t].z);
+                nf |= ((r[t].x - r[t].x) + (r[t].y - r[t].y)) + (r[t].z - r[t].z) == 0.0f ? 0u : 1u;
+            }
+            float ic = vc, is = vs;
+            double iz = vz;
+            ic = row_add<0x111>(ic); is = row_add<0x111>(is); iz = row_add_f64<0x111>(iz);
+            ic = row_add<0x112>(ic); is = row_add<0x112>(is); iz = row_add_f64<0x112>(iz);
+            ic = row_add<0x114>(ic); is = row_add<0x114>(is); iz = row_add_f64<0x114>(iz);
+            ic = row_add<0x118>(ic); is = row_add<0x118>(is); iz = row_add_f64<0x118>(iz);
+            float bc = 0.0f, bs = 0.0f;
+            double bz = 0.0;
+#pragma unroll
+            for (int r4 = 0; r4 < 3; r4++) {
+                const float tc = __shfl(ic, 16 * r4 + 15, 64), ts = __shfl(is, 16 * r4 + 15, 64);
+                const double tz = __shfl(iz, 16 * r4 + 15, 64);
+                if ((int)(lane >> 4) > r4) { bc += tc; bs += ts; bz += tz; }
+            }
+            ic += bc; is += bs; iz += bz;                                   // inclusive over the 64 lanes
+            pc[64u * t + lane] = carry_c + (ic - vc);                       // records of the row before this one
+            ps[64u * t + lane] = carry_s + (is - vs);
+            pz[64u * t + lane] = carry_z + (iz - vz);
+            carry_c += __shfl(ic, 63, 64);
+            carry_s += __shfl(is, 63, 64);
+            carry_z += __shfl(iz, 63, 64);
         }
+        if (lane == 0u) { pc[n_here] = carry_c; ps[n_here] = carry_s; pz[n_here] = carry_z; }   // behind the piece's last record
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // the cells whose first record lies in this piece (a cell that starts where the piece ends belongs to the next
+        // piece — or, behind the row's last record, to this one)
+        const bool last = base + n_here >= qb;
+        for (uint32_t j = lane; j <= ncs; j += 64u) {
+            const uint32_t q0 = j < ncs ? cstart[ra * ncs + j] : qb;
+            if (q0 >= base && (q0 < base + n_here || (last && q0 == qb))) {
+                LocalRowPre o;
+                o.sc = pc[q0 - base]; o.ss = ps[q0 - base]; o.sz = pz[q0 - base];
+                out[j] = o;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (qb == qa) break;                                                // (an empty row: one trip for its cells)
+    }
+    // the frame's extrema of the normal coordinate and its "a coordinate is not finite" flag
+    for (int off = 32; off >= 1; off >>= 1) {
+        zlo = fminf(zlo, __shfl_xor(zlo, off, 64));
+        zhi = fmaxf(zhi, __shfl_xor(zhi, off, 64));
+        nf |= (uint32_t)__shfl_xor((int)nf, off, 64);
+    }
+    if (lane == 0u) {
+        uint32_t *fi = reinterpret_cast<uint32_t *>(a.finfo + s);
+        if (zlo <= zhi) {
+            atomicMin(fi, local_float_key(zlo));
+            atomicMax(fi + 1, local_float_key(zhi));
+        }
+        if (nf) atomicOr(fi + 2, 1u);
     }
 }
 
@@ -936,8 +1099,9 @@ __device__ __noinline__ void local_flags_head(const LocalArgs &a, uint32_t s, ui
         hb = (uint32_t)fminf(fmaxf(floorf(wb / box[db] * (float)ncb), 0.0f), (float)(ncb - 1u));
     }
     const uint32_t *cstart = a.cell_count + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u);
-    const float4 *rec = reinterpret_cast<const float4 *>(a.trig) + (size_t)s * a.n_membrane;
-    const float *rsn = a.rsn + (size_t)s * a.n_membrane;
+    const float4 *rec = reinterpret_cast<const float4 *>(a.trig) + (size_t)s * a.rec_stride;
+    const float *rsn = a.rsn + (size_t)s * a.rec_stride;
+    const uint32_t ncs = local_row_stride(a, ncb, kb);      // cells between two rows of the grid
     const float La = box[da], Lb = box[db], Ln = box[dn];
     const float thr = a.radius_thr;
     // rows (ha - ka .. ha + ka) mod nca; in a row the cells (hb - kb .. hb + kb) mod ncb = runs [b0, b1) and [0, b2)
@@ -946,7 +1110,8 @@ __device__ __noinline__ void local_flags_head(const LocalArgs &a, uint32_t s, ui
     uint32_t a0 = ha + nca - ka, b0 = hb + ncb - kb;
     a0 -= a0 >= nca ? nca : 0u;
     b0 -= b0 >= ncb ? ncb : 0u;
-    const uint32_t b1 = min(b0 + n_cols, ncb), b2 = b0 + n_cols - b1;
+    // (with the halo the cells b0 .. b0 + n_cols - 1 of a row are there as such: one run, never a second one)
+    const uint32_t b1 = a.halo ? b0 + n_cols : min(b0 + n_cols, ncb), b2 = b0 + n_cols - b1;
     const bool pbc = a.pbc != 0;
     auto inside = [&](float ra, float rb) {
         float ea = ra - ha_pos, eb = rb - hb_pos;
@@ -975,7 +1140,7 @@ __device__ __noinline__ void local_flags_head(const LocalArgs &a, uint32_t s, ui
     if (!done && lane < n_runs) {       // (the run table serves the general passes only)
         uint32_t ra = a0 + (lane >> 1);
         ra -= ra >= nca ? nca : 0u;
-        const uint32_t row = ra * ncb;
+        const uint32_t row = ra * ncs;
         rq0 = (lane & 1u) ? cstart[row] : cstart[row + b0];
         rq1 = (lane & 1u) ? cstart[row + b2] : cstart[row + b1];
     }
@@ -1078,7 +1243,7 @@ __device__ __noinline__ void local_flags_head(const LocalArgs &a, uint32_t s, ui
         }
     } else {
         for (uint32_t ia = 0; ia < n_rows; ia++) {
-            const uint32_t row = ((a0 + ia) % nca) * ncb;
+            const uint32_t row = ((a0 + ia) % nca) * ncs;
             for (uint32_t part = 0; part < 2u; part++) {
                 const uint32_t q0 = part == 0 ? cstart[row + b0] : cstart[row];
                 const uint32_t q1 = part == 0 ? cstart[row + b1] : cstart[row + b2];
@@ -1106,7 +1271,7 @@ __device__ __noinline__ void local_flags_head(const LocalArgs &a, uint32_t s, ui
         float ref = 0.0f;
         if (!one_pass) {       // rare: membership is simply tested again, run by run
             for (uint32_t ia = 0; ia < n_rows; ia++) {
-                const uint32_t row = ((a0 + ia) % nca) * ncb;
+                const uint32_t row = ((a0 + ia) % nca) * ncs;
                 for (uint32_t part = 0; part < 2u; part++) {
                     const uint32_t q0 = part == 0 ? cstart[row + b0] : cstart[row];
                     const uint32_t q1 = part == 0 ? cstart[row + b1] : cstart[row + b2];
@@ -1141,62 +1306,78 @@ __global__ __launch_bounds__(256) void k_local_flags(LocalArgs a) {
     local_flags_head(a, blockIdx.y, m);
 }
 
-// ---- cells instead of atoms where a whole cell lies inside the cylinder; a head per ROW of 16 lanes ----------------
-// A head's (2ka+1) x (2kb+1) cells are classified against the cylinder with the head's true position inside its cell:
-// a cell whose farthest corner is closer than the radius holds members only — its precomputed sums (k_local_cellsums)
-// are added as a block; a cell whose nearest point is farther holds none; only the ring of cells the circle crosses is
-// looked at atom by atom, in pieces of <= 16 records.  Membership itself stays the exact distance test; the margins
-// only decide who is tested.  Every periodic image of a neighbourhood cell other than the direct one lies beyond the
-// radius (at least k cells of >= 1.0001 r / k away, local_axis), so the direct displacement is the minimum image here —
-// unless a coordinate sits outside the box, which the flag `redo` catches.
-// FOUR heads per wave, one per DPP row: a piece of the ring is as long as a row, the 81 cells of a head take 6 rounds of
-// 16 lanes (84 % of the lanes busy; 63 % in two rounds of 64), and everything that is per head — the head's cell, the
-// sums over the lanes (row shifts only), the centre, atan2f — is paid once per four heads.  A head the cells cannot
-// decide (thick membrane, coordinates outside the box, an overfull cell or list) is handed, wave by wave, to the
-// general passes (local_flags_head).
-// block = 256 threads = 4 waves = 16 heads; grid = (ceil(n_mol / 16), n_slab).  Periodic boxes only.
-constexpr uint32_t kRowRing = 96;              // ring pieces a head may list (typically ~48)
-template <int CTRL>
-__device__ __forceinline__ double row_add_f64(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
-    return v + __hiloint2double(hi, lo);
+// ---- a head per ROW of 16 lanes; the cells wholly inside the cylinder as spans of row prefix sums ------------------------
+// The cells around a head (radius / 7 wide, 15 x 15 of them) are classified against the cylinder with the head's true
+// position inside its cell, a ROW OF CELLS PER LANE: along a row the cells whose farthest corner is closer than the
+// radius form one span of consecutive cells — taken as a block, the difference of two entries of k_local_rowprefix's
+// running sums —, the cells the circle crosses form at most one run on each side of that span (one run altogether
+// where the row has no inner cell), and the rest is outside.  Only the atoms of those ring runs are tested one by
+// one: runs are contiguous in the record array (the halo keeps them so across the periodic boundary), cut into pieces
+// of <= 8 records, two pieces per row and iteration.  Membership itself stays the exact distance test; the margins
+// (4e-4 of r^2 either way) only decide who is tested.  Every periodic image of a neighbourhood cell other than the direct
+// one lies beyond the radius (at least k cells of >= 1.0001 r / k away, local_axis), so the direct displacement is the
+// minimum image here — unless a coordinate sits outside the box, which the flag `redo` catches.
+// The block sum of u = MI(z - z_head) over an inner span is  sum z - n z_head  when no atom of the FRAME needs a shift
+// relative to this head (finfo: the membrane's extrema of the normal coordinate; a membrane thicker than half the box,
+// or a frame with a non-finite coordinate, sends the head to the general passes).
+// FOUR heads per wave, one per DPP row: everything that is per head — the head's cell, the sums over the lanes (row
+// shifts only), the centre, atan2f — is paid once per four heads.  A head the rows cannot decide is put on the list of
+// k_local_flags_todo.
+// block = 256 threads = 4 waves = 16 heads; grid = ceil(n_mol / 16) * (n_slab rounded up to 8), one dimension (see the
+// XCD mapping below).  Periodic boxes, halo layout.
+// atan2 to ~1e-5 rad (minimax polynomial of atan on [0, 1], hardware reciprocal); (0, 0) -> 0
+__device__ __forceinline__ float local_atan2_fast(float y, float x) {
+    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+    const float hi = fmaxf(ax, ay), lo = fminf(ax, ay);
+    const float t = hi > 0.0f ? lo * __builtin_amdgcn_rcpf(hi) : 0.0f, s = t * t;
+    float r = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(__builtin_fmaf(0.0208351f, s, -0.0851330f), s, 0.1801410f), s, -0.3302995f), s, 0.9998660f) * t;
+    r = ay > ax ? 1.5707964f - r : r;
+    r = x < 0.0f ? 3.1415927f - r : r;
+    return y < 0.0f ? -r : r;
 }
-template <int CTRL>
-__device__ __forceinline__ uint32_t row_add_u32(uint32_t v) {
-    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
-}
+constexpr uint32_t kRowRing = 96;              // ring pieces (<= 8 records each) a head may list (typically ~45)
 __global__ __launch_bounds__(256) void k_local_flags_rows(LocalArgs a) {
     __shared__ uint2 l_ring[16][kRowRing];
     const uint32_t lane = threadIdx.x & 63u, row = lane >> 4, sub = lane & 15u;
     const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t s = blockIdx.y;
-    const uint32_t m_raw = (blockIdx.x * 4u + wave) * 4u + row;
-    if ((blockIdx.x * 4u + wave) * 4u >= a.n_mol_total) return;           // the whole wave is past the last head
+    // Workgroups go to the 8 XCDs round-robin in launch order, and every XCD has an L2 of its own: the heads of ONE frame
+    // share that frame's records (a head reads ~330 ring records, neighbouring heads mostly the same ones), so all the
+    // workgroups of a frame are given to one XCD — launch index L -> XCD L mod 8 takes frames (L / 8) / groups * 8 + L mod 8 —
+    // and a frame's records come from HBM once instead of once per XCD (measured: 2.1 GB -> see DESIGN, K6).
+    const uint32_t n_groups = a.rows_groups, linear = blockIdx.x;
+    const uint32_t xcd = linear & 7u, k = linear >> 3;
+    const uint32_t s = (k / n_groups) * 8u + xcd, bx = k - (k / n_groups) * n_groups;
+    if (s >= a.n_slab) return;                                              // (the slab's frame count rounded up to 8)
+    const uint32_t m_raw = (bx * 4u + wave) * 4u + row;
+    if ((bx * 4u + wave) * 4u >= a.n_mol_total) return;                   // the whole wave is past the last head
     const bool head_ok = m_raw < a.n_mol_total;
     const uint32_t m = head_ok ? m_raw : a.n_mol_total - 1u;              // idle rows shadow the last head, write nothing
     const uint32_t f = a.aframes ? a.aframes[s] : a.frame0 + s;
     float box[3];
     frame_box(a, f, box);
     const uint4 g = a.grid[s];
-    const uint32_t nca = g.x, ncb = g.y, ka = g.z, kb = g.w;
+    const uint4 fk = reinterpret_cast<const uint4 *>(a.finfo)[s];
+    const float z_min = local_key_float(fk.x), z_max = local_key_float(fk.y);
+    const uint32_t nca = g.x, ncb = g.y, ka = g.z, kb = g.w, ncs = ncb + 2u * kb;
     const int da = (int)((a.dim + 1u) % 3u), db = (int)((a.dim + 2u) % 3u), dn = (int)a.dim;
     const float La = box[da], Lb = box[db], Ln = box[dn];
     const float halfa = La / 2.0f, halfb = Lb / 2.0f, halfn = Ln / 2.0f;
     const float thr = a.radius_thr;
-    const uint32_t n_rows = 2u * ka + 1u, n_cols = 2u * kb + 1u, n_cells = n_rows * n_cols;
+    const uint32_t n_rows = 2u * ka + 1u;
     const uint32_t *cstart = a.cell_count + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u);
-    const float4 *rec = reinterpret_cast<const float4 *>(a.trig) + (size_t)s * a.n_membrane;
-    const float *rsn = a.rsn + (size_t)s * a.n_membrane;
-    const float4 *agg = a.agg + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D) * 2u;
-    bool fail = !(ka >= 1u && kb >= 1u && n_cells <= 128u);               // (uniform) grids the cells do not handle
+    const float4 *rec = reinterpret_cast<const float4 *>(a.trig) + (size_t)s * a.rec_stride;
+    const float *rsn = a.rsn + (size_t)s * a.rec_stride;
+    const LocalRowPre *pre = a.rowpre + (size_t)s * (kLocalMaxCells1D * (kLocalMaxCells1D + 1u));
+    // (uniform) grids the rows do not handle, frames with a non-finite coordinate
+    const bool fail = !(ka >= 1u && kb >= 1u && n_rows <= 16u && fk.z == 0u && fk.x <= fk.y);
 
     // ---- the head of this row
     const float *hp = a.xyz + ((size_t)f * a.n_atoms + a.heads[m]) * 3u;
     const float ha_pos = hp[da], hb_pos = hp[db], hn_pos = hp[dn];
     int bad = 0;
-    const float wa = gm_wrap(ha_pos, La, bad), wb = gm_wrap(hb_pos, Lb, bad);
+    // gm_wrap's first step as selects (a head more than a box length outside leaves [0, L]: the general passes)
+    const float wa = ha_pos < 0.0f ? ha_pos + La : (ha_pos > La ? ha_pos - La : ha_pos);
+    const float wb = hb_pos < 0.0f ? hb_pos + Lb : (hb_pos > Lb ? hb_pos - Lb : hb_pos);
     const float ca = La / (float)nca, cb = Lb / (float)ncb;                // cell edges
     const uint32_t ha = (uint32_t)fminf(fmaxf(floorf(wa / La * (float)nca), 0.0f), (float)(nca - 1u));
     const uint32_t hb = (uint32_t)fminf(fmaxf(floorf(wb / Lb * (float)ncb), 0.0f), (float)(ncb - 1u));
@@ -1204,120 +1385,115 @@ __global__ __launch_bounds__(256) void k_local_flags_rows(LocalArgs a) {
     uint32_t a0 = ha + nca - ka, b0 = hb + ncb - kb;
     a0 -= a0 >= nca ? nca : 0u;
     b0 -= b0 >= ncb ? ncb : 0u;
-    // a head outside the box by more than rounding, or not where its cell says: the general passes decide
-    bool redo = !(fa >= -1e-4f * ca && fa <= ca * 1.0001f && fb >= -1e-4f * cb && fb <= cb * 1.0001f);
+    // a head outside the box by more than rounding, or not where its cell says: the general passes decide;
+    // so they do when a member of the frame could need a shift along the normal relative to this head
+    const float ulo_g = z_min - hn_pos, uhi_g = z_max - hn_pos;
+    bool redo = !(fa >= -1e-4f * ca && fa <= ca * 1.0001f && fb >= -1e-4f * cb && fb <= cb * 1.0001f) ||
+                !(wa >= 0.0f && wa <= La && wb >= 0.0f && wb <= Lb) || !(ulo_g >= -halfn && uhi_g <= halfn);
 
-    // ---- the cells, 16 per round and row
-    float sc = 0.0f, ss = 0.0f, su = 0.0f, ulo = 3.0e38f, uhi = -3.0e38f;
-    uint32_t cnt = 0, nf = 0, n_ring = 0;
-    const float r_in = thr * (1.0f - 4e-4f), r_out = thr * (1.0f + 4e-4f);
-    const uint32_t inv_cols = n_cols == 9u ? 7282u : (65536u + n_cols - 1u) / n_cols;
+    // ---- this lane's row of cells: the inner span and the ring runs on either side
+    float sc = 0.0f, ss = 0.0f, su = 0.0f;
+    uint32_t cnt = 0, n_ring = 0;
     uint2 *ring = l_ring[wave * 4u + row];
-    // two rounds of 16 cells per trip to memory: the loads of both (sums of inner cells, runs of the others) go out
-    // before the first use — with four heads per wave there are few waves, and a wave that waits for one round at a
-    // time leaves the SIMD idle
-    struct CellRound {
-        float4 g0, g1;
-        uint32_t q0, q1;
-        bool inner, ring_cell;
-    };
-    auto classify = [&](uint32_t c0, CellRound &cr) {
-        const uint32_t ci = c0 + sub;
-        const bool valid = ci < n_cells;
-        // ci / n_cols for ci < 128, n_cols <= 128 by one multiplication: floor(ci * ceil(2^16 / n) / 2^16) is exact there
-        const uint32_t ia = valid ? (ci * inv_cols) >> 16 : 0u, ib = valid ? ci - ia * n_cols : 0u;
-        const float a_lo = ((float)ia - (float)ka) * ca - fa, a_hi = a_lo + ca;      // the cell's rectangle relative to the head
-        const float b_lo = ((float)ib - (float)kb) * cb - fb, b_hi = b_lo + cb;
-        const float fa_far = fmaxf(fabsf(a_lo), fabsf(a_hi)), fb_far = fmaxf(fabsf(b_lo), fabsf(b_hi));
-        const float fa_near = (a_lo <= 0.0f && a_hi >= 0.0f) ? 0.0f : fminf(fabsf(a_lo), fabsf(a_hi));
-        const float fb_near = (b_lo <= 0.0f && b_hi >= 0.0f) ? 0.0f : fminf(fabsf(b_lo), fabsf(b_hi));
-        cr.inner = valid && (fa_far * fa_far + fb_far * fb_far < r_in);
-        const bool outer = !valid || (fa_near * fa_near + fb_near * fb_near > r_out);
-        uint32_t ra = a0 + ia, rb = b0 + ib;
-        ra -= ra >= nca ? nca : 0u;
-        rb -= rb >= ncb ? ncb : 0u;
-        const uint32_t cell = ra * ncb + rb;
-        cr.ring_cell = !cr.inner && !outer;
-        cr.g0 = cr.inner ? agg[2u * cell] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        cr.g1 = cr.inner ? agg[2u * cell + 1u] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        cr.q0 = outer ? 0u : cstart[cell];
-        cr.q1 = outer ? 0u : cstart[cell + 1u];
-    };
-    auto absorb = [&](CellRound &cr) {
-        if (cr.inner && cr.g0.w > 0.0f) {
-            // the block sum of u = MI(z - z_head) is sum z - n z_head when no atom of the cell needs a shift
-            if (!(cr.g1.x - hn_pos >= -halfn && cr.g1.y - hn_pos <= halfn && cr.g0.z - cr.g0.z == 0.0f)) {
-                cr.ring_cell = true;                               // atom by atom instead (also carries a NaN on)
-            } else {
-                cnt += (uint32_t)cr.g0.w;
-                sc += cr.g0.x;
-                ss += cr.g0.y;
-                su += cr.g0.z - cr.g0.w * hn_pos;
-                ulo = fminf(ulo, cr.g1.x - hn_pos);
-                uhi = fmaxf(uhi, cr.g1.y - hn_pos);
+    uint32_t run_q0[2] = {0u, 0u}, run_q1[2] = {0u, 0u};
+    if (!fail && sub < n_rows) {
+        const float r_in = thr * (1.0f - 4e-4f), r_out = thr * (1.0f + 4e-4f);
+        const float a_lo = ((float)sub - (float)ka) * ca - fa, a_hi = a_lo + ca;      // the row's strip relative to the head
+        const float a_far = fmaxf(fabsf(a_lo), fabsf(a_hi));
+        const float a_near = (a_lo <= 0.0f && a_hi >= 0.0f) ? 0.0f : fminf(fabsf(a_lo), fabsf(a_hi));
+        const float w_out2 = r_out - a_near * a_near, w_in2 = r_in - a_far * a_far;
+        if (w_out2 > 0.0f) {
+            // cell j of the row covers b in [(j - kb) cb - fb, (j - kb + 1) cb - fb]; with t = b / cb + kb (cell units
+            // from the first cell's lower edge) cell j is [j, j + 1]
+            // (1-ulp hardware square root and reciprocal: the bounds below carry 1e-3 of a cell of slack, the margins of
+            // r_in / r_out 4e-4 of r^2)
+            const float inv_cb = __builtin_amdgcn_rcpf(cb), t0 = fb * inv_cb + (float)kb;
+            const float w_out = __builtin_amdgcn_sqrtf(w_out2) * inv_cb;
+            // cells the circle may touch: j + 1 > t0 - w_out and j < t0 + w_out (one cell more on either side when the
+            // bound is within rounding of a cell edge)
+            const float jo_lo_f = floorf(t0 - w_out - 1e-3f), jo_hi_f = floorf(t0 + w_out + 1e-3f);
+            const uint32_t jo_lo = (uint32_t)fminf(fmaxf(jo_lo_f, 0.0f), (float)(2u * kb));
+            const uint32_t jo_hi = (uint32_t)fminf(fmaxf(jo_hi_f, 0.0f), (float)(2u * kb));
+            // cells wholly inside: j >= t0 - w_in and j + 1 <= t0 + w_in (one cell less on either side near an edge)
+            uint32_t ji_lo = 1u, ji_hi = 0u;                                          // empty
+            if (w_in2 > 0.0f) {
+                const float w_in = __builtin_amdgcn_sqrtf(w_in2) * inv_cb;
+                const float lo_f = ceilf(t0 - w_in + 1e-3f), hi_f = floorf(t0 + w_in - 1e-3f) - 1.0f;
+                if (hi_f >= lo_f) {
+                    ji_lo = (uint32_t)fmaxf(lo_f, (float)jo_lo);
+                    ji_hi = (uint32_t)fminf(hi_f, (float)jo_hi);
+                }
             }
+            uint32_t ra = a0 + sub;
+            ra -= ra >= nca ? nca : 0u;
+            const uint32_t c0 = ra * ncs + b0;
+            const bool inner = ji_lo <= ji_hi;
+            const uint32_t qa0 = cstart[c0 + jo_lo], qb1 = cstart[c0 + jo_hi + 1u];
+            const uint32_t qa1 = inner ? cstart[c0 + ji_lo] : qb1;
+            const uint32_t qb0 = inner ? cstart[c0 + ji_hi + 1u] : qb1;
+            if (inner) {
+                const LocalRowPre p_lo = pre[ra * (ncs + 1u) + b0 + ji_lo], p_hi = pre[ra * (ncs + 1u) + b0 + ji_hi + 1u];
+                const uint32_t n_in = qb0 - qa1;
+                cnt += n_in;
+                sc += p_hi.sc - p_lo.sc;
+                ss += p_hi.ss - p_lo.ss;
+                su += (float)((p_hi.sz - p_lo.sz) - (double)n_in * (double)hn_pos);
+            }
+            run_q0[0] = qa0; run_q1[0] = qa1;
+            run_q0[1] = qb0; run_q1[1] = qb1;
         }
-        // ring cells go to the row's list in pieces of <= 16 records
-        const uint32_t n_at = cr.ring_cell ? cr.q1 - cr.q0 : 0u;
-        redo |= n_at > 64u;                                    // an overfull cell: the general passes
-#pragma unroll
-        for (uint32_t j = 0; j < 4u; j++) {
-            const bool has = n_at > 16u * j;
-            const uint64_t mask = __ballot(has);
-            if (!mask) break;                                  // (wave-uniform) no cell of any row has a j-th piece
-            const uint32_t mine = (uint32_t)(mask >> (16u * row)) & 0xffffu;          // this row's lanes
-            const uint32_t pos = n_ring + (uint32_t)__popc(mine & ((1u << sub) - 1u));
-            if (has && pos < kRowRing) ring[pos] = make_uint2(cr.q0 + 16u * j, min(cr.q1, cr.q0 + 16u * j + 16u));
-            n_ring += (uint32_t)__popc(mine);
-        }
-    };
-    for (uint32_t c0 = 0; !fail && c0 < n_cells; c0 += 32u) {
-        CellRound ra_, rb_;
-        classify(c0, ra_);
-        classify(c0 + 16u, rb_);           // (past the last cell: every lane invalid -> outer, nothing loaded)
-        absorb(ra_);
-        absorb(rb_);
+    }
+    // ---- the ring runs go to the row's list in pieces of <= 8 records: every lane's share of the list starts where
+    // the lanes before it in the row end (exclusive scan of the piece counts by row shifts)
+    {
+        const uint32_t n_a = run_q1[0] - run_q0[0], n_b = run_q1[1] - run_q0[1];
+        const uint32_t p_a = (n_a + 7u) >> 3, p_b = (n_b + 7u) >> 3, mine = p_a + p_b;
+        uint32_t incl = mine;
+        incl = row_add_u32<0x111>(incl); incl = row_add_u32<0x112>(incl); incl = row_add_u32<0x114>(incl); incl = row_add_u32<0x118>(incl);
+        const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 15), t1 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31);
+        const uint32_t t2 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 47), t3 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        n_ring = row == 0u ? t0 : (row == 1u ? t1 : (row == 2u ? t2 : t3));
+        uint32_t pos = incl - mine;
+        for (uint32_t k = 0; k < p_a; k++, pos++)
+            if (pos < kRowRing) ring[pos] = make_uint2(run_q0[0] + 8u * k, min(run_q1[0], run_q0[0] + 8u * k + 8u));
+        for (uint32_t k = 0; k < p_b; k++, pos++)
+            if (pos < kRowRing) ring[pos] = make_uint2(run_q0[1] + 8u * k, min(run_q1[1], run_q0[1] + 8u * k + 8u));
     }
     redo |= n_ring > kRowRing;                                  // the list ran over: the general passes
     __builtin_amdgcn_wave_barrier();
-    // ---- the ring: one piece per row and iteration, one record per lane; the records of eight iterations together
+    // ---- the ring: two pieces per row and iteration (lanes 0-7 and 8-15), one record per lane; the records of four
+    // iterations are fetched together (eight cost 20 registers more and a wave per SIMD: the kernel waits on memory)
     uint32_t n_max = max(max((uint32_t)__builtin_amdgcn_readlane((int)n_ring, 0), (uint32_t)__builtin_amdgcn_readlane((int)n_ring, 16)),
                          max((uint32_t)__builtin_amdgcn_readlane((int)n_ring, 32), (uint32_t)__builtin_amdgcn_readlane((int)n_ring, 48)));
     n_max = min(n_max, kRowRing);
+    const uint32_t n_mine = min(n_ring, kRowRing), half = sub >> 3, sub8 = sub & 7u;
     for (uint32_t t = 0; !fail && t < n_max; t += 8u) {
-        float4 r[8];
-        float sn[8];
-        bool v[8];
+        float4 r[4];
+        float sn[4];
+        bool v[4];
 #pragma unroll
-        for (uint32_t u = 0; u < 8u; u++) {
-            const uint32_t e = t + u;
+        for (uint32_t u = 0; u < 4u; u++) {
+            const uint32_t e = t + 2u * u + half;
             uint2 run = make_uint2(0u, 0u);
-            if (e < min(n_ring, kRowRing)) run = ring[e];
-            const uint32_t q = run.x + sub;
+            if (e < n_mine) run = ring[e];
+            const uint32_t q = run.x + sub8;
             v[u] = q < run.y;
             const uint32_t qc = v[u] ? q : 0u;
             r[u] = rec[qc];
             sn[u] = rsn[qc];
         }
 #pragma unroll
-        for (uint32_t u = 0; u < 8u; u++) {
+        for (uint32_t u = 0; u < 4u; u++) {
             const float ea = __builtin_fabsf(r[u].x - ha_pos), eb = __builtin_fabsf(r[u].y - hb_pos);
             const float ta = La - ea, tb = Lb - eb;
             const float ma = ea > halfa ? ta : ea, mb = eb > halfb ? tb : eb;
             const bool in = v[u] & (ma * ma + mb * mb < thr);
             redo |= v[u] & ((ta < 0.0f) | (tb < 0.0f));
-            if (in) {
-                const float dz = r[u].z - hn_pos;
-                const float uz = __builtin_fabsf(dz) > halfn ? dz - __builtin_copysignf(Ln, dz) : dz;
-                redo |= __builtin_fabsf(uz) > halfn;
-                cnt += 1u;
-                nf |= (r[u].z - r[u].z == 0.0f) ? 0u : 1u;
-                sc += r[u].w;
-                ss += sn[u];
-                su += uz;
-                ulo = __builtin_fminf(ulo, uz);
-                uhi = __builtin_fmaxf(uhi, uz);
-            }
+            // (no shift along the normal: the frame's extrema were checked against this head above)
+            cnt += in ? 1u : 0u;
+            sc += in ? r[u].w : 0.0f;
+            ss += in ? sn[u] : 0.0f;
+            su += in ? r[u].z - hn_pos : 0.0f;
         }
     }
     // ---- per row: totals in lane 15 of the row (row shifts only), then the centre as in the general passes
@@ -1327,22 +1503,20 @@ __global__ __launch_bounds__(256) void k_local_flags_rows(LocalArgs a) {
     sc = row_add<0x112>(sc); ss = row_add<0x112>(ss); cnt = row_add_u32<0x112>(cnt);
     sc = row_add<0x114>(sc); ss = row_add<0x114>(ss); cnt = row_add_u32<0x114>(cnt);
     sc = row_add<0x118>(sc); ss = row_add<0x118>(ss); cnt = row_add_u32<0x118>(cnt);
-    ulo = fminf(ulo, row_shifted<0x111>(ulo)); uhi = fmaxf(uhi, row_shifted<0x111>(uhi));
-    ulo = fminf(ulo, row_shifted<0x112>(ulo)); uhi = fmaxf(uhi, row_shifted<0x112>(uhi));
-    ulo = fminf(ulo, row_shifted<0x114>(ulo)); uhi = fmaxf(uhi, row_shifted<0x114>(uhi));
-    ulo = fminf(ulo, row_shifted<0x118>(ulo)); uhi = fmaxf(uhi, row_shifted<0x118>(uhi));
-    // any lane of the row: redo / non-finite member
-    const uint64_t redo_mask = __ballot(redo), nf_mask = __ballot(nf != 0u);
+    const uint64_t redo_mask = __ballot(redo);
     const bool row_redo = ((redo_mask >> (16u * row)) & 0xffffull) != 0ull;
-    const bool row_nf = ((nf_mask >> (16u * row)) & 0xffffull) != 0ull;
     bool general = fail || row_redo;
     if (sub == 15u && head_ok && !general) {
-        if (cnt == 0u || row_nf) {
+        if (cnt == 0u) {
             raise_error(a.err, GORDER_ERR_INVALID_LOCAL_MEMBRANE_CENTER, f, kStageTypes, a.mol_slot0 ? a.mol_slot0[m] : 0u, 0, m);
         } else {
-            const float est = (atan2f(-ss, -sc) + 3.1415927f) / (6.2831855f / Ln);
+            // (the estimate only anchors the image choice — est + MI(z_head - est) is z_head's image next to it whatever
+            // its last digits —, so a 1e-5 rad arctangent does)
+            const float est = (local_atan2_fast(-ss, -sc) + 3.1415927f) * (Ln * 0.15915494f);
             const float shift = gm_min_image(hn_pos - est, Ln, bad), margin = 1e-4f * Ln;
-            if (ulo + shift > -halfn + margin && uhi + shift < halfn - margin) {
+            // every member's image around the head is its image around the estimate as well (the bounds are the frame's
+            // extrema: a superset of the members)
+            if (ulo_g + shift > -halfn + margin && uhi_g + shift < halfn - margin) {
                 const float center = gm_wrap((est + shift) + (float)(tu / (double)cnt), Ln, bad);
                 if (center != center) {
                     raise_error(a.err, GORDER_ERR_INVALID_LOCAL_MEMBRANE_CENTER, f, kStageTypes, a.mol_slot0 ? a.mol_slot0[m] : 0u, 0, m);
@@ -1357,8 +1531,8 @@ __global__ __launch_bounds__(256) void k_local_flags_rows(LocalArgs a) {
         }
     }
     if (bad) raise_box_range(a.err, f);
-    // ---- heads the cells could not decide go on the list of k_local_flags_todo (calling the general passes from here
-    // would cost this kernel their registers and a stack: 102 VGPRs and 4 waves per SIMD instead of what the rows need)
+    // ---- heads the rows could not decide go on the list of k_local_flags_todo (calling the general passes from here
+    // would cost this kernel their registers and a stack)
     if (general && head_ok && sub == 15u) {
         const uint32_t at = atomicAdd(&a.todo[0].x, 1u);
         a.todo[1u + at] = make_uint2(s, m);

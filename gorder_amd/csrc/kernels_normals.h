@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void k_dyn_normals(LocalArgs a, float4 *__rest
         hb = (uint32_t)fminf(fmaxf(floorf(wb / box[db] * (float)ncb), 0.0f), (float)(ncb - 1u));
     }
     const uint32_t *cstart = a.cell_count + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u);
-    const float4 *rec = reinterpret_cast<const float4 *>(a.trig) + (size_t)s * a.n_membrane;
+    const float4 *rec = reinterpret_cast<const float4 *>(a.trig) + (size_t)s * a.rec_stride;
     const float thr = a.radius_thr;
     const bool pbc = a.pbc != 0;
     const uint32_t n_rows = 2u * ka + 1u, n_cols = 2u * kb + 1u;

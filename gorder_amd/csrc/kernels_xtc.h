@@ -1,20 +1,29 @@
-// kernels_xtc.h — k_xtc_decode: GROMACS xdr3dcoord bit streams -> f32 coordinates of the analysed atoms, on the device.
-// Part of the single translation unit gorder_hip.hip; device code for gfx950 only.
+// kernels_xtc.h — k_xtc_scan + k_xtc_chunks: GROMACS xdr3dcoord bit streams -> f32 coordinates of the analysed atoms, on
+// the device.  Part of the single translation unit gorder_hip.hip; device code for gfx950 only.
 //
 // What it replaces: the decoding half of the reference's reader (groan_rs GroupXtcReader -> molly 0.5.0, reached from
 // common.rs:283-304) — "the reference's true bottleneck" (SURVEY §6, §8f row 1).  The host only copies the compressed
-// blocks (gorder_xtc_pack_window); the bit stream of a frame is strictly sequential (every field's position and the
-// adaptive `smallidx` depend on everything before it), so the parallel axis is the FRAME: one lane decodes one frame,
-// a wave 64 frames, a window of thousands of frames a few hundred waves.  Same integers, same `int * (1 / precision)`
-// as gorder_xtc_next (xtc_reader.cpp): the two decoders are compared bit for bit in tests/test_xtc_device_gpu.py.
+// blocks (gorder_xtc_pack_window).  Same integers, same `int * (1 / precision)` as gorder_xtc_next (xtc_reader.cpp): the
+// two decoders are compared bit for bit in tests/test_xtc_device_gpu.py.
 //
-// Shape of the loop.  The reference algorithm is "one full-width atom, then a run of 0..8 small atoms"; here every
-// iteration of every lane decodes exactly ONE atom — full-width or small, by the lane's own state — so the atom
-// counter is wave-uniform (the slot lookups are scalar loads, the stores of a wave go to the same atom of 64 frames)
-// and the trip count is the number of atoms up to the last analysed one, not a data-dependent quantity.
-// The bit reader keeps 128 bits of the stream in registers and the next 64 prefetched from the lane's ring in LDS, which
-// is refilled in 64-byte pieces at the service points of the loop (see k_xtc_decode): no load is on the dependency
-// chain of a field, and no instruction of the loop waits for memory.
+// The bit stream of a frame is sequential — every field's position and the adaptive `smallidx` depend on everything
+// before it — but WHERE the fields lie can be found without decoding them: a group is one full-width atom of a width
+// the frame header fixes, one flag bit, and with the flag five bits that give the number of small atoms behind it
+// (each `smallidx` bits wide) and the step of `smallidx`.  So the work is cut in two:
+//   k_xtc_scan   (one wave per frame): walks the groups, reading six bits per group — 64 groups at a time where the
+//                stream allows —, and writes a checkpoint — bit offset, smallidx, run length, atom index — at the
+//                first group boundary at or behind every kXtcChunk-th atom;
+//   k_xtc_chunks (one lane per (frame, chunk)): decodes a chunk of ~kXtcChunk atoms from its checkpoint; a group
+//                starts with an absolute atom, so a chunk needs nothing from the atoms before it.
+// A batch of 3 566 frames of 25 088 atoms is 3 566 waves in the first kernel (a short one: no divisions, no output)
+// and 5 460 waves in the second, where the first version of this file (one lane per frame for the whole decode) kept
+// 6 % of the machine busy for 14 ms whatever the batch size.
+//
+// Shape of the chunk loop.  The reference algorithm is "one full-width atom, then a run of 0..8 small atoms"; here
+// every iteration of every lane decodes exactly ONE atom — full-width or small, by the lane's own state — so the atom
+// counter (relative to the chunk's first atom) is wave-uniform.  The bit reader keeps 128 bits of the stream in
+// registers and the next 64 prefetched from the lane's ring in LDS, which is refilled in 64-byte pieces at the service
+// points of the loop: no load is on the dependency chain of a field, and no instruction of the loop waits for memory.
 #pragma once
 
 #include "../../include/gorder_xtc.h"
@@ -22,8 +31,11 @@
 namespace {
 
 constexpr int kXtcFirstIdx = 9, kXtcLastIdx = 73;
-constexpr uint32_t kXtcGroup = 8;      // atoms written out together (see k_xtc_decode)
-constexpr uint32_t kXtcWaves = 1;      // waves per workgroup (co-resident waves do not shorten a wave; 12 per CU measured 25 % slower)
+constexpr uint32_t kXtcGroup = 8;      // atoms written out together (see k_xtc_chunks)
+constexpr uint32_t kXtcChunk = 256;    // atoms between two checkpoints (a chunk starts at the first group boundary behind)
+// where a chunk starts in its frame's stream, and the decoder's state there: `state` = smallidx | run << 8 (the run
+// length is carried from group to group: a group without the flag repeats the last one's)
+struct XtcCheckpoint { unsigned long long bit; uint32_t atom; uint32_t state; };
 constexpr uint32_t kXtcRingWords = 32;  // a lane's input ring in LDS: 256 bytes of its stream, refilled 64 bytes at a time
 constexpr uint32_t kXtcRingPitch = 33;  // words per lane (bank spread)
 constexpr uint32_t kXtcPitch = 65;     // floats per (atom, coordinate) row of the LDS staging: 64 frames + 1 (bank spread)
@@ -42,13 +54,15 @@ struct XtcBits {
     unsigned long long w0, w1, pre;        // w0:w1 = the next 128 bits of the stream, MSB first; pre = the raw word behind them
     uint32_t off;                          // bits of w0 already taken
     unsigned long long taken;              // bits taken in all
-    __device__ __forceinline__ void open(const unsigned long long *lane_ring) {   // the first 3 words are in the ring
+    // the stream from bit `start` (< 512) of what the ring holds from its word 0 on; words start/64 .. +2 are in the ring
+    __device__ __forceinline__ void open(const unsigned long long *lane_ring, uint32_t start = 0) {
         ring = lane_ring;
-        w0 = __builtin_bswap64(ring[0]);
-        w1 = __builtin_bswap64(ring[1]);
-        pre = ring[2];
-        rd = 3;
-        off = 0;
+        const uint32_t w = start >> 6;
+        w0 = __builtin_bswap64(ring[w]);
+        w1 = __builtin_bswap64(ring[w + 1u]);
+        pre = ring[w + 2u];
+        rd = w + 3u;
+        off = start & 63u;
         taken = 0;
     }
     __device__ __forceinline__ unsigned long long peek() const {        // the next 64 bits
@@ -143,21 +157,131 @@ __device__ __forceinline__ void xtc_ints(XtcBits &b, uint32_t nbits, uint32_t s1
     out[2] = (int)c2;
 }
 
-// grid = ceil(n_frames / 64) blocks of ONE wave; lane = frame.
+// ---- pass 1: where the chunks start ---------------------------------------------------------------------------------
+// block = 256 threads = 4 waves = 4 frames, a WAVE per frame; grid = ceil(n_frames / 4).
 //   blob, frames : what gorder_xtc_pack_window produced (device copies)
 //   natoms       : atoms per frame in the file;  n_stop: atoms to go through (up to the last analysed one)
-//   slot_of      : [natoms] output slot of an atom or -1 (null: every atom, slot = atom)
-//   out          : [n_frames][n_out][3]
+//   cp           : [n_frames][n_chunks + 1] checkpoints, n_chunks = ceil(n_stop / kXtcChunk); entry c = the first group
+//                  boundary with at least c * kXtcChunk atoms before it, the last entry = where the walk ended
+//   slot_of, out : used here only for the uncompressed frames of files with <= 9 atoms (written directly)
 //   stat, short_list : null, or 2 words (zeroed by the caller) + [n_frames] words: see the end of the kernel
-__global__ __launch_bounds__(64 * kXtcWaves) void k_xtc_decode(const uint8_t *__restrict__ blob, unsigned long long blob_bytes,
+// The chain of groups is sequential, but between two groups that carry the flag nothing changes: run length and
+// smallidx stay, so every group is the same number of bits, S = width + 1 + (run / 3) smallidx, and the same number of
+// atoms.  The 64 lanes therefore look at the flag bits of the NEXT 64 groups at once, assuming no flag in between —
+// lane k at bit pos + width + k S —, the first lane that sees a flag (ballot) tells how far the assumption held, the
+// wave moves over those k groups in one step and through the flagged group behind them by hand.  A stream without
+// runs (one flag in a hundred groups) goes by 64 groups a step, water (every group alike) too; a stream that changes
+// its run length at every other group still takes two groups a step, and a frame is a wave, not a lane: a batch of a
+// few thousand frames fills the machine.
+__global__ __launch_bounds__(256) void k_xtc_scan(const uint8_t *__restrict__ blob, unsigned long long blob_bytes,
+                                                  const gorder_xtc_frame_t *__restrict__ frames, uint32_t n_frames,
+                                                  uint32_t natoms, const int32_t *__restrict__ slot_of, uint32_t n_stop,
+                                                  float *__restrict__ out, uint32_t n_out, uint32_t *err, uint32_t *stat,
+                                                  uint32_t *short_list, XtcCheckpoint *__restrict__ cp, uint32_t n_chunks) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t fr = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (fr >= n_frames) return;                  // (uniform per wave; no workgroup barrier in this kernel)
+    const gorder_xtc_frame_t d = frames[fr];
+    // the frame's region of the blob: the block rounded up to whole 64-byte pieces plus one piece of zeros
+    const unsigned long long region = (((unsigned long long)d.n_bytes + 63ull) & ~63ull) + 64ull;
+    bool bad = (d.offset & 63ull) != 0ull || d.offset + region > blob_bytes;
+    const uint8_t *p = blob + (bad ? 0ull : d.offset);
+    const uint32_t last_byte = bad ? 62u : (uint32_t)(region > 0xfffffffeull ? 0xfffffffeull : region) - 2u;   // two bytes are read at a time
+    XtcCheckpoint *mycp = cp + (size_t)fr * (n_chunks + 1u);
+
+    if (natoms <= 9u) {      // uncompressed small systems: big-endian floats, written here; the chunks are empty
+        float *o = out + (size_t)fr * n_out * 3u;
+        for (uint32_t t = lane; t < n_stop; t += 64u) {
+            const int32_t slot = slot_of ? slot_of[t] : (int32_t)t;
+            if (slot < 0 || (uint32_t)slot >= n_out || bad || d.n_bytes < 12u * natoms) continue;
+            const uint32_t *w = reinterpret_cast<const uint32_t *>(p) + 3u * t;
+            for (int c = 0; c < 3; c++) o[3u * (size_t)slot + c] = __uint_as_float(__builtin_bswap32(w[c]));
+        }
+        for (uint32_t c = lane; c <= n_chunks; c += 64u) mycp[c] = XtcCheckpoint{0ull, n_stop, (uint32_t)kXtcFirstIdx};
+        if (bad && lane == 0u) raise_error(err, GORDER_ERR_TRAJECTORY_FORMAT, fr, kStageBox);
+        return;
+    }
+    int smallidx = d.smallidx;
+    if (smallidx < kXtcFirstIdx || smallidx >= kXtcLastIdx) { bad = true; smallidx = kXtcFirstIdx; }
+    // bits of a full-width atom: one mixed-radix number, or three fields
+    const uint32_t width = d.bitsize ? d.bitsize : (d.bitsizeint & 0xffu) + ((d.bitsizeint >> 8) & 0xffu) + ((d.bitsizeint >> 16) & 0xffu);
+    // (bit positions in 32 bits: a frame of 256 MB or more is refused here — gorder_xtc_pack_window's blob could not
+    // hold many of them either)
+    if (d.n_bytes >= (1u << 28)) bad = true;
+    // the walk's state is the same in every lane
+    uint32_t pos = 0;                // bits of the stream before the current group
+    uint32_t atoms = 0, next_cp = 0;
+    uint32_t run3 = 0;               // small atoms behind a full-width atom (run / 3); a group without the flag keeps the last value
+    // checkpoints at the starts of the groups j < k of a stretch of equal groups (S bits, A atoms each) from (pos, atoms):
+    // checkpoint c goes to the first group with at least c kXtcChunk atoms before it; lane i looks after checkpoint next_cp + i
+    auto checkpoints = [&](uint32_t k, uint32_t S, uint32_t A) {
+        const uint32_t c = next_cp + lane, need = c * kXtcChunk;
+        const uint32_t j = need <= atoms ? 0u : (need - atoms + A - 1u) / A;
+        const bool mine = c <= n_chunks && j < k;
+        if (mine) mycp[c] = XtcCheckpoint{(unsigned long long)pos + (unsigned long long)j * S, atoms + j * A, (uint32_t)smallidx | ((3u * run3) << 8)};
+        next_cp += (uint32_t)__popcll(__ballot(mine));
+    };
+    while (!bad && atoms < n_stop) {
+        const uint32_t A = 1u + run3, S = width + 1u + run3 * (uint32_t)smallidx;
+        // groups still wanted: the walk ends with the first group boundary at or behind n_stop atoms
+        const uint32_t k_want = (n_stop - atoms + A - 1u) / A;
+        // lane k: the flag bit of group k and the five bits behind it, IF the groups before it are all like this one
+        const unsigned long long fp = (unsigned long long)pos + width + (unsigned long long)lane * S;
+        const unsigned long long by64 = fp >> 3;
+        const uint32_t by = by64 < last_byte ? (uint32_t)by64 : last_byte;            // (past the block: its zero padding)
+        const uint32_t two = ((uint32_t)p[by] << 8) | (uint32_t)p[by + 1u];
+        const uint32_t six = by64 < last_byte ? (two >> (10u - ((uint32_t)fp & 7u))) & 63u : 0u;
+        const unsigned long long flagged = __ballot((six & 32u) != 0u && lane < k_want);
+        const uint32_t k_flag = flagged ? (uint32_t)__builtin_ctzll(flagged) : 64u;
+        const uint32_t k = min(k_flag, min(k_want, 64u));     // groups without a flag from here on
+        checkpoints(k, S, A);
+        pos += k * S;
+        atoms += k * A;
+        if (k_flag < 64u && k == k_flag) {      // the group with the flag: its run length and the step of smallidx
+            const uint32_t s6 = (uint32_t)__builtin_amdgcn_readlane((int)six, (int)k_flag);
+            const uint32_t r5 = s6 & 31u, q3 = (r5 * 43u) >> 7;       // r5 / 3 for r5 < 64
+            const int is_smaller = (int)(r5 - 3u * q3) - 1;
+            run3 = q3;
+            const uint32_t A1 = 1u + run3, S1 = width + 6u + run3 * (uint32_t)smallidx;
+            checkpoints(1u, S1, A1);
+            pos += S1;
+            atoms += A1;
+            smallidx += is_smaller;
+            if (smallidx < kXtcFirstIdx || smallidx >= kXtcLastIdx) { bad = true; smallidx = kXtcFirstIdx; }
+        }
+        if (atoms > natoms || pos > 0x7ffffff0u) bad = true;
+    }
+    // Read into the padding?  A frame of which only a leading part was copied (bit 1 of kind) is then SHORT, not corrupt
+    // (whatever else went wrong while it walked zeros): it goes on the caller's list and is decoded elsewhere.
+    // stat[0] = short frames, stat[1] = max over frames of bytes needed / bytes given, in units of 2^-16.
+    const bool over = (unsigned long long)pos > 8ull * d.n_bytes;
+    // a frame that cannot be decoded gets empty chunks; the checkpoints not reached are where the walk ended
+    if (bad || over) { next_cp = 0; atoms = 0; pos = 0; }
+    for (uint32_t c = next_cp + lane; c <= n_chunks; c += 64u) mycp[c] = XtcCheckpoint{(unsigned long long)pos, atoms, (uint32_t)smallidx | ((3u * run3) << 8)};
+    if (lane == 0u) {
+        if (stat) {
+            const unsigned long long q16 = ((((unsigned long long)pos + 7ull) >> 3) << 16) / (d.n_bytes ? d.n_bytes : 1u);
+            atomicMax(&stat[1], (uint32_t)(q16 > 0xffffffffull ? 0xffffffffull : q16));
+        }
+        if (over && (d.kind & 2u) && stat && short_list) short_list[atomicAdd(&stat[0], 1u)] = fr;
+        else if (bad || over) raise_error(err, GORDER_ERR_TRAJECTORY_FORMAT, fr, kStageBox);
+    }
+}
+
+// ---- pass 2: the chunks -----------------------------------------------------------------------------------------------
+// grid = ceil(n_frames * n_chunks / 64) blocks of ONE wave; lane = (frame, chunk), consecutive lanes = consecutive chunks.
+//   slot_of : [natoms] output slot of an atom or -1 (null: every atom, slot = atom)
+//   out     : [n_frames][n_out][3]
+__global__ __launch_bounds__(64) void k_xtc_chunks(const uint8_t *__restrict__ blob, unsigned long long blob_bytes,
                                                    const gorder_xtc_frame_t *__restrict__ frames, uint32_t n_frames,
                                                    uint32_t natoms, const int32_t *__restrict__ slot_of, uint32_t n_stop,
-                                                   float *__restrict__ out, uint32_t n_out, uint32_t *err,
-                                                   uint32_t *stat, uint32_t *short_list) {
+                                                   float *__restrict__ out, uint32_t n_out,
+                                                   const XtcCheckpoint *__restrict__ cp, uint32_t n_chunks) {
     __shared__ uint32_t l_magic[kXtcLastIdx];
     __shared__ unsigned long long l_recip[kXtcLastIdx];
     __shared__ double l_inv[kXtcLastIdx];
-    for (uint32_t k = threadIdx.x; k < (uint32_t)kXtcLastIdx; k += 64u * kXtcWaves) {
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t k = lane; k < (uint32_t)kXtcLastIdx; k += 64u) {
         const uint32_t m = kXtcMagic[k];
         l_magic[k] = m;
         // floor(2^64 / m): a power of two divides 2^64 exactly, for anything else it is floor((2^64 - 1) / m)
@@ -165,89 +289,92 @@ __global__ __launch_bounds__(64 * kXtcWaves) void k_xtc_decode(const uint8_t *__
         l_inv[k] = m == 0u ? 0.0 : 1.0 / (double)m;
     }
     __syncthreads();
-    // a wave = 64 frames; the waves of a workgroup share nothing but the tables above and a CU: with a few thousand
-    // frames per launch there are far fewer waves than SIMDs, and the dispatcher would give each a SIMD of its own,
-    // where every dependent instruction, LDS access and load is waited for in full (measured: 190 instructions per
-    // atom take 2 100 cycles).  Twelve waves per workgroup put three on each SIMD of one CU instead.
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t frame0 = (blockIdx.x * kXtcWaves + wave) * 64u;
-    if (frame0 >= n_frames) return;              // (no workgroup barrier below this line)
-    const uint32_t fr = frame0 + lane;
-    const bool live = fr < n_frames;
-    const gorder_xtc_frame_t d = frames[live ? fr : n_frames - 1u];
-    float *o = out + (size_t)(live ? fr : 0u) * n_out * 3u;      // (the raw path below)
+    const unsigned long long total = (unsigned long long)n_frames * n_chunks;
+    const unsigned long long item = (unsigned long long)blockIdx.x * 64u + lane;
+    const bool live = item < total;
+    const unsigned long long it = live ? item : total - 1ull;
+    const uint32_t fr = (uint32_t)(it / n_chunks), ch = (uint32_t)(it - (unsigned long long)fr * n_chunks);
+    const gorder_xtc_frame_t d = frames[fr];
+    const XtcCheckpoint ca = cp[(size_t)fr * (n_chunks + 1u) + ch], cb = cp[(size_t)fr * (n_chunks + 1u) + ch + 1u];
     const float inv_p = d.inv_precision;
-    // the frame's region of the blob: the block rounded up to whole 64-byte pieces plus one piece of zeros
     const unsigned long long region = (((unsigned long long)d.n_bytes + 63ull) & ~63ull) + 64ull;
-    bool bad = (d.offset & 63ull) != 0ull || d.offset + region > blob_bytes;
-    const uint8_t *p = blob + (bad ? 0ull : d.offset);
-    const unsigned long long last_piece = bad ? 0ull : region - 64ull;      // (a bad frame reads the blob's first piece, harmlessly)
+    const bool bad_frame = (d.offset & 63ull) != 0ull || d.offset + region > blob_bytes || natoms <= 9u;
+    const uint8_t *p = blob + (bad_frame ? 0ull : d.offset);
+    const unsigned long long last_piece = bad_frame ? 0ull : region - 64ull;
+    const uint32_t atom0 = ca.atom;
+    // atoms of this chunk (a checkpoint lies within a group of the chunk's nominal start: never more than kXtcChunk + 8)
+    uint32_t n_at = (live && !bad_frame && cb.atom >= ca.atom && cb.atom - ca.atom <= kXtcChunk + 16u) ? cb.atom - ca.atom : 0u;
+    uint32_t n_max = n_at;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) n_max = max(n_max, (uint32_t)__shfl_xor((int)n_max, off, 64));
+    if (n_max == 0u) return;                     // (uniform; no workgroup barrier below this line)
 
-    // Decoded atoms go through LDS: a lane writing its frame's atom straight to memory is one 4-byte piece in each of
-    // 64 cache lines per store instruction.  Instead a lane parks atom i at l_atoms[i mod 16] and, once 8 consecutive
-    // atoms are final, the wave writes them frame by frame: 24 lanes = 8 atoms x 3 coordinates = one contiguous 96-byte
-    // piece of a frame when the analysed atoms are consecutive in the file (any other order is still correct, only
-    // less coalesced), two frames per store instruction.
-    __shared__ float l_atoms_all[kXtcWaves * 2u * kXtcGroup * 3u * kXtcPitch];
-    float *l_atoms = l_atoms_all + wave * (2u * kXtcGroup * 3u * kXtcPitch);
-    const uint32_t n_live = min(64u, n_frames - frame0);
-    auto put = [&](const int (&c)[3], uint32_t idx) {        // idx is wave-uniform
+    // Decoded atoms go through LDS: a lane writing its chunk's atom straight to memory is one 12-byte piece in each of
+    // 64 places per store instruction.  Instead a lane parks atom i of its chunk at l_atoms[i mod 16] and, once 8
+    // consecutive atoms are final, the wave writes them chunk by chunk: 24 lanes = 8 atoms x 3 coordinates = one
+    // contiguous 96-byte piece of a frame when the analysed atoms are consecutive in the file (any other order is still
+    // correct, only less coalesced), two chunks per store instruction.  The slots of those atoms (each lane looks up its
+    // own, one service point ahead) and the chunks' places in `out` go through LDS as well.
+    __shared__ float l_atoms[2u * kXtcGroup * 3u * kXtcPitch];
+    __shared__ int32_t l_slot[kXtcGroup * kXtcPitch];
+    __shared__ unsigned long long l_obase[64];
+    l_obase[lane] = (unsigned long long)fr * n_out * 3u;
+    auto put = [&](const int (&c)[3], uint32_t idx) {        // idx (atom of the chunk) is wave-uniform
         float *q = l_atoms + (idx & (2u * kXtcGroup - 1u)) * 3u * kXtcPitch + lane;
         q[0] = (float)c[0] * inv_p;
         q[kXtcPitch] = (float)c[1] * inv_p;
         q[2u * kXtcPitch] = (float)c[2] * inv_p;
     };
-    // the output slot of the (atom, coordinate) this lane writes in the flush of the group that starts at first_atom
+    auto slot_of_local = [&](uint32_t t) -> int32_t {        // output slot of atom t of MY chunk (-1: none)
+        const uint32_t idx = atom0 + t;
+        const bool want = t < n_at && idx < n_stop;
+        if (!slot_of) return want ? (int32_t)idx : -1;
+        const int32_t sl = slot_of[want ? idx : 0u];
+        return want ? sl : -1;
+    };
+    int32_t snext[kXtcGroup];
+#pragma unroll
+    for (uint32_t j = 0; j < kXtcGroup; j++) snext[j] = slot_of_local(j);
     const uint32_t fl_half = lane >= 3u * kXtcGroup ? 1u : 0u, fl_l = lane - fl_half * 3u * kXtcGroup;
     const uint32_t fl_j = fl_l / 3u, fl_c = fl_l - 3u * fl_j;
-    auto slot_for = [&](uint32_t first_atom) -> int32_t {
-        const uint32_t idx = first_atom + fl_j;
-        if (lane >= 6u * kXtcGroup || idx >= n_stop) return -1;
-        return slot_of ? slot_of[idx] : (int32_t)idx;
-    };
-    auto flush = [&](uint32_t first_atom, int32_t slot) {    // atoms first_atom .. first_atom + 7, all final
+    auto flush = [&](uint32_t first) {    // atoms first .. first + 7 of every chunk, all final; their slots are in snext
+#pragma unroll
+        for (uint32_t j = 0; j < kXtcGroup; j++) l_slot[j * kXtcPitch + lane] = snext[j];
         // the wave reads what its own lanes wrote: LDS instructions of one wave execute in order, the fences only keep
         // the compiler from moving the reads up
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // lanes 0..23: (atom, coordinate) of the even frames, lanes 24..47: of the odd frames — 96 contiguous bytes each
-        const uint32_t half = fl_half, c = fl_c, idx = first_atom + fl_j;
-        if (slot >= 0 && (uint32_t)slot < n_out) {
-            const float *q = l_atoms + ((idx & (2u * kXtcGroup - 1u)) * 3u + c) * kXtcPitch;
-            float *dst = out + ((size_t)frame0 * n_out + (uint32_t)slot) * 3u + c;
+        // lanes 0..23: (atom, coordinate) of the even chunks, lanes 24..47: of the odd chunks — 96 contiguous bytes each
+        if (lane < 6u * kXtcGroup) {
+            const float *q = l_atoms + (((first + fl_j) & (2u * kXtcGroup - 1u)) * 3u + fl_c) * kXtcPitch;
+            const int32_t *sl = l_slot + fl_j * kXtcPitch;
 #pragma unroll 4
-            for (uint32_t f = half; f < n_live; f += 2u) dst[(size_t)f * n_out * 3u] = q[f];
+            for (uint32_t f = fl_half; f < 64u; f += 2u) {
+                const int32_t slot = sl[f];
+                if (slot >= 0 && (uint32_t)slot < n_out) out[l_obase[f] + (size_t)(uint32_t)slot * 3u + fl_c] = q[f];
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
 
-    if (natoms <= 9u) {      // uncompressed small systems: big-endian floats
-        for (uint32_t t = 0; t < n_stop; t++) {
-            const int32_t slot = slot_of ? slot_of[t] : (int32_t)t;
-            if (slot < 0 || (uint32_t)slot >= n_out || !live || bad || d.n_bytes < 12u * natoms) continue;
-            const uint32_t *w = reinterpret_cast<const uint32_t *>(p) + 3u * t;
-            for (int c = 0; c < 3; c++) o[3u * (size_t)slot + c] = __uint_as_float(__builtin_bswap32(w[c]));
-        }
-        if (bad && live) raise_error(err, GORDER_ERR_TRAJECTORY_FORMAT, fr, kStageBox);
-        return;
-    }
-
     // ---- the input side: each lane's stream goes through a 256-byte ring in LDS, refilled in 64-byte pieces at the
     // same points where the output is flushed.  A piece is REQUESTED at one service point (global loads into registers)
-    // and LANDED in the ring at the next one, eight atoms later: no instruction of the loop ever waits for memory, and
-    // the wait for the loads no longer waits for the flush's stores either (gfx9 counts both in vmcnt) — they are all
-    // one service point old by then.  A lane uses at most 78 bytes between two service points (8 atoms of 72 + 6 bits)
-    // and gets up to 128, a corrupt stream just runs into the region's zero piece (the piece ADDRESS is clamped).
+    // and LANDED in the ring at the next one, eight atoms later: no instruction of the loop ever waits for memory.  A
+    // lane uses at most 78 bytes between two service points (8 atoms of 72 + 6 bits) and gets up to 128, a corrupt
+    // stream just runs into the region's zero piece (the piece ADDRESS is clamped).  The lane's stream starts at the
+    // 64-byte piece that holds its checkpoint's bit.
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    __shared__ unsigned long long l_in_all[kXtcWaves * 64u * kXtcRingPitch];
-    unsigned long long *ring = l_in_all + (wave * 64u + lane) * kXtcRingPitch;
-    uint32_t wr = 0;                 // bytes of the stream landed in the ring (a multiple of 64)
+    __shared__ unsigned long long l_in[64u * kXtcRingPitch];
+    unsigned long long *ring = l_in + lane * kXtcRingPitch;
+    const unsigned long long byte0 = (ca.bit >> 9) * 64ull;
+    uint32_t wr = 0;                 // bytes of the lane's stream (from byte0 on) landed in the ring (a multiple of 64)
     uint32_t n_req = 0;              // pieces requested at the last service point (0..2)
     u32x4 pc[8];
     auto piece_at = [&](uint32_t off) {
-        return reinterpret_cast<const u32x4 *>(p + (off < last_piece ? (unsigned long long)off : last_piece));
+        const unsigned long long at = byte0 + off;
+        return reinterpret_cast<const u32x4 *>(p + (at < last_piece ? at : last_piece));
     };
     auto land = [&](const u32x4 *v) {           // one piece into the ring at stream offset wr (8-byte stores: odd pitch)
         unsigned long long *dst = ring + ((wr >> 3) & (kXtcRingWords - 1u));
@@ -267,23 +394,23 @@ __global__ __launch_bounds__(64 * kXtcWaves) void k_xtc_decode(const uint8_t *__
         }
     }
     XtcBits b;
-    b.open(ring);
+    b.open(ring, (uint32_t)(ca.bit & 511ull));
     // A service point, every kXtcGroup atoms: land what was requested at the last one, flush the finished atoms, request
     // the next pieces and the output slots of the next flush.  Every global load is consumed one service point after it
     // was issued, so the only waits on memory are for operations eight atoms old.
-    int32_t slot_next = slot_for(0);
-    auto service = [&](uint32_t first_atom) {
+    auto service = [&](uint32_t first) {
         if (n_req >= 1u) land(pc);
         if (n_req == 2u) land(pc + 4);
-        flush(first_atom, slot_next);
-        slot_next = slot_for(first_atom + kXtcGroup);
+        flush(first);
+#pragma unroll
+        for (uint32_t j = 0; j < kXtcGroup; j++) snext[j] = slot_of_local(first + kXtcGroup + j);
         const uint32_t room = 8u * kXtcRingWords - (wr - 8u * b.rd);        // bytes of the ring not holding unread stream
         n_req = min(2u, room / 64u);
         if (n_req >= 1u) { const u32x4 *src = piece_at(wr); pc[0] = src[0]; pc[1] = src[1]; pc[2] = src[2]; pc[3] = src[3]; }
         if (n_req == 2u) { const u32x4 *src = piece_at(wr + 64u); pc[4] = src[0]; pc[5] = src[1]; pc[6] = src[2]; pc[7] = src[3]; }
     };
-    int smallidx = d.smallidx;
-    if (smallidx < kXtcFirstIdx || smallidx >= kXtcLastIdx) { bad = true; smallidx = kXtcFirstIdx; }
+    int smallidx = (int)(ca.state & 0xffu);
+    if (smallidx < kXtcFirstIdx || smallidx >= kXtcLastIdx) { n_at = 0; smallidx = kXtcFirstIdx; }
     uint32_t sizesmall = l_magic[smallidx];
     unsigned long long rsmall = l_recip[smallidx];
     double sinv = l_inv[smallidx];
@@ -294,35 +421,34 @@ __global__ __launch_bounds__(64 * kXtcWaves) void k_xtc_decode(const uint8_t *__
     auto adapt = [&](int is_smaller) {
         if (is_smaller == 0) return;
         smallidx += is_smaller;
-        if (smallidx < kXtcFirstIdx || smallidx >= kXtcLastIdx) { bad = true; smallidx = kXtcFirstIdx; }
+        if (smallidx < kXtcFirstIdx || smallidx >= kXtcLastIdx) smallidx = kXtcFirstIdx;     // (k_xtc_scan has raised the error)
         sizesmall = l_magic[smallidx];
         rsmall = l_recip[smallidx];
         sinv = l_inv[smallidx];
         smallnum = (int)(sizesmall / 2u);
     };
-    int run = 0, pend = 0;
+    int run = (int)((ca.state >> 8) & 0xffu), pend = 0;      // (a group without the flag repeats the run length before it)
     uint32_t run_left = 0;          // small atoms of the current run still to come
     bool first = false;             // the next small atom is the first of its run (it swaps places with its predecessor)
     int prev[3] = {0, 0, 0};
-    // an atom is final one iteration after it was read (the swap): one iteration past the last analysed atom
-    const uint32_t n_iter = min(natoms, n_stop + 1u);
-    uint32_t flushed = 0;           // atoms written out so far (a multiple of kXtcGroup)
+    uint32_t flushed = 0;           // atoms of the chunk written out so far (a multiple of kXtcGroup)
     // ---- the usual case, for the whole wave: every frame's full-width atom is ONE number of at most 53 bits (box edges
     // below ~100 000 grid steps).  A full-width atom and a small-offset atom are then the SAME computation with other
     // parameters — a mixed-radix number of nb bits with radices (s1, s2), cut out of the next 64 bits of the stream —
-    // so the lanes of a wave, which are in the two states at the same time, run ONE copy of it instead of both
-    // (measured 2 000 cycles per iteration with two copies).  The two divisions are done in f64: v < 2^53 is exact as a
-    // double, floor(v * (1 / s)) is within 1 of the quotient, the remainder by fma is exact and repairs it — 8 f64
-    // operations per division where floor(2^64 / s) arithmetic needs 7 quarter-rate integer multiplications.
+    // so the lanes of a wave, which are in the two states at the same time, run ONE copy of it instead of both.  The two
+    // divisions are done in f64: v < 2^53 is exact as a double, floor(v * (1 / s)) is within 1 of the quotient, the
+    // remainder by fma is exact and repairs it — 8 f64 operations per division where floor(2^64 / s) arithmetic needs 7
+    // quarter-rate integer multiplications.
     const bool simple = d.bitsize >= 1u && d.bitsize <= 53u;
     if (__ballot(!simple) == 0ull) {
         const double ls1 = (double)d.sizeint[1], ls2 = (double)d.sizeint[2];
         const double li1 = 1.0 / ls1, li2 = 1.0 / ls2;
-        for (uint32_t t = 0; t < n_iter; t++) {
+        for (uint32_t t = 0; t < n_max; t++) {
             if (t == flushed + kXtcGroup + 1u) {     // atoms < t - 1 are final
                 service(flushed);
                 flushed += kXtcGroup;
             }
+            if (t >= n_at) continue;
             const bool large = run_left == 0u;
             const uint32_t nb = large ? d.bitsize : (uint32_t)smallidx;
             const unsigned long long P = b.peek();
@@ -366,7 +492,7 @@ __global__ __launch_bounds__(64 * kXtcWaves) void k_xtc_decode(const uint8_t *__
                     run_left = (uint32_t)run / 3u;
                     first = true;
                     pend = is_smaller;
-                    if (t + 1u + run_left > natoms) { bad = true; run_left = 0; }
+                    if (t + 1u + run_left > n_at) run_left = 0;      // (a corrupt stream; k_xtc_scan has raised the error)
                 } else {
                     put(c3, t);
                     adapt(is_smaller);
@@ -390,11 +516,12 @@ __global__ __launch_bounds__(64 * kXtcWaves) void k_xtc_decode(const uint8_t *__
         }
     } else
     // ---- every form of the format (edges beyond 2^24 grid steps, numbers of 54..72 bits): field by field
-    for (uint32_t t = 0; t < n_iter; t++) {
+    for (uint32_t t = 0; t < n_max; t++) {
         if (t == flushed + kXtcGroup + 1u) {     // atoms < t - 1 are final
             service(flushed);
             flushed += kXtcGroup;
         }
+        if (t >= n_at) continue;
         if (run_left == 0u) {
             int cur[3];
             if (d.bitsize == 0u) {
@@ -417,7 +544,7 @@ __global__ __launch_bounds__(64 * kXtcWaves) void k_xtc_decode(const uint8_t *__
                 run_left = (uint32_t)run / 3u;
                 first = true;
                 pend = is_smaller;
-                if (t + 1u + run_left > natoms) { bad = true; run_left = 0; }
+                if (t + 1u + run_left > n_at) run_left = 0;
             } else {
                 put(cur, t);
                 adapt(is_smaller);
@@ -439,18 +566,10 @@ __global__ __launch_bounds__(64 * kXtcWaves) void k_xtc_decode(const uint8_t *__
             if (--run_left == 0u) adapt(pend);
         }
     }
-    for (; flushed < n_stop; flushed += kXtcGroup) flush(flushed, slot_for(flushed));
-    // Read into the padding?  A frame of which only a leading part was copied (bit 1 of kind) is then SHORT, not corrupt
-    // (whatever else went wrong while it decoded zeros): it goes on the caller's list and is decoded elsewhere.
-    // stat[0] = short frames, stat[1] = max over frames of bytes needed / bytes given, in units of 2^-16.
-    const bool over = b.taken > 8ull * d.n_bytes;
-    if (live) {
-        if (stat) {
-            const unsigned long long q16 = (((b.taken + 7ull) >> 3) << 16) / (d.n_bytes ? d.n_bytes : 1u);
-            atomicMax(&stat[1], (uint32_t)(q16 > 0xffffffffull ? 0xffffffffull : q16));
-        }
-        if (over && (d.kind & 2u) && stat && short_list) short_list[atomicAdd(&stat[0], 1u)] = fr;
-        else if (bad || over) raise_error(err, GORDER_ERR_TRAJECTORY_FORMAT, fr, kStageBox);
+    for (; flushed < n_max; flushed += kXtcGroup) {
+        flush(flushed);
+#pragma unroll
+        for (uint32_t j = 0; j < kXtcGroup; j++) snext[j] = slot_of_local(flushed + kXtcGroup + j);
     }
 }
 

@@ -36,6 +36,7 @@ struct TrajSlot {
     // what the decoder reports back (2 words: short frames, largest need in 2^-16 of the bytes given; then the list of
     // the short frames), on the device and pinned; where every frame of the batch lies in which file
     uint32_t *d_stat = nullptr, *d_short = nullptr, *h_stat = nullptr, *h_short = nullptr;
+    XtcCheckpoint *d_cp = nullptr;   // where the chunks of the batch's frames start (between the decoder's two kernels)
     std::vector<int64_t> file_pos;
     std::vector<uint32_t> file_idx;
     uint32_t prefix_q16 = 65536;    // the part of every block this batch was packed with
@@ -54,7 +55,7 @@ struct TrajCache {
     static constexpr int kSlots = 4;     // the host-decode route uses three of them
     TrajSlot slot[kSlots];
     bool dev = false;
-    uint32_t batch = 0;
+    uint32_t batch = 0, n_stop = 0;
     size_t blob_cap = 0, xyz_bytes = 0;
     hipStream_t copy_stream = nullptr;
     unsigned long long *h_err = nullptr;     // pinned mirror of the device error key
@@ -96,6 +97,7 @@ void traj_cache_free(gorder_hip_handle *h) {
         (void)hipFree(s.d_box_in);
         (void)hipFree(s.d_stat);
         (void)hipFree(s.d_short);
+        (void)hipFree(s.d_cp);
         if (s.h_stat) (void)hipHostFree(s.h_stat);
         if (s.h_short) (void)hipHostFree(s.h_short);
         if (s.stream) (void)hipStreamDestroy(s.stream);
@@ -252,14 +254,15 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
     const size_t blob_cap = dev ? std::max<size_t>(std::min<size_t>((size_t)batch * n_file_atoms * 6u, (size_t)1 << 30),
                                                    (size_t)n_file_atoms * 12u + 4096u) + 4096u : 0;
     TrajCache *cache = static_cast<TrajCache *>(h->traj_cache);
-    if (cache && !(cache->dev == dev && cache->batch == batch && cache->blob_cap == blob_cap && cache->xyz_bytes == xyz_bytes)) {
+    if (cache && !(cache->dev == dev && cache->batch == batch && cache->blob_cap == blob_cap && cache->xyz_bytes == xyz_bytes &&
+                   cache->n_stop == n_stop)) {
         traj_cache_free(h);            // another shape of run: start over
         cache = nullptr;
     }
     if (!cache) {
         cache = new (std::nothrow) TrajCache();
         if (!cache) return fail(h, GORDER_ERR_DEVICE, "out of host memory");
-        cache->dev = dev; cache->batch = batch; cache->blob_cap = blob_cap; cache->xyz_bytes = xyz_bytes;
+        cache->dev = dev; cache->batch = batch; cache->blob_cap = blob_cap; cache->xyz_bytes = xyz_bytes; cache->n_stop = n_stop;
         h->traj_cache = cache;
         h->traj_cache_free = &traj_cache_free;
     }
@@ -300,6 +303,7 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
             ok(hipMalloc((void **)&s.d_box_in, box_bytes));
             ok(hipMalloc((void **)&s.d_stat, 4 * sizeof(uint32_t)));      // [0..1] the decoder's report, [2..3] its error key
             ok(hipMalloc((void **)&s.d_short, (size_t)batch * sizeof(uint32_t)));
+            ok(hipMalloc((void **)&s.d_cp, xtc_checkpoints(batch, n_stop) * sizeof(XtcCheckpoint)));
             ok(hipHostMalloc((void **)&s.h_stat, 2 * sizeof(uint32_t), hipHostMallocDefault));
             ok(hipHostMalloc((void **)&s.h_short, (size_t)batch * sizeof(uint32_t), hipHostMallocDefault));
             s.file_pos.resize(batch);
@@ -524,7 +528,7 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
             if (e == hipSuccess) e = hipMemcpyAsync(s.d_box, s.d_box_in, nb, hipMemcpyDeviceToDevice, feed);
             if (e == hipSuccess && status == GORDER_OK)
                 status = xtc_decode_on(h, feed, s.d_blob, s.blob_bytes, s.d_frames, s.n, n_file_atoms, d_slot_of, n_stop,
-                                       s.d_xyz, n_atoms, s.d_stat, s.d_short, s.d_stat + 2);
+                                       s.d_xyz, n_atoms, s.d_stat, s.d_short, s.d_stat + 2, s.d_cp);
             if (e == hipSuccess) e = hipMemcpyAsync(s.h_stat, s.d_stat, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, feed);
             if (e == hipSuccess) e = hipMemcpyAsync(s.h_short, s.d_short, (size_t)s.n * sizeof(uint32_t), hipMemcpyDeviceToHost, feed);
         } else {
