@@ -103,7 +103,7 @@ struct gorder_hip_handle {
     bool dyn = false;
     uint32_t *d_dyn_cloud = nullptr, *d_dyn_heads = nullptr;
     uint32_t *d_dyn_cell_of = nullptr, *d_dyn_count = nullptr;
-    float *d_dyn_rec = nullptr, *d_dyn_rsn = nullptr;
+    float *d_dyn_rec = nullptr;
     float4 *d_dyn_normals = nullptr;
     size_t dyn_normals_cap = 0;
     std::vector<float> last_normals;   // [n_mol_total][4] of the last submitted frame
@@ -125,7 +125,7 @@ struct gorder_hip_handle {
     size_t aflags_rows = 0;
     float *d_adist = nullptr;
     // Local leaflets scratch (sized for local_slab assignment frames)
-    uint32_t *d_lcell_of = nullptr, *d_lcell_count = nullptr, *d_lcell_fill = nullptr, *d_lcell_atoms = nullptr;
+    uint32_t *d_lcell_of = nullptr, *d_lcell_count = nullptr, *d_lcell_fill = nullptr;
     float *d_ltrig = nullptr;
     uint32_t *d_arow = nullptr, *d_aframes = nullptr;
     // what those two hold right now: equal batches (same length, same assignment pattern) skip the upload
@@ -363,7 +363,7 @@ int run_dynamic_normals(gorder_hip_handle *h, const FrameArgs &a) {
     lo.n_mol_total = n_mol; lo.heads = h->d_dyn_heads; lo.membrane = h->d_dyn_cloud; lo.n_membrane = dn.n_cloud;
     lo.dim = 2; lo.pbc = a.pbc; lo.radius = dn.radius; lo.radius_thr = local_radius_threshold(dn.radius);
     lo.halo = 0; lo.rec_stride = dn.n_cloud;
-    lo.cell_of = h->d_dyn_cell_of; lo.trig = h->d_dyn_rec; lo.rsn = h->d_dyn_rsn;
+    lo.cell_of = h->d_dyn_cell_of; lo.trig = h->d_dyn_rec;
     lo.cell_count = h->d_dyn_count; lo.cell_fill = h->d_dyn_count + h->dyn_slab * (ncell + 1);
     lo.err = h->d_err; lo.aframes = nullptr; lo.write_dist_frame = -1;
     for (uint32_t done = 0; done < a.n_frames; done += h->dyn_slab) {
@@ -951,7 +951,6 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_local_build), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)kLocalBuildLds));
         HIP_TRY(h, hipMalloc((void **)&h->d_dyn_cell_of, sl * nm * sizeof(uint32_t)));
-        HIP_TRY(h, hipMalloc((void **)&h->d_dyn_rsn, sl * nm * sizeof(float)));
         HIP_TRY(h, hipMalloc((void **)&h->d_dyn_rec, sl * nm * 4 * sizeof(float)));
         HIP_TRY(h, hipMalloc((void **)&h->d_dyn_count, sl * (2 * ncell + 1) * sizeof(uint32_t)));
         h->dyn = true;
@@ -1011,8 +1010,7 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
             h->local_halo = t->handle_pbc && !env_flag("GORDER_HIP_LOCAL_ATOMS_ONLY");
             h->local_rec_stride = (h->local_halo ? 2u : 1u) * nm;
             HIP_TRY(h, hipMalloc((void **)&h->d_lcell_of, sl * nm * sizeof(uint32_t)));
-            HIP_TRY(h, hipMalloc((void **)&h->d_lcell_atoms, sl * h->local_rec_stride * sizeof(float)));   // sin column
-            HIP_TRY(h, hipMalloc((void **)&h->d_ltrig, sl * h->local_rec_stride * 4 * sizeof(float)));
+            HIP_TRY(h, hipMalloc((void **)&h->d_ltrig, sl * h->local_rec_stride * sizeof(LocalRec)));
             HIP_TRY(h, hipMalloc((void **)&h->d_lcell_count, sl * (ncell + 1) * sizeof(uint32_t)));
             HIP_TRY(h, hipMalloc((void **)&h->d_lcell_fill, sl * ncell * sizeof(uint32_t)));
             HIP_TRY(h, hipMalloc((void **)&h->d_lgrid, sl * sizeof(uint4)));
@@ -1047,14 +1045,14 @@ void gorder_hip_destroy(gorder_hip_handle *h) {
     (void)hipFree(h->d_runs); (void)hipFree(h->d_run_begin); (void)hipFree(h->d_items_by_slot);
     (void)hipFree(h->d_item_run); (void)hipFree(h->d_ua_item_run); (void)hipFree(h->d_lgrid); (void)hipFree(h->d_lrowpre); (void)hipFree(h->d_lfinfo); (void)hipFree(h->d_ltodo);
     (void)hipFree(h->d_dyn_cloud); (void)hipFree(h->d_dyn_heads); (void)hipFree(h->d_dyn_cell_of); (void)hipFree(h->d_dyn_count);
-    (void)hipFree(h->d_dyn_rec); (void)hipFree(h->d_dyn_rsn); (void)hipFree(h->d_dyn_normals);
+    (void)hipFree(h->d_dyn_rec); (void)hipFree(h->d_dyn_normals);
     if (!h->acc_external) (void)hipFree(h->d_acc);
     (void)hipFree(h->d_rep);
     (void)hipFree(h->d_heads); (void)hipFree(h->d_membrane); (void)hipFree(h->d_methyl_begin);
     (void)hipFree(h->d_methyl_atoms); (void)hipFree(h->d_aflags); (void)hipFree(h->d_adist);
     (void)hipFree(h->d_arow); (void)hipFree(h->d_aframes);
     (void)hipFree(h->d_lcell_of); (void)hipFree(h->d_lcell_count); (void)hipFree(h->d_lcell_fill);
-    (void)hipFree(h->d_lcell_atoms); (void)hipFree(h->d_ltrig);
+    (void)hipFree(h->d_ltrig);
     for (int k = 0; k < 2; k++) {
         (void)hipFree(h->d_stage_xyz[k]); (void)hipFree(h->d_stage_box[k]);
         if (h->stage_copied[k]) (void)hipEventDestroy(h->stage_copied[k]);
@@ -1145,7 +1143,7 @@ static int run_leaflets(gorder_hip_handle *h, const float *d_xyz, const float *d
         lo.radius = lf.radius;
         lo.radius_thr = local_radius_threshold(lf.radius);
         lo.cell_of = h->d_lcell_of; lo.trig = h->d_ltrig; lo.cell_count = h->d_lcell_count;
-        lo.cell_fill = h->d_lcell_fill; lo.rsn = reinterpret_cast<float *>(h->d_lcell_atoms); lo.err = h->d_err;
+        lo.cell_fill = h->d_lcell_fill; lo.err = h->d_err;
         lo.grid = h->d_lgrid;
         lo.halo = h->local_halo ? 1 : 0;
         lo.rec_stride = (uint32_t)h->local_rec_stride;

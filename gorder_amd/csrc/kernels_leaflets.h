@@ -28,6 +28,13 @@ struct LeafletArgs {
 // cos / sin of 2*pi*u by the hardware v_cos_f32 / v_sin_f32 (argument in revolutions, ~1e-6 absolute
 // error).  Used only for the Bai-Breen circular-mean ESTIMATE: the estimate merely anchors the
 // minimum-image refinement pass that produces the centre, so its last digits do not matter.
+__device__ __forceinline__ void fast_sincos_rev(float u, float *sn, float *cs);
+// sin / cos of the angle 2 pi wrap(z) / L of a record's normal coordinate (they only make the ESTIMATE of a circular
+// mean, which anchors an image choice: a multiplication by 1 / L is enough, and a coordinate outside the box gives an
+// angle off by whole turns — the same sine and cosine)
+__device__ __forceinline__ void local_trig(float z, float inv_L, float *sn, float *cs) {
+    fast_sincos_rev(z * inv_L, sn, cs);          // (v_sin / v_cos take revolutions and reduce the range themselves)
+}
 __device__ __forceinline__ void fast_sincos_rev(float u, float *sn, float *cs) {
     *sn = __builtin_amdgcn_sinf(u);
     *cs = __builtin_amdgcn_cosf(u);
@@ -469,14 +476,17 @@ constexpr uint32_t kLocalMaxCells1D = 128;
 constexpr uint32_t kLocalSlabMax = 256;
 inline uint32_t local_slab_frames(size_t n_membrane) {
     // (the heads' to-do list, 8 bytes per head and frame, is on top: heads are a fraction of the membrane atoms)
-    // (records and their sin column twice — the halo copies —, the cell of every atom, two tables of cell counts, the rows'
-    // prefix sums)
-    const size_t per_frame = n_membrane * (2u * 20u + 4u) + (size_t)(2 * 4u + 16u) * kLocalMaxCells1D * (kLocalMaxCells1D + 1u) + 32u;
+    // (records twice — the halo copies —, the cell of every atom, two tables of cell counts, the rows' prefix sums)
+    const size_t per_frame = n_membrane * (2u * 12u + 4u) + (size_t)(2 * 4u + 16u) * kLocalMaxCells1D * (kLocalMaxCells1D + 1u) + 32u;
     const size_t n = ((size_t)512 << 20) / per_frame;
     return (uint32_t)(n < 4 ? 4 : (n > kLocalSlabMax ? kLocalSlabMax : n));
 }
 
 struct LocalRowPre { float sc, ss; double sz; };   // sum cos, sum sin, sum of the normal coordinate: cells before this one in its row
+// a membrane atom in cell order: (in-plane a, in-plane b, normal coordinate), 12 bytes.  (Round 2 kept cos and sin of the
+// normal angle next to it, 20 bytes an atom: the kernels that walk the records are bound by the bytes they pull through
+// L2, and the two hardware transcendentals that make the pair again from the coordinate cost less than the 8 bytes.)
+struct LocalRec { float x, y, z; };
 
 struct LocalArgs {
     const float *xyz;
@@ -503,8 +513,7 @@ struct LocalArgs {
     float radius_thr;           // local_radius_threshold(radius)
     // scratch, per slab frame
     uint32_t *cell_of;          // [n_slab][n_membrane]
-    float *trig;                // [n_slab][n_membrane] float4 records in cell order (see k_local_scatter)
-    float *rsn;                 // [n_slab][n_membrane] sin of the normal angle, cell order
+    float *trig;                // [n_slab][rec_stride] LocalRec records in cell order (see k_local_scatter)
     uint32_t *cell_count;       // [n_slab][kLocalMaxCells1D^2 + 1] counts -> starts
     uint32_t *cell_fill;        // [n_slab][kLocalMaxCells1D^2]
     // rows of cells with a HALO (local leaflets in a periodic box): a row of the grid carries, behind its ncb cells,
@@ -673,8 +682,7 @@ __global__ __launch_bounds__(1024) void k_local_scan(LocalArgs a) {
 
 // Places every membrane atom in its cell's run and writes a cell-ordered RECORD next to it so that the
 // flags kernel streams contiguous data instead of chasing two indices per candidate:
-//   rec[q] = (in-plane a, in-plane b, normal coordinate, cos(2 pi wrap(normal)/L)),  rsn[q] = sin(...)
-// Only the normal component of the local centre is consumed (leaflets.rs:725), hence one angle.
+//   rec[q] = (in-plane a, in-plane b, normal coordinate)   (LocalRec)
 __global__ __launch_bounds__(256) void k_local_scatter(LocalArgs a) {
     __shared__ uint32_t hist[kLocalLdsCells];   // per-block count, then the block's base offset in each cell
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -707,18 +715,13 @@ __global__ __launch_bounds__(256) void k_local_scatter(LocalArgs a) {
     if (!valid) return;
     const uint32_t start = a.cell_count[(size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u) + c];
     const float *p = a.xyz + ((size_t)f * a.n_atoms + a.membrane[i]) * 3u;
-    int bad = 0;
-    float sn = 0.0f, cs = 0.0f;
-    if (a.pbc) fast_sincos_rev(gm_wrap(p[dn], box[dn], bad) / box[dn], &sn, &cs);
     const size_t q = (size_t)s * a.rec_stride + start + rank;
-    reinterpret_cast<float4 *>(a.trig)[q] = make_float4(p[da], p[db], p[dn], cs);
-    a.rsn[q] = sn;
+    reinterpret_cast<LocalRec *>(a.trig)[q] = LocalRec{p[da], p[db], p[dn]};
     if (a.halo && c % ncs < 2u * kb) {              // the copy in the row's halo
         const uint32_t c2 = c + ncb;
         const size_t q2 = (size_t)s * a.rec_stride + a.cell_count[(size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u) + c2] +
                           atomicAdd(&fill[c2], 1u);
-        reinterpret_cast<float4 *>(a.trig)[q2] = make_float4(p[da], p[db], p[dn], cs);
-        a.rsn[q2] = sn;
+        reinterpret_cast<LocalRec *>(a.trig)[q2] = LocalRec{p[da], p[db], p[dn]};
     }
 }
 
@@ -849,8 +852,7 @@ __global__ __launch_bounds__(1024) void k_local_build(LocalArgs a) {
     }
     if (tid == 0 && a.grid) { a.grid[s] = make_uint4(nca, ncb, ka, kb); local_finfo_init(a, s); }
     __syncthreads();
-    float4 *rec = reinterpret_cast<float4 *>(a.trig) + (size_t)s * a.rec_stride;
-    float *rsn = a.rsn + (size_t)s * a.rec_stride;
+    LocalRec *rec = reinterpret_cast<LocalRec *>(a.trig) + (size_t)s * a.rec_stride;
 #pragma unroll
     for (uint32_t trip = 0; trip < kLocalBuildTrips; trip++) {
         const uint32_t i0 = tid + trip * U * 1024u;
@@ -868,14 +870,10 @@ __global__ __launch_bounds__(1024) void k_local_build(LocalArgs a) {
             if (i0 + u * 1024u >= a.n_membrane) continue;
             const uint32_t c = cell_ab(pa[u], pb[u]);
             const uint32_t q = l_start[c] + (use_fill ? atomicAdd(&l_fill[c], 1u) : (place[trip][u >> 2] >> (8u * (u & 3u))) & 255u);
-            float sn = 0.0f, cs = 0.0f;
-            if (a.pbc) fast_sincos_rev(gm_wrap(pn[u], box[dn], bad) / box[dn], &sn, &cs);
-            rec[q] = make_float4(pa[u], pb[u], pn[u], cs);
-            rsn[q] = sn;
+            rec[q] = LocalRec{pa[u], pb[u], pn[u]};
             if (in_halo) {
                 const uint32_t q2 = l_start[c + ncb] + (use_fill ? atomicAdd(&l_fill[c + ncb], 1u) : (place2[trip][u >> 2] >> (8u * (u & 3u))) & 255u);
-                rec[q2] = make_float4(pa[u], pb[u], pn[u], cs);
-                rsn[q2] = sn;
+                rec[q2] = LocalRec{pa[u], pb[u], pn[u]};
             }
         }
     }
@@ -904,8 +902,10 @@ __global__ __launch_bounds__(256) void k_local_rowprefix(LocalArgs a) {
     if (blockIdx.x == 0 && s == 0 && threadIdx.x == 0) a.todo[0] = make_uint2(0u, 0u);        // this slab's list starts empty
     if (ra >= nca) return;                                                                       // (uniform per wave; no workgroup barrier below)
     const uint32_t *cstart = a.cell_count + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u);
-    const float4 *rec = reinterpret_cast<const float4 *>(a.trig) + (size_t)s * a.rec_stride;
-    const float *rsn = a.rsn + (size_t)s * a.rec_stride;
+    const LocalRec *rec = reinterpret_cast<const LocalRec *>(a.trig) + (size_t)s * a.rec_stride;
+    float box[3];
+    frame_box(a, a.aframes ? a.aframes[s] : a.frame0 + s, box);
+    const float inv_Ln = 1.0f / box[a.dim];
     LocalRowPre *out = a.rowpre + (size_t)s * (kLocalMaxCells1D * (kLocalMaxCells1D + 1u)) + (size_t)ra * (ncs + 1u);
     const uint32_t qa = cstart[ra * ncs], qb = cstart[(ra + 1u) * ncs];
     float zlo = 3.0e38f, zhi = -3.0e38f;
@@ -916,20 +916,20 @@ __global__ __launch_bounds__(256) void k_local_rowprefix(LocalArgs a) {
     double *pz = l_z[wave];
     for (uint32_t base = qa; base < qb || base == qa; base += kRowPrefixPiece) {
         const uint32_t n_here = min(kRowPrefixPiece, qb - base);
-        float4 r[8];
-        float sn[8];
+        LocalRec r[8];
 #pragma unroll
         for (uint32_t t = 0; t < 8u; t++) {
             const uint32_t q = base + 64u * t + lane;
             const uint32_t qc = q < qb ? q : (qb ? qb - 1u : 0u);
             r[t] = rec[qc];
-            sn[t] = rsn[qc];
         }
 #pragma unroll
         for (uint32_t t = 0; t < 8u; t++) {
             if (64u * t >= n_here) break;                                   // (uniform)
             const bool valid = base + 64u * t + lane < qb;
-            const float vc = valid ? r[t].w : 0.0f, vs = valid ? sn[t] : 0.0f;
+            float sn_t, cs_t;
+            local_trig(r[t].z, inv_Ln, &sn_t, &cs_t);
+            const float vc = valid ? cs_t : 0.0f, vs = valid ? sn_t : 0.0f;
             const double vz = valid ? (double)r[t].z : 0.0;
             if (valid) {
                 zlo = fminf(zlo, r[t].z);
@@ -1099,10 +1099,9 @@ __device__ __noinline__ void local_flags_head(const LocalArgs &a, uint32_t s, ui
         hb = (uint32_t)fminf(fmaxf(floorf(wb / box[db] * (float)ncb), 0.0f), (float)(ncb - 1u));
     }
     const uint32_t *cstart = a.cell_count + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u);
-    const float4 *rec = reinterpret_cast<const float4 *>(a.trig) + (size_t)s * a.rec_stride;
-    const float *rsn = a.rsn + (size_t)s * a.rec_stride;
+    const LocalRec *rec = reinterpret_cast<const LocalRec *>(a.trig) + (size_t)s * a.rec_stride;
     const uint32_t ncs = local_row_stride(a, ncb, kb);      // cells between two rows of the grid
-    const float La = box[da], Lb = box[db], Ln = box[dn];
+    const float La = box[da], Lb = box[db], Ln = box[dn], inv_Ln = 1.0f / Ln;
     const float thr = a.radius_thr;
     // rows (ha - ka .. ha + ka) mod nca; in a row the cells (hb - kb .. hb + kb) mod ncb = runs [b0, b1) and [0, b2)
     const uint32_t n_rows = 2u * ka + 1u, n_cols = 2u * kb + 1u;       // <= nca, ncb by local_axis
@@ -1163,12 +1162,14 @@ __device__ __noinline__ void local_flags_head(const LocalArgs &a, uint32_t s, ui
     // u = MI(z - z_head), with its minimum and maximum over the members.  If, once the estimate is known, every
     // member's image around the head is also its image around the estimate, then sum MI(z - est) = sum u +
     // n MI(z_head - est) and pass 2 is not needed (k_leaflets_global_contig explains the argument).
-    auto take = [&](const float4 r, const float sn) {
+    auto take = [&](const LocalRec r) {
         if (inside(r.x, r.y)) {
             cnt += 1;
             nf |= (r.z - r.z == 0.0f) ? 0u : 1u;
             if (pbc) {
-                sc += r.w; ss += sn;
+                float sn, cs;
+                local_trig(r.z, inv_Ln, &sn, &cs);
+                sc += cs; ss += sn;
                 const float u = gm_min_image(r.z - hn_pos, Ln, bad);
                 su += u;
                 ulo = fminf(ulo, u);
@@ -1186,8 +1187,7 @@ __device__ __noinline__ void local_flags_head(const LocalArgs &a, uint32_t s, ui
         const float halfa = La / 2.0f, halfb = Lb / 2.0f, halfn = Ln / 2.0f;
         bool redo = false;
         for (uint32_t it0 = 0; it0 < n_it; it0 += 4u) {
-            float4 r[4];
-            float sn[4];
+            LocalRec r[4];
             bool v[4];
 #pragma unroll
             for (uint32_t u = 0; u < 4u; u++) {
@@ -1196,7 +1196,6 @@ __device__ __noinline__ void local_flags_head(const LocalArgs &a, uint32_t s, ui
                 v[u] = q < (uint32_t)__builtin_amdgcn_readlane((int)it_end, (int)iter);   // lanes >= n_it hold 0: never
                 const uint32_t qc = v[u] ? q : 0u;
                 r[u] = rec[qc];
-                sn[u] = rsn[qc];
             }
 #pragma unroll
             for (uint32_t u = 0; u < 4u; u++) {
@@ -1211,8 +1210,10 @@ __device__ __noinline__ void local_flags_head(const LocalArgs &a, uint32_t s, ui
                     redo |= __builtin_fabsf(uz) > halfn;
                     cnt += 1u;
                     nf |= (r[u].z - r[u].z == 0.0f) ? 0u : 1u;
-                    sc += r[u].w;
-                    ss += sn[u];
+                    float sn, cs;
+                    local_trig(r[u].z, inv_Ln, &sn, &cs);
+                    sc += cs;
+                    ss += sn;
                     su += uz;
                     ulo = __builtin_fminf(ulo, uz);
                     uhi = __builtin_fmaxf(uhi, uz);
@@ -1225,8 +1226,7 @@ __device__ __noinline__ void local_flags_head(const LocalArgs &a, uint32_t s, ui
     if (done) {
     } else if (flat) {
         for (uint32_t it0 = 0; it0 < n_it; it0 += 4u) {
-            float4 r[4];
-            float sn[4];
+            LocalRec r[4];
             bool v[4];
 #pragma unroll
             for (uint32_t u = 0; u < 4u; u++) {
@@ -1235,11 +1235,10 @@ __device__ __noinline__ void local_flags_head(const LocalArgs &a, uint32_t s, ui
                 v[u] = q < (uint32_t)__builtin_amdgcn_readlane((int)it_end, (int)iter);   // lanes >= n_it hold 0: never
                 const uint32_t qc = v[u] ? q : 0u;
                 r[u] = rec[qc];
-                sn[u] = pbc ? rsn[qc] : 0.0f;
             }
 #pragma unroll
             for (uint32_t u = 0; u < 4u; u++)
-                if (v[u]) take(r[u], sn[u]);
+                if (v[u]) take(r[u]);
         }
     } else {
         for (uint32_t ia = 0; ia < n_rows; ia++) {
@@ -1247,7 +1246,7 @@ __device__ __noinline__ void local_flags_head(const LocalArgs &a, uint32_t s, ui
             for (uint32_t part = 0; part < 2u; part++) {
                 const uint32_t q0 = part == 0 ? cstart[row + b0] : cstart[row];
                 const uint32_t q1 = part == 0 ? cstart[row + b1] : cstart[row + b2];
-                for (uint32_t q = q0 + lane; q < q1; q += 64u) take(rec[q], pbc ? rsn[q] : 0.0f);
+                for (uint32_t q = q0 + lane; q < q1; q += 64u) take(rec[q]);
             }
         }
     }
@@ -1276,7 +1275,7 @@ __device__ __noinline__ void local_flags_head(const LocalArgs &a, uint32_t s, ui
                     const uint32_t q0 = part == 0 ? cstart[row + b0] : cstart[row];
                     const uint32_t q1 = part == 0 ? cstart[row + b1] : cstart[row + b2];
                     for (uint32_t q = q0 + lane; q < q1; q += 64u) {
-                        const float4 r = rec[q];
+                        const LocalRec r = rec[q];
                         if (inside(r.x, r.y)) ref += gm_min_image(r.z - est, Ln, bad);
                     }
                 }
@@ -1361,12 +1360,11 @@ __global__ __launch_bounds__(256) void k_local_flags_rows(LocalArgs a) {
     const uint32_t nca = g.x, ncb = g.y, ka = g.z, kb = g.w, ncs = ncb + 2u * kb;
     const int da = (int)((a.dim + 1u) % 3u), db = (int)((a.dim + 2u) % 3u), dn = (int)a.dim;
     const float La = box[da], Lb = box[db], Ln = box[dn];
-    const float halfa = La / 2.0f, halfb = Lb / 2.0f, halfn = Ln / 2.0f;
+    const float halfa = La / 2.0f, halfb = Lb / 2.0f, halfn = Ln / 2.0f, inv_Ln = 1.0f / Ln;
     const float thr = a.radius_thr;
     const uint32_t n_rows = 2u * ka + 1u;
     const uint32_t *cstart = a.cell_count + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u);
-    const float4 *rec = reinterpret_cast<const float4 *>(a.trig) + (size_t)s * a.rec_stride;
-    const float *rsn = a.rsn + (size_t)s * a.rec_stride;
+    const LocalRec *rec = reinterpret_cast<const LocalRec *>(a.trig) + (size_t)s * a.rec_stride;
     const LocalRowPre *pre = a.rowpre + (size_t)s * (kLocalMaxCells1D * (kLocalMaxCells1D + 1u));
     // (uniform) grids the rows do not handle, frames with a non-finite coordinate
     const bool fail = !(ka >= 1u && kb >= 1u && n_rows <= 16u && fk.z == 0u && fk.x <= fk.y);
@@ -1468,8 +1466,7 @@ __global__ __launch_bounds__(256) void k_local_flags_rows(LocalArgs a) {
     n_max = min(n_max, kRowRing);
     const uint32_t n_mine = min(n_ring, kRowRing), half = sub >> 3, sub8 = sub & 7u;
     for (uint32_t t = 0; !fail && t < n_max; t += 8u) {
-        float4 r[4];
-        float sn[4];
+        LocalRec r[4];
         bool v[4];
 #pragma unroll
         for (uint32_t u = 0; u < 4u; u++) {
@@ -1480,7 +1477,6 @@ __global__ __launch_bounds__(256) void k_local_flags_rows(LocalArgs a) {
             v[u] = q < run.y;
             const uint32_t qc = v[u] ? q : 0u;
             r[u] = rec[qc];
-            sn[u] = rsn[qc];
         }
 #pragma unroll
         for (uint32_t u = 0; u < 4u; u++) {
@@ -1490,9 +1486,11 @@ __global__ __launch_bounds__(256) void k_local_flags_rows(LocalArgs a) {
             const bool in = v[u] & (ma * ma + mb * mb < thr);
             redo |= v[u] & ((ta < 0.0f) | (tb < 0.0f));
             // (no shift along the normal: the frame's extrema were checked against this head above)
+            float sn, cs;
+            local_trig(r[u].z, inv_Ln, &sn, &cs);
             cnt += in ? 1u : 0u;
-            sc += in ? r[u].w : 0.0f;
-            ss += in ? sn[u] : 0.0f;
+            sc += in ? cs : 0.0f;
+            ss += in ? sn : 0.0f;
             su += in ? r[u].z - hn_pos : 0.0f;
         }
     }

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void k_dyn_normals(LocalArgs a, float4 *__rest
         hb = (uint32_t)fminf(fmaxf(floorf(wb / box[db] * (float)ncb), 0.0f), (float)(ncb - 1u));
     }
     const uint32_t *cstart = a.cell_count + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u);
-    const float4 *rec = reinterpret_cast<const float4 *>(a.trig) + (size_t)s * a.rec_stride;
+    const LocalRec *rec = reinterpret_cast<const LocalRec *>(a.trig) + (size_t)s * a.rec_stride;
     const float thr = a.radius_thr;
     const bool pbc = a.pbc != 0;
     const uint32_t n_rows = 2u * ka + 1u, n_cols = 2u * kb + 1u;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void k_dyn_normals(LocalArgs a, float4 *__rest
             const uint32_t q0 = part == 0 ? cstart[row + b0] : cstart[row];
             const uint32_t q1 = part == 0 ? cstart[row + b1] : cstart[row + b2];
             for (uint32_t q = q0 + lane; q < q1; q += 64u) {
-                const float4 r = rec[q];
+                const LocalRec r = rec[q];
                 float dx = r.x - hx, dy = r.y - hy, dz = r.z - hz;
                 if (pbc) { dx = gm_min_image(dx, box[0], bad); dy = gm_min_image(dy, box[1], bad); dz = gm_min_image(dz, box[2], bad); }
                 if ((dx * dx + dy * dy) + dz * dz < thr) {          // == sqrt(..) < radius (local_radius_threshold)
