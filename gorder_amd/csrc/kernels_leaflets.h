@@ -744,6 +744,130 @@ template <int CTRL>
 __device__ __forceinline__ uint32_t row_add_u32(uint32_t v) {
     return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
 }
+// Per row of cells: running sums along the row (the halo cells continue it), so that k_local_flags_rows takes the
+// cells of a row that lie wholly inside a head's cylinder — always one span of consecutive cells — as the difference
+// of two entries:  rowpre[ra (ncs + 1) + j] = sums over the cells 0 .. j-1 of row ra (cos and sin of the normal angle
+// in f32: they only make the estimate that anchors the image choice; the normal coordinate itself in f64).
+// (k_local_rowprefix, below: a scan over the row's RECORDS, read off at the cells' first records.)  The same pass makes the frame's record for the rows kernel: finfo[s] = (min, max of the normal
+// coordinate over the membrane, whether a coordinate of a record is not finite), kept as ordered integers.
+// block = 256 threads = 4 waves = 4 rows of cells, a wave per row; grid = (ceil(kLocalMaxCells1D / 4), n_slab).
+// The wave streams its row's records (contiguous: the row's cells one after the other, halo copies included) 512 at a
+// time with coalesced loads — all eight loads of a piece in flight together —, scans them (inclusive scan over the 64
+// lanes by row shifts + the totals of the 16-lane rows before, carried from load to load), parks the exclusive sums in
+// LDS, and then gives every cell of the row the sum parked at its first record.  (A lane per CELL summing its own
+// handful of records took 140 us per 256 frames: 64 short gathers per load instruction.)
+// One row of cells by one wave: PIECE records at a time (PIECE / 64 coalesced loads in flight), pc / ps / pz = the
+// wave's PIECE + 1 parking places in LDS.  zlo / zhi / nf collect the frame's extrema and non-finite flag.
+template <uint32_t PIECE>
+__device__ __forceinline__ void local_row_prefix(const uint32_t *__restrict__ cstart, const LocalRec *__restrict__ rec,
+                                                 LocalRowPre *__restrict__ out, uint32_t ra, uint32_t ncs, float inv_Ln,
+                                                 float *pc, float *ps, double *pz, float &zlo, float &zhi, uint32_t &nf) {
+    constexpr uint32_t T = PIECE / 64u;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t qa = cstart[ra * ncs], qb = cstart[(ra + 1u) * ncs];
+    float carry_c = 0.0f, carry_s = 0.0f;
+    double carry_z = 0.0;
+    for (uint32_t base = qa; base < qb || base == qa; base += PIECE) {
+        const uint32_t n_here = min(PIECE, qb - base);
+        LocalRec r[T];
+#pragma unroll
+        for (uint32_t t = 0; t < T; t++) {
+            const uint32_t q = base + 64u * t + lane;
+            const uint32_t qc = q < qb ? q : (qb ? qb - 1u : 0u);
+            r[t] = rec[qc];
+        }
+#pragma unroll
+        for (uint32_t t = 0; t < T; t++) {
+            if (64u * t >= n_here) break;                                   // (uniform)
+            const bool valid = base + 64u * t + lane < qb;
+            float sn_t, cs_t;
+            local_trig(r[t].z, inv_Ln, &sn_t, &cs_t);
+            const float vc = valid ? cs_t : 0.0f, vs = valid ? sn_t : 0.0f;
+            const double vz = valid ? (double)r[t].z : 0.0;
+            if (valid) {
+                zlo = fminf(zlo, r[t].z);
+                zhi = fmaxf(zhi, r[t].z);
+                nf |= ((r[t].x - r[t].x) + (r[t].y - r[t].y)) + (r[t].z - r[t].z) == 0.0f ? 0u : 1u;
+            }
+            float ic = vc, is = vs;
+            double iz = vz;
+            ic = row_add<0x111>(ic); is = row_add<0x111>(is); iz = row_add_f64<0x111>(iz);
+            ic = row_add<0x112>(ic); is = row_add<0x112>(is); iz = row_add_f64<0x112>(iz);
+            ic = row_add<0x114>(ic); is = row_add<0x114>(is); iz = row_add_f64<0x114>(iz);
+            ic = row_add<0x118>(ic); is = row_add<0x118>(is); iz = row_add_f64<0x118>(iz);
+            float bc = 0.0f, bs = 0.0f;
+            double bz = 0.0;
+#pragma unroll
+            for (int r4 = 0; r4 < 3; r4++) {
+                const float tc = __shfl(ic, 16 * r4 + 15, 64), ts = __shfl(is, 16 * r4 + 15, 64);
+                const double tz = __shfl(iz, 16 * r4 + 15, 64);
+                if ((int)(lane >> 4) > r4) { bc += tc; bs += ts; bz += tz; }
+            }
+            ic += bc; is += bs; iz += bz;                                   // inclusive over the 64 lanes
+            pc[64u * t + lane] = carry_c + (ic - vc);                       // records of the row before this one
+            ps[64u * t + lane] = carry_s + (is - vs);
+            pz[64u * t + lane] = carry_z + (iz - vz);
+            carry_c += __shfl(ic, 63, 64);
+            carry_s += __shfl(is, 63, 64);
+            carry_z += __shfl(iz, 63, 64);
+        }
+        if (lane == 0u) { pc[n_here] = carry_c; ps[n_here] = carry_s; pz[n_here] = carry_z; }   // behind the piece's last record
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // the cells whose first record lies in this piece (a cell that starts where the piece ends belongs to the next
+        // piece — or, behind the row's last record, to this one)
+        const bool last = base + n_here >= qb;
+        for (uint32_t j = lane; j <= ncs; j += 64u) {
+            const uint32_t q0 = j < ncs ? cstart[ra * ncs + j] : qb;
+            if (q0 >= base && (q0 < base + n_here || (last && q0 == qb))) {
+                LocalRowPre o;
+                o.sc = pc[q0 - base]; o.ss = ps[q0 - base]; o.sz = pz[q0 - base];
+                out[j] = o;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (qb == qa) break;                                                // (an empty row: one trip for its cells)
+    }
+}
+// the frame's extrema of the normal coordinate and its "a coordinate is not finite" flag, from one wave
+__device__ __forceinline__ void local_finfo_merge(const LocalArgs &a, uint32_t s, float zlo, float zhi, uint32_t nf) {
+    for (int off = 32; off >= 1; off >>= 1) {
+        zlo = fminf(zlo, __shfl_xor(zlo, off, 64));
+        zhi = fmaxf(zhi, __shfl_xor(zhi, off, 64));
+        nf |= (uint32_t)__shfl_xor((int)nf, off, 64);
+    }
+    if ((threadIdx.x & 63u) == 0u) {
+        uint32_t *fi = reinterpret_cast<uint32_t *>(a.finfo + s);
+        if (zlo <= zhi) {
+            atomicMin(fi, local_float_key(zlo));
+            atomicMax(fi + 1, local_float_key(zhi));
+        }
+        if (nf) atomicOr(fi + 2, 1u);
+    }
+}
+constexpr uint32_t kRowPrefixPiece = 512;
+__global__ __launch_bounds__(256) void k_local_rowprefix(LocalArgs a) {
+    __shared__ float l_c[4][kRowPrefixPiece + 1], l_s[4][kRowPrefixPiece + 1];
+    __shared__ double l_z[4][kRowPrefixPiece + 1];
+    const uint32_t s = blockIdx.y, wave = threadIdx.x >> 6, ra = blockIdx.x * 4u + wave;
+    const uint4 g = a.grid[s];
+    const uint32_t nca = g.x, ncs = local_row_stride(a, g.y, g.w);
+    if (blockIdx.x == 0 && s == 0 && threadIdx.x == 0) a.todo[0] = make_uint2(0u, 0u);        // this slab's list starts empty
+    if (ra >= nca) return;                                                                       // (uniform per wave; no workgroup barrier below)
+    if (reinterpret_cast<const uint4 *>(a.finfo)[s].w == 1u) return;                             // k_local_build made this frame's sums
+    const uint32_t *cstart = a.cell_count + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u);
+    const LocalRec *rec = reinterpret_cast<const LocalRec *>(a.trig) + (size_t)s * a.rec_stride;
+    float box[3];
+    frame_box(a, a.aframes ? a.aframes[s] : a.frame0 + s, box);
+    LocalRowPre *out = a.rowpre + (size_t)s * (kLocalMaxCells1D * (kLocalMaxCells1D + 1u)) + (size_t)ra * (ncs + 1u);
+    float zlo = 3.0e38f, zhi = -3.0e38f;
+    uint32_t nf = 0;
+    local_row_prefix<kRowPrefixPiece>(cstart, rec, out, ra, ncs, 1.0f / box[a.dim], l_c[wave], l_s[wave], l_z[wave], zlo, zhi, nf);
+    local_finfo_merge(a, s, zlo, zhi, nf);
+}
+
 // bin + scan + scatter in ONE kernel, one block per slab frame (membranes of up to kLocalBuildMax atoms: the slab then has
 // enough frames to fill the chip with one block each).  The cell counts live in LDS (no global atomics, no memsets,
 // no cell_of round trip): pass 1 counts — the counting atomic's return value is the atom's place inside its cell, which
@@ -878,119 +1002,10 @@ __global__ __launch_bounds__(1024) void k_local_build(LocalArgs a) {
         }
     }
     if (bad) raise_box_range(a.err, f);
-}
-
-// Per row of cells: running sums along the row (the halo cells continue it), so that k_local_flags_rows takes the
-// cells of a row that lie wholly inside a head's cylinder — always one span of consecutive cells — as the difference
-// of two entries:  rowpre[ra (ncs + 1) + j] = sums over the cells 0 .. j-1 of row ra (cos and sin of the normal angle
-// in f32: they only make the estimate that anchors the image choice; the normal coordinate itself in f64).
-// (k_local_rowprefix, below: a scan over the row's RECORDS, read off at the cells' first records.)  The same pass makes the frame's record for the rows kernel: finfo[s] = (min, max of the normal
-// coordinate over the membrane, whether a coordinate of a record is not finite), kept as ordered integers.
-// block = 256 threads = 4 waves = 4 rows of cells, a wave per row; grid = (ceil(kLocalMaxCells1D / 4), n_slab).
-// The wave streams its row's records (contiguous: the row's cells one after the other, halo copies included) 512 at a
-// time with coalesced loads — all eight loads of a piece in flight together —, scans them (inclusive scan over the 64
-// lanes by row shifts + the totals of the 16-lane rows before, carried from load to load), parks the exclusive sums in
-// LDS, and then gives every cell of the row the sum parked at its first record.  (A lane per CELL summing its own
-// handful of records took 140 us per 256 frames: 64 short gathers per load instruction.)
-constexpr uint32_t kRowPrefixPiece = 512;
-__global__ __launch_bounds__(256) void k_local_rowprefix(LocalArgs a) {
-    __shared__ float l_c[4][kRowPrefixPiece + 1], l_s[4][kRowPrefixPiece + 1];
-    __shared__ double l_z[4][kRowPrefixPiece + 1];
-    const uint32_t s = blockIdx.y, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, ra = blockIdx.x * 4u + wave;
-    const uint4 g = a.grid[s];
-    const uint32_t nca = g.x, ncs = local_row_stride(a, g.y, g.w);
-    if (blockIdx.x == 0 && s == 0 && threadIdx.x == 0) a.todo[0] = make_uint2(0u, 0u);        // this slab's list starts empty
-    if (ra >= nca) return;                                                                       // (uniform per wave; no workgroup barrier below)
-    const uint32_t *cstart = a.cell_count + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u);
-    const LocalRec *rec = reinterpret_cast<const LocalRec *>(a.trig) + (size_t)s * a.rec_stride;
-    float box[3];
-    frame_box(a, a.aframes ? a.aframes[s] : a.frame0 + s, box);
-    const float inv_Ln = 1.0f / box[a.dim];
-    LocalRowPre *out = a.rowpre + (size_t)s * (kLocalMaxCells1D * (kLocalMaxCells1D + 1u)) + (size_t)ra * (ncs + 1u);
-    const uint32_t qa = cstart[ra * ncs], qb = cstart[(ra + 1u) * ncs];
-    float zlo = 3.0e38f, zhi = -3.0e38f;
-    uint32_t nf = 0;
-    float carry_c = 0.0f, carry_s = 0.0f;
-    double carry_z = 0.0;
-    float *pc = l_c[wave], *ps = l_s[wave];
-    double *pz = l_z[wave];
-    for (uint32_t base = qa; base < qb || base == qa; base += kRowPrefixPiece) {
-        const uint32_t n_here = min(kRowPrefixPiece, qb - base);
-        LocalRec r[8];
-#pragma unroll
-        for (uint32_t t = 0; t < 8u; t++) {
-            const uint32_t q = base + 64u * t + lane;
-            const uint32_t qc = q < qb ? q : (qb ? qb - 1u : 0u);
-            r[t] = rec[qc];
-        }
-#pragma unroll
-        for (uint32_t t = 0; t < 8u; t++) {
-            if (64u * t >= n_here) break;                                   // (uniform)
-            const bool valid = base + 64u * t + lane < qb;
-            float sn_t, cs_t;
-            local_trig(r[t].z, inv_Ln, &sn_t, &cs_t);
-            const float vc = valid ? cs_t : 0.0f, vs = valid ? sn_t : 0.0f;
-            const double vz = valid ? (double)r[t].z : 0.0;
-            if (valid) {
-                zlo = fminf(zlo, r[t].z);
-                zhi = fmaxf(zhi, r[t].z);
-                nf |= ((r[t].x - r[t].x) + (r[t].y - r[t].y)) + (r[t].z - r[t].z) == 0.0f ? 0u : 1u;
-            }
-            float ic = vc, is = vs;
-            double iz = vz;
-            ic = row_add<0x111>(ic); is = row_add<0x111>(is); iz = row_add_f64<0x111>(iz);
-            ic = row_add<0x112>(ic); is = row_add<0x112>(is); iz = row_add_f64<0x112>(iz);
-            ic = row_add<0x114>(ic); is = row_add<0x114>(is); iz = row_add_f64<0x114>(iz);
-            ic = row_add<0x118>(ic); is = row_add<0x118>(is); iz = row_add_f64<0x118>(iz);
-            float bc = 0.0f, bs = 0.0f;
-            double bz = 0.0;
-#pragma unroll
-            for (int r4 = 0; r4 < 3; r4++) {
-                const float tc = __shfl(ic, 16 * r4 + 15, 64), ts = __shfl(is, 16 * r4 + 15, 64);
-                const double tz = __shfl(iz, 16 * r4 + 15, 64);
-                if ((int)(lane >> 4) > r4) { bc += tc; bs += ts; bz += tz; }
-            }
-            ic += bc; is += bs; iz += bz;                                   // inclusive over the 64 lanes
-            pc[64u * t + lane] = carry_c + (ic - vc);                       // records of the row before this one
-            ps[64u * t + lane] = carry_s + (is - vs);
-            pz[64u * t + lane] = carry_z + (iz - vz);
-            carry_c += __shfl(ic, 63, 64);
-            carry_s += __shfl(is, 63, 64);
-            carry_z += __shfl(iz, 63, 64);
-        }
-        if (lane == 0u) { pc[n_here] = carry_c; ps[n_here] = carry_s; pz[n_here] = carry_z; }   // behind the piece's last record
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // the cells whose first record lies in this piece (a cell that starts where the piece ends belongs to the next
-        // piece — or, behind the row's last record, to this one)
-        const bool last = base + n_here >= qb;
-        for (uint32_t j = lane; j <= ncs; j += 64u) {
-            const uint32_t q0 = j < ncs ? cstart[ra * ncs + j] : qb;
-            if (q0 >= base && (q0 < base + n_here || (last && q0 == qb))) {
-                LocalRowPre o;
-                o.sc = pc[q0 - base]; o.ss = ps[q0 - base]; o.sz = pz[q0 - base];
-                out[j] = o;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (qb == qa) break;                                                // (an empty row: one trip for its cells)
-    }
-    // the frame's extrema of the normal coordinate and its "a coordinate is not finite" flag
-    for (int off = 32; off >= 1; off >>= 1) {
-        zlo = fminf(zlo, __shfl_xor(zlo, off, 64));
-        zhi = fmaxf(zhi, __shfl_xor(zhi, off, 64));
-        nf |= (uint32_t)__shfl_xor((int)nf, off, 64);
-    }
-    if (lane == 0u) {
-        uint32_t *fi = reinterpret_cast<uint32_t *>(a.finfo + s);
-        if (zlo <= zhi) {
-            atomicMin(fi, local_float_key(zlo));
-            atomicMax(fi + 1, local_float_key(zhi));
-        }
-        if (nf) atomicOr(fi + 2, 1u);
-    }
+    // (The rows' prefix sums stay a kernel of their own, k_local_rowprefix: done here behind pass 2 — a wave per row, six
+    // rows per wave, the records still in this XCD's L2 — they took 190 us per 256 frames against 100 for the kernel,
+    // whose 23 000 waves hide the latency of the four dependent loads a row needs; with per-cell sums made by LDS
+    // atomics in pass 2 instead, +130 us: LDS atomics are served one lane per cycle.)
 }
 
 // `sqrt(d2) < radius` (groan_rs Cylinder::inside) is evaluated as `d2 < thr` with thr = the smallest float
