@@ -21,8 +21,11 @@
 #include <condition_variable>
 #include <deque>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
+#include <immintrin.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <vector>
@@ -184,6 +187,17 @@ double bed(const uint8_t *p) {
 
 }  // namespace
 
+// A read-only mapping of a trajectory file: the block copies of gorder_xtc_pack_window* read the page cache through it
+// (streaming stores into the staging blob) instead of one pread per block — the kernel's copy_to_user writes the
+// destination through the cache, and with sixteen threads those read-for-ownership misses, not the copy, are the
+// ceiling (tools/microbench/copy_bench.cpp: 5 GB/s with pread or memcpy on 8 threads, 32-38 GB/s with non-temporal
+// stores).  Shared with the copy jobs of a pool so that the reader may be closed before they are done.
+struct FileMap {
+    const uint8_t *base = nullptr;
+    size_t size = 0;
+    ~FileMap() { if (base) munmap(const_cast<uint8_t *>(base), size); }
+};
+
 struct gorder_xtc_reader {
     std::string path;                 // for the worker threads of gorder_xtc_read_window_mt (own file handles)
     FILE *fp = nullptr;
@@ -196,6 +210,8 @@ struct gorder_xtc_reader {
                                       // sequential, but nothing after that atom is wanted — e.g. the water behind the lipids)
     std::vector<uint8_t> buf;
     std::vector<int> ints;            // decoded integer coordinates of one frame
+    std::shared_ptr<struct FileMap> map;   // gorder_xtc_pack_window*: the file mapped once (made at the first window)
+    bool map_tried = false;
 };
 
 namespace {
@@ -991,11 +1007,35 @@ uint32_t gorder_xtc_n_atoms_needed(const gorder_xtc_reader *r) {
 
 namespace {
 struct PackSrc { off_t pos; uint32_t n; uint64_t dst; };
-// the blocks [i0, i1) of a window into the blob (pread does not move the file position)
-int pack_copy(int fd, const PackSrc *src, size_t i0, size_t i1, uint8_t *blob) {
+// n bytes to a 32-byte aligned destination with non-temporal stores (the blob is written once and read by the DMA engine)
+__attribute__((target("avx2"))) void stream_copy_avx2(uint8_t *dst, const uint8_t *src, size_t n) {
+    size_t i = 0;
+    for (; i + 128 <= n; i += 128) {
+        const __m256i a = _mm256_loadu_si256((const __m256i *)(src + i)), b = _mm256_loadu_si256((const __m256i *)(src + i + 32));
+        const __m256i c = _mm256_loadu_si256((const __m256i *)(src + i + 64)), d = _mm256_loadu_si256((const __m256i *)(src + i + 96));
+        _mm256_stream_si256((__m256i *)(dst + i), a);
+        _mm256_stream_si256((__m256i *)(dst + i + 32), b);
+        _mm256_stream_si256((__m256i *)(dst + i + 64), c);
+        _mm256_stream_si256((__m256i *)(dst + i + 96), d);
+    }
+    if (i < n) memcpy(dst + i, src + i, n - i);
+    _mm_sfence();
+}
+bool have_avx2() {
+    static const bool yes = __builtin_cpu_supports("avx2");
+    return yes;
+}
+// the blocks [i0, i1) of a window into the blob: from the file's mapping when there is one (streaming stores), else by
+// pread (which does not move the file position)
+int pack_copy(int fd, const FileMap *map, const PackSrc *src, size_t i0, size_t i1, uint8_t *blob) {
+    const bool stream = map && map->base && have_avx2() && !getenv("GORDER_XTC_PREAD");
     for (size_t i = i0; i < i1; i++) {
         uint8_t *dst = blob + src[i].dst;
         size_t done = 0;
+        if (stream && ((uintptr_t)dst & 31u) == 0 && (size_t)src[i].pos + src[i].n <= map->size) {
+            stream_copy_avx2(dst, map->base + src[i].pos, src[i].n);
+            done = src[i].n;
+        }
         while (done < src[i].n) {
             const ssize_t g = pread(fd, dst + done, src[i].n - done, src[i].pos + (off_t)done);
             if (g <= 0) return GORDER_XTC_ERR_FORMAT;
@@ -1027,10 +1067,29 @@ int64_t pack_window_impl(gorder_xtc_reader *r, float begin_ps, float end_ps, uin
     const double last_time_at_entry = *last_time;
     struct stat sb;
     const off_t file_end = fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) ? sb.st_size : (off_t)-1;
+    if (!r->map_tried) {            // the file mapped once, for the block copies and the header scan
+        r->map_tried = true;
+        if (file_end > 0) {
+            void *m = mmap(nullptr, (size_t)file_end, PROT_READ, MAP_SHARED, fd, 0);
+            if (m != MAP_FAILED) {
+                (void)madvise(m, (size_t)file_end, MADV_SEQUENTIAL);
+                r->map = std::make_shared<FileMap>();
+                r->map->base = static_cast<const uint8_t *>(m);
+                r->map->size = (size_t)file_end;
+            }
+        }
+    }
+    const FileMap *map = r->map.get();
     while (src.size() < capacity) {
         const off_t pos0 = pos;
         uint8_t head[56 + 36];
-        const ssize_t got = pread(fd, head, sizeof(head), pos0);
+        ssize_t got;
+        if (map && map->base && pos0 >= 0 && (size_t)pos0 <= map->size) {      // (no system call per frame)
+            got = (ssize_t)std::min<size_t>(sizeof(head), map->size - (size_t)pos0);
+            memcpy(head, map->base + pos0, (size_t)got);
+        } else {
+            got = pread(fd, head, sizeof(head), pos0);
+        }
         if (got == 0) break;
         if (got < 56 || be32(head) != 1995u || be32(head + 4) != natoms || be32(head + 52) != natoms)
             return GORDER_XTC_ERR_FORMAT;
@@ -1118,12 +1177,13 @@ int64_t pack_window_impl(gorder_xtc_reader *r, float begin_ps, float end_ps, uin
         const int fd2 = dup(fd);
         if (fd2 < 0) return GORDER_XTC_ERR_OPEN;
         auto left = std::make_shared<std::atomic<size_t>>(nj);
+        std::shared_ptr<FileMap> keep = r->map;
         {
             std::lock_guard<std::mutex> lk(pool->mu);
             for (size_t w = 0; w < nj; w++) {
                 const size_t i0 = n * w / nj, i1 = n * (w + 1) / nj;
-                pool->jobs.emplace_back([shared, fd2, left, i0, i1, blob]() {
-                    const int st = pack_copy(fd2, shared->data(), i0, i1, blob);
+                pool->jobs.emplace_back([shared, fd2, left, i0, i1, blob, keep]() {
+                    const int st = pack_copy(fd2, keep.get(), shared->data(), i0, i1, blob);
                     if (left->fetch_sub(1) == 1) close(fd2);
                     return st;
                 });
@@ -1135,7 +1195,7 @@ int64_t pack_window_impl(gorder_xtc_reader *r, float begin_ps, float end_ps, uin
     }
     const uint32_t nt = (uint32_t)std::min<size_t>(std::max(1u, n_threads), n);
     std::vector<int> status(nt, GORDER_XTC_OK);
-    auto work = [&](uint32_t w) { status[w] = pack_copy(fd, src.data(), n * w / nt, n * (w + 1) / nt, blob); };
+    auto work = [&](uint32_t w) { status[w] = pack_copy(fd, map, src.data(), n * w / nt, n * (w + 1) / nt, blob); };
     if (nt == 1) {
         work(0);
     } else {

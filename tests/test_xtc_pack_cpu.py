@@ -161,6 +161,37 @@ def test_a_block_longer_than_the_file_is_a_format_error(built, tmp_path):
         xtc.pack_trajectory([bad], chunk=4, blob_capacity=1 << 20)
 
 
+def test_mapped_copies_equal_pread_copies(built, tmp_path, monkeypatch):
+    """The block copies go through a mapping of the file with streaming stores when the destination is 32-byte aligned
+    (the driver's pinned blob is); GORDER_XTC_PREAD=1 takes the pread route: the same bytes, the same tables."""
+    import ctypes as C
+    from gorder_amd.abi import CXtcFrame
+    path = synthetic(tmp_path, n_frames=9, n_atoms=1500)
+    lib = xtc._lib()
+
+    def pack(aligned):
+        r = C.c_void_p()
+        assert lib.gorder_xtc_open(path.encode(), None, 0, C.byref(r)) == 0
+        raw = np.zeros((1 << 20) + 64, np.uint8)
+        shift = (-raw.ctypes.data) % 64 + (0 if aligned else 1)
+        blob = raw[shift:shift + (1 << 20)]
+        assert (blob.ctypes.data % 32 == 0) == aligned
+        state, last, used = C.c_uint64(0), C.c_double(float("-inf")), C.c_uint64(0)
+        frames = (CXtcFrame * 16)()
+        box, t = np.empty((16, 9), np.float32), np.empty(16, np.float32)
+        got = lib.gorder_xtc_pack_window(r, 0.0, -1.0, 1, C.byref(state), C.byref(last), blob.ctypes.data, 1 << 20, C.byref(used),
+                                         C.cast(frames, C.c_void_p), box.ctypes.data, t.ctypes.data, 16, 3)
+        lib.gorder_xtc_close(r)
+        assert got == 9
+        return bytes(blob[:used.value]), bytes(frames)[: 9 * C.sizeof(CXtcFrame)]
+
+    mapped = pack(True)
+    unaligned = pack(False)            # falls back to pread block by block
+    monkeypatch.setenv("GORDER_XTC_PREAD", "1")
+    plain = pack(True)
+    assert mapped == plain == unaligned
+
+
 def test_pool_copies_the_same_bytes(built, tmp_path):
     a = synthetic(tmp_path, n_frames=29, name="a.xtc")
     b = synthetic(tmp_path, n_frames=11, seed=5, n_atoms=700, name="b.xtc")
