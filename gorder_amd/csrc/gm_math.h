@@ -287,6 +287,99 @@ __device__ __forceinline__ float gm_sch_axis_acos(float vx, float vy, float vz, 
     const float co = gm_cosf(gm_acosf_t<true>(c));
     return (1.5f * co * co) - 0.5f;
 }
+// ---- the same literal evaluation for TWO frames at a time in packed registers -----------------------------------------
+// v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 do two IEEE f32 operations per lane and instruction; lane 0 / lane 1 of a
+// gm_f2 hold the sample in two consecutive frames.  Every component goes through exactly the operations of the scalar
+// routines above (gm_sqrt_core, gm_div_core, gm_acosf_t<true>, gm_cosf) in the same order, so the bits are the same;
+// compares, selects, the hardware sqrt / rcp seeds and the integer steps are done per component.  The literal mode is
+// bound by VALU issue, not by memory, and about half of its instructions are multiplications, additions and fmas.
+typedef float gm_f2 __attribute__((ext_vector_type(2)));
+typedef int gm_i2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ gm_f2 gm2(float v) { return gm_f2{v, v}; }
+__device__ __forceinline__ gm_f2 gm2_fma(gm_f2 a, gm_f2 b, gm_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ gm_f2 gm2_min_image_step(gm_f2 d, gm_f2 L, gm_i2 &slow) {
+    const gm_f2 half = L / 2.0f;
+    const gm_f2 r = __builtin_elementwise_abs(d) > half ? d - __builtin_elementwise_copysign(L, d) : d;
+    slow |= __builtin_elementwise_abs(r) > half;
+    return r;
+}
+__device__ __forceinline__ gm_f2 gm2_sqrt_core(gm_f2 x) {
+    const gm_f2 s = gm_f2{__builtin_amdgcn_sqrtf(x.x), __builtin_amdgcn_sqrtf(x.y)};
+    const gm_i2 si = __builtin_bit_cast(gm_i2, s);
+    const gm_f2 sm = __builtin_bit_cast(gm_f2, si - 1), sp = __builtin_bit_cast(gm_f2, si + 1);
+    const gm_f2 rm = gm2_fma(-sm, s, x), rp = gm2_fma(-sp, s, x);
+    gm_f2 r = rm <= gm2(0.0f) ? sm : s;
+    r = rp > gm2(0.0f) ? sp : r;
+    return r;
+}
+__device__ __forceinline__ gm_f2 gm2_div_core(gm_f2 n, gm_f2 d) {
+    gm_f2 r = gm_f2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    const gm_f2 e = gm2_fma(-d, r, gm2(1.0f));
+    r = gm2_fma(e, r, r);
+    gm_f2 q = n * r;
+    const gm_f2 e2 = gm2_fma(-d, q, n);
+    q = gm2_fma(e2, r, q);
+    const gm_f2 e3 = gm2_fma(-d, q, n);
+    return gm2_fma(e3, r, q);
+}
+__device__ __forceinline__ gm_f2 gm2_asin_r(gm_f2 z) {
+    gm_f2 p = gm2(0x1.15e1a4p-5f);
+    p = gm2_fma(p, z, gm2(0x1.169f76p-6f));
+    p = gm2_fma(p, z, gm2(0x1.fe10bap-6f));
+    p = gm2_fma(p, z, gm2(0x1.6d55e6p-5f));
+    p = gm2_fma(p, z, gm2(0x1.333448p-4f));
+    p = gm2_fma(p, z, gm2(0x1.555554p-3f));
+    return p;
+}
+__device__ __forceinline__ gm_f2 gm2_acosf_cores(gm_f2 x) {       // gm_acosf_t<true>, |x| <= 1 (the caller's quotient)
+    const gm_f2 ax = __builtin_elementwise_abs(x);
+    const gm_i2 small = ax <= gm2(0.5f);
+    const gm_f2 z = small ? x * x : (gm2(1.0f) - ax) * 0.5f;
+    const gm_f2 r = z * gm2_asin_r(z);
+    const gm_f2 r_small = gm2(GM_PIO2_HI) - (x - (gm2(GM_PIO2_LO) - x * r));
+    const gm_f2 s = gm2_sqrt_core(z);
+    const gm_f2 quo = gm2_div_core(gm2_fma(-s, s, z), s + s);
+    const gm_f2 c = s > gm2(0.0f) ? quo : gm2(0.0f);
+    const gm_f2 w = gm2_fma(s, r, c);
+    const gm_f2 r_pos = 2.0f * (s + w);
+    const gm_f2 r_neg = 2.0f * (gm2(GM_PIO2_HI) - (s + (w - gm2(GM_PIO2_LO))));
+    gm_f2 r_large = x > gm2(0.0f) ? r_pos : r_neg;
+    asm volatile("" : "+v"(r_large));           // (see gm_acosf_t: keep this range's arithmetic out of a branch)
+    return small ? r_small : r_large;
+}
+__device__ __forceinline__ gm_f2 gm2_kcos(gm_f2 r) {
+    const gm_f2 z = r * r;
+    const gm_f2 zl = gm2_fma(r, r, -z);
+    const gm_f2 c = gm2_fma(gm2_fma(gm2(0x1.9bd908p-16f), z, gm2(-0x1.6c12d4p-10f)), z, gm2(0x1.555554p-5f));
+    const gm_f2 hz = 0.5f * z;
+    const gm_f2 w = gm2(1.0f) - hz;
+    return w + ((((gm2(1.0f) - w) - hz) - 0.5f * zl) + z * (z * c));
+}
+__device__ __forceinline__ gm_f2 gm2_ksin(gm_f2 r) {
+    const gm_f2 z = r * r;
+    const gm_f2 s = gm2_fma(gm2_fma(gm2_fma(gm2(0x1.6dbf02p-19f), z, gm2(-0x1.a013acp-13f)), z, gm2(0x1.11110ep-7f)), z,
+                            gm2(-0x1.555556p-3f));
+    return gm2_fma(r * z, s, r);
+}
+__device__ __forceinline__ gm_f2 gm2_cosf(gm_f2 t) {              // gm_cosf
+    const gm_i2 lo = t < gm2(GM_PIO4);
+    const gm_i2 mid = ~lo & (t <= gm2(GM_3PIO4));
+    const gm_f2 rc = lo ? t : (gm2(GM_PI_HI) - t) + gm2(GM_PI_LO);
+    const gm_f2 rs = (gm2(GM_PIO2_HI) - t) + gm2(GM_PIO2_LO);
+    const gm_f2 kc = gm2_kcos(rc);
+    const gm_f2 ks = gm2_ksin(rs);
+    return mid ? ks : (lo ? kc : -kc);
+}
+// gm_sch_axis_acos for the sample in two frames; `rare` gets the lanes' "recompute with the general routine" flags
+template <int AXIS>
+__device__ __forceinline__ gm_f2 gm2_sch_axis_acos(gm_f2 vx, gm_f2 vy, gm_f2 vz, gm_i2 &rare) {
+    const gm_f2 s2 = (vx * vx + vy * vy) + vz * vz;
+    const gm_f2 prod = AXIS == 0 ? vx : (AXIS == 1 ? vy : vz);
+    rare |= ~((s2 >= gm2(0x1p-40f)) & (s2 <= gm2(0x1p+40f)));
+    const gm_f2 c = gm2_div_core(prod, gm2_sqrt_core(s2));
+    const gm_f2 co = gm2_cosf(gm2_acosf_cores(c));
+    return (1.5f * co * co) - 0.5f;
+}
 // gm_tick for a sample that is known not to be NaN (the caller's rare path takes those)
 __device__ __forceinline__ int gm_tick_finite(float s) {
     const double t = (double)s * 1000000.0;

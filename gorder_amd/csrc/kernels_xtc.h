@@ -178,9 +178,14 @@ __global__ __launch_bounds__(256) void k_xtc_scan(const uint8_t *__restrict__ bl
                                                   uint32_t natoms, const int32_t *__restrict__ slot_of, uint32_t n_stop,
                                                   float *__restrict__ out, uint32_t n_out, uint32_t *err, uint32_t *stat,
                                                   uint32_t *short_list, XtcCheckpoint *__restrict__ cp, uint32_t n_chunks) {
+    // the stretch of the frame's stream the wave is looking at, in LDS (a step reads two bytes per lane within
+    // 64 groups of the current one: 320 bytes for groups of 40 bits, 6.4 KB for the widest possible ones)
+    constexpr uint32_t kWin = 8192;
+    __shared__ __attribute__((aligned(16))) uint8_t l_win[4][kWin + 16];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t fr = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (fr >= n_frames) return;                  // (uniform per wave; no workgroup barrier in this kernel)
+    uint8_t *win = l_win[threadIdx.x >> 6];
     const gorder_xtc_frame_t d = frames[fr];
     // the frame's region of the blob: the block rounded up to whole 64-byte pieces plus one piece of zeros
     const unsigned long long region = (((unsigned long long)d.n_bytes + 63ull) & ~63ull) + 64ull;
@@ -221,20 +226,44 @@ __global__ __launch_bounds__(256) void k_xtc_scan(const uint8_t *__restrict__ bl
         if (mine) mycp[c] = XtcCheckpoint{(unsigned long long)pos + (unsigned long long)j * S, atoms + j * A, (uint32_t)smallidx | ((3u * run3) << 8)};
         next_cp += (uint32_t)__popcll(__ballot(mine));
     };
+    uint32_t wbase = 0xffffffffu;    // first byte of the stream in the window (a multiple of 64); nothing loaded yet
+    const unsigned long long region_last16 = bad ? 0ull : region - 16ull;       // the region's last 16 bytes are zeros
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     while (!bad && atoms < n_stop) {
         const uint32_t A = 1u + run3, S = width + 1u + run3 * (uint32_t)smallidx;
-        // groups still wanted: the walk ends with the first group boundary at or behind n_stop atoms
-        const uint32_t k_want = (n_stop - atoms + A - 1u) / A;
+        {   // the window must hold the bytes every lane reads in this step
+            const uint32_t first = pos >> 3;
+            const unsigned long long need_end = (((unsigned long long)pos + width + 63ull * S) >> 3) + 2ull;
+            if (wbase == 0xffffffffu || first < wbase || need_end > (unsigned long long)wbase + kWin) {      // (uniform)
+                wbase = first & ~63u;
+                u32x4 v[kWin / 1024u];
+#pragma unroll
+                for (uint32_t t = 0; t < kWin / 1024u; t++) {
+                    const unsigned long long off = (unsigned long long)wbase + (t * 64u + lane) * 16u;
+                    v[t] = *reinterpret_cast<const u32x4 *>(p + (off < region_last16 ? off : region_last16));
+                }
+#pragma unroll
+                for (uint32_t t = 0; t < kWin / 1024u; t++) *reinterpret_cast<u32x4 *>(win + (t * 64u + lane) * 16u) = v[t];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+        // groups still wanted: the walk ends with the first group boundary at or behind n_stop atoms (an integer division
+        // costs as much as the rest of the step: only near the end)
+        const uint32_t left = n_stop - atoms;
+        const uint32_t k_want = left >= 64u * A ? 64u : (left + A - 1u) / A;
         // lane k: the flag bit of group k and the five bits behind it, IF the groups before it are all like this one
         const unsigned long long fp = (unsigned long long)pos + width + (unsigned long long)lane * S;
         const unsigned long long by64 = fp >> 3;
-        const uint32_t by = by64 < last_byte ? (uint32_t)by64 : last_byte;            // (past the block: its zero padding)
-        const uint32_t two = ((uint32_t)p[by] << 8) | (uint32_t)p[by + 1u];
-        const uint32_t six = by64 < last_byte ? (two >> (10u - ((uint32_t)fp & 7u))) & 63u : 0u;
+        const uint32_t by = (uint32_t)by64 - wbase;                                   // (inside the window by the check above)
+        const uint32_t two = ((uint32_t)win[by] << 8) | (uint32_t)win[by + 1u];
+        const uint32_t six = by64 < last_byte ? (two >> (10u - ((uint32_t)fp & 7u))) & 63u : 0u;     // (past the block: zeros)
         const unsigned long long flagged = __ballot((six & 32u) != 0u && lane < k_want);
         const uint32_t k_flag = flagged ? (uint32_t)__builtin_ctzll(flagged) : 64u;
-        const uint32_t k = min(k_flag, min(k_want, 64u));     // groups without a flag from here on
-        checkpoints(k, S, A);
+        const uint32_t k = min(k_flag, k_want);               // groups without a flag from here on
+        // (a checkpoint falls on one of them only if the last of them starts with enough atoms before it)
+        if (k > 0u && next_cp <= n_chunks && next_cp * kXtcChunk <= atoms + (k - 1u) * A) checkpoints(k, S, A);
         pos += k * S;
         atoms += k * A;
         if (k_flag < 64u && k == k_flag) {      // the group with the flag: its run length and the step of smallidx
@@ -243,7 +272,7 @@ __global__ __launch_bounds__(256) void k_xtc_scan(const uint8_t *__restrict__ bl
             const int is_smaller = (int)(r5 - 3u * q3) - 1;
             run3 = q3;
             const uint32_t A1 = 1u + run3, S1 = width + 6u + run3 * (uint32_t)smallidx;
-            checkpoints(1u, S1, A1);
+            if (next_cp <= n_chunks && next_cp * kXtcChunk <= atoms) checkpoints(1u, S1, A1);
             pos += S1;
             atoms += A1;
             smallidx += is_smaller;
