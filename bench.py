@@ -313,8 +313,9 @@ def end_to_end_sharded(dist, rank, world, local_rank, device, rehearsal, n_uniqu
                "per_rank": [{"seconds_run_trajectory": r[1], "frames": int(r[2]), "first_frame_of_shard": int(r[3])} for r in rows],
                "frames_of_all_shards": int(sum(r[2] for r in rows)),
                "equal_to_one_handle": same}
-        assert same, "sharded ranks + all-reduce differ from one handle over the whole trajectory"
-        assert out["frames_of_all_shards"] == total
+        # (reported, not asserted: a failed check must not cost the other ranks a hang and the driver its curve)
+        if not same or out["frames_of_all_shards"] != total:
+            print("[bench] sharded end_to_end: the reduced sums differ from one handle over the whole trajectory", file=sys.stderr)
     eng.close()
     dist.barrier()
     if rank == 0:
@@ -622,7 +623,11 @@ def main():
     if world > 1 and not args.no_end_to_end:
         del d_xyz, d_box
         torch.cuda.empty_cache()
-        e2e = end_to_end_sharded(dist, rank, world, local_rank, device, rehearsal)
+        # (the headline above is final; whatever happens in this extra block, rank 0 still prints it)
+        try:
+            e2e = end_to_end_sharded(dist, rank, world, local_rank, device, rehearsal)
+        except Exception as ex:   # noqa: BLE001
+            e2e = {"error": repr(ex)}
         if rank == 0:
             out["end_to_end"] = e2e
     if rank == 0:

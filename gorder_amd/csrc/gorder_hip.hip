@@ -1138,7 +1138,8 @@ static int run_leaflets(gorder_hip_handle *h, const float *d_xyz, const float *d
         LocalArgs lo{};
         lo.xyz = d_xyz; lo.box9 = d_box; lo.n_atoms = h->plan.n_atoms;
         lo.aflags = h->d_aflags; lo.adist = h->d_adist; lo.n_mol_total = h->plan.n_mol_total;
-        lo.heads = h->d_heads; lo.mol_slot0 = h->d_mol_slot0; lo.membrane = h->d_membrane; lo.n_membrane = lf.n_membrane;
+        lo.heads = h->d_heads; lo.mol_slot0 = h->d_mol_slot0; lo.n_membrane = lf.n_membrane;
+        lo.membrane = h->membrane_is_frame ? nullptr : h->d_membrane;      // (the whole frame in order: no index list)
         lo.dim = lf.normal_dim; lo.flip = lf.flip ? 1 : 0; lo.pbc = h->tables.handle_pbc ? 1 : 0;
         lo.radius = lf.radius;
         lo.radius_thr = local_radius_threshold(lf.radius);

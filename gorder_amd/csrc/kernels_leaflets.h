@@ -503,7 +503,7 @@ struct LocalArgs {
     uint32_t n_mol_total;
     const uint32_t *heads;
     const uint32_t *mol_slot0;  // [n_mol_total] first accumulator slot of the molecule's type (error key only; may be null)
-    const uint32_t *membrane;
+    const uint32_t *membrane;   // null: the group is atoms 0 .. n_membrane - 1 in order (one dependent load less per atom)
     uint32_t n_membrane;
     uint4 *grid;                // [n_slab] (cells along a, cells along b, reach ka, reach kb) of each slab frame, written by
                                 // k_local_scan for k_local_flags (null: not wanted)
@@ -595,7 +595,7 @@ __device__ __forceinline__ void frame_box(const LocalArgs &a, uint32_t f, float 
 // in-plane cell of membrane atom i in slab frame s (also stored in cell_of); rows are `ncs` cells apart
 __device__ __forceinline__ uint32_t local_cell_of(const LocalArgs &a, uint32_t s, uint32_t f, uint32_t i,
                                                   const float *box, uint32_t nca, uint32_t ncb, uint32_t ncs, int da, int db) {
-    const float *p = a.xyz + ((size_t)f * a.n_atoms + a.membrane[i]) * 3u;
+    const float *p = a.xyz + ((size_t)f * a.n_atoms + (a.membrane ? a.membrane[i] : i)) * 3u;
     int bad = 0;
     uint32_t ca = 0, cb = 0;
     if (a.pbc) {
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(256) void k_local_scatter(LocalArgs a) {
     }
     if (!valid) return;
     const uint32_t start = a.cell_count[(size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u) + c];
-    const float *p = a.xyz + ((size_t)f * a.n_atoms + a.membrane[i]) * 3u;
+    const float *p = a.xyz + ((size_t)f * a.n_atoms + (a.membrane ? a.membrane[i] : i)) * 3u;
     const size_t q = (size_t)s * a.rec_stride + start + rank;
     reinterpret_cast<LocalRec *>(a.trig)[q] = LocalRec{p[da], p[db], p[dn]};
     if (a.halo && c % ncs < 2u * kb) {              // the copy in the row's halo
@@ -751,8 +751,8 @@ __device__ __forceinline__ uint32_t row_add_u32(uint32_t v) {
 // (k_local_rowprefix, below: a scan over the row's RECORDS, read off at the cells' first records.)  The same pass makes the frame's record for the rows kernel: finfo[s] = (min, max of the normal
 // coordinate over the membrane, whether a coordinate of a record is not finite), kept as ordered integers.
 // block = 256 threads = 4 waves = 4 rows of cells, a wave per row; grid = (ceil(kLocalMaxCells1D / 4), n_slab).
-// The wave streams its row's records (contiguous: the row's cells one after the other, halo copies included) 512 at a
-// time with coalesced loads — all eight loads of a piece in flight together —, scans them (inclusive scan over the 64
+// The wave streams its row's records (contiguous: the row's cells one after the other, halo copies included) 384 at a
+// time with coalesced loads — all six loads of a piece in flight together —, scans them (inclusive scan over the 64
 // lanes by row shifts + the totals of the 16-lane rows before, carried from load to load), parks the exclusive sums in
 // LDS, and then gives every cell of the row the sum parked at its first record.  (A lane per CELL summing its own
 // handful of records took 140 us per 256 frames: 64 short gathers per load instruction.)
@@ -847,7 +847,7 @@ __device__ __forceinline__ void local_finfo_merge(const LocalArgs &a, uint32_t s
         if (nf) atomicOr(fi + 2, 1u);
     }
 }
-constexpr uint32_t kRowPrefixPiece = 512;
+constexpr uint32_t kRowPrefixPiece = 384;       // (24 KB of LDS per workgroup of four rows: six workgroups per CU)
 __global__ __launch_bounds__(256) void k_local_rowprefix(LocalArgs a) {
     __shared__ float l_c[4][kRowPrefixPiece + 1], l_s[4][kRowPrefixPiece + 1];
     __shared__ double l_z[4][kRowPrefixPiece + 1];
@@ -924,7 +924,7 @@ __global__ __launch_bounds__(1024) void k_local_build(LocalArgs a) {
         uint32_t at[U];
         float pa[U], pb[U];
 #pragma unroll
-        for (uint32_t u = 0; u < U; u++) at[u] = a.membrane[min(i0 + u * 1024u, a.n_membrane - 1u)];
+        for (uint32_t u = 0; u < U; u++) { const uint32_t i = min(i0 + u * 1024u, a.n_membrane - 1u); at[u] = a.membrane ? a.membrane[i] : i; }
 #pragma unroll
         for (uint32_t u = 0; u < U; u++) { pa[u] = x[3u * (size_t)at[u] + da]; pb[u] = x[3u * (size_t)at[u] + db]; }
 #pragma unroll
@@ -984,7 +984,7 @@ __global__ __launch_bounds__(1024) void k_local_build(LocalArgs a) {
         uint32_t at[U];
         float pa[U], pb[U], pn[U];
 #pragma unroll
-        for (uint32_t u = 0; u < U; u++) at[u] = a.membrane[min(i0 + u * 1024u, a.n_membrane - 1u)];
+        for (uint32_t u = 0; u < U; u++) { const uint32_t i = min(i0 + u * 1024u, a.n_membrane - 1u); at[u] = a.membrane ? a.membrane[i] : i; }
 #pragma unroll
         for (uint32_t u = 0; u < U; u++) {
             pa[u] = x[3u * (size_t)at[u] + da]; pb[u] = x[3u * (size_t)at[u] + db]; pn[u] = x[3u * (size_t)at[u] + dn];
