@@ -206,7 +206,7 @@ def end_to_end(system, device_index, n_unique=500, repeats=200):
     out["file_MB"] = size * repeats / 1e6
     out["path"] = ("XTC file (repo encoder, precision 1000, %d frames read %d x as one concatenated trajectory, encoded in "
                    "%.1f s) -> gorder_hip_run_trajectory.  value: device_decode = host threads copy the compressed blocks "
-                   "(gorder_xtc_pack_window) -> pinned staging x3 -> hipMemcpyAsync -> k_xtc_decode (one frame per lane) "
+                   "(gorder_xtc_pack_window) -> pinned staging x3 -> hipMemcpyAsync -> k_xtc_scan + k_xtc_chunks (a lane per 256-atom chunk) "
                    "-> kernels.  host_decode: gorder_xtc_read_window_mt on the same threads -> pinned -> hipMemcpyAsync "
                    "-> kernels.  Both routes give identical sums (checked)." % (n_unique, repeats, t_write))
     return out

@@ -532,7 +532,7 @@ class HipEngine:
         """The reference's `read_trajectory` (common.rs:239-342) as one library call: read (and concatenate) the
         files, apply the time window / step, decode on `threads` host threads and analyse batch by batch with copies
         and kernels overlapped (gorder_hip_run_trajectory).  `device_decode`: the host threads only copy the compressed
-        XTC blocks, the device unpacks them (one frame per lane).  `shard` = (i, n): analyse only the i-th of n
+        XTC blocks, the device unpacks them (k_xtc_scan + k_xtc_chunks).  `shard` = (i, n): analyse only the i-th of n
         contiguous shares of the selected frames (one rank of a multi-GPU run).  -> the pipeline's statistics."""
         arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
         grp = None if group is None else np.ascontiguousarray(group, dtype=np.uint32)

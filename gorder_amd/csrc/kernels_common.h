@@ -41,7 +41,7 @@ struct FrameArgs {
 //   [37:24] accumulator slot (first slot of the type for its leaflet assignment; clamped to 2^14 - 1)
 //   [23]    0 = leaflet assignment of the type, 1 = order sample
 //   [22:6]  global molecule id (clamped to 2^17 - 1)   [5:4] detail (which atom of the sample / cloud size)
-//   [3:0]   code: gorder_status_t 1..7, 8 = GORDER_ERR_BOX_RANGE, 9 = GORDER_ERR_TRAJECTORY_FORMAT (k_xtc_decode)
+//   [3:0]   code: gorder_status_t 1..7, 8 = GORDER_ERR_BOX_RANGE, 9 = GORDER_ERR_TRAJECTORY_FORMAT (k_xtc_scan)
 // The payload of gorder_hip_last_error_index (an atom index) is resolved on the host from (slot, molecule, detail).
 constexpr unsigned long long kErrNone = ~0ull;
 enum ErrStage : uint32_t { kStageBox = 0, kStageSystem = 1, kStageTypes = 2, kStageEnd = 3 };
@@ -62,7 +62,7 @@ __device__ __forceinline__ void raise_box_range(uint32_t *err, uint32_t frame) {
 }
 
 // End of a batch (stream-ordered behind its kernels): the batch's key — and the key its frames' decoder left in a
-// record of its own (k_xtc_decode of a slot of gorder_hip_run_trajectory runs on another stream, beside the kernels
+// record of its own (the decoder of a slot of gorder_hip_run_trajectory runs on another stream, beside the kernels
 // of the batch before) — becomes THE error of the run if no earlier batch had one.  Keys order errors inside a batch
 // only (frame IN BATCH is their leading field); across batches the order of submission decides, which is the order
 // of the trajectory: the first error as the reference's sequential walk meets it (common.rs:248).

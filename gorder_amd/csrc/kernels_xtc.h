@@ -49,7 +49,7 @@ __device__ const uint32_t kXtcMagic[kXtcLastIdx] = {
     16777216};
 
 struct XtcBits {
-    const unsigned long long *ring;        // this lane's ring of kXtcRingWords stream words in LDS (k_xtc_decode keeps it filled)
+    const unsigned long long *ring;        // this lane's ring of kXtcRingWords stream words in LDS (k_xtc_chunks keeps it filled)
     uint32_t rd;                           // words of the stream handed to the window so far
     unsigned long long w0, w1, pre;        // w0:w1 = the next 128 bits of the stream, MSB first; pre = the raw word behind them
     uint32_t off;                          // bits of w0 already taken

@@ -11,7 +11,7 @@
 // A slot's host buffer is refilled once its copy has completed, its device buffer is overwritten once the kernels
 // that read it have completed (the copy stream waits for that event) — no stream-wide synchronisation anywhere.
 // With gorder_trajectory_t::device_decode the host threads only COPY the compressed blocks (gorder_xtc_pack_window),
-// the slot's own stream carries blob + frame table + boxes to the device and runs k_xtc_decode (one frame per lane)
+// the slot's own stream carries blob + frame table + boxes to the device and runs the decoder (k_xtc_scan + k_xtc_chunks)
 // into the slot's coordinate buffer; the handle's stream waits for that kernel instead of for a copy.
 #pragma once
 

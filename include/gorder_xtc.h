@@ -81,7 +81,7 @@ int64_t gorder_xtc_read_window_mt(gorder_xtc_reader *r, float begin_ps, float en
  * Decoding the bit stream is the dominant cost of reading a trajectory ("optional GPU bit-unpack
  * later").  Instead of decoding, gorder_xtc_pack_window copies the still-compressed coordinate blocks of the selected
  * frames into one caller buffer (`blob`, meant to be pinned host memory) and describes each with a gorder_xtc_frame_t;
- * the device decodes one frame per lane.  Frame selection (time window, step, duplicate boundary frame), `state`,
+ * the device decodes them (a wave per frame finds where chunks of 256 atoms start, a lane per chunk unpacks).  Frame selection (time window, step, duplicate boundary frame), `state`,
  * `last_time`, box and time outputs are exactly those of gorder_xtc_read_window.  XTC only (not TRR / GRO). */
 typedef struct {
     uint64_t offset;         /* of the frame's bit stream in the blob: a multiple of 64; the stream is followed by zeros up to
@@ -124,7 +124,7 @@ int64_t gorder_xtc_pack_window_pool(gorder_xtc_reader *r, float begin_ps, float 
 /* The general form.  `pool` may be NULL (then `n_threads` copying threads, synchronously).  `prefix_q16` < 65536 copies
  * only the leading prefix_q16 / 65536 of every block (+ 2 KB): the analysed atoms come first in a frame and the decoder
  * stops behind them, so the tail — the solvent — need not travel; such a frame has bit 1 of `kind` set and `n_bytes` =
- * the bytes copied, and a decoder that runs past them must report the frame as SHORT, not as corrupt (k_xtc_decode
+ * the bytes copied, and a decoder that runs past them must report the frame as SHORT, not as corrupt (k_xtc_scan
  * does; the trajectory driver then decodes that frame on the host from `file_pos`).  `file_pos` (may be NULL)
  * receives the file offset of every packed frame's header, for gorder_xtc_read_at. */
 int64_t gorder_xtc_pack_window_ex(gorder_xtc_reader *r, float begin_ps, float end_ps, uint32_t step, uint64_t *state,

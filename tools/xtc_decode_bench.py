@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Throughput of k_xtc_decode (XTC frames decompressed on the device, one frame per lane) against the window size,
+"""Throughput of the device XTC decoder (k_xtc_scan + k_xtc_chunks: frames decompressed on the device) against the window size,
 next to the host decoder on all cores.
 
     python tools/xtc_decode_bench.py [workload] [unique_frames] [window,window,...]
