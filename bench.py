@@ -86,6 +86,13 @@ def host_cores():
     return max(1, min(cores_available(), cap))
 
 
+def reader_threads():
+    """Host threads for the trajectory reader (block copies / host decoder): the library's own default, at most 16.  More
+    is slower on a two-socket box: tools/microbench/copy_bench.cpp on the 256-thread EPYC host of an MI355X copies
+    90-147 GB/s out of the page cache with 16 threads, 40-55 with 64, 22-40 with 128."""
+    return max(1, min(cores_available(), 16))
+
+
 def cpu_baseline(system, seconds_target=8.0):
     """Oracle (kind 'port') on the host cores: reference-faithful libm trig, one accumulator clone per thread +
     ordered reduce like groan_rs' traj_iter_map_reduce.  Timed at 1 thread and at all cores."""
@@ -156,7 +163,7 @@ def end_to_end(system, device_index, n_unique=500, repeats=200):
     """The workload from an XTC FILE through gorder_hip_run_trajectory: the repo's encoder writes n_unique synthetic
     frames (precision 1000 like GROMACS), the file is read `repeats` times as one concatenated trajectory."""
     from gorder_amd import HipEngine, xtc
-    cores = host_cores()
+    cores = reader_threads()
     xyz = system.frames(n_unique, seed=4242)
     box = system.box9(n_unique)
     with tempfile.TemporaryDirectory(prefix="gorder_bench_") as tmp:
@@ -217,7 +224,7 @@ def end_to_end_solvated(system, device_index, n_unique=100, repeats=200, water_p
     as many solvent atoms.  The host decoder stops at the last analysed atom; the device route learns from the decoder's
     first report which leading part of every compressed block it needs and copies only that."""
     from gorder_amd import HipEngine, xtc
-    cores = host_cores()
+    cores = reader_threads()
     rng = np.random.default_rng(7)
     n_sel = system.n_atoms
     n_w = water_per_atom * n_sel
