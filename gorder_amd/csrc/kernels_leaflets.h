@@ -1349,9 +1349,13 @@ __device__ __forceinline__ float local_atan2_fast(float y, float x) {
     r = x < 0.0f ? 3.1415927f - r : r;
     return y < 0.0f ? -r : r;
 }
+#ifndef GORDER_ROW_FLIGHT
+#define GORDER_ROW_FLIGHT 4
+#endif
+constexpr uint32_t kRowFlight = GORDER_ROW_FLIGHT;            // iterations of the ring loop whose records are fetched together
 constexpr uint32_t kRowRing = 96;              // ring pieces (<= 8 records each) a head may list (typically ~45)
 __global__ __launch_bounds__(256) void k_local_flags_rows(LocalArgs a) {
-    __shared__ uint2 l_ring[16][kRowRing];
+    __shared__ uint2 l_ring[16][kRowRing + 2u * kRowFlight];      // (the loop below reads past a list's end, and masks)
     const uint32_t lane = threadIdx.x & 63u, row = lane >> 4, sub = lane & 15u;
     const uint32_t wave = threadIdx.x >> 6;
     // Workgroups go to the 8 XCDs round-robin in launch order, and every XCD has an L2 of its own: the heads of ONE frame
@@ -1375,7 +1379,7 @@ __global__ __launch_bounds__(256) void k_local_flags_rows(LocalArgs a) {
     const uint32_t nca = g.x, ncb = g.y, ka = g.z, kb = g.w, ncs = ncb + 2u * kb;
     const int da = (int)((a.dim + 1u) % 3u), db = (int)((a.dim + 2u) % 3u), dn = (int)a.dim;
     const float La = box[da], Lb = box[db], Ln = box[dn];
-    const float halfa = La / 2.0f, halfb = Lb / 2.0f, halfn = Ln / 2.0f, inv_Ln = 1.0f / Ln;
+    const float halfn = Ln / 2.0f;
     const float thr = a.radius_thr;
     const uint32_t n_rows = 2u * ka + 1u;
     const uint32_t *cstart = a.cell_count + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u);
@@ -1398,15 +1402,15 @@ __global__ __launch_bounds__(256) void k_local_flags_rows(LocalArgs a) {
     uint32_t a0 = ha + nca - ka, b0 = hb + ncb - kb;
     a0 -= a0 >= nca ? nca : 0u;
     b0 -= b0 >= ncb ? ncb : 0u;
-    // a head outside the box by more than rounding, or not where its cell says: the general passes decide;
-    // so they do when a member of the frame could need a shift along the normal relative to this head
+    // a head outside the box by more than rounding, or not where its cell says: the general passes decide
     const float ulo_g = z_min - hn_pos, uhi_g = z_max - hn_pos;
     bool redo = !(fa >= -1e-4f * ca && fa <= ca * 1.0001f && fb >= -1e-4f * cb && fb <= cb * 1.0001f) ||
-                !(wa >= 0.0f && wa <= La && wb >= 0.0f && wb <= Lb) || !(ulo_g >= -halfn && uhi_g <= halfn);
+                !(wa >= 0.0f && wa <= La && wb >= 0.0f && wb <= Lb);
 
     // ---- this lane's row of cells: the inner span and the ring runs on either side
-    float sc = 0.0f, ss = 0.0f, su = 0.0f;
-    uint32_t cnt = 0, n_ring = 0;
+    float sc = 0.0f, ss = 0.0f, su = 0.0f;            // (sc, ss: over the cells wholly inside only, see the end)
+    double inner_z = 0.0;
+    uint32_t cnt = 0, n_inner = 0, n_ring = 0;
     uint2 *ring = l_ring[wave * 4u + row];
     uint32_t run_q0[2] = {0u, 0u}, run_q1[2] = {0u, 0u};
     if (!fail && sub < n_rows) {
@@ -1448,9 +1452,10 @@ __global__ __launch_bounds__(256) void k_local_flags_rows(LocalArgs a) {
                 const LocalRowPre p_lo = pre[ra * (ncs + 1u) + b0 + ji_lo], p_hi = pre[ra * (ncs + 1u) + b0 + ji_hi + 1u];
                 const uint32_t n_in = qb0 - qa1;
                 cnt += n_in;
+                n_inner = n_in;
                 sc += p_hi.sc - p_lo.sc;
                 ss += p_hi.ss - p_lo.ss;
-                su += (float)((p_hi.sz - p_lo.sz) - (double)n_in * (double)hn_pos);
+                inner_z = p_hi.sz - p_lo.sz;
             }
             run_q0[0] = qa0; run_q1[0] = qa1;
             run_q0[1] = qb0; run_q1[1] = qb1;
@@ -1466,56 +1471,67 @@ __global__ __launch_bounds__(256) void k_local_flags_rows(LocalArgs a) {
         const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 15), t1 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31);
         const uint32_t t2 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 47), t3 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         n_ring = row == 0u ? t0 : (row == 1u ? t1 : (row == 2u ? t2 : t3));
+        // (a piece = the BYTE offsets of its first record and of the end of its run: the loop below adds a lane's share)
+        constexpr uint32_t kRec = (uint32_t)sizeof(LocalRec);
         uint32_t pos = incl - mine;
         for (uint32_t k = 0; k < p_a; k++, pos++)
-            if (pos < kRowRing) ring[pos] = make_uint2(run_q0[0] + 8u * k, min(run_q1[0], run_q0[0] + 8u * k + 8u));
+            if (pos < kRowRing) ring[pos] = make_uint2((run_q0[0] + 8u * k) * kRec, min(run_q1[0], run_q0[0] + 8u * k + 8u) * kRec);
         for (uint32_t k = 0; k < p_b; k++, pos++)
-            if (pos < kRowRing) ring[pos] = make_uint2(run_q0[1] + 8u * k, min(run_q1[1], run_q0[1] + 8u * k + 8u));
+            if (pos < kRowRing) ring[pos] = make_uint2((run_q0[1] + 8u * k) * kRec, min(run_q1[1], run_q0[1] + 8u * k + 8u) * kRec);
     }
     redo |= n_ring > kRowRing;                                  // the list ran over: the general passes
-    __builtin_amdgcn_wave_barrier();
-    // ---- the ring: two pieces per row and iteration (lanes 0-7 and 8-15), one record per lane; the records of four
-    // iterations are fetched together (eight cost 20 registers more and a wave per SIMD: the kernel waits on memory)
+    // ---- the ring: two pieces per row and iteration (lanes 0-7 and 8-15), one record per lane, the records of
+    // kRowFlight iterations fetched together.  The loop runs to the longest of the wave's four lists; the shorter ones are
+    // filled up with empty pieces, so that a lane's record is in its piece exactly when its offset is below the piece's
+    // end — the only test —, and the records come by buffer loads: 32-bit offsets from one scalar descriptor of this
+    // frame's records, no address arithmetic, and an offset past the frame's last record (the lanes past the end of the
+    // last piece) reads zeros instead of the neighbour's memory.
     uint32_t n_max = max(max((uint32_t)__builtin_amdgcn_readlane((int)n_ring, 0), (uint32_t)__builtin_amdgcn_readlane((int)n_ring, 16)),
                          max((uint32_t)__builtin_amdgcn_readlane((int)n_ring, 32), (uint32_t)__builtin_amdgcn_readlane((int)n_ring, 48)));
     n_max = min(n_max, kRowRing);
-    const uint32_t n_mine = min(n_ring, kRowRing), half = sub >> 3, sub8 = sub & 7u;
-    for (uint32_t t = 0; !fail && t < n_max; t += 8u) {
-        LocalRec r[4];
-        bool v[4];
+    const uint32_t n_mine = min(n_ring, kRowRing), half = sub >> 3, lane_off = (sub & 7u) * (uint32_t)sizeof(LocalRec);
+    const uint32_t n_end = (n_max + 2u * kRowFlight - 1u) / (2u * kRowFlight) * (2u * kRowFlight);
+    for (uint32_t e = n_mine + sub; e < n_end; e += 16u) ring[e] = make_uint2(0u, 0u);
+    __builtin_amdgcn_wave_barrier();
+    const __amdgpu_buffer_rsrc_t rec_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<LocalRec *>(rec), 0, a.rec_stride * (uint32_t)sizeof(LocalRec), 0x00020000);
+    typedef uint32_t u3 __attribute__((ext_vector_type(3)));
+    typedef float f3 __attribute__((ext_vector_type(3)));
+    float t_min = 0.0f;                 // the smallest of the L - |d| seen (negative: a displacement of more than a box)
+    for (uint32_t t = 0; !fail && t < n_max; t += 2u * kRowFlight) {
+        f3 r[kRowFlight];
+        uint2 run[kRowFlight];
+        bool v[kRowFlight];
 #pragma unroll
-        for (uint32_t u = 0; u < 4u; u++) {
-            const uint32_t e = t + 2u * u + half;
-            uint2 run = make_uint2(0u, 0u);
-            if (e < n_mine) run = ring[e];
-            const uint32_t q = run.x + sub8;
-            v[u] = q < run.y;
-            const uint32_t qc = v[u] ? q : 0u;
-            r[u] = rec[qc];
+        for (uint32_t u = 0; u < kRowFlight; u++) run[u] = ring[t + 2u * u + half];
+#pragma unroll
+        for (uint32_t u = 0; u < kRowFlight; u++) {
+            const uint32_t q = run[u].x + lane_off;
+            v[u] = q < run[u].y;
+            r[u] = __builtin_bit_cast(f3, (u3)__builtin_amdgcn_raw_buffer_load_b96(rec_rsrc, (int)q, 0, 0));
         }
 #pragma unroll
-        for (uint32_t u = 0; u < 4u; u++) {
+        for (uint32_t u = 0; u < kRowFlight; u++) {
+            // |d - copysign(L, d)| = L - |d| for |d| > L / 2, and L - |d| < |d| exactly then (L / 2 is exact, the rounding of
+            // the difference monotonic): the one-step minimum image's magnitude is the smaller of the two.
+            // (Lanes without a record test whatever they fetched — a record of the frame, or zeros — and are masked; that
+            // such a record may raise the more-than-a-box flag only sends a head to the general passes needlessly.)
             const float ea = __builtin_fabsf(r[u].x - ha_pos), eb = __builtin_fabsf(r[u].y - hb_pos);
             const float ta = La - ea, tb = Lb - eb;
-            const float ma = ea > halfa ? ta : ea, mb = eb > halfb ? tb : eb;
+            const float ma = __builtin_fminf(ea, ta), mb = __builtin_fminf(eb, tb);
             const bool in = v[u] & (ma * ma + mb * mb < thr);
-            redo |= v[u] & ((ta < 0.0f) | (tb < 0.0f));
-            // (no shift along the normal: the frame's extrema were checked against this head above)
-            float sn, cs;
-            local_trig(r[u].z, inv_Ln, &sn, &cs);
+            t_min = __builtin_fminf(t_min, __builtin_fminf(ta, tb));
             cnt += in ? 1u : 0u;
-            sc += in ? cs : 0.0f;
-            ss += in ? sn : 0.0f;
-            su += in ? r[u].z - hn_pos : 0.0f;
+            su += in ? r[u].z : 0.0f;                   // (the coordinate as it is: see the end)
         }
     }
+    redo |= t_min < 0.0f;
     // ---- per row: totals in lane 15 of the row (row shifts only), then the centre as in the general passes
-    double tu = (double)su;
+    double tu = (double)su + inner_z;
     tu = row_add_f64<0x111>(tu); tu = row_add_f64<0x112>(tu); tu = row_add_f64<0x114>(tu); tu = row_add_f64<0x118>(tu);
-    sc = row_add<0x111>(sc); ss = row_add<0x111>(ss); cnt = row_add_u32<0x111>(cnt);
-    sc = row_add<0x112>(sc); ss = row_add<0x112>(ss); cnt = row_add_u32<0x112>(cnt);
-    sc = row_add<0x114>(sc); ss = row_add<0x114>(ss); cnt = row_add_u32<0x114>(cnt);
-    sc = row_add<0x118>(sc); ss = row_add<0x118>(ss); cnt = row_add_u32<0x118>(cnt);
+    sc = row_add<0x111>(sc); ss = row_add<0x111>(ss); cnt = row_add_u32<0x111>(cnt); n_inner = row_add_u32<0x111>(n_inner);
+    sc = row_add<0x112>(sc); ss = row_add<0x112>(ss); cnt = row_add_u32<0x112>(cnt); n_inner = row_add_u32<0x112>(n_inner);
+    sc = row_add<0x114>(sc); ss = row_add<0x114>(ss); cnt = row_add_u32<0x114>(cnt); n_inner = row_add_u32<0x114>(n_inner);
+    sc = row_add<0x118>(sc); ss = row_add<0x118>(ss); cnt = row_add_u32<0x118>(cnt); n_inner = row_add_u32<0x118>(n_inner);
     const uint64_t redo_mask = __ballot(redo);
     const bool row_redo = ((redo_mask >> (16u * row)) & 0xffffull) != 0ull;
     bool general = fail || row_redo;
@@ -1523,14 +1539,22 @@ __global__ __launch_bounds__(256) void k_local_flags_rows(LocalArgs a) {
         if (cnt == 0u) {
             raise_error(a.err, GORDER_ERR_INVALID_LOCAL_MEMBRANE_CENTER, f, kStageTypes, a.mol_slot0 ? a.mol_slot0[m] : 0u, 0, m);
         } else {
-            // (the estimate only anchors the image choice — est + MI(z_head - est) is z_head's image next to it whatever
-            // its last digits —, so a 1e-5 rad arctangent does)
+            // The reference's estimate (the circular mean of ALL members) only picks, per member, the image next to it;
+            // the centre is the plain mean of those images.  Here the circular mean of the members in the cells wholly
+            // inside stands in for it — prefix sums, no sine and cosine per ring record —, with a bound on how far the
+            // two can lie apart: the resultants differ by the ring members' unit vectors, |R_all - R_inner| <= e = the
+            // number of ring members, so the directions differ by at most asin(e / |R_inner|) <= (pi / 2) e / |R_inner|,
+            // a length of (e / |R_inner|) L / 4 along the normal.  If every coordinate of the frame (a superset of the
+            // members) keeps that distance, and a margin, from the far side of the box as seen from the stand-in, each
+            // member's image next to the reference's estimate is its own coordinate moved by the SAME number of box
+            // lengths, and the centre is the wrapped plain mean.  (The +1 covers the rounding of the f32 prefix
+            // differences, the 1e-5 rad arctangent and the hardware sine / cosine, generously.)
+            const float r_inner = __builtin_amdgcn_sqrtf(sc * sc + ss * ss), e_ring = (float)(cnt - n_inner) + 1.0f;
             const float est = (local_atan2_fast(-ss, -sc) + 3.1415927f) * (Ln * 0.15915494f);
-            const float shift = gm_min_image(hn_pos - est, Ln, bad), margin = 1e-4f * Ln;
-            // every member's image around the head is its image around the estimate as well (the bounds are the frame's
-            // extrema: a superset of the members)
-            if (ulo_g + shift > -halfn + margin && uhi_g + shift < halfn - margin) {
-                const float center = gm_wrap((est + shift) + (float)(tu / (double)cnt), Ln, bad);
+            const float shift = gm_min_image(hn_pos - est, Ln, bad);
+            const float margin = 1e-4f * Ln + e_ring * __builtin_amdgcn_rcpf(r_inner) * (0.2501f * Ln);
+            if (e_ring < r_inner && ulo_g + shift > -halfn + margin && uhi_g + shift < halfn - margin) {
+                const float center = gm_wrap((float)(tu / (double)cnt), Ln, bad);
                 if (center != center) {
                     raise_error(a.err, GORDER_ERR_INVALID_LOCAL_MEMBRANE_CENTER, f, kStageTypes, a.mol_slot0 ? a.mol_slot0[m] : 0u, 0, m);
                 } else {
@@ -1539,7 +1563,7 @@ __global__ __launch_bounds__(256) void k_local_flags_rows(LocalArgs a) {
                     if ((int)s == a.write_dist_frame && a.adist) a.adist[m] = d;
                 }
             } else {
-                general = true;          // a membrane thicker than half the box: the second pass of the general code
+                general = true;          // too thick a membrane for the bound: the general passes
             }
         }
     }
