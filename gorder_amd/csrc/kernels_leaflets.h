@@ -1395,9 +1395,12 @@ __global__ __launch_bounds__(256) void k_local_flags_rows(LocalArgs a) {
     // gm_wrap's first step as selects (a head more than a box length outside leaves [0, L]: the general passes)
     const float wa = ha_pos < 0.0f ? ha_pos + La : (ha_pos > La ? ha_pos - La : ha_pos);
     const float wb = hb_pos < 0.0f ? hb_pos + Lb : (hb_pos > Lb ? hb_pos - Lb : hb_pos);
-    const float ca = La / (float)nca, cb = Lb / (float)ncb;                // cell edges
-    const uint32_t ha = (uint32_t)fminf(fmaxf(floorf(wa / La * (float)nca), 0.0f), (float)(nca - 1u));
-    const uint32_t hb = (uint32_t)fminf(fmaxf(floorf(wb / Lb * (float)ncb), 0.0f), (float)(ncb - 1u));
+    // cell edges and the head's cell by hardware reciprocals (1 ulp): the head may land in the cell next to the one
+    // k_local_build's arithmetic would give when it sits within an ulp of an edge — `fa`, `fb` below then lie that much
+    // outside [0, edge], which the span bounds allow for (1e-3 of a cell) and the test below accepts (1e-4)
+    const float ca = La * __builtin_amdgcn_rcpf((float)nca), cb = Lb * __builtin_amdgcn_rcpf((float)ncb);
+    const uint32_t ha = (uint32_t)fminf(fmaxf(floorf(wa * __builtin_amdgcn_rcpf(ca)), 0.0f), (float)(nca - 1u));
+    const uint32_t hb = (uint32_t)fminf(fmaxf(floorf(wb * __builtin_amdgcn_rcpf(cb)), 0.0f), (float)(ncb - 1u));
     const float fa = wa - (float)ha * ca, fb = wb - (float)hb * cb;        // the head inside its cell
     uint32_t a0 = ha + nca - ka, b0 = hb + ncb - kb;
     a0 -= a0 >= nca ? nca : 0u;
@@ -1473,11 +1476,13 @@ __global__ __launch_bounds__(256) void k_local_flags_rows(LocalArgs a) {
         n_ring = row == 0u ? t0 : (row == 1u ? t1 : (row == 2u ? t2 : t3));
         // (a piece = the BYTE offsets of its first record and of the end of its run: the loop below adds a lane's share)
         constexpr uint32_t kRec = (uint32_t)sizeof(LocalRec);
-        uint32_t pos = incl - mine;
-        for (uint32_t k = 0; k < p_a; k++, pos++)
-            if (pos < kRowRing) ring[pos] = make_uint2((run_q0[0] + 8u * k) * kRec, min(run_q1[0], run_q0[0] + 8u * k + 8u) * kRec);
-        for (uint32_t k = 0; k < p_b; k++, pos++)
-            if (pos < kRowRing) ring[pos] = make_uint2((run_q0[1] + 8u * k) * kRec, min(run_q1[1], run_q0[1] + 8u * k + 8u) * kRec);
+        const uint32_t pos = incl - mine;
+        const uint32_t a_from = run_q0[0] * kRec, a_to = run_q1[0] * kRec, b_from = run_q0[1] * kRec, b_to = run_q1[1] * kRec;
+        for (uint32_t k = 0; k < mine; k++) {          // (one loop over both runs: the wave makes the longest lane's trips)
+            const bool second = k >= p_a;
+            const uint32_t from = (second ? b_from - p_a * (8u * kRec) : a_from) + k * (8u * kRec), to = second ? b_to : a_to;
+            if (pos + k < kRowRing) ring[pos + k] = make_uint2(from, min(to, from + 8u * kRec));
+        }
     }
     redo |= n_ring > kRowRing;                                  // the list ran over: the general passes
     // ---- the ring: two pieces per row and iteration (lanes 0-7 and 8-15), one record per lane, the records of
@@ -1554,7 +1559,12 @@ __global__ __launch_bounds__(256) void k_local_flags_rows(LocalArgs a) {
             const float shift = gm_min_image(hn_pos - est, Ln, bad);
             const float margin = 1e-4f * Ln + e_ring * __builtin_amdgcn_rcpf(r_inner) * (0.2501f * Ln);
             if (e_ring < r_inner && ulo_g + shift > -halfn + margin && uhi_g + shift < halfn - margin) {
-                const float center = gm_wrap((float)(tu / (double)cnt), Ln, bad);
+                // (the quotient by a reciprocal and one Newton step: 2^-52 or so, a division's worth without its cost)
+                const double dc = (double)cnt;
+                double rc = __builtin_amdgcn_rcp(dc);
+                rc = __builtin_fma(__builtin_fma(-dc, rc, 1.0), rc, rc);
+                rc = __builtin_fma(__builtin_fma(-dc, rc, 1.0), rc, rc);
+                const float center = gm_wrap((float)(tu * rc), Ln, bad);
                 if (center != center) {
                     raise_error(a.err, GORDER_ERR_INVALID_LOCAL_MEMBRANE_CENTER, f, kStageTypes, a.mol_slot0 ? a.mol_slot0[m] : 0u, 0, m);
                 } else {
