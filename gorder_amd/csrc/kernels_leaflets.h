@@ -764,7 +764,17 @@ __device__ __forceinline__ void local_row_prefix(const uint32_t *__restrict__ cs
                                                  float *pc, float *ps, double *pz, float &zlo, float &zhi, uint32_t &nf) {
     constexpr uint32_t T = PIECE / 64u;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t qa = cstart[ra * ncs], qb = cstart[(ra + 1u) * ncs];
+    // the row's cell starts first, all of them at once (cell j = lane + 64 i; entry ncs = the end of the row): the record
+    // loads below then depend on ONE round trip, and the cells' read-out at the end of a piece on none
+    constexpr uint32_t CQ = kLocalMaxCells1D / 64u + 1u;
+    uint32_t cq[CQ];
+#pragma unroll
+    for (uint32_t i = 0; i < CQ; i++) cq[i] = lane + 64u * i <= ncs ? cstart[ra * ncs + lane + 64u * i] : 0xffffffffu;
+    const uint32_t qa = (uint32_t)__builtin_amdgcn_readfirstlane((int)cq[0]);
+    uint32_t qb = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < CQ; i++)
+        if ((ncs >> 6) == i) qb = (uint32_t)__shfl((int)cq[i], (int)(ncs & 63u), 64);       // (uniform)
     float carry_c = 0.0f, carry_s = 0.0f;
     double carry_z = 0.0;
     for (uint32_t base = qa; base < qb || base == qa; base += PIECE) {
@@ -818,9 +828,10 @@ __device__ __forceinline__ void local_row_prefix(const uint32_t *__restrict__ cs
         // the cells whose first record lies in this piece (a cell that starts where the piece ends belongs to the next
         // piece — or, behind the row's last record, to this one)
         const bool last = base + n_here >= qb;
-        for (uint32_t j = lane; j <= ncs; j += 64u) {
-            const uint32_t q0 = j < ncs ? cstart[ra * ncs + j] : qb;
-            if (q0 >= base && (q0 < base + n_here || (last && q0 == qb))) {
+#pragma unroll
+        for (uint32_t i = 0; i < CQ; i++) {
+            const uint32_t j = lane + 64u * i, q0 = cq[i];
+            if (j <= ncs && q0 >= base && (q0 < base + n_here || (last && q0 == qb))) {
                 LocalRowPre o;
                 o.sc = pc[q0 - base]; o.ss = ps[q0 - base]; o.sz = pz[q0 - base];
                 out[j] = o;
@@ -847,7 +858,9 @@ __device__ __forceinline__ void local_finfo_merge(const LocalArgs &a, uint32_t s
         if (nf) atomicOr(fi + 2, 1u);
     }
 }
-constexpr uint32_t kRowPrefixPiece = 384;       // (24 KB of LDS per workgroup of four rows: six workgroups per CU)
+// (pieces of 128 to 640 records — 8 to 41 KB of LDS per workgroup — all take 87-89 us per 256 frames of the 3072-lipid
+// membrane: neither the waves in flight nor the round trips per row bound this kernel; 256 keeps the LDS small)
+constexpr uint32_t kRowPrefixPiece = 256;
 __global__ __launch_bounds__(256) void k_local_rowprefix(LocalArgs a) {
     __shared__ float l_c[4][kRowPrefixPiece + 1], l_s[4][kRowPrefixPiece + 1];
     __shared__ double l_z[4][kRowPrefixPiece + 1];
