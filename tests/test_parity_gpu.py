@@ -569,6 +569,30 @@ def test_local_leaflets_membrane_thicker_than_half_the_box(built):
         np.testing.assert_array_equal(got.sums, want.sums)
 
 
+@pytest.mark.parametrize("box_z,amplitude", [(7.0, 0.0), (8.4, 0.6), (10.0, 1.2), (14.0, 2.5), (9.0, 2.0)])
+def test_local_leaflets_of_an_undulating_membrane(built, box_z, amplitude):
+    """k_local_flags_rows takes the circular mean of the cells wholly inside a head's cylinder as a stand-in for the
+    reference's estimate and bounds the distance between the two (kernels_leaflets.h); whether the bound holds (a thin
+    water layer or a strongly bent membrane: it does not, and the general passes decide) must not show in the flags."""
+    system = synthetic.cg_membrane(400, leaflets=LEAFLETS_LOCAL, radius=2.0, n_types=2, box=(16.0, 16.0, box_z))
+    n = 5
+    xyz = system.frames(n, seed=31)
+    wave = amplitude * np.sin(2 * np.pi * xyz[:, :, 0] / 16.0) * np.cos(2 * np.pi * xyz[:, :, 1] / 16.0)
+    xyz[:, :, 2] = (xyz[:, :, 2] + wave + 0.37).astype(np.float32)        # (not wrapped: some atoms may leave the box)
+    eng, got = run_gpu(system, xyz, system.box9(n), batches=2)
+    o, want = run_oracle(system, xyz, system.box9(n))
+    flags, _ = eng.leaflets()
+    oflags, odist, _ = o.leaflets()
+    diff = flags != oflags
+    assert not diff.any() or np.abs(odist[diff]).max() < 1e-4
+    np.testing.assert_allclose(eng.leaflet_distances()[~diff], odist[~diff], atol=5e-5)
+    assert 0 < flags.sum() < len(flags)
+    assert_sums_given_device_flags(system.tables, xyz, system.box9(n), got)
+    if not diff.any():
+        np.testing.assert_array_equal(got.sums, want.sums)
+        np.testing.assert_array_equal(got.counts, want.counts)
+
+
 def test_independent_handles_interleaved_and_threaded(built):
     """A handle is thread-compatible like one SystemTopology clone (topology/mod.rs:256-278): several handles, each
     with its own stream, fed from different host threads at the same time, do not disturb each other."""
