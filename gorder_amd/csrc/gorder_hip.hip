@@ -79,7 +79,7 @@ struct gorder_hip_handle {
     gorder::MapRun *d_ua_runs = nullptr, *d_runs = nullptr;
     uint32_t *d_ua_run_begin = nullptr, *d_run_begin = nullptr;
     Item *d_items_by_slot = nullptr;
-    uint32_t *d_item_run = nullptr, *d_ua_item_run = nullptr;
+    uint32_t *d_ua_item_run = nullptr;
     uint4 *d_lgrid = nullptr;       // per slab frame: the cell grid of the local-leaflet kernels
     LocalRowPre *d_lrowpre = nullptr;   // per slab frame: prefix sums along the rows of cells (k_local_rowprefix)
     float4 *d_lfinfo = nullptr;     // per slab frame: extrema of the membrane's normal coordinate, finite flag
@@ -538,7 +538,7 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
                 b.n_frames = hi;
                 b.frames_per_chunk = fpc;
                 e.map_rec = staged ? h->d_map_rec : nullptr;
-                e.item_run = pass == 0 ? h->d_item_run : h->d_ua_item_run;
+                e.item_run = pass == 0 ? nullptr : h->d_ua_item_run;      // (bond tiles: a lane's words are its own, rec_store)
                 e.rec_frame0 = lo;
                 e.rec_stride = (nf + 15u) / 16u * 16u;
                 const dim3 g(pass == 0 ? nt * n_chunks : (nt * n_chunks + 7u) / 8u * 8u), blk(kBlock);   // united atoms: see the XCD mapping in k_ua_extras
@@ -548,9 +548,39 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
     hipLaunchKernelGGL((k_bonds_extras<AC, MO>), g, blk, 0, h->stream, b, e, b.xyz, b.box9, b.aflags, b.arow,       \
                        h->d_tiles, items, h->d_tile_slots, nt)
                     const bool maps_only = staged && !e.tw && !e.geom_kind && !e.dyn;
-                    name("k_bonds_extras");
-                    if (maps_only) { if (ac) GORDER_LAUNCH_BONDS(true, true); else GORDER_LAUNCH_BONDS(false, true); }
+                    // maps and nothing else, the default cosine, four frames per stage: the tiled kernel with the staged
+                    // words as a second output (k_bonds_tiled_maps)
+                    const bool tiled_maps = maps_only && !ac && !h->use_gather && h->frames_per_stage == (int)kRecFrames &&
+                                            !env_flag("GORDER_HIP_MAPS_GATHER");
+#define GORDER_LAUNCH_TM_A(NPF_, PBC_, LF_, AX_)                                                                   \
+    hipLaunchKernelGGL((k_bonds_tiled_maps<NPF_, PBC_, LF_, AX_>), g, blk, h->lds_bytes, h->stream, b, e, b.xyz, b.box9, \
+                       b.aflags, b.arow, h->d_tiles, items, h->d_tile_slots, nt, h->lw)
+#define GORDER_LAUNCH_TM_V(NPF_, PBC_, LF_)                                                                        \
+    do {                                                                                                            \
+        if (h->axis == 2) GORDER_LAUNCH_TM_A(NPF_, PBC_, LF_, 2);                                                   \
+        else if (h->axis == 1) GORDER_LAUNCH_TM_A(NPF_, PBC_, LF_, 1);                                              \
+        else if (h->axis == 0) GORDER_LAUNCH_TM_A(NPF_, PBC_, LF_, 0);                                              \
+        else GORDER_LAUNCH_TM_A(NPF_, PBC_, LF_, -1);                                                               \
+    } while (0)
+#define GORDER_LAUNCH_TM(NPF_)                                                                                     \
+    do {                                                                                                            \
+        switch ((b.pbc ? 2 : 0) | (b.leaflets ? 1 : 0)) {                                                           \
+            case 0: GORDER_LAUNCH_TM_V(NPF_, false, false); break;                                                  \
+            case 1: GORDER_LAUNCH_TM_V(NPF_, false, true); break;                                                   \
+            case 2: GORDER_LAUNCH_TM_V(NPF_, true, false); break;                                                   \
+            default: GORDER_LAUNCH_TM_V(NPF_, true, true); break;                                                   \
+        }                                                                                                           \
+    } while (0)
+                    name(tiled_maps ? "k_bonds_tiled_maps" : "k_bonds_extras");
+                    if (tiled_maps) {
+                        if ((3u * p.max_window + 6u) / 4u <= 4u * 64u && !env_flag("GORDER_HIP_NPF5")) GORDER_LAUNCH_TM(4);
+                        else GORDER_LAUNCH_TM(5);
+                    }
+                    else if (maps_only) { if (ac) GORDER_LAUNCH_BONDS(true, true); else GORDER_LAUNCH_BONDS(false, true); }
                     else { if (ac) GORDER_LAUNCH_BONDS(true, false); else GORDER_LAUNCH_BONDS(false, false); }
+#undef GORDER_LAUNCH_TM
+#undef GORDER_LAUNCH_TM_V
+#undef GORDER_LAUNCH_TM_A
 #undef GORDER_LAUNCH_BONDS
                 } else {
 #define GORDER_LAUNCH_UA(AC, MODE)                                                                                \
@@ -569,12 +599,16 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
                         const uint32_t planes = h->tables.leaflets.method != GORDER_LEAFLETS_NONE ? 2u : 1u;
                         const uint32_t ntm = h->map_nx * h->map_ny, n_words = planes * ntm;
                         // enough blocks for ~2 per CU; a block flushes <= n_words atomics, so keep its chunk long
-                        uint32_t mchunks = std::max(1u, 512u / std::max(1u, p.n_acc));
+                        // bonds: a lane per molecule of the slot (256 threads do for the slots of one molecule type of up to
+                        // 256 molecules), so more, shorter chunks; united atoms: the whole block strides over long runs
+                        const uint32_t mthreads = 1024u;
+                        uint32_t mchunks = std::max(1u, (pass == 0 ? 512u : 512u) / std::max(1u, p.n_acc));
+                        if (const char *ev = getenv("GORDER_HIP_MAP_CHUNKS")) mchunks = (uint32_t)std::max(1, atoi(ev));
                         mchunks = std::min(mchunks, std::max(1u, nf / 16u));
                         const uint32_t mfpc = ((nf + mchunks - 1) / mchunks + 15u) / 16u * 16u;   // whole frame blocks
                         mchunks = (nf + mfpc - 1) / mfpc;
                         name("k_map_accumulate");
-                        hipLaunchKernelGGL(k_map_accumulate, dim3(p.n_acc * mchunks), dim3(1024),
+                        hipLaunchKernelGGL(k_map_accumulate, dim3(p.n_acc * mchunks), dim3(mthreads),
                                            n_words * sizeof(unsigned long long), h->stream, h->d_map_rec,
                                            pass == 0 ? h->d_runs : h->d_ua_runs, pass == 0 ? h->d_run_begin : h->d_ua_run_begin,
                                            p.n_acc, nf, e.rec_stride, mfpc, pass == 0 ? 1u : 3u, n_words, ntm, h->d_map_packed,
@@ -834,7 +868,6 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
                 if ((st = upload(h, &h->d_runs, p.runs)) != GORDER_OK) return st;
                 if ((st = upload(h, &h->d_run_begin, p.run_begin)) != GORDER_OK) return st;
                 if ((st = upload(h, &h->d_items_by_slot, p.items_by_slot)) != GORDER_OK) return st;
-                if ((st = upload(h, &h->d_item_run, p.item_run)) != GORDER_OK) return st;
                 if ((st = upload(h, &h->d_ua_item_run, p.ua_item_run)) != GORDER_OK) return st;
                 HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_map_accumulate),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -1043,7 +1076,7 @@ void gorder_hip_destroy(gorder_hip_handle *h) {
     (void)hipFree(h->d_geom_group); (void)hipFree(h->d_shapes);
     (void)hipFree(h->d_map_rec); (void)hipFree(h->d_ua_runs); (void)hipFree(h->d_ua_run_begin);
     (void)hipFree(h->d_runs); (void)hipFree(h->d_run_begin); (void)hipFree(h->d_items_by_slot);
-    (void)hipFree(h->d_item_run); (void)hipFree(h->d_ua_item_run); (void)hipFree(h->d_lgrid); (void)hipFree(h->d_lrowpre); (void)hipFree(h->d_lfinfo); (void)hipFree(h->d_ltodo);
+    (void)hipFree(h->d_ua_item_run); (void)hipFree(h->d_lgrid); (void)hipFree(h->d_lrowpre); (void)hipFree(h->d_lfinfo); (void)hipFree(h->d_ltodo);
     (void)hipFree(h->d_dyn_cloud); (void)hipFree(h->d_dyn_heads); (void)hipFree(h->d_dyn_cell_of); (void)hipFree(h->d_dyn_count);
     (void)hipFree(h->d_dyn_rec); (void)hipFree(h->d_dyn_normals);
     if (!h->acc_external) (void)hipFree(h->d_acc);

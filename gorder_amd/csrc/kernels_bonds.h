@@ -5,6 +5,37 @@
 
 namespace {
 
+// groan_rs GridMap::get_mut_at: nearest tile centre, None outside (oracle: gridmap_index)
+// `core`: the bin width lies in [2^-40, 2^40] (checked once on the host), so the quotient can come from the Newton
+// core of the IEEE division (gm_div_core): a numerator small or large enough for v_div_scale to matter gives a tile
+// index of 0 or none either way.  The reciprocal refinement is loop-invariant (one bin width for all samples).
+__device__ __forceinline__ int grid_index(float x, float lo, float bin, uint32_t n, bool core) {
+    const float k = __builtin_roundf(core ? gm_div_core(x - lo, bin) : (x - lo) / bin);
+    if (!(k >= 0.0f) || !(k < (float)n)) return -1;
+    return (int)k;
+}
+// Ordermap samples out of the tiled kernel (k_bonds_tiled_maps, kernels_extras.h): the grid of the map and this
+// thread's words of the stage's kRecFrames frames.
+constexpr uint32_t kRecFrames = 4;               // frames per block of the bond tiles' staging layout = frames of a stage
+struct TiledMapOut {
+    uint32_t plane;                  // 0 xy, 1 xz, 2 yz -> (z, y)
+    float x0, y0, binx, biny;
+    uint32_t nx, ny;
+    int bin_core;
+    unsigned long long *words;
+};
+// the staged word of one sample: (plane-of-leaflet * tiles + tile) << 32 | tick, or kMapNoSample outside the map
+__device__ __forceinline__ unsigned long long map_sample_word(const TiledMapOut &mo, float px, float py, float pz, int tick, bool lower) {
+    float x, y;
+    if (mo.plane == 0) { x = px; y = py; }
+    else if (mo.plane == 1) { x = px; y = pz; }
+    else { x = pz; y = py; }
+    const int ix = grid_index(x, mo.x0, mo.binx, mo.nx, mo.bin_core != 0), iy = grid_index(y, mo.y0, mo.biny, mo.ny, mo.bin_core != 0);
+    if (ix < 0 || iy < 0) return kMapNoSample;
+    const uint32_t nt = mo.nx * mo.ny, t = (uint32_t)ix * mo.ny + (uint32_t)iy;
+    return ((unsigned long long)((lower ? nt : 0u) + t) << 32) | (unsigned long long)(uint32_t)tick;
+}
+
 // ---- one bond sample (bond.rs:407-443) -----------------------------------------------------
 constexpr uint32_t kNoNan = 0xffffffffu;   // "this sample has met no undefined position yet"
 struct SampleAcc {
@@ -16,7 +47,7 @@ struct SampleAcc {
 template <bool ACOS_COS>
 __device__ __forceinline__ bool bond_sample(const FrameArgs &a, uint32_t f, float p1x, float p1y, float p1z,
                                             float p2x, float p2y, float p2z, uint32_t mol, SampleAcc &acc,
-                                            int &bad) {
+                                            int &bad, const TiledMapOut *mo = nullptr, unsigned long long *word = nullptr) {
     float vx = p2x - p1x, vy = p2y - p1y, vz = p2z - p1z;
     if (a.pbc) {
         const float *b = a.box9 + 9 * (size_t)f;
@@ -37,13 +68,16 @@ __device__ __forceinline__ bool bond_sample(const FrameArgs &a, uint32_t f, floa
     const long long tick = gm_tick(sch);
     acc.s_tot += tick;
     acc.n_tot += 1;
+    bool lower = false;
     if (a.leaflets) {
         const uint8_t fl = a.aflags[(size_t)a.arow[f] * a.n_mol_total + mol];
+        lower = fl != 0;
         if (fl == 0) {   // Leaflet::Upper = 0 (lib.rs:416-422)
             acc.s_up += tick;
             acc.n_up += 1;
         }
     }
+    if (mo) *word = map_sample_word(*mo, p1x + vx / 2.0f, p1y + vy / 2.0f, p1z + vz / 2.0f, (int)tick, lower);   // bond position = p1 + v / 2 (bond.rs:422)
     return sch != sch;
 }
 
@@ -104,14 +138,21 @@ struct TiledStage {
     // The common path is straight-line code (selects only) so that the G independent dependency chains
     // interleave; the rare cases (atoms more than 1.5 box lengths apart -> literal minimum-image loops;
     // NaN result -> which atom is undefined?) are collected in a bit mask and handled after the stage.
-    template <int NF>
+    template <int NF, bool MAPS = false>
     static __device__ __forceinline__ void compute_core(const FrameArgs &a, const Tile &t, const Item &it,
                                                         uint32_t f0, const float (&P)[NF][6], SampleAcc &acc,
-                                                        int &bad, uint32_t &nan_which, uint32_t &nan_frame) {
+                                                        int &bad, uint32_t &nan_which, uint32_t &nan_frame,
+                                                        const TiledMapOut *mo = nullptr, uint32_t k0 = 0) {
         int tick[NF];
         uint8_t fl[NF];
         float bx[NF], by[NF], bz[NF];
         uint32_t rare = 0;
+        // MAPS: the sample's word (bond position = p1 + v / 2, bond.rs:422, v the SIGNED minimum-image vector) goes to
+        // this thread's word of frame k0 + k of the stage as soon as its tick is known
+        auto stage_word = [&](int k, float vx, float vy, float vz) {
+            mo->words[k0 + (uint32_t)k] =
+                map_sample_word(*mo, P[k][0] + vx / 2.0f, P[k][1] + vy / 2.0f, P[k][2] + vz / 2.0f, tick[k], LEAF && fl[k] != 0);
+        };
         // uniform per-frame inputs of the whole stage first (scalar loads, issued back to back)
 #pragma unroll
         for (int k = 0; k < NF; k++) {
@@ -147,7 +188,7 @@ struct TiledStage {
         for (int k = 0; k < NF; k++) {
             float vx = P[k][3] - P[k][0], vy = P[k][4] - P[k][1], vz = P[k][5] - P[k][2];
             bool slow = false;
-            if (PBC && AXIS >= 0 && !ACOS_COS) {
+            if (PBC && AXIS >= 0 && !ACOS_COS && !MAPS) {
                 // only squares are taken below, so magnitudes are enough: |dx - copysign(L, dx)| = |L - |dx|| bit for
                 // bit.  One shift suffices while |dx| <= L (then L - |dx| >= 0 and <= L/2): a negative L - |dx| in any
                 // dimension sends the sample to the literal loops (a superset of gm_min_image_step's `slow`).
@@ -176,6 +217,7 @@ struct TiledStage {
                 rare |= ((slow || nonfinite || sch != sch) ? 1u : 0u) << k;
                 tick[k] = gm_tick(sch);
             }
+            if (MAPS) stage_word(k, vx, vy, vz);
         }
         if (__builtin_expect(rare != 0, 0)) {
 #pragma unroll
@@ -189,6 +231,7 @@ struct TiledStage {
                 }
                 const float sch = gm_calc_sch<ACOS_COS>(vx, vy, vz, a.nx, a.ny, a.nz, a.n2, a.n2sq);
                 tick[k] = gm_tick(sch);
+                if (MAPS) stage_word(k, vx, vy, vz);
                 if (sch != sch && nan_frame == kNoNan) {   // the FIRST undefined position this sample meets (bond.rs:410-416)
                     if (P[k][0] != P[k][0]) { nan_which = 0; nan_frame = f0 + k; }
                     else if (P[k][3] != P[k][3]) { nan_which = 1; nan_frame = f0 + k; }
@@ -211,11 +254,13 @@ struct TiledStage {
         acc.n_up += nu;
     }
     // LDS-staged variant: pick my two atoms out of the staged windows
+    template <bool MAPS = false>
     static __device__ __forceinline__ void compute(const FrameArgs &a, const Tile &t, const Item &it, uint32_t f0,
                                                    const float *lds, uint32_t lw, SampleAcc &acc, int &bad,
-                                                   uint32_t &nan_which, uint32_t &nan_frame) {
+                                                   uint32_t &nan_which, uint32_t &nan_frame, const TiledMapOut *mo = nullptr) {
         // NF frames at a time: NF independent dependency chains interleave; fewer live registers than all G at once
-        constexpr int NF = GORDER_COMPUTE_NF < G ? GORDER_COMPUTE_NF : G;
+        // (with the map words two at a time: four chains and their tile arithmetic do not fit the 128 registers)
+        constexpr int NF = MAPS ? 2 : (GORDER_COMPUTE_NF < G ? GORDER_COMPUTE_NF : G);
 #pragma unroll
         for (int h = 0; h < G; h += NF) {
             float P[NF][6];
@@ -226,14 +271,31 @@ struct TiledStage {
                 P[k][0] = w[3u * it.li]; P[k][1] = w[3u * it.li + 1]; P[k][2] = w[3u * it.li + 2];
                 P[k][3] = w[3u * it.lj]; P[k][4] = w[3u * it.lj + 1]; P[k][5] = w[3u * it.lj + 2];
             }
-            compute_core<NF>(a, t, it, f0 + h, P, acc, bad, nan_which, nan_frame);
+            compute_core<NF, MAPS>(a, t, it, f0 + h, P, acc, bad, nan_which, nan_frame, mo, (uint32_t)h);
         }
     }
     // partial last stage: frames f0 .. f_end-1, one at a time (not performance relevant)
+    template <bool MAPS = false>
     static __device__ __forceinline__ void compute_tail(const FrameArgs &a, const Tile &t, const Item &it,
                                                         uint32_t f0, uint32_t f_end, const float *lds, uint32_t lw,
                                                         SampleAcc &acc, int &bad, uint32_t &nan_which,
-                                                        uint32_t &nan_frame) {
+                                                        uint32_t &nan_frame, const TiledMapOut *mo = nullptr) {
+        if (MAPS) {     // (unrolled: the words stay in registers)
+#pragma unroll
+            for (int k = 0; k < G; k++) {
+                const uint32_t f = f0 + (uint32_t)k;
+                if (f >= f_end) continue;
+                const uint32_t sh = (uint32_t)((((size_t)f * a.n_atoms + t.atom0) * 3u) & 3u);
+                const float *w = lds + (size_t)k * lw + sh;
+                const float p1x = w[3u * it.li], p1y = w[3u * it.li + 1], p1z = w[3u * it.li + 2];
+                const float p2x = w[3u * it.lj], p2y = w[3u * it.lj + 1], p2z = w[3u * it.lj + 2];
+                if (bond_sample<ACOS_COS>(a, f, p1x, p1y, p1z, p2x, p2y, p2z, it.mol, acc, bad, mo, mo->words + k) && nan_frame == kNoNan) {
+                    if (p1x != p1x) { nan_which = 0; nan_frame = f; }
+                    else if (p2x != p2x) { nan_which = 1; nan_frame = f; }
+                }
+            }
+            return;
+        }
 #pragma unroll 1
         for (uint32_t f = f0; f < f_end; f++) {
             const uint32_t sh = (uint32_t)((((size_t)f * a.n_atoms + t.atom0) * 3u) & 3u);

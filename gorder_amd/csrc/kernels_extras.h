@@ -18,12 +18,15 @@ struct ExtraArgs {
     float x0, y0, binx, biny;
     uint32_t nx, ny;
     unsigned long long *map_packed;  // [leaflets ? 2 : 1][n_acc][nx*ny] packed (count << 42) + sum, see k_fold_maps
-    // sample staging (k_map_accumulate), or null.  The `n` lanes of a tile that hold the molecules of one slot (a
-    // MapRun, from lane tid0) own the words [((tile * K + k) * kBlock + tid0) * rec_stride ...) laid out
-    // [frame - rec_frame0][n]: what one slot reads back is one contiguous piece per run (K = 1 bonds, 3 united atoms).
-    // Bond tiles (runs of a few lanes only) block the frames by kRecFrames instead: a tile's words of one block of
-    // frames are contiguous, [frame block][tid0 * kRecFrames + (frame in block) * n + lane in run] — written as whole
-    // rows after a transposition in LDS, read back as pieces of kRecFrames * n words.
+    // sample staging (k_map_accumulate), or null: 64-bit words (plane-tile << 32 | tick), kMapNoSample where a lane has
+    // no sample.  The `n` lanes of a tile that hold the molecules of one slot (a MapRun, from lane tid0) own contiguous
+    // pieces.  United atoms (K = 3 hydrogens): the words [((tile * K + k) * kBlock + tid0) * rec_stride ...) laid out
+    // [frame - rec_frame0][n].  Bond tiles block the frames by kRecFrames = 4: a tile's words of one block of frames are
+    // [frame block][lane][frame in block] — a thread writes its own four samples of a stage, 32 bytes, no transposition —
+    // and a run's piece of a frame block the kRecFrames * n words from kRecFrames * tid0 (128 bytes for the four molecules
+    // a tile of the 256-lipid membrane holds per slot: whole cache lines for the reader).
+    // (Five-byte samples — a 32-bit word and a byte in a second array — were tried: the producer gained 20 us per 3000
+    // frames, the reader lost 50: its pieces fell below the 128-byte line)
     unsigned long long *map_rec;
     const uint32_t *item_run;        // per item: (tid0 << 16) | n
     uint32_t rec_frame0, rec_stride; // rec_stride: words per lane = frames of the sub-range rounded up to 16
@@ -63,16 +66,6 @@ __device__ __forceinline__ bool geom_inside(const ExtraArgs &e, const float *sh,
         in = __builtin_sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) < sh[6];
     }
     return in != (e.geom_invert != 0);
-}
-
-// groan_rs GridMap::get_mut_at: nearest tile centre, None outside (oracle: gridmap_index)
-// `core`: the bin width lies in [2^-40, 2^40] (checked once on the host), so the quotient can come from the Newton
-// core of the IEEE division (gm_div_core): a numerator small or large enough for v_div_scale to matter gives a tile
-// index of 0 or none either way.  The reciprocal refinement is loop-invariant (one bin width for all samples).
-__device__ __forceinline__ int grid_index(float x, float lo, float bin, uint32_t n, bool core) {
-    const float k = __builtin_roundf(core ? gm_div_core(x - lo, bin) : (x - lo) / bin);
-    if (!(k >= 0.0f) || !(k < (float)n)) return -1;
-    return (int)k;
 }
 
 // BondLike::add_order for the scatter targets (bond.rs:184-215): maps and the per-frame LDS partials
@@ -130,22 +123,17 @@ __device__ __forceinline__ void extras_flush_tw(const FrameArgs &a, const ExtraA
     }
 }
 
-constexpr uint32_t kRecFrames = 4;               // frames per block of the bond tiles' staging layout
-constexpr uint32_t kRecPitch = kBlock + 4;       // LDS row pitch in words (the flush reads columns)
 
-// The staged samples of one block of <= kRecFrames frames (frames f_first .. f_first + c) from LDS to the blocked layout
-// described at ExtraArgs::map_rec: whole rows, the runs of a slot contiguous.  l_rec[frame in block][lane], l_run[lane].
-__device__ __forceinline__ void rec_flush(const ExtraArgs &e, uint32_t tile_id, uint32_t f_first, uint32_t c, uint32_t tid,
-                                          const unsigned long long *l_rec, const uint32_t *l_run) {
-    unsigned long long *row = e.map_rec + (size_t)tile_id * kBlock * e.rec_stride +
-                              (size_t)((f_first - e.rec_frame0) / kRecFrames) * (kRecFrames * kBlock);
-#pragma unroll
-    for (uint32_t m = 0; m < kRecFrames; m++) {
-        const uint32_t w = tid + kBlock * m, run = l_run[w / kRecFrames];
-        const uint32_t tid0 = run >> 16, n = run & 0xffffu, rem = w - kRecFrames * tid0;
-        const uint32_t cc = (rem >= n ? 1u : 0u) + (rem >= 2u * n ? 1u : 0u) + (rem >= 3u * n ? 1u : 0u);
-        row[w] = cc <= c ? l_rec[cc * kRecPitch + tid0 + (rem - cc * n)] : kMapNoSample;
-    }
+// A thread's staged samples of one block of kRecFrames frames (from frame f_first; kMapNoSample where there is none) to
+// the blocked layout described at ExtraArgs::map_rec: 32 bytes of its own.
+__device__ __forceinline__ void rec_store(const ExtraArgs &e, uint32_t tile_id, uint32_t f_first, uint32_t tid,
+                                          const unsigned long long (&v)[kRecFrames]) {
+    static_assert(kRecFrames == 4, "a thread's four words");
+    typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+    ull2 *row = reinterpret_cast<ull2 *>(e.map_rec + (size_t)tile_id * kBlock * e.rec_stride +
+                                         (size_t)((f_first - e.rec_frame0) / kRecFrames) * (kRecFrames * kBlock) + (size_t)tid * kRecFrames);
+    __builtin_nontemporal_store(ull2{v[0], v[1]}, row);               // (written once, read once by k_map_accumulate)
+    __builtin_nontemporal_store(ull2{v[2], v[3]}, row + 1);
 }
 
 // MAPS_ONLY: staged ordermap samples and nothing else (no geometry selection, timewise rows, per-molecule normals)
@@ -161,8 +149,6 @@ __global__ __launch_bounds__(kBlock) void k_bonds_extras(FrameArgs a_in, ExtraAr
     __shared__ uint32_t l_n[2 * kBlock];
     __shared__ int l_tw[MAPS_ONLY ? 1 : 3 * kBlock];
     __shared__ uint32_t l_twn[MAPS_ONLY ? 1 : 3 * kBlock];
-    __shared__ unsigned long long l_rec[kRecFrames * kRecPitch];
-    __shared__ uint32_t l_run[kBlock];
     FrameArgs a = a_in;
     a.xyz = xyz; a.box9 = box9; a.aflags = aflags; a.arow = arow;
     const uint32_t tile_id = blockIdx.x % n_tiles, chunk = blockIdx.x / n_tiles;
@@ -179,9 +165,9 @@ __global__ __launch_bounds__(kBlock) void k_bonds_extras(FrameArgs a_in, ExtraAr
     const float *pj = xyz + ((size_t)t.atom0 + it.lj) * 3u;
     if (!MAPS_ONLY)
         for (uint32_t k = tid; k < 3 * kBlock; k += kBlock) { l_tw[k] = 0; l_twn[k] = 0; }
-    l_run[tid] = (active && (MAPS_ONLY || e.map_rec)) ? e.item_run[t.item0 + tid] : ((tid << 16) | 1u);   // a padding lane: a run of its own
     __syncthreads();
     SampleAcc acc;
+    unsigned long long recs[kRecFrames] = {kMapNoSample, kMapNoSample, kMapNoSample, kMapNoSample};
     int bad = 0;
     // the two atoms of the next frames are fetched ahead of the arithmetic of this one (the gather is latency-bound)
     constexpr uint32_t kAhead = 2;
@@ -246,13 +232,14 @@ __global__ __launch_bounds__(kBlock) void k_bonds_extras(FrameArgs a_in, ExtraAr
                                       (MAPS_ONLY || e.map_rec) ? &rec : nullptr);
             }
         }
-        if (MAPS_ONLY || e.map_rec) {   // staged samples: kRecFrames frames gathered in LDS, then written as rows of the blocked layout
+        if (MAPS_ONLY || e.map_rec) {   // staged samples: a thread's words of kRecFrames frames go out together
             const uint32_t c = (f - f_begin) % kRecFrames;      // the host keeps f_begin - rec_frame0 a multiple of kRecFrames
-            l_rec[c * kRecPitch + tid] = rec;
+#pragma unroll
+            for (uint32_t m = 0; m < kRecFrames; m++) recs[m] = m == c ? rec : recs[m];      // (selects: the array stays in registers)
             if (c == kRecFrames - 1 || f + 1 == f_end) {
-                __syncthreads();
-                rec_flush(e, tile_id, f - c, c, tid, l_rec, l_run);
-                __syncthreads();
+                rec_store(e, tile_id, f - c, tid, recs);
+#pragma unroll
+                for (uint32_t m = 0; m < kRecFrames; m++) recs[m] = kMapNoSample;
             }
         }
         if (!MAPS_ONLY && e.tw) {
@@ -262,6 +249,89 @@ __global__ __launch_bounds__(kBlock) void k_bonds_extras(FrameArgs a_in, ExtraAr
         }
     }
     if (bad) raise_box_range(a.err, f_begin);
+    l_s[tid] = 0; l_s[kBlock + tid] = 0; l_n[tid] = 0; l_n[kBlock + tid] = 0;
+    __syncthreads();
+    if (active && acc.n_tot) {
+        atomicAdd(&l_s[it.lslot], (unsigned long long)acc.s_tot);
+        atomicAdd(&l_n[it.lslot], acc.n_tot);
+        if (acc.n_up) {
+            atomicAdd(&l_s[kBlock + it.lslot], (unsigned long long)acc.s_up);
+            atomicAdd(&l_n[kBlock + it.lslot], acc.n_up);
+        }
+    }
+    __syncthreads();
+    if (tid < t.n_slots && l_n[tid]) {
+        unsigned long long *accp = a.rep + (size_t)(blockIdx.x % a.n_rep) * 4u * a.n_acc;
+        const uint32_t slot = tile_slots[t.slot0 + tid];
+        atomicAdd(&accp[slot], l_s[tid]);
+        atomicAdd(&accp[2u * a.n_acc + slot], (unsigned long long)l_n[tid]);
+        if (l_n[kBlock + tid]) {
+            atomicAdd(&accp[a.n_acc + slot], l_s[kBlock + tid]);
+            atomicAdd(&accp[3u * a.n_acc + slot], (unsigned long long)l_n[kBlock + tid]);
+        }
+    }
+}
+
+// ---- ordermaps and nothing else, bonds: K1's staging (kernels_bonds.h: a tile's atom window of G = kRecFrames frames
+// HBM -> registers -> LDS, every byte read once, the next stage's loads in flight) with the staged map words as a second
+// output: compute_core<MAPS> leaves a thread's word per frame of the stage in registers, and they go out as one 16-byte
+// store + one of four bytes (rec_store).  k_bonds_extras<*, true> — a thread gathers its two atoms per frame from global memory — took 294 us per
+// 3000 frames of the 256-lipid all-atom membrane where this kernel's read-only twin takes 144.
+// grid = n_tiles * n_chunks (frames_per_chunk a multiple of kRecFrames, a.frame0 = the sub-range's first frame).
+template <int NPF, bool PBC, bool LEAF, int AXIS>
+__global__ __launch_bounds__(kBlock, 4) void k_bonds_tiled_maps(FrameArgs a_in, ExtraArgs e, const float *__restrict__ xyz,
+                                                               const float *__restrict__ box9, const uint8_t *__restrict__ aflags,
+                                                               const uint32_t *__restrict__ arow, const Tile *__restrict__ tiles,
+                                                               const Item *__restrict__ items, const uint32_t *__restrict__ tile_slots,
+                                                               uint32_t n_tiles, uint32_t lw) {
+    constexpr int G = (int)kRecFrames;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    using S = TiledStage<G, NPF, false, PBC, LEAF, AXIS>;
+    FrameArgs a = a_in;
+    a.xyz = xyz; a.box9 = box9; a.aflags = aflags; a.arow = arow;
+    const uint32_t tile_id = blockIdx.x % n_tiles, chunk = blockIdx.x / n_tiles;
+    const Tile t = tiles[tile_id];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t sk = tid / S::TPF, si = tid % S::TPF;
+    const bool active = tid < t.n_items;
+    Item it{0, 0, 0, 0, 0};
+    if (active) it = items[t.item0 + tid];
+    const uint32_t f_begin = a.frame0 + chunk * a.frames_per_chunk;
+    const uint32_t f_end = min(a.n_frames, f_begin + a.frames_per_chunk);
+    const uint32_t f_full = f_begin + ((f_end - f_begin) / G) * G;
+    unsigned long long words[kRecFrames] = {kMapNoSample, kMapNoSample, kMapNoSample, kMapNoSample};       // (padding lanes: none)
+    TiledMapOut mo;
+    mo.plane = e.plane; mo.x0 = e.x0; mo.y0 = e.y0; mo.binx = e.binx; mo.biny = e.biny; mo.nx = e.nx; mo.ny = e.ny;
+    mo.bin_core = e.bin_core; mo.words = words;
+    SampleAcc acc;
+    int bad = 0;
+    uint32_t nan_which = 0, nan_frame = kNoNan;
+    v4f pre[NPF];
+    if (f_begin < f_full) S::template load<false>(a, t, f_begin, f_end, sk, si, pre);
+    for (uint32_t f0 = f_begin; f0 < f_full; f0 += G) {
+        S::template store<false>(a, t, f0, f_end, sk, si, pre, lds, lw);
+        __syncthreads();
+        if (f0 + G < f_full) S::template load<false>(a, t, f0 + G, f_end, sk, si, pre);
+        if (active) S::template compute<true>(a, t, it, f0, lds, lw, acc, bad, nan_which, nan_frame, &mo);
+        rec_store(e, tile_id, f0, tid, words);
+        __syncthreads();
+    }
+    if (f_full < f_end) {   // last, partial stage of the sub-range
+        S::template load<true>(a, t, f_full, f_end, sk, si, pre);
+        S::template store<true>(a, t, f_full, f_end, sk, si, pre, lds, lw);
+        __syncthreads();
+#pragma unroll
+        for (uint32_t m = 0; m < kRecFrames; m++) words[m] = kMapNoSample;
+        if (active) S::template compute_tail<true>(a, t, it, f_full, f_end, lds, lw, acc, bad, nan_which, nan_frame, &mo);
+        rec_store(e, tile_id, f_full, tid, words);
+        __syncthreads();
+    }
+    if (nan_frame != kNoNan)
+        raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, nan_frame, kStageTypes, tile_slots[t.slot0 + it.lslot], 1, it.mol, nan_which);
+    if (bad) raise_box_range(a.err, f_begin);
+    __syncthreads();
+    unsigned long long *l_s = reinterpret_cast<unsigned long long *>(lds);   // [2][256]
+    uint32_t *l_n = reinterpret_cast<uint32_t *>(l_s + 2 * kBlock);          // [2][256]
     l_s[tid] = 0; l_s[kBlock + tid] = 0; l_n[tid] = 0; l_n[kBlock + tid] = 0;
     __syncthreads();
     if (active && acc.n_tot) {
@@ -718,12 +788,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 }
 
 // ---- ordermaps, second step ------------------------------------------------------------------------
-// The sample kernels stage every sample as (plane-tile << 32 | tick), run by run (ExtraArgs::map_rec); here a block
+// The sample kernels stage every sample as five bytes (tick, plane-tile: ExtraArgs::map_rec), run by run; here a block
 // owns ONE accumulator slot for a range of frames: it reads the slot's runs (gorder::MapRun, contiguous pieces),
 // adds the samples into a packed map held in LDS (ds_add_u64) and flushes the tiles it touched
 // into the global packed map with one atomic each.  Scattered global atomics run at ~24 G/s on this chip
 // whatever one does (tools/microbench/atomic_scatter.hip); this way their number drops from one per sample to
 // at most one per (slot, chunk, tile).
+constexpr uint32_t kMapRunBatch = 1024;          // runs of a slot whose lanes k_map_accumulate lays out at a time
 __global__ __launch_bounds__(1024) void k_map_accumulate(const unsigned long long *__restrict__ rec,
                                                          const gorder::MapRun *__restrict__ runs,
                                                          const uint32_t *__restrict__ run_begin, uint32_t n_slots,
@@ -732,37 +803,101 @@ __global__ __launch_bounds__(1024) void k_map_accumulate(const unsigned long lon
                                                          uint32_t n_words /* planes * tiles */, uint32_t n_tiles_map,
                                                          unsigned long long *__restrict__ map_packed, uint32_t n_acc) {
     extern __shared__ unsigned long long l_map[];
+    typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
     const uint32_t slot = blockIdx.x % n_slots, chunk = blockIdx.x / n_slots;
     const uint32_t r0 = run_begin[slot], r1 = run_begin[slot + 1];
     if (r0 == r1) return;                               // no samples of this kind (bond / united atom) in the slot
     const uint32_t f0 = chunk * frames_per_chunk, f1 = min(rec_frames, f0 + frames_per_chunk);
     for (uint32_t w = threadIdx.x; w < n_words; w += blockDim.x) l_map[w] = 0ull;
     __syncthreads();
-    // many short runs (bond tiles, small united-atom groups): one wave per run at a time; few long ones: the whole
-    // block strides over each run
-    const uint32_t n_waves = blockDim.x >> 6;
-    const bool per_wave = r1 - r0 >= n_waves;
-    const uint32_t r_first = r0 + (per_wave ? threadIdx.x >> 6 : 0u), r_step = per_wave ? n_waves : 1u;
-    const uint32_t i_first = per_wave ? threadIdx.x & 63u : threadIdx.x, i_step = per_wave ? 64u : blockDim.x;
-    for (uint32_t r = r_first; r < r1; r += r_step) {
-        const gorder::MapRun run = runs[r];
-        if (k_max == 1u) {     // bond tiles: per block of kRecFrames frames one piece of kRecFrames * n words
-            const uint32_t pl = kRecFrames * run.n, fb0 = f0 / kRecFrames, fb1 = (f1 + kRecFrames - 1) / kRecFrames;
-            const unsigned long long *tile = rec + (size_t)run.tile * kBlock * rec_stride + kRecFrames * run.tid0;
-            for (uint32_t i = i_first; i < (fb1 - fb0) * pl; i += i_step) {
-                const uint32_t b = i / pl;
-                const unsigned long long v = tile[(size_t)(fb0 + b) * (kRecFrames * kBlock) + (i - b * pl)];
-                if (v != kMapNoSample)
-                    atomicAdd(&l_map[(uint32_t)(v >> 32)], kMapOne + (unsigned long long)(long long)(int)(uint32_t)v);
+    auto add = [&](unsigned long long v) {
+        if (v != kMapNoSample) atomicAdd(&l_map[(uint32_t)(v >> 32)], kMapOne + (unsigned long long)(long long)(int)(uint32_t)v);
+    };
+    if (k_max == 1u) {
+        // Bond tiles.  A lane takes ONE molecule of the slot — lane j of a run — and walks its samples through the frame
+        // blocks of its share of the chunk, in time order (the addresses are base + block * stride: no run table in the
+        // loop, the next block's loads go out before this one's samples are added); samples that follow each other into
+        // the same tile — a molecule moves less than a tile between most frames — are added up in registers and cost
+        // ONE ds_add_u64.
+        __shared__ uint32_t l_pref[kMapRunBatch + 1];
+        const uint32_t fb0 = f0 / kRecFrames, fb1 = (f1 + kRecFrames - 1) / kRecFrames;
+        for (uint32_t rb = r0; rb < r1; rb += kMapRunBatch) {
+            const uint32_t nr = min(kMapRunBatch, r1 - rb);
+            for (uint32_t i = threadIdx.x; i < nr; i += blockDim.x) l_pref[i + 1u] = runs[rb + i].n;
+            if (threadIdx.x == 0) l_pref[0] = 0;
+            __syncthreads();
+            if (threadIdx.x < 64u) {            // inclusive scan by one wave
+                uint32_t carry = 0;
+                for (uint32_t i0 = 1; i0 <= nr; i0 += 64u) {
+                    const uint32_t i = i0 + threadIdx.x, v = i <= nr ? l_pref[i] : 0u;
+                    uint32_t incl = v;
+                    for (uint32_t off = 1; off < 64u; off <<= 1) {
+                        const uint32_t u = __shfl_up(incl, off, 64);
+                        if (threadIdx.x >= off) incl += u;
+                    }
+                    if (i <= nr) l_pref[i] = carry + incl;
+                    carry += __shfl(incl, 63, 64);
+                }
             }
-        } else {               // united-atom tiles: the run's words of the frames [f0, f1) are one contiguous piece
+            __syncthreads();
+            const uint32_t total = l_pref[nr];
+            // fewer molecules than threads: the frame blocks of the chunk are shared out among `parts` lanes per molecule
+            const uint32_t parts = total ? max(1u, min(blockDim.x / total, fb1 - fb0)) : 1u;
+            const uint32_t fb_per = (fb1 - fb0 + parts - 1u) / parts;
+            for (uint32_t lane_item = threadIdx.x; lane_item < total * parts; lane_item += blockDim.x) {
+                const uint32_t item = lane_item % total, part = lane_item / total;
+                const uint32_t fb_lo = fb0 + part * fb_per, fb_hi = min(fb1, fb_lo + fb_per);
+                uint32_t lo = 0, hi = nr;                      // the run with l_pref[lo] <= item < l_pref[lo + 1]
+                while (hi - lo > 1u) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (l_pref[mid] <= item) lo = mid; else hi = mid;
+                }
+                const gorder::MapRun run = runs[rb + lo];
+                const unsigned long long *base = rec + (size_t)run.tile * kBlock * rec_stride + kRecFrames * (run.tid0 + (item - l_pref[lo]));
+                uint32_t cur = 0;
+                unsigned long long sum = 0ull;
+                ull2 wa, wb, na, nb;
+                auto fetch = [&](uint32_t fb, ull2 &a2, ull2 &b2) {
+                    const ull2 *p = reinterpret_cast<const ull2 *>(base + (size_t)fb * (kRecFrames * kBlock));
+                    a2 = __builtin_nontemporal_load(p);
+                    b2 = __builtin_nontemporal_load(p + 1);
+                };
+                if (fb_lo < fb_hi) fetch(fb_lo, na, nb);
+                for (uint32_t fb = fb_lo; fb < fb_hi; fb++) {
+                    wa = na; wb = nb;
+                    if (fb + 1u < fb_hi) fetch(fb + 1u, na, nb);
+                    const unsigned long long w[4] = {wa.x, wa.y, wb.x, wb.y};
+#pragma unroll
+                    for (uint32_t m = 0; m < 4u; m++) {
+                        if (w[m] == kMapNoSample) continue;
+                        const uint32_t pt = (uint32_t)(w[m] >> 32);
+                        if (sum != 0ull && pt != cur) { atomicAdd(&l_map[cur], sum); sum = 0ull; }
+                        cur = pt;
+                        sum += kMapOne + (unsigned long long)(long long)(int)(uint32_t)w[m];
+                    }
+                }
+                if (sum != 0ull) atomicAdd(&l_map[cur], sum);
+            }
+            __syncthreads();
+        }
+    } else {
+        // united-atom tiles: few long runs — the whole block strides over each run's contiguous piece of the frames
+        // [f0, f1) —, or many short ones: a wave per run at a time
+        const uint32_t n_waves = blockDim.x >> 6;
+        const bool per_wave = r1 - r0 >= n_waves;
+        const uint32_t r_first = r0 + (per_wave ? threadIdx.x >> 6 : 0u), r_step = per_wave ? n_waves : 1u;
+        const uint32_t i_first = per_wave ? threadIdx.x & 63u : threadIdx.x, i_step = per_wave ? 64u : blockDim.x;
+        for (uint32_t r = r_first; r < r1; r += r_step) {
+            const gorder::MapRun run = runs[r];
             const uint32_t total = (f1 - f0) * run.n;
             const unsigned long long *piece = rec + (((size_t)run.tile * k_max + run.k) * kBlock + run.tid0) * rec_stride + (size_t)f0 * run.n;
-            for (uint32_t i = i_first; i < total; i += i_step) {
-                const unsigned long long v = piece[i];
-                if (v != kMapNoSample)
-                    atomicAdd(&l_map[(uint32_t)(v >> 32)], kMapOne + (unsigned long long)(long long)(int)(uint32_t)v);
+            // (the piece starts at a multiple of 16 words: pairs — 16-byte loads —, then the last chunk's odd word)
+            for (uint32_t i = i_first; i < total / 2u; i += i_step) {
+                const ull2 w = __builtin_nontemporal_load(reinterpret_cast<const ull2 *>(piece) + i);
+                add(w.x);
+                add(w.y);
             }
+            if ((total & 1u) && i_first == 0u) add(piece[total - 1u]);
         }
     }
     __syncthreads();
