@@ -593,6 +593,29 @@ def test_local_leaflets_of_an_undulating_membrane(built, box_z, amplitude):
         np.testing.assert_array_equal(got.counts, want.counts)
 
 
+def test_local_leaflets_with_a_cell_of_more_than_255_atoms(built):
+    """k_local_build keeps an atom's place inside its cell in a byte; a cell that holds more atoms than a byte counts
+    makes the whole frame take its places from counters instead (`use_fill`).  340 atoms of the membrane stacked on one
+    spot of the plane (their normal coordinates left alone) — and the flags are the oracle's."""
+    system = synthetic.cg_membrane(160, leaflets=LEAFLETS_LOCAL, radius=2.0, n_types=2, box=(11.0, 11.0, 10.0))
+    n = 3
+    xyz = system.frames(n, seed=37)
+    rng = np.random.default_rng(5)
+    crowd = rng.choice(xyz.shape[1], 340, replace=False)
+    xyz[1:, crowd, 0] = (4.11 + rng.normal(0, 0.01, (n - 1, 340))).astype(np.float32)       # (frame 0 stays ordinary)
+    xyz[1:, crowd, 1] = (6.52 + rng.normal(0, 0.01, (n - 1, 340))).astype(np.float32)
+    eng, got = run_gpu(system, xyz, system.box9(n), batches=1)
+    o, want = run_oracle(system, xyz, system.box9(n))
+    flags, _ = eng.leaflets()
+    oflags, odist, _ = o.leaflets()
+    diff = flags != oflags
+    assert not diff.any() or np.abs(odist[diff]).max() < 1e-4
+    assert_sums_given_device_flags(system.tables, xyz, system.box9(n), got)
+    if not diff.any():
+        np.testing.assert_array_equal(got.sums, want.sums)
+        np.testing.assert_array_equal(got.counts, want.counts)
+
+
 def test_independent_handles_interleaved_and_threaded(built):
     """A handle is thread-compatible like one SystemTopology clone (topology/mod.rs:256-278): several handles, each
     with its own stream, fed from different host threads at the same time, do not disturb each other."""
