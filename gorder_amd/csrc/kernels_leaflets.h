@@ -869,7 +869,7 @@ __global__ __launch_bounds__(256) void k_local_rowprefix(LocalArgs a) {
     const uint32_t nca = g.x, ncs = local_row_stride(a, g.y, g.w);
     if (blockIdx.x == 0 && s == 0 && threadIdx.x == 0) a.todo[0] = make_uint2(0u, 0u);        // this slab's list starts empty
     if (ra >= nca) return;                                                                       // (uniform per wave; no workgroup barrier below)
-    if (reinterpret_cast<const uint4 *>(a.finfo)[s].w == 1u) return;                             // k_local_build made this frame's sums
+    const bool merge = reinterpret_cast<const uint4 *>(a.finfo)[s].w != 2u;                     // 2: k_local_build made the frame's record
     const uint32_t *cstart = a.cell_count + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u);
     const LocalRec *rec = reinterpret_cast<const LocalRec *>(a.trig) + (size_t)s * a.rec_stride;
     float box[3];
@@ -878,7 +878,7 @@ __global__ __launch_bounds__(256) void k_local_rowprefix(LocalArgs a) {
     float zlo = 3.0e38f, zhi = -3.0e38f;
     uint32_t nf = 0;
     local_row_prefix<kRowPrefixPiece>(cstart, rec, out, ra, ncs, 1.0f / box[a.dim], l_c[wave], l_s[wave], l_z[wave], zlo, zhi, nf);
-    local_finfo_merge(a, s, zlo, zhi, nf);
+    if (merge) local_finfo_merge(a, s, zlo, zhi, nf);
 }
 
 // bin + scan + scatter in ONE kernel, one block per slab frame (membranes of up to kLocalBuildMax atoms: the slab then has
@@ -990,6 +990,8 @@ __global__ __launch_bounds__(1024) void k_local_build(LocalArgs a) {
     if (tid == 0 && a.grid) { a.grid[s] = make_uint4(nca, ncb, ka, kb); local_finfo_init(a, s); }
     __syncthreads();
     LocalRec *rec = reinterpret_cast<LocalRec *>(a.trig) + (size_t)s * a.rec_stride;
+    float zlo = 3.0e38f, zhi = -3.0e38f;            // the frame's record for the rows kernel (finfo), made on the way
+    uint32_t nf = 0;
 #pragma unroll
     for (uint32_t trip = 0; trip < kLocalBuildTrips; trip++) {
         const uint32_t i0 = tid + trip * U * 1024u;
@@ -1008,6 +1010,9 @@ __global__ __launch_bounds__(1024) void k_local_build(LocalArgs a) {
             const uint32_t c = cell_ab(pa[u], pb[u]);
             const uint32_t q = l_start[c] + (use_fill ? atomicAdd(&l_fill[c], 1u) : (place[trip][u >> 2] >> (8u * (u & 3u))) & 255u);
             rec[q] = LocalRec{pa[u], pb[u], pn[u]};
+            zlo = fminf(zlo, pn[u]);
+            zhi = fmaxf(zhi, pn[u]);
+            nf |= ((pa[u] - pa[u]) + (pb[u] - pb[u])) + (pn[u] - pn[u]) == 0.0f ? 0u : 1u;
             if (in_halo) {
                 const uint32_t q2 = l_start[c + ncb] + (use_fill ? atomicAdd(&l_fill[c + ncb], 1u) : (place2[trip][u >> 2] >> (8u * (u & 3u))) & 255u);
                 rec[q2] = LocalRec{pa[u], pb[u], pn[u]};
@@ -1015,6 +1020,25 @@ __global__ __launch_bounds__(1024) void k_local_build(LocalArgs a) {
         }
     }
     if (bad) raise_box_range(a.err, f);
+    // The extrema of the normal coordinate and the "a coordinate is not finite" flag of the frame, in one place: 84 waves
+    // of k_local_rowprefix adding theirs by atomics — 2 000 of them per cache line of finfo — was what that kernel took
+    // most of its time for.
+    if (a.finfo) {
+        __shared__ float l_zlo[16], l_zhi[16];
+        __shared__ uint32_t l_nf[16];
+        for (int off = 32; off >= 1; off >>= 1) {
+            zlo = fminf(zlo, __shfl_xor(zlo, off, 64));
+            zhi = fmaxf(zhi, __shfl_xor(zhi, off, 64));
+            nf |= (uint32_t)__shfl_xor((int)nf, off, 64);
+        }
+        if ((tid & 63u) == 0u) { l_zlo[tid >> 6] = zlo; l_zhi[tid >> 6] = zhi; l_nf[tid >> 6] = nf; }
+        __syncthreads();
+        if (tid == 0) {
+            for (uint32_t w = 1; w < 16u; w++) { zlo = fminf(zlo, l_zlo[w]); zhi = fmaxf(zhi, l_zhi[w]); nf |= l_nf[w]; }
+            reinterpret_cast<uint4 *>(a.finfo)[s] = zlo <= zhi ? make_uint4(local_float_key(zlo), local_float_key(zhi), nf, 2u)
+                                                                : make_uint4(0xffffffffu, 0u, nf, 2u);
+        }
+    }
     // (The rows' prefix sums stay a kernel of their own, k_local_rowprefix: done here behind pass 2 — a wave per row, six
     // rows per wave, the records still in this XCD's L2 — they took 190 us per 256 frames against 100 for the kernel,
     // whose 23 000 waves hide the latency of the four dependent loads a row needs; with per-cell sums made by LDS
