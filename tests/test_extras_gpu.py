@@ -47,6 +47,36 @@ def test_ordermaps(built, plane, leaflets):
     assert (tot <= got.counts).all() and tot.sum() > 0.97 * got.counts.sum()
 
 
+@pytest.mark.parametrize("gather", [False, True])
+@pytest.mark.parametrize("pbc,normal,leaflets", [(True, (0.0, 0.0, 1.0), LEAFLETS_NONE), (True, (0.3, -0.2, 0.9), LEAFLETS_GLOBAL),
+                                                 (False, (0.0, 1.0, 0.0), LEAFLETS_NONE), (True, (1.0, 0.0, 0.0), LEAFLETS_INDIVIDUAL)])
+def test_ordermaps_of_bonds_through_both_producers(built, monkeypatch, gather, pbc, normal, leaflets):
+    """Maps and nothing else: the samples come out of K1's staging (k_bonds_tiled_maps) — or, with GORDER_HIP_MAPS_GATHER,
+    out of k_bonds_extras — and go through k_map_accumulate.  37 frames in one batch (nine whole stages and a partial
+    one), periodic or not, the normal an axis or not, with and without leaflets: the oracle's maps tile for tile."""
+    if gather:
+        monkeypatch.setenv("GORDER_HIP_MAPS_GATHER", "1")
+    system = synthetic.cg_membrane(230, leaflets=leaflets, n_types=3, handle_pbc=pbc, normal=normal)
+    bx = system.box
+    system.tables.ordermap = OrderMap(enabled=True, plane=0, span_x=(0.0, float(bx[0])), span_y=(0.0, float(bx[1])), bin=(0.45, 0.8))
+    n = 37
+    xyz = system.frames(n, seed=12)
+    box = system.box9(n) if pbc else None
+    eng = HipEngine(system.tables)
+    eng.kernel_time()                       # (switches the event pairs on: the kernels of the batch are then named)
+    o = oracle.OracleEngine(system.tables, trig=oracle.TRIG_DIRECT, n_threads=2)
+    eng.submit_host(xyz, box, np.arange(n))
+    o.submit(xyz, box, np.arange(n))
+    got, want = eng.finish(), o.finish()
+    np.testing.assert_array_equal(got.sums, want.sums)
+    np.testing.assert_array_equal(got.counts, want.counts)
+    np.testing.assert_array_equal(got.map_counts, want.map_counts)
+    np.testing.assert_array_equal(got.map_sums, want.map_sums)
+    assert got.map_counts.sum() > 0
+    names = eng.kernel_names()
+    assert ("k_bonds_extras" if gather else "k_bonds_tiled_maps") in names and "k_map_accumulate" in names
+
+
 @pytest.mark.parametrize("leaflets", [LEAFLETS_NONE, LEAFLETS_GLOBAL])
 def test_ordermap_words_are_folded_before_they_overflow(built, monkeypatch, leaflets):
     """The kernels add count and tick sum into one packed word per tile (k_fold_maps); with the fold
