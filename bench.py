@@ -66,6 +66,23 @@ def make_system(name):
                 "UAOrder 256 united-atom lipids (62 virtual C-H per lipid) + 91x91 ordermaps")
     if name == "ua256":
         return synthetic.ua_membrane(256), "UAOrder 256 united-atom lipids (62 virtual C-H per lipid)"
+    if name == "cg3k-dynamic":   # membrane normal: dynamic (normal.rs:160-199): per lipid and frame, PCA of the heads within 2 nm
+        import numpy as np
+        from gorder_amd.abi import DynamicNormal, LEAFLETS_GLOBAL as LG
+        system = synthetic.cg_membrane(3072, leaflets=LG)
+        cloud = []
+        for m in system.tables.molecule_types:
+            m.normal_heads = np.asarray(m.heads, dtype=np.uint32)
+            cloud.append(m.normal_heads)
+        system.tables.dynamic_normal = DynamicNormal(enabled=True, radius=2.0, cloud=np.concatenate(cloud))
+        return system, "CGOrder Martini bilayer 3072 lipids + dynamic membrane normals (r = 2.0 nm)"
+    if name == "aa256-cylinder":  # geometry selection (geometry.rs): bonds inside a cylinder around the box centre
+        from gorder_amd.abi import GEOM_CYLINDER, GEOMREF_BOX_CENTER, Geometry
+        system = synthetic.aa_membrane(256)
+        system.tables.geometry = Geometry(kind=GEOM_CYLINDER, reference=GEOMREF_BOX_CENTER, invert=False, radius=3.0, orientation=2,
+                                          point=(0.0, 0.0, 0.0), xdim=(0.0, 0.0), ydim=(0.0, 0.0), zdim=(0.0, 0.0),
+                                          span=(-float("inf"), float("inf")), structure_box=tuple(float(x) for x in system.box))
+        return system, "AAOrder 256 lipids + cylinder selection (r = 3 nm around the box centre)"
     if name == "cg1m":
         return synthetic.cg_membrane(83334), "CGOrder synthetic 1M-bead bilayer (1000008 beads, 916674 bonds/frame)"
     raise SystemExit(f"unknown workload {name}")

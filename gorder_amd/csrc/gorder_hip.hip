@@ -105,6 +105,7 @@ struct gorder_hip_handle {
     uint32_t *d_dyn_cell_of = nullptr, *d_dyn_count = nullptr;
     float *d_dyn_rec = nullptr;
     float4 *d_dyn_normals = nullptr;
+    DynCov *d_dyn_cov = nullptr;       // per (slab frame, molecule): the sums of k_dyn_cov for k_dyn_eigen
     size_t dyn_normals_cap = 0;
     std::vector<float> last_normals;   // [n_mol_total][4] of the last submitted frame
     // manual membrane normals (ManualMembraneNormal, normal.rs:266-300): handed over per batch by the host
@@ -372,7 +373,9 @@ int run_dynamic_normals(gorder_hip_handle *h, const FrameArgs &a) {
         lo.n_slab = ns;
         if ((st = launch_cell_list(h, lo, ns, dn.n_cloud, h->d_dyn_count,
                                    (size_t)h->dyn_slab * (2 * ncell + 1) * sizeof(uint32_t))) != GORDER_OK) return st;
-        hipLaunchKernelGGL(k_dyn_normals, dim3((n_mol + 3) / 4, ns), dim3(256), 0, h->stream, lo, h->d_dyn_normals);
+        hipLaunchKernelGGL(k_dyn_cov, dim3((n_mol + 15) / 16, ns), dim3(256), 0, h->stream, lo, h->d_dyn_cov);
+        hipLaunchKernelGGL(k_dyn_eigen, dim3((uint32_t)(((size_t)ns * n_mol + 255) / 256)), dim3(256), 0, h->stream, lo, h->d_dyn_cov,
+                           h->d_dyn_normals);
     }
     HIP_TRY(h, hipGetLastError());
     // keep the last frame's normals for gorder_hip_normals (stream-ordered copy into pageable memory)
@@ -399,7 +402,7 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
         h->timed_kernels += k;
     };
     if (h->dyn && !h->manual_active) {
-        name("k_dyn_normals");
+        name("k_dyn_cov + k_dyn_eigen");
         const int st2 = run_dynamic_normals(h, a);
         if (st2 != GORDER_OK) return st2;
     }
@@ -986,6 +989,7 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
         HIP_TRY(h, hipMalloc((void **)&h->d_dyn_cell_of, sl * nm * sizeof(uint32_t)));
         HIP_TRY(h, hipMalloc((void **)&h->d_dyn_rec, sl * nm * 4 * sizeof(float)));
         HIP_TRY(h, hipMalloc((void **)&h->d_dyn_count, sl * (2 * ncell + 1) * sizeof(uint32_t)));
+        HIP_TRY(h, hipMalloc((void **)&h->d_dyn_cov, sl * (size_t)(p.n_mol_total ? p.n_mol_total : 1) * sizeof(DynCov)));
         h->dyn = true;
     }
 
@@ -1078,7 +1082,7 @@ void gorder_hip_destroy(gorder_hip_handle *h) {
     (void)hipFree(h->d_runs); (void)hipFree(h->d_run_begin); (void)hipFree(h->d_items_by_slot);
     (void)hipFree(h->d_ua_item_run); (void)hipFree(h->d_lgrid); (void)hipFree(h->d_lrowpre); (void)hipFree(h->d_lfinfo); (void)hipFree(h->d_ltodo);
     (void)hipFree(h->d_dyn_cloud); (void)hipFree(h->d_dyn_heads); (void)hipFree(h->d_dyn_cell_of); (void)hipFree(h->d_dyn_count);
-    (void)hipFree(h->d_dyn_rec); (void)hipFree(h->d_dyn_normals);
+    (void)hipFree(h->d_dyn_rec); (void)hipFree(h->d_dyn_normals); (void)hipFree(h->d_dyn_cov);
     if (!h->acc_external) (void)hipFree(h->d_acc);
     (void)hipFree(h->d_rep);
     (void)hipFree(h->d_heads); (void)hipFree(h->d_membrane); (void)hipFree(h->d_methyl_begin);
