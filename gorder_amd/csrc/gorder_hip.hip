@@ -79,7 +79,7 @@ struct gorder_hip_handle {
     gorder::MapRun *d_ua_runs = nullptr, *d_runs = nullptr;
     uint32_t *d_ua_run_begin = nullptr, *d_run_begin = nullptr;
     Item *d_items_by_slot = nullptr;
-    uint32_t *d_ua_item_run = nullptr;
+    uint32_t *d_ua_item_run = nullptr, *d_item_run = nullptr;
     uint4 *d_lgrid = nullptr;       // per slab frame: the cell grid of the local-leaflet kernels
     LocalRowPre *d_lrowpre = nullptr;   // per slab frame: prefix sums along the rows of cells (k_local_rowprefix)
     float4 *d_lfinfo = nullptr;     // per slab frame: extrema of the membrane's normal coordinate, finite flag
@@ -535,18 +535,23 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
                 n_chunks = std::min(n_chunks, nf);
                 uint32_t fpc = (nf + n_chunks - 1) / n_chunks;
                 if (staged) fpc = (fpc + 15u) / 16u * 16u;   // whole frame blocks (kRecFrames) and whole lines per workgroup
+                // per-frame rows and nothing else, the default cosine, four frames per stage: the tiled kernel with the
+                // stage's ticks as a second output (k_bonds_tiled_tw)
+                const bool tiled_tw = pass == 0 && e.tw && !e.maps && !e.geom_kind && !e.dyn && !ac && !h->use_gather && h->d_item_run &&
+                                      h->frames_per_stage == (int)kRecFrames && !env_flag("GORDER_HIP_TW_GATHER");
+                if (tiled_tw) fpc = (fpc + kRecFrames - 1u) / kRecFrames * kRecFrames;       // whole stages
                 n_chunks = (nf + fpc - 1) / fpc;
                 FrameArgs b = a;
                 b.frame0 = lo;
                 b.n_frames = hi;
                 b.frames_per_chunk = fpc;
                 e.map_rec = staged ? h->d_map_rec : nullptr;
-                e.item_run = pass == 0 ? nullptr : h->d_ua_item_run;      // (bond tiles: a lane's words are its own, rec_store)
+                e.item_run = pass == 0 ? h->d_item_run : h->d_ua_item_run;      // (bond tiles: k_bonds_tiled_tw only)
                 e.rec_frame0 = lo;
                 e.rec_stride = (nf + 15u) / 16u * 16u;
                 const dim3 g(pass == 0 ? nt * n_chunks : (nt * n_chunks + 7u) / 8u * 8u), blk(kBlock);   // united atoms: see the XCD mapping in k_ua_extras
                 if (pass == 0) {
-                    const Item *items = staged ? h->d_items_by_slot : h->d_items;
+                    const Item *items = (staged || tiled_tw) ? h->d_items_by_slot : h->d_items;
 #define GORDER_LAUNCH_BONDS(AC, MO)                                                                               \
     hipLaunchKernelGGL((k_bonds_extras<AC, MO>), g, blk, 0, h->stream, b, e, b.xyz, b.box9, b.aflags, b.arow,       \
                        h->d_tiles, items, h->d_tile_slots, nt)
@@ -556,8 +561,14 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
                     const bool tiled_maps = maps_only && !ac && !h->use_gather && h->frames_per_stage == (int)kRecFrames &&
                                             !env_flag("GORDER_HIP_MAPS_GATHER");
 #define GORDER_LAUNCH_TM_A(NPF_, PBC_, LF_, AX_)                                                                   \
-    hipLaunchKernelGGL((k_bonds_tiled_maps<NPF_, PBC_, LF_, AX_>), g, blk, h->lds_bytes, h->stream, b, e, b.xyz, b.box9, \
-                       b.aflags, b.arow, h->d_tiles, items, h->d_tile_slots, nt, h->lw)
+    do {                                                                                                            \
+        if (tiled_tw)                                                                                               \
+            hipLaunchKernelGGL((k_bonds_tiled_tw<NPF_, PBC_, LF_, AX_>), g, blk, h->lds_bytes, h->stream, b, e, b.xyz,  \
+                               b.box9, b.aflags, b.arow, h->d_tiles, items, h->d_tile_slots, nt, h->lw);               \
+        else                                                                                                        \
+            hipLaunchKernelGGL((k_bonds_tiled_maps<NPF_, PBC_, LF_, AX_>), g, blk, h->lds_bytes, h->stream, b, e, b.xyz, \
+                               b.box9, b.aflags, b.arow, h->d_tiles, items, h->d_tile_slots, nt, h->lw);               \
+    } while (0)
 #define GORDER_LAUNCH_TM_V(NPF_, PBC_, LF_)                                                                        \
     do {                                                                                                            \
         if (h->axis == 2) GORDER_LAUNCH_TM_A(NPF_, PBC_, LF_, 2);                                                   \
@@ -574,8 +585,8 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
             default: GORDER_LAUNCH_TM_V(NPF_, true, true); break;                                                   \
         }                                                                                                           \
     } while (0)
-                    name(tiled_maps ? "k_bonds_tiled_maps" : "k_bonds_extras");
-                    if (tiled_maps) {
+                    name(tiled_maps ? "k_bonds_tiled_maps" : (tiled_tw ? "k_bonds_tiled_tw" : "k_bonds_extras"));
+                    if (tiled_maps || tiled_tw) {
                         if ((3u * p.max_window + 6u) / 4u <= 4u * 64u && !env_flag("GORDER_HIP_NPF5")) GORDER_LAUNCH_TM(4);
                         else GORDER_LAUNCH_TM(5);
                     }
@@ -882,6 +893,10 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
             e.map_packed = h->d_map_packed;
         }
         e.tw = t->timewise ? 1 : 0;
+        if (t->timewise && !p.tiles.empty()) {      // k_bonds_tiled_tw: the tile items in slot order and their runs
+            if (!h->d_items_by_slot && (st = upload(h, &h->d_items_by_slot, p.items_by_slot)) != GORDER_OK) return st;
+            if ((st = upload(h, &h->d_item_run, p.item_run)) != GORDER_OK) return st;
+        }
         const gorder_geometry_t &ge = t->geometry;
         if (ge.kind != GORDER_GEOM_NONE) {
             if (ge.kind > GORDER_GEOM_SPHERE || ge.reference > GORDER_GEOMREF_GROUP || ge.orientation > 2)
@@ -1080,7 +1095,7 @@ void gorder_hip_destroy(gorder_hip_handle *h) {
     (void)hipFree(h->d_geom_group); (void)hipFree(h->d_shapes);
     (void)hipFree(h->d_map_rec); (void)hipFree(h->d_ua_runs); (void)hipFree(h->d_ua_run_begin);
     (void)hipFree(h->d_runs); (void)hipFree(h->d_run_begin); (void)hipFree(h->d_items_by_slot);
-    (void)hipFree(h->d_ua_item_run); (void)hipFree(h->d_lgrid); (void)hipFree(h->d_lrowpre); (void)hipFree(h->d_lfinfo); (void)hipFree(h->d_ltodo);
+    (void)hipFree(h->d_ua_item_run); (void)hipFree(h->d_item_run); (void)hipFree(h->d_lgrid); (void)hipFree(h->d_lrowpre); (void)hipFree(h->d_lfinfo); (void)hipFree(h->d_ltodo);
     (void)hipFree(h->d_dyn_cloud); (void)hipFree(h->d_dyn_heads); (void)hipFree(h->d_dyn_cell_of); (void)hipFree(h->d_dyn_count);
     (void)hipFree(h->d_dyn_rec); (void)hipFree(h->d_dyn_normals); (void)hipFree(h->d_dyn_cov);
     if (!h->acc_external) (void)hipFree(h->d_acc);

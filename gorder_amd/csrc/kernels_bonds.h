@@ -26,6 +26,7 @@ struct TiledMapOut {
 };
 // the staged word of one sample: (plane-of-leaflet * tiles + tile) << 32 | tick, or kMapNoSample outside the map
 __device__ __forceinline__ unsigned long long map_sample_word(const TiledMapOut &mo, float px, float py, float pz, int tick, bool lower) {
+    if (mo.nx == 0u) return ((unsigned long long)(lower ? 1u : 0u) << 32) | (unsigned long long)(uint32_t)tick;     // (k_bonds_tiled_tw: the tick and the side)
     float x, y;
     if (mo.plane == 0) { x = px; y = py; }
     else if (mo.plane == 1) { x = px; y = pz; }

@@ -355,6 +355,135 @@ __global__ __launch_bounds__(kBlock, 4) void k_bonds_tiled_maps(FrameArgs a_in, 
     }
 }
 
+// ---- per-frame rows (timewise sums, timewise.rs:130-186) and nothing else, bonds: K1's staging again, the stage's ticks
+// as a second output.  The tile's items come in slot order (MapRun), so the samples of a slot are neighbouring lanes: a
+// lane leaves its tick (and leaflet) of each frame of the stage in LDS, and one thread per slot of the tile adds its run
+// up — no LDS atomics (k_bonds_extras: two to four per sample, one lane per cycle) — and sends the frame's partial sums
+// to the rows with the same global atomics as extras_flush_tw.  No barrier of its own: the ticks are written before the
+// barrier that ends a stage and read behind it, next to the staging of the next stage.
+// grid = n_tiles * n_chunks; items = the slot-ordered copy, e.item_run its runs.
+template <int NPF, bool PBC, bool LEAF, int AXIS>
+__global__ __launch_bounds__(kBlock, 4) void k_bonds_tiled_tw(FrameArgs a_in, ExtraArgs e, const float *__restrict__ xyz,
+                                                             const float *__restrict__ box9, const uint8_t *__restrict__ aflags,
+                                                             const uint32_t *__restrict__ arow, const Tile *__restrict__ tiles,
+                                                             const Item *__restrict__ items, const uint32_t *__restrict__ tile_slots,
+                                                             uint32_t n_tiles, uint32_t lw) {
+    constexpr int G = (int)kRecFrames;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ int l_tick[kRecFrames][kBlock];
+    __shared__ uint8_t l_side[kRecFrames][kBlock];      // 0 upper, 1 lower (LEAF), 2: no sample
+    __shared__ uint32_t l_slot_run[kBlock];             // per slot of the tile: (first lane << 16) | lanes
+    __shared__ uint32_t l_slot_id[kBlock];              // ... and its accumulator slot
+    using S = TiledStage<G, NPF, false, PBC, LEAF, AXIS>;
+    FrameArgs a = a_in;
+    a.xyz = xyz; a.box9 = box9; a.aflags = aflags; a.arow = arow;
+    const uint32_t tile_id = blockIdx.x % n_tiles, chunk = blockIdx.x / n_tiles;
+    const Tile t = tiles[tile_id];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t sk = tid / S::TPF, si = tid % S::TPF;
+    const bool active = tid < t.n_items;
+    Item it{0, 0, 0, 0, 0};
+    if (active) {
+        it = items[t.item0 + tid];
+        const uint32_t run = e.item_run[t.item0 + tid];
+        if ((run >> 16) == tid) l_slot_run[it.lslot] = run;          // the first lane of a run writes it down
+    }
+    const uint32_t f_begin = a.frame0 + chunk * a.frames_per_chunk;
+    const uint32_t f_end = min(a.n_frames, f_begin + a.frames_per_chunk);
+    unsigned long long words[kRecFrames];
+    TiledMapOut mo{};
+    mo.nx = 0;                      // ticks only: word = (lower << 32) | tick
+    mo.words = words;
+    SampleAcc acc;
+    int bad = 0;
+    uint32_t nan_which = 0, nan_frame = kNoNan;
+    v4f pre[NPF];
+    const uint32_t my_slot = tid < t.n_slots ? tile_slots[t.slot0 + tid] : 0u;
+    l_slot_id[tid] = my_slot;
+    if (f_begin + G <= f_end) S::template load<false>(a, t, f_begin, f_end, sk, si, pre);
+    for (uint32_t fs = f_begin; fs < f_end; fs += G) {
+        const bool full = fs + G <= f_end;
+        if (full) {
+            S::template store<false>(a, t, fs, f_end, sk, si, pre, lds, lw);
+        } else {
+            S::template load<true>(a, t, fs, f_end, sk, si, pre);
+            S::template store<true>(a, t, fs, f_end, sk, si, pre, lds, lw);
+        }
+        __syncthreads();
+        if (full && fs + 2u * G <= f_end) S::template load<false>(a, t, fs + G, f_end, sk, si, pre);     // next stage in flight
+#pragma unroll
+        for (uint32_t k = 0; k < kRecFrames; k++) words[k] = kMapNoSample;
+        if (active) {
+            if (full) S::template compute<true>(a, t, it, fs, lds, lw, acc, bad, nan_which, nan_frame, &mo);
+            else S::template compute_tail<true>(a, t, it, fs, f_end, lds, lw, acc, bad, nan_which, nan_frame, &mo);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kRecFrames; k++) {
+            l_tick[k][tid] = (int)(uint32_t)words[k];
+            l_side[k][tid] = words[k] == kMapNoSample ? (uint8_t)2 : (uint8_t)(words[k] >> 32);
+        }
+        __syncthreads();
+        // a thread per (slot of the tile, frame of the stage) adds the slot's run up; the next stage's staging goes on
+        // meanwhile (other LDS), and its ticks are written behind its own barrier
+        for (uint32_t w = tid; w < kRecFrames * t.n_slots; w += kBlock) {
+            const uint32_t k = w % kRecFrames, ls = w / kRecFrames;
+            if (fs + k >= f_end) continue;
+            const uint32_t run = l_slot_run[ls], tid0 = run >> 16, n = run & 0xffffu;
+            int s_all = 0, s_low = 0;
+            uint32_t n_all = 0, n_low = 0;
+            for (uint32_t j = 0; j < n; j++) {
+                const uint32_t side = l_side[k][tid0 + j];
+                const int tick = l_tick[k][tid0 + j];
+                if (side == 2u) continue;
+                s_all += tick; n_all += 1u;
+                if (side == 1u) { s_low += tick; n_low += 1u; }
+            }
+            if (!n_all) continue;
+            const uint32_t slot = l_slot_id[ls];
+            const size_t row = ((size_t)e.tw_row0 + fs + k) * 3u * a.n_acc;
+            atomicAdd(&e.tw_sums[row + slot], (unsigned long long)(long long)s_all);
+            atomicAdd(&e.tw_cnts[row + slot], (unsigned long long)n_all);
+            if (LEAF) {
+                const uint32_t n_up = n_all - n_low;
+                if (n_up) {
+                    atomicAdd(&e.tw_sums[row + (size_t)a.n_acc + slot], (unsigned long long)(long long)(s_all - s_low));
+                    atomicAdd(&e.tw_cnts[row + (size_t)a.n_acc + slot], (unsigned long long)n_up);
+                }
+                if (n_low) {
+                    atomicAdd(&e.tw_sums[row + 2u * (size_t)a.n_acc + slot], (unsigned long long)(long long)s_low);
+                    atomicAdd(&e.tw_cnts[row + 2u * (size_t)a.n_acc + slot], (unsigned long long)n_low);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (nan_frame != kNoNan)
+        raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, nan_frame, kStageTypes, tile_slots[t.slot0 + it.lslot], 1, it.mol, nan_which);
+    if (bad) raise_box_range(a.err, f_begin);
+    unsigned long long *l_s = reinterpret_cast<unsigned long long *>(lds);   // [2][256]
+    uint32_t *l_n = reinterpret_cast<uint32_t *>(l_s + 2 * kBlock);          // [2][256]
+    l_s[tid] = 0; l_s[kBlock + tid] = 0; l_n[tid] = 0; l_n[kBlock + tid] = 0;
+    __syncthreads();
+    if (active && acc.n_tot) {
+        atomicAdd(&l_s[it.lslot], (unsigned long long)acc.s_tot);
+        atomicAdd(&l_n[it.lslot], acc.n_tot);
+        if (acc.n_up) {
+            atomicAdd(&l_s[kBlock + it.lslot], (unsigned long long)acc.s_up);
+            atomicAdd(&l_n[kBlock + it.lslot], acc.n_up);
+        }
+    }
+    __syncthreads();
+    if (tid < t.n_slots && l_n[tid]) {
+        unsigned long long *accp = a.rep + (size_t)(blockIdx.x % a.n_rep) * 4u * a.n_acc;
+        atomicAdd(&accp[my_slot], l_s[tid]);
+        atomicAdd(&accp[2u * a.n_acc + my_slot], (unsigned long long)l_n[tid]);
+        if (l_n[kBlock + tid]) {
+            atomicAdd(&accp[a.n_acc + my_slot], l_s[kBlock + tid]);
+            atomicAdd(&accp[3u * a.n_acc + my_slot], (unsigned long long)l_n[kBlock + tid]);
+        }
+    }
+}
+
 // ---- united atoms: hydrogen construction, restating uaorder.rs:947-1104 with the operation order of
 // nalgebra's Rotation3::from_axis_angle / matrix * vector and groan_rs' shift / wrap (oracle:
 // gorder_oracle_predict_hydrogens).  All f32, no FMA.

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box): tools/bench_all.sh <outfile>  — one bench.py line per workload of BASELINE.json's configs
+# usage (on the GPU box): tools/bench_all.sh <outfile>  — one bench.py line per workload: BASELINE.json's configs, then the other options
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=${1:-$ROOT/gpurun_out/bench_all.jsonl}
 : > $OUT
@@ -14,6 +14,10 @@ run cg3k-local 512 10 4
 run ua256 3000 50 40
 run ua256-maps 3000 50 30
 run cg1m 500 40 30
+# the options no BASELINE config uses (timewise rows)
+run aa256-timewise 3000 50 40
+run aa256-cylinder 3000 50 40
+run cg3k-dynamic 512 10 4
 python3 - <<PY
 import json
 for line in open("$OUT"):
