@@ -50,6 +50,36 @@ def test_ordermaps(built, plane, leaflets):
 @pytest.mark.parametrize("gather", [False, True])
 @pytest.mark.parametrize("pbc,normal,leaflets", [(True, (0.0, 0.0, 1.0), LEAFLETS_NONE), (True, (0.3, -0.2, 0.9), LEAFLETS_GLOBAL),
                                                  (False, (0.0, 1.0, 0.0), LEAFLETS_NONE), (True, (1.0, 0.0, 0.0), LEAFLETS_INDIVIDUAL)])
+def test_timewise_rows_of_bonds_through_both_producers(built, monkeypatch, gather, pbc, normal, leaflets):
+    """Per-frame rows and nothing else: out of K1's staging (k_bonds_tiled_tw: the stage's ticks through LDS, a thread per
+    slot and frame) — or, with GORDER_HIP_TW_GATHER, out of k_bonds_extras' LDS atomics.  39 frames in two batches (whole
+    stages and partial ones), several molecule types, with and without leaflets: the oracle's rows."""
+    if gather:
+        monkeypatch.setenv("GORDER_HIP_TW_GATHER", "1")
+    system = synthetic.cg_membrane(230, leaflets=leaflets, n_types=3, handle_pbc=pbc, normal=normal, timewise=True)
+    n = 39
+    xyz = system.frames(n, seed=13)
+    box = system.box9(n) if pbc else None
+    eng = HipEngine(system.tables)
+    eng.kernel_time()
+    o = oracle.OracleEngine(system.tables, trig=oracle.TRIG_DIRECT, n_threads=2)
+    for a, b in ((0, 22), (22, n)):
+        eng.submit_host(xyz[a:b], None if box is None else box[a:b], np.arange(a, b))
+        o.submit(xyz[a:b], None if box is None else box[a:b], np.arange(a, b))
+    got, want = eng.finish(), o.finish()
+    np.testing.assert_array_equal(got.sums, want.sums)
+    np.testing.assert_array_equal(got.counts, want.counts)
+    gs, gc = eng.timewise(n)
+    ws, wc = o.timewise(n)
+    np.testing.assert_array_equal(gs, ws)
+    np.testing.assert_array_equal(gc, wc)
+    assert gc[:, 0].sum() > 0 and (leaflets == LEAFLETS_NONE or (gc[:, 1].sum() > 0 and gc[:, 2].sum() > 0))
+    assert ("k_bonds_extras" if gather else "k_bonds_tiled_tw") in eng.kernel_names()
+
+
+@pytest.mark.parametrize("gather", [False, True])
+@pytest.mark.parametrize("pbc,normal,leaflets", [(True, (0.0, 0.0, 1.0), LEAFLETS_NONE), (True, (0.3, -0.2, 0.9), LEAFLETS_GLOBAL),
+                                                 (False, (0.0, 1.0, 0.0), LEAFLETS_NONE), (True, (1.0, 0.0, 0.0), LEAFLETS_INDIVIDUAL)])
 def test_ordermaps_of_bonds_through_both_producers(built, monkeypatch, gather, pbc, normal, leaflets):
     """Maps and nothing else: the samples come out of K1's staging (k_bonds_tiled_maps) — or, with GORDER_HIP_MAPS_GATHER,
     out of k_bonds_extras — and go through k_map_accumulate.  37 frames in one batch (nine whole stages and a partial
