@@ -219,6 +219,10 @@ __global__ __launch_bounds__(kBlock) void k_bonds_extras(FrameArgs a_in, ExtraAr
                     if (n.w < 3.0f) raise_error(a.err, GORDER_ERR_DYNAMIC_NORMAL, f, kStageTypes, gslot, 1, it.mol, (uint32_t)n.w);
                     const float n2sq = (n.x * n.x + n.y * n.y) + n.z * n.z;
                     sch = gm_calc_sch<ACOS_COS>(vx, vy, vz, n.x, n.y, n.z, __builtin_sqrtf(n2sq), n2sq);
+                } else if (!ACOS_COS && e.axis >= 0) {     // the static normal is a coordinate axis: K1's short form, same bits
+                    bool rare = false;
+                    sch = e.axis == 0 ? gm_sch_axis<0>(vx, vy, vz, rare) : (e.axis == 1 ? gm_sch_axis<1>(vx, vy, vz, rare) : gm_sch_axis<2>(vx, vy, vz, rare));
+                    if (__builtin_expect(rare, 0)) sch = gm_calc_sch<ACOS_COS>(vx, vy, vz, a.nx, a.ny, a.nz, a.n2, a.n2sq);
                 } else {
                     sch = gm_calc_sch<ACOS_COS>(vx, vy, vz, a.nx, a.ny, a.nz, a.n2, a.n2sq);
                 }
