@@ -24,9 +24,12 @@ struct TiledMapOut {
     int bin_core;
     unsigned long long *words;
 };
+// what k_bonds_tiled_tw wants of a sample: its side and its tick
+__device__ __forceinline__ unsigned long long tick_sample_word(int tick, bool lower) {
+    return ((unsigned long long)(lower ? 1u : 0u) << 32) | (unsigned long long)(uint32_t)tick;
+}
 // the staged word of one sample: (plane-of-leaflet * tiles + tile) << 32 | tick, or kMapNoSample outside the map
 __device__ __forceinline__ unsigned long long map_sample_word(const TiledMapOut &mo, float px, float py, float pz, int tick, bool lower) {
-    if (mo.nx == 0u) return ((unsigned long long)(lower ? 1u : 0u) << 32) | (unsigned long long)(uint32_t)tick;     // (k_bonds_tiled_tw: the tick and the side)
     float x, y;
     if (mo.plane == 0) { x = px; y = py; }
     else if (mo.plane == 1) { x = px; y = pz; }
@@ -78,7 +81,8 @@ __device__ __forceinline__ bool bond_sample(const FrameArgs &a, uint32_t f, floa
             acc.n_up += 1;
         }
     }
-    if (mo) *word = map_sample_word(*mo, p1x + vx / 2.0f, p1y + vy / 2.0f, p1z + vz / 2.0f, (int)tick, lower);   // bond position = p1 + v / 2 (bond.rs:422)
+    if (mo) *word = mo->nx == 0u ? tick_sample_word((int)tick, lower)        // (k_bonds_tiled_tw)
+                                 : map_sample_word(*mo, p1x + vx / 2.0f, p1y + vy / 2.0f, p1z + vz / 2.0f, (int)tick, lower);   // bond position = p1 + v / 2 (bond.rs:422)
     return sch != sch;
 }
 
@@ -139,11 +143,12 @@ struct TiledStage {
     // The common path is straight-line code (selects only) so that the G independent dependency chains
     // interleave; the rare cases (atoms more than 1.5 box lengths apart -> literal minimum-image loops;
     // NaN result -> which atom is undefined?) are collected in a bit mask and handled after the stage.
-    template <int NF, bool MAPS = false>
+    template <int NF, int OUT = 0>       // OUT: 0 the accumulators only, 1 + the ordermap words, 2 + (side, tick) words
     static __device__ __forceinline__ void compute_core(const FrameArgs &a, const Tile &t, const Item &it,
                                                         uint32_t f0, const float (&P)[NF][6], SampleAcc &acc,
                                                         int &bad, uint32_t &nan_which, uint32_t &nan_frame,
                                                         const TiledMapOut *mo = nullptr, uint32_t k0 = 0) {
+        constexpr bool MAPS = OUT != 0;
         int tick[NF];
         uint8_t fl[NF];
         float bx[NF], by[NF], bz[NF];
@@ -151,8 +156,9 @@ struct TiledStage {
         // MAPS: the sample's word (bond position = p1 + v / 2, bond.rs:422, v the SIGNED minimum-image vector) goes to
         // this thread's word of frame k0 + k of the stage as soon as its tick is known
         auto stage_word = [&](int k, float vx, float vy, float vz) {
-            mo->words[k0 + (uint32_t)k] =
-                map_sample_word(*mo, P[k][0] + vx / 2.0f, P[k][1] + vy / 2.0f, P[k][2] + vz / 2.0f, tick[k], LEAF && fl[k] != 0);
+            mo->words[k0 + (uint32_t)k] = OUT == 2
+                ? tick_sample_word(tick[k], LEAF && fl[k] != 0)
+                : map_sample_word(*mo, P[k][0] + vx / 2.0f, P[k][1] + vy / 2.0f, P[k][2] + vz / 2.0f, tick[k], LEAF && fl[k] != 0);
         };
         // uniform per-frame inputs of the whole stage first (scalar loads, issued back to back)
 #pragma unroll
@@ -255,13 +261,13 @@ struct TiledStage {
         acc.n_up += nu;
     }
     // LDS-staged variant: pick my two atoms out of the staged windows
-    template <bool MAPS = false>
+    template <int OUT = 0>
     static __device__ __forceinline__ void compute(const FrameArgs &a, const Tile &t, const Item &it, uint32_t f0,
                                                    const float *lds, uint32_t lw, SampleAcc &acc, int &bad,
                                                    uint32_t &nan_which, uint32_t &nan_frame, const TiledMapOut *mo = nullptr) {
         // NF frames at a time: NF independent dependency chains interleave; fewer live registers than all G at once
         // (with the map words two at a time: four chains and their tile arithmetic do not fit the 128 registers)
-        constexpr int NF = MAPS ? 2 : (GORDER_COMPUTE_NF < G ? GORDER_COMPUTE_NF : G);
+        constexpr int NF = OUT == 1 ? 2 : (GORDER_COMPUTE_NF < G ? GORDER_COMPUTE_NF : G);
 #pragma unroll
         for (int h = 0; h < G; h += NF) {
             float P[NF][6];
@@ -272,16 +278,16 @@ struct TiledStage {
                 P[k][0] = w[3u * it.li]; P[k][1] = w[3u * it.li + 1]; P[k][2] = w[3u * it.li + 2];
                 P[k][3] = w[3u * it.lj]; P[k][4] = w[3u * it.lj + 1]; P[k][5] = w[3u * it.lj + 2];
             }
-            compute_core<NF, MAPS>(a, t, it, f0 + h, P, acc, bad, nan_which, nan_frame, mo, (uint32_t)h);
+            compute_core<NF, OUT>(a, t, it, f0 + h, P, acc, bad, nan_which, nan_frame, mo, (uint32_t)h);
         }
     }
     // partial last stage: frames f0 .. f_end-1, one at a time (not performance relevant)
-    template <bool MAPS = false>
+    template <int OUT = 0>
     static __device__ __forceinline__ void compute_tail(const FrameArgs &a, const Tile &t, const Item &it,
                                                         uint32_t f0, uint32_t f_end, const float *lds, uint32_t lw,
                                                         SampleAcc &acc, int &bad, uint32_t &nan_which,
                                                         uint32_t &nan_frame, const TiledMapOut *mo = nullptr) {
-        if (MAPS) {     // (unrolled: the words stay in registers)
+        if (OUT != 0) {     // (unrolled: the words stay in registers)
 #pragma unroll
             for (int k = 0; k < G; k++) {
                 const uint32_t f = f0 + (uint32_t)k;

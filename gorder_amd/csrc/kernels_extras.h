@@ -316,7 +316,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_bonds_tiled_maps(FrameArgs a_in, 
         S::template store<false>(a, t, f0, f_end, sk, si, pre, lds, lw);
         __syncthreads();
         if (f0 + G < f_full) S::template load<false>(a, t, f0 + G, f_end, sk, si, pre);
-        if (active) S::template compute<true>(a, t, it, f0, lds, lw, acc, bad, nan_which, nan_frame, &mo);
+        if (active) S::template compute<1>(a, t, it, f0, lds, lw, acc, bad, nan_which, nan_frame, &mo);
         rec_store(e, tile_id, f0, tid, words);
         __syncthreads();
     }
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_bonds_tiled_maps(FrameArgs a_in, 
         __syncthreads();
 #pragma unroll
         for (uint32_t m = 0; m < kRecFrames; m++) words[m] = kMapNoSample;
-        if (active) S::template compute_tail<true>(a, t, it, f_full, f_end, lds, lw, acc, bad, nan_which, nan_frame, &mo);
+        if (active) S::template compute_tail<1>(a, t, it, f_full, f_end, lds, lw, acc, bad, nan_which, nan_frame, &mo);
         rec_store(e, tile_id, f_full, tid, words);
         __syncthreads();
     }
@@ -418,8 +418,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_bonds_tiled_tw(FrameArgs a_in, Ex
 #pragma unroll
         for (uint32_t k = 0; k < kRecFrames; k++) words[k] = kMapNoSample;
         if (active) {
-            if (full) S::template compute<true>(a, t, it, fs, lds, lw, acc, bad, nan_which, nan_frame, &mo);
-            else S::template compute_tail<true>(a, t, it, fs, f_end, lds, lw, acc, bad, nan_which, nan_frame, &mo);
+            if (full) S::template compute<2>(a, t, it, fs, lds, lw, acc, bad, nan_which, nan_frame, &mo);
+            else S::template compute_tail<2>(a, t, it, fs, f_end, lds, lw, acc, bad, nan_which, nan_frame, &mo);
         }
 #pragma unroll
         for (uint32_t k = 0; k < kRecFrames; k++) {
