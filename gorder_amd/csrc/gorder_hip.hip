@@ -914,6 +914,7 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
                 if ((st = upload(h, &h->d_geom_group, grp)) != GORDER_OK) return st;
             }
             e.geom_kind = (int)ge.kind; e.geom_invert = ge.invert ? 1 : 0; e.geom_orient = (int)ge.orientation;
+            e.geom_thr = local_radius_threshold(ge.radius);
             h->tables.geometry.group = nullptr;
         }
         if ((e.maps || e.tw || e.geom_kind) && !p.direct.empty())

@@ -41,29 +41,40 @@ struct ExtraArgs {
     float sin_tet, cos_tet, sin_ch3, cos_ch3, sin_half, cos_half;
     // geometry selection (geometry.rs): per-frame shapes [n_frames][8] = anchor xyz, extents xyz, radius, height
     int geom_kind, geom_invert, geom_orient;
+    float geom_thr;                  // cylinder / sphere: local_radius_threshold(radius), d2 < geom_thr == sqrt(d2) < radius
     const float *shapes;
 };
 
-// groan_rs Rectangular / Cylinder / Sphere ::inside (oracle: inside_shape), XOR invert (geometry.rs:181-189)
+// groan_rs Rectangular / Cylinder / Sphere ::inside (oracle: inside_shape), XOR invert (geometry.rs:181-189).
+// No array is indexed by a run-time value (the cylinder's axis picks its operands by selects: arrays indexed by it went
+// to scratch memory), and `sqrt(d2) < radius` is `d2 < e.geom_thr` (local_radius_threshold: the smallest float whose
+// correctly rounded square root reaches the radius — the same samples, no IEEE square root per sample).
 __device__ __forceinline__ bool geom_inside(const ExtraArgs &e, const float *sh, float px, float py, float pz,
                                             const float *box, bool pbc, int &bad) {
-    const float p[3] = {px, py, pz};
     bool in = true;
     if (e.geom_kind == GORDER_GEOM_CUBOID) {
-        for (int d = 0; d < 3; d++) {
-            float x = p[d] - sh[d];
-            if (pbc) { x = gm_wrap(x, box[d], bad); in = in && (x <= sh[3 + d]); }
-            else in = in && (x >= 0.0f) && (x <= sh[3 + d]);
+        float x = px - sh[0], y = py - sh[1], z = pz - sh[2];
+        if (pbc) {
+            x = gm_wrap(x, box[0], bad); y = gm_wrap(y, box[1], bad); z = gm_wrap(z, box[2], bad);
+            in = (x <= sh[3]) && (y <= sh[4]) && (z <= sh[5]);
+        } else {
+            in = (x >= 0.0f) && (x <= sh[3]) && (y >= 0.0f) && (y <= sh[4]) && (z >= 0.0f) && (z <= sh[5]);
         }
     } else if (e.geom_kind == GORDER_GEOM_CYLINDER) {
-        const int o = e.geom_orient, a = (o + 1) % 3, b = (o + 2) % 3;
-        float da = p[a] - sh[a], db = p[b] - sh[b], x = p[o] - sh[o];
-        if (pbc) { da = gm_min_image(da, box[a], bad); db = gm_min_image(db, box[b], bad); x = gm_wrap(x, box[o], bad); }
-        in = (__builtin_sqrtf(da * da + db * db) < sh[6]) && (pbc ? true : (x >= 0.0f)) && (x <= sh[7]);
+        // orientation o, in-plane axes a = (o + 1) % 3 and b = (o + 2) % 3
+        const int o = e.geom_orient;
+        const float dx = px - sh[0], dy = py - sh[1], dz = pz - sh[2];
+        float x = o == 0 ? dx : (o == 1 ? dy : dz), da = o == 0 ? dy : (o == 1 ? dz : dx), db = o == 0 ? dz : (o == 1 ? dx : dy);
+        if (pbc) {
+            const float bo = o == 0 ? box[0] : (o == 1 ? box[1] : box[2]), ba = o == 0 ? box[1] : (o == 1 ? box[2] : box[0]),
+                        bb = o == 0 ? box[2] : (o == 1 ? box[0] : box[1]);
+            da = gm_min_image(da, ba, bad); db = gm_min_image(db, bb, bad); x = gm_wrap(x, bo, bad);
+        }
+        in = (da * da + db * db < e.geom_thr) && (pbc ? true : (x >= 0.0f)) && (x <= sh[7]);
     } else {
-        float d[3];
-        for (int k = 0; k < 3; k++) { d[k] = p[k] - sh[k]; if (pbc) d[k] = gm_min_image(d[k], box[k], bad); }
-        in = __builtin_sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) < sh[6];
+        float dx = px - sh[0], dy = py - sh[1], dz = pz - sh[2];
+        if (pbc) { dx = gm_min_image(dx, box[0], bad); dy = gm_min_image(dy, box[1], bad); dz = gm_min_image(dz, box[2], bad); }
+        in = (dx * dx + dy * dy) + dz * dz < e.geom_thr;
     }
     return in != (e.geom_invert != 0);
 }
