@@ -59,6 +59,10 @@ def make_system(name):
         from gorder_amd.abi import OrderMap
         om = OrderMap(enabled=True, plane=0, span_x=(0.0, 9.0), span_y=(0.0, 9.0), bin=(0.1, 0.1))
         return synthetic.aa_membrane(256, ordermap=om), "AAOrder 256 lipids + 91x91 ordermaps"
+    if name == "aa256-maps-timewise":
+        from gorder_amd.abi import OrderMap
+        om = OrderMap(enabled=True, plane=0, span_x=(0.0, 9.0), span_y=(0.0, 9.0), bin=(0.1, 0.1))
+        return synthetic.aa_membrane(256, ordermap=om, timewise=True), "AAOrder 256 lipids + 91x91 ordermaps + per-frame rows"
     if name == "ua256-maps":     # BASELINE configs[3]
         from gorder_amd.abi import OrderMap
         om = OrderMap(enabled=True, plane=0, span_x=(0.0, 9.0), span_y=(0.0, 9.0), bin=(0.1, 0.1))

@@ -537,7 +537,8 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
                 if (staged) fpc = (fpc + 15u) / 16u * 16u;   // whole frame blocks (kRecFrames) and whole lines per workgroup
                 // per-frame rows and nothing else, the default cosine, four frames per stage: the tiled kernel with the
                 // stage's ticks as a second output (k_bonds_tiled_tw)
-                const bool tiled_tw = pass == 0 && e.tw && !e.maps && !e.geom_kind && !e.dyn && !ac && !h->use_gather && h->d_item_run &&
+                // (with staged ordermaps as well: the same kernel writes the map words too)
+                const bool tiled_tw = pass == 0 && e.tw && (!e.maps || staged) && !e.geom_kind && !e.dyn && !ac && !h->use_gather && h->d_item_run &&
                                       h->frames_per_stage == (int)kRecFrames && !env_flag("GORDER_HIP_TW_GATHER");
                 if (tiled_tw) fpc = (fpc + kRecFrames - 1u) / kRecFrames * kRecFrames;       // whole stages
                 n_chunks = (nf + fpc - 1) / fpc;
@@ -562,8 +563,11 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
                                             !env_flag("GORDER_HIP_MAPS_GATHER");
 #define GORDER_LAUNCH_TM_A(NPF_, PBC_, LF_, AX_)                                                                   \
     do {                                                                                                            \
-        if (tiled_tw)                                                                                               \
-            hipLaunchKernelGGL((k_bonds_tiled_tw<NPF_, PBC_, LF_, AX_>), g, blk, h->lds_bytes, h->stream, b, e, b.xyz,  \
+        if (tiled_tw && staged)                                                                                     \
+            hipLaunchKernelGGL((k_bonds_tiled_tw<NPF_, PBC_, LF_, AX_, true>), g, blk, h->lds_bytes, h->stream, b, e, b.xyz, \
+                               b.box9, b.aflags, b.arow, h->d_tiles, items, h->d_tile_slots, nt, h->lw);               \
+        else if (tiled_tw)                                                                                          \
+            hipLaunchKernelGGL((k_bonds_tiled_tw<NPF_, PBC_, LF_, AX_, false>), g, blk, h->lds_bytes, h->stream, b, e, b.xyz, \
                                b.box9, b.aflags, b.arow, h->d_tiles, items, h->d_tile_slots, nt, h->lw);               \
         else                                                                                                        \
             hipLaunchKernelGGL((k_bonds_tiled_maps<NPF_, PBC_, LF_, AX_>), g, blk, h->lds_bytes, h->stream, b, e, b.xyz, \

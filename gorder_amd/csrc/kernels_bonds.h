@@ -23,6 +23,7 @@ struct TiledMapOut {
     uint32_t nx, ny;
     int bin_core;
     unsigned long long *words;
+    unsigned long long *ticks;       // OUT = 3: the (side, tick) words next to the ordermap words
 };
 // what k_bonds_tiled_tw wants of a sample: its side and its tick
 __device__ __forceinline__ unsigned long long tick_sample_word(int tick, bool lower) {
@@ -51,7 +52,8 @@ struct SampleAcc {
 template <bool ACOS_COS>
 __device__ __forceinline__ bool bond_sample(const FrameArgs &a, uint32_t f, float p1x, float p1y, float p1z,
                                             float p2x, float p2y, float p2z, uint32_t mol, SampleAcc &acc,
-                                            int &bad, const TiledMapOut *mo = nullptr, unsigned long long *word = nullptr) {
+                                            int &bad, const TiledMapOut *mo = nullptr, unsigned long long *word = nullptr,
+                                            unsigned long long *tick_word = nullptr) {
     float vx = p2x - p1x, vy = p2y - p1y, vz = p2z - p1z;
     if (a.pbc) {
         const float *b = a.box9 + 9 * (size_t)f;
@@ -81,8 +83,11 @@ __device__ __forceinline__ bool bond_sample(const FrameArgs &a, uint32_t f, floa
             acc.n_up += 1;
         }
     }
-    if (mo) *word = mo->nx == 0u ? tick_sample_word((int)tick, lower)        // (k_bonds_tiled_tw)
-                                 : map_sample_word(*mo, p1x + vx / 2.0f, p1y + vy / 2.0f, p1z + vz / 2.0f, (int)tick, lower);   // bond position = p1 + v / 2 (bond.rs:422)
+    if (mo) {
+        *word = mo->nx == 0u ? tick_sample_word((int)tick, lower)        // (k_bonds_tiled_tw)
+                             : map_sample_word(*mo, p1x + vx / 2.0f, p1y + vy / 2.0f, p1z + vz / 2.0f, (int)tick, lower);   // bond position = p1 + v / 2 (bond.rs:422)
+        if (tick_word) *tick_word = tick_sample_word((int)tick, lower);
+    }
     return sch != sch;
 }
 
@@ -143,7 +148,7 @@ struct TiledStage {
     // The common path is straight-line code (selects only) so that the G independent dependency chains
     // interleave; the rare cases (atoms more than 1.5 box lengths apart -> literal minimum-image loops;
     // NaN result -> which atom is undefined?) are collected in a bit mask and handled after the stage.
-    template <int NF, int OUT = 0>       // OUT: 0 the accumulators only, 1 + the ordermap words, 2 + (side, tick) words
+    template <int NF, int OUT = 0>       // OUT: 0 the accumulators only, 1 + the ordermap words, 2 + (side, tick) words, 3 + both
     static __device__ __forceinline__ void compute_core(const FrameArgs &a, const Tile &t, const Item &it,
                                                         uint32_t f0, const float (&P)[NF][6], SampleAcc &acc,
                                                         int &bad, uint32_t &nan_which, uint32_t &nan_frame,
@@ -159,6 +164,7 @@ struct TiledStage {
             mo->words[k0 + (uint32_t)k] = OUT == 2
                 ? tick_sample_word(tick[k], LEAF && fl[k] != 0)
                 : map_sample_word(*mo, P[k][0] + vx / 2.0f, P[k][1] + vy / 2.0f, P[k][2] + vz / 2.0f, tick[k], LEAF && fl[k] != 0);
+            if (OUT == 3) mo->ticks[k0 + (uint32_t)k] = tick_sample_word(tick[k], LEAF && fl[k] != 0);
         };
         // uniform per-frame inputs of the whole stage first (scalar loads, issued back to back)
 #pragma unroll
@@ -267,7 +273,7 @@ struct TiledStage {
                                                    uint32_t &nan_which, uint32_t &nan_frame, const TiledMapOut *mo = nullptr) {
         // NF frames at a time: NF independent dependency chains interleave; fewer live registers than all G at once
         // (with the map words two at a time: four chains and their tile arithmetic do not fit the 128 registers)
-        constexpr int NF = OUT == 1 ? 2 : (GORDER_COMPUTE_NF < G ? GORDER_COMPUTE_NF : G);
+        constexpr int NF = (OUT == 1 || OUT == 3) ? 2 : (GORDER_COMPUTE_NF < G ? GORDER_COMPUTE_NF : G);
 #pragma unroll
         for (int h = 0; h < G; h += NF) {
             float P[NF][6];
@@ -296,7 +302,8 @@ struct TiledStage {
                 const float *w = lds + (size_t)k * lw + sh;
                 const float p1x = w[3u * it.li], p1y = w[3u * it.li + 1], p1z = w[3u * it.li + 2];
                 const float p2x = w[3u * it.lj], p2y = w[3u * it.lj + 1], p2z = w[3u * it.lj + 2];
-                if (bond_sample<ACOS_COS>(a, f, p1x, p1y, p1z, p2x, p2y, p2z, it.mol, acc, bad, mo, mo->words + k) && nan_frame == kNoNan) {
+                if (bond_sample<ACOS_COS>(a, f, p1x, p1y, p1z, p2x, p2y, p2z, it.mol, acc, bad, mo, mo->words + k, OUT == 3 ? mo->ticks + k : nullptr) &&
+                    nan_frame == kNoNan) {
                     if (p1x != p1x) { nan_which = 0; nan_frame = f; }
                     else if (p2x != p2x) { nan_which = 1; nan_frame = f; }
                 }

@@ -370,14 +370,14 @@ __global__ __launch_bounds__(kBlock, 4) void k_bonds_tiled_maps(FrameArgs a_in, 
     }
 }
 
-// ---- per-frame rows (timewise sums, timewise.rs:130-186) and nothing else, bonds: K1's staging again, the stage's ticks
-// as a second output.  The tile's items come in slot order (MapRun), so the samples of a slot are neighbouring lanes: a
+// ---- per-frame rows (timewise sums, timewise.rs:130-186), alone or (MAPS) with staged ordermaps, bonds: K1's staging
+// again, the stage's ticks as a second output (and the ordermap words as a third, written like k_bonds_tiled_maps').  The tile's items come in slot order (MapRun), so the samples of a slot are neighbouring lanes: a
 // lane leaves its tick (and leaflet) of each frame of the stage in LDS, and one thread per slot of the tile adds its run
 // up — no LDS atomics (k_bonds_extras: two to four per sample, one lane per cycle) — and sends the frame's partial sums
 // to the rows with the same global atomics as extras_flush_tw.  No barrier of its own: the ticks are written before the
 // barrier that ends a stage and read behind it, next to the staging of the next stage.
 // grid = n_tiles * n_chunks; items = the slot-ordered copy, e.item_run its runs.
-template <int NPF, bool PBC, bool LEAF, int AXIS>
+template <int NPF, bool PBC, bool LEAF, int AXIS, bool MAPS>
 __global__ __launch_bounds__(kBlock, 4) void k_bonds_tiled_tw(FrameArgs a_in, ExtraArgs e, const float *__restrict__ xyz,
                                                              const float *__restrict__ box9, const uint8_t *__restrict__ aflags,
                                                              const uint32_t *__restrict__ arow, const Tile *__restrict__ tiles,
@@ -405,10 +405,15 @@ __global__ __launch_bounds__(kBlock, 4) void k_bonds_tiled_tw(FrameArgs a_in, Ex
     }
     const uint32_t f_begin = a.frame0 + chunk * a.frames_per_chunk;
     const uint32_t f_end = min(a.n_frames, f_begin + a.frames_per_chunk);
-    unsigned long long words[kRecFrames];
+    unsigned long long words[kRecFrames], mwords[MAPS ? kRecFrames : 1];
     TiledMapOut mo{};
-    mo.nx = 0;                      // ticks only: word = (lower << 32) | tick
-    mo.words = words;
+    if (MAPS) {                     // the ordermap words as well (staged like k_bonds_tiled_maps')
+        mo.plane = e.plane; mo.x0 = e.x0; mo.y0 = e.y0; mo.binx = e.binx; mo.biny = e.biny; mo.nx = e.nx; mo.ny = e.ny;
+        mo.bin_core = e.bin_core; mo.words = mwords; mo.ticks = words;
+    } else {
+        mo.nx = 0;                  // ticks only: word = (lower << 32) | tick
+        mo.words = words;
+    }
     SampleAcc acc;
     int bad = 0;
     uint32_t nan_which = 0, nan_frame = kNoNan;
@@ -427,11 +432,12 @@ __global__ __launch_bounds__(kBlock, 4) void k_bonds_tiled_tw(FrameArgs a_in, Ex
         __syncthreads();
         if (full && fs + 2u * G <= f_end) S::template load<false>(a, t, fs + G, f_end, sk, si, pre);     // next stage in flight
 #pragma unroll
-        for (uint32_t k = 0; k < kRecFrames; k++) words[k] = kMapNoSample;
+        for (uint32_t k = 0; k < kRecFrames; k++) { words[k] = kMapNoSample; if (MAPS) mwords[k] = kMapNoSample; }
         if (active) {
-            if (full) S::template compute<2>(a, t, it, fs, lds, lw, acc, bad, nan_which, nan_frame, &mo);
-            else S::template compute_tail<2>(a, t, it, fs, f_end, lds, lw, acc, bad, nan_which, nan_frame, &mo);
+            if (full) S::template compute<MAPS ? 3 : 2>(a, t, it, fs, lds, lw, acc, bad, nan_which, nan_frame, &mo);
+            else S::template compute_tail<MAPS ? 3 : 2>(a, t, it, fs, f_end, lds, lw, acc, bad, nan_which, nan_frame, &mo);
         }
+        if constexpr (MAPS) rec_store(e, tile_id, fs, tid, mwords);
 #pragma unroll
         for (uint32_t k = 0; k < kRecFrames; k++) {
             l_tick[k][tid] = (int)(uint32_t)words[k];

@@ -48,6 +48,39 @@ def test_ordermaps(built, plane, leaflets):
 
 
 @pytest.mark.parametrize("gather", [False, True])
+@pytest.mark.parametrize("leaflets", [LEAFLETS_NONE, LEAFLETS_GLOBAL])
+def test_ordermaps_and_timewise_rows_of_bonds_together(built, monkeypatch, gather, leaflets):
+    """Staged ordermaps AND per-frame rows: one tiled kernel leaves both kinds of words (k_bonds_tiled_tw<..., MAPS>);
+    with GORDER_HIP_TW_GATHER the general k_bonds_extras.  41 frames in two batches against the oracle."""
+    if gather:
+        monkeypatch.setenv("GORDER_HIP_TW_GATHER", "1")
+    system = synthetic.cg_membrane(210, leaflets=leaflets, n_types=2, timewise=True)
+    bx = system.box
+    system.tables.ordermap = OrderMap(enabled=True, plane=0, span_x=(0.0, float(bx[0])), span_y=(0.0, float(bx[1])), bin=(0.5, 0.7))
+    n = 41
+    xyz = system.frames(n, seed=14)
+    box = system.box9(n)
+    eng = HipEngine(system.tables)
+    eng.kernel_time()
+    o = oracle.OracleEngine(system.tables, trig=oracle.TRIG_DIRECT, n_threads=2)
+    for a, b in ((0, 19), (19, n)):
+        eng.submit_host(xyz[a:b], box[a:b], np.arange(a, b))
+        o.submit(xyz[a:b], box[a:b], np.arange(a, b))
+    got, want = eng.finish(), o.finish()
+    np.testing.assert_array_equal(got.sums, want.sums)
+    np.testing.assert_array_equal(got.counts, want.counts)
+    np.testing.assert_array_equal(got.map_counts, want.map_counts)
+    np.testing.assert_array_equal(got.map_sums, want.map_sums)
+    gs, gc = eng.timewise(n)
+    ws, wc = o.timewise(n)
+    np.testing.assert_array_equal(gs, ws)
+    np.testing.assert_array_equal(gc, wc)
+    assert got.map_counts.sum() > 0 and gc[:, 0].sum() > 0
+    names = eng.kernel_names()
+    assert ("k_bonds_extras" if gather else "k_bonds_tiled_tw") in names and "k_map_accumulate" in names
+
+
+@pytest.mark.parametrize("gather", [False, True])
 @pytest.mark.parametrize("pbc,normal,leaflets", [(True, (0.0, 0.0, 1.0), LEAFLETS_NONE), (True, (0.3, -0.2, 0.9), LEAFLETS_GLOBAL),
                                                  (False, (0.0, 1.0, 0.0), LEAFLETS_NONE), (True, (1.0, 0.0, 0.0), LEAFLETS_INDIVIDUAL)])
 def test_timewise_rows_of_bonds_through_both_producers(built, monkeypatch, gather, pbc, normal, leaflets):
