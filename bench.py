@@ -68,6 +68,8 @@ def make_system(name):
         om = OrderMap(enabled=True, plane=0, span_x=(0.0, 9.0), span_y=(0.0, 9.0), bin=(0.1, 0.1))
         return (synthetic.ua_membrane(256, ordermap=om),
                 "UAOrder 256 united-atom lipids (62 virtual C-H per lipid) + 91x91 ordermaps")
+    if name == "ua256-timewise":
+        return synthetic.ua_membrane(256, timewise=True), "UAOrder 256 united-atom lipids + per-frame rows (error estimation)"
     if name == "ua256":
         return synthetic.ua_membrane(256), "UAOrder 256 united-atom lipids (62 virtual C-H per lipid)"
     if name == "cg3k-dynamic":   # membrane normal: dynamic (normal.rs:160-199): per lipid and frame, PCA of the heads within 2 nm

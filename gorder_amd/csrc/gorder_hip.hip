@@ -608,6 +608,7 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
                     const bool maps_only = extras && staged && !e.tw && !e.geom_kind && !e.dyn;
                     name("k_ua_extras");
                     if (maps_only) { if (ac) GORDER_LAUNCH_UA(true, 1); else GORDER_LAUNCH_UA(false, 1); }
+                    else if (extras && e.tw && !e.maps && !e.geom_kind && !e.dyn) { if (ac) GORDER_LAUNCH_UA(true, 3); else GORDER_LAUNCH_UA(false, 3); }
                     else if (extras) { if (ac) GORDER_LAUNCH_UA(true, 2); else GORDER_LAUNCH_UA(false, 2); }
                     else { if (ac) GORDER_LAUNCH_UA(true, 0); else GORDER_LAUNCH_UA(false, 0); }
 #undef GORDER_LAUNCH_UA

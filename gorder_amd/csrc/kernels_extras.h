@@ -80,12 +80,12 @@ __device__ __forceinline__ bool geom_inside(const ExtraArgs &e, const float *sh,
 }
 
 // BondLike::add_order for the scatter targets (bond.rs:184-215): maps and the per-frame LDS partials
-template <bool STAGED_ONLY = false>
+template <bool STAGED_ONLY = false, bool NO_MAPS = false>
 __device__ __forceinline__ void extras_add(const FrameArgs &a, const ExtraArgs &e, uint32_t gslot, uint32_t lslot,
                                            int tick, float px, float py, float pz, int leaflet /* -1 none */,
                                            int *l_tw, uint32_t *l_twn, uint32_t lstride,
-                                           unsigned long long *rec = nullptr) {
-    if (STAGED_ONLY || e.maps) {
+                                           unsigned long long *rec = nullptr, bool skip_tw = false) {
+    if (!NO_MAPS && (STAGED_ONLY || e.maps)) {
         float x, y;
         if (e.plane == 0) { x = px; y = py; }
         else if (e.plane == 1) { x = px; y = pz; }
@@ -105,7 +105,7 @@ __device__ __forceinline__ void extras_add(const FrameArgs &a, const ExtraArgs &
             }
         }
     }
-    if (!STAGED_ONLY && e.tw) {
+    if (!STAGED_ONLY && e.tw && !skip_tw) {
         atomicAdd(&l_tw[lslot], tick);
         atomicAdd(&l_twn[lslot], 1u);
         if (leaflet >= 0) {
@@ -772,8 +772,17 @@ __device__ __noinline__ UaBonds ua_carbon_slow(uint32_t kind, UaCarbon c, UaCons
     return ua_carbon(kind, c, e, pl);
 }
 
+// sum of an int over the 64 lanes (DPP row shifts + row broadcasts; every lane of the wave must be here)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int ua_dpp_add(int v) { return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, true); }
+__device__ __forceinline__ int ua_wave_sum(int v) {
+    v = ua_dpp_add<0x111, 0xf>(v); v = ua_dpp_add<0x112, 0xf>(v); v = ua_dpp_add<0x114, 0xf>(v); v = ua_dpp_add<0x118, 0xf>(v);
+    v = ua_dpp_add<0x142, 0xa>(v); v = ua_dpp_add<0x143, 0xc>(v);
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 // MODE 0: order parameters only; 1: + staged ordermap samples, nothing else (no geometry selection, timewise rows or
-// per-molecule normals — the common ordermap run, and a much smaller kernel); 2: every extra
+// per-molecule normals — the common ordermap run, and a much smaller kernel); 2: every extra; 3: per-frame rows, nothing else
 template <bool ACOS_COS, int MODE>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ua_extras(FrameArgs a_in, ExtraArgs e, const float *__restrict__ xyz,
                                                        const float *__restrict__ box9,
@@ -782,7 +791,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                                                        const Tile *__restrict__ tiles,
                                                        const gorder::UaItem *__restrict__ items,
                                                        const uint32_t *__restrict__ tile_slots, uint32_t n_tiles) {
-    constexpr bool EXTRAS = MODE != 0, GENERAL = MODE == 2;
+    constexpr bool EXTRAS = MODE != 0, GENERAL = MODE >= 2, FULL = MODE == 2, MAPS_POSSIBLE = MODE == 1 || MODE == 2;
     constexpr uint32_t LS = 3 * kBlock;   // local slots per block (<= 3 hydrogens per carbon)
     __shared__ unsigned long long l_s[2 * LS];
     __shared__ uint32_t l_n[2 * LS];
@@ -807,10 +816,23 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     const uint32_t f_begin = a.frame0 + chunk * a.frames_per_chunk;
     const uint32_t f_end = min(a.n_frames, f_begin + a.frames_per_chunk);
     const size_t fstride = (size_t)a.n_atoms * 3u;
+    // Per-frame rows: when the lanes of every wave of the tile hold carbons of ONE kind and slot (the tiles are cut from
+    // groups of 64 molecules ordered by kind and slot: the normal case) a frame's sums per slot are sums over a wave —
+    // DPP adds, then one lane sends them to the rows —: no LDS atomic per hydrogen (two to four, served one lane per
+    // cycle) and no barriers per frame.  Otherwise the LDS partials of extras_add / extras_flush_tw.
+    __shared__ uint32_t l_mixed;
+    if (GENERAL && tid == 0) l_mixed = 0u;
     if (GENERAL)
         for (uint32_t k = tid; k < 3 * LS; k += kBlock) { l_tw[k] = 0; l_twn[k] = 0; }
     for (uint32_t k = tid; k < 2 * LS; k += kBlock) { l_s[k] = 0; l_n[k] = 0; }
     __syncthreads();
+    if (GENERAL) {
+        const uint32_t key = active ? ((uint32_t)it.lslot0 << 8) | kind : 0xffffffffu;
+        const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);      // (lane 0 of the wave: active lanes come first)
+        if (!__all(!active || key == first)) l_mixed = 1u;
+    }
+    __syncthreads();
+    const bool tw_waves = GENERAL && e.tw && l_mixed == 0u;                     // (uniform over the workgroup)
     long long s_tot[3] = {0, 0, 0}, s_up[3] = {0, 0, 0};
     uint32_t n_tot[3] = {0, 0, 0}, n_up[3] = {0, 0, 0};
     int bad = 0;
@@ -819,7 +841,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     unsigned long long *rec_row = nullptr;
     uint32_t rec_n = 0;
     const size_t rec_plane = (size_t)kBlock * e.rec_stride;      // hydrogen k of the same lanes: k planes further
-    if (EXTRAS && (!GENERAL || e.map_rec) && active) {
+    if (MAPS_POSSIBLE && (!GENERAL || e.map_rec) && active) {
         const uint32_t run = e.item_run[t.item0 + tid], tid0 = run >> 16;
         rec_n = run & 0xffffu;
         rec_row = e.map_rec + ((size_t)tile_id * 3u * kBlock + tid0) * e.rec_stride + (tid - tid0);
@@ -837,6 +859,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         return c;
     };
     for (uint32_t f = f_begin; f < f_end; f++) {
+        int tw_s[3] = {0, 0, 0}, tw_sl[3] = {0, 0, 0}, tw_n[3] = {0, 0, 0};      // tw_waves: this lane's ticks, lower-leaflet ticks, counts (all | lower << 16)
         if (active) {
             const UaCarbon c = fetch(f);
             V3 bx3{1.0f, 1.0f, 1.0f};
@@ -862,7 +885,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             int leaflet = -1;
             if (a.leaflets) leaflet = a.aflags[(size_t)a.arow[f] * a.n_mol_total + it.mol] ? 1 : 0;
             float nrx = a.nx, nry = a.ny, nrz = a.nz, nr2 = a.n2, nr2sq = a.n2sq;
-            if (GENERAL && e.dyn) {   // fetched for every molecule, before the geometry test (uaorder.rs:412-413)
+            if (FULL && e.dyn) {   // fetched for every molecule, before the geometry test (uaorder.rs:412-413)
                 const float4 n = e.dyn[(size_t)f * a.n_mol_total + it.mol];
                 if (n.w < 3.0f) raise_error(a.err, GORDER_ERR_DYNAMIC_NORMAL, f, kStageTypes, gslot0, 1, it.mol, (uint32_t)n.w);
                 nrx = n.x; nry = n.y; nrz = n.z;
@@ -874,7 +897,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                 if (k >= nh) return;
                 float sch;
                 const float s2 = (v.x * v.x + v.y * v.y) + v.z * v.z;
-                if (!ACOS_COS && e.axis >= 0 && !(GENERAL && e.dyn) && s2 >= 0x1p-40f && s2 <= 0x1p+40f) {
+                if (!ACOS_COS && e.axis >= 0 && !(FULL && e.dyn) && s2 >= 0x1p-40f && s2 <= 0x1p+40f) {
                     // static normal along an axis, |v|^2 in the guarded range: the squared cosine by the division core,
                     // no clamp (gm_sch_axis has the argument); anything else takes the general routine
                     const float prod = e.axis == 0 ? v.x : (e.axis == 1 ? v.y : v.z);
@@ -883,28 +906,59 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                     sch = gm_calc_sch<ACOS_COS>(v.x, v.y, v.z, nrx, nry, nrz, nr2, nr2sq);
                 }
                 const int tick = gm_tick(sch);
-                if (GENERAL) {
+                if (FULL) {
                     const float box[3] = {bx3.x, bx3.y, bx3.z};
                     if (e.geom_kind && !geom_inside(e, e.shapes + 8 * (size_t)f, b.x, b.y, b.z, box, pbc, bad)) return;
                 }
                 s_tot[k] += tick;
                 n_tot[k] += 1;
                 if (leaflet == 0) { s_up[k] += tick; n_up[k] += 1; }
+                if (tw_waves) {
+                    tw_s[k] = tick;
+                    tw_sl[k] = leaflet == 1 ? tick : 0;
+                    tw_n[k] = 1 | (leaflet == 1 ? 1 << 16 : 0);
+                }
                 if (EXTRAS)
-                    extras_add<!GENERAL>(a, e, gslot0 + (uint32_t)k, it.lslot0 + (uint32_t)k, tick, b.x, b.y, b.z, leaflet, l_tw,
-                                         l_twn, LS, (!GENERAL || e.map_rec) ? &recs[k] : nullptr);
+                    extras_add<!GENERAL, !MAPS_POSSIBLE>(a, e, gslot0 + (uint32_t)k, it.lslot0 + (uint32_t)k, tick, b.x, b.y, b.z, leaflet, l_tw,
+                                                         l_twn, LS, (MAPS_POSSIBLE && (!GENERAL || e.map_rec)) ? &recs[k] : nullptr, tw_waves);
             };
             sample(0, ub.v0, ub.b0);
             sample(1, ub.v1, ub.b1);
             sample(2, ub.v2, ub.b2);
-            if (EXTRAS && (!GENERAL || e.map_rec)) {   // one word per hydrogen this carbon has, into its run's piece
+            if (MAPS_POSSIBLE && (!GENERAL || e.map_rec)) {   // one word per hydrogen this carbon has, into its run's piece
                 unsigned long long *row = rec_row + (size_t)(f - e.rec_frame0) * rec_n;
                 row[0] = recs[0];
                 if (nh > 1) row[rec_plane] = recs[1];
                 if (nh > 2) row[2u * rec_plane] = recs[2];
             }
         }
-        if (GENERAL && e.tw) {
+        if (tw_waves) {             // every lane of the wave is here
+            const uint32_t slot0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)gslot0);
+            const int nh_w = __builtin_amdgcn_readfirstlane(active ? nh : 0);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                if (k >= nh_w) break;                               // (uniform)
+                const int s_all = ua_wave_sum(tw_s[k]), s_low = ua_wave_sum(tw_sl[k]), n = ua_wave_sum(tw_n[k]);
+                const uint32_t n_all = (uint32_t)n & 0xffffu, n_low = (uint32_t)n >> 16;
+                if ((tid & 63u) == 0u && n_all) {
+                    const size_t row = ((size_t)e.tw_row0 + f) * 3u * a.n_acc;
+                    const uint32_t slot = slot0 + (uint32_t)k;
+                    atomicAdd(&e.tw_sums[row + slot], (unsigned long long)(long long)s_all);
+                    atomicAdd(&e.tw_cnts[row + slot], (unsigned long long)n_all);
+                    if (a.leaflets) {
+                        const uint32_t n_up_w = n_all - n_low;
+                        if (n_up_w) {
+                            atomicAdd(&e.tw_sums[row + (size_t)a.n_acc + slot], (unsigned long long)(long long)(s_all - s_low));
+                            atomicAdd(&e.tw_cnts[row + (size_t)a.n_acc + slot], (unsigned long long)n_up_w);
+                        }
+                        if (n_low) {
+                            atomicAdd(&e.tw_sums[row + 2u * (size_t)a.n_acc + slot], (unsigned long long)(long long)s_low);
+                            atomicAdd(&e.tw_cnts[row + 2u * (size_t)a.n_acc + slot], (unsigned long long)n_low);
+                        }
+                    }
+                }
+            }
+        } else if (GENERAL && e.tw) {
             __syncthreads();
             extras_flush_tw(a, e, tile_slots + t.slot0, t.n_slots, f, l_tw, l_twn, LS);
             __syncthreads();

@@ -17,6 +17,7 @@ run cg1m 500 40 30
 # the options no BASELINE config uses (timewise rows)
 run aa256-timewise 3000 50 40
 run aa256-maps-timewise 3000 50 40
+run ua256-timewise 3000 50 40
 run aa256-cylinder 3000 50 40
 run cg3k-dynamic 512 10 4
 python3 - <<PY
