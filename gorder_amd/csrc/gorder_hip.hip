@@ -341,7 +341,10 @@ int fold_maps(gorder_hip_handle *h) {
 int launch_cell_list(gorder_hip_handle *h, const LocalArgs &lo, uint32_t ns, uint32_t n_list, void *counts, size_t count_bytes) {
     const bool three = env_flag("GORDER_HIP_LOCAL_THREE_KERNELS");   // A/B switch; also what membranes beyond kLocalBuildMax take
     if (n_list <= kLocalBuildMax && !three) {
-        hipLaunchKernelGGL(k_local_build, dim3(ns), dim3(1024), kLocalBuildLds, h->stream, lo);
+        // (a thread keeps a byte per atom it places: the kernel compiled for 2, 5 or 8 trips of eight atoms per thread)
+        if (n_list <= 2u * 8192u) hipLaunchKernelGGL(k_local_build<2>, dim3(ns), dim3(1024), kLocalBuildLds, h->stream, lo);
+        else if (n_list <= 5u * 8192u) hipLaunchKernelGGL(k_local_build<5>, dim3(ns), dim3(1024), kLocalBuildLds, h->stream, lo);
+        else hipLaunchKernelGGL(k_local_build<kLocalBuildTrips>, dim3(ns), dim3(1024), kLocalBuildLds, h->stream, lo);
         return GORDER_OK;
     }
     HIP_TRY(h, hipMemsetAsync(counts, 0, count_bytes, h->stream));
@@ -1005,8 +1008,9 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
         h->host_dyn_heads = nheads;
         const size_t nm = dn.n_cloud, ncell = (size_t)kLocalMaxCells1D * kLocalMaxCells1D;
         const size_t sl = h->dyn_slab = local_slab_frames(nm);
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_local_build), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)kLocalBuildLds));
+        for (const void *fn : {reinterpret_cast<const void *>(k_local_build<2>), reinterpret_cast<const void *>(k_local_build<5>),
+                               reinterpret_cast<const void *>(k_local_build<kLocalBuildTrips>)})
+            HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLocalBuildLds));
         HIP_TRY(h, hipMalloc((void **)&h->d_dyn_cell_of, sl * nm * sizeof(uint32_t)));
         HIP_TRY(h, hipMalloc((void **)&h->d_dyn_rec, sl * nm * 4 * sizeof(float)));
         HIP_TRY(h, hipMalloc((void **)&h->d_dyn_count, sl * (2 * ncell + 1) * sizeof(uint32_t)));
@@ -1061,8 +1065,9 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
         if (lf.method == GORDER_LEAFLETS_LOCAL) {
             const size_t nm = lf.n_membrane, ncell = (size_t)kLocalMaxCells1D * kLocalMaxCells1D;
             const size_t sl = h->local_slab = local_slab_frames(nm);
-            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_local_build),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLocalBuildLds));
+            for (const void *fn : {reinterpret_cast<const void *>(k_local_build<2>), reinterpret_cast<const void *>(k_local_build<5>),
+                                   reinterpret_cast<const void *>(k_local_build<kLocalBuildTrips>)})
+                HIP_TRY(h, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLocalBuildLds));
             // rows of cells with a halo (periodic boxes, k_local_flags_rows): the first cells of a row are there twice,
             // records included — room for twice the membrane
             h->local_halo = t->handle_pbc && !env_flag("GORDER_HIP_LOCAL_ATOMS_ONLY");

@@ -894,6 +894,8 @@ __global__ __launch_bounds__(256) void k_local_rowprefix(LocalArgs a) {
 constexpr uint32_t kLocalBuildMax = 65536;
 constexpr uint32_t kLocalBuildLds = 2u * kLocalMaxCells1D * kLocalMaxCells1D * (uint32_t)sizeof(uint32_t);
 constexpr uint32_t kLocalBuildTrips = kLocalBuildMax / (8u * 1024u);       // trips of eight atoms a thread makes at most
+// TRIPS: trips of eight atoms a thread makes at most (2, 5 or kLocalBuildTrips: the places it keeps cost registers)
+template <uint32_t TRIPS>
 __global__ __launch_bounds__(1024) void k_local_build(LocalArgs a) {
     extern __shared__ uint32_t l_build[];
     __shared__ uint32_t l_wave[16];
@@ -927,10 +929,10 @@ __global__ __launch_bounds__(1024) void k_local_build(LocalArgs a) {
     // eight atoms per trip: the index and coordinate loads of all of them go out before the first is used (a thread walks
     // ~36 atoms; one dependent load pair per atom would leave the 16 waves of the block waiting most of the time)
     constexpr uint32_t U = 8;
-    uint32_t place[kLocalBuildTrips][2], place2[kLocalBuildTrips][2];       // a byte per atom: its place in its cell / in the halo cell
+    uint32_t place[TRIPS][2], place2[TRIPS][2];       // a byte per atom: its place in its cell / in the halo cell
     bool over = false;
 #pragma unroll
-    for (uint32_t trip = 0; trip < kLocalBuildTrips; trip++) {
+    for (uint32_t trip = 0; trip < TRIPS; trip++) {
         const uint32_t i0 = tid + trip * U * 1024u;
         place[trip][0] = place[trip][1] = place2[trip][0] = place2[trip][1] = 0u;
         if (trip * U * 1024u >= a.n_membrane) continue;                     // (uniform)
@@ -993,7 +995,7 @@ __global__ __launch_bounds__(1024) void k_local_build(LocalArgs a) {
     float zlo = 3.0e38f, zhi = -3.0e38f;            // the frame's record for the rows kernel (finfo), made on the way
     uint32_t nf = 0;
 #pragma unroll
-    for (uint32_t trip = 0; trip < kLocalBuildTrips; trip++) {
+    for (uint32_t trip = 0; trip < TRIPS; trip++) {
         const uint32_t i0 = tid + trip * U * 1024u;
         if (trip * U * 1024u >= a.n_membrane) continue;                     // (uniform)
         uint32_t at[U];
