@@ -660,9 +660,7 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
                                n_items, bpc);
         HIP_TRY(h, hipGetLastError());
     }
-    hipLaunchKernelGGL(k_count_frames, dim3(1), dim3(1), 0, h->stream, a.acc + 4 * (size_t)a.n_acc, a.n_frames);
-    HIP_TRY(h, hipGetLastError());
-    return timing_end(h, tslot);
+    return timing_end(h, tslot);       // (the frames are counted by k_batch_end)
 }
 
 }  // namespace
@@ -929,8 +927,9 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
             return fail(h, GORDER_ERR_INVALID_ARGUMENT,
                         "ordermaps / timewise / geometry need every bond to fit an atom window");
     }
-    HIP_TRY(h, hipMalloc((void **)&h->d_err, kErrWords * sizeof(uint32_t)));
+    HIP_TRY(h, hipMalloc((void **)&h->d_err, (kErrWords + 2u) * sizeof(uint32_t)));     // (+ the ticket of k_batch_end)
     HIP_TRY(h, hipMemset(h->d_err, 0xff, kErrWords * sizeof(uint32_t)));   // kErrNone
+    HIP_TRY(h, hipMemset(h->d_err + kErrWords, 0, 2u * sizeof(uint32_t)));
     h->acc_words = 4 * (size_t)p.n_acc + 1;
     HIP_TRY(h, hipMalloc((void **)&h->d_acc, h->acc_words * sizeof(unsigned long long)));
     HIP_TRY(h, hipMemset(h->d_acc, 0, h->acc_words * sizeof(unsigned long long)));
@@ -1302,11 +1301,7 @@ int gorder_hip_submit_device(gorder_hip_handle *h, const float *d_xyz, const flo
         h->assignment_frame = last_assign_frame;
         n_new_rows = aframes.size();
     }
-    if (pbc) {
-        hipLaunchKernelGGL(k_check_box, dim3((n_frames + 255) / 256), dim3(256), 0, h->stream, d_box, n_frames,
-                           h->d_err);
-        HIP_TRY(h, hipGetLastError());
-    }
+    // (check_box: k_batch_end, at the end of the batch)
     if (h->extra.tw && h->n_frames + n_frames > h->tw_cap) {   // grow the per-frame rows (timewise.rs:183-186)
         const size_t row = 3 * (size_t)p.n_acc;
         const uint64_t ncap = (h->n_frames + n_frames) * 2;
@@ -1358,8 +1353,10 @@ int gorder_hip_submit_device(gorder_hip_handle *h, const float *d_xyz, const flo
             if (frame_index[f] != rec.first + (uint64_t)f * rec.stride) { rec.list.assign(frame_index, frame_index + n_frames); break; }
         if (h->batch_log.size() >= gorder_hip_handle::kBatchLog) h->batch_log.pop_front();
         h->batch_log.push_back(std::move(rec));
-        hipLaunchKernelGGL(k_err_commit, dim3(1), dim3(1), 0, h->stream, reinterpret_cast<unsigned long long *>(h->d_err),
-                           (unsigned long long)h->n_submits, h->decoder_key);
+        // check_box, total_frames and the batch's error key in one launch behind the batch's kernels
+        hipLaunchKernelGGL(k_batch_end, dim3(pbc ? std::min<uint32_t>((n_frames + 255u) / 256u, 256u) : 1u), dim3(256), 0, h->stream,
+                           pbc ? d_box : nullptr, n_frames, h->d_err,
+                           h->d_acc + 4 * (size_t)p.n_acc, (unsigned long long)h->n_submits, h->decoder_key);
         HIP_TRY(h, hipGetLastError());
         h->n_submits++;
     }

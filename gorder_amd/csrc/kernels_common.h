@@ -61,25 +61,14 @@ __device__ __forceinline__ void raise_box_range(uint32_t *err, uint32_t frame) {
     raise_error(err, GORDER_ERR_BOX_RANGE, frame, kStageEnd);
 }
 
-// End of a batch (stream-ordered behind its kernels): the batch's key — and the key its frames' decoder left in a
+// End of a batch (k_batch_end, stream-ordered behind the batch's kernels): the batch's key — and the key its frames' decoder left in a
 // record of its own (the decoder of a slot of gorder_hip_run_trajectory runs on another stream, beside the kernels
 // of the batch before) — becomes THE error of the run if no earlier batch had one.  Keys order errors inside a batch
 // only (frame IN BATCH is their leading field); across batches the order of submission decides, which is the order
 // of the trajectory: the first error as the reference's sequential walk meets it (common.rs:248).
-__global__ void k_err_commit(unsigned long long *err, unsigned long long ordinal, const unsigned long long *decoder_key) {
-    unsigned long long cur = err[0];
-    if (decoder_key && *decoder_key < cur) cur = *decoder_key;
-    if (err[1] == kErrNone && cur != kErrNone) {
-        err[1] = cur;
-        err[2] = ordinal;
-    }
-    err[0] = kErrNone;
-}
 
-// ---- check_box (common.rs:186-198), one thread per frame -----------------------------------
-__global__ void k_check_box(const float *__restrict__ box9, uint32_t n_frames, uint32_t *err) {
-    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= n_frames) return;
+// ---- check_box (common.rs:186-198) for one frame
+__device__ __forceinline__ void check_box_frame(const float *__restrict__ box9, uint32_t f, uint32_t *err) {
     const float *b = box9 + 9 * (size_t)f;
     bool all_nan = true;
     for (int i = 0; i < 9; i++) all_nan = all_nan && (b[i] != b[i]);
@@ -92,9 +81,40 @@ __global__ void k_check_box(const float *__restrict__ box9, uint32_t n_frames, u
     if (!(b[0] > 0.0f) || !(b[4] > 0.0f) || !(b[8] > 0.0f)) raise_error(err, GORDER_ERR_BOX_RANGE, f, kStageBox);
 }
 
-// total_frames (topology/mod.rs:141-144) lives in the last word of the accumulator block so that a
-// multi-GPU all-reduce sums it together with the order sums (topology/mod.rs:243)
-__global__ void k_count_frames(unsigned long long *word, uint32_t n_frames) { atomicAdd(word, (unsigned long long)n_frames); }
+// ---- the end of a batch in ONE launch (three 5-us launches were 3 % of a 10 000-frame step of the headline workload):
+// check_box for every frame (box9 null: no periodic boundaries), the frames counted (total_frames, topology/mod.rs:141-144,
+// lives in the last word of the accumulator block so that a multi-GPU all-reduce sums it with the order sums,
+// topology/mod.rs:243), and the batch's error key committed by the workgroup that finishes last: it sees the box errors of
+// all frames.
+__global__ __launch_bounds__(256) void k_batch_end(const float *__restrict__ box9, uint32_t n_frames, uint32_t *err,
+                                                   unsigned long long *frames_word, unsigned long long ordinal,
+                                                   const unsigned long long *decoder_key) {
+    __shared__ uint32_t l_last;
+    if (box9)
+        for (uint32_t f = blockIdx.x * blockDim.x + threadIdx.x; f < n_frames; f += gridDim.x * blockDim.x) check_box_frame(box9, f, err);
+    // the workgroup that finishes last commits (a ticket behind the error record; it leaves it at zero for the next batch)
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) l_last = atomicAdd(err + kErrWords, 1u) == gridDim.x - 1u ? 1u : 0u;
+    __syncthreads();
+    if (!l_last || threadIdx.x != 0) return;
+    err[kErrWords] = 0u;
+    atomicAdd(frames_word, (unsigned long long)n_frames);
+    unsigned long long *e = reinterpret_cast<unsigned long long *>(err);
+    unsigned long long cur = atomicAdd(&e[0], 0ull);           // (an atomic read: the raises are atomics in L2)
+    if (decoder_key && *decoder_key < cur) cur = *decoder_key;
+    if (e[1] == kErrNone && cur != kErrNone) {
+        e[1] = cur;
+        e[2] = ordinal;
+    }
+    e[0] = kErrNone;
+}
+
+// ---- check_box, one thread per frame (the frame that primes a leaflet assignment) --------------
+__global__ void k_check_box(const float *__restrict__ box9, uint32_t n_frames, uint32_t *err) {
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < n_frames) check_box_frame(box9, f, err);
+}
 
 // acc[i] += sum_r rep[r][i]; rep := 0   (i < 4 * n_acc)
 __global__ void k_fold_replicas(unsigned long long *acc, unsigned long long *rep, uint32_t n_rep, uint32_t n) {

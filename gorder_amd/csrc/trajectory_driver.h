@@ -592,7 +592,7 @@ extern "C" int gorder_hip_run_trajectory(gorder_hip_handle *h, const gorder_traj
         if (e != hipSuccess && status == GORDER_OK) { status = GORDER_ERR_DEVICE; hip_msg = std::string("trajectory copy: ") + hipGetErrorString(e); }
         if (status == GORDER_OK) {
             // a frame the decoder could not make sense of is an error of THIS batch, ordered with the errors its analysis
-            // raises (the frame's number leads the key) and behind those of the batches before (k_err_commit)
+            // raises (the frame's number leads the key) and behind those of the batches before (k_batch_end)
             h->decoder_key = dev ? reinterpret_cast<const unsigned long long *>(s.d_stat + 2) : nullptr;
             status = gorder_hip_submit_device(h, s.d_xyz, h->tables.handle_pbc ? s.d_box : nullptr, s.fidx.data(), s.n);
             h->decoder_key = nullptr;
