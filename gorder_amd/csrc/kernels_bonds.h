@@ -273,7 +273,7 @@ struct TiledStage {
                                                    uint32_t &nan_which, uint32_t &nan_frame, const TiledMapOut *mo = nullptr) {
         // NF frames at a time: NF independent dependency chains interleave; fewer live registers than all G at once
         // (with the map words two at a time: four chains and their tile arithmetic do not fit the 128 registers)
-        constexpr int NF = (OUT == 1 || OUT == 3) ? 2 : (GORDER_COMPUTE_NF < G ? GORDER_COMPUTE_NF : G);
+        constexpr int NF = (OUT == 1 || OUT == 3 || (OUT == 2 && LEAF)) ? 2 : (GORDER_COMPUTE_NF < G ? GORDER_COMPUTE_NF : G);
 #pragma unroll
         for (int h = 0; h < G; h += NF) {
             float P[NF][6];
