@@ -7,7 +7,7 @@
 //   BondLike::add_order                topology/bond.rs:184-215         (register accumulators)
 //   calc_sch / vector_to               mod.rs:78-82, pbc.rs:378-385     (gm_math.h)
 //   OrderValue / AnalysisOrder         order.rs:13-66, 178-188          (i64 ticks, u64 counts)
-//   check_box                          common.rs:186-198             -> k_check_box
+//   check_box                          common.rs:186-198             -> k_batch_end (k_check_box for a priming frame)
 //   SystemLeafletClassification::run   leaflets.rs:171-205           -> k_leaflets_global
 //   common_identify_leaflet            leaflets.rs:711-732              (same kernel)
 //   IndividualClassification           leaflets.rs:777-801           -> k_leaflets_individual
