@@ -43,6 +43,12 @@ def main():
         # GRBM_GUI_ACTIVE sums the 8 XCDs.  (Round 2 used 4 cycles here and reported fractions above 1.)
         res["valu_busy_fraction"] = counters["SQ_INSTS_VALU"] * 2.0 / 1024.0 / (counters["GRBM_GUI_ACTIVE"] / 8.0)
         res["valu_instructions_per_wave"] = counters["SQ_INSTS_VALU"] / counters["SQ_WAVES"] if counters.get("SQ_WAVES") else None
+        # what the busy fraction above cannot say: how many SIMD cycles the kernel spends per VALU instruction it issues.
+        # tools/microbench/valu_rate.hip on this chip, 8 waves per SIMD: 2.8 cycles for independent v_fma_f32, 4.3 for a
+        # dependent chain and for v_pk_fma_f32 (two fmas each) — a kernel between those figures is bound by VALU issue.
+        res["simd_cycles_per_valu_instruction"] = 1024.0 * (counters["GRBM_GUI_ACTIVE"] / 8.0) / counters["SQ_INSTS_VALU"]
+        res["valu_rate_reference"] = {"independent_v_fma_f32": 2.8, "dependent_v_fma_f32": 4.3, "v_pk_fma_f32": 4.3,
+                                      "source": "tools/microbench/valu_rate.hip, 8 waves per SIMD"}
     json.dump(res, sys.stdout, indent=1)
     print()
 
