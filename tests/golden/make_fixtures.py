@@ -163,7 +163,11 @@ if __name__ == "__main__":
               "aa_order_basic_POPC.xvg", "aa_order_leaflets_POPC.xvg", "cg_order_leaflets_POPC.xvg",
               "ua_order_leaflets_POPC.xvg",
               "aa_order_convergence.xvg", "aa_order_leaflets_convergence.xvg", "cg_order_convergence.xvg",
-              "aa_order_convergence_s5.xvg"):
+              "aa_order_convergence_s5.xvg",
+              # united-atom per-frame rows (tests_ua.rs:509-630) and the writers' other united-atom files
+              "ua_order_convergence.xvg", "ua_order_leaflets_convergence.xvg", "ua_order_error.csv", "ua_order_error.tab",
+              "ua_order_leaflets_error.csv", "ua_order_leaflets_error.tab", "ua_order_basic_POPC.xvg",
+              "ua_order_basic_POPS.xvg", "ua_order_leaflets_POPS.xvg"):
         src = os.path.join(REF, f)
         if os.path.exists(src):
             shutil.copy(src, os.path.join(HERE, "expected", f))
@@ -173,8 +177,9 @@ if __name__ == "__main__":
     # all-atom frame with its water (long runs of small offsets) and a small multi-frame system
     shutil.copy(os.path.join(REF, "split", "pcpepg4.xtc"), os.path.join(HERE, "pcpepg4.xtc"))
     shutil.copy(os.path.join(REF, "multiple_resid_same_name.xtc"), os.path.join(HERE, "multiple_resid_same_name.xtc"))
-    # the 12 united-atom ordermaps compared by tests_ua.rs:351-410 (made from ua.xtc)
+    # the united-atom ordermaps (made from ua.xtc): the 12 `_full` maps compared by tests_ua.rs:351-410 and the 24
+    # `_upper` / `_lower` maps of test_ua_order_maps_leaflets (tests_ua.rs:418-507, Global leaflets)
     os.makedirs(os.path.join(HERE, "expected", "ordermaps_ua"), exist_ok=True)
     for f in sorted(os.listdir(os.path.join(REF, "ordermaps_ua"))):
-        if f.endswith("_full.dat"):
+        if f.endswith(("_full.dat", "_upper.dat", "_lower.dat")):
             shutil.copy(os.path.join(REF, "ordermaps_ua", f), os.path.join(HERE, "expected", "ordermaps_ua", f))

@@ -228,6 +228,33 @@ def test_ua_ordermaps(ua):
     np.testing.assert_array_equal(res.map_counts, ref.map_counts)
 
 
+@pytest.mark.parametrize("route", ["staged", "direct"])
+def test_ua_ordermaps_with_leaflets(ua, route, monkeypatch):
+    # tests_ua.rs:418-507 (test_ua_order_maps_leaflets): 36 maps — the `_upper` / `_lower` planes of Map::add_order
+    # (ordermap.rs:100-113, bond.rs:199-213) against the reference's own files, through k_map_accumulate's
+    # leaflet branch (staged) and through one atomic per sample (GORDER_HIP_MAP_DIRECT=1)
+    if route == "direct":
+        monkeypatch.setenv("GORDER_HIP_MAP_DIRECT", "1")
+    tables, labels, midx, om = ordermap_setup(ua, leaflets=True)
+    frames = ua.window()
+    eng, res, xyz, box, fi = gpu_run(tables, ua, midx, frames)
+    assert eng.plan()["map_staged"] == int(route == "staged")
+    assert check_ordermaps(res, labels, om, leaflets=True) == 21
+    np.testing.assert_array_equal(res.map_counts[0], res.map_counts[1] + res.map_counts[2])
+    np.testing.assert_array_equal(res.map_sums[0], res.map_sums[1] + res.map_sums[2])
+    o, ref = oracle_run(tables, xyz, box, fi, oracle.TRIG_DIRECT)
+    flags, _ = eng.leaflets()
+    oflags, odist, _ = o.leaflets()
+    if np.array_equal(flags, oflags):
+        np.testing.assert_array_equal(res.map_counts, ref.map_counts)
+        np.testing.assert_array_equal(res.map_sums, ref.map_sums)
+        np.testing.assert_array_equal(res.sums, ref.sums)
+    else:
+        np.testing.assert_array_equal(res.map_counts[0], ref.map_counts[0])
+        np.testing.assert_array_equal(res.map_sums[0], ref.map_sums[0])
+        assert_sums_given_device_flags(tables, xyz, box, res, fi)
+
+
 # ---- single-frame tests of the reference ------------------------------------------------------------------
 from test_golden_oracle import check_single_frame, single_frame   # noqa: E402
 

@@ -327,39 +327,50 @@ def test_error_estimation(kind, lf, want, pcpepg, cg):
 # tests/files/ua.xtc (precision 1000), which IS there.)
 from gorder_amd.abi import OrderMap   # noqa: E402
 from golden_util import compare_maps, map_of, read_map   # noqa: E402
+from gorder_amd.select import select   # noqa: E402
 
 
-def ordermap_setup(fx):
+def ordermap_setup(fx, leaflets=False):
     """`resname POPC and name C50 C20 C13` saturated, `resname POPC and name C24` unsaturated, bin [0.5, 2.0],
-    span Auto = (0, box of the structure), xy plane, min_samples 5."""
+    span Auto = (0, box of the structure), xy plane, min_samples 5; with `leaflets` the classifier of
+    test_ua_order_maps_leaflets (tests_ua.rs:443): Global, `@membrane`, heads `name r'^P'`."""
     s = fx.structure
     popc = np.array(s.resnames) == "POPC"
     sat = popc & fx.name_in("C50", "C20", "C13")
     unsat = popc & fx.name_in("C24")
     bx = fx.boxes[0]            # ua.tpr's box = the box of the trajectory's first frame (6.28779 nm)
     om = OrderMap(enabled=True, plane=0, span_x=(0.0, float(bx[0, 0])), span_y=(0.0, float(bx[1, 1])), bin=(0.5, 2.0))
-    tables, labels, midx = st.build_tables_ua(s, sat, unsat, np.ones(s.n_atoms, dtype=bool), ordermap=om)
+    lf = None
+    if leaflets:
+        lf = {"method": METHODS["global"], "membrane": select(s, "@membrane"), "heads": select(s, "name r'^P'"),
+              "methyls": np.zeros(s.n_atoms, dtype=bool), "frequency": 1, "radius": 2.5}
+    tables, labels, midx = st.build_tables_ua(s, sat, unsat, np.ones(s.n_atoms, dtype=bool), ordermap=om, leaflets=lf)
     return tables, labels, midx, om
 
 
-def check_ordermaps(res, labels, om):
-    """Every map the reference's test compares: per virtual bond, per carbon (its bonds aggregated) and the
-    average over all bonds."""
+def check_ordermaps(res, labels, om, leaflets=False):
+    """Every map the reference's tests compare: per virtual bond, per carbon (its bonds aggregated) and the average
+    over all bonds — the `_full` plane (tests_ua.rs:351-410) and, with leaflets, the `_upper` and `_lower` planes as
+    well (Map::add_order routes a sample to its molecule's leaflet, ordermap.rs:100-113, bond.rs:199-213;
+    tests_ua.rs:418-507), tile for tile with assert_eq_maps' rule (NaN where NaN, else within 2e-4)."""
     (ml,) = labels
     assert ml.name == "POPC"
-    slot, allslots, n_maps = ml.slot0, [], 0
-    for c in ml.carbons:
-        slots = list(range(slot, slot + c.n_h))
-        slot += c.n_h
-        allslots += slots
-        bad = compare_maps(map_of(res, slots, 0, om, 5), read_map(f"ordermap_POPC-{c.name}-{c.rel}_full.dat"))
-        assert not bad, (c.name, bad[:5])
-        for k, sl in enumerate(slots):
-            bad = compare_maps(map_of(res, [sl], 0, om, 5), read_map(f"ordermap_POPC-{c.name}-{c.rel}--POPC-H{k + 1}-{c.rel}_full.dat"))
-            assert not bad, (c.name, k, bad[:5])
-            n_maps += 1
-    bad = compare_maps(map_of(res, allslots, 0, om, 5), read_map("ordermap_average_full.dat"))
-    assert not bad, bad[:5]
+    n_maps = 0
+    for w, plane in enumerate(("full", "upper", "lower") if leaflets else ("full",)):
+        slot, allslots = ml.slot0, []
+        for c in ml.carbons:
+            slots = list(range(slot, slot + c.n_h))
+            slot += c.n_h
+            allslots += slots
+            bad = compare_maps(map_of(res, slots, w, om, 5), read_map(f"ordermap_POPC-{c.name}-{c.rel}_{plane}.dat"))
+            assert not bad, (c.name, plane, bad[:5])
+            for k, sl in enumerate(slots):
+                bad = compare_maps(map_of(res, [sl], w, om, 5),
+                                   read_map(f"ordermap_POPC-{c.name}-{c.rel}--POPC-H{k + 1}-{c.rel}_{plane}.dat"))
+                assert not bad, (c.name, k, plane, bad[:5])
+                n_maps += 1
+        bad = compare_maps(map_of(res, allslots, w, om, 5), read_map(f"ordermap_average_{plane}.dat"))
+        assert not bad, (plane, bad[:5])
     return n_maps
 
 
@@ -371,6 +382,21 @@ def test_ua_ordermaps(ua):
     res = eng.finish()
     assert res.map_sums.shape[2:] == (14, 4)          # GridMap: round(6.288 / 0.5) + 1, round(6.288 / 2) + 1
     assert check_ordermaps(res, labels, om) == 7
+
+
+@pytest.mark.parametrize("trig", ["libm", "direct"])
+def test_ua_ordermaps_with_leaflets(ua, trig):
+    # tests_ua.rs:418-507: 36 maps, the upper / lower planes included
+    tables, labels, midx, om = ordermap_setup(ua, leaflets=True)
+    frames = ua.window()
+    eng = oracle.OracleEngine(tables, trig=oracle.TRIG_LIBM if trig == "libm" else oracle.TRIG_DIRECT, n_threads=3)
+    eng.submit(master_frames(ua, midx, frames), ua.boxes[frames], frames)
+    res = eng.finish()
+    assert res.map_sums.shape == (3, res.sums.shape[1], 14, 4)
+    assert check_ordermaps(res, labels, om, leaflets=True) == 21
+    # a sample lands in exactly one leaflet plane: total = upper + lower, tile by tile (bond.rs:199-213)
+    np.testing.assert_array_equal(res.map_counts[0], res.map_counts[1] + res.map_counts[2])
+    np.testing.assert_array_equal(res.map_sums[0], res.map_sums[1] + res.map_sums[2])
 
 
 # ---- single-frame tests of the reference (aaorder.rs:226-464, cgorder.rs:188-351) ------------------------------

@@ -74,14 +74,16 @@ def test_exported_dynamic_normals(fixtures):
 
 
 @pytest.mark.parametrize("kind,leaflets,name", [("aa", False, "aa_order_convergence.xvg"), ("aa", True, "aa_order_leaflets_convergence.xvg"),
-                                                ("cg", False, "cg_order_convergence.xvg")])
+                                                ("cg", False, "cg_order_convergence.xvg"),
+                                                ("ua", False, "ua_order_convergence.xvg"), ("ua", True, "ua_order_leaflets_convergence.xvg")])
 def test_convergence_of_the_per_frame_rows(fixtures, kind, leaflets, name):
-    """The device's per-frame (timewise) rows reproduce the reference's convergence files frame by frame."""
+    """The device's per-frame (timewise) rows reproduce the reference's convergence files frame by frame
+    (tests_aa.rs:2580-2630, tests_cg.rs, tests_ua.rs:509-630)."""
     from gorder_amd import writers
-    from golden_util import METHODS, aa_setup, cg_setup
+    from golden_util import METHODS, aa_setup, cg_setup, ua_setup
     from test_writers_cpu import golden, same_tokens
-    fx = fixtures["pcpepg" if kind == "aa" else "cg"]
-    setup = aa_setup if kind == "aa" else cg_setup
+    fx = fixtures[{"aa": "pcpepg", "cg": "cg", "ua": "ua"}[kind]]
+    setup = {"aa": aa_setup, "cg": cg_setup, "ua": ua_setup}[kind]
     tables, labels, midx = setup(fx, leaflets=METHODS["global"] if leaflets else None, timewise=True)
     frames = fx.window()
     eng = HipEngine(tables)

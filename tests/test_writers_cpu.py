@@ -51,7 +51,8 @@ def golden(name):
 
 CASES = [("aa", False, False, "aa_order_basic"), ("aa", True, False, "aa_order_leaflets"), ("aa", False, True, "aa_order_error"),
          ("cg", False, False, "cg_order_basic"), ("cg", True, False, "cg_order_leaflets"), ("cg", True, True, "cg_order_error_leaflets"),
-         ("ua", False, False, "ua_order_basic"), ("ua", True, False, "ua_order_leaflets")]
+         ("ua", False, False, "ua_order_basic"), ("ua", True, False, "ua_order_leaflets"),
+         ("ua", False, True, "ua_order_error"), ("ua", True, True, "ua_order_leaflets_error")]    # tests_ua.rs:509-630
 
 
 @pytest.fixture(scope="module")
@@ -74,8 +75,10 @@ def test_yaml_and_csv_text(fixtures, kind, leaflets, errors, name):
     same_items(writers.yaml_text(tree, header="# made here"), golden(name + ".yaml"), skip=1)
     same_items(writers.csv_text(tree), golden(name + ".csv"), sep=",")
     same_tokens(writers.tab_text(tree), golden(name + ".tab"))
-    if not errors and (kind, leaflets) != ("ua", False) and (kind, leaflets) != ("cg", False):
+    if not errors and (kind, leaflets) != ("cg", False):
         same_tokens(writers.xvg_text(tree, "POPC", united=kind == "ua"), golden(name + "_POPC.xvg"))
+    if kind == "ua" and not errors:
+        same_tokens(writers.xvg_text(tree, "POPS", united=True), golden(name + "_POPS.xvg"))
 
 
 def test_csv_prints_nan_below_min_samples(fixtures):
@@ -92,12 +95,13 @@ def test_csv_prints_nan_below_min_samples(fixtures):
 
 
 @pytest.mark.parametrize("kind,leaflets,name", [("aa", False, "aa_order_convergence.xvg"), ("aa", True, "aa_order_leaflets_convergence.xvg"),
-                                                ("cg", False, "cg_order_convergence.xvg")])
+                                                ("cg", False, "cg_order_convergence.xvg"),
+                                                ("ua", False, "ua_order_convergence.xvg"), ("ua", True, "ua_order_leaflets_convergence.xvg")])
 def test_convergence_of_the_per_frame_rows(fixtures, kind, leaflets, name):
-    """tests_aa.rs:2580-2630, tests_cg.rs: the running averages after every frame — pins the per-frame (timewise)
-    rows one frame at a time, not just their block statistics."""
+    """tests_aa.rs:2580-2630, tests_cg.rs, tests_ua.rs:509-630: the running averages after every frame — pins the
+    per-frame (timewise) rows one frame at a time, not just their block statistics."""
     fx = fixtures[kind]
-    setup = aa_setup if kind == "aa" else cg_setup
+    setup = {"aa": aa_setup, "cg": cg_setup, "ua": ua_setup}[kind]
     tables, labels, midx = setup(fx, leaflets=METHODS["global"] if leaflets else None, timewise=True)
     frames = fx.window()
     eng = oracle.OracleEngine(tables, trig=oracle.TRIG_LIBM, n_threads=4)
