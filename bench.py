@@ -116,32 +116,38 @@ def reader_threads():
     return max(1, min(cores_available(), 16))
 
 
-def cpu_baseline(system, seconds_target=8.0):
+def cpu_baseline(system, seconds_target=8.0, threads=None):
     """Oracle (kind 'port') on the host cores: reference-faithful libm trig, one accumulator clone per thread +
-    ordered reduce like groan_rs' traj_iter_map_reduce.  Timed at 1 thread and at all cores."""
+    ordered reduce like groan_rs' traj_iter_map_reduce.  Timed at 1 thread and at `cores` threads.
+    Every thread gets at least 64 frames per pass and the worker threads stay alive across the passes of a timing
+    (gorder_oracle_submit_passes) — the reference keeps its threads for the whole trajectory (common.rs:283-339), and
+    round 3's 8 frames per thread and pass measured thread start-up, not arithmetic."""
     from oracle import oracle
-    cores = host_cores()
-    n_sample = max(cores * 4, min(512, int(2e8 // max(1, system.n_atoms * 12))))
+    cores = threads or host_cores()
+    n_sample = max(cores * 64, min(512, int(2e8 // max(1, system.n_atoms * 12))))
+    n_sample = min(n_sample, max(cores, int(4e9 // max(1, system.n_atoms * 12))))       # at most 4 GB of frames
     xyz = system.frames(n_sample, seed=99)
     box = system.box9(n_sample)
 
-    def timed(threads):
-        eng = oracle.OracleEngine(system.tables, trig=oracle.TRIG_LIBM, n_threads=threads)
+    def timed(n_threads, n_frames):
+        eng = oracle.OracleEngine(system.tables, trig=oracle.TRIG_LIBM, n_threads=n_threads)
         t0 = time.perf_counter()
-        eng.submit(xyz, box)
+        eng.submit(xyz[:n_frames], box[:n_frames])
         t1 = time.perf_counter() - t0
-        reps = int(max(1, min(200, seconds_target / max(t1, 1e-6))))
+        passes = int(max(1, min(2000, seconds_target / max(t1, 1e-6))))
         t0 = time.perf_counter()
-        for _ in range(reps):
-            eng.submit(xyz, box)
-        return reps * n_sample / (time.perf_counter() - t0), reps
+        eng.submit(xyz[:n_frames], box[:n_frames], passes=passes)          # ONE call: the threads live through all passes
+        return passes * n_frames / (time.perf_counter() - t0), passes
 
-    all_cores, reps = timed(cores)
-    one, reps1 = timed(1)
-    return {"value": all_cores, "unit": "frames/s", "cores": cores, "cores_available": cores_available(), "kind": "port",
-            "value_1_thread": one,
-            "sample": f"{n_sample} synthetic frames of the same workload x {reps} passes on {cores} threads "
-                      f"(x {reps1} passes on 1 thread); libm trig, frame-interleaved threads + ordered reduce"}
+    all_cores, reps = timed(cores, n_sample)
+    n_one = min(n_sample, 512)
+    one, reps1 = timed(1, n_one)
+    out = {"value": all_cores, "unit": "frames/s", "cores": cores, "cores_available": cores_available(), "kind": "port",
+           "value_1_thread": one, "parallel_efficiency": all_cores / (cores * one) if one > 0 else None,
+           "sample": f"{n_sample} synthetic frames of the same workload ({n_sample // cores} per thread) x {reps} passes on {cores} "
+                     f"threads that live through all passes ({n_one} frames x {reps1} passes on 1 thread); libm trig, "
+                     f"frame-interleaved threads + ordered reduce"}
+    return out
 
 
 def warm_up(step, sync, n_steps, agree=None):
@@ -277,6 +283,101 @@ def end_to_end_solvated(system, device_index, n_unique=100, repeats=200, water_p
                           "frames_decoded_by_host_after_all": st["frames_decoded_by_host"]}
         eng.close()
     np.testing.assert_array_equal(sums["host_decode"], sums["device_decode"])
+    return out
+
+
+class Watchdog:
+    """Extra blocks of the N > 1 line run collectives after the headline is final.  If a rank fails alone, the others would
+    wait for it forever and the driver would lose the line: after `seconds` without disarm() rank 0 prints the line as it
+    stands (the block marked as timed out) and every rank leaves with exit code 0."""
+
+    def __init__(self, seconds, rank, line):
+        import threading
+        self.rank, self.line, self.lock, self.done = rank, line, threading.Lock(), False
+        self.timer = threading.Timer(seconds, self.fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def fire(self):
+        with self.lock:
+            if self.done:
+                return
+            self.done = True
+            if self.rank == 0:
+                out = self.line()
+                out.setdefault("extras_timed_out", True)
+                print(json.dumps(out), flush=True)
+            sys.stderr.write(f"[rank {self.rank}] bench: an extra block did not finish; leaving with the headline\n")
+            sys.stderr.flush()
+            os._exit(0)
+
+    def disarm(self):
+        with self.lock:
+            self.done = True
+        self.timer.cancel()
+
+
+def all_agree(dist, ok, tdev):
+    """MIN over ranks of a success flag — called OUTSIDE any try block, so that every rank reaches it."""
+    import torch
+    t = torch.tensor([1 if ok else 0], device=tdev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item())
+
+
+def lib_allreduce_check(dist, rank, world, device, rehearsal, tables, d_xyz, d_box, fidx, want):
+    """The library's own RCCL route on N ranks (gorder_hip_comm_unique_id / _create / gorder_hip_allreduce — what a Rust
+    host without a collective library calls; SystemTopology::reduce, topology/mod.rs:256-272): a second handle per rank
+    analyses the rank's shard once, the library reduces, and the result must equal what torch.distributed reduced
+    (`want`: the strong-scaling job's last step, or None).  Errors are reported, never raised; every collective sits
+    outside the try blocks and is entered by all ranks or none."""
+    import torch
+    from gorder_amd import HipEngine
+    tdev = "cpu" if rehearsal else device
+    out = {"ok": False, "equal_to_torch": None, "ms": None, "ranks": world}
+    ids = [None]
+    if rank == 0:
+        try:
+            ids[0] = HipEngine.comm_unique_id()
+        except Exception as ex:   # noqa: BLE001
+            out["error"] = "gorder_hip_comm_unique_id: " + repr(ex)
+    dist.broadcast_object_list(ids, src=0)
+    if ids[0] is None:
+        out.setdefault("error", "no unique id from rank 0")
+        return out
+    eng2, comm, err = None, None, None
+    try:
+        eng2 = HipEngine(tables)
+        comm = eng2.comm_create(ids[0], world, rank)
+        eng2.submit_device(d_xyz, d_box, fidx)
+        eng2.synchronize()
+    except Exception as ex:   # noqa: BLE001
+        err = "setup: " + repr(ex)
+    if not all_agree(dist, err is None, tdev):
+        out["error"] = err or "another rank failed to create its communicator"
+    else:
+        t0 = time.perf_counter()
+        try:
+            eng2.allreduce(comm)
+            eng2.synchronize()
+            ms = (time.perf_counter() - t0) * 1e3
+            got = eng2.finish()
+            out["ms"] = ms
+            out["ok"] = True
+            if want is not None:
+                out["equal_to_torch"] = bool(np.array_equal(got.sums, want.sums) and np.array_equal(got.counts, want.counts)
+                                             and got.n_frames == want.n_frames)
+        except Exception as ex:   # noqa: BLE001
+            out["error"] = "gorder_hip_allreduce: " + repr(ex)
+        ok_all = all_agree(dist, out["ok"], tdev)
+        out["ok_on_all_ranks"] = ok_all
+    try:
+        if comm is not None:
+            eng2.comm_destroy(comm)
+        if eng2 is not None:
+            eng2.close()
+    except Exception as ex:   # noqa: BLE001
+        out.setdefault("error", "teardown: " + repr(ex))
     return out
 
 
@@ -546,6 +647,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    kernel_groups = eng.kernel_groups()    # [(name, ms, segments)] per kernel group of the timed submits: adds up to kernel_ms
     kernel_ms, launches = eng.kernel_time()
     kernel_names = eng.kernel_names()      # what the timed region really launched (gorder_hip_kernel_time_names)
     res = eng.finish()
@@ -582,7 +684,15 @@ def main():
         # (tools/pmc.sh); the committed summary for this workload and launch size is reported, else null
         traffic, traffic_src = None, None
         prof_dir = os.path.join(ROOT, "profiles")
-        first_kernel = kernel_names.split(" + ")[0] if kernel_names else "k_bonds_tiled"
+        # the step as the device saw it: every kernel group a submit queues, timed between events on the launch stream
+        # (leaflet kernels, normals, order kernels, map accumulation, k_batch_end); the DOMINANT group is the longest one
+        per_launch_bytes = system.bytes_per_frame * frames
+        groups = [{"name": n, "ms": ms / max(1, launches),
+                   "share_of_step": ms / kernel_ms if kernel_ms > 0 else 0.0,
+                   "frac": per_launch_bytes / (ms / max(1, launches) / 1e3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None,
+                   "launches_per_step": seg / max(1, launches)} for n, ms, seg in kernel_groups]
+        dominant = max(groups, key=lambda g: g["ms"]) if groups else {"name": "k_bonds_tiled", "ms": 0.0}
+        first_kernel = dominant["name"].split(" + ")[0]
         for cand in sorted(glob.glob(os.path.join(prof_dir, f"r*_pmc_{name}_{first_kernel}*.json")), reverse=True):
             with open(cand) as fh:
                 pmc = json.load(fh)
@@ -598,9 +708,10 @@ def main():
             break
         total_frames = args.steps * total
         value = total_frames / dt
-        per_launch_bytes = system.bytes_per_frame * frames
-        avg_launch_s = (kernel_ms / 1e3) / max(1, launches)
+        step_s = (kernel_ms / 1e3) / max(1, launches)             # device time of a whole step (all groups)
+        avg_launch_s = dominant["ms"] / 1e3                        # ... of its dominant kernel group
         achieved = per_launch_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        whole_step = per_launch_bytes / step_s / 1e9 if step_s > 0 else 0.0
         if world == 1:
             parallelism = "single GPU"
         elif strong:
@@ -620,8 +731,11 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
                          "traffic_source": traffic_src,
-                         "kernel": kernel_names, "launches": launches, "avg_launch_ms": avg_launch_s * 1e3,
-                         "algorithmic_bytes_per_launch": per_launch_bytes, "frac_per_rank": per_rank},
+                         "kernel": dominant["name"], "launches": launches, "avg_launch_ms": avg_launch_s * 1e3,
+                         "algorithmic_bytes_per_launch": per_launch_bytes, "frac_per_rank": per_rank,
+                         # every kernel group of the step; `ms` add up to whole_step_ms, `share_of_step` to 1
+                         "kernels": groups, "timed": kernel_names, "whole_step_ms": step_s * 1e3,
+                         "whole_step_achieved": whole_step, "whole_step_frac": whole_step / HBM_PEAK_GBS},
             "sanity": {"frames_accumulated": res.n_frames, "expected": expect_frames, "counts_ok": ok_counts},
         }
         if allreduce_ms is not None:
@@ -650,23 +764,41 @@ def main():
             free_b, _ = torch.cuda.mem_get_info(device)
             if free_b > 150 * (1 << 30):
                 out["scaling_reference"] = scaling_reference(device)
-    if world > 1 and not args.no_end_to_end:
-        del d_xyz, d_box
-        torch.cuda.empty_cache()
-        # (the headline above is final; whatever happens in this extra block, rank 0 still prints it)
-        try:
-            e2e = end_to_end_sharded(dist, rank, world, local_rank, device, rehearsal)
-        except Exception as ex:   # noqa: BLE001
-            e2e = {"error": repr(ex)}
-        if rank == 0:
-            out["end_to_end"] = e2e
-    if rank == 0:
-        print(json.dumps(out))
     if world > 1:
+        # The headline above is final.  The extra blocks below run collectives; a rank that fails alone would leave the
+        # others waiting, so a watchdog prints the line as it stands and ends every rank if they do not come back.
+        wd = Watchdog(float(os.environ.get("GORDER_BENCH_EXTRAS_TIMEOUT", "600")), rank, lambda: dict(out) if rank == 0 else {})
+        # (1) the library's own RCCL route on all ranks, on a second handle over the same shard
+        try:
+            lib = lib_allreduce_check(dist, rank, world, device, rehearsal, system.tables, d_xyz, d_box, fidx,
+                                      res if strong else None)
+        except Exception as ex:   # noqa: BLE001
+            lib = {"ok": False, "error": repr(ex)}
+        if rank == 0:
+            out["lib_allreduce"] = lib
+        # (2) the sharded trajectory from a FILE
+        if not args.no_end_to_end:
+            del d_xyz, d_box
+            torch.cuda.empty_cache()
+            try:
+                e2e = end_to_end_sharded(dist, rank, world, local_rank, device, rehearsal)
+            except Exception as ex:   # noqa: BLE001
+                e2e = {"error": repr(ex)}
+            if rank == 0:
+                out["end_to_end"] = e2e
+        wd.disarm()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import threading
+        t_end = threading.Timer(60.0, lambda: os._exit(0))     # the line is out: a stuck teardown must not turn into a failed run
+        t_end.daemon = True
+        t_end.start()
         dist.barrier()
         if comm is not None:
             eng.comm_destroy(comm)
         dist.destroy_process_group()
+        t_end.cancel()
 
 
 if __name__ == "__main__":

@@ -307,7 +307,7 @@ _EXPORTS = [
     "gorder_hip_finish", "gorder_hip_timewise", "gorder_hip_leaflets", "gorder_hip_leaflet_distances",
     "gorder_hip_normals", "gorder_hip_export_maps", "gorder_hip_set_normals",
     "gorder_hip_accumulators_device", "gorder_hip_bind_accumulators", "gorder_hip_last_error_index", "gorder_hip_last_error_frame", "gorder_hip_kernel_time_names",
-    "gorder_hip_last_error_message", "gorder_hip_strerror", "gorder_hip_kernel_time", "gorder_hip_plan",
+    "gorder_hip_last_error_message", "gorder_hip_strerror", "gorder_hip_kernel_time", "gorder_hip_kernel_time_group", "gorder_hip_plan",
     "gorder_hip_plan_tables", "gorder_hip_selftest_arithmetic", "gorder_hip_run_trajectory",
     "gorder_hip_comm_unique_id", "gorder_hip_comm_create", "gorder_hip_comm_destroy", "gorder_hip_allreduce",
     "gorder_hip_reset", "gorder_hip_xtc_decode", "gorder_hip_release_staging",
@@ -377,6 +377,7 @@ def load_library() -> C.CDLL:
     lib.gorder_hip_strerror.argtypes = [i32]
     lib.gorder_hip_strerror.restype = C.c_char_p
     lib.gorder_hip_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(u64), i32]
+    lib.gorder_hip_kernel_time_group.argtypes = [vp, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(u64)]
     lib.gorder_hip_plan.argtypes = [vp, C.POINTER(CPlan)]
     lib.gorder_hip_plan_tables.argtypes = [C.POINTER(CTables), C.POINTER(CPlan), C.POINTER(i32)]
     lib.gorder_hip_selftest_arithmetic.argtypes = [i32, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
@@ -688,8 +689,19 @@ class HipEngine:
         return ms.value, int(n.value)
 
     def kernel_names(self) -> str:
-        """The kernels inside the region gorder_hip_kernel_time measured on the last batch."""
+        """The kernel groups gorder_hip_kernel_time has measured since the last reset, joined by ' + '."""
         return self.lib.gorder_hip_kernel_time_names(self._h).decode()
+
+    def kernel_groups(self):
+        """[(name, ms, segments)] per kernel group of the timed submits since the last reset (the times add up to
+        kernel_time()'s ms).  Call before kernel_time(reset=True)."""
+        out, k = [], 0
+        while True:
+            name, ms, n = C.c_char_p(), C.c_double(), C.c_uint64()
+            if self.lib.gorder_hip_kernel_time_group(self._h, k, C.byref(name), C.byref(ms), C.byref(n)) != 0:
+                return out
+            out.append((name.value.decode(), ms.value, int(n.value)))
+            k += 1
 
     def plan(self) -> dict:
         p = CPlan()

@@ -144,7 +144,7 @@ struct gorder_hip_handle {
     hipStream_t copy_stream = nullptr;
     float n2 = 1.0f, n2sq = 1.0f;
     int axis = -1;   // 0/1/2 when the static normal is exactly that unit axis (kernel specialisation)
-    int frames_per_stage = kFramesPerStage;   // G (2, 4 or 8); GORDER_HIP_FRAMES_PER_STAGE overrides
+    int frames_per_stage = kFramesPerStage;   // G = 4 frames staged per pass (8 was measured at 26 % and spilled: removed in round 4)
     bool membrane_is_frame = false;            // the membrane group is every atom of the frame, in order
     bool use_gather = false;                   // GORDER_HIP_KERNEL=gather: L1-gather kernel instead of LDS staging
     uint32_t wg_capacity = 256u * 6u;          // co-resident workgroups of the tiled kernel on this device
@@ -154,15 +154,23 @@ struct gorder_hip_handle {
     uint64_t n_frames = 0;
     uint64_t err_index = 0;
     std::string err_msg;
-    // kernel timing (gorder_hip_kernel_time): OFF until the host asks for it once; then a fixed ring of event pairs
-    // that is drained (oldest first) when it runs full — nothing grows with the length of the trajectory
-    static constexpr uint32_t kTimingRing = 64;
+    // kernel timing (gorder_hip_kernel_time / _group): OFF until the host asks for it once.  Everything a handle queues
+    // runs in order on ONE stream, so a submit is a chain of labelled segments between events E0 [leaflet kernels] E1
+    // [order kernels] E2 ... En: timing_mark(label) closes the open segment with a new event and opens the next.  The
+    // events are a fixed ring, drained (oldest segment first) when it runs low — nothing grows with the trajectory.
+    static constexpr uint32_t kTimingEvents = 1024;
+    struct TimingSeg { uint32_t label, ev_a, ev_b; };
     bool timing_on = false;
-    hipEvent_t timing_ev[kTimingRing][2] = {};
-    uint32_t timing_head = 0, timing_count = 0;   // pairs [head - count, head) are recorded and not yet read
-    double timing_ms = 0.0;
-    uint64_t timing_launches = 0;
-    std::string timed_kernels;                    // what the last timed region launched (gorder_hip_kernel_time_names)
+    hipEvent_t timing_ev[kTimingEvents] = {};
+    uint32_t timing_next_ev = 0;                  // ring position of the next event to record
+    int timing_open_label = -1;                   // the segment being queued (-1: none)
+    uint32_t timing_open_ev = 0;
+    std::deque<TimingSeg> timing_pending;         // closed segments whose events have not been read yet
+    std::vector<std::string> timing_labels;       // group names in order of first appearance since the last reset
+    std::vector<double> timing_label_ms;
+    std::vector<uint64_t> timing_label_n;
+    uint64_t timing_launches = 0;                 // submits (chains) since the last reset
+    std::string timed_kernels;                    // the labels joined by " + " (gorder_hip_kernel_time_names)
     // host copies behind the payload of gorder_hip_last_error_index
     std::vector<uint32_t> host_heads, host_dyn_heads;
     uint32_t *d_mol_slot0 = nullptr;
@@ -274,39 +282,52 @@ int check_device_error(gorder_hip_handle *h) {
     return status;
 }
 
-// ---- kernel timing ring (see gorder_hip_handle::timing_ev) ---------------------------------------------
+// ---- kernel timing: labelled segments between events on the handle's stream (see gorder_hip_handle::timing_ev) -----
 int timing_drain_oldest(gorder_hip_handle *h) {
-    const uint32_t slot = (h->timing_head + gorder_hip_handle::kTimingRing - h->timing_count) % gorder_hip_handle::kTimingRing;
+    const gorder_hip_handle::TimingSeg sg = h->timing_pending.front();
     float t = 0.0f;
-    HIP_TRY(h, hipEventSynchronize(h->timing_ev[slot][1]));
-    HIP_TRY(h, hipEventElapsedTime(&t, h->timing_ev[slot][0], h->timing_ev[slot][1]));
-    h->timing_ms += t;
-    h->timing_count--;
+    HIP_TRY(h, hipEventSynchronize(h->timing_ev[sg.ev_b]));
+    HIP_TRY(h, hipEventElapsedTime(&t, h->timing_ev[sg.ev_a], h->timing_ev[sg.ev_b]));
+    h->timing_label_ms[sg.label] += t;
+    h->timing_label_n[sg.label] += 1;
+    h->timing_pending.pop_front();
     return GORDER_OK;
 }
-// the next free pair (events are created on first use and then reused), or -1 when timing is off
-int timing_begin(gorder_hip_handle *h, int *slot_out) {
-    *slot_out = -1;
+// Close the open segment (if any) at a new event and, with a label, open the next one there.  No-op while timing is off.
+int timing_mark(gorder_hip_handle *h, const char *label) {
     if (!h->timing_on) return GORDER_OK;
-    if (h->timing_count == gorder_hip_handle::kTimingRing) {
+    if (!label && h->timing_open_label < 0) return GORDER_OK;
+    // a pending segment holds at most two events of the ring: keep fewer than half of it pending
+    while (h->timing_pending.size() >= gorder_hip_handle::kTimingEvents / 2u - 2u) {
         const int st = timing_drain_oldest(h);
         if (st != GORDER_OK) return st;
     }
-    const uint32_t slot = h->timing_head;
-    for (int k = 0; k < 2; k++)
-        if (!h->timing_ev[slot][k]) HIP_TRY(h, hipEventCreate(&h->timing_ev[slot][k]));
-    HIP_TRY(h, hipEventRecord(h->timing_ev[slot][0], h->stream));
-    *slot_out = (int)slot;
+    const uint32_t ev = h->timing_next_ev;
+    h->timing_next_ev = (ev + 1u) % gorder_hip_handle::kTimingEvents;
+    if (!h->timing_ev[ev]) HIP_TRY(h, hipEventCreate(&h->timing_ev[ev]));
+    HIP_TRY(h, hipEventRecord(h->timing_ev[ev], h->stream));
+    if (h->timing_open_label >= 0) h->timing_pending.push_back({(uint32_t)h->timing_open_label, h->timing_open_ev, ev});
+    h->timing_open_label = -1;
+    if (label) {
+        size_t k = 0;
+        while (k < h->timing_labels.size() && h->timing_labels[k] != label) k++;
+        if (k == h->timing_labels.size()) {
+            h->timing_labels.push_back(label);
+            h->timing_label_ms.push_back(0.0);
+            h->timing_label_n.push_back(0);
+            if (!h->timed_kernels.empty()) h->timed_kernels += " + ";
+            h->timed_kernels += label;
+        }
+        h->timing_open_label = (int)k;
+        h->timing_open_ev = ev;
+    }
     return GORDER_OK;
 }
-int timing_end(gorder_hip_handle *h, int slot) {
-    if (slot < 0) return GORDER_OK;
-    HIP_TRY(h, hipEventRecord(h->timing_ev[slot][1], h->stream));
-    h->timing_head = (h->timing_head + 1) % gorder_hip_handle::kTimingRing;   // only a completed pair enters the ring
-    h->timing_count++;
-    h->timing_launches++;
-    return GORDER_OK;
-}
+#define TIMING_MARK(h, label)                                   \
+    do {                                                        \
+        const int tm_ = timing_mark(h, label);                  \
+        if (tm_ != GORDER_OK) return tm_;                       \
+    } while (0)
 
 bool env_flag(const char *name) {
     const char *v = getenv(name);
@@ -340,6 +361,7 @@ int fold_maps(gorder_hip_handle *h) {
 // lo.cell_count and lo.cell_fill words the three-kernel form needs zeroed
 int launch_cell_list(gorder_hip_handle *h, const LocalArgs &lo, uint32_t ns, uint32_t n_list, void *counts, size_t count_bytes) {
     const bool three = env_flag("GORDER_HIP_LOCAL_THREE_KERNELS");   // A/B switch; also what membranes beyond kLocalBuildMax take
+    TIMING_MARK(h, n_list <= kLocalBuildMax && !three ? "k_local_build" : "k_local_bin + k_local_scan + k_local_scatter");
     if (n_list <= kLocalBuildMax && !three) {
         // (a thread keeps a byte per atom it places: the kernel compiled for 2, 5 or 8 trips of eight atoms per thread)
         if (n_list <= 2u * 8192u) hipLaunchKernelGGL(k_local_build<2>, dim3(ns), dim3(1024), kLocalBuildLds, h->stream, lo);
@@ -376,6 +398,7 @@ int run_dynamic_normals(gorder_hip_handle *h, const FrameArgs &a) {
         lo.n_slab = ns;
         if ((st = launch_cell_list(h, lo, ns, dn.n_cloud, h->d_dyn_count,
                                    (size_t)h->dyn_slab * (2 * ncell + 1) * sizeof(uint32_t))) != GORDER_OK) return st;
+        TIMING_MARK(h, "k_dyn_cov + k_dyn_eigen");
         hipLaunchKernelGGL(k_dyn_cov, dim3((n_mol + 15) / 16, ns), dim3(256), 0, h->stream, lo, h->d_dyn_cov);
         hipLaunchKernelGGL(k_dyn_eigen, dim3((uint32_t)(((size_t)ns * n_mol + 255) / 256)), dim3(256), 0, h->stream, lo, h->d_dyn_cov,
                            h->d_dyn_normals);
@@ -391,21 +414,10 @@ int run_dynamic_normals(gorder_hip_handle *h, const FrameArgs &a) {
 int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
     const Plan &p = h->plan;
     const uint32_t n_tiles = (uint32_t)p.tiles.size();
-    int tslot = -1;
-    {
-        const int st0 = timing_begin(h, &tslot);
-        if (st0 != GORDER_OK) return st0;
-    }
     const bool extras = h->extra.maps || h->extra.tw || h->extra.geom_kind || h->dyn || h->manual_active;
-    const bool naming = tslot >= 0;
-    if (naming) h->timed_kernels.clear();
-    auto name = [&](const char *k) {
-        if (!naming || h->timed_kernels.find(k) != std::string::npos) return;
-        if (!h->timed_kernels.empty()) h->timed_kernels += " + ";
-        h->timed_kernels += k;
-    };
+    // (every kernel group of the batch opens a timing segment of its own: gorder_hip_kernel_time_group)
+#define name(k) TIMING_MARK(h, k)
     if (h->dyn && !h->manual_active) {
-        name("k_dyn_cov + k_dyn_eigen");
         const int st2 = run_dynamic_normals(h, a);
         if (st2 != GORDER_OK) return st2;
     }
@@ -420,9 +432,9 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
         for (int d = 0; d < 2; d++) { ga.xdim[d] = ge.xdim[d]; ga.ydim[d] = ge.ydim[d]; ga.zdim[d] = ge.zdim[d]; ga.span[d] = ge.span[d]; }
         ga.radius = ge.radius; ga.group = h->d_geom_group; ga.n_group = ge.n_group;
         ga.shapes = h->d_shapes; ga.err = h->d_err;
+        name("k_geom_shapes");
         hipLaunchKernelGGL(k_geom_shapes, dim3(a.n_frames), dim3(256), 0, h->stream, ga);
         HIP_TRY(h, hipGetLastError());
-        name("k_geom_shapes");
     }
     if (n_tiles && !extras) {
         // enough workgroups to fill 256 CUs x 8 blocks, frames split into chunks of whole stages
@@ -488,14 +500,9 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
         if (h->use_gather) {
             GORDER_LAUNCH_GATHER(4);
         } else {
-            switch (h->frames_per_stage) {
-                case 8: GORDER_LAUNCH_TILED(8, 10); break;
-                default:
-                    // prefetch registers per thread: enough float4 for the widest window (64 threads stage a frame)
-                    if ((3u * p.max_window + 6u) / 4u <= 4u * 64u && !env_flag("GORDER_HIP_NPF5")) GORDER_LAUNCH_TILED(4, 4);
-                    else GORDER_LAUNCH_TILED(4, 5);
-                    break;
-            }
+            // prefetch registers per thread: enough float4 for the widest window (64 threads stage a frame)
+            if ((3u * p.max_window + 6u) / 4u <= 4u * 64u && !env_flag("GORDER_HIP_NPF5")) GORDER_LAUNCH_TILED(4, 4);
+            else GORDER_LAUNCH_TILED(4, 5);
         }
 #undef GORDER_LAUNCH_GATHER
 #undef GORDER_LAUNCH_GATHER_V
@@ -660,7 +667,8 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
                                n_items, bpc);
         HIP_TRY(h, hipGetLastError());
     }
-    return timing_end(h, tslot);       // (the frames are counted by k_batch_end)
+#undef name
+    return GORDER_OK;       // (the frames are counted by k_batch_end, which also closes the batch's timing chain)
 }
 
 }  // namespace
@@ -954,10 +962,6 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
             if (n[d] == 1.0f && n[(d + 1) % 3] == 0.0f && n[(d + 2) % 3] == 0.0f) h->axis = d;
         h->extra.axis = h->axis;
     }
-    if (const char *e = getenv("GORDER_HIP_FRAMES_PER_STAGE")) {
-        const int g = atoi(e);
-        if (g == 4 || g == 8) h->frames_per_stage = g;
-    }
     if (const char *e = getenv("GORDER_HIP_KERNEL")) h->use_gather = strcmp(e, "gather") == 0;
     if (const char *e = getenv("GORDER_HIP_WG_TARGET")) {
         const int w = atoi(e);
@@ -965,23 +969,14 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
     }
     h->lw = ((3u * p.max_window + 3u + 3u) / 4u) * 4u;
     h->lds_bytes = (size_t)h->frames_per_stage * h->lw * sizeof(float);
-    if (h->frames_per_stage == 8 && h->lds_bytes > 64u * 1024u) {   // wide windows: 8 staged frames exceed the 64 KB a
-        h->frames_per_stage = 4;                                    // launch gets without opting in; 4 always fit (48 KB)
-        h->lds_bytes = (size_t)h->frames_per_stage * h->lw * sizeof(float);
-    }
     if (h->lds_bytes < (size_t)kBlock * 24) h->lds_bytes = (size_t)kBlock * 24;
     {   // how many workgroups of the tiled kernel are co-resident: the frame range of a batch is cut so
         // that the grid is a whole number of such rounds (no half-empty last round)
         int n_cu = 256, per_cu = 6;
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device);
         const bool ac = (t->flags & GORDER_FLAG_TRIG_ACOS_COS) != 0;
-        hipError_t e;
-        switch (h->frames_per_stage) {
-            case 8: e = ac ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bonds_tiled<8, 10, true, true, false, -1>, kBlock, h->lds_bytes)
-                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bonds_tiled<8, 10, false, true, false, 2>, kBlock, h->lds_bytes); break;
-            default: e = ac ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bonds_tiled<4, 5, true, true, false, -1>, kBlock, h->lds_bytes)
-                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bonds_tiled<4, 5, false, true, false, 2>, kBlock, h->lds_bytes); break;
-        }
+        const hipError_t e = ac ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bonds_tiled<4, 5, true, true, false, -1>, kBlock, h->lds_bytes)
+                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bonds_tiled<4, 5, false, true, false, 2>, kBlock, h->lds_bytes);
         if (e != hipSuccess || per_cu < 1) per_cu = 4;
         h->wg_capacity = (uint32_t)n_cu * (uint32_t)per_cu;
     }
@@ -1094,9 +1089,8 @@ void gorder_hip_destroy(gorder_hip_handle *h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->traj_cache_free) h->traj_cache_free(h);
-    for (auto &pair : h->timing_ev)
-        for (hipEvent_t ev : pair)
-            if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : h->timing_ev)
+        if (ev) (void)hipEventDestroy(ev);
     (void)hipFree(h->d_mol_slot0);
     (void)hipFree(h->d_tiles); (void)hipFree(h->d_items); (void)hipFree(h->d_tile_slots);
     (void)hipFree(h->d_direct); (void)hipFree(h->d_err); (void)hipFree(h->d_xtc_cp);
@@ -1178,10 +1172,12 @@ static int run_leaflets(gorder_hip_handle *h, const float *d_xyz, const float *d
     la.err = h->d_err;
     if (lf.method == GORDER_LEAFLETS_GLOBAL) {
         const dim3 g((uint32_t)aframes.size()), b(1024);
+        TIMING_MARK(h, h->membrane_is_frame ? "k_leaflets_global_contig" : "k_leaflets_global");
         if (h->membrane_is_frame) hipLaunchKernelGGL(k_leaflets_global_contig, g, dim3(256), 0, h->stream, la);
         else hipLaunchKernelGGL(k_leaflets_global, g, b, 0, h->stream, la);
     } else if (lf.method == GORDER_LEAFLETS_INDIVIDUAL) {
         // gridDim.y <= 65535: launch in slabs
+        TIMING_MARK(h, "k_leaflets_individual");
         size_t done = 0;
         while (done < aframes.size()) {
             const uint32_t ny = (uint32_t)std::min<size_t>(aframes.size() - done, 65535);
@@ -1224,13 +1220,18 @@ static int run_leaflets(gorder_hip_handle *h, const float *d_xyz, const float *d
             const int cst = launch_cell_list(h, lo, ns, lf.n_membrane, h->d_lcell_count, ns * (ncell + 1) * sizeof(uint32_t));
             if (cst != GORDER_OK) return cst;
             if (lo.halo) {
+                TIMING_MARK(h, "k_local_rowprefix");
                 hipLaunchKernelGGL(k_local_rowprefix, dim3(kLocalMaxCells1D / 4u, ns), dim3(256), 0, h->stream, lo);
                 lo.rows_groups = (lo.n_mol_total + 15u) / 16u;
+                TIMING_MARK(h, "k_local_flags_rows");
                 hipLaunchKernelGGL(k_local_flags_rows, dim3(lo.rows_groups * ((ns + 7u) / 8u * 8u)), dim3(256), 0, h->stream, lo);
                 // the heads the rows left over (normally none: the grid finds an empty list and leaves)
+                TIMING_MARK(h, "k_local_flags_todo");
                 hipLaunchKernelGGL(k_local_flags_todo, dim3(512), dim3(256), 0, h->stream, lo);
-            } else
+            } else {
+                TIMING_MARK(h, "k_local_flags");
                 hipLaunchKernelGGL(k_local_flags, dim3((lo.n_mol_total + 3) / 4, ns), dim3(256), 0, h->stream, lo);
+            }
         }
     }
     HIP_TRY(h, hipGetLastError());
@@ -1258,6 +1259,18 @@ int gorder_hip_submit_device(gorder_hip_handle *h, const float *d_xyz, const flo
     // batches (AssignedLeaflets::local, leaflets.rs:1371-1380), rows 1.. = assignment frames here
     const bool leaflets = lf.method != GORDER_LEAFLETS_NONE;
     size_t n_new_rows = 0;
+    // argument errors come before the first kernel of the batch is queued (a batch that fails later leaves through
+    // abort_batch below, so that a key its kernels raised is not committed under the next batch's ordinal)
+    if (h->manual_frames) {
+        if (h->manual_frames != n_frames) return fail(h, GORDER_ERR_INVALID_ARGUMENT, "gorder_hip_set_normals: frame count differs from the batch");
+        if (!p.direct.empty()) return fail(h, GORDER_ERR_INVALID_ARGUMENT, "manual normals: a bond spans more than the LDS window");
+    }
+    auto abort_batch = [&](int status) {
+        hipLaunchKernelGGL(k_batch_abort, dim3(1), dim3(1), 0, h->stream, h->d_err);
+        (void)hipGetLastError();
+        (void)timing_mark(h, nullptr);
+        return status;
+    };
     if (leaflets) {
         std::vector<uint32_t> arow(n_frames), aframes;
         uint32_t cur = 0;
@@ -1296,7 +1309,7 @@ int gorder_hip_submit_device(gorder_hip_handle *h, const float *d_xyz, const flo
             h->up_arow = arow;
             h->up_arow_at = h->d_arow;
         }
-        if ((st = run_leaflets(h, d_xyz, d_box, aframes, 1)) != GORDER_OK) return st;
+        if ((st = run_leaflets(h, d_xyz, d_box, aframes, 1)) != GORDER_OK) return abort_batch(st);
         h->have_assignment = true;
         h->assignment_frame = last_assign_frame;
         n_new_rows = aframes.size();
@@ -1328,19 +1341,18 @@ int gorder_hip_submit_device(gorder_hip_handle *h, const float *d_xyz, const flo
     a.leaflets = leaflets ? 1 : 0; a.aflags = h->d_aflags; a.arow = h->d_arow; a.n_mol_total = p.n_mol_total;
     a.acc = h->d_acc; a.rep = h->d_rep; a.n_rep = h->n_rep; a.n_acc = p.n_acc; a.err = h->d_err;
     h->manual_active = false;
-    if (h->manual_frames) {   // normals the host supplied for exactly this batch
-        if (h->manual_frames != n_frames) return fail(h, GORDER_ERR_INVALID_ARGUMENT, "gorder_hip_set_normals: frame count differs from the batch");
-        if (!p.direct.empty()) return fail(h, GORDER_ERR_INVALID_ARGUMENT, "manual normals: a bond spans more than the LDS window");
+    if (h->manual_frames) {   // normals the host supplied for exactly this batch (arguments checked above)
         const size_t n4 = (size_t)n_frames * p.n_mol_total;
-        if ((st = ensure(h, &h->d_dyn_normals, &h->dyn_normals_cap, n4)) != GORDER_OK) return st;
-        HIP_TRY(h, hipStreamSynchronize(h->stream));   // earlier batches may still read the buffer
-        HIP_TRY(h, hipMemcpy(h->d_dyn_normals, h->manual_normals.data(), n4 * 4 * sizeof(float), hipMemcpyHostToDevice));
+        if ((st = ensure(h, &h->d_dyn_normals, &h->dyn_normals_cap, n4)) != GORDER_OK) return abort_batch(st);
+        if (hipStreamSynchronize(h->stream) != hipSuccess ||   // earlier batches may still read the buffer
+            hipMemcpy(h->d_dyn_normals, h->manual_normals.data(), n4 * 4 * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+            return abort_batch(fail(h, GORDER_ERR_DEVICE, "manual normals: copy to the device failed"));
         h->manual_active = true;
         h->manual_frames = 0;
     }
     st = launch_orders(h, a);
     h->manual_active = false;
-    if (st != GORDER_OK) return st;
+    if (st != GORDER_OK) return abort_batch(st);
     h->rep_dirty = true;
     if (n_new_rows) {   // newest assignment becomes the carry row of the next batch
         HIP_TRY(h, hipMemcpyAsync(h->d_aflags, h->d_aflags + n_new_rows * (size_t)p.n_mol_total, p.n_mol_total,
@@ -1354,10 +1366,13 @@ int gorder_hip_submit_device(gorder_hip_handle *h, const float *d_xyz, const flo
         if (h->batch_log.size() >= gorder_hip_handle::kBatchLog) h->batch_log.pop_front();
         h->batch_log.push_back(std::move(rec));
         // check_box, total_frames and the batch's error key in one launch behind the batch's kernels
+        TIMING_MARK(h, "k_batch_end");
         hipLaunchKernelGGL(k_batch_end, dim3(pbc ? std::min<uint32_t>((n_frames + 255u) / 256u, 256u) : 1u), dim3(256), 0, h->stream,
                            pbc ? d_box : nullptr, n_frames, h->d_err,
                            h->d_acc + 4 * (size_t)p.n_acc, (unsigned long long)h->n_submits, h->decoder_key);
         HIP_TRY(h, hipGetLastError());
+        TIMING_MARK(h, nullptr);          // the batch's chain of timed segments ends here
+        if (h->timing_on) h->timing_launches++;
         h->n_submits++;
     }
     h->n_frames += n_frames;
@@ -1678,14 +1693,34 @@ const char *gorder_hip_last_error_message(const gorder_hip_handle *h) { return h
 int gorder_hip_kernel_time(gorder_hip_handle *h, double *ms, uint64_t *launches, int reset) {
     if (!h) return GORDER_ERR_INVALID_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->device));
-    h->timing_on = true;   // the first call switches the event pairs on (submits before it are not timed)
-    while (h->timing_count) {
+    h->timing_on = true;   // the first call switches the events on (submits before it are not timed)
+    while (!h->timing_pending.empty()) {
         const int st = timing_drain_oldest(h);
         if (st != GORDER_OK) return st;
     }
-    if (ms) *ms = h->timing_ms;
+    double total = 0.0;
+    for (double v : h->timing_label_ms) total += v;
+    if (ms) *ms = total;
     if (launches) *launches = h->timing_launches;
-    if (reset) { h->timing_ms = 0.0; h->timing_launches = 0; }
+    if (reset) {
+        h->timing_labels.clear(); h->timing_label_ms.clear(); h->timing_label_n.clear();
+        h->timed_kernels.clear();
+        h->timing_launches = 0;
+    }
+    return GORDER_OK;
+}
+
+int gorder_hip_kernel_time_group(gorder_hip_handle *h, uint32_t index, const char **name, double *ms, uint64_t *segments) {
+    if (!h) return GORDER_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    while (!h->timing_pending.empty()) {
+        const int st = timing_drain_oldest(h);
+        if (st != GORDER_OK) return st;
+    }
+    if (index >= h->timing_labels.size()) return GORDER_ERR_INVALID_ARGUMENT;
+    if (name) *name = h->timing_labels[index].c_str();
+    if (ms) *ms = h->timing_label_ms[index];
+    if (segments) *segments = h->timing_label_n[index];
     return GORDER_OK;
 }
 

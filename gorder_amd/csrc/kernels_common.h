@@ -110,6 +110,13 @@ __global__ __launch_bounds__(256) void k_batch_end(const float *__restrict__ box
     e[0] = kErrNone;
 }
 
+// A batch that failed on the host after some of its kernels were queued: what they raised is dropped with the batch
+// (the host reports its own status), so that the next batch's k_batch_end does not commit it under ITS ordinal.
+__global__ void k_batch_abort(uint32_t *err) {
+    reinterpret_cast<unsigned long long *>(err)[0] = kErrNone;
+    err[kErrWords] = 0u;
+}
+
 // ---- check_box, one thread per frame (the frame that primes a leaflet assignment) --------------
 __global__ void k_check_box(const float *__restrict__ box9, uint32_t n_frames, uint32_t *err) {
     const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;

@@ -988,6 +988,8 @@ __global__ __launch_bounds__(1024) void k_local_build(LocalArgs a) {
             }
             run += cnt[k];
         }
+        // a grid that fills the table (128 rows of 114 + 2 * 7 cells): entry ncell lies behind the last thread's cells
+        if (tid == 1023u && c0 + PER == ncell) cstart[ncell] = run;
     }
     if (tid == 0 && a.grid) { a.grid[s] = make_uint4(nca, ncb, ka, kb); local_finfo_init(a, s); }
     __syncthreads();

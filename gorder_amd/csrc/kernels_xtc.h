@@ -213,6 +213,12 @@ __global__ __launch_bounds__(256) void k_xtc_scan(const uint8_t *__restrict__ bl
     // (bit positions in 32 bits: a frame of 256 MB or more is refused here — gorder_xtc_pack_window's blob could not
     // hold many of them either)
     if (d.n_bytes >= (1u << 28)) bad = true;
+    // widths no XTC writer produces (the table is the caller's: gorder_hip_xtc_decode is public): a mixed-radix atom of
+    // more than 72 bits, a separate field of more than 32, or no bits at all — 63 groups of such a width would not
+    // fit the window below, and the chunk decoder's bit reader takes at most 64 bits at a time
+    if (d.bitsize > 72u || width == 0u ||
+        (!d.bitsize && ((d.bitsizeint & 0xffu) > 32u || ((d.bitsizeint >> 8) & 0xffu) > 32u || ((d.bitsizeint >> 16) & 0xffu) > 32u)))
+        bad = true;
     // the walk's state is the same in every lane
     uint32_t pos = 0;                // bits of the stream before the current group
     uint32_t atoms = 0, next_cp = 0;

@@ -245,8 +245,9 @@ typedef struct {
     uint64_t first_frame_index;  /* 0 for a whole trajectory; a rank that reads a later window passes where it starts */
     uint32_t device_decode;      /* 1: XTC files are decompressed ON THE DEVICE — the host threads only copy the compressed
                                     blocks into pinned memory (gorder_xtc_pack_window), the copy engine moves those
-                                    (about a third of the decoded bytes) and gorder_hip_xtc_decode unpacks one frame
-                                    per lane.  Same coordinates bit for bit.  A run with a TRR or GRO file in it, or of frames
+                                    (about a third of the decoded bytes) and gorder_hip_xtc_decode unpacks them (k_xtc_scan:
+                                    a wave per frame finds where every 256-atom chunk starts; k_xtc_chunks: a lane per
+                                    chunk decodes).  Same coordinates bit for bit.  A run with a TRR or GRO file in it, or of frames
                                     so large that fewer than 512 fit a 4-GiB batch (about 700 000 analysed atoms; a launch
                                     takes 0.6 us per atom whatever its size), uses the host decoder.  When the analysed
                                     atoms end before the frame does, only the leading part of every compressed block the
@@ -293,8 +294,10 @@ void gorder_hip_release_staging(gorder_hip_handle *h);
  * [n_atoms_file] maps a file atom to its place in the output frame or -1 (NULL: every atom, in order), `n_stop` is
  * the number of atoms to go through (gorder_xtc_n_atoms_needed), `d_xyz` [n_frames][n_atoms_out][3] receives exactly
  * what gorder_xtc_next would have written, bit for bit.  Asynchronous on the handle's stream; a corrupt frame is
- * reported as GORDER_ERR_TRAJECTORY_FORMAT by the next synchronising call.  One lane decodes one frame (a frame's bit
- * stream is sequential), so throughput grows with n_frames up to ~64 k frames per call. */
+ * reported as GORDER_ERR_TRAJECTORY_FORMAT by the next synchronising call.  Two kernels: k_xtc_scan (a wave per frame walks the
+ * group headers, 64 groups a step, and leaves a checkpoint per 256 atoms) and k_xtc_chunks (a lane per chunk decodes from
+ * its checkpoint); a frame table with widths no writer produces (more than 72 bits per atom, a field of more than 32, none at
+ * all) is a format error too.  2.5 ms per 3 566 frames of 25 088 atoms. */
 int gorder_hip_xtc_decode(gorder_hip_handle *h, const uint8_t *d_blob, uint64_t blob_bytes,
                           const gorder_xtc_frame_t *d_frames, uint32_t n_frames, uint32_t n_atoms_file,
                           const int32_t *d_slot_of, uint32_t n_stop, float *d_xyz, uint32_t n_atoms_out);
@@ -388,11 +391,19 @@ uint64_t gorder_hip_last_error_frame(const gorder_hip_handle *h);
 const char *gorder_hip_last_error_message(const gorder_hip_handle *h);
 const char *gorder_hip_strerror(int status);
 
-/* Device time (ms, HIP events on the launch stream) and launch count of the dominant per-frame
- * kernel since the last call with reset != 0. */
+/* Device time of the submits since the last call with reset != 0 (ms, HIP events on the stream the handle launches on) and
+ * their number.  The first call switches the timing on; submits before it are not timed.  A submit is timed as a chain of
+ * segments, one per kernel group it queues — the leaflet kernels ("k_leaflets_global_contig"; "k_local_build",
+ * "k_local_rowprefix", "k_local_flags_rows", "k_local_flags_todo" per 256-frame slab; ...), "k_dyn_cov + k_dyn_eigen",
+ * "k_geom_shapes", the order kernels ("k_bonds_tiled", "k_ua_extras", "k_bonds_tiled_maps", ...), "k_map_accumulate",
+ * "k_bonds_direct", "k_batch_end" —; *ms is the sum over all segments, i.e. the WHOLE step on the device. */
 int gorder_hip_kernel_time(gorder_hip_handle *h, double *ms, uint64_t *launches, int reset);
-/* The kernels inside the timed region of the LAST timed batch, e.g. "k_bonds_tiled" or
- * "k_ua_extras + k_map_accumulate" ("" before the first timed batch); valid until the next submit. */
+/* Group `index` of the same measurement (in order of first appearance since the last reset): its name, the device time
+ * of its segments and their number.  GORDER_ERR_INVALID_ARGUMENT past the last group.  The times of all groups add up to
+ * gorder_hip_kernel_time's *ms.  Call before gorder_hip_kernel_time(..., reset = 1). */
+int gorder_hip_kernel_time_group(gorder_hip_handle *h, uint32_t index, const char **name, double *ms, uint64_t *segments);
+/* The group names since the last reset joined by " + ", e.g. "k_bonds_tiled + k_batch_end" ("" before the first timed
+ * submit); valid until the next submit or reset. */
 const char *gorder_hip_kernel_time_names(const gorder_hip_handle *h);
 
 /* Introspection for tests / DESIGN.md: how the bond table was tiled. */

@@ -992,6 +992,7 @@ typedef struct {
     const float *xyz, *box;
     const uint8_t *frame_flags; /* [n_frames][n_mol_total] or NULL */
     uint32_t n_frames, tid, nthr;
+    uint32_t passes;               /* gorder_oracle_submit_passes: walk the thread's frames this many times (>= 1) */
     o_acc acc;
     int64_t *tw_s; uint64_t *tw_n; /* batch timewise rows (shared, disjoint rows per thread) */
     const float *manual;           /* manual normals of the batch or NULL */
@@ -1005,6 +1006,7 @@ static void *worker(void *arg) {
     const size_t row = 3 * (size_t)h->n_acc;
     const int use_normals = h->dyn.enabled || j->manual;
     float *normals = use_normals ? (float *)malloc(4 * sizeof(float) * (size_t)(h->n_mol_total ? h->n_mol_total : 1)) : NULL;
+    for (uint32_t pass = 0; pass < j->passes && j->status == GORDER_OK; pass++)
     for (uint32_t f = j->tid; f < j->n_frames; f += j->nthr) {
         float box3[3] = {0, 0, 0};
         if (h->pbc) {
@@ -1025,8 +1027,23 @@ static void *worker(void *arg) {
     return NULL;
 }
 
+static int oracle_submit(gorder_oracle_handle *h, const float *xyz, const float *box,
+                         const uint64_t *frame_index, uint32_t n_frames, uint32_t passes);
 int gorder_oracle_submit(gorder_oracle_handle *h, const float *xyz, const float *box,
                          const uint64_t *frame_index, uint32_t n_frames) {
+    return oracle_submit(h, xyz, box, frame_index, n_frames, 1);
+}
+/* Benchmark aid (bench.py's cpu_baseline): the same batch analysed `passes` times by the SAME worker threads — every
+ * thread walks its frames t, t + n, ... `passes` times into its accumulator clone, one ordered reduce at the end —, so
+ * that a timing does not consist of thread start-up (the reference keeps its threads for the whole trajectory,
+ * groan_rs traj_iter_map_reduce; common.rs:283-339).  Sums and counts come out `passes` times those of one pass; the
+ * frame counter advances by n_frames only; not meant for timewise rows. */
+int gorder_oracle_submit_passes(gorder_oracle_handle *h, const float *xyz, const float *box,
+                                const uint64_t *frame_index, uint32_t n_frames, uint32_t passes) {
+    return oracle_submit(h, xyz, box, frame_index, n_frames, passes < 1 ? 1 : passes);
+}
+static int oracle_submit(gorder_oracle_handle *h, const float *xyz, const float *box,
+                         const uint64_t *frame_index, uint32_t n_frames, uint32_t passes) {
     if (!h || !xyz || (!box && h->pbc) || !frame_index) return GORDER_ERR_INVALID_ARGUMENT;
     if (n_frames == 0) return GORDER_OK;
     const size_t row = 3 * (size_t)h->n_acc;
@@ -1083,7 +1100,7 @@ int gorder_oracle_submit(gorder_oracle_handle *h, const float *xyz, const float 
         pthread_t *th = (pthread_t *)calloc(nthr, sizeof(pthread_t));
         for (uint32_t t = 0; t < nthr; t++) {
             jobs[t].h = h; jobs[t].xyz = xyz; jobs[t].box = box; jobs[t].frame_flags = frame_flags;
-            jobs[t].n_frames = n_run; jobs[t].tid = t; jobs[t].nthr = nthr;
+            jobs[t].n_frames = n_run; jobs[t].tid = t; jobs[t].nthr = nthr; jobs[t].passes = passes;
             jobs[t].manual = (h->manual_frames == n_frames) ? h->manual_normals : NULL;
             jobs[t].tw_s = tw_s; jobs[t].tw_n = tw_n; jobs[t].status = GORDER_OK;
             acc_alloc(h, &jobs[t].acc);

@@ -37,6 +37,9 @@ uint32_t gorder_oracle_ordermap_dims(const gorder_oracle_handle *h, uint32_t *nx
 /* xyz [n_frames][n_atoms][3], box [n_frames][3][3], frame_index [n_frames]; host memory */
 int gorder_oracle_submit(gorder_oracle_handle *h, const float *xyz, const float *box,
                          const uint64_t *frame_index, uint32_t n_frames);
+/* benchmark aid: the same batch walked `passes` times by the same worker threads (sums come out `passes` times as large) */
+int gorder_oracle_submit_passes(gorder_oracle_handle *h, const float *xyz, const float *box,
+                                const uint64_t *frame_index, uint32_t n_frames, uint32_t passes);
 int gorder_oracle_prime_leaflets(gorder_oracle_handle *h, const float *xyz, const float *box,
                                  uint64_t frame_index);
 int gorder_oracle_set_manual_leaflets(gorder_oracle_handle *h, const uint8_t *flags,

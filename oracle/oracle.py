@@ -39,6 +39,7 @@ def load():
     lib.gorder_oracle_ordermap_dims.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
     lib.gorder_oracle_ordermap_dims.restype = u32
     lib.gorder_oracle_submit.argtypes = [vp, vp, vp, vp, u32]
+    lib.gorder_oracle_submit_passes.argtypes = [vp, vp, vp, vp, u32, u32]
     lib.gorder_oracle_prime_leaflets.argtypes = [vp, vp, vp, u64]
     lib.gorder_oracle_set_manual_leaflets.argtypes = [vp, vp, u64]
     lib.gorder_oracle_finish.argtypes = [vp, vp, vp, vp, vp, C.POINTER(u64)]
@@ -183,7 +184,8 @@ class OracleEngine:
         if st != OK:
             raise OracleError(st, self.lib.gorder_oracle_last_error_index(self._h))
 
-    def submit(self, xyz, box, frame_index=None):
+    def submit(self, xyz, box, frame_index=None, passes=1):
+        """`passes` > 1 (benchmark aid): the worker threads walk the batch that many times before the one reduce."""
         xyz = _f32(xyz)
         n_frames = xyz.shape[0]
         assert xyz.shape[1:] == (self.tables.n_atoms, 3)
@@ -194,7 +196,10 @@ class OracleEngine:
         if box is not None:
             box = _f32(box).reshape(n_frames, 9)
             bp = box.ctypes.data
-        self._check(self.lib.gorder_oracle_submit(self._h, xyz.ctypes.data, bp, fi.ctypes.data, n_frames))
+        if passes > 1:
+            self._check(self.lib.gorder_oracle_submit_passes(self._h, xyz.ctypes.data, bp, fi.ctypes.data, n_frames, int(passes)))
+        else:
+            self._check(self.lib.gorder_oracle_submit(self._h, xyz.ctypes.data, bp, fi.ctypes.data, n_frames))
 
     submit_host = submit
 

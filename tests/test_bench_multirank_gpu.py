@@ -54,3 +54,14 @@ def test_two_ranks_strong_scaling_default(built):
     e2e = out["end_to_end"]
     assert e2e["equal_to_one_handle"] and e2e["frames_of_all_shards"] == e2e["frames"] == 500 * 80
     assert [r["frames"] for r in e2e["per_rank"]] == [20000, 20000] and e2e["per_rank"][1]["first_frame_of_shard"] == 20000
+    # the library's own RCCL route (gorder_hip_comm_unique_id / _create / gorder_hip_allreduce) is exercised after the
+    # timed region on every multi-rank run.  Two ranks on ONE device is something RCCL refuses: the block must be there,
+    # say so, and cost neither the line nor the other blocks (on a real multi-GPU node: ok and equal_to_torch true).
+    lib = out["lib_allreduce"]
+    assert set(lib) >= {"ok", "equal_to_torch", "ms", "ranks"} and lib["ranks"] == 2
+    assert (lib["ok"] and lib["equal_to_torch"] is True and lib["ms"] > 0) or (not lib["ok"] and lib.get("error"))
+    assert "extras_timed_out" not in out
+    # every kernel group of the step is in the line, and the groups add up to the step
+    r = out["roofline"]
+    assert abs(sum(k["share_of_step"] for k in r["kernels"]) - 1.0) < 1e-6
+    assert abs(sum(k["ms"] for k in r["kernels"]) - r["whole_step_ms"]) < 1e-6 * max(1.0, r["whole_step_ms"])

@@ -435,14 +435,13 @@ def test_priming_replaces_cross_thread_wait(built):
     np.testing.assert_array_equal(head.counts + tail.counts, ref.counts)
 
 
-@pytest.mark.parametrize("g", ["4", "8"])
-def test_frames_per_stage_variants(built, monkeypatch, g):
-    monkeypatch.setenv("GORDER_HIP_FRAMES_PER_STAGE", g)
+def test_frame_count_not_a_multiple_of_the_stage(built, monkeypatch):
+    # 43 frames in stages of 4 with few workgroups: partial last stage, several chunks
     monkeypatch.setenv("GORDER_HIP_WG_TARGET", "40")
     system = synthetic.cg_membrane(150, leaflets=LEAFLETS_GLOBAL, frequency=3)
     xyz = system.frames(43, seed=21)
     eng, _ = assert_parity(system, xyz, system.box9(43))
-    assert eng.plan()["frames_per_stage"] == int(g)
+    assert eng.plan()["frames_per_stage"] == 4
 
 
 def test_launch_geometry_invariance(built):
@@ -616,6 +615,34 @@ def test_local_leaflets_with_a_cell_of_more_than_255_atoms(built):
         np.testing.assert_array_equal(got.counts, want.counts)
 
 
+def test_local_leaflets_on_a_grid_that_fills_the_cell_table(built):
+    """Cells of r / 7 with a halo of 2 x 7 columns: 128 rows of 114 + 14 cells are exactly the 16 384 entries the cell
+    tables hold, and the end entry of the starts (index 16 384) lies behind the last thread's share of the scan in
+    k_local_build — it must be written all the same (the rows kernel reads it for the last cell of the last row)."""
+    radius = 1.0
+    box = (18.3595, 16.3595, 10.0)
+
+    def cells(L, k=7):                      # kernels_leaflets.h local_axis, in f32
+        return int(np.floor(np.float32(L) / (np.float32(radius) / np.float32(k)) * np.float32(0.9999)))
+    assert cells(box[0]) == 128 and cells(box[1]) == 114
+    system = synthetic.cg_membrane(900, leaflets=LEAFLETS_LOCAL, radius=radius, n_types=2, box=box)
+    n = 3
+    xyz = system.frames(n, seed=43)
+    # lipids in the far corner of the plane: their cylinders cover the last cells of the last rows
+    assert ((xyz[0, :, 0] > box[0] - 0.1) & (xyz[0, :, 1] > box[1] - 0.1 - 14 * 0.1431)).any()
+    eng, got = run_gpu(system, xyz, system.box9(n), batches=1)
+    o, want = run_oracle(system, xyz, system.box9(n))
+    flags, _ = eng.leaflets()
+    oflags, odist, _ = o.leaflets()
+    diff = flags != oflags
+    assert not diff.any() or np.abs(odist[diff]).max() < 1e-4
+    np.testing.assert_allclose(eng.leaflet_distances()[~diff], odist[~diff], atol=5e-5)
+    assert_sums_given_device_flags(system.tables, xyz, system.box9(n), got)
+    if not diff.any():
+        np.testing.assert_array_equal(got.sums, want.sums)
+        np.testing.assert_array_equal(got.counts, want.counts)
+
+
 def test_independent_handles_interleaved_and_threaded(built):
     """A handle is thread-compatible like one SystemTopology clone (topology/mod.rs:256-278): several handles, each
     with its own stream, fed from different host threads at the same time, do not disturb each other."""
@@ -770,10 +797,9 @@ def test_global_leaflets_with_unwrapped_coordinates(built):
     assert_sums_given_device_flags(system.tables, xyz, box, got)
 
 
-def test_eight_frames_per_stage_falls_back_on_wide_windows(built, monkeypatch):
-    """GORDER_HIP_FRAMES_PER_STAGE=8 with an atom window of ~860 atoms would need 82 KB of LDS per workgroup, more than
-    a launch gets without opting in: the handle then stages 4 frames (48 KB at the widest window) instead of failing."""
-    monkeypatch.setenv("GORDER_HIP_FRAMES_PER_STAGE", "8")
+def test_wide_windows_fit_the_default_lds_budget(built):
+    """An atom window of ~860 atoms staged for 4 frames takes 41 KB of LDS per workgroup: inside the 64 KB a launch
+    gets without opting in (the widest window, 1024 atoms, takes 48 KB)."""
     rng = np.random.default_rng(4)
     n_atoms, n_mol = 3000, 60
     wide = np.stack([np.arange(n_mol), np.arange(n_mol) + 800], axis=1)

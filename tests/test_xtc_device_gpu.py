@@ -162,7 +162,7 @@ def test_corrupt_block_is_reported(built, tmp_path):
     rng = np.random.default_rng(13)
     path = write(tmp_path, "c.xtc", clustered(rng, 2000, 5, 6.0), 6.0, 1000.0)
     w = xtc.pack_trajectory([path])[0]
-    for damage in ("truncated", "smallidx", "offset"):
+    for damage in ("truncated", "smallidx", "offset", "bitsize", "bitsizeint", "no bits"):
         mt = abi.MolType(n_molecules=1, bonds=np.array([[[0, 1]]], dtype=np.uint32))
         eng = HipEngine(abi.Tables(n_atoms=2, molecule_types=[mt]))
         fr = w["frames"].copy()
@@ -170,6 +170,14 @@ def test_corrupt_block_is_reported(built, tmp_path):
             fr["n_bytes"][3] = 400                          # the stream ends long before the last atom
         elif damage == "smallidx":
             fr["smallidx"][3] = 80
+        elif damage == "bitsize":                           # widths no writer produces (the table is the caller's):
+            fr["bitsize"][3] = 200                          # 63 groups of them would not fit the scan's window
+        elif damage == "bitsizeint":
+            fr["bitsize"][3] = 0
+            fr["bitsizeint"][3] = 255 | (255 << 8) | (255 << 16)
+        elif damage == "no bits":
+            fr["bitsize"][3] = 0
+            fr["bitsizeint"][3] = 0
         else:
             fr["offset"][3] = w["blob"].size                # outside the blob: nothing may be read
         blob = torch.from_numpy(w["blob"]).cuda()
