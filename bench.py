@@ -72,6 +72,11 @@ def make_system(name):
         return synthetic.ua_membrane(256, timewise=True), "UAOrder 256 united-atom lipids + per-frame rows (error estimation)"
     if name == "ua256":
         return synthetic.ua_membrane(256), "UAOrder 256 united-atom lipids (62 virtual C-H per lipid)"
+    if name in ("ua256-fast", "ua256-maps-fast"):      # the same two with GORDER_FLAG_UA_FAST_NORMALISE (opt-in, tolerance-bounded)
+        from gorder_amd.abi import FLAG_UA_FAST_NORMALISE
+        system, text = make_system(name[:-5])
+        system.tables.flags |= FLAG_UA_FAST_NORMALISE
+        return system, text + " [GORDER_FLAG_UA_FAST_NORMALISE]"
     if name == "cg3k-dynamic":   # membrane normal: dynamic (normal.rs:160-199): per lipid and frame, PCA of the heads within 2 nm
         import numpy as np
         from gorder_amd.abi import DynamicNormal, LEAFLETS_GLOBAL as LG
@@ -94,11 +99,41 @@ def make_system(name):
     raise SystemExit(f"unknown workload {name}")
 
 
+def cpu_quota():
+    """CPUs the container may use at once according to its cgroup (v2 cpu.max, v1 cfs quota), or None: a box that shows
+    256 hardware threads through the affinity mask may still be held to 16 by a CPU quota — 64 threads then run at a quarter
+    of their speed each, which is what round 3's "25.2 k frames/s on 64 threads" was."""
+    def read(path):
+        try:
+            with open(path) as fh:
+                return fh.read().split()
+        except OSError:
+            return None
+    candidates = ["/sys/fs/cgroup/cpu.max"]
+    try:
+        with open("/proc/self/cgroup") as fh:
+            for line in fh:
+                parts = line.strip().split(":", 2)
+                if len(parts) == 3 and parts[1] == "":
+                    candidates.insert(0, "/sys/fs/cgroup" + parts[2].rstrip("/") + "/cpu.max")
+    except OSError:
+        pass
+    for path in candidates:
+        v = read(path)
+        if v and len(v) == 2 and v[0] != "max":
+            return max(1.0, float(v[0]) / float(v[1]))
+    q, per = read("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), read("/sys/fs/cgroup/cpu/cpu.cfs_period_us")
+    if q and per and float(q[0]) > 0:
+        return max(1.0, float(q[0]) / float(per[0]))
+    return None
+
+
 def cores_available():
     try:
-        return max(1, len(os.sched_getaffinity(0)))
+        n = max(1, len(os.sched_getaffinity(0)))
     except AttributeError:
-        return max(1, os.cpu_count() or 1)
+        n = max(1, os.cpu_count() or 1)
+    return n
 
 
 def host_cores():
@@ -116,38 +151,54 @@ def reader_threads():
     return max(1, min(cores_available(), 16))
 
 
-def cpu_baseline(system, seconds_target=8.0, threads=None):
+def cpu_baseline(system, seconds_target=2.0, threads=None):
     """Oracle (kind 'port') on the host cores: reference-faithful libm trig, one accumulator clone per thread +
-    ordered reduce like groan_rs' traj_iter_map_reduce.  Timed at 1 thread and at `cores` threads.
-    Every thread gets at least 64 frames per pass and the worker threads stay alive across the passes of a timing
-    (gorder_oracle_submit_passes) — the reference keeps its threads for the whole trajectory (common.rs:283-339), and
-    round 3's 8 frames per thread and pass measured thread start-up, not arithmetic."""
+    ordered reduce like groan_rs' traj_iter_map_reduce.  Every thread gets at least 64 frames per pass
+    and the worker threads stay alive across the passes of a timing (gorder_oracle_submit_passes) — the reference keeps
+    its threads for the whole trajectory (common.rs:283-339).  How many threads this box really runs at once is
+    MEASURED: the scaling table 1 / 2 / 4 / ... / `host_cores()` threads is part of the block, `value` is its best row
+    and `cores` that row's thread count (the affinity mask of a GPU box shows every hardware thread of the host, its CPU
+    quota may be a fraction of that)."""
     from oracle import oracle
-    cores = threads or host_cores()
-    n_sample = max(cores * 64, min(512, int(2e8 // max(1, system.n_atoms * 12))))
-    n_sample = min(n_sample, max(cores, int(4e9 // max(1, system.n_atoms * 12))))       # at most 4 GB of frames
+    cap = threads or host_cores()
+    counts = [1]
+    while counts[-1] * 2 <= cap:
+        counts.append(counts[-1] * 2)
+    if counts[-1] != cap:
+        counts.append(cap)
+    n_sample = max(cap * 64, 512)
+    n_sample = min(n_sample, max(cap, int(4e9 // max(1, system.n_atoms * 12))))       # at most 4 GB of frames
     xyz = system.frames(n_sample, seed=99)
     box = system.box9(n_sample)
 
-    def timed(n_threads, n_frames):
+    def timed(n_threads):
+        n_frames = min(n_sample, max(512, 64 * n_threads))
         eng = oracle.OracleEngine(system.tables, trig=oracle.TRIG_LIBM, n_threads=n_threads)
         t0 = time.perf_counter()
         eng.submit(xyz[:n_frames], box[:n_frames])
         t1 = time.perf_counter() - t0
-        passes = int(max(1, min(2000, seconds_target / max(t1, 1e-6))))
+        passes = int(max(1, min(5000, seconds_target / max(t1, 1e-6))))
         t0 = time.perf_counter()
         eng.submit(xyz[:n_frames], box[:n_frames], passes=passes)          # ONE call: the threads live through all passes
-        return passes * n_frames / (time.perf_counter() - t0), passes
+        return passes * n_frames / (time.perf_counter() - t0), n_frames, passes
 
-    all_cores, reps = timed(cores, n_sample)
-    n_one = min(n_sample, 512)
-    one, reps1 = timed(1, n_one)
-    out = {"value": all_cores, "unit": "frames/s", "cores": cores, "cores_available": cores_available(), "kind": "port",
-           "value_1_thread": one, "parallel_efficiency": all_cores / (cores * one) if one > 0 else None,
-           "sample": f"{n_sample} synthetic frames of the same workload ({n_sample // cores} per thread) x {reps} passes on {cores} "
-                     f"threads that live through all passes ({n_one} frames x {reps1} passes on 1 thread); libm trig, "
-                     f"frame-interleaved threads + ordered reduce"}
-    return out
+    table = []
+    for n in counts:
+        v, nf, passes = timed(n)
+        table.append({"threads": n, "frames_per_s": v, "frames": nf, "passes": passes})
+    one = table[0]["frames_per_s"]
+    best = max(table, key=lambda r: r["frames_per_s"])
+    for r in table:
+        r["speedup"] = r["frames_per_s"] / one
+    quota = cpu_quota()
+    return {"value": best["frames_per_s"], "unit": "frames/s", "cores": best["threads"], "cores_available": cores_available(),
+            "cpu_quota": quota, "kind": "port", "value_1_thread": one,
+            "parallel_efficiency": best["frames_per_s"] / (best["threads"] * one),
+            "scaling": table,
+            "sample": f"{best['frames']} synthetic frames of the same workload ({best['frames'] // best['threads']} per thread) x "
+                      f"{best['passes']} passes on {best['threads']} threads that live through all passes — the best row of the "
+                      f"scaling table over {counts} threads, ~{seconds_target:.0f} s each (1 thread: {table[0]['frames']} frames x "
+                      f"{table[0]['passes']} passes); libm trig, frame-interleaved threads + ordered reduce"}
 
 
 def warm_up(step, sync, n_steps, agree=None):

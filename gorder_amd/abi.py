@@ -38,6 +38,7 @@ ERR_TRAJECTORY_FORMAT = 106
 
 LEAFLETS_NONE, LEAFLETS_GLOBAL, LEAFLETS_LOCAL, LEAFLETS_INDIVIDUAL, LEAFLETS_MANUAL = range(5)
 FLAG_TRIG_ACOS_COS = 1
+FLAG_UA_FAST_NORMALISE = 2      # united atoms: tolerance-bounded hydrogen construction (include/gorder_hip.h)
 UA_CH1_SAT, UA_CH2, UA_CH3, UA_CH1_UNSAT = 1, 2, 3, 4
 UA_N_H = {UA_CH1_SAT: 1, UA_CH2: 2, UA_CH3: 3, UA_CH1_UNSAT: 1}
 

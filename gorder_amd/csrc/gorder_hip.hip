@@ -94,6 +94,8 @@ struct gorder_hip_handle {
     ExtraArgs extra{};
     uint32_t *d_geom_group = nullptr;
     float *d_shapes = nullptr;
+    float *d_inv_box = nullptr;      // GORDER_FLAG_UA_FAST_NORMALISE: 1 / box edge per frame of the batch
+    size_t inv_box_cap = 0;
     // dynamic membrane normals: cloud + per-molecule heads, cell-list scratch (dyn_slab frames), normals of the batch
     uint32_t dyn_slab = 4, local_slab = 4;
     bool local_halo = false;           // local leaflets: rows of cells with a halo + prefix sums (k_local_flags_rows)
@@ -516,6 +518,14 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
         ExtraArgs e = h->extra;
         e.tw_sums = h->d_tw_sums; e.tw_cnts = h->d_tw_cnts; e.tw_row0 = h->n_frames;
         e.shapes = h->d_shapes;
+        const bool ua_fast = (h->tables.flags & GORDER_FLAG_UA_FAST_NORMALISE) != 0 && !p.ua_tiles.empty();
+        e.inv_box = nullptr;
+        if (ua_fast && a.pbc) {      // 1 / box edge per frame, once per frame instead of once per lane and frame
+            int st3;
+            if ((st3 = ensure(h, &h->d_inv_box, &h->inv_box_cap, (size_t)a.n_frames * 3)) != GORDER_OK) return st3;
+            hipLaunchKernelGGL(k_inv_box, dim3((3u * a.n_frames + 255u) / 256u), dim3(256), 0, h->stream, a.box9, a.n_frames, h->d_inv_box);
+            e.inv_box = h->d_inv_box;
+        }
         e.dyn = (h->dyn || h->manual_active) ? h->d_dyn_normals : nullptr;
         const bool ac = (h->tables.flags & GORDER_FLAG_TRIG_ACOS_COS) != 0;
         // with ordermaps the frames go in sub-ranges short enough for the packed map words (k_fold_maps)
@@ -612,8 +622,14 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
 #undef GORDER_LAUNCH_BONDS
                 } else {
 #define GORDER_LAUNCH_UA(AC, MODE)                                                                                \
-    hipLaunchKernelGGL((k_ua_extras<AC, MODE>), g, blk, 0, h->stream, b, e, b.xyz, b.box9, b.aflags, b.arow,        \
-                       h->d_ua_tiles, h->d_ua_items, h->d_ua_tile_slots, nt)
+    do {                                                                                                            \
+        if (!AC && ua_fast)                                                                                         \
+            hipLaunchKernelGGL((k_ua_extras<false, MODE, true>), g, blk, 0, h->stream, b, e, b.xyz, b.box9, b.aflags, \
+                               b.arow, h->d_ua_tiles, h->d_ua_items, h->d_ua_tile_slots, nt);                      \
+        else                                                                                                        \
+            hipLaunchKernelGGL((k_ua_extras<AC, MODE, false>), g, blk, 0, h->stream, b, e, b.xyz, b.box9, b.aflags, \
+                               b.arow, h->d_ua_tiles, h->d_ua_items, h->d_ua_tile_slots, nt);                      \
+    } while (0)
                     // staged ordermap samples and nothing else: the lean kernel
                     const bool maps_only = extras && staged && !e.tw && !e.geom_kind && !e.dyn;
                     name("k_ua_extras");
@@ -847,6 +863,8 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
     h->tables.leaflets.membrane = nullptr;
     h->device = t->device;
     HIP_TRY(h, hipSetDevice(h->device));
+    if ((t->flags & GORDER_FLAG_UA_FAST_NORMALISE) && (t->flags & GORDER_FLAG_TRIG_ACOS_COS))
+        return fail(h, GORDER_ERR_INVALID_ARGUMENT, "GORDER_FLAG_UA_FAST_NORMALISE (tolerance-bounded) and GORDER_FLAG_TRIG_ACOS_COS (literal) exclude each other");
     int st = gorder::build_plan(*t, env_flag("GORDER_HIP_FORCE_DIRECT"), h->plan);
     if (st != GORDER_OK) return fail(h, st, "invalid bond tables");
     const Plan &p = h->plan;
@@ -1096,7 +1114,7 @@ void gorder_hip_destroy(gorder_hip_handle *h) {
     (void)hipFree(h->d_direct); (void)hipFree(h->d_err); (void)hipFree(h->d_xtc_cp);
     (void)hipFree(h->d_ua_tiles); (void)hipFree(h->d_ua_items); (void)hipFree(h->d_ua_tile_slots);
     (void)hipFree(h->d_map_sums); (void)hipFree(h->d_map_cnts); (void)hipFree(h->d_map_packed); (void)hipFree(h->d_tw_sums); (void)hipFree(h->d_tw_cnts);
-    (void)hipFree(h->d_geom_group); (void)hipFree(h->d_shapes);
+    (void)hipFree(h->d_geom_group); (void)hipFree(h->d_shapes); (void)hipFree(h->d_inv_box);
     (void)hipFree(h->d_map_rec); (void)hipFree(h->d_ua_runs); (void)hipFree(h->d_ua_run_begin);
     (void)hipFree(h->d_runs); (void)hipFree(h->d_run_begin); (void)hipFree(h->d_items_by_slot);
     (void)hipFree(h->d_ua_item_run); (void)hipFree(h->d_item_run); (void)hipFree(h->d_lgrid); (void)hipFree(h->d_lrowpre); (void)hipFree(h->d_lfinfo); (void)hipFree(h->d_ltodo);

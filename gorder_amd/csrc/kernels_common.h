@@ -123,6 +123,12 @@ __global__ void k_check_box(const float *__restrict__ box9, uint32_t n_frames, u
     if (f < n_frames) check_box_frame(box9, f, err);
 }
 
+// 1 / box edge per frame (GORDER_FLAG_UA_FAST_NORMALISE): inv[f][d] = 1.0f / box9[f][4 d], an IEEE division
+__global__ void k_inv_box(const float *__restrict__ box9, uint32_t n_frames, float *__restrict__ inv) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 3u * n_frames) inv[i] = 1.0f / box9[9u * (size_t)(i / 3u) + 4u * (i % 3u)];
+}
+
 // acc[i] += sum_r rep[r][i]; rep := 0   (i < 4 * n_acc)
 __global__ void k_fold_replicas(unsigned long long *acc, unsigned long long *rep, uint32_t n_rep, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -43,6 +43,9 @@ struct ExtraArgs {
     int geom_kind, geom_invert, geom_orient;
     float geom_thr;                  // cylinder / sphere: local_radius_threshold(radius), d2 < geom_thr == sqrt(d2) < radius
     const float *shapes;
+    // GORDER_FLAG_UA_FAST_NORMALISE: 1 / box edge per frame [n_frames][3] (k_inv_box: IEEE divisions, once per frame instead
+    // of once per lane and frame), or null
+    const float *inv_box;
 };
 
 // groan_rs Rectangular / Cylinder / Sphere ::inside (oracle: inside_shape), XOR invert (geometry.rs:181-189).
@@ -765,6 +768,171 @@ __device__ __forceinline__ UaBonds ua_carbon_pairs(uint32_t kind, UaCarbon c, Ua
     return r;
 }
 
+// ---- GORDER_FLAG_UA_FAST_NORMALISE: the same constructions with tolerance-bounded arithmetic ---------------------------
+// Opt-in (include/gorder_hip.h).  The exact path above spends most of its instructions on being the reference's bits:
+// six normalisations by correctly rounded square root and division (46 instructions each as pairs), select chains for
+// the periodic shifts.  Here
+//  * a / |a| is a * rsqrt(|a|^2) with |a|^2 by fused multiply-adds and rsqrt by an integer seed and three Newton steps
+//    (every step an IEEE mul / fma: the oracle's FAST mode restates it operation for operation, so device and oracle sums
+//    stay EQUAL; relative error ~1e-7, the reference's own two roundings leave 6e-8);
+//  * the axis that is already a unit vector is not normalised again (Unit::new_normalize(rot_axis), uaorder.rs:990-1003);
+//  * the hydrogen is target + dir * (rsqrt * 0.109) by one fma per component;
+//  * minimum image and wrap are d - L * rint(d / L) and x - L * floor(x / L) with 1 / L from k_inv_box: for shifts of
+//    at most one box length the same values as the reference's loops except AT the boundaries (|d| = L / 2, x = L) and
+//    where d / L rounds across one; more than one box length (|k| > 1) goes to the literal-loop evaluation like before.
+// What it costs in fidelity is measured, not assumed: tools/ua_fast_fidelity.py (fraction of samples that move by a tick
+// against the libm oracle, fraction of bond positions that change ordermap tile) -> profiles/r04_ua_fast_fidelity.json.
+__device__ __forceinline__ float ua_fast_rsqrt(float x) {
+    float y = __int_as_float(0x5f375a86 - (__float_as_int(x) >> 1));
+    const float hx = 0.5f * x;
+    y = y * __builtin_fmaf(-(hx * y), y, 1.5f);
+    y = y * __builtin_fmaf(-(hx * y), y, 1.5f);
+    y = y * __builtin_fmaf(-(hx * y), y, 1.5f);
+    return y;
+}
+struct PbcFast {
+    V3 box, inv;
+    bool pbc;
+    bool slow = false;
+    __device__ __forceinline__ float mi1(float d, float L, float iL) {
+        if (!pbc) return d;
+        const float k = __builtin_rintf(d * iL);
+        slow = slow || (__builtin_fabsf(k) > 1.0f);
+        return __builtin_fmaf(-L, k, d);
+    }
+    __device__ __forceinline__ float wr1(float x, float L, float iL) {
+        if (!pbc) return x;
+        const float k = __builtin_floorf(x * iL);
+        slow = slow || (__builtin_fabsf(k) > 1.0f);
+        return __builtin_fmaf(-L, k, x);
+    }
+    __device__ __forceinline__ V3 to(V3 p1, V3 p2) {
+        return {mi1(p2.x - p1.x, box.x, inv.x), mi1(p2.y - p1.y, box.y, inv.y), mi1(p2.z - p1.z, box.z, inv.z)};
+    }
+    // 1 / |a|; |a|^2 outside [2^-40, 2^40] (zero, inf, NaN included) raises `slow`
+    __device__ __forceinline__ float rnorm(V3 a) {
+        const float s2 = __builtin_fmaf(a.z, a.z, __builtin_fmaf(a.y, a.y, a.x * a.x));
+        slow = slow || !(s2 >= 0x1p-40f && s2 <= 0x1p+40f);
+        return ua_fast_rsqrt(s2);
+    }
+    __device__ __forceinline__ V3 unit(V3 a) { const float r = rnorm(a); return {a.x * r, a.y * r, a.z * r}; }
+    // target + dir / |dir| * BOND_LENGTH, wrapped
+    __device__ __forceinline__ V3 shift_wrap(V3 t, V3 dir) {
+        const float r = rnorm(dir) * 0.109f;
+        return {wr1(__builtin_fmaf(dir.x, r, t.x), box.x, inv.x), wr1(__builtin_fmaf(dir.y, r, t.y), box.y, inv.y),
+                wr1(__builtin_fmaf(dir.z, r, t.z), box.z, inv.z)};
+    }
+};
+struct PbcFast2 {       // PbcFast on pairs
+    V3 box, inv;
+    bool pbc;
+    i2 slow2 = {0, 0};
+    __device__ __forceinline__ bool slow() const { return (slow2.x | slow2.y) != 0; }
+    __device__ __forceinline__ f2 mi1(f2 d, float L, float iL) {
+        if (!pbc) return d;
+        const f2 q = d * iL;
+        const f2 k = f2{__builtin_rintf(q.x), __builtin_rintf(q.y)};
+        slow2 |= __builtin_elementwise_abs(k) > f2_splat(1.0f);
+        return f2_fma(f2_splat(-L), k, d);
+    }
+    __device__ __forceinline__ f2 wr1(f2 x, float L, float iL) {
+        if (!pbc) return x;
+        const f2 q = x * iL;
+        const f2 k = f2{__builtin_floorf(q.x), __builtin_floorf(q.y)};
+        slow2 |= __builtin_elementwise_abs(k) > f2_splat(1.0f);
+        return f2_fma(f2_splat(-L), k, x);
+    }
+    __device__ __forceinline__ V3P to(V3 t, V3 p, V3 q) {
+        return {mi1(f2{p.x, q.x} - f2_splat(t.x), box.x, inv.x), mi1(f2{p.y, q.y} - f2_splat(t.y), box.y, inv.y),
+                mi1(f2{p.z, q.z} - f2_splat(t.z), box.z, inv.z)};
+    }
+    __device__ __forceinline__ V3P to(V3 t, V3P h) {
+        return {mi1(h.x - f2_splat(t.x), box.x, inv.x), mi1(h.y - f2_splat(t.y), box.y, inv.y), mi1(h.z - f2_splat(t.z), box.z, inv.z)};
+    }
+    __device__ __forceinline__ f2 rnorm(V3P a) {
+        const f2 s2 = f2_fma(a.z, a.z, f2_fma(a.y, a.y, a.x * a.x));
+        slow2 |= ~((s2 >= f2_splat(0x1p-40f)) & (s2 <= f2_splat(0x1p+40f)));
+        const i2 seed = i2{0x5f375a86, 0x5f375a86} - (__builtin_bit_cast(i2, s2) >> 1);
+        f2 y = __builtin_bit_cast(f2, seed);
+        const f2 hx = s2 * 0.5f;
+        y = y * f2_fma(-(hx * y), y, f2_splat(1.5f));
+        y = y * f2_fma(-(hx * y), y, f2_splat(1.5f));
+        y = y * f2_fma(-(hx * y), y, f2_splat(1.5f));
+        return y;
+    }
+    __device__ __forceinline__ V3P unit(V3P a) { const f2 r = rnorm(a); return {a.x * r, a.y * r, a.z * r}; }
+    __device__ __forceinline__ V3P shift_wrap(V3 t, V3P dir) {
+        const f2 r = rnorm(dir) * 0.109f;
+        return {wr1(f2_fma(dir.x, r, f2_splat(t.x)), box.x, inv.x), wr1(f2_fma(dir.y, r, f2_splat(t.y)), box.y, inv.y),
+                wr1(f2_fma(dir.z, r, f2_splat(t.z)), box.z, inv.z)};
+    }
+};
+// every kind of carbon with the fast forms; `slow` comes back raised when the literal-loop evaluation is needed instead
+__device__ __forceinline__ UaBonds ua_carbon_fast(uint32_t kind, UaCarbon c, UaConsts e, V3 box, V3 inv, bool pbc, bool &slow) {
+    const V3 zero{0.0f, 0.0f, 0.0f};
+    PbcFast ps{box, inv, pbc};
+    PbcFast2 pp{box, inv, pbc};
+    UaBonds r;
+    r.v0 = r.v1 = r.v2 = r.b0 = r.b1 = r.b2 = zero;
+    r.bad = 0;
+    if (kind == GORDER_UA_CH2 || kind == GORDER_UA_CH3) {
+        const V3 target = c.p1;
+        V3P h;                                   // CH2: hydrogens 0, 1; CH3: hydrogens 1, 2
+        if (kind == GORDER_UA_CH2) {            // uaorder.rs:985-1020
+            const V3P th = pp.unit(pp.to(target, c.p0, c.p2));
+            const V3 th1 = v3p_lane0(th), th2 = v3p_lane1(th);
+            const V3 pn = v3_cross(th2, th1);
+            const V3 ra = ps.unit(V3{th1.x - th2.x, th1.y - th2.y, th1.z - th2.z});      // (not normalised a second time)
+            const V3 rv = v3_cross(pn, ra);
+            h = pp.shift_wrap(target, v3p_rotate_pm(ra, e.sin_half, e.cos_half, rv));
+        } else {                                // CH3, uaorder.rs:947-981
+            const V3P th = pp.to(target, c.p0, c.p2);
+            const V3 th1 = v3p_lane0(th), th2 = v3p_lane1(th);
+            const V3 ua = ps.unit(v3_cross(th2, th1));
+            const V3 hv1 = v3_rotate(ua, e.sin_tet, e.cos_tet, th1);
+            const V3 h0 = ps.shift_wrap(target, hv1);
+            const V3 n1 = ps.unit(th1);
+            h = pp.shift_wrap(target, v3p_rotate_pm(n1, e.sin_ch3, e.cos_ch3, hv1));
+            r.v0 = ps.to(target, h0);
+            r.b0 = {h0.x + r.v0.x / 2.0f, h0.y + r.v0.y / 2.0f, h0.z + r.v0.z / 2.0f};
+        }
+        const V3P v = pp.to(target, h);
+        const V3P b = {h.x + v.x / 2.0f, h.y + v.y / 2.0f, h.z + v.z / 2.0f};
+        if (kind == GORDER_UA_CH2) {
+            r.v0 = v3p_lane0(v); r.b0 = v3p_lane0(b);
+            r.v1 = v3p_lane1(v); r.b1 = v3p_lane1(b);
+        } else {
+            r.v1 = v3p_lane0(v); r.b1 = v3p_lane0(b);
+            r.v2 = v3p_lane1(v); r.b2 = v3p_lane1(b);
+        }
+    } else {
+        V3 target = c.p1, h0;
+        if (kind == GORDER_UA_CH1_UNSAT) {      // uaorder.rs:1024-1045
+            const V3 th1 = ps.to(target, c.p0), th2 = ps.to(target, c.p2);
+            const float prod = (th1.x * th2.x + th1.y * th2.y) + th1.z * th2.z;
+            const float n1 = v3_norm(th1), n2 = v3_norm(th2);
+            float gamma = 0.0f;
+            if (!(n1 == 0.0f || n2 == 0.0f)) {
+                float cs = prod / (n1 * n2);
+                cs = cs < -1.0f ? -1.0f : (cs > 1.0f ? 1.0f : cs);
+                gamma = gm_acosf(cs);
+            }
+            const float ang = 3.14159265358979323846f - (gamma / 2.0f);
+            const float sn = gm_sinf_0pi(ang), cs = gm_cosf(ang);
+            const V3 ua = ps.unit(v3_cross(th1, th2));
+            h0 = ps.shift_wrap(target, ang == 0.0f ? th2 : v3_rotate(ua, sn, cs, th2));
+        } else {                                // CH1 saturated, uaorder.rs:1087-1104 (h1, h2, h3, target)
+            target = c.p3;
+            const V3 t1 = ps.unit(ps.to(target, c.p0)), t2 = ps.unit(ps.to(target, c.p1)), t3 = ps.unit(ps.to(target, c.p2));
+            h0 = ps.shift_wrap(target, V3{-((t1.x + t2.x) + t3.x), -((t1.y + t2.y) + t3.y), -((t1.z + t2.z) + t3.z)});
+        }
+        r.v0 = ps.to(target, h0);
+        r.b0 = {h0.x + r.v0.x / 2.0f, h0.y + r.v0.y / 2.0f, h0.z + r.v0.z / 2.0f};
+    }
+    slow = ps.slow || pp.slow();
+    return r;
+}
+
 // the literal-loop variant, kept out of line: it runs only for carbons more than 1.5 box lengths away
 // from a helper
 __device__ __noinline__ UaBonds ua_carbon_slow(uint32_t kind, UaCarbon c, UaConsts e, V3 box, bool pbc) {
@@ -783,7 +951,8 @@ __device__ __forceinline__ int ua_wave_sum(int v) {
 
 // MODE 0: order parameters only; 1: + staged ordermap samples, nothing else (no geometry selection, timewise rows or
 // per-molecule normals — the common ordermap run, and a much smaller kernel); 2: every extra; 3: per-frame rows, nothing else
-template <bool ACOS_COS, int MODE>
+// FAST: GORDER_FLAG_UA_FAST_NORMALISE (ua_carbon_fast; e.inv_box holds 1 / box edge per frame)
+template <bool ACOS_COS, int MODE, bool FAST = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ua_extras(FrameArgs a_in, ExtraArgs e, const float *__restrict__ xyz,
                                                        const float *__restrict__ box9,
                                                        const uint8_t *__restrict__ aflags,
@@ -871,7 +1040,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             else if (c.p3.x != c.p3.x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, f, kStageTypes, gslot0, 1, it.mol, 3);
             bool slow = false;
             UaBonds ub;
-            if (kind == GORDER_UA_CH2 || kind == GORDER_UA_CH3) {       // the two common kinds: paired arithmetic
+            if (FAST) {
+                V3 inv3{1.0f, 1.0f, 1.0f};
+                if (pbc) { const float *ib = e.inv_box + 3 * (size_t)f; inv3 = {ib[0], ib[1], ib[2]}; }
+                ub = ua_carbon_fast(kind, c, uc, bx3, inv3, pbc, slow);
+            } else if (kind == GORDER_UA_CH2 || kind == GORDER_UA_CH3) {       // the two common kinds: paired arithmetic
                 ub = ua_carbon_pairs(kind, c, uc, bx3, pbc, slow);
             } else {
                 PbcStep ps{bx3, pbc};

@@ -171,9 +171,20 @@ typedef struct {
  *   more, mean shift 2.6e-10 — inside the 1e-6 parity tolerance but NOT bit-identical to the reference.  The squared
  *   form also has half the exponent range (|v| below ~1e-19 nm or above ~1e19 nm is no longer the reference's value).
  * GORDER_FLAG_TRIG_ACOS_COS: evaluate the literal acos -> cos round trip like the reference (own f32 polynomial
- *   kernels, < 1 ulp each; 1.6 % of samples move by one tick vs glibc 2.35). */
+ *   kernels, < 1 ulp each; 1.6 % of samples move by one tick vs glibc 2.35).
+ * GORDER_FLAG_UA_FAST_NORMALISE (united atoms only, opt-in, default off): the virtual-hydrogen construction
+ *   (uaorder.rs:947-1104) with tolerance-bounded arithmetic instead of the reference's operation sequence — a / |a| as
+ *   a * rsqrt(|a|^2) (integer seed + three Newton steps, relative error ~1e-7 where the reference's two roundings leave
+ *   6e-8), no second normalisation of the CH2 rotation axis (uaorder.rs:990-1003), minimum image / wrap as
+ *   d - L rint(d / L) and x - L floor(x / L).  Every operation is an IEEE mul / add / fma, restated by the oracle's
+ *   FAST mode: device and oracle sums stay EQUAL.  Against the reference-faithful (libm) oracle every order parameter
+ *   stays within one 1e-6 tick; single samples move more often than with the default (a hydrogen position is
+ *   target + 0.109 nm * unit vector rounded to the grid of the target's coordinates, so an ulp in the unit vector
+ *   flips that rounding in ~1 % of the components): measured in profiles/r04_ua_fast_fidelity.json.  Not with
+ *   GORDER_FLAG_TRIG_ACOS_COS (gorder_hip_create refuses the pair).  The default path is bit-unchanged. */
 typedef enum {
-    GORDER_FLAG_TRIG_ACOS_COS = 1u
+    GORDER_FLAG_TRIG_ACOS_COS = 1u,
+    GORDER_FLAG_UA_FAST_NORMALISE = 2u
 } gorder_flags_t;
 
 typedef struct {

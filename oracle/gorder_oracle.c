@@ -384,6 +384,132 @@ static int predict_hydrogens_mode(uint32_t kind, const float pos[4][3], const fl
     }
     return -2;
 }
+/* ---- GORDER_FLAG_UA_FAST_NORMALISE: restatement of the DEVICE's tolerance-bounded construction
+ * (gorder_amd/csrc/kernels_extras.h: ua_fast_rsqrt, PbcFast, ua_carbon_fast), operation for operation — every step
+ * there is an IEEE mul / add / fma, rint or floor, so the bits are reproducible here.  Not the reference's arithmetic:
+ * the LIBM mode never takes this path; tools/ua_fast_fidelity.py measures one against the other. */
+static inline float fast_rsqrt(float x) {
+    union { float f; int32_t i; } u;
+    u.f = x;
+    u.i = 0x5f375a86 - (u.i >> 1);
+    float y = u.f;
+    const float hx = 0.5f * x;
+    y = y * fmaf(-(hx * y), y, 1.5f);
+    y = y * fmaf(-(hx * y), y, 1.5f);
+    y = y * fmaf(-(hx * y), y, 1.5f);
+    return y;
+}
+typedef struct { const float *box; float inv[3]; int pbc; int slow; } fast_ctx;
+static inline float fast_mi(fast_ctx *c, float d, int k) {
+    if (!c->pbc) return d;
+    const float q = rintf(d * c->inv[k]);
+    if (fabsf(q) > 1.0f) c->slow = 1;
+    return fmaf(-c->box[k], q, d);
+}
+static inline float fast_wr(fast_ctx *c, float x, int k) {
+    if (!c->pbc) return x;
+    const float q = floorf(x * c->inv[k]);
+    if (fabsf(q) > 1.0f) c->slow = 1;
+    return fmaf(-c->box[k], q, x);
+}
+static inline void fast_to(fast_ctx *c, const float *p1, const float *p2, float *o) {
+    for (int d = 0; d < 3; d++) o[d] = fast_mi(c, p2[d] - p1[d], d);
+}
+static inline float fast_rnorm(fast_ctx *c, const float *a) {
+    const float s2 = fmaf(a[2], a[2], fmaf(a[1], a[1], a[0] * a[0]));
+    if (!(s2 >= 0x1p-40f && s2 <= 0x1p+40f)) c->slow = 1;
+    return fast_rsqrt(s2);
+}
+static inline void fast_unit(fast_ctx *c, const float *a, float *o) {
+    const float r = fast_rnorm(c, a);
+    o[0] = a[0] * r; o[1] = a[1] * r; o[2] = a[2] * r;
+}
+static inline void fast_shift_wrap(fast_ctx *c, const float *t, const float *dir, float *h) {
+    const float r = fast_rnorm(c, dir) * BOND_LENGTH;
+    for (int d = 0; d < 3; d++) h[d] = fast_wr(c, fmaf(dir[d], r, t[d]), d);
+}
+/* Rotation3::from_axis_angle with given sine and cosine (the constants of the construction are evaluated once on the
+ * host with libm — sinf / cosf of the same literals — exactly as the device's ExtraArgs carries them) */
+static void rotate_sc(const float *u, float s, float c, const float *v, float *o) {
+    const float ux = u[0], uy = u[1], uz = u[2];
+    const float sqx = ux * ux, sqy = uy * uy, sqz = uz * uz, omc = 1.0f - c;
+    const float m11 = sqx + (1.0f - sqx) * c, m12 = ux * uy * omc - uz * s, m13 = ux * uz * omc + uy * s;
+    const float m21 = ux * uy * omc + uz * s, m22 = sqy + (1.0f - sqy) * c, m23 = uy * uz * omc - ux * s;
+    const float m31 = ux * uz * omc - uy * s, m32 = uy * uz * omc + ux * s, m33 = sqz + (1.0f - sqz) * c;
+    o[0] = (m11 * v[0] + m12 * v[1]) + m13 * v[2];
+    o[1] = (m21 * v[0] + m22 * v[1]) + m23 * v[2];
+    o[2] = (m31 * v[0] + m32 * v[1]) + m33 * v[2];
+}
+/* -> number of hydrogens, their positions and the vectors target -> H; *slow = 1: the device re-evaluates this carbon
+ * with the reference's literal loops (predict_hydrogens_mode + vector_to), and so must the caller */
+static int predict_hydrogens_fast(uint32_t kind, const float pos[4][3], const float box[3], int pbc,
+                                  float out[3][3], float vec[3][3], int *slow) {
+    fast_ctx c;
+    c.box = box; c.pbc = pbc; c.slow = 0;
+    for (int d = 0; d < 3; d++) c.inv[d] = pbc ? 1.0f / box[d] : 1.0f;      /* k_inv_box */
+    const float *t = kind == GORDER_UA_CH1_SAT ? pos[3] : pos[1];
+    int nh;
+    if (kind == GORDER_UA_CH3) {
+        float th1[3], th2[3], axis[3], ua[3], hv1[3], n1[3], hv[3];
+        fast_to(&c, t, pos[0], th1);
+        fast_to(&c, t, pos[2], th2);
+        cross3(th2, th1, axis);
+        fast_unit(&c, axis, ua);
+        rotate_sc(ua, sinf(TETRAHEDRAL_ANGLE), cosf(TETRAHEDRAL_ANGLE), th1, hv1);
+        fast_shift_wrap(&c, t, hv1, out[0]);
+        fast_unit(&c, th1, n1);
+        rotate_sc(n1, sinf(CH3_ANGLE), cosf(CH3_ANGLE), hv1, hv);
+        fast_shift_wrap(&c, t, hv, out[1]);
+        rotate_sc(n1, -sinf(CH3_ANGLE), cosf(CH3_ANGLE), hv1, hv);
+        fast_shift_wrap(&c, t, hv, out[2]);
+        nh = 3;
+    } else if (kind == GORDER_UA_CH2) {
+        float a[3], b[3], th1[3], th2[3], pn[3], diff[3], ra[3], rv[3], hv[3];
+        fast_to(&c, t, pos[0], a);
+        fast_to(&c, t, pos[2], b);
+        fast_unit(&c, a, th1);
+        fast_unit(&c, b, th2);
+        cross3(th2, th1, pn);
+        for (int d = 0; d < 3; d++) diff[d] = th1[d] - th2[d];
+        fast_unit(&c, diff, ra);                 /* (the unit axis is not normalised a second time) */
+        cross3(pn, ra, rv);
+        rotate_sc(ra, sinf(TETRAHEDRAL_ANGLE_HALF), cosf(TETRAHEDRAL_ANGLE_HALF), rv, hv);
+        fast_shift_wrap(&c, t, hv, out[0]);
+        rotate_sc(ra, -sinf(TETRAHEDRAL_ANGLE_HALF), cosf(TETRAHEDRAL_ANGLE_HALF), rv, hv);
+        fast_shift_wrap(&c, t, hv, out[1]);
+        nh = 2;
+    } else if (kind == GORDER_UA_CH1_UNSAT) {
+        float th1[3], th2[3], axis[3], ua[3], hv[3];
+        fast_to(&c, t, pos[0], th1);
+        fast_to(&c, t, pos[2], th2);
+        const float gamma = angle3(th1, th2, GORDER_ORACLE_TRIG_MIRROR, NULL);
+        const float ang = 3.14159265358979323846f - (gamma / 2.0f);
+        cross3(th1, th2, axis);
+        fast_unit(&c, axis, ua);
+        if (ang == 0.0f) { hv[0] = th2[0]; hv[1] = th2[1]; hv[2] = th2[2]; }
+        else rotate_sc(ua, gorder_oracle_mirror_sinf(ang), gorder_oracle_mirror_cosf(ang), th2, hv);
+        fast_shift_wrap(&c, t, hv, out[0]);
+        nh = 1;
+    } else if (kind == GORDER_UA_CH1_SAT) {
+        float a[3], th1[3], th2[3], th3[3], hv[3];
+        fast_to(&c, t, pos[0], a); fast_unit(&c, a, th1);
+        fast_to(&c, t, pos[1], a); fast_unit(&c, a, th2);
+        fast_to(&c, t, pos[2], a); fast_unit(&c, a, th3);
+        for (int d = 0; d < 3; d++) hv[d] = -((th1[d] + th2[d]) + th3[d]);
+        fast_shift_wrap(&c, t, hv, out[0]);
+        nh = 1;
+    } else {
+        return -2;
+    }
+    for (int k = 0; k < nh; k++) fast_to(&c, t, out[k], vec[k]);
+    *slow = c.slow;
+    return nh;
+}
+int gorder_oracle_predict_hydrogens_fast(uint32_t kind, const float pos[4][3], const float box[3], int pbc,
+                                         float out[3][3], float vec[3][3], int *slow) {
+    return predict_hydrogens_fast(kind, pos, box, pbc, out, vec, slow);
+}
+
 int gorder_oracle_predict_hydrogens(uint32_t kind, const float pos[4][3], const float box[3],
                                     int pbc, float out[3][3]) {
     return predict_hydrogens_mode(kind, pos, box, pbc, GORDER_ORACLE_TRIG_LIBM, out);
@@ -600,6 +726,7 @@ struct gorder_oracle_handle {
     uint32_t n_atoms, n_mt, n_acc, n_mol_total;
     o_moltype *mt;
     int pbc, trig, n_threads, timewise;
+    int ua_fast;              /* GORDER_FLAG_UA_FAST_NORMALISE and a non-libm mode: restate the device's fast construction */
     float normal[3];
     gorder_leaflets_t lf;
     uint32_t *membrane;
@@ -678,6 +805,8 @@ int gorder_oracle_create(const gorder_tables_t *t, int trig_mode, int n_threads,
     h->n_mt = t->n_molecule_types;
     h->pbc = t->handle_pbc != 0;
     h->trig = trig_mode;
+    /* the reference-faithful mode ignores the flag: it IS the reference's arithmetic */
+    h->ua_fast = (t->flags & GORDER_FLAG_UA_FAST_NORMALISE) && trig_mode != GORDER_ORACLE_TRIG_LIBM;
     h->n_threads = n_threads < 1 ? 1 : n_threads;
     h->timewise = t->timewise != 0;
     memcpy(h->normal, t->normal, sizeof(h->normal));
@@ -962,13 +1091,20 @@ static int analyze_frame_orders(const gorder_oracle_handle *h, o_acc *a, int64_t
                     if (p[0] != p[0]) { *err_index = ix[k]; return GORDER_ERR_UNDEFINED_POSITION; }
                     pos[k][0] = p[0]; pos[k][1] = p[1]; pos[k][2] = p[2];
                 }
-                float hy[3][3];
-                const int nh = predict_hydrogens_mode(kind, pos, box, h->pbc, h->trig, hy);
+                float hy[3][3], hv[3][3];
+                int nh = -1, fast_ok = 0;
+                if (h->ua_fast) {   /* the device's fast construction; a carbon it flags takes the literal path below */
+                    int slow = 0;
+                    nh = predict_hydrogens_fast(kind, pos, box, h->pbc, hy, hv, &slow);
+                    fast_ok = nh > 0 && !slow;
+                }
+                if (!fast_ok) nh = predict_hydrogens_mode(kind, pos, box, h->pbc, h->trig, hy);
                 if (nh < 0) { bad = 1; continue; }
                 for (int k = 0; k < nh; k++) {
                     /* UAAtom::calculate_sch, uaorder.rs:375-397: vec = target->H, pos = H + vec/2 (sic) */
                     float v[3], bp[3];
-                    bad |= vector_to(pos[ti], hy[k], box, h->pbc, v);
+                    if (fast_ok) { v[0] = hv[k][0]; v[1] = hv[k][1]; v[2] = hv[k][2]; }
+                    else bad |= vector_to(pos[ti], hy[k], box, h->pbc, v);
                     for (int d = 0; d < 3; d++) bp[d] = hy[k][d] + v[d] / 2.0f;
                     if (geom && !inside_shape(&h->geom, &shape, bp, box, h->pbc, &bad)) continue; /* uaorder.rs:388-390 */
                     const float sch = calc_sch(v, normal, h->trig);
@@ -979,6 +1115,84 @@ static int analyze_frame_orders(const gorder_oracle_handle *h, o_acc *a, int64_t
         }
     }
     return bad ? GORDER_ERR_BOX_RANGE : GORDER_OK;
+}
+
+/* ---- fidelity of the fast united-atom construction (tools/ua_fast_fidelity.py): every virtual C-H sample of the given
+ * frames evaluated twice — the reference's arithmetic (literal construction + libm acosf / cosf, the LIBM mode) and the
+ * device's GORDER_FLAG_UA_FAST_NORMALISE arithmetic (fast construction + the squared cosine) — and compared one by one.
+ *   hist[k]        samples whose tick differs by k (k = 15: by 15 or more)
+ *   out[0] samples, out[1] carbons the fast path hands to the literal loops, out[2] samples whose bond position falls
+ *   into another ordermap tile (0 without an ordermap), out[3] sum of signed tick differences + 2^62 (bias of the mean),
+ *   out[4] samples that differ between the plain default (literal construction + squared cosine) and libm — the
+ *   "5.9 %" of the default path, for comparison.  Static normal only. */
+int gorder_oracle_ua_fast_fidelity(const gorder_oracle_handle *h, const float *xyz, const float *box9, uint32_t n_frames,
+                                   uint64_t hist[16], uint64_t out[5]) {
+    if (!h || !xyz || (!box9 && h->pbc)) return GORDER_ERR_INVALID_ARGUMENT;
+    for (int k = 0; k < 16; k++) hist[k] = 0;
+    out[0] = out[1] = out[2] = out[4] = 0;
+    int64_t bias = 0;
+    for (uint32_t f = 0; f < n_frames; f++) {
+        const float *x = xyz + 3 * (size_t)h->n_atoms * f;
+        float box[3] = {0, 0, 0};
+        if (h->pbc) { box[0] = box9[9 * (size_t)f]; box[1] = box9[9 * (size_t)f + 4]; box[2] = box9[9 * (size_t)f + 8]; }
+        for (uint32_t m = 0; m < h->n_mt; m++) {
+            const o_moltype *mt = &h->mt[m];
+            for (uint32_t ua = 0; ua < mt->n_ua_atoms; ua++) {
+                const uint32_t kind = mt->ua_kind[ua];
+                const int ti = kind == GORDER_UA_CH1_SAT ? 3 : 1;
+                const int nidx = kind == GORDER_UA_CH1_SAT ? 4 : 3;
+                for (uint32_t i = 0; i < mt->n_molecules; i++) {
+                    const uint32_t *ix = mt->ua_idx[ua] + 4 * (size_t)i;
+                    float pos[4][3] = {{0}};
+                    for (int k = 0; k < nidx; k++)
+                        for (int d = 0; d < 3; d++) pos[k][d] = x[3 * (size_t)ix[k] + d];
+                    float hy_ref[3][3], hy_def[3][3], hy_fast[3][3], v_fast[3][3];
+                    int slow = 0;
+                    const int nh = predict_hydrogens_mode(kind, pos, box, h->pbc, GORDER_ORACLE_TRIG_LIBM, hy_ref);
+                    const int nh_d = predict_hydrogens_mode(kind, pos, box, h->pbc, GORDER_ORACLE_TRIG_DIRECT, hy_def);
+                    const int nh_f = predict_hydrogens_fast(kind, pos, box, h->pbc, hy_fast, v_fast, &slow);
+                    if (nh < 0 || nh_f != nh || nh_d != nh) continue;
+                    if (slow) out[1]++;
+                    for (int k = 0; k < nh; k++) {
+                        float v[3], vd[3], vf[3], bp[3], bpf[3];
+                        vector_to(pos[ti], hy_ref[k], box, h->pbc, v);
+                        vector_to(pos[ti], hy_def[k], box, h->pbc, vd);
+                        if (slow) { vf[0] = vd[0]; vf[1] = vd[1]; vf[2] = vd[2]; }
+                        else { vf[0] = v_fast[k][0]; vf[1] = v_fast[k][1]; vf[2] = v_fast[k][2]; }
+                        const float *hf = slow ? hy_def[k] : hy_fast[k];
+                        for (int d = 0; d < 3; d++) { bp[d] = hy_ref[k][d] + v[d] / 2.0f; bpf[d] = hf[d] + vf[d] / 2.0f; }
+                        const int64_t t_ref = gorder_oracle_tick(calc_sch(v, h->normal, GORDER_ORACLE_TRIG_LIBM));
+                        const int64_t t_def = gorder_oracle_tick(calc_sch(vd, h->normal, GORDER_ORACLE_TRIG_DIRECT));
+                        const int64_t t_fast = gorder_oracle_tick(calc_sch(vf, h->normal, GORDER_ORACLE_TRIG_DIRECT));
+                        int64_t dlt = t_fast - t_ref;
+                        bias += dlt;
+                        if (dlt < 0) dlt = -dlt;
+                        hist[dlt > 15 ? 15 : dlt]++;
+                        if (t_def != t_ref) out[4]++;
+                        out[0]++;
+                        if (h->om.enabled) {
+                            int tile[2];
+                            for (int w = 0; w < 2; w++) {
+                                const float *p = w ? bpf : bp;
+                                float px, py;
+                                switch (h->om.plane) {
+                                    case 0: px = p[0]; py = p[1]; break;
+                                    case 1: px = p[0]; py = p[2]; break;
+                                    default: px = p[2]; py = p[1]; break;
+                                }
+                                const int gx = gridmap_index(px, h->om.span_x[0], h->om.bin[0], h->nx);
+                                const int gy = gridmap_index(py, h->om.span_y[0], h->om.bin[1], h->ny);
+                                tile[w] = (gx >= 0 && gy >= 0) ? gx * (int)h->ny + gy : -1;
+                            }
+                            if (tile[0] != tile[1]) out[2]++;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    out[3] = (uint64_t)(bias + ((int64_t)1 << 62));
+    return GORDER_OK;
 }
 
 /* ---- batch driver: restates groan_rs traj_iter_map_reduce as used at common.rs:283-339:

@@ -76,6 +76,13 @@ float gorder_oracle_mirror_cosf(float x);
 float gorder_oracle_mirror_sinf(float x);   /* x in [0, pi] */
 /* UA hydrogen construction (uaorder.rs:947-1104); pos = [4][3] in the order of `indices`;
  * out = [n_h][3]; returns n_h */
+/* the device's GORDER_FLAG_UA_FAST_NORMALISE construction restated (hydrogens, vectors target -> H, and whether the
+ * device would re-evaluate the carbon with the literal loops) — test / fidelity tooling */
+int gorder_oracle_predict_hydrogens_fast(uint32_t kind, const float pos[4][3], const float box[3], int pbc,
+                                         float out[3][3], float vec[3][3], int *slow);
+/* per-sample comparison of the fast construction with the reference's arithmetic (see the definition) */
+int gorder_oracle_ua_fast_fidelity(const gorder_oracle_handle *h, const float *xyz, const float *box9, uint32_t n_frames,
+                                   uint64_t hist[16], uint64_t out[5]);
 int gorder_oracle_predict_hydrogens(uint32_t kind, const float pos[4][3], const float box[3],
                                     int handle_pbc, float out[3][3]);
 /* TimeWiseData::estimate_error (timewise.rs:191-231) and prefix_average (:259-274) */

@@ -40,6 +40,7 @@ def load():
     lib.gorder_oracle_ordermap_dims.restype = u32
     lib.gorder_oracle_submit.argtypes = [vp, vp, vp, vp, u32]
     lib.gorder_oracle_submit_passes.argtypes = [vp, vp, vp, vp, u32, u32]
+    lib.gorder_oracle_ua_fast_fidelity.argtypes = [vp, vp, vp, u32, vp, vp]
     lib.gorder_oracle_prime_leaflets.argtypes = [vp, vp, vp, u64]
     lib.gorder_oracle_set_manual_leaflets.argtypes = [vp, vp, u64]
     lib.gorder_oracle_finish.argtypes = [vp, vp, vp, vp, vp, C.POINTER(u64)]
@@ -202,6 +203,25 @@ class OracleEngine:
             self._check(self.lib.gorder_oracle_submit(self._h, xyz.ctypes.data, bp, fi.ctypes.data, n_frames))
 
     submit_host = submit
+
+    def ua_fast_fidelity(self, xyz, box):
+        """Per-sample comparison of the GORDER_FLAG_UA_FAST_NORMALISE construction with the reference's arithmetic on the
+        given frames (gorder_oracle_ua_fast_fidelity) -> dict."""
+        xyz = _f32(xyz)
+        n_frames = xyz.shape[0]
+        bp = None
+        if box is not None:
+            box = _f32(box).reshape(n_frames, 9)
+            bp = box.ctypes.data
+        hist = np.zeros(16, dtype=np.uint64)
+        out = np.zeros(5, dtype=np.uint64)
+        self._check(self.lib.gorder_oracle_ua_fast_fidelity(self._h, xyz.ctypes.data, bp, n_frames, hist.ctypes.data, out.ctypes.data))
+        n = int(out[0])
+        return {"samples": n, "tick_difference_histogram": [int(v) for v in hist],
+                "fraction_moved": float(1.0 - hist[0] / max(1, n)), "fraction_moved_by_more_than_one_tick": float(hist[2:].sum() / max(1, n)),
+                "mean_shift_ticks": float((int(out[3]) - (1 << 62)) / max(1, n)),
+                "carbons_sent_to_the_literal_loops": int(out[1]), "bond_positions_in_another_ordermap_tile": int(out[2]),
+                "fraction_moved_default_path": float(int(out[4]) / max(1, n))}
 
     def prime_leaflets(self, xyz, box, frame_index):
         xyz = _f32(xyz)

@@ -37,7 +37,7 @@ def test_single_gpu_line(built):
     assert r["whole_step_ms"] <= d["ms_per_step"] * 1.02
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and 1 <= c["cores"] <= c["cores_available"] and c["value"] > 0 and "sample" in c
-    assert c["parallel_efficiency"] > 0.3                       # threads that are not starved (round 3: 0.26 on 64 threads)
+    assert c["parallel_efficiency"] > 0.5 and len(c["scaling"]) >= 2    # the best row of the measured scaling table (round 3: 0.26 on 64 threads)
     e = d["end_to_end"]
     assert e["decoded_on"] == "device" and e["host_decode"]["decoded_on"] == "host"
     assert e["value"] > e["host_decode"]["value"] > 0

@@ -13,6 +13,8 @@ run cg3k 4000 100 60
 run cg3k-local 512 10 4
 run ua256 3000 50 40
 run ua256-maps 3000 50 30
+run ua256-fast 3000 50 40
+run ua256-maps-fast 3000 50 30
 run cg1m 500 40 30
 # the options no BASELINE config uses (timewise rows)
 run aa256-timewise 3000 50 40
@@ -25,5 +27,5 @@ import json
 for line in open("$OUT"):
     d = json.loads(line)
     r = d["roofline"]
-    print(f'{d["config"]["workload"][:70]:70s} {d["value"]/1e6:9.3f} Mframes/s  kernel {r["avg_launch_ms"]:8.3f} ms/launch  {r["frac"]*100:5.1f}% HBM')
+    print(f'{d["config"]["workload"][:70]:70s} {d["value"]/1e6:9.3f} Mframes/s  step {r["whole_step_ms"]:8.3f} ms = {r["whole_step_frac"]*100:5.1f}% HBM; longest: {r["kernel"]} {r["avg_launch_ms"]:8.3f} ms {r["frac"]*100:5.1f}%')
 PY
