@@ -779,7 +779,13 @@ __device__ __forceinline__ UaBonds ua_carbon_pairs(uint32_t kind, UaCarbon c, Ua
 //  * the hydrogen is target + dir * (rsqrt * 0.109) by one fma per component;
 //  * minimum image and wrap are d - L * rint(d / L) and x - L * floor(x / L) with 1 / L from k_inv_box: for shifts of
 //    at most one box length the same values as the reference's loops except AT the boundaries (|d| = L / 2, x = L) and
-//    where d / L rounds across one; more than one box length (|k| > 1) goes to the literal-loop evaluation like before.
+//    where d / L rounds across one; more than one box length (|k| > 1) goes to the literal-loop evaluation like before;
+//  * rotations by Rodrigues' formula, v c + (u x v) s [+ u (u.v)(1 - c)], instead of nalgebra's rotation matrix — the
+//    axis is perpendicular to the rotated vector by construction in all but the second methyl rotation;
+//  * the C -> H vector is taken from the hydrogen BEFORE it is wrapped, (target + dir r) - target, not as the minimum
+//    image of the wrapped hydrogen (the same vector; the reference's form loses the last bits of it when the hydrogen
+//    lands across a box face), and the wrapped hydrogen — consumed only through the bond position of ordermaps and
+//    geometry selections — is not computed at all when neither is on (POS = false).
 // What it costs in fidelity is measured, not assumed: tools/ua_fast_fidelity.py (fraction of samples that move by a tick
 // against the libm oracle, fraction of bond positions that change ordermap tile) -> profiles/r04_ua_fast_fidelity.json.
 __device__ __forceinline__ float ua_fast_rsqrt(float x) {
@@ -816,13 +822,34 @@ struct PbcFast {
         return ua_fast_rsqrt(s2);
     }
     __device__ __forceinline__ V3 unit(V3 a) { const float r = rnorm(a); return {a.x * r, a.y * r, a.z * r}; }
-    // target + dir / |dir| * BOND_LENGTH, wrapped
-    __device__ __forceinline__ V3 shift_wrap(V3 t, V3 dir) {
+    // target + dir / |dir| * BOND_LENGTH, NOT wrapped
+    __device__ __forceinline__ V3 shift(V3 t, V3 dir) {
         const float r = rnorm(dir) * 0.109f;
-        return {wr1(__builtin_fmaf(dir.x, r, t.x), box.x, inv.x), wr1(__builtin_fmaf(dir.y, r, t.y), box.y, inv.y),
-                wr1(__builtin_fmaf(dir.z, r, t.z), box.z, inv.z)};
+        return {__builtin_fmaf(dir.x, r, t.x), __builtin_fmaf(dir.y, r, t.y), __builtin_fmaf(dir.z, r, t.z)};
     }
+    __device__ __forceinline__ V3 wrap(V3 h) { return {wr1(h.x, box.x, inv.x), wr1(h.y, box.y, inv.y), wr1(h.z, box.z, inv.z)}; }
 };
+// v rotated about the unit axis u perpendicular to it: v c + (u x v) s
+__device__ __forceinline__ V3 v3_rotate_perp(V3 u, float s, float c, V3 v) {
+    const V3 w = v3_cross(u, v);
+    return {__builtin_fmaf(w.x, s, v.x * c), __builtin_fmaf(w.y, s, v.y * c), __builtin_fmaf(w.z, s, v.z * c)};
+}
+// ... by +angle (lane 0) and -angle (lane 1)
+__device__ __forceinline__ V3P v3p_rotate_perp_pm(V3 u, float s, float c, V3 v) {
+    const V3 w = v3_cross(u, v);
+    const f2 sv = f2{s, -s};
+    return {f2_fma(f2_splat(w.x), sv, f2_splat(v.x * c)), f2_fma(f2_splat(w.y), sv, f2_splat(v.y * c)),
+            f2_fma(f2_splat(w.z), sv, f2_splat(v.z * c))};
+}
+// ... about any unit axis: v c + (u x v) s + u (u.v)(1 - c)
+__device__ __forceinline__ V3P v3p_rotate_rod_pm(V3 u, float s, float c, V3 v) {
+    const V3 w = v3_cross(u, v);
+    const float k = __builtin_fmaf(u.z, v.z, __builtin_fmaf(u.y, v.y, u.x * v.x)) * (1.0f - c);
+    const f2 sv = f2{s, -s};
+    return {f2_fma(f2_splat(u.x), f2_splat(k), f2_fma(f2_splat(w.x), sv, f2_splat(v.x * c))),
+            f2_fma(f2_splat(u.y), f2_splat(k), f2_fma(f2_splat(w.y), sv, f2_splat(v.y * c))),
+            f2_fma(f2_splat(u.z), f2_splat(k), f2_fma(f2_splat(w.z), sv, f2_splat(v.z * c)))};
+}
 struct PbcFast2 {       // PbcFast on pairs
     V3 box, inv;
     bool pbc;
@@ -861,43 +888,49 @@ struct PbcFast2 {       // PbcFast on pairs
         return y;
     }
     __device__ __forceinline__ V3P unit(V3P a) { const f2 r = rnorm(a); return {a.x * r, a.y * r, a.z * r}; }
-    __device__ __forceinline__ V3P shift_wrap(V3 t, V3P dir) {
+    __device__ __forceinline__ V3P shift(V3 t, V3P dir) {
         const f2 r = rnorm(dir) * 0.109f;
-        return {wr1(f2_fma(dir.x, r, f2_splat(t.x)), box.x, inv.x), wr1(f2_fma(dir.y, r, f2_splat(t.y)), box.y, inv.y),
-                wr1(f2_fma(dir.z, r, f2_splat(t.z)), box.z, inv.z)};
+        return {f2_fma(dir.x, r, f2_splat(t.x)), f2_fma(dir.y, r, f2_splat(t.y)), f2_fma(dir.z, r, f2_splat(t.z))};
     }
+    __device__ __forceinline__ V3P wrap(V3P h) { return {wr1(h.x, box.x, inv.x), wr1(h.y, box.y, inv.y), wr1(h.z, box.z, inv.z)}; }
 };
-// every kind of carbon with the fast forms; `slow` comes back raised when the literal-loop evaluation is needed instead
-__device__ __forceinline__ UaBonds ua_carbon_fast(uint32_t kind, UaCarbon c, UaConsts e, V3 box, V3 inv, bool pbc, bool &slow) {
+// every kind of carbon with the fast forms; `slow` comes back raised when the literal-loop evaluation is needed instead.
+// POS: the bond positions (hydrogen wrapped into the box + half the bond vector) are consumed — ordermaps, geometry.
+// (need_pos: the same at run time — the general kernel is compiled with POS and asks its arguments)
+template <bool POS>
+__device__ __forceinline__ UaBonds ua_carbon_fast(uint32_t kind, UaCarbon c, UaConsts e, V3 box, V3 inv, bool pbc, bool need_pos, bool &slow) {
     const V3 zero{0.0f, 0.0f, 0.0f};
     PbcFast ps{box, inv, pbc};
     PbcFast2 pp{box, inv, pbc};
     UaBonds r;
     r.v0 = r.v1 = r.v2 = r.b0 = r.b1 = r.b2 = zero;
     r.bad = 0;
+    auto bond = [&](V3 target, V3 hu, V3 &v, V3 &b) {          // C -> H from the unwrapped hydrogen; position = wrapped H + v / 2
+        v = {hu.x - target.x, hu.y - target.y, hu.z - target.z};
+        if (POS && need_pos) { const V3 h = ps.wrap(hu); b = {h.x + v.x / 2.0f, h.y + v.y / 2.0f, h.z + v.z / 2.0f}; }
+    };
     if (kind == GORDER_UA_CH2 || kind == GORDER_UA_CH3) {
         const V3 target = c.p1;
-        V3P h;                                   // CH2: hydrogens 0, 1; CH3: hydrogens 1, 2
+        V3P hu;                                  // CH2: hydrogens 0, 1; CH3: hydrogens 1, 2 (not wrapped)
         if (kind == GORDER_UA_CH2) {            // uaorder.rs:985-1020
             const V3P th = pp.unit(pp.to(target, c.p0, c.p2));
             const V3 th1 = v3p_lane0(th), th2 = v3p_lane1(th);
             const V3 pn = v3_cross(th2, th1);
             const V3 ra = ps.unit(V3{th1.x - th2.x, th1.y - th2.y, th1.z - th2.z});      // (not normalised a second time)
-            const V3 rv = v3_cross(pn, ra);
-            h = pp.shift_wrap(target, v3p_rotate_pm(ra, e.sin_half, e.cos_half, rv));
+            const V3 rv = v3_cross(pn, ra);                                                // perpendicular to ra
+            hu = pp.shift(target, v3p_rotate_perp_pm(ra, e.sin_half, e.cos_half, rv));
         } else {                                // CH3, uaorder.rs:947-981
             const V3P th = pp.to(target, c.p0, c.p2);
             const V3 th1 = v3p_lane0(th), th2 = v3p_lane1(th);
-            const V3 ua = ps.unit(v3_cross(th2, th1));
-            const V3 hv1 = v3_rotate(ua, e.sin_tet, e.cos_tet, th1);
-            const V3 h0 = ps.shift_wrap(target, hv1);
+            const V3 ua = ps.unit(v3_cross(th2, th1));                                     // perpendicular to th1
+            const V3 hv1 = v3_rotate_perp(ua, e.sin_tet, e.cos_tet, th1);
+            bond(target, ps.shift(target, hv1), r.v0, r.b0);
             const V3 n1 = ps.unit(th1);
-            h = pp.shift_wrap(target, v3p_rotate_pm(n1, e.sin_ch3, e.cos_ch3, hv1));
-            r.v0 = ps.to(target, h0);
-            r.b0 = {h0.x + r.v0.x / 2.0f, h0.y + r.v0.y / 2.0f, h0.z + r.v0.z / 2.0f};
+            hu = pp.shift(target, v3p_rotate_rod_pm(n1, e.sin_ch3, e.cos_ch3, hv1));
         }
-        const V3P v = pp.to(target, h);
-        const V3P b = {h.x + v.x / 2.0f, h.y + v.y / 2.0f, h.z + v.z / 2.0f};
+        const V3P v = {hu.x - f2_splat(target.x), hu.y - f2_splat(target.y), hu.z - f2_splat(target.z)};
+        V3P b = {f2_splat(0.0f), f2_splat(0.0f), f2_splat(0.0f)};
+        if (POS && need_pos) { const V3P h = pp.wrap(hu); b = {h.x + v.x / 2.0f, h.y + v.y / 2.0f, h.z + v.z / 2.0f}; }
         if (kind == GORDER_UA_CH2) {
             r.v0 = v3p_lane0(v); r.b0 = v3p_lane0(b);
             r.v1 = v3p_lane1(v); r.b1 = v3p_lane1(b);
@@ -906,7 +939,7 @@ __device__ __forceinline__ UaBonds ua_carbon_fast(uint32_t kind, UaCarbon c, UaC
             r.v2 = v3p_lane1(v); r.b2 = v3p_lane1(b);
         }
     } else {
-        V3 target = c.p1, h0;
+        V3 target = c.p1, hu;
         if (kind == GORDER_UA_CH1_UNSAT) {      // uaorder.rs:1024-1045
             const V3 th1 = ps.to(target, c.p0), th2 = ps.to(target, c.p2);
             const float prod = (th1.x * th2.x + th1.y * th2.y) + th1.z * th2.z;
@@ -919,15 +952,14 @@ __device__ __forceinline__ UaBonds ua_carbon_fast(uint32_t kind, UaCarbon c, UaC
             }
             const float ang = 3.14159265358979323846f - (gamma / 2.0f);
             const float sn = gm_sinf_0pi(ang), cs = gm_cosf(ang);
-            const V3 ua = ps.unit(v3_cross(th1, th2));
-            h0 = ps.shift_wrap(target, ang == 0.0f ? th2 : v3_rotate(ua, sn, cs, th2));
+            const V3 ua = ps.unit(v3_cross(th1, th2));                                     // perpendicular to th2
+            hu = ps.shift(target, ang == 0.0f ? th2 : v3_rotate_perp(ua, sn, cs, th2));
         } else {                                // CH1 saturated, uaorder.rs:1087-1104 (h1, h2, h3, target)
             target = c.p3;
             const V3 t1 = ps.unit(ps.to(target, c.p0)), t2 = ps.unit(ps.to(target, c.p1)), t3 = ps.unit(ps.to(target, c.p2));
-            h0 = ps.shift_wrap(target, V3{-((t1.x + t2.x) + t3.x), -((t1.y + t2.y) + t3.y), -((t1.z + t2.z) + t3.z)});
+            hu = ps.shift(target, V3{-((t1.x + t2.x) + t3.x), -((t1.y + t2.y) + t3.y), -((t1.z + t2.z) + t3.z)});
         }
-        r.v0 = ps.to(target, h0);
-        r.b0 = {h0.x + r.v0.x / 2.0f, h0.y + r.v0.y / 2.0f, h0.z + r.v0.z / 2.0f};
+        bond(target, hu, r.v0, r.b0);
     }
     slow = ps.slow || pp.slow();
     return r;
@@ -951,15 +983,30 @@ __device__ __forceinline__ int ua_wave_sum(int v) {
 
 // MODE 0: order parameters only; 1: + staged ordermap samples, nothing else (no geometry selection, timewise rows or
 // per-molecule normals — the common ordermap run, and a much smaller kernel); 2: every extra; 3: per-frame rows, nothing else
-// FAST: GORDER_FLAG_UA_FAST_NORMALISE (ua_carbon_fast; e.inv_box holds 1 / box edge per frame)
-template <bool ACOS_COS, int MODE, bool FAST = false>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ua_extras(FrameArgs a_in, ExtraArgs e, const float *__restrict__ xyz,
+// FAST: GORDER_FLAG_UA_FAST_NORMALISE (ua_carbon_fast; inv_box holds 1 / box edge per frame).
+// How the atoms arrive (round 4).  Until round 3 every lane gathered its carbon's three or four atoms itself: the lanes of a
+// wave are 64 MOLECULES (one kind of carbon per wave), 624 bytes apart, so every load instruction touched 64 cache lines
+// — 1.6 M wave loads x 64 lines per 3 000-frame launch keep the CUs' L1 busy for about as long as the exact arithmetic keeps
+// the VALU busy (PMC, profiles/r04_pmc_ua256_*), which is why 41 % fewer VALU instructions bought 5 %.  Now the workgroup
+// stages the atoms its tile NEEDS (plan.h: the sorted list of distinct atoms the tile's carbons touch, ~6 per molecule) for
+// one frame in LDS with coalesced loads — thread t fetches dword t, t + 256, ... of the list; the runs of neighbouring atoms
+// of a molecule are contiguous in the frame —, the next frame's loads in flight during this frame's arithmetic, two
+// buffers, one barrier per frame; a lane then reads its atoms from LDS by their positions in the list (UaPos).
+// The body is shared by k_ua_extras (the exact path) and k_ua_extras_fast.
+constexpr uint32_t kUaStageRegs = 6;      // dwords of the need list a thread keeps in flight (6 x 256 dwords = 512 atoms)
+template <bool ACOS_COS, int MODE, bool FAST>
+__device__ __forceinline__ void ua_extras_body(FrameArgs a_in, ExtraArgs e, const float *__restrict__ xyz,
                                                        const float *__restrict__ box9,
                                                        const uint8_t *__restrict__ aflags,
                                                        const uint32_t *__restrict__ arow,
                                                        const Tile *__restrict__ tiles,
                                                        const gorder::UaItem *__restrict__ items,
-                                                       const uint32_t *__restrict__ tile_slots, uint32_t n_tiles) {
+                                                       const uint32_t *__restrict__ tile_slots, uint32_t n_tiles,
+                                                       const float *__restrict__ inv_box,
+                                                       const uint32_t *__restrict__ need_begin,
+                                                       const uint16_t *__restrict__ need,
+                                                       const gorder::UaPos *__restrict__ pos, uint32_t stage_dw) {
+    extern __shared__ float l_stage[];     // [2][stage_dw]: the tile's needed atoms of two consecutive frames
     constexpr bool EXTRAS = MODE != 0, GENERAL = MODE >= 2, FULL = MODE == 2, MAPS_POSSIBLE = MODE == 1 || MODE == 2;
     constexpr uint32_t LS = 3 * kBlock;   // local slots per block (<= 3 hydrogens per carbon)
     __shared__ unsigned long long l_s[2 * LS];
@@ -1015,22 +1062,46 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         rec_n = run & 0xffffu;
         rec_row = e.map_rec + ((size_t)tile_id * 3u * kBlock + tid0) * e.rec_stride + (tid - tid0);
     }
-    const float *src[4];
+    // ---- staging: dword j of the tile's need list lives at frame + (atom0 + need[j / 3]) * 3 + j % 3
+    const uint32_t need0 = need_begin[tile_id], n_dw = 3u * (need_begin[tile_id + 1] - need0);
+    const float *tile_src = xyz + (size_t)t.atom0 * 3u;
+    uint32_t soff[kUaStageRegs];          // this thread's dwords of the list: source offsets (0xffffffff: none)
 #pragma unroll
-    for (int q = 0; q < 4; q++) src[q] = xyz + ((size_t)t.atom0 + (active ? it.l[q] : 0u)) * 3u;
-    auto fetch = [&](uint32_t f) {
-        UaCarbon c;
-        const size_t o = (size_t)f * fstride;
-        c.p0 = {src[0][o], src[0][o + 1], src[0][o + 2]};
-        c.p1 = {src[1][o], src[1][o + 1], src[1][o + 2]};
-        c.p2 = {src[2][o], src[2][o + 1], src[2][o + 2]};
-        c.p3 = {src[3][o], src[3][o + 1], src[3][o + 2]};
-        return c;
+    for (uint32_t k = 0; k < kUaStageRegs; k++) {
+        const uint32_t j = tid + k * kBlock;
+        soff[k] = j < n_dw ? (uint32_t)need[need0 + j / 3u] * 3u + j % 3u : 0xffffffffu;
+    }
+    float sv[kUaStageRegs];
+    auto stage_load = [&](uint32_t f) {
+        const float *fs = tile_src + (size_t)f * fstride;
+#pragma unroll
+        for (uint32_t k = 0; k < kUaStageRegs; k++) sv[k] = soff[k] != 0xffffffffu ? fs[soff[k]] : 0.0f;
     };
+    auto stage_store = [&](uint32_t f, uint32_t buf) {
+        float *lb = l_stage + buf * stage_dw;
+#pragma unroll
+        for (uint32_t k = 0; k < kUaStageRegs; k++)
+            if (soff[k] != 0xffffffffu) lb[tid + k * kBlock] = sv[k];
+        // (a need list of more than 512 atoms — carbons picked far apart in long molecules: its tail is copied in place)
+        const float *fs = tile_src + (size_t)f * fstride;
+        for (uint32_t j = tid + kUaStageRegs * kBlock; j < n_dw; j += kBlock) lb[j] = fs[(uint32_t)need[need0 + j / 3u] * 3u + j % 3u];
+    };
+    gorder::UaPos ip{};
+    if (active) ip = pos[t.item0 + tid];
+    if (f_begin < f_end) { stage_load(f_begin); stage_store(f_begin, 0u); }
+    __syncthreads();
     for (uint32_t f = f_begin; f < f_end; f++) {
         int tw_s[3] = {0, 0, 0}, tw_sl[3] = {0, 0, 0}, tw_n[3] = {0, 0, 0};      // tw_waves: this lane's ticks, lower-leaflet ticks, counts (all | lower << 16)
+        const uint32_t buf = (f - f_begin) & 1u;
+        const bool more = f + 1 < f_end;               // (uniform)
+        if (more) stage_load(f + 1);                   // in flight during this frame's arithmetic
         if (active) {
-            const UaCarbon c = fetch(f);
+            const float *lb = l_stage + buf * stage_dw;
+            UaCarbon c;
+            c.p0 = {lb[3u * ip.p[0]], lb[3u * ip.p[0] + 1u], lb[3u * ip.p[0] + 2u]};
+            c.p1 = {lb[3u * ip.p[1]], lb[3u * ip.p[1] + 1u], lb[3u * ip.p[1] + 2u]};
+            c.p2 = {lb[3u * ip.p[2]], lb[3u * ip.p[2] + 1u], lb[3u * ip.p[2] + 2u]};
+            c.p3 = {lb[3u * ip.p[3]], lb[3u * ip.p[3] + 1u], lb[3u * ip.p[3] + 2u]};
             V3 bx3{1.0f, 1.0f, 1.0f};
             if (pbc) { const float *b = a.box9 + 9 * (size_t)f; bx3 = {b[0], b[4], b[8]}; }
             // the atoms are checked in index order (uaorder.rs:400-437 via get_position of each helper); the smallest key wins
@@ -1042,8 +1113,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             UaBonds ub;
             if (FAST) {
                 V3 inv3{1.0f, 1.0f, 1.0f};
-                if (pbc) { const float *ib = e.inv_box + 3 * (size_t)f; inv3 = {ib[0], ib[1], ib[2]}; }
-                ub = ua_carbon_fast(kind, c, uc, bx3, inv3, pbc, slow);
+                if (pbc) { const float *ib = inv_box + 3 * (size_t)f; inv3 = {ib[0], ib[1], ib[2]}; }
+                ub = ua_carbon_fast<MAPS_POSSIBLE>(kind, c, uc, bx3, inv3, pbc, e.maps != 0 || e.geom_kind != 0, slow);
             } else if (kind == GORDER_UA_CH2 || kind == GORDER_UA_CH3) {       // the two common kinds: paired arithmetic
                 ub = ua_carbon_pairs(kind, c, uc, bx3, pbc, slow);
             } else {
@@ -1136,6 +1207,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             extras_flush_tw(a, e, tile_slots + t.slot0, t.n_slots, f, l_tw, l_twn, LS);
             __syncthreads();
         }
+        if (more) stage_store(f + 1, buf ^ 1u);
+        __syncthreads();        // frame f + 1 is in its buffer, and nobody reads frame f any more (its buffer is written next)
     }
     if (bad) raise_box_range(a.err, f_begin);
     if (active) {
@@ -1163,6 +1236,25 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         }
     }
 }
+
+#define GORDER_UA_KERNEL_ARGS                                                                                              \
+    FrameArgs a_in, ExtraArgs e, const float *__restrict__ xyz, const float *__restrict__ box9,                               \
+        const uint8_t *__restrict__ aflags, const uint32_t *__restrict__ arow, const Tile *__restrict__ tiles,                \
+        const gorder::UaItem *__restrict__ items, const uint32_t *__restrict__ tile_slots, uint32_t n_tiles,                  \
+        const float *__restrict__ inv_box, const uint32_t *__restrict__ need_begin, const uint16_t *__restrict__ need,        \
+        const gorder::UaPos *__restrict__ pos, uint32_t stage_dw
+template <bool ACOS_COS, int MODE>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ua_extras(GORDER_UA_KERNEL_ARGS) {
+    ua_extras_body<ACOS_COS, MODE, false>(a_in, e, xyz, box9, aflags, arow, tiles, items, tile_slots, n_tiles, inv_box, need_begin,
+                                          need, pos, stage_dw);
+}
+// GORDER_FLAG_UA_FAST_NORMALISE (the default cosine only)
+template <int MODE>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ua_extras_fast(GORDER_UA_KERNEL_ARGS) {
+    ua_extras_body<false, MODE, true>(a_in, e, xyz, box9, aflags, arow, tiles, items, tile_slots, n_tiles, inv_box, need_begin,
+                                      need, pos, stage_dw);
+}
+#undef GORDER_UA_KERNEL_ARGS
 
 // ---- ordermaps, second step ------------------------------------------------------------------------
 // The sample kernels stage every sample as five bytes (tick, plane-tile: ExtraArgs::map_rec), run by run; here a block

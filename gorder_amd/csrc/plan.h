@@ -45,6 +45,10 @@ struct UaItem {          // one united-atom carbon instance (uaorder.rs:911-915,
     uint32_t mol;
 };
 
+struct UaPos {           // the same carbon's atoms as positions in its tile's need list (Plan::ua_need): what the kernel reads from LDS
+    uint16_t p[4];
+};
+
 struct MapRun {          // `n` consecutive threads of a united-atom tile (from tid0) are the molecules of ONE slot:
     uint32_t tile, tid0, n, k;   // their hydrogen k.  Lets k_map_accumulate read a slot's staged samples in runs.
 };
@@ -61,6 +65,13 @@ struct Plan {
     std::vector<Tile> ua_tiles;
     std::vector<UaItem> ua_items;
     std::vector<uint32_t> ua_tile_slots;
+    // per tile the sorted list of the DISTINCT atoms its carbons touch (window-relative, ~6 per molecule): the workgroup
+    // stages exactly these per frame (coalesced where they are neighbours in the frame), ua_pos holds every item's atoms
+    // as positions in that list
+    std::vector<uint16_t> ua_need;
+    std::vector<uint32_t> ua_need_begin;    // [n_ua_tiles + 1]
+    std::vector<UaPos> ua_pos;              // parallel to ua_items
+    uint32_t ua_max_need = 0;
     std::vector<MapRun> ua_runs;            // grouped by accumulator slot:
     std::vector<uint32_t> ua_run_begin;     // [n_acc + 1] (CSR)
     // the same for bond tiles: `items_by_slot` = every tile's items re-ordered so that the molecules of one slot
@@ -227,6 +238,22 @@ inline int build_plan(const gorder_tables_t &t, bool force_direct, Plan &p) {
             }
             tile.n_window = top - tile.atom0 + 1;
             tile.n_slots = (uint32_t)slots.size();
+            {   // the tile's need list and the items' positions in it
+                std::vector<uint16_t> nl;
+                for (uint32_t i = 0; i < tile.n_items; i++)
+                    for (int c = 0; c < 4; c++) nl.push_back(p.ua_items[tile.item0 + i].l[c]);
+                std::sort(nl.begin(), nl.end());
+                nl.erase(std::unique(nl.begin(), nl.end()), nl.end());
+                if (p.ua_need_begin.empty()) p.ua_need_begin.push_back(0);
+                p.ua_pos.resize((size_t)tile.item0 + tile.n_items);
+                for (uint32_t i = 0; i < tile.n_items; i++)
+                    for (int c = 0; c < 4; c++)
+                        p.ua_pos[tile.item0 + i].p[c] =
+                            (uint16_t)(std::lower_bound(nl.begin(), nl.end(), p.ua_items[tile.item0 + i].l[c]) - nl.begin());
+                p.ua_need.insert(p.ua_need.end(), nl.begin(), nl.end());
+                p.ua_need_begin.push_back((uint32_t)p.ua_need.size());
+                p.ua_max_need = std::max(p.ua_max_need, (uint32_t)nl.size());
+            }
             const uint32_t tile_id = (uint32_t)p.ua_tiles.size();
             for (uint32_t i = 0; i < tile.n_items;) {   // the lanes of one slot: a MapRun per hydrogen
                 const UaItem &it = p.ua_items[tile.item0 + i];
@@ -433,6 +460,20 @@ inline int selfcheck_plan(const gorder_tables_t &t, const Plan &p) {
                 }
             }
         if (lanes != want_lanes) return 15;
+        // the need lists: sorted, distinct, inside the window, and every item's positions name its own atoms
+        if (p.ua_need_begin.size() != p.ua_tiles.size() + 1 || p.ua_pos.size() != p.ua_items.size()) return 18;
+        for (size_t ti = 0; ti < p.ua_tiles.size(); ti++) {
+            const Tile &tile = p.ua_tiles[ti];
+            const uint32_t b = p.ua_need_begin[ti], n = p.ua_need_begin[ti + 1] - b;
+            if (n == 0 || n > 4u * tile.n_items || n > p.ua_max_need) return 19;
+            for (uint32_t k = 0; k < n; k++)
+                if (p.ua_need[b + k] >= tile.n_window || (k && p.ua_need[b + k] <= p.ua_need[b + k - 1])) return 20;
+            for (uint32_t i = 0; i < tile.n_items; i++)
+                for (int c = 0; c < 4; c++) {
+                    const uint16_t q = p.ua_pos[tile.item0 + i].p[c];
+                    if (q >= n || p.ua_need[b + q] != p.ua_items[tile.item0 + i].l[c]) return 21;
+                }
+        }
     }
     return 0;
 }

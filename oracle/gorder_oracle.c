@@ -399,7 +399,22 @@ static inline float fast_rsqrt(float x) {
     y = y * fmaf(-(hx * y), y, 1.5f);
     return y;
 }
-typedef struct { const float *box; float inv[3]; int pbc; int slow; } fast_ctx;
+typedef struct { const float *box; float inv[3]; int pbc; int slow; int need_pos; float hu[3]; } fast_ctx;
+/* Rotations by Rodrigues' formula with given sine and cosine (the constants of the construction are evaluated once on
+ * the host with libm — sinf / cosf of the same literals — exactly as the device's ExtraArgs carries them), not by
+ * nalgebra's rotation matrix.  v rotated about the unit axis u PERPENDICULAR to it: v c + (u x v) s */
+static void rotate_perp(const float *u, float s, float c, const float *v, float *o) {
+    float w[3];
+    cross3(u, v, w);
+    for (int d = 0; d < 3; d++) o[d] = fmaf(w[d], s, v[d] * c);
+}
+/* general Rodrigues: v c + (u x v) s + u (u.v)(1 - c) */
+static void rotate_rod(const float *u, float s, float c, const float *v, float *o) {
+    float w[3];
+    cross3(u, v, w);
+    const float k = fmaf(u[2], v[2], fmaf(u[1], v[1], u[0] * v[0])) * (1.0f - c);
+    for (int d = 0; d < 3; d++) o[d] = fmaf(u[d], k, fmaf(w[d], s, v[d] * c));
+}
 static inline float fast_mi(fast_ctx *c, float d, int k) {
     if (!c->pbc) return d;
     const float q = rintf(d * c->inv[k]);
@@ -426,42 +441,36 @@ static inline void fast_unit(fast_ctx *c, const float *a, float *o) {
 }
 static inline void fast_shift_wrap(fast_ctx *c, const float *t, const float *dir, float *h) {
     const float r = fast_rnorm(c, dir) * BOND_LENGTH;
-    for (int d = 0; d < 3; d++) h[d] = fast_wr(c, fmaf(dir[d], r, t[d]), d);
-}
-/* Rotation3::from_axis_angle with given sine and cosine (the constants of the construction are evaluated once on the
- * host with libm — sinf / cosf of the same literals — exactly as the device's ExtraArgs carries them) */
-static void rotate_sc(const float *u, float s, float c, const float *v, float *o) {
-    const float ux = u[0], uy = u[1], uz = u[2];
-    const float sqx = ux * ux, sqy = uy * uy, sqz = uz * uz, omc = 1.0f - c;
-    const float m11 = sqx + (1.0f - sqx) * c, m12 = ux * uy * omc - uz * s, m13 = ux * uz * omc + uy * s;
-    const float m21 = ux * uy * omc + uz * s, m22 = sqy + (1.0f - sqy) * c, m23 = uy * uz * omc - ux * s;
-    const float m31 = ux * uz * omc - uy * s, m32 = uy * uz * omc + ux * s, m33 = sqz + (1.0f - sqz) * c;
-    o[0] = (m11 * v[0] + m12 * v[1]) + m13 * v[2];
-    o[1] = (m21 * v[0] + m22 * v[1]) + m23 * v[2];
-    o[2] = (m31 * v[0] + m32 * v[1]) + m33 * v[2];
+    for (int d = 0; d < 3; d++) {
+        c->hu[d] = fmaf(dir[d], r, t[d]);
+        /* the wrapped hydrogen is only consumed through the bond position (ordermaps, geometry selection): a run
+         * without them neither wraps nor looks at how many box lengths a wrap would take */
+        h[d] = c->need_pos ? fast_wr(c, c->hu[d], d) : c->hu[d];
+    }
 }
 /* -> number of hydrogens, their positions and the vectors target -> H; *slow = 1: the device re-evaluates this carbon
  * with the reference's literal loops (predict_hydrogens_mode + vector_to), and so must the caller */
-static int predict_hydrogens_fast(uint32_t kind, const float pos[4][3], const float box[3], int pbc,
+static int predict_hydrogens_fast(uint32_t kind, const float pos[4][3], const float box[3], int pbc, int need_pos,
                                   float out[3][3], float vec[3][3], int *slow) {
     fast_ctx c;
-    c.box = box; c.pbc = pbc; c.slow = 0;
+    c.box = box; c.pbc = pbc; c.slow = 0; c.need_pos = need_pos;
     for (int d = 0; d < 3; d++) c.inv[d] = pbc ? 1.0f / box[d] : 1.0f;      /* k_inv_box */
     const float *t = kind == GORDER_UA_CH1_SAT ? pos[3] : pos[1];
     int nh;
+    float hus[3][3];
     if (kind == GORDER_UA_CH3) {
         float th1[3], th2[3], axis[3], ua[3], hv1[3], n1[3], hv[3];
         fast_to(&c, t, pos[0], th1);
         fast_to(&c, t, pos[2], th2);
         cross3(th2, th1, axis);
         fast_unit(&c, axis, ua);
-        rotate_sc(ua, sinf(TETRAHEDRAL_ANGLE), cosf(TETRAHEDRAL_ANGLE), th1, hv1);
-        fast_shift_wrap(&c, t, hv1, out[0]);
+        rotate_perp(ua, sinf(TETRAHEDRAL_ANGLE), cosf(TETRAHEDRAL_ANGLE), th1, hv1);   /* ua _|_ th1 */
+        fast_shift_wrap(&c, t, hv1, out[0]); memcpy(hus[0], c.hu, sizeof(c.hu));
         fast_unit(&c, th1, n1);
-        rotate_sc(n1, sinf(CH3_ANGLE), cosf(CH3_ANGLE), hv1, hv);
-        fast_shift_wrap(&c, t, hv, out[1]);
-        rotate_sc(n1, -sinf(CH3_ANGLE), cosf(CH3_ANGLE), hv1, hv);
-        fast_shift_wrap(&c, t, hv, out[2]);
+        rotate_rod(n1, sinf(CH3_ANGLE), cosf(CH3_ANGLE), hv1, hv);
+        fast_shift_wrap(&c, t, hv, out[1]); memcpy(hus[1], c.hu, sizeof(c.hu));
+        rotate_rod(n1, -sinf(CH3_ANGLE), cosf(CH3_ANGLE), hv1, hv);
+        fast_shift_wrap(&c, t, hv, out[2]); memcpy(hus[2], c.hu, sizeof(c.hu));
         nh = 3;
     } else if (kind == GORDER_UA_CH2) {
         float a[3], b[3], th1[3], th2[3], pn[3], diff[3], ra[3], rv[3], hv[3];
@@ -473,10 +482,10 @@ static int predict_hydrogens_fast(uint32_t kind, const float pos[4][3], const fl
         for (int d = 0; d < 3; d++) diff[d] = th1[d] - th2[d];
         fast_unit(&c, diff, ra);                 /* (the unit axis is not normalised a second time) */
         cross3(pn, ra, rv);
-        rotate_sc(ra, sinf(TETRAHEDRAL_ANGLE_HALF), cosf(TETRAHEDRAL_ANGLE_HALF), rv, hv);
-        fast_shift_wrap(&c, t, hv, out[0]);
-        rotate_sc(ra, -sinf(TETRAHEDRAL_ANGLE_HALF), cosf(TETRAHEDRAL_ANGLE_HALF), rv, hv);
-        fast_shift_wrap(&c, t, hv, out[1]);
+        rotate_perp(ra, sinf(TETRAHEDRAL_ANGLE_HALF), cosf(TETRAHEDRAL_ANGLE_HALF), rv, hv);   /* ra _|_ rv */
+        fast_shift_wrap(&c, t, hv, out[0]); memcpy(hus[0], c.hu, sizeof(c.hu));
+        rotate_perp(ra, -sinf(TETRAHEDRAL_ANGLE_HALF), cosf(TETRAHEDRAL_ANGLE_HALF), rv, hv);
+        fast_shift_wrap(&c, t, hv, out[1]); memcpy(hus[1], c.hu, sizeof(c.hu));
         nh = 2;
     } else if (kind == GORDER_UA_CH1_UNSAT) {
         float th1[3], th2[3], axis[3], ua[3], hv[3];
@@ -487,8 +496,8 @@ static int predict_hydrogens_fast(uint32_t kind, const float pos[4][3], const fl
         cross3(th1, th2, axis);
         fast_unit(&c, axis, ua);
         if (ang == 0.0f) { hv[0] = th2[0]; hv[1] = th2[1]; hv[2] = th2[2]; }
-        else rotate_sc(ua, gorder_oracle_mirror_sinf(ang), gorder_oracle_mirror_cosf(ang), th2, hv);
-        fast_shift_wrap(&c, t, hv, out[0]);
+        else rotate_perp(ua, gorder_oracle_mirror_sinf(ang), gorder_oracle_mirror_cosf(ang), th2, hv);   /* ua _|_ th2 */
+        fast_shift_wrap(&c, t, hv, out[0]); memcpy(hus[0], c.hu, sizeof(c.hu));
         nh = 1;
     } else if (kind == GORDER_UA_CH1_SAT) {
         float a[3], th1[3], th2[3], th3[3], hv[3];
@@ -496,18 +505,20 @@ static int predict_hydrogens_fast(uint32_t kind, const float pos[4][3], const fl
         fast_to(&c, t, pos[1], a); fast_unit(&c, a, th2);
         fast_to(&c, t, pos[2], a); fast_unit(&c, a, th3);
         for (int d = 0; d < 3; d++) hv[d] = -((th1[d] + th2[d]) + th3[d]);
-        fast_shift_wrap(&c, t, hv, out[0]);
+        fast_shift_wrap(&c, t, hv, out[0]); memcpy(hus[0], c.hu, sizeof(c.hu));
         nh = 1;
     } else {
         return -2;
     }
-    for (int k = 0; k < nh; k++) fast_to(&c, t, out[k], vec[k]);
+    for (int k = 0; k < nh; k++) {
+        for (int d = 0; d < 3; d++) vec[k][d] = hus[k][d] - t[d];      /* from the hydrogen before it is wrapped */
+    }
     *slow = c.slow;
     return nh;
 }
 int gorder_oracle_predict_hydrogens_fast(uint32_t kind, const float pos[4][3], const float box[3], int pbc,
                                          float out[3][3], float vec[3][3], int *slow) {
-    return predict_hydrogens_fast(kind, pos, box, pbc, out, vec, slow);
+    return predict_hydrogens_fast(kind, pos, box, pbc, 1, out, vec, slow);
 }
 
 int gorder_oracle_predict_hydrogens(uint32_t kind, const float pos[4][3], const float box[3],
@@ -1095,7 +1106,7 @@ static int analyze_frame_orders(const gorder_oracle_handle *h, o_acc *a, int64_t
                 int nh = -1, fast_ok = 0;
                 if (h->ua_fast) {   /* the device's fast construction; a carbon it flags takes the literal path below */
                     int slow = 0;
-                    nh = predict_hydrogens_fast(kind, pos, box, h->pbc, hy, hv, &slow);
+                    nh = predict_hydrogens_fast(kind, pos, box, h->pbc, h->om.enabled || geom, hy, hv, &slow);
                     fast_ok = nh > 0 && !slow;
                 }
                 if (!fast_ok) nh = predict_hydrogens_mode(kind, pos, box, h->pbc, h->trig, hy);
@@ -1150,7 +1161,7 @@ int gorder_oracle_ua_fast_fidelity(const gorder_oracle_handle *h, const float *x
                     int slow = 0;
                     const int nh = predict_hydrogens_mode(kind, pos, box, h->pbc, GORDER_ORACLE_TRIG_LIBM, hy_ref);
                     const int nh_d = predict_hydrogens_mode(kind, pos, box, h->pbc, GORDER_ORACLE_TRIG_DIRECT, hy_def);
-                    const int nh_f = predict_hydrogens_fast(kind, pos, box, h->pbc, hy_fast, v_fast, &slow);
+                    const int nh_f = predict_hydrogens_fast(kind, pos, box, h->pbc, 1, hy_fast, v_fast, &slow);
                     if (nh < 0 || nh_f != nh || nh_d != nh) continue;
                     if (slow) out[1]++;
                     for (int k = 0; k < nh; k++) {
