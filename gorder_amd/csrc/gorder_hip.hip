@@ -69,9 +69,6 @@ struct gorder_hip_handle {
     DirectItem *d_direct = nullptr;
     Tile *d_ua_tiles = nullptr;
     gorder::UaItem *d_ua_items = nullptr;
-    uint32_t *d_ua_need_begin = nullptr;       // the tiles' need lists (plan.h) and the items' positions in them
-    uint16_t *d_ua_need = nullptr;
-    gorder::UaPos *d_ua_pos = nullptr;
     uint32_t *d_ua_tile_slots = nullptr;
     // ordermaps [3][n_acc][nx*ny] and timewise rows [cap][3][n_acc]
     uint32_t map_nx = 0, map_ny = 0;
@@ -624,19 +621,14 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
 #undef GORDER_LAUNCH_TM_A
 #undef GORDER_LAUNCH_BONDS
                 } else {
-                    // dynamic LDS: the tile's needed atoms of two frames (k_ua_extras: staging)
-                    const uint32_t stage_dw = 3u * p.ua_max_need;
-                    const size_t stage_bytes = 2u * (size_t)stage_dw * sizeof(float);
 #define GORDER_LAUNCH_UA(AC, MODE)                                                                                \
     do {                                                                                                            \
         if (!AC && ua_fast)                                                                                         \
-            hipLaunchKernelGGL((k_ua_extras_fast<MODE>), g, blk, stage_bytes, h->stream, b, e, b.xyz, b.box9, b.aflags, \
-                               b.arow, h->d_ua_tiles, h->d_ua_items, h->d_ua_tile_slots, nt, (const float *)e.inv_box, \
-                               h->d_ua_need_begin, h->d_ua_need, h->d_ua_pos, stage_dw);                           \
+            hipLaunchKernelGGL((k_ua_extras_fast<MODE>), g, blk, 0, h->stream, b, e, b.xyz, b.box9, b.aflags,      \
+                               b.arow, h->d_ua_tiles, h->d_ua_items, h->d_ua_tile_slots, nt, (const float *)e.inv_box); \
         else                                                                                                        \
-            hipLaunchKernelGGL((k_ua_extras<AC, MODE>), g, blk, stage_bytes, h->stream, b, e, b.xyz, b.box9, b.aflags, \
-                               b.arow, h->d_ua_tiles, h->d_ua_items, h->d_ua_tile_slots, nt, (const float *)nullptr, \
-                               h->d_ua_need_begin, h->d_ua_need, h->d_ua_pos, stage_dw);                           \
+            hipLaunchKernelGGL((k_ua_extras<AC, MODE>), g, blk, 0, h->stream, b, e, b.xyz, b.box9, b.aflags,        \
+                               b.arow, h->d_ua_tiles, h->d_ua_items, h->d_ua_tile_slots, nt, (const float *)nullptr); \
     } while (0)
                     // staged ordermap samples and nothing else: the lean kernel
                     const bool maps_only = extras && staged && !e.tw && !e.geom_kind && !e.dyn;
@@ -873,7 +865,7 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
     HIP_TRY(h, hipSetDevice(h->device));
     if ((t->flags & GORDER_FLAG_UA_FAST_NORMALISE) && (t->flags & GORDER_FLAG_TRIG_ACOS_COS))
         return fail(h, GORDER_ERR_INVALID_ARGUMENT, "GORDER_FLAG_UA_FAST_NORMALISE (tolerance-bounded) and GORDER_FLAG_TRIG_ACOS_COS (literal) exclude each other");
-    int st = gorder::build_plan(*t, env_flag("GORDER_HIP_FORCE_DIRECT"), h->plan);
+    int st = gorder::build_plan(*t, env_flag("GORDER_HIP_FORCE_DIRECT"), h->plan, !env_flag("GORDER_HIP_UA_SLOT_WAVES"));
     if (st != GORDER_OK) return fail(h, st, "invalid bond tables");
     const Plan &p = h->plan;
     for (uint32_t m = 0; m < t->n_molecule_types; m++)
@@ -886,9 +878,6 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
     if ((st = upload(h, &h->d_direct, p.direct)) != GORDER_OK) return st;
     if ((st = upload(h, &h->d_ua_tiles, p.ua_tiles)) != GORDER_OK) return st;
     if ((st = upload(h, &h->d_ua_items, p.ua_items)) != GORDER_OK) return st;
-    if ((st = upload(h, &h->d_ua_need_begin, p.ua_need_begin)) != GORDER_OK) return st;
-    if ((st = upload(h, &h->d_ua_need, p.ua_need)) != GORDER_OK) return st;
-    if ((st = upload(h, &h->d_ua_pos, p.ua_pos)) != GORDER_OK) return st;
     if ((st = upload(h, &h->d_ua_tile_slots, p.ua_tile_slots)) != GORDER_OK) return st;
     {
         ExtraArgs &e = h->extra;
@@ -1124,7 +1113,6 @@ void gorder_hip_destroy(gorder_hip_handle *h) {
     (void)hipFree(h->d_tiles); (void)hipFree(h->d_items); (void)hipFree(h->d_tile_slots);
     (void)hipFree(h->d_direct); (void)hipFree(h->d_err); (void)hipFree(h->d_xtc_cp);
     (void)hipFree(h->d_ua_tiles); (void)hipFree(h->d_ua_items); (void)hipFree(h->d_ua_tile_slots);
-    (void)hipFree(h->d_ua_need_begin); (void)hipFree(h->d_ua_need); (void)hipFree(h->d_ua_pos);
     (void)hipFree(h->d_map_sums); (void)hipFree(h->d_map_cnts); (void)hipFree(h->d_map_packed); (void)hipFree(h->d_tw_sums); (void)hipFree(h->d_tw_cnts);
     (void)hipFree(h->d_geom_group); (void)hipFree(h->d_shapes); (void)hipFree(h->d_inv_box);
     (void)hipFree(h->d_map_rec); (void)hipFree(h->d_ua_runs); (void)hipFree(h->d_ua_run_begin);

@@ -972,29 +972,29 @@ __device__ __noinline__ UaBonds ua_carbon_slow(uint32_t kind, UaCarbon c, UaCons
     return ua_carbon(kind, c, e, pl);
 }
 
-// sum of an int over the 64 lanes (DPP row shifts + row broadcasts; every lane of the wave must be here)
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ int ua_dpp_add(int v) { return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, true); }
-__device__ __forceinline__ int ua_wave_sum(int v) {
-    v = ua_dpp_add<0x111, 0xf>(v); v = ua_dpp_add<0x112, 0xf>(v); v = ua_dpp_add<0x114, 0xf>(v); v = ua_dpp_add<0x118, 0xf>(v);
-    v = ua_dpp_add<0x142, 0xa>(v); v = ua_dpp_add<0x143, 0xc>(v);
-    return __builtin_amdgcn_readlane(v, 63);
+// sums of an int over the DPP rows of a wave (16 lanes each; row shifts: every lane of the wave must be here): lane 15 of
+// a row gets the row's sum
+template <int CTRL>
+__device__ __forceinline__ int ua_dpp_add(int v) { return v + __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+__device__ __forceinline__ int ua_row_sum(int v) {
+    v = ua_dpp_add<0x111>(v); v = ua_dpp_add<0x112>(v); v = ua_dpp_add<0x114>(v); v = ua_dpp_add<0x118>(v);
+    return v;
 }
 
 // MODE 0: order parameters only; 1: + staged ordermap samples, nothing else (no geometry selection, timewise rows or
 // per-molecule normals — the common ordermap run, and a much smaller kernel); 2: every extra; 3: per-frame rows, nothing else
-// FAST: GORDER_FLAG_UA_FAST_NORMALISE (ua_carbon_fast; inv_box holds 1 / box edge per frame).
-// How the atoms arrive (round 4).  Until round 3 every lane gathered its carbon's three or four atoms itself: the lanes of a
-// wave are 64 MOLECULES (one kind of carbon per wave), 624 bytes apart, so every load instruction touched 64 cache lines
-// — 1.6 M wave loads x 64 lines per 3 000-frame launch keep the CUs' L1 busy for about as long as the exact arithmetic keeps
-// the VALU busy (PMC, profiles/r04_pmc_ua256_*), which is why 41 % fewer VALU instructions bought 5 %.  Now the workgroup
-// stages the atoms its tile NEEDS (plan.h: the sorted list of distinct atoms the tile's carbons touch, ~6 per molecule) for
-// one frame in LDS with coalesced loads — thread t fetches dword t, t + 256, ... of the list; the runs of neighbouring atoms
-// of a molecule are contiguous in the frame —, the next frame's loads in flight during this frame's arithmetic, two
-// buffers, one barrier per frame; a lane then reads its atoms from LDS by their positions in the list (UaPos).
+// FAST: GORDER_FLAG_UA_FAST_NORMALISE (ua_carbon_fast; inv_box holds 1 / box edge per frame).  PREFETCH: the next frame's
+// atoms are requested before this frame's arithmetic (the fast arithmetic no longer hides the gather's latency by itself;
+// the exact path is bound by its arithmetic and keeps its registers).
 // The body is shared by k_ua_extras (the exact path) and k_ua_extras_fast.
-constexpr uint32_t kUaStageRegs = 6;      // dwords of the need list a thread keeps in flight (6 x 256 dwords = 512 atoms)
-template <bool ACOS_COS, int MODE, bool FAST>
+// (Measured and NOT kept in round 4: the tile's needed atoms staged in LDS per frame by coalesced loads, two buffers, one
+// barrier per frame — every test green, 0.36 -> 0.47 ms per 3 000 frames for the exact path and 0.30 -> 0.35 for the fast
+// one: a frame is only ~300 instructions per lane, a barrier and seventeen LDS operations per frame cost more than the
+// gather they replace.)
+// (Also measured and not kept: periodic boundaries as a template parameter, so that the `if (!pbc)` in front of every
+// minimum image and wrap disappears and the x / y / z chains interleave — 0.284 -> 0.279 ms for the fast path, the exact
+// path with maps 0.42 -> 0.49: twice the kernels for nothing.)
+template <bool ACOS_COS, int MODE, bool FAST, bool PREFETCH>
 __device__ __forceinline__ void ua_extras_body(FrameArgs a_in, ExtraArgs e, const float *__restrict__ xyz,
                                                        const float *__restrict__ box9,
                                                        const uint8_t *__restrict__ aflags,
@@ -1002,11 +1002,7 @@ __device__ __forceinline__ void ua_extras_body(FrameArgs a_in, ExtraArgs e, cons
                                                        const Tile *__restrict__ tiles,
                                                        const gorder::UaItem *__restrict__ items,
                                                        const uint32_t *__restrict__ tile_slots, uint32_t n_tiles,
-                                                       const float *__restrict__ inv_box,
-                                                       const uint32_t *__restrict__ need_begin,
-                                                       const uint16_t *__restrict__ need,
-                                                       const gorder::UaPos *__restrict__ pos, uint32_t stage_dw) {
-    extern __shared__ float l_stage[];     // [2][stage_dw]: the tile's needed atoms of two consecutive frames
+                                                       const float *__restrict__ inv_box) {
     constexpr bool EXTRAS = MODE != 0, GENERAL = MODE >= 2, FULL = MODE == 2, MAPS_POSSIBLE = MODE == 1 || MODE == 2;
     constexpr uint32_t LS = 3 * kBlock;   // local slots per block (<= 3 hydrogens per carbon)
     __shared__ unsigned long long l_s[2 * LS];
@@ -1032,23 +1028,30 @@ __device__ __forceinline__ void ua_extras_body(FrameArgs a_in, ExtraArgs e, cons
     const uint32_t f_begin = a.frame0 + chunk * a.frames_per_chunk;
     const uint32_t f_end = min(a.n_frames, f_begin + a.frames_per_chunk);
     const size_t fstride = (size_t)a.n_atoms * 3u;
-    // Per-frame rows: when the lanes of every wave of the tile hold carbons of ONE kind and slot (the tiles are cut from
-    // groups of 64 molecules ordered by kind and slot: the normal case) a frame's sums per slot are sums over a wave —
-    // DPP adds, then one lane sends them to the rows —: no LDS atomic per hydrogen (two to four, served one lane per
-    // cycle) and no barriers per frame.  Otherwise the LDS partials of extras_add / extras_flush_tw.
+    // Per-frame rows: when the lanes of every DPP ROW (16 lanes) of the tile hold carbons of ONE kind and slot (the tiles are
+    // cut from groups of 64 molecules ordered so that a wave is 4 slots x 16 molecules: the normal case) a frame's sums per
+    // slot are sums over a row — DPP adds, then the row's last lane sends them to the rows —: no LDS atomic per hydrogen
+    // (two to four, served one lane per cycle) and no barriers per frame.  Otherwise the LDS partials of extras_add /
+    // extras_flush_tw.
     __shared__ uint32_t l_mixed;
     if (GENERAL && tid == 0) l_mixed = 0u;
     if (GENERAL)
         for (uint32_t k = tid; k < 3 * LS; k += kBlock) { l_tw[k] = 0; l_twn[k] = 0; }
     for (uint32_t k = tid; k < 2 * LS; k += kBlock) { l_s[k] = 0; l_n[k] = 0; }
     __syncthreads();
+    uint32_t row_slot0 = 0;      // the row's first lane: its first slot and its number of hydrogens (active lanes come first)
+    int row_nh = 0;
     if (GENERAL) {
         const uint32_t key = active ? ((uint32_t)it.lslot0 << 8) | kind : 0xffffffffu;
-        const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);      // (lane 0 of the wave: active lanes come first)
+        const int lane0 = (int)(tid & 63u & ~15u);
+        const uint32_t first = (uint32_t)__shfl((int)key, lane0, 64);
+        row_slot0 = (uint32_t)__shfl((int)gslot0, lane0, 64);
+        row_nh = first == 0xffffffffu ? 0 : __shfl(nh, lane0, 64);
         if (!__all(!active || key == first)) l_mixed = 1u;
     }
     __syncthreads();
     const bool tw_waves = GENERAL && e.tw && l_mixed == 0u;                     // (uniform over the workgroup)
+    const int nh_wave = GENERAL ? (__any(row_nh > 2) ? 3 : (__any(row_nh > 1) ? 2 : 1)) : 0;      // (uniform over the wave)
     long long s_tot[3] = {0, 0, 0}, s_up[3] = {0, 0, 0};
     uint32_t n_tot[3] = {0, 0, 0}, n_up[3] = {0, 0, 0};
     int bad = 0;
@@ -1062,46 +1065,25 @@ __device__ __forceinline__ void ua_extras_body(FrameArgs a_in, ExtraArgs e, cons
         rec_n = run & 0xffffu;
         rec_row = e.map_rec + ((size_t)tile_id * 3u * kBlock + tid0) * e.rec_stride + (tid - tid0);
     }
-    // ---- staging: dword j of the tile's need list lives at frame + (atom0 + need[j / 3]) * 3 + j % 3
-    const uint32_t need0 = need_begin[tile_id], n_dw = 3u * (need_begin[tile_id + 1] - need0);
-    const float *tile_src = xyz + (size_t)t.atom0 * 3u;
-    uint32_t soff[kUaStageRegs];          // this thread's dwords of the list: source offsets (0xffffffff: none)
+    const float *src[4];
 #pragma unroll
-    for (uint32_t k = 0; k < kUaStageRegs; k++) {
-        const uint32_t j = tid + k * kBlock;
-        soff[k] = j < n_dw ? (uint32_t)need[need0 + j / 3u] * 3u + j % 3u : 0xffffffffu;
-    }
-    float sv[kUaStageRegs];
-    auto stage_load = [&](uint32_t f) {
-        const float *fs = tile_src + (size_t)f * fstride;
-#pragma unroll
-        for (uint32_t k = 0; k < kUaStageRegs; k++) sv[k] = soff[k] != 0xffffffffu ? fs[soff[k]] : 0.0f;
+    for (int q = 0; q < 4; q++) src[q] = xyz + ((size_t)t.atom0 + (active ? it.l[q] : 0u)) * 3u;
+    auto fetch = [&](uint32_t f) {
+        UaCarbon c;
+        const size_t o = (size_t)f * fstride;
+        c.p0 = {src[0][o], src[0][o + 1], src[0][o + 2]};
+        c.p1 = {src[1][o], src[1][o + 1], src[1][o + 2]};
+        c.p2 = {src[2][o], src[2][o + 1], src[2][o + 2]};
+        c.p3 = {src[3][o], src[3][o + 1], src[3][o + 2]};
+        return c;
     };
-    auto stage_store = [&](uint32_t f, uint32_t buf) {
-        float *lb = l_stage + buf * stage_dw;
-#pragma unroll
-        for (uint32_t k = 0; k < kUaStageRegs; k++)
-            if (soff[k] != 0xffffffffu) lb[tid + k * kBlock] = sv[k];
-        // (a need list of more than 512 atoms — carbons picked far apart in long molecules: its tail is copied in place)
-        const float *fs = tile_src + (size_t)f * fstride;
-        for (uint32_t j = tid + kUaStageRegs * kBlock; j < n_dw; j += kBlock) lb[j] = fs[(uint32_t)need[need0 + j / 3u] * 3u + j % 3u];
-    };
-    gorder::UaPos ip{};
-    if (active) ip = pos[t.item0 + tid];
-    if (f_begin < f_end) { stage_load(f_begin); stage_store(f_begin, 0u); }
-    __syncthreads();
+    UaCarbon c_next{};
+    if (PREFETCH && active && f_begin < f_end) c_next = fetch(f_begin);
     for (uint32_t f = f_begin; f < f_end; f++) {
         int tw_s[3] = {0, 0, 0}, tw_sl[3] = {0, 0, 0}, tw_n[3] = {0, 0, 0};      // tw_waves: this lane's ticks, lower-leaflet ticks, counts (all | lower << 16)
-        const uint32_t buf = (f - f_begin) & 1u;
-        const bool more = f + 1 < f_end;               // (uniform)
-        if (more) stage_load(f + 1);                   // in flight during this frame's arithmetic
         if (active) {
-            const float *lb = l_stage + buf * stage_dw;
-            UaCarbon c;
-            c.p0 = {lb[3u * ip.p[0]], lb[3u * ip.p[0] + 1u], lb[3u * ip.p[0] + 2u]};
-            c.p1 = {lb[3u * ip.p[1]], lb[3u * ip.p[1] + 1u], lb[3u * ip.p[1] + 2u]};
-            c.p2 = {lb[3u * ip.p[2]], lb[3u * ip.p[2] + 1u], lb[3u * ip.p[2] + 2u]};
-            c.p3 = {lb[3u * ip.p[3]], lb[3u * ip.p[3] + 1u], lb[3u * ip.p[3] + 2u]};
+            const UaCarbon c = PREFETCH ? c_next : fetch(f);
+            if (PREFETCH && f + 1 < f_end) c_next = fetch(f + 1);
             V3 bx3{1.0f, 1.0f, 1.0f};
             if (pbc) { const float *b = a.box9 + 9 * (size_t)f; bx3 = {b[0], b[4], b[8]}; }
             // the atoms are checked in index order (uaorder.rs:400-437 via get_position of each helper); the smallest key wins
@@ -1177,16 +1159,14 @@ __device__ __forceinline__ void ua_extras_body(FrameArgs a_in, ExtraArgs e, cons
             }
         }
         if (tw_waves) {             // every lane of the wave is here
-            const uint32_t slot0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)gslot0);
-            const int nh_w = __builtin_amdgcn_readfirstlane(active ? nh : 0);
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                if (k >= nh_w) break;                               // (uniform)
-                const int s_all = ua_wave_sum(tw_s[k]), s_low = ua_wave_sum(tw_sl[k]), n = ua_wave_sum(tw_n[k]);
+                if (k >= nh_wave) break;                            // (uniform)
+                const int s_all = ua_row_sum(tw_s[k]), s_low = ua_row_sum(tw_sl[k]), n = ua_row_sum(tw_n[k]);
                 const uint32_t n_all = (uint32_t)n & 0xffffu, n_low = (uint32_t)n >> 16;
-                if ((tid & 63u) == 0u && n_all) {
+                if ((tid & 15u) == 15u && k < row_nh && n_all) {
                     const size_t row = ((size_t)e.tw_row0 + f) * 3u * a.n_acc;
-                    const uint32_t slot = slot0 + (uint32_t)k;
+                    const uint32_t slot = row_slot0 + (uint32_t)k;
                     atomicAdd(&e.tw_sums[row + slot], (unsigned long long)(long long)s_all);
                     atomicAdd(&e.tw_cnts[row + slot], (unsigned long long)n_all);
                     if (a.leaflets) {
@@ -1207,8 +1187,6 @@ __device__ __forceinline__ void ua_extras_body(FrameArgs a_in, ExtraArgs e, cons
             extras_flush_tw(a, e, tile_slots + t.slot0, t.n_slots, f, l_tw, l_twn, LS);
             __syncthreads();
         }
-        if (more) stage_store(f + 1, buf ^ 1u);
-        __syncthreads();        // frame f + 1 is in its buffer, and nobody reads frame f any more (its buffer is written next)
     }
     if (bad) raise_box_range(a.err, f_begin);
     if (active) {
@@ -1241,18 +1219,15 @@ __device__ __forceinline__ void ua_extras_body(FrameArgs a_in, ExtraArgs e, cons
     FrameArgs a_in, ExtraArgs e, const float *__restrict__ xyz, const float *__restrict__ box9,                               \
         const uint8_t *__restrict__ aflags, const uint32_t *__restrict__ arow, const Tile *__restrict__ tiles,                \
         const gorder::UaItem *__restrict__ items, const uint32_t *__restrict__ tile_slots, uint32_t n_tiles,                  \
-        const float *__restrict__ inv_box, const uint32_t *__restrict__ need_begin, const uint16_t *__restrict__ need,        \
-        const gorder::UaPos *__restrict__ pos, uint32_t stage_dw
+        const float *__restrict__ inv_box
 template <bool ACOS_COS, int MODE>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ua_extras(GORDER_UA_KERNEL_ARGS) {
-    ua_extras_body<ACOS_COS, MODE, false>(a_in, e, xyz, box9, aflags, arow, tiles, items, tile_slots, n_tiles, inv_box, need_begin,
-                                          need, pos, stage_dw);
+    ua_extras_body<ACOS_COS, MODE, false, false>(a_in, e, xyz, box9, aflags, arow, tiles, items, tile_slots, n_tiles, inv_box);
 }
 // GORDER_FLAG_UA_FAST_NORMALISE (the default cosine only)
 template <int MODE>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ua_extras_fast(GORDER_UA_KERNEL_ARGS) {
-    ua_extras_body<false, MODE, true>(a_in, e, xyz, box9, aflags, arow, tiles, items, tile_slots, n_tiles, inv_box, need_begin,
-                                      need, pos, stage_dw);
+    ua_extras_body<false, MODE, true, true>(a_in, e, xyz, box9, aflags, arow, tiles, items, tile_slots, n_tiles, inv_box);
 }
 #undef GORDER_UA_KERNEL_ARGS
 

@@ -10,6 +10,8 @@
 // Samples whose own atoms span more than `max_window` atoms go to a direct-gather list.
 #pragma once
 #include <algorithm>
+#include <map>
+#include <tuple>
 #include <cstdint>
 #include <utility>
 #include <vector>
@@ -45,10 +47,6 @@ struct UaItem {          // one united-atom carbon instance (uaorder.rs:911-915,
     uint32_t mol;
 };
 
-struct UaPos {           // the same carbon's atoms as positions in its tile's need list (Plan::ua_need): what the kernel reads from LDS
-    uint16_t p[4];
-};
-
 struct MapRun {          // `n` consecutive threads of a united-atom tile (from tid0) are the molecules of ONE slot:
     uint32_t tile, tid0, n, k;   // their hydrogen k.  Lets k_map_accumulate read a slot's staged samples in runs.
 };
@@ -65,13 +63,6 @@ struct Plan {
     std::vector<Tile> ua_tiles;
     std::vector<UaItem> ua_items;
     std::vector<uint32_t> ua_tile_slots;
-    // per tile the sorted list of the DISTINCT atoms its carbons touch (window-relative, ~6 per molecule): the workgroup
-    // stages exactly these per frame (coalesced where they are neighbours in the frame), ua_pos holds every item's atoms
-    // as positions in that list
-    std::vector<uint16_t> ua_need;
-    std::vector<uint32_t> ua_need_begin;    // [n_ua_tiles + 1]
-    std::vector<UaPos> ua_pos;              // parallel to ua_items
-    uint32_t ua_max_need = 0;
     std::vector<MapRun> ua_runs;            // grouped by accumulator slot:
     std::vector<uint32_t> ua_run_begin;     // [n_acc + 1] (CSR)
     // the same for bond tiles: `items_by_slot` = every tile's items re-ordered so that the molecules of one slot
@@ -161,7 +152,7 @@ inline void spread_over_banks(Item *items, uint32_t n) {
 }
 
 // Returns GORDER_OK or GORDER_ERR_INVALID_ARGUMENT (index out of range, self bond, ...).
-inline int build_plan(const gorder_tables_t &t, bool force_direct, Plan &p) {
+inline int build_plan(const gorder_tables_t &t, bool force_direct, Plan &p, bool ua_quads = true) {
     p = Plan();
     p.n_atoms = t.n_atoms;
     if (t.n_atoms == 0 || (t.n_molecule_types && !t.molecule_types)) return GORDER_ERR_INVALID_ARGUMENT;
@@ -238,22 +229,6 @@ inline int build_plan(const gorder_tables_t &t, bool force_direct, Plan &p) {
             }
             tile.n_window = top - tile.atom0 + 1;
             tile.n_slots = (uint32_t)slots.size();
-            {   // the tile's need list and the items' positions in it
-                std::vector<uint16_t> nl;
-                for (uint32_t i = 0; i < tile.n_items; i++)
-                    for (int c = 0; c < 4; c++) nl.push_back(p.ua_items[tile.item0 + i].l[c]);
-                std::sort(nl.begin(), nl.end());
-                nl.erase(std::unique(nl.begin(), nl.end()), nl.end());
-                if (p.ua_need_begin.empty()) p.ua_need_begin.push_back(0);
-                p.ua_pos.resize((size_t)tile.item0 + tile.n_items);
-                for (uint32_t i = 0; i < tile.n_items; i++)
-                    for (int c = 0; c < 4; c++)
-                        p.ua_pos[tile.item0 + i].p[c] =
-                            (uint16_t)(std::lower_bound(nl.begin(), nl.end(), p.ua_items[tile.item0 + i].l[c]) - nl.begin());
-                p.ua_need.insert(p.ua_need.end(), nl.begin(), nl.end());
-                p.ua_need_begin.push_back((uint32_t)p.ua_need.size());
-                p.ua_max_need = std::max(p.ua_max_need, (uint32_t)nl.size());
-            }
             const uint32_t tile_id = (uint32_t)p.ua_tiles.size();
             for (uint32_t i = 0; i < tile.n_items;) {   // the lanes of one slot: a MapRun per hydrogen
                 const UaItem &it = p.ua_items[tile.item0 + i];
@@ -291,11 +266,37 @@ inline int build_plan(const gorder_tables_t &t, bool force_direct, Plan &p) {
                 if (span == 1) return GORDER_ERR_INVALID_ARGUMENT;      // one molecule wider than 16-bit offsets reach
                 span /= 2;
             }
-            std::stable_sort(ua_samples.begin() + q, ua_samples.begin() + e, [](const UaSample &x, const UaSample &y) {
-                if (x.kind != y.kind) return x.kind < y.kind;
-                if (x.slot0 != y.slot0) return x.slot0 < y.slot0;
-                return x.mol < y.mol;
-            });
+            if (!ua_quads) {
+                std::stable_sort(ua_samples.begin() + q, ua_samples.begin() + e, [](const UaSample &x, const UaSample &y) {
+                    if (x.kind != y.kind) return x.kind < y.kind;
+                    if (x.slot0 != y.slot0) return x.slot0 < y.slot0;
+                    return x.mol < y.mol;
+                });
+            } else {
+                // A wave = 4 neighbouring carbons (slots) of one kind x 16 molecules, a DPP row of 16 lanes per slot: the
+                // lanes of a wave then gather from 16 molecules' neighbourhoods (a line or two each) instead of from 64
+                // molecules (64 lines per load instruction), and a slot's lanes are still a run of 16 for the staged
+                // ordermap samples and the per-frame sums.
+                std::map<std::pair<uint32_t, uint32_t>, uint32_t> rank;      // (kind, slot0) -> rank of the slot in its kind
+                {
+                    std::vector<std::pair<uint32_t, uint32_t>> ks;
+                    for (size_t i = q; i < e; i++) ks.push_back({ua_samples[i].kind, ua_samples[i].slot0});
+                    std::sort(ks.begin(), ks.end());
+                    ks.erase(std::unique(ks.begin(), ks.end()), ks.end());
+                    uint32_t r = 0;
+                    for (size_t i = 0; i < ks.size(); i++) {
+                        if (i && ks[i].first != ks[i - 1].first) r = 0;
+                        rank[ks[i]] = r++;
+                    }
+                }
+                const uint32_t mol_first = ua_samples[q].mol;
+                auto key = [&](const UaSample &u) {
+                    const uint32_t r = rank[{u.kind, u.slot0}];
+                    return std::make_tuple(u.kind, r / 4u, (u.mol - mol_first) / 16u, u.slot0, u.mol);
+                };
+                std::stable_sort(ua_samples.begin() + q, ua_samples.begin() + e,
+                                 [&](const UaSample &x, const UaSample &y) { return key(x) < key(y); });
+            }
             for (size_t b = q; b < e; b += kBlock) emit_tile(b, std::min(e, b + kBlock));
             q = e;
         }
@@ -460,20 +461,6 @@ inline int selfcheck_plan(const gorder_tables_t &t, const Plan &p) {
                 }
             }
         if (lanes != want_lanes) return 15;
-        // the need lists: sorted, distinct, inside the window, and every item's positions name its own atoms
-        if (p.ua_need_begin.size() != p.ua_tiles.size() + 1 || p.ua_pos.size() != p.ua_items.size()) return 18;
-        for (size_t ti = 0; ti < p.ua_tiles.size(); ti++) {
-            const Tile &tile = p.ua_tiles[ti];
-            const uint32_t b = p.ua_need_begin[ti], n = p.ua_need_begin[ti + 1] - b;
-            if (n == 0 || n > 4u * tile.n_items || n > p.ua_max_need) return 19;
-            for (uint32_t k = 0; k < n; k++)
-                if (p.ua_need[b + k] >= tile.n_window || (k && p.ua_need[b + k] <= p.ua_need[b + k - 1])) return 20;
-            for (uint32_t i = 0; i < tile.n_items; i++)
-                for (int c = 0; c < 4; c++) {
-                    const uint16_t q = p.ua_pos[tile.item0 + i].p[c];
-                    if (q >= n || p.ua_need[b + q] != p.ua_items[tile.item0 + i].l[c]) return 21;
-                }
-        }
     }
     return 0;
 }

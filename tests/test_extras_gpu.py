@@ -220,9 +220,13 @@ def test_united_atoms_with_interleaved_molecule_types(built):
     assert np.abs(got.order_ticks() - want.order_ticks()).max() <= 1
 
 
+@pytest.mark.parametrize("lanes", ["4 slots x 16 molecules", "a slot per wave"])
 @pytest.mark.parametrize("pbc", [True, False])
 @pytest.mark.parametrize("leaflets", [LEAFLETS_NONE, LEAFLETS_GLOBAL])
-def test_united_atoms(built, leaflets, pbc):
+def test_united_atoms(built, monkeypatch, leaflets, pbc, lanes):
+    # (how the carbons of a group of molecules are dealt to the lanes: the default since round 4, and rounds 1-3's order)
+    if lanes == "a slot per wave":
+        monkeypatch.setenv("GORDER_HIP_UA_SLOT_WAVES", "1")
     system = synthetic.ua_membrane(40, leaflets=leaflets, handle_pbc=pbc)
     n = 11
     xyz = system.frames(n, seed=8)
@@ -250,8 +254,11 @@ def test_united_atoms(built, leaflets, pbc):
     assert np.all(s >= -0.5 - 1e-6) and np.all(s <= 1.0 + 1e-6)
 
 
-def test_united_atoms_with_maps_and_timewise(built):
-    system = synthetic.ua_membrane(16, leaflets=LEAFLETS_GLOBAL, timewise=True,
+@pytest.mark.parametrize("lanes,n_lipids", [("4 slots x 16 molecules", 16), ("4 slots x 16 molecules", 100), ("a slot per wave", 70)])
+def test_united_atoms_with_maps_and_timewise(built, monkeypatch, lanes, n_lipids):
+    if lanes == "a slot per wave":
+        monkeypatch.setenv("GORDER_HIP_UA_SLOT_WAVES", "1")
+    system = synthetic.ua_membrane(n_lipids, leaflets=LEAFLETS_GLOBAL, timewise=True,
                                    ordermap=OrderMap(enabled=True, plane=0, span_x=(0.0, 9.0), span_y=(0.0, 9.0),
                                                      bin=(1.0, 1.0)))
     n = 7
