@@ -160,7 +160,10 @@ def cpu_baseline(system, seconds_target=2.0, threads=None):
     and `cores` that row's thread count (the affinity mask of a GPU box shows every hardware thread of the host, its CPU
     quota may be a fraction of that)."""
     from oracle import oracle
+    quota = cpu_quota()
     cap = threads or host_cores()
+    if quota and not threads:       # more threads than the CPU quota allows only take turns (measured: 16 -> 13.4 x, 32 -> 14.1 x, 64 -> 13.3 x on a quota of 16)
+        cap = max(1, min(cap, int(quota + 0.5)))
     counts = [1]
     while counts[-1] * 2 <= cap:
         counts.append(counts[-1] * 2)
@@ -190,7 +193,6 @@ def cpu_baseline(system, seconds_target=2.0, threads=None):
     best = max(table, key=lambda r: r["frames_per_s"])
     for r in table:
         r["speedup"] = r["frames_per_s"] / one
-    quota = cpu_quota()
     return {"value": best["frames_per_s"], "unit": "frames/s", "cores": best["threads"], "cores_available": cores_available(),
             "cpu_quota": quota, "kind": "port", "value_1_thread": one,
             "parallel_efficiency": best["frames_per_s"] / (best["threads"] * one),
@@ -296,6 +298,85 @@ def end_to_end(system, device_index, n_unique=500, repeats=200):
                    "(gorder_xtc_pack_window) -> pinned staging x3 -> hipMemcpyAsync -> k_xtc_scan + k_xtc_chunks (a lane per 256-atom chunk) "
                    "-> kernels.  host_decode: gorder_xtc_read_window_mt on the same threads -> pinned -> hipMemcpyAsync "
                    "-> kernels.  Both routes give identical sums (checked)." % (n_unique, repeats, t_write))
+    return out
+
+
+def end_to_end_large(system, name, device_index, hot_value):
+    """From-file throughput on a trajectory that no cache level between the disk and the DRAM holds: GORDER_BENCH_LARGE_GB
+    (default 8) gigabytes of DISTINCT encoder-written frames (tools/make_large_xtc.py, one process per part file, all
+    parts one concatenated trajectory), analysed by gorder_hip_run_trajectory (device decode)
+      cold   after fsync + posix_fadvise(POSIX_FADV_DONTNEED) on every part: the bytes come from the disk,
+      warm   again, right after: the bytes come from the page cache (DRAM) — 8 GB do not fit the host's L3, which is
+             what the hot-file figure (one 62-MB file read 200 times) profits from.
+    Returns a dict; {"skipped": reason} when the box has no room for the files."""
+    import shutil
+    import subprocess
+    from gorder_amd import HipEngine
+    gb = float(os.environ.get("GORDER_BENCH_LARGE_GB", "8"))
+    if gb <= 0:
+        return {"skipped": "GORDER_BENCH_LARGE_GB=0"}
+    bytes_per_frame = 125e3 * system.n_atoms / 25088.0           # XTC at precision 1000: ~5 bytes per atom
+    n_frames = int(gb * 1e9 / bytes_per_frame)
+    workers = max(1, min(16, int(cpu_quota() or cores_available()), cores_available()))
+    per = (n_frames + workers - 1) // workers
+    n_frames = per * workers
+    tmp_root = os.environ.get("GORDER_BENCH_TMPDIR") or tempfile.gettempdir()
+    try:
+        free = shutil.disk_usage(tmp_root).free
+    except OSError as ex:
+        return {"skipped": f"{tmp_root}: {ex}"}
+    if free < 1.5 * gb * 1e9:
+        return {"skipped": f"{tmp_root} has {free / 1e9:.1f} GB free, {1.5 * gb:.0f} GB wanted"}
+    tmp = tempfile.mkdtemp(prefix="gorder_bench_large_", dir=tmp_root)
+    out = {"frames": n_frames, "parts": workers}
+    try:
+        paths = [os.path.join(tmp, f"part{w:02d}.xtc") for w in range(workers)]
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "make_large_xtc.py"), name, paths[w],
+                                   str(w * per), str(per)]) for w in range(workers)]
+        if any(p.wait() != 0 for p in procs):
+            return {"skipped": "tools/make_large_xtc.py failed"}
+        out["seconds_to_write"] = time.perf_counter() - t0
+        size = sum(os.path.getsize(p) for p in paths)
+        out["file_GB"] = size / 1e9
+        dropped = True
+        for p in paths:          # the page cache lets go of clean pages only: write them out first
+            fd = os.open(p, os.O_RDONLY)
+            try:
+                os.fsync(fd)
+                os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
+            except OSError:
+                dropped = False
+            finally:
+                os.close(fd)
+        system.tables.device = device_index
+        eng = HipEngine(system.tables)
+        threads = reader_threads()
+
+        def block(st):
+            sec = st["seconds_total"]
+            return {"value": st["n_frames"] / sec, "unit": "frames/s", "seconds": sec, "file_read_MBps": size / sec / 1e6,
+                    "pcie_GBps": st["bytes_h2d"] / sec / 1e9, "reader_busy_fraction": st["seconds_decode"] / sec,
+                    "gpu_waiting_for_reader_s": st["seconds_gpu_starved"], "batches": st["n_batches"]}
+        cold = eng.run_trajectory(paths, threads=threads, device_decode=True)
+        res_cold = eng.finish()
+        eng.reset()
+        warm = eng.run_trajectory(paths, threads=threads, device_decode=True)
+        res_warm = eng.finish()
+        eng.reset()
+        warm2 = eng.run_trajectory(paths, threads=threads, device_decode=True)
+        eng.close()
+        assert cold["n_frames"] == warm["n_frames"] == n_frames == res_cold.n_frames
+        np.testing.assert_array_equal(res_cold.sums, res_warm.sums)
+        out["cold"] = block(cold)
+        out["cold"]["page_cache_dropped"] = dropped
+        out["cold"]["note"] = ("first read after fsync + posix_fadvise(DONTNEED): disk -> page cache -> pinned -> device; also "
+                               "this handle's first call (staging buffers are pinned inside it)")
+        out["warm"] = block(warm if warm["seconds_total"] <= warm2["seconds_total"] else warm2)
+        out["warm"]["note"] = "read again: every byte comes out of the page cache in DRAM (the better of two runs)"
+        out["hot_file_value"] = hot_value
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
     return out
 
 
@@ -808,9 +889,25 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(system)
         if not args.no_end_to_end:
-            out["end_to_end"] = end_to_end(system, local_rank)
+            out["end_to_end"] = e2e = end_to_end(system, local_rank)
+            e2e["value_is"] = "hot_file: one 62-MB file read 200 x as one trajectory (host L3 / page cache resident)"
             if name == "aa256":
-                out["end_to_end"]["solvated"] = end_to_end_solvated(system, local_rank)
+                e2e["solvated"] = end_to_end_solvated(system, local_rank)
+                try:
+                    large = end_to_end_large(system, name, local_rank, e2e["value"])
+                except Exception as ex:   # noqa: BLE001 — a full disk must not cost the line
+                    large = {"skipped": repr(ex)}
+                e2e["large"] = large
+                if "warm" in large:
+                    # the figure to quote: distinct frames, larger than any cache but DRAM
+                    e2e["hot_file"] = {"value": e2e["value"], "first_call_value": e2e["first_call_value"], "pcie_GBps": e2e["pcie_GBps"],
+                                       "file_read_MBps": e2e["file_read_MBps"]}
+                    e2e["value"] = large["warm"]["value"]
+                    e2e["pcie_GBps"] = large["warm"]["pcie_GBps"]
+                    e2e["file_read_MBps"] = large["warm"]["file_read_MBps"]
+                    e2e["value_is"] = ("large.warm: %.1f GB of distinct frames in %d files, read from the page cache (DRAM); "
+                                       "large.cold = the same from the disk, hot_file = one 62-MB file read 200 x" % (large["file_GB"], large["parts"]))
+                    e2e["path"] = "value = large.warm.  " + e2e["path"]
         if not args.no_scaling_reference and name == "aa256" and not args.frames and args.trig == "squared":
             free_b, _ = torch.cuda.mem_get_info(device)
             if free_b > 150 * (1 << 30):
