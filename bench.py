@@ -821,7 +821,9 @@ def main():
         per_launch_bytes = system.bytes_per_frame * frames
         groups = [{"name": n, "ms": ms / max(1, launches),
                    "share_of_step": ms / kernel_ms if kernel_ms > 0 else 0.0,
-                   "frac": per_launch_bytes / (ms / max(1, launches) / 1e3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None,
+                   # (the step's algorithmic bytes over this group's time: what the group would reach alone; meaningless for
+                   # the bookkeeping launches, hence only for groups that are at least 2 % of the step)
+                   "frac": per_launch_bytes / (ms / max(1, launches) / 1e3) / 1e9 / HBM_PEAK_GBS if ms > 0.02 * kernel_ms else None,
                    "launches_per_step": seg / max(1, launches)} for n, ms, seg in kernel_groups]
         dominant = max(groups, key=lambda g: g["ms"]) if groups else {"name": "k_bonds_tiled", "ms": 0.0}
         first_kernel = dominant["name"].split(" + ")[0]
