@@ -78,7 +78,6 @@ def make_system(name):
         system.tables.flags |= FLAG_UA_FAST_NORMALISE
         return system, text + " [GORDER_FLAG_UA_FAST_NORMALISE]"
     if name == "cg3k-dynamic":   # membrane normal: dynamic (normal.rs:160-199): per lipid and frame, PCA of the heads within 2 nm
-        import numpy as np
         from gorder_amd.abi import DynamicNormal, LEAFLETS_GLOBAL as LG
         system = synthetic.cg_membrane(3072, leaflets=LG)
         cloud = []
@@ -94,6 +93,15 @@ def make_system(name):
                                           point=(0.0, 0.0, 0.0), xdim=(0.0, 0.0), ydim=(0.0, 0.0), zdim=(0.0, 0.0),
                                           span=(-float("inf"), float("inf")), structure_box=tuple(float(x) for x in system.box))
         return system, "AAOrder 256 lipids + cylinder selection (r = 3 nm around the box centre)"
+    if name == "cg1m-local-r2.5":      # a membrane beyond k_local_build's 65 536 atoms: k_local_bin / _scan / _scatter make the cell lists
+        from gorder_amd.abi import LEAFLETS_LOCAL
+        return (synthetic.cg_membrane(83334, leaflets=LEAFLETS_LOCAL, radius=2.5),
+                "CGOrder synthetic 1M-bead bilayer + local leaflets (r = 2.5 nm, every frame): the cell-list fallback for membranes > 65536 atoms")
+    if name == "aa256-leaflets-subset":   # the membrane group is an index LIST (every second atom): k_leaflets_global, not the contiguous kernel
+        system = synthetic.aa_membrane(256, leaflets=LEAFLETS_GLOBAL)
+        lf = system.tables.leaflets
+        lf.membrane = np.ascontiguousarray(np.asarray(lf.membrane)[::2], dtype=np.uint32)
+        return system, "AAOrder 256 lipids + global leaflets, membrane group = every second atom (index list: the generic leaflet kernel)"
     if name == "cg1m":
         return synthetic.cg_membrane(83334), "CGOrder synthetic 1M-bead bilayer (1000008 beads, 916674 bonds/frame)"
     raise SystemExit(f"unknown workload {name}")

@@ -1225,8 +1225,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     ua_extras_body<ACOS_COS, MODE, false, false>(a_in, e, xyz, box9, aflags, arow, tiles, items, tile_slots, n_tiles, inv_box);
 }
 // GORDER_FLAG_UA_FAST_NORMALISE (the default cosine only)
+#ifndef GORDER_UA_FAST_WAVES
+#define GORDER_UA_FAST_WAVES 4      // (3, 5 and 6 waves per SIMD measured in round 4: see DESIGN)
+#endif
 template <int MODE>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ua_extras_fast(GORDER_UA_KERNEL_ARGS) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GORDER_UA_FAST_WAVES, GORDER_UA_FAST_WAVES))) void k_ua_extras_fast(GORDER_UA_KERNEL_ARGS) {
     ua_extras_body<false, MODE, true, true>(a_in, e, xyz, box9, aflags, arow, tiles, items, tile_slots, n_tiles, inv_box);
 }
 #undef GORDER_UA_KERNEL_ARGS

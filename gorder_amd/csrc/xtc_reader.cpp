@@ -1079,15 +1079,20 @@ int64_t pack_window_impl(gorder_xtc_reader *r, float begin_ps, float end_ps, uin
             }
         }
     }
+    // A file that has SHRUNK since it was mapped must not be touched through the mapping any more (pages behind the new
+    // end raise SIGBUS): this reader goes back to pread for good.  A file that has GROWN keeps its mapping for the part
+    // that was there and takes pread behind it.  (A file truncated while a copy is in flight can still fault: for
+    // trajectories another process rewrites, or on file systems that return I/O errors late, set GORDER_XTC_PREAD=1.)
+    if (r->map && (getenv("GORDER_XTC_PREAD") || (file_end >= 0 && (size_t)file_end < r->map->size))) r->map.reset();
     const FileMap *map = r->map.get();
     while (src.size() < capacity) {
         const off_t pos0 = pos;
         uint8_t head[56 + 36];
         ssize_t got;
-        if (map && map->base && pos0 >= 0 && (size_t)pos0 <= map->size) {      // (no system call per frame)
-            got = (ssize_t)std::min<size_t>(sizeof(head), map->size - (size_t)pos0);
-            memcpy(head, map->base + pos0, (size_t)got);
-        } else {
+        if (map && map->base && pos0 >= 0 && (size_t)pos0 + sizeof(head) <= map->size) {      // (no system call per frame)
+            got = (ssize_t)sizeof(head);
+            memcpy(head, map->base + pos0, sizeof(head));
+        } else {            // the last bytes of the mapping, or behind it (the file has grown): the file itself decides
             got = pread(fd, head, sizeof(head), pos0);
         }
         if (got == 0) break;

@@ -103,7 +103,12 @@ typedef struct {
  * (GORDER_XTC_ERR_NO_SPACE when not even ONE frame fits the blob — nothing has happened then: file position, *state
  * and *last_time are those of the call's entry; GORDER_XTC_ERR_ARGUMENT for a TRR / GRO reader; GORDER_XTC_ERR_FORMAT
  * also for a block whose byte count runs past the end of the file).
- * `*blob_bytes` receives the bytes of the blob in use.  The blocks are read by `n_threads` threads (pread). */
+ * `*blob_bytes` receives the bytes of the blob in use.  The blocks are copied by `n_threads` threads: out of a read-only
+ * mapping of the file made at the reader's first window (streaming stores into the blob), `pread` where there is no
+ * mapping.  A file that has shrunk since it was mapped is read by `pread` from then on, the part of a file that has
+ * grown behind the mapping too.  What a mapping cannot turn into an error code is a file truncated, or an I/O error of the
+ * file system, WHILE a copy is reading those pages: that is SIGBUS.  For trajectories a running simulation rewrites, and
+ * on network file systems, set GORDER_XTC_PREAD=1 (every byte by pread, errors as GORDER_XTC_ERR_FORMAT). */
 int64_t gorder_xtc_pack_window(gorder_xtc_reader *r, float begin_ps, float end_ps, uint32_t step, uint64_t *state,
                                double *last_time, uint8_t *blob, uint64_t blob_capacity, uint64_t *blob_bytes,
                                gorder_xtc_frame_t *frames, float *box9, float *time_ps, uint64_t capacity,

@@ -192,6 +192,69 @@ def test_mapped_copies_equal_pread_copies(built, tmp_path, monkeypatch):
     assert mapped == plain == unaligned
 
 
+def test_a_file_that_grows_or_shrinks_behind_its_mapping(built, tmp_path):
+    """The reader maps the file at its first window.  Frames APPENDED later (a running simulation) lie behind the mapping
+    and must still be found (by pread); a file that has become SHORTER must not be touched through the mapping again
+    (SIGBUS) — the reader reads what is left by pread and reports the end, or a format error, as a status."""
+    import ctypes as C
+    import shutil
+    from gorder_amd.abi import CXtcFrame
+    whole = synthetic(tmp_path, n_frames=9, n_atoms=1500, name="whole.xtc")
+    raw = open(whole, "rb").read()
+    ws = xtc.pack_trajectory([whole], chunk=64)
+    ends = [int(p) for p in np.cumsum([len(raw) // 9] * 9)]          # (all frames of this file have the same size or nearly)
+    # exact frame boundaries: the reader tells them (file positions of the packed frames' headers)
+    lib = xtc._lib()
+    growing = str(tmp_path / "growing.xtc")
+
+    def window(r, want_state):
+        raw_blob = np.zeros((1 << 21) + 64, np.uint8)
+        blob = raw_blob[(-raw_blob.ctypes.data) % 64:][: 1 << 21]
+        used = C.c_uint64(0)
+        frames = (CXtcFrame * 16)()
+        box, t = np.empty((16, 9), np.float32), np.empty(16, np.float32)
+        got = lib.gorder_xtc_pack_window(r, 0.0, -1.0, 1, C.byref(want_state[0]), C.byref(want_state[1]), blob.ctypes.data, 1 << 21,
+                                         C.byref(used), C.cast(frames, C.c_void_p), box.ctypes.data, t.ctypes.data, 16, 2)
+        return got, t[:max(got, 0)].copy()
+
+    # where frame 5 starts: the size of a file that holds the first five frames
+    five = str(tmp_path / "five.xtc")
+    x, b, t = xtc.read_trajectory([whole])
+    xtc.write_trajectory(five, x[:5], b[:5], times=t[:5], precision=1000.0)
+    n5 = os.path.getsize(five)
+    assert raw[:n5] == open(five, "rb").read()
+    shutil.copy(five, growing)
+    r = C.c_void_p()
+    assert lib.gorder_xtc_open(growing.encode(), None, 0, C.byref(r)) == 0
+    st = (C.c_uint64(0), C.c_double(float("-inf")))
+    got, tt = window(r, st)
+    assert got == 5 and list(tt) == [0.0, 10.0, 20.0, 30.0, 40.0]     # (the mapping now covers these five frames)
+    with open(growing, "ab") as f:                                    # four more frames arrive
+        f.write(raw[n5:])
+    got, tt = window(r, st)
+    assert got == 4 and list(tt) == [50.0, 60.0, 70.0, 80.0]
+    assert window(r, st)[0] == 0
+    lib.gorder_xtc_close(r)
+    # ... and a file cut short after the mapping was made
+    shrinking = str(tmp_path / "shrinking.xtc")
+    shutil.copy(whole, shrinking)
+    r = C.c_void_p()
+    assert lib.gorder_xtc_open(shrinking.encode(), None, 0, C.byref(r)) == 0
+    st = (C.c_uint64(0), C.c_double(float("-inf")))
+    used = C.c_uint64(0)
+    frames = (CXtcFrame * 16)()
+    box, t2 = np.empty((16, 9), np.float32), np.empty(16, np.float32)
+    raw_blob = np.zeros((1 << 21) + 64, np.uint8)
+    blob = raw_blob[(-raw_blob.ctypes.data) % 64:][: 1 << 21]
+    assert lib.gorder_xtc_pack_window(r, 0.0, -1.0, 1, C.byref(st[0]), C.byref(st[1]), blob.ctypes.data, 1 << 21, C.byref(used),
+                                      C.cast(frames, C.c_void_p), box.ctypes.data, t2.ctypes.data, 3, 2) == 3      # maps all nine
+    os.truncate(shrinking, n5)                                        # frames 5.. are gone
+    got, tt = window(r, st)
+    assert got == 2 and list(tt) == [30.0, 40.0]                      # what is left, by pread; no fault
+    assert window(r, st)[0] == 0
+    lib.gorder_xtc_close(r)
+
+
 def test_pool_copies_the_same_bytes(built, tmp_path):
     a = synthetic(tmp_path, n_frames=29, name="a.xtc")
     b = synthetic(tmp_path, n_frames=11, seed=5, n_atoms=700, name="b.xtc")

@@ -22,6 +22,9 @@ run aa256-maps-timewise 3000 50 40
 run ua256-timewise 3000 50 40
 run aa256-cylinder 3000 50 40
 run cg3k-dynamic 512 10 4
+# fallback kernels real inputs can reach (round-3 review): membranes beyond 65 536 atoms, index-list membrane groups
+run cg1m-local-r2.5 64 3 2
+run aa256-leaflets-subset 4000 50 40
 python3 - <<PY
 import json
 for line in open("$OUT"):
