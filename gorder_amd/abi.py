@@ -309,7 +309,7 @@ _EXPORTS = [
     "gorder_hip_normals", "gorder_hip_export_maps", "gorder_hip_set_normals",
     "gorder_hip_accumulators_device", "gorder_hip_bind_accumulators", "gorder_hip_last_error_index", "gorder_hip_last_error_frame", "gorder_hip_kernel_time_names",
     "gorder_hip_last_error_message", "gorder_hip_strerror", "gorder_hip_kernel_time", "gorder_hip_kernel_time_group", "gorder_hip_plan",
-    "gorder_hip_plan_tables", "gorder_hip_selftest_arithmetic", "gorder_hip_run_trajectory",
+    "gorder_hip_plan_tables", "gorder_hip_selftest_arithmetic", "gorder_hip_selftest_trig", "gorder_hip_run_trajectory",
     "gorder_hip_comm_unique_id", "gorder_hip_comm_create", "gorder_hip_comm_destroy", "gorder_hip_allreduce",
     "gorder_hip_reset", "gorder_hip_xtc_decode", "gorder_hip_release_staging",
 ]
@@ -382,6 +382,7 @@ def load_library() -> C.CDLL:
     lib.gorder_hip_plan.argtypes = [vp, C.POINTER(CPlan)]
     lib.gorder_hip_plan_tables.argtypes = [C.POINTER(CTables), C.POINTER(CPlan), C.POINTER(i32)]
     lib.gorder_hip_selftest_arithmetic.argtypes = [i32, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.gorder_hip_selftest_trig.argtypes = [i32, i32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
     lib.gorder_hip_run_trajectory.argtypes = [vp, C.POINTER(CTrajectory), C.POINTER(CTrajectoryStats)]
     lib.gorder_hip_comm_unique_id.argtypes = [vp]
     lib.gorder_hip_comm_create.argtypes = [vp, vp, i32, i32, C.POINTER(vp)]
@@ -394,6 +395,16 @@ def load_library() -> C.CDLL:
     lib.gorder_hip_release_staging.restype = None
     _lib = lib
     return lib
+
+
+def selftest_trig(fn: str, first_bits: int, stride: int, n: int, device: int = 0) -> np.ndarray:
+    """The device's acos ('acos', 'acos_cores'), cos or sin of the floats with bit patterns first_bits + i * stride."""
+    lib = load_library()
+    out = np.empty(n, dtype=np.float32)
+    st = lib.gorder_hip_selftest_trig(device, {"acos": 0, "acos_cores": 1, "cos": 2, "sin": 3}[fn], first_bits, stride, n, out.ctypes.data)
+    if st != 0:
+        raise GorderHipError(st, "gorder_hip_selftest_trig")
+    return out
 
 
 def selftest_arithmetic(n: int = 1 << 26, seed: int = 1, device: int = 0):

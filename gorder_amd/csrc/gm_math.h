@@ -98,94 +98,89 @@ __device__ __forceinline__ float gm_wrap(float x, float L, int &bad) {
     return x;
 }
 
-// ---- trig kernels: acos on [-1,1], cos on [0,pi]; < 1 ulp (acos 0.78, cos 0.6 away from pi/2).
-// Coefficients from tools/derive_trig_coeffs.py (Remez fit, rounded to f32).
-#define GM_PIO2_HI 0x1.921fb6p+0f
-#define GM_PIO2_LO (-0x1.777a5cp-25f)
-#define GM_PI_HI 0x1.921fb6p+1f
-#define GM_PI_LO (-0x1.777a5cp-24f)
-#define GM_PIO4 0x1.921fb6p-1f
-#define GM_3PIO4 0x1.2d97c8p+1f
-
-__device__ __forceinline__ float gm_asin_r(float z) {
-    float p = 0x1.15e1a4p-5f;
-    p = __builtin_fmaf(p, z, 0x1.169f76p-6f);
-    p = __builtin_fmaf(p, z, 0x1.fe10bap-6f);
-    p = __builtin_fmaf(p, z, 0x1.6d55e6p-5f);
-    p = __builtin_fmaf(p, z, 0x1.333448p-4f);
-    p = __builtin_fmaf(p, z, 0x1.555554p-3f);
-    return p;
-}
+// ---- acos, cos, sin as the reference's libm computes them -------------------------------------------------------------
+// The reference evaluates `angle = acos(clamp(c))`, `angle.cos()` (mod.rs:78-82) and, for the unsaturated united-atom
+// carbon, `sin_cos` of pi - gamma / 2 (uaorder.rs:1024-1045) with Rust's f32 methods, which on linux-gnu are glibc's
+// acosf / cosf / sinf.  Rounds 1-3 used own polynomial kernels here (< 1 ulp, 1.6 % of the ticks one off).  Since round 4
+// these are RESTATEMENTS OF GLIBC'S ALGORITHMS (2.28 - 2.40: fdlibm's e_acosf.c; s_cosf.c / s_sinf.c of 2018, double
+// precision polynomials after a one-multiplication range reduction), operation for operation, so that the literal mode
+// (GORDER_FLAG_TRIG_ACOS_COS) and the united-atom construction give the libm's bits: the oracle restates the same
+// sequences (gorder_oracle_mirror_*), tests/test_oracle_kat.py compares those with the host's acosf / cosf / sinf over
+// their whole domains (0 mismatches on glibc 2.35; tools/microbench/libm_restatement.c is the exhaustive form), and the
+// device's sums are EQUAL to the oracle's LIBM mode.  Only the ranges the path can produce are implemented: acos on
+// [-1, 1] (else NaN), cos and sin on [0, pi] (the range of acos) and NaN.
+#define GM_ACOS_PI 3.1415925026e+00f
+#define GM_ACOS_PIO2_HI 1.5707962513e+00f
+#define GM_ACOS_PIO2_LO 7.5497894159e-08f
 
 __device__ __forceinline__ float gm_div_core(float n, float d);
 __device__ __forceinline__ float gm_sqrt_core(float x);
 
-// Branch-free (a wave almost always holds lanes of every range); the arithmetic of each range is
-// exactly the sequence restated in oracle/gorder_oracle.c (gorder_oracle_mirror_acosf).
-// CORES: the square root and the division of the |x| > 1/2 range by their Newton cores (gm_sqrt_core / gm_div_core
-// below).  Same bits: there z = (1 - |x|) / 2 is 0 or lies in [2^-25, 1/4) — inside the cores' guarded range, and
-// gm_sqrt_core(0) = 0 —, the divisor s + s in [2^-12, 1], and the numerator z - s^2 is 0 or at least 2^-74 in
-// magnitude (a multiple of ulp(s)^2); for |x| <= 1/2 both results are computed and discarded.
+// glibc sysdeps/ieee754/flt-32/e_acosf.c.  Branch-free (a wave almost always holds lanes of every range): z, the
+// rational p / q and the square root are common to the ranges, the three tails are selected.
+// CORES: the division p / q, the square root and the division of the x > 1/2 range by their Newton cores (gm_sqrt_core /
+// gm_div_core below).  Same bits: q lies in (0.3, 1]; where p is so small that v_div_fixup would matter (|x| < 2^-50) the
+// quotient does not reach the result; for |x| >= 1/2, z = (1 - |x|) / 2 is 0 or lies in [2^-25, 1/4], the divisor s + df
+// in [2^-12, 1] and z - df^2 is 0 or at least 2^-36 z (results for |x| = 1 and |x| <= 2^-57 are constants anyway).
 template <bool CORES = false>
 __device__ __forceinline__ float gm_acosf_t(float x) {
+    const float pS0 = 1.6666667163e-01f, pS1 = -3.2556581497e-01f, pS2 = 2.0121252537e-01f, pS3 = -4.0055535734e-02f,
+                pS4 = 7.9153501429e-04f, pS5 = 3.4793309169e-05f, qS1 = -2.4033949375e+00f, qS2 = 2.0209457874e+00f,
+                qS3 = -6.8828397989e-01f, qS4 = 7.7038154006e-02f;
+    const uint32_t hx = __float_as_uint(x), ix = hx & 0x7fffffffu;
+    const bool small = ix < 0x3f000000u;                                     // |x| < 1/2
     const float ax = __builtin_fabsf(x);
-    // both argument reductions share the polynomial: z = x^2 (|x| <= 1/2) or (1-|x|)/2
-    const bool small = ax <= 0.5f;
-    const float z = small ? x * x : (1.0f - ax) * 0.5f;
-    const float r = z * gm_asin_r(z);
-    const float r_small = GM_PIO2_HI - (x - (GM_PIO2_LO - x * r));
+    const float z = small ? x * x : (1.0f - ax) * 0.5f;                      // ((one + x) * 0.5 for x < 0: the same subtraction)
+    const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    const float r = CORES ? gm_div_core(p, q) : p / q;
     const float s = CORES ? gm_sqrt_core(z) : __builtin_sqrtf(z);
-    const float quo = CORES ? gm_div_core(__builtin_fmaf(-s, s, z), s + s) : __builtin_fmaf(-s, s, z) / (s + s);
-    const float c = (s > 0.0f) ? quo : 0.0f;
-    const float w = __builtin_fmaf(s, r, c);
-    const float r_pos = 2.0f * (s + w);
-    const float r_neg = 2.0f * (GM_PIO2_HI - (s + (w - GM_PIO2_LO)));
-    float r_large = x > 0.0f ? r_pos : r_neg;
-    // (the streaming kernel evaluates several frames as interleaved straight-line chains: keep the compiler from
-    // sinking this range's arithmetic into a branch on `small` — a wave always has lanes of both ranges)
-    if (CORES) asm volatile("" : "+v"(r_large));
-    float res = small ? r_small : r_large;
-    return (ax <= 1.0f) ? res : __builtin_nanf("");
+    const float r_small = GM_ACOS_PIO2_HI - (x - (GM_ACOS_PIO2_LO - x * r));
+    const float r_neg = GM_ACOS_PI - 2.0f * (s + (r * s - GM_ACOS_PIO2_LO));
+    const float df = __uint_as_float(__float_as_uint(s) & 0xfffff000u);
+    const float num = z - df * df, den = s + df;
+    const float c = CORES ? gm_div_core(num, den) : num / den;
+    float r_pos = 2.0f * (df + (r * s + c));
+    // (the streaming kernel evaluates several frames as interleaved straight-line chains: keep the compiler from sinking
+    // a range's arithmetic into a branch — a wave always has lanes of every range)
+    if (CORES) asm volatile("" : "+v"(r_pos));
+    float res = small ? r_small : ((hx >> 31) ? r_neg : r_pos);
+    res = ix <= 0x23000000u ? GM_ACOS_PIO2_HI + GM_ACOS_PIO2_LO : res;      // |x| <= 2^-57
+    res = ix == 0x3f800000u ? ((hx >> 31) ? GM_ACOS_PI + 2.0f * GM_ACOS_PIO2_LO : 0.0f) : res;
+    return ix > 0x3f800000u ? __builtin_nanf("") : res;                     // |x| > 1, NaN: (x - x) / (x - x)
 }
 __device__ __forceinline__ float gm_acosf(float x) { return gm_acosf_t<false>(x); }
 
-__device__ __forceinline__ float gm_kcos(float r) {
-    const float z = r * r;
-    const float zl = __builtin_fmaf(r, r, -z);
-    const float c = __builtin_fmaf(__builtin_fmaf(0x1.9bd908p-16f, z, -0x1.6c12d4p-10f), z, 0x1.555554p-5f);
-    const float hz = 0.5f * z;
-    const float w = 1.0f - hz;
-    return w + ((((1.0f - w) - hz) - 0.5f * zl) + z * (z * c));
+// glibc sysdeps/ieee754/flt-32/s_cosf.c + s_sinf.c + sincosf.h (reduce_fast, sinf_poly) for t in [0, pi] or NaN: the
+// argument in double, n = round(t * 2 / pi) by one multiplication and an integer shift (0, 1 or 2 here), the remainder
+// t - n * (pi / 2), then the cosine or the sine polynomial in double and ONE rounding to float.  The second table of
+// glibc (n & 2) holds the cosine coefficients negated: every operation is sign-symmetric, so that is the negated result.
+__device__ __forceinline__ void gm_sincosf_0pi(float t, float &sn, float &cs) {
+    const double hpi_inv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0;
+    const double c0 = 0x1p0, c1 = -0x1.ffffffd0c621cp-2, c2 = 0x1.55553e1068f19p-5, c3 = -0x1.6c087e89a359dp-10,
+                 c4 = 0x1.99343027bf8c3p-16, s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+    const uint32_t top = (__float_as_uint(t) >> 20) & 0x7ffu;               // abstop12
+    const bool first = top < 0x3f4u;                                        // abstop12(t) < abstop12(pi / 4): t < 0.75
+    const bool tiny = top < 0x398u;                                         // t < 2^-12: cos = 1, sin = t
+    const double x0 = (double)t;
+    const int n = first ? 0 : (((int)(x0 * hpi_inv) + 0x800000) >> 24);
+    const double x = first ? x0 : x0 - (double)n * hpi;
+    const double x2 = x * x;
+    // sinf_poly, odd n: the cosine
+    const double x4 = x2 * x2, cc2 = c3 + x2 * c4, cc1 = c0 + x2 * c1, x6 = x4 * x2, cc = cc1 + x4 * c2;
+    const float cosp = (float)(cc + x6 * cc2);
+    // sinf_poly, even n: the sine
+    const double x3 = x * x2, ss1 = s2 + x2 * s3, x7 = x3 * x2, ss = x + x3 * s1;
+    const float sinp = (float)(ss + x7 * ss1);
+    // cos: n = 0 cos(x), 1 -sin(x) (sign[1] = -1 on the odd polynomial), 2 -cos(x) (the negated table)
+    cs = n == 1 ? -sinp : (n == 2 ? -cosp : cosp);
+    // sin: n = 0 sin(x), 1 cos(x), 2 -sin(x)
+    sn = n == 1 ? cosp : (n == 2 ? -sinp : sinp);
+    cs = tiny ? 1.0f : cs;
+    sn = tiny ? t : sn;
 }
-__device__ __forceinline__ float gm_ksin(float r) {
-    const float z = r * r;
-    const float s = __builtin_fmaf(
-        __builtin_fmaf(__builtin_fmaf(0x1.6dbf02p-19f, z, -0x1.a013acp-13f), z, 0x1.11110ep-7f), z,
-        -0x1.555556p-3f);
-    return __builtin_fmaf(r * z, s, r);
-}
-// t in [0, pi] (the range of acos) or NaN.  Both kernels are evaluated and selected.
-__device__ __forceinline__ float gm_cosf(float t) {
-    const bool lo = t < GM_PIO4;
-    const bool mid = !lo && (t <= GM_3PIO4);
-    const float rc = lo ? t : (GM_PI_HI - t) + GM_PI_LO;
-    const float rs = (GM_PIO2_HI - t) + GM_PIO2_LO;
-    const float kc = gm_kcos(rc);
-    const float ks = gm_ksin(rs);
-    return mid ? ks : (lo ? kc : -kc);   // t = NaN: rc = NaN -> NaN
-}
-
-// sin on [0, pi] from the same two kernels (the rotation angle of the unsaturated-CH hydrogen, pi - gamma / 2,
-// uaorder.rs:1024-1045, lies in [pi/2, pi]); restated by oracle/gorder_oracle.c (gorder_oracle_mirror_sinf).
-__device__ __forceinline__ float gm_sinf_0pi(float t) {
-    const bool lo = t < GM_PIO4;
-    const bool mid = !lo && (t <= GM_3PIO4);
-    const float rs = lo ? t : (GM_PI_HI - t) + GM_PI_LO;
-    const float rc = (t - GM_PIO2_HI) - GM_PIO2_LO;
-    const float ks = gm_ksin(rs);
-    const float kc = gm_kcos(rc);
-    return mid ? kc : ks;                // t = NaN: NaN
-}
+__device__ __forceinline__ float gm_cosf(float t) { float s, c; gm_sincosf_0pi(t, s, c); return c; }
+__device__ __forceinline__ float gm_sinf_0pi(float t) { float s, c; gm_sincosf_0pi(t, s, c); return s; }
 
 // P2 of the angle between the bond vector v and the membrane normal n (calc_sch, mod.rs:78-82).
 //   n2 = |n|, n2sq = |n|^2, both precomputed on the host with nalgebra's f32 sequence.
@@ -285,99 +280,6 @@ __device__ __forceinline__ float gm_sch_axis_acos(float vx, float vy, float vz, 
     rare = rare || !(s2 >= 0x1p-40f && s2 <= 0x1p+40f);
     const float c = gm_div_core(prod, gm_sqrt_core(s2));
     const float co = gm_cosf(gm_acosf_t<true>(c));
-    return (1.5f * co * co) - 0.5f;
-}
-// ---- the same literal evaluation for TWO frames at a time in packed registers -----------------------------------------
-// v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 do two IEEE f32 operations per lane and instruction; lane 0 / lane 1 of a
-// gm_f2 hold the sample in two consecutive frames.  Every component goes through exactly the operations of the scalar
-// routines above (gm_sqrt_core, gm_div_core, gm_acosf_t<true>, gm_cosf) in the same order, so the bits are the same;
-// compares, selects, the hardware sqrt / rcp seeds and the integer steps are done per component.  The literal mode is
-// bound by VALU issue, not by memory, and about half of its instructions are multiplications, additions and fmas.
-typedef float gm_f2 __attribute__((ext_vector_type(2)));
-typedef int gm_i2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ gm_f2 gm2(float v) { return gm_f2{v, v}; }
-__device__ __forceinline__ gm_f2 gm2_fma(gm_f2 a, gm_f2 b, gm_f2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ gm_f2 gm2_min_image_step(gm_f2 d, gm_f2 L, gm_i2 &slow) {
-    const gm_f2 half = L / 2.0f;
-    const gm_f2 r = __builtin_elementwise_abs(d) > half ? d - __builtin_elementwise_copysign(L, d) : d;
-    slow |= __builtin_elementwise_abs(r) > half;
-    return r;
-}
-__device__ __forceinline__ gm_f2 gm2_sqrt_core(gm_f2 x) {
-    const gm_f2 s = gm_f2{__builtin_amdgcn_sqrtf(x.x), __builtin_amdgcn_sqrtf(x.y)};
-    const gm_i2 si = __builtin_bit_cast(gm_i2, s);
-    const gm_f2 sm = __builtin_bit_cast(gm_f2, si - 1), sp = __builtin_bit_cast(gm_f2, si + 1);
-    const gm_f2 rm = gm2_fma(-sm, s, x), rp = gm2_fma(-sp, s, x);
-    gm_f2 r = rm <= gm2(0.0f) ? sm : s;
-    r = rp > gm2(0.0f) ? sp : r;
-    return r;
-}
-__device__ __forceinline__ gm_f2 gm2_div_core(gm_f2 n, gm_f2 d) {
-    gm_f2 r = gm_f2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
-    const gm_f2 e = gm2_fma(-d, r, gm2(1.0f));
-    r = gm2_fma(e, r, r);
-    gm_f2 q = n * r;
-    const gm_f2 e2 = gm2_fma(-d, q, n);
-    q = gm2_fma(e2, r, q);
-    const gm_f2 e3 = gm2_fma(-d, q, n);
-    return gm2_fma(e3, r, q);
-}
-__device__ __forceinline__ gm_f2 gm2_asin_r(gm_f2 z) {
-    gm_f2 p = gm2(0x1.15e1a4p-5f);
-    p = gm2_fma(p, z, gm2(0x1.169f76p-6f));
-    p = gm2_fma(p, z, gm2(0x1.fe10bap-6f));
-    p = gm2_fma(p, z, gm2(0x1.6d55e6p-5f));
-    p = gm2_fma(p, z, gm2(0x1.333448p-4f));
-    p = gm2_fma(p, z, gm2(0x1.555554p-3f));
-    return p;
-}
-__device__ __forceinline__ gm_f2 gm2_acosf_cores(gm_f2 x) {       // gm_acosf_t<true>, |x| <= 1 (the caller's quotient)
-    const gm_f2 ax = __builtin_elementwise_abs(x);
-    const gm_i2 small = ax <= gm2(0.5f);
-    const gm_f2 z = small ? x * x : (gm2(1.0f) - ax) * 0.5f;
-    const gm_f2 r = z * gm2_asin_r(z);
-    const gm_f2 r_small = gm2(GM_PIO2_HI) - (x - (gm2(GM_PIO2_LO) - x * r));
-    const gm_f2 s = gm2_sqrt_core(z);
-    const gm_f2 quo = gm2_div_core(gm2_fma(-s, s, z), s + s);
-    const gm_f2 c = s > gm2(0.0f) ? quo : gm2(0.0f);
-    const gm_f2 w = gm2_fma(s, r, c);
-    const gm_f2 r_pos = 2.0f * (s + w);
-    const gm_f2 r_neg = 2.0f * (gm2(GM_PIO2_HI) - (s + (w - gm2(GM_PIO2_LO))));
-    gm_f2 r_large = x > gm2(0.0f) ? r_pos : r_neg;
-    asm volatile("" : "+v"(r_large));           // (see gm_acosf_t: keep this range's arithmetic out of a branch)
-    return small ? r_small : r_large;
-}
-__device__ __forceinline__ gm_f2 gm2_kcos(gm_f2 r) {
-    const gm_f2 z = r * r;
-    const gm_f2 zl = gm2_fma(r, r, -z);
-    const gm_f2 c = gm2_fma(gm2_fma(gm2(0x1.9bd908p-16f), z, gm2(-0x1.6c12d4p-10f)), z, gm2(0x1.555554p-5f));
-    const gm_f2 hz = 0.5f * z;
-    const gm_f2 w = gm2(1.0f) - hz;
-    return w + ((((gm2(1.0f) - w) - hz) - 0.5f * zl) + z * (z * c));
-}
-__device__ __forceinline__ gm_f2 gm2_ksin(gm_f2 r) {
-    const gm_f2 z = r * r;
-    const gm_f2 s = gm2_fma(gm2_fma(gm2_fma(gm2(0x1.6dbf02p-19f), z, gm2(-0x1.a013acp-13f)), z, gm2(0x1.11110ep-7f)), z,
-                            gm2(-0x1.555556p-3f));
-    return gm2_fma(r * z, s, r);
-}
-__device__ __forceinline__ gm_f2 gm2_cosf(gm_f2 t) {              // gm_cosf
-    const gm_i2 lo = t < gm2(GM_PIO4);
-    const gm_i2 mid = ~lo & (t <= gm2(GM_3PIO4));
-    const gm_f2 rc = lo ? t : (gm2(GM_PI_HI) - t) + gm2(GM_PI_LO);
-    const gm_f2 rs = (gm2(GM_PIO2_HI) - t) + gm2(GM_PIO2_LO);
-    const gm_f2 kc = gm2_kcos(rc);
-    const gm_f2 ks = gm2_ksin(rs);
-    return mid ? ks : (lo ? kc : -kc);
-}
-// gm_sch_axis_acos for the sample in two frames; `rare` gets the lanes' "recompute with the general routine" flags
-template <int AXIS>
-__device__ __forceinline__ gm_f2 gm2_sch_axis_acos(gm_f2 vx, gm_f2 vy, gm_f2 vz, gm_i2 &rare) {
-    const gm_f2 s2 = (vx * vx + vy * vy) + vz * vz;
-    const gm_f2 prod = AXIS == 0 ? vx : (AXIS == 1 ? vy : vz);
-    rare |= ~((s2 >= gm2(0x1p-40f)) & (s2 <= gm2(0x1p+40f)));
-    const gm_f2 c = gm2_div_core(prod, gm2_sqrt_core(s2));
-    const gm_f2 co = gm2_cosf(gm2_acosf_cores(c));
     return (1.5f * co * co) - 0.5f;
 }
 // gm_tick for a sample that is known not to be NaN (the caller's rare path takes those)

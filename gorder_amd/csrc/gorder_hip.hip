@@ -828,6 +828,33 @@ int gorder_hip_selftest_arithmetic(int device, uint64_t n, uint64_t seed, uint64
     return st;
 }
 
+namespace {
+__global__ void k_selftest_trig(int fn, uint32_t first_bits, uint32_t stride, uint32_t n, float *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = __uint_as_float(first_bits + i * stride);
+    float s, c;
+    gm_sincosf_0pi(x, s, c);
+    out[i] = fn == 0 ? gm_acosf_t<false>(x) : fn == 1 ? gm_acosf_t<true>(x) : fn == 2 ? c : s;
+}
+}  // namespace
+
+int gorder_hip_selftest_trig(int device, int fn, uint32_t first_bits, uint32_t stride, uint32_t n, float *out) {
+    if (!out || fn < 0 || fn > 3) return GORDER_ERR_INVALID_ARGUMENT;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return GORDER_ERR_NO_DEVICE;
+    if (device < 0 || device >= count || hipSetDevice(device) != hipSuccess) return GORDER_ERR_INVALID_ARGUMENT;
+    if (n == 0) return GORDER_OK;
+    float *d = nullptr;
+    if (hipMalloc((void **)&d, (size_t)n * sizeof(float)) != hipSuccess) return GORDER_ERR_DEVICE;
+    hipLaunchKernelGGL(k_selftest_trig, dim3((n + 255u) / 256u), dim3(256), 0, 0, fn, first_bits, stride, n, d);
+    int st = GORDER_OK;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out, d, (size_t)n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+        st = GORDER_ERR_DEVICE;
+    (void)hipFree(d);
+    return st;
+}
+
 int gorder_hip_plan_tables(const gorder_tables_t *tables, gorder_hip_plan_t *out, int *selfcheck) {
     if (!tables || !out) return GORDER_ERR_INVALID_ARGUMENT;
     Plan p;

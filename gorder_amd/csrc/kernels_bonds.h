@@ -175,28 +175,6 @@ struct TiledStage {
             }
             if (LEAF) fl[k] = a.aflags[(size_t)a.arow[f0 + k] * a.n_mol_total + it.mol];
         }
-        if (ACOS_COS && AXIS >= 0) {
-            // the reference's literal acos -> cos round trip, static normal along an axis: two frames per packed
-            // operation (gm2_sch_axis_acos) — this mode is bound by VALU issue
-            static_assert(!(ACOS_COS && AXIS >= 0) || NF % 2 == 0, "frames in pairs");
-#pragma unroll
-            for (int k = 0; k + 1 < NF; k += 2) {
-                gm_f2 vx = gm_f2{P[k][3], P[k + 1][3]} - gm_f2{P[k][0], P[k + 1][0]};
-                gm_f2 vy = gm_f2{P[k][4], P[k + 1][4]} - gm_f2{P[k][1], P[k + 1][1]};
-                gm_f2 vz = gm_f2{P[k][5], P[k + 1][5]} - gm_f2{P[k][2], P[k + 1][2]};
-                gm_i2 slow2 = {0, 0};
-                if (PBC) {
-                    vx = gm2_min_image_step(vx, gm_f2{bx[k], bx[k + 1]}, slow2);
-                    vy = gm2_min_image_step(vy, gm_f2{by[k], by[k + 1]}, slow2);
-                    vz = gm2_min_image_step(vz, gm_f2{bz[k], bz[k + 1]}, slow2);
-                }
-                const gm_f2 sch = gm2_sch_axis_acos<AXIS < 0 ? 0 : AXIS>(vx, vy, vz, slow2);
-                rare |= (slow2.x ? 1u : 0u) << k;
-                rare |= (slow2.y ? 1u : 0u) << (k + 1);
-                tick[k] = gm_tick_finite(sch.x);
-                tick[k + 1] = gm_tick_finite(sch.y);
-            }
-        } else
 #pragma unroll
         for (int k = 0; k < NF; k++) {
             float vx = P[k][3] - P[k][0], vy = P[k][4] - P[k][1], vz = P[k][5] - P[k][2];

@@ -440,6 +440,11 @@ int gorder_hip_plan_tables(const gorder_tables_t *tables, gorder_hip_plan_t *pla
  * mismatches[0] division, mismatches[1] square root and the acos kernel with the cores inside against the same kernel
  * with IEEE operations (arguments over all of [-1, 1]).  Both must be 0. */
 int gorder_hip_selftest_arithmetic(int device, uint64_t n, uint64_t seed, uint64_t mismatches[2]);
+/* Diagnostic: the device's acos (fn 0; 1: with the division / square-root cores inside), cos (2) and sin (3) — restatements
+ * of glibc's acosf / cosf / sinf algorithms, gm_math.h — of the `n` floats with bit patterns first_bits + i * stride, into
+ * the HOST array `out`: to be compared with the host's libm (tests/test_parity_gpu.py does, over all of [-1, 1] and
+ * [0, pi] in strides). */
+int gorder_hip_selftest_trig(int device, int fn, uint32_t first_bits, uint32_t stride, uint32_t n, float *out);
 
 #ifdef __cplusplus
 }

@@ -81,67 +81,106 @@ int gorder_oracle_vector_to(const float p1[3], const float p2[3], const float bo
 static inline float dot3(const float *a, const float *b) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
 static inline float norm3(const float *a) { return sqrtf(dot3(a, a)); }
 
-/* ---- MIRROR-mode trig: restatement of gorder_amd/csrc/gm_math.h (same operations, same order) */
-static const float M_PIO2_HI = 0x1.921fb6p+0f, M_PIO2_LO = -0x1.777a5cp-25f;
-static const float M_PI_HI = 0x1.921fb6p+1f, M_PI_LO = -0x1.777a5cp-24f;
-static const float M_PIO4 = 0x1.921fb6p-1f, M_3PIO4 = 0x1.2d97c8p+1f;
-
-static inline float m_asin_r(float z) {
-    float p = 0x1.15e1a4p-5f;
-    p = fmaf(p, z, 0x1.169f76p-6f);
-    p = fmaf(p, z, 0x1.fe10bap-6f);
-    p = fmaf(p, z, 0x1.6d55e6p-5f);
-    p = fmaf(p, z, 0x1.333448p-4f);
-    p = fmaf(p, z, 0x1.555554p-3f);
-    return p;
-}
+/* ---- MIRROR-mode trig.  Rounds 1-3: a restatement of the device's own polynomial kernels.  Since round 4 the device
+ * computes acos / cos / sin the way glibc does (gorder_amd/csrc/gm_math.h), and these are the same restatements of
+ * glibc 2.28 - 2.40's algorithms — sysdeps/ieee754/flt-32/e_acosf.c (fdlibm), s_cosf.c / s_sinf.c / sincosf.h (2018:
+ * reduce_fast + sinf_poly in double) — written from the published algorithms, on the domains the path can produce
+ * (acos on [-1, 1], cos and sin on [0, pi]).  On a host whose libm IS such a glibc they equal acosf / cosf / sinf bit for
+ * bit (tests/test_oracle_kat.py checks that over the whole domains), i.e. MIRROR = LIBM there; on a host with another
+ * libm MIRROR still says what the DEVICE computes. */
+static inline uint32_t f_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float bits_f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
 float gorder_oracle_mirror_acosf(float x) {
-    const float ax = fabsf(x);
-    if (!(ax <= 1.0f)) return NAN;
-    if (ax <= 0.5f) {
-        const float z = x * x;
-        const float r = z * m_asin_r(z);
-        return M_PIO2_HI - (x - (M_PIO2_LO - x * r));
+    static const float one = 1.0f, pi = 3.1415925026e+00f, pio2_hi = 1.5707962513e+00f, pio2_lo = 7.5497894159e-08f,
+        pS0 = 1.6666667163e-01f, pS1 = -3.2556581497e-01f, pS2 = 2.0121252537e-01f, pS3 = -4.0055535734e-02f,
+        pS4 = 7.9153501429e-04f, pS5 = 3.4793309169e-05f, qS1 = -2.4033949375e+00f, qS2 = 2.0209457874e+00f,
+        qS3 = -6.8828397989e-01f, qS4 = 7.7038154006e-02f;
+    float z, p, q, r, w, s, c, df;
+    const int32_t hx = (int32_t)f_bits(x), ix = hx & 0x7fffffff;
+    if (ix == 0x3f800000) return hx > 0 ? 0.0f : pi + 2.0f * pio2_lo;      /* |x| = 1 */
+    if (ix > 0x3f800000) return (x - x) / (x - x);                          /* |x| > 1, NaN */
+    if (ix < 0x3f000000) {                                                  /* |x| < 0.5 */
+        if (ix <= 0x23000000) return pio2_hi + pio2_lo;                     /* |x| <= 2^-57 */
+        z = x * x;
+        p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        r = p / q;
+        return pio2_hi - (x - (pio2_lo - x * r));
     }
-    const float z = (1.0f - ax) * 0.5f;
-    const float s = sqrtf(z);
-    const float r = z * m_asin_r(z);
-    const float c = (s > 0.0f) ? fmaf(-s, s, z) / (s + s) : 0.0f;
-    float w = fmaf(s, r, c);
-    if (x > 0.0f) return 2.0f * (s + w);
-    w = w - M_PIO2_LO;
-    return 2.0f * (M_PIO2_HI - (s + w));
+    if (hx < 0) {                                                           /* x < -0.5 */
+        z = (one + x) * 0.5f;
+        p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        s = sqrtf(z);
+        r = p / q;
+        w = r * s - pio2_lo;
+        return pi - 2.0f * (s + w);
+    }
+    z = (one - x) * 0.5f;                                                   /* x > 0.5 */
+    s = sqrtf(z);
+    df = bits_f(f_bits(s) & 0xfffff000u);
+    c = (z - df * df) / (s + df);
+    p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    r = p / q;
+    w = r * s + c;
+    return 2.0f * (df + w);
 }
 
-static inline float m_kcos(float r) {
-    const float z = r * r;
-    const float zl = fmaf(r, r, -z);
-    const float c = fmaf(fmaf(0x1.9bd908p-16f, z, -0x1.6c12d4p-10f), z, 0x1.555554p-5f);
-    const float hz = 0.5f * z;
-    const float w = 1.0f - hz;
-    return w + ((((1.0f - w) - hz) - 0.5f * zl) + z * (z * c));
+/* sincosf.h: sinf_poly (even n: the sine, odd n: the cosine; `neg`: glibc's second table = negated cosine coefficients) */
+static inline float m_sinf_poly(double x, double x2, int neg, int n) {
+    static const double c0 = 0x1p0, c1 = -0x1.ffffffd0c621cp-2, c2 = 0x1.55553e1068f19p-5, c3 = -0x1.6c087e89a359dp-10,
+                        c4 = 0x1.99343027bf8c3p-16, s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7,
+                        s3 = -0x1.994eb3774cf24p-13;
+    if ((n & 1) == 0) {
+        const double x3 = x * x2, t1 = s2 + x2 * s3, x7 = x3 * x2, s = x + x3 * s1;
+        return (float)(s + x7 * t1);
+    }
+    const double sg = neg ? -1.0 : 1.0;
+    const double x4 = x2 * x2, t2 = sg * c3 + x2 * (sg * c4), t1 = sg * c0 + x2 * (sg * c1), x6 = x4 * x2, c = t1 + x4 * (sg * c2);
+    return (float)(c + x6 * t2);
 }
-static inline float m_ksin(float r) {
-    const float z = r * r;
-    const float s =
-        fmaf(fmaf(fmaf(0x1.6dbf02p-19f, z, -0x1.a013acp-13f), z, 0x1.11110ep-7f), z, -0x1.555556p-3f);
-    return fmaf(r * z, s, r);
+static inline double m_reduce_fast(double x, int *np) {
+    const double r = x * 0x1.45F306DC9C883p+23;
+    const int n = ((int32_t)r + 0x800000) >> 24;
+    *np = n;
+    return x - n * 0x1.921FB54442D18p0;
 }
-/* valid for t in [0, pi] (the range of acos); NaN propagates */
+static inline uint32_t m_abstop12(float x) { return (f_bits(x) >> 20) & 0x7ffu; }
+static const double m_sign[4] = {1.0, -1.0, -1.0, 1.0};
+/* valid for t in [0, pi] (the range of acos; glibc's own range of this branch is |t| < 120); NaN propagates */
 float gorder_oracle_mirror_cosf(float t) {
-    if (t < M_PIO4) return m_kcos(t);
-    if (t <= M_3PIO4) return m_ksin((M_PIO2_HI - t) + M_PIO2_LO);
+    double x = t;
+    int n;
     if (t != t) return t;
-    return -m_kcos((M_PI_HI - t) + M_PI_LO);
+    if (m_abstop12(t) < m_abstop12(0x1.921FB6p-1f)) {
+        if (m_abstop12(t) < m_abstop12(0x1p-12f)) return 1.0f;
+        return m_sinf_poly(x, x * x, 0, 1);
+    }
+    x = m_reduce_fast(x, &n);
+    return m_sinf_poly(x * m_sign[n & 3], x * x, (n & 2) != 0, n ^ 1);
 }
-
-/* sin on [0, pi], the device's sequence (gm_math.h: gm_sinf_0pi) */
 float gorder_oracle_mirror_sinf(float t) {
-    if (t < M_PIO4) return m_ksin(t);
-    if (t <= M_3PIO4) return m_kcos((t - M_PIO2_HI) - M_PIO2_LO);
+    double x = t;
+    int n;
     if (t != t) return t;
-    return m_ksin((M_PI_HI - t) + M_PI_LO);
+    if (m_abstop12(t) < m_abstop12(0x1.921FB6p-1f)) {
+        if (m_abstop12(t) < m_abstop12(0x1p-12f)) return t;
+        return m_sinf_poly(x, x * x, 0, 0);
+    }
+    x = m_reduce_fast(x, &n);
+    return m_sinf_poly(x * m_sign[n & 3], x * x, (n & 2) != 0, n);
+}
+/* batch forms for the tests: fn 0 acos, 1 cos, 2 sin of the floats with bit patterns first + i * stride; which = 0 the
+ * restatement above, 1 the host's libm */
+void gorder_oracle_trig_batch(int fn, int which, uint32_t first_bits, uint32_t stride, uint32_t n, float *out) {
+    for (uint32_t i = 0; i < n; i++) {
+        const float x = bits_f(first_bits + i * stride);
+        out[i] = fn == 0 ? (which ? acosf(x) : gorder_oracle_mirror_acosf(x))
+               : fn == 1 ? (which ? cosf(x) : gorder_oracle_mirror_cosf(x))
+                         : (which ? sinf(x) : gorder_oracle_mirror_sinf(x));
+    }
 }
 
 /* [3rd-party] nalgebra Matrix::angle, reached through groan_rs Vector3D::angle (mod.rs:79):

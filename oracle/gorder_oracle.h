@@ -74,6 +74,9 @@ float gorder_oracle_calc_order(int64_t sum, uint64_t n, uint64_t min_samples);
 float gorder_oracle_mirror_acosf(float x);
 float gorder_oracle_mirror_cosf(float x);
 float gorder_oracle_mirror_sinf(float x);   /* x in [0, pi] */
+/* fn 0 acos, 1 cos, 2 sin of the floats with bit patterns first_bits + i * stride (i < n); which = 0 the restatement of
+ * glibc's algorithms above (= what the device computes), 1 the host's libm */
+void gorder_oracle_trig_batch(int fn, int which, uint32_t first_bits, uint32_t stride, uint32_t n, float *out);
 /* UA hydrogen construction (uaorder.rs:947-1104); pos = [4][3] in the order of `indices`;
  * out = [n_h][3]; returns n_h */
 /* the device's GORDER_FLAG_UA_FAST_NORMALISE construction restated (hydrogens, vectors target -> H, and whether the

@@ -58,6 +58,8 @@ def load():
     lib.gorder_oracle_tick.restype = C.c_int64
     lib.gorder_oracle_calc_order.argtypes = [C.c_int64, u64, u64]
     lib.gorder_oracle_calc_order.restype = f32
+    lib.gorder_oracle_trig_batch.argtypes = [i32, i32, u32, u32, u32, vp]
+    lib.gorder_oracle_trig_batch.restype = None
     lib.gorder_oracle_mirror_acosf.argtypes = [f32]
     lib.gorder_oracle_mirror_acosf.restype = f32
     lib.gorder_oracle_mirror_cosf.argtypes = [f32]
@@ -93,6 +95,15 @@ def vector_to(p1, p2, box, pbc=True):
                                       out.ctypes.data)
     if bad:
         raise OracleError(103)
+    return out
+
+
+def trig_batch(fn: str, which: str, first_bits: int, stride: int, n: int) -> np.ndarray:
+    """acos / cos / sin of the floats with bit patterns first_bits + i * stride: which = 'mirror' (the restatement of
+    glibc's algorithms = what the device computes) or 'libm' (the host's)."""
+    out = np.empty(n, dtype=np.float32)
+    load().gorder_oracle_trig_batch({"acos": 0, "cos": 1, "sin": 2}[fn], {"mirror": 0, "libm": 1}[which], first_bits, stride, n,
+                                    out.ctypes.data)
     return out
 
 

@@ -254,6 +254,30 @@ def test_united_atoms(built, monkeypatch, leaflets, pbc, lanes):
     assert np.all(s >= -0.5 - 1e-6) and np.all(s <= 1.0 + 1e-6)
 
 
+@pytest.mark.parametrize("leaflets", [LEAFLETS_NONE, LEAFLETS_GLOBAL])
+def test_united_atoms_in_the_literal_mode_are_the_references_arithmetic(built, leaflets):
+    """GORDER_FLAG_TRIG_ACOS_COS on united atoms: the construction is IEEE f32 operation for operation, the one
+    data-dependent angle (unsaturated CH: acos, sin, cos) and P2's acos -> cos go through restatements of glibc's
+    algorithms — so on a glibc 2.28 - 2.40 host the device's integers are those of the reference-faithful (libm) oracle."""
+    import platform
+    system = synthetic.ua_membrane(48, leaflets=leaflets)
+    system.tables.flags = abi.FLAG_TRIG_ACOS_COS
+    n = 9
+    xyz = system.frames(n, seed=14)
+    eng, o, got, want = both(system, xyz, system.box9(n))           # (MIRROR mode)
+    np.testing.assert_array_equal(got.counts, want.counts)
+    np.testing.assert_array_equal(got.sums, want.sums)
+    ref = oracle.OracleEngine(system.tables, trig=oracle.TRIG_LIBM)
+    ref.submit(xyz, system.box9(n))
+    libm = ref.finish()
+    assert np.abs(got.order_ticks() - libm.order_ticks()).max() <= 1
+    if platform.libc_ver()[0] == "glibc" and "2.28" <= platform.libc_ver()[1] <= "2.40":
+        flags, _ = eng.leaflets() if leaflets else (None, None)
+        np.testing.assert_array_equal(got.sums[0], libm.sums[0])
+        if not leaflets:
+            np.testing.assert_array_equal(got.sums, libm.sums)
+
+
 @pytest.mark.parametrize("lanes,n_lipids", [("4 slots x 16 molecules", 16), ("4 slots x 16 molecules", 100), ("a slot per wave", 70)])
 def test_united_atoms_with_maps_and_timewise(built, monkeypatch, lanes, n_lipids):
     if lanes == "a slot per wave":

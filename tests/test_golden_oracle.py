@@ -134,6 +134,39 @@ def test_ua_order_basic(ua):
     assert not bad, bad[:10]
 
 
+def test_ua_fast_mode_of_the_oracle(ua):
+    """GORDER_FLAG_UA_FAST_NORMALISE (include/gorder_hip.h): the oracle's non-libm modes restate the DEVICE's
+    tolerance-bounded construction when the flag is in the tables (tests/test_ua_fast_gpu.py compares the two bit for
+    bit); the libm mode — the reference's arithmetic — ignores it.  Here, without a GPU: the fast construction still
+    reproduces the reference's golden file within its tolerance, every order parameter stays within one 1e-6 tick of the
+    libm mode, and single samples move in a bounded fraction of the cases (profiles/r04_ua_fast_fidelity.json)."""
+    from gorder_amd.abi import FLAG_UA_FAST_NORMALISE
+    tables, labels, midx = ua_setup(ua, leaflets=METHODS["global"])
+    frames = ua.window()
+    xyz = master_frames(ua, midx, frames)
+
+    def run(trig, flag):
+        tables.flags = FLAG_UA_FAST_NORMALISE if flag else 0
+        eng = oracle.OracleEngine(tables, trig=trig, n_threads=4)
+        eng.submit(xyz, ua.boxes[frames], frames)
+        return eng, eng.finish()
+    _, libm = run(oracle.TRIG_LIBM, False)
+    _, libm_flag = run(oracle.TRIG_LIBM, True)
+    np.testing.assert_array_equal(libm.sums, libm_flag.sums)               # the reference-faithful mode ignores the flag
+    _, plain = run(oracle.TRIG_DIRECT, False)
+    eng, fast = run(oracle.TRIG_DIRECT, True)
+    assert not np.array_equal(plain.sums, fast.sums)                        # ... the device-restating mode does not
+    np.testing.assert_array_equal(fast.counts, libm.counts)
+    assert np.abs(fast.order_ticks() - libm.order_ticks()).max() <= 1
+    bad = st.compare_trees(st.results_tree_ua(fast, labels, leaflets=True), expected("ua_order_leaflets.yaml"))
+    assert not bad, bad[:10]
+    fid = eng.ua_fast_fidelity(xyz[:10], ua.boxes[frames][:10])
+    assert fid["samples"] == 10 * int(libm.counts[0].sum()) // len(frames)
+    assert fid["fraction_moved"] < 0.12 and fid["fraction_moved_by_more_than_one_tick"] < 0.03
+    assert abs(fid["mean_shift_ticks"]) < 0.02 and fid["carbons_sent_to_the_literal_loops"] == 0
+    assert fid["fraction_moved_default_path"] < fid["fraction_moved"]
+
+
 @pytest.mark.parametrize("method,frequency", [("global", 1), ("local", 5), ("individual", 100), ("global", 0)])
 def test_ua_order_leaflets(ua, method, frequency):
     # tests_ua.rs:147-200: every method and every frequency reproduces ua_order_leaflets.yaml

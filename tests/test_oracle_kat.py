@@ -63,6 +63,31 @@ def test_mirror_trig_accuracy(built):
     assert oracle.mirror_acosf(1.0) == 0.0 and oracle.mirror_cosf(0.0) == 1.0
 
 
+def _trig_domains():
+    """(fn, first bit pattern, last bit pattern) of the float ranges the path can hand to acos / cos / sin: acos on [-1, 1]
+    (both signs), cos and sin on [0, pi]"""
+    one, pi = 0x3f800000, 0x40490fdb
+    return [("acos", 0x00000000, one), ("acos", 0x80000000, 0x80000000 + one), ("cos", 0, pi), ("sin", 0, pi)]
+
+
+@pytest.mark.parametrize("stride", [61, 1021])
+def test_mirror_trig_is_the_hosts_libm(built, stride):
+    """MIRROR restates glibc's acosf / cosf / sinf algorithms (what the device computes since round 4).  On this image
+    (glibc 2.35) the restatement must BE the libm: every `stride`-th float of the whole domains, plus the ends, bit for
+    bit — tools/microbench/libm_restatement.c is the exhaustive form of this test (0 mismatches in 4.3e9 evaluations)."""
+    import platform
+    if platform.libc_ver()[0] != "glibc" or not ("2.28" <= platform.libc_ver()[1] <= "2.40"):
+        pytest.skip("the host's libm is not a glibc 2.28 - 2.40: MIRROR then restates the device, LIBM the host")
+    for fn, lo, hi in _trig_domains():
+        n = (hi - lo) // stride + 1
+        a = oracle.trig_batch(fn, "mirror", lo, stride, n)
+        b = oracle.trig_batch(fn, "libm", lo, stride, n)
+        np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+        for edge in (lo, hi, hi - 1, lo + 1):
+            np.testing.assert_array_equal(oracle.trig_batch(fn, "mirror", edge, 1, 1).view(np.uint32),
+                                          oracle.trig_batch(fn, "libm", edge, 1, 1).view(np.uint32))
+
+
 def test_min_image_semantics(built):
     box = [4.0, 4.0, 4.0]
     np.testing.assert_allclose(oracle.vector_to([1, 2, 3], [3.5, 1, 0.5], box), [-1.5, -1, 1.5], atol=1e-6)

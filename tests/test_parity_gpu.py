@@ -48,6 +48,10 @@ def run_gpu(system, xyz, box, frame_index=None, host=False, batches=1):
     return eng, res
 
 
+import platform   # noqa: E402
+LIBM_IS_GLIBC = platform.libc_ver()[0] == "glibc" and "2.28" <= platform.libc_ver()[1] <= "2.40"
+
+
 def run_oracle(system, xyz, box, frame_index=None, trig=None, n_threads=1):
     if trig is None:   # the oracle mode that restates the device library's cosine evaluation
         trig = oracle.TRIG_MIRROR if (system.tables.flags & abi.FLAG_TRIG_ACOS_COS) else oracle.TRIG_DIRECT
@@ -78,6 +82,10 @@ def assert_parity(system, xyz, box, frame_index=None, **kw):
     _, libm = run_oracle(system, xyz, box, frame_index, trig=oracle.TRIG_LIBM)
     np.testing.assert_array_equal(got.counts, libm.counts)
     assert_within_tolerance(got, libm)
+    if (system.tables.flags & abi.FLAG_TRIG_ACOS_COS) and LIBM_IS_GLIBC and system.tables.leaflets.method in (0, 4):
+        # the literal mode computes acos and cos as glibc does: with this libm the device's sums ARE the reference-faithful
+        # oracle's, bit for bit (no leaflets or a manual assignment: nothing else could differ)
+        np.testing.assert_array_equal(got.sums, libm.sums)
     return eng, got
 
 
@@ -291,6 +299,27 @@ def test_division_and_sqrt_cores_equal_the_ieee_operations(built):
     torch_cuda()
     assert abi.selftest_arithmetic(1 << 27, seed=20240213) == (0, 0)
     assert abi.selftest_arithmetic(1 << 24, seed=7) == (0, 0)
+
+
+def test_device_trig_is_the_hosts_libm(built):
+    """gm_acosf_t / gm_sincosf_0pi (gm_math.h) restate glibc's acosf / cosf / sinf: every 257th float of [-1, 1] and of
+    [0, pi] through the device (acos also with the Newton cores of division and square root inside) against the oracle's
+    restatement — and against the host's libm where that is such a glibc: bit for bit."""
+    import platform
+    torch_cuda()
+    from test_oracle_kat import _trig_domains
+    glibc = platform.libc_ver()[0] == "glibc" and "2.28" <= platform.libc_ver()[1] <= "2.40"
+    stride = 257
+    for fn, lo, hi in _trig_domains():
+        n = (hi - lo) // stride + 1
+        want = oracle.trig_batch(fn, "mirror", lo, stride, n).view(np.uint32)
+        for dev_fn in ([fn] if fn != "acos" else ["acos", "acos_cores"]):
+            got = abi.selftest_trig(dev_fn, lo, stride, n).view(np.uint32)
+            np.testing.assert_array_equal(got, want)
+        if glibc:
+            np.testing.assert_array_equal(want, oracle.trig_batch(fn, "libm", lo, stride, n).view(np.uint32))
+    # out of range: NaN like (x - x) / (x - x)
+    assert np.isnan(abi.selftest_trig("acos", 0x3f800001, 1, 4)).all() and np.isnan(abi.selftest_trig("acos", 0x7fc00000, 1, 1)).all()
 
 
 def test_errors_mirror_the_reference(built):
