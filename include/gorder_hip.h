@@ -170,8 +170,15 @@ typedef struct {
  *   reference pipeline with glibc's acosf / cosf (tools/trig_fidelity.c): 5.9 % of samples move by one 1e-6 tick, never
  *   more, mean shift 2.6e-10 — inside the 1e-6 parity tolerance but NOT bit-identical to the reference.  The squared
  *   form also has half the exponent range (|v| below ~1e-19 nm or above ~1e19 nm is no longer the reference's value).
- * GORDER_FLAG_TRIG_ACOS_COS: evaluate the literal acos -> cos round trip like the reference (own f32 polynomial
- *   kernels, < 1 ulp each; 1.6 % of samples move by one tick vs glibc 2.35).
+ * GORDER_FLAG_TRIG_ACOS_COS: evaluate the literal acos -> cos round trip like the reference, with acos and cos computed
+ *   BY GLIBC'S ALGORITHMS (restatements of glibc 2.28 - 2.40's acosf and cosf, gm_math.h; rounds 1-3 used own polynomial
+ *   kernels, 1.6 % of the ticks one off).  Rust's f32::acos / f32::cos are the platform libm's acosf / cosf: against a
+ *   reference built on such a glibc the order sums of this mode are the reference's integers — EQUAL to the oracle's LIBM
+ *   mode in the tests, the device's acos / cos / sin compared with the host's over their whole domains
+ *   (gorder_hip_selftest_trig).  The price is the f64 polynomial of glibc's cosf: 51 % of the HBM roofline on the
+ *   256-lipid membrane where the default runs at 80 %.
+ *   The one data-dependent angle of the united-atom construction (unsaturated CH: acos, sin, cos, uaorder.rs:1024-1045)
+ *   goes through the same restatements in EVERY mode.
  * GORDER_FLAG_UA_FAST_NORMALISE (united atoms only, opt-in, default off): the virtual-hydrogen construction
  *   (uaorder.rs:947-1104) with tolerance-bounded arithmetic instead of the reference's operation sequence — a / |a| as
  *   a * rsqrt(|a|^2) (integer seed + three Newton steps, relative error ~1e-7 where the reference's two roundings leave
