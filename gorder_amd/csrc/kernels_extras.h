@@ -974,10 +974,15 @@ __device__ __noinline__ UaBonds ua_carbon_slow(uint32_t kind, UaCarbon c, UaCons
 
 // sums of an int over the DPP rows of a wave (16 lanes each; row shifts: every lane of the wave must be here): lane 15 of
 // a row gets the row's sum
-template <int CTRL>
-__device__ __forceinline__ int ua_dpp_add(int v) { return v + __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ int ua_dpp_add(int v) { return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, true); }
 __device__ __forceinline__ int ua_row_sum(int v) {
     v = ua_dpp_add<0x111>(v); v = ua_dpp_add<0x112>(v); v = ua_dpp_add<0x114>(v); v = ua_dpp_add<0x118>(v);
+    return v;
+}
+// ... and on over the rows (row broadcasts): lane 63 gets the wave's sum
+__device__ __forceinline__ int ua_rows_to_wave(int v) {
+    v = ua_dpp_add<0x142, 0xa>(v); v = ua_dpp_add<0x143, 0xc>(v);
     return v;
 }
 
@@ -1052,6 +1057,10 @@ __device__ __forceinline__ void ua_extras_body(FrameArgs a_in, ExtraArgs e, cons
     __syncthreads();
     const bool tw_waves = GENERAL && e.tw && l_mixed == 0u;                     // (uniform over the workgroup)
     const int nh_wave = GENERAL ? (__any(row_nh > 2) ? 3 : (__any(row_nh > 1) ? 2 : 1)) : 0;      // (uniform over the wave)
+    // all four rows of the wave hold the same slot (a slot per wave: the lane order of per-frame rows alone): one lane of the
+    // wave sends the sums instead of one per row
+    const bool wave_one_slot = GENERAL && __all(row_nh == 0 || (row_slot0 == (uint32_t)__builtin_amdgcn_readfirstlane((int)row_slot0) &&
+                                                                  row_nh == __builtin_amdgcn_readfirstlane(row_nh)));
     long long s_tot[3] = {0, 0, 0}, s_up[3] = {0, 0, 0};
     uint32_t n_tot[3] = {0, 0, 0}, n_up[3] = {0, 0, 0};
     int bad = 0;
@@ -1162,11 +1171,16 @@ __device__ __forceinline__ void ua_extras_body(FrameArgs a_in, ExtraArgs e, cons
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 if (k >= nh_wave) break;                            // (uniform)
-                const int s_all = ua_row_sum(tw_s[k]), s_low = ua_row_sum(tw_sl[k]), n = ua_row_sum(tw_n[k]);
+                int s_all = ua_row_sum(tw_s[k]), s_low = ua_row_sum(tw_sl[k]), n = ua_row_sum(tw_n[k]);
+                if (wave_one_slot) { s_all = ua_rows_to_wave(s_all); s_low = ua_rows_to_wave(s_low); n = ua_rows_to_wave(n); }
                 const uint32_t n_all = (uint32_t)n & 0xffffu, n_low = (uint32_t)n >> 16;
-                if ((tid & 15u) == 15u && k < row_nh && n_all) {
+                const bool sender = wave_one_slot ? (tid & 63u) == 63u : (tid & 15u) == 15u;
+                // (a wave that ends inside the tile: its last rows are idle, the wave's slot is that of its first lane)
+                const int send_nh = wave_one_slot ? __builtin_amdgcn_readfirstlane(row_nh) : row_nh;
+                const uint32_t send_slot0 = wave_one_slot ? (uint32_t)__builtin_amdgcn_readfirstlane((int)row_slot0) : row_slot0;
+                if (sender && k < send_nh && n_all) {
                     const size_t row = ((size_t)e.tw_row0 + f) * 3u * a.n_acc;
-                    const uint32_t slot = row_slot0 + (uint32_t)k;
+                    const uint32_t slot = send_slot0 + (uint32_t)k;
                     atomicAdd(&e.tw_sums[row + slot], (unsigned long long)(long long)s_all);
                     atomicAdd(&e.tw_cnts[row + slot], (unsigned long long)n_all);
                     if (a.leaflets) {
