@@ -917,12 +917,16 @@ __global__ __launch_bounds__(1024) void k_local_build(LocalArgs a) {
     const float *x = a.xyz + (size_t)f * a.n_atoms * 3u;
     int bad = 0;
     bool in_halo = false;
+    // cells per length, once (an atom within an ulp or two of a cell edge may land in the neighbour of the cell the
+    // division wa / L * n would give: the consumers' margins — 4e-4 r^2 and 1e-3 of a cell in the rows kernel, cells
+    // 1.0001 r / k wide in the general passes — are orders of magnitude wider; membership itself is always the exact test)
+    const float inv_a = a.pbc ? (float)nca / box[da] : 0.0f, inv_b = a.pbc ? (float)ncb / box[db] : 0.0f;
     auto cell_ab = [&](float xa, float xb) -> uint32_t {
         in_halo = false;
         if (!a.pbc) return 0u;
         const float wa = gm_wrap(xa, box[da], bad), wb = gm_wrap(xb, box[db], bad);
-        const uint32_t ca = (uint32_t)fminf(fmaxf(floorf(wa / box[da] * (float)nca), 0.0f), (float)(nca - 1u));
-        const uint32_t cb = (uint32_t)fminf(fmaxf(floorf(wb / box[db] * (float)ncb), 0.0f), (float)(ncb - 1u));
+        const uint32_t ca = (uint32_t)fminf(fmaxf(floorf(wa * inv_a), 0.0f), (float)(nca - 1u));
+        const uint32_t cb = (uint32_t)fminf(fmaxf(floorf(wb * inv_b), 0.0f), (float)(ncb - 1u));
         in_halo = cb < n_halo;
         return ca * ncs + cb;
     };
@@ -930,11 +934,13 @@ __global__ __launch_bounds__(1024) void k_local_build(LocalArgs a) {
     // ~36 atoms; one dependent load pair per atom would leave the 16 waves of the block waiting most of the time)
     constexpr uint32_t U = 8;
     uint32_t place[TRIPS][2], place2[TRIPS][2];       // a byte per atom: its place in its cell / in the halo cell
+    uint32_t cells[TRIPS][4];                         // 16 bits per atom: its cell (14 bits) and the "has a halo copy" bit, for pass 2
     bool over = false;
 #pragma unroll
     for (uint32_t trip = 0; trip < TRIPS; trip++) {
         const uint32_t i0 = tid + trip * U * 1024u;
         place[trip][0] = place[trip][1] = place2[trip][0] = place2[trip][1] = 0u;
+        cells[trip][0] = cells[trip][1] = cells[trip][2] = cells[trip][3] = 0u;
         if (trip * U * 1024u >= a.n_membrane) continue;                     // (uniform)
         uint32_t at[U];
         float pa[U], pb[U];
@@ -946,6 +952,7 @@ __global__ __launch_bounds__(1024) void k_local_build(LocalArgs a) {
         for (uint32_t u = 0; u < U; u++)
             if (i0 + u * 1024u < a.n_membrane) {
                 const uint32_t c = cell_ab(pa[u], pb[u]);
+                cells[trip][u >> 1] |= (c | (in_halo ? 0x4000u : 0u)) << (16u * (u & 1u));
                 const uint32_t r = atomicAdd(&l_start[c], 1u);
                 over |= r > 255u;
                 place[trip][u >> 2] |= (r & 255u) << (8u * (u & 3u));
@@ -1011,7 +1018,9 @@ __global__ __launch_bounds__(1024) void k_local_build(LocalArgs a) {
 #pragma unroll
         for (uint32_t u = 0; u < U; u++) {
             if (i0 + u * 1024u >= a.n_membrane) continue;
-            const uint32_t c = cell_ab(pa[u], pb[u]);
+            const uint32_t cw = (cells[trip][u >> 1] >> (16u * (u & 1u))) & 0xffffu;       // (pass 1's cell: not computed twice)
+            const uint32_t c = cw & 0x3fffu;
+            in_halo = (cw & 0x4000u) != 0u;
             const uint32_t q = l_start[c] + (use_fill ? atomicAdd(&l_fill[c], 1u) : (place[trip][u >> 2] >> (8u * (u & 3u))) & 255u);
             rec[q] = LocalRec{pa[u], pb[u], pn[u]};
             zlo = fminf(zlo, pn[u]);
