@@ -1025,11 +1025,6 @@ bool have_avx2() {
     static const bool yes = __builtin_cpu_supports("avx2");
     return yes;
 }
-// GORDER_XTC_NO_POPULATE=1: leave the mapping's pages to the fault handler (A/B)
-bool populate_pages() {
-    static const bool yes = !getenv("GORDER_XTC_NO_POPULATE");
-    return yes;
-}
 // the blocks [i0, i1) of a window into the blob: from the file's mapping when there is one (streaming stores), else by
 // pread (which does not move the file position)
 int pack_copy(int fd, const FileMap *map, const PackSrc *src, size_t i0, size_t i1, uint8_t *blob) {
@@ -1038,14 +1033,9 @@ int pack_copy(int fd, const FileMap *map, const PackSrc *src, size_t i0, size_t 
         uint8_t *dst = blob + src[i].dst;
         size_t done = 0;
         if (stream && ((uintptr_t)dst & 31u) == 0 && (size_t)src[i].pos + src[i].n <= map->size) {
-            // A block's pages are touched once: taken one by one that is a minor fault per 4 KB (31 per block of the
-            // 256-lipid membrane, 2 M per 8 GB of trajectory).  MADV_POPULATE_READ (Linux 5.14) maps the block's pages
-            // in one call; where the kernel does not know it the faults do the same work as before.
-            if (populate_pages()) {
-                const uintptr_t lo = (uintptr_t)(map->base + src[i].pos) & ~(uintptr_t)4095u;
-                const uintptr_t hi = ((uintptr_t)(map->base + src[i].pos) + src[i].n + 4095u) & ~(uintptr_t)4095u;
-                (void)madvise((void *)lo, hi - lo, 22 /* MADV_POPULATE_READ */);
-            }
+            // (Measured in round 4 and not kept: MADV_POPULATE_READ on the block's pages before the copy — one call instead
+            // of 31 minor faults per block: 217 k against 222 k frames/s on 8 GB of distinct frames; the copy out of DRAM
+            // itself, 27 GB/s on the 16 CPUs of the box's quota, is the bound, not the faults.)
             stream_copy_avx2(dst, map->base + src[i].pos, src[i].n);
             done = src[i].n;
         }
