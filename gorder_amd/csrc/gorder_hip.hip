@@ -1482,6 +1482,7 @@ int gorder_hip_prime_leaflets(gorder_hip_handle *h, const float *d_xyz, const fl
     }
     std::vector<uint32_t> aframes(1, 0);
     const int st = run_leaflets(h, d_xyz, d_box, aframes, 0);
+    (void)timing_mark(h, nullptr);      // (the priming frame's kernels are a chain of their own: nothing stays open until the next submit)
     if (st != GORDER_OK) return st;
     h->have_assignment = true;
     h->assignment_frame = frame_index;
@@ -1754,6 +1755,7 @@ int gorder_hip_kernel_time(gorder_hip_handle *h, double *ms, uint64_t *launches,
         h->timing_labels.clear(); h->timing_label_ms.clear(); h->timing_label_n.clear();
         h->timed_kernels.clear();
         h->timing_launches = 0;
+        h->timing_open_label = -1;       // (a segment left open — there is none between submits — would name a label that is gone)
     }
     return GORDER_OK;
 }
