@@ -66,6 +66,8 @@ def make_case(seed):
         t.dynamic_normal = DynamicNormal(enabled=True, radius=float(rng.uniform(2.2, 3.0)), cloud=np.concatenate(cloud))
     if rng.random() < 0.3:
         t.flags = abi.FLAG_TRIG_ACOS_COS
+    elif kind == "ua" and rng.random() < 0.5:
+        t.flags = abi.FLAG_UA_FAST_NORMALISE          # (round 4) the tolerance-bounded construction, restated by the oracle
     n = int(rng.integers(5, 14))
     batches = int(rng.integers(1, 4))
     return system, n, batches, kind
@@ -112,9 +114,9 @@ def test_random_configuration(built, seed):
         if diff.any():
             pytest.skip("a lipid sits on the mid-plane in this random system")
     np.testing.assert_array_equal(got.counts, want.counts)
-    # exact integer sums, except where the documented <= 1 tick per sample applies: unsaturated CH hydrogens
-    # (device sincosf) and dynamic normals (summation order of the cloud)
-    loose = kind == "ua" or t.dynamic_normal.enabled
+    # exact integer sums (united atoms too: every angle function is restated by the oracle, in the default, the literal and
+    # the fast mode), except with dynamic normals (summation order of the cloud): <= 1 tick there
+    loose = bool(t.dynamic_normal.enabled)
     if loose:
         assert np.abs(got.order_ticks() - want.order_ticks()).max() <= 1
     else:
