@@ -121,6 +121,8 @@ def csv_text(tree: dict) -> str:
 
 def _pm(value, errors: bool) -> str:
     if errors:
+        if value["mean"] != value["mean"]:             # tab_presenter.rs:135-139: one centred NaN, no error beside it
+            return f"{'NaN':^17s}"
         return f"{_fixed(value['mean']):>8s} ± {_fixed(value['error'])}"
     return f"{_fixed(value):>8s}"
 

@@ -167,7 +167,17 @@ if __name__ == "__main__":
               # united-atom per-frame rows (tests_ua.rs:509-630) and the writers' other united-atom files
               "ua_order_convergence.xvg", "ua_order_leaflets_convergence.xvg", "ua_order_error.csv", "ua_order_error.tab",
               "ua_order_leaflets_error.csv", "ua_order_leaflets_error.tab", "ua_order_basic_POPC.xvg",
-              "ua_order_basic_POPS.xvg", "ua_order_leaflets_POPS.xvg"):
+              "ua_order_basic_POPS.xvg", "ua_order_leaflets_POPS.xvg",
+              # the remaining text twins of analyses this checkout's data reproduces (round 4)
+              "aa_order_basic_POPE.xvg", "aa_order_basic_POPG.xvg", "aa_order_leaflets_POPE.xvg", "aa_order_leaflets_POPG.xvg",
+              "aa_order_error_leaflets.csv", "aa_order_error_leaflets.tab", "aa_order_error_leaflets_limit.csv",
+              "aa_order_error_leaflets_limit.tab", "aa_order_error_limit.csv", "aa_order_error_limit.tab",
+              "aa_order_leaflets_limit.tab", "aa_order_different_hydrogen_numbers.csv", "aa_order_different_hydrogen_numbers.tab",
+              "cg_order_basic_POPC.xvg", "cg_order_basic_POPE.xvg", "cg_order_basic_POPG.xvg", "cg_order_leaflets_POPE.xvg",
+              "cg_order_leaflets_POPG.xvg", "cg_order_error.csv", "cg_order_error.tab", "cg_order_error_leaflets_limit.csv",
+              "cg_order_error_leaflets_limit.tab", "cg_order_error_limit.csv", "cg_order_error_limit.tab",
+              "cg_order_leaflets_limit.csv", "cg_order_leaflets_limit.tab", "cg_order_leaflets_convergence.xvg",
+              "cg_order_convergence_s5.xvg"):
         src = os.path.join(REF, f)
         if os.path.exists(src):
             shutil.copy(src, os.path.join(HERE, "expected", f))

@@ -120,3 +120,72 @@ def test_convergence_with_a_step(fixtures):
     eng.submit(np.ascontiguousarray(fx.xyz[frames][:, midx, :]), fx.boxes[frames], np.arange(len(frames)) * 5)
     eng.finish()
     same_tokens(writers.convergence_text(eng.timewise(len(frames)), labels, "aa", False, step=5), golden("aa_order_convergence_s5.xvg"))
+
+
+# ---- the remaining text twins of analyses the checkout's data reproduces (round 4) -------------------------------------
+def analysed(fx, kind, leaflets=False, errors=False, min_samples=1, heavy=None):
+    setup = {"aa": aa_setup, "cg": cg_setup}[kind]
+    kw = dict(leaflets=METHODS["global"] if leaflets else None, timewise=errors)
+    if heavy is not None:
+        kw["heavy"] = heavy
+    tables, labels, midx = setup(fx, **kw)
+    frames = fx.window()
+    eng = oracle.OracleEngine(tables, trig=oracle.TRIG_LIBM, n_threads=4)
+    eng.submit(np.ascontiguousarray(fx.xyz[frames][:, midx, :]), fx.boxes[frames], frames)
+    res = eng.finish()
+    tw = eng.timewise(len(frames)) if errors else None
+    return st.results_tree(res, labels, kind, leaflets=leaflets, timewise=tw, min_samples=min_samples)
+
+
+MORE_TEXT = [   # (kind, leaflets, errors, min_samples, files)   tests_aa.rs / tests_cg.rs: the csv / tab / xvg outputs of the same runs
+    ("aa", False, False, 1, ["aa_order_basic_POPE.xvg", "aa_order_basic_POPG.xvg"]),
+    ("aa", True, False, 1, ["aa_order_leaflets_POPE.xvg", "aa_order_leaflets_POPG.xvg"]),
+    ("aa", True, True, 1, ["aa_order_error_leaflets.csv", "aa_order_error_leaflets.tab"]),
+    ("aa", True, True, 500, ["aa_order_error_leaflets_limit.csv", "aa_order_error_leaflets_limit.tab"]),
+    ("aa", False, True, 2000, ["aa_order_error_limit.csv", "aa_order_error_limit.tab"]),
+    ("aa", True, False, 500, ["aa_order_leaflets_limit.tab"]),
+    ("cg", False, False, 1, ["cg_order_basic_POPC.xvg", "cg_order_basic_POPE.xvg", "cg_order_basic_POPG.xvg"]),
+    ("cg", True, False, 1, ["cg_order_leaflets_POPE.xvg", "cg_order_leaflets_POPG.xvg"]),
+    ("cg", False, True, 1, ["cg_order_error.csv", "cg_order_error.tab"]),
+    ("cg", True, True, 2000, ["cg_order_error_leaflets_limit.csv", "cg_order_error_leaflets_limit.tab"]),
+    ("cg", False, True, 5000, ["cg_order_error_limit.csv", "cg_order_error_limit.tab"]),
+    ("cg", True, False, 2000, ["cg_order_leaflets_limit.csv", "cg_order_leaflets_limit.tab"]),
+]
+
+
+def check_text(tree, name, kind):
+    if name.endswith(".csv"):
+        same_items(writers.csv_text(tree), golden(name), sep=",")
+    elif name.endswith(".tab"):
+        same_tokens(writers.tab_text(tree), golden(name))
+    else:
+        same_tokens(writers.xvg_text(tree, name.rsplit("_", 1)[1][:-4], united=False), golden(name))
+
+
+@pytest.mark.parametrize("kind,leaflets,errors,min_samples,files", MORE_TEXT, ids=[c[4][0] for c in MORE_TEXT])
+def test_more_text_outputs(fixtures, kind, leaflets, errors, min_samples, files):
+    tree = analysed(fixtures[kind], kind, leaflets, errors, min_samples)
+    for name in files:
+        check_text(tree, name, kind)
+
+
+def test_molecule_types_with_different_numbers_of_hydrogens(fixtures):
+    # tests_aa.rs:1043-1095: POPC's two selected carbons carry one hydrogen, POPE's up to three: the table pads the columns
+    from gorder_amd.select import select
+    fx = fixtures["aa"]
+    heavy = select(fx.structure, "(resname POPC and name C29 C210) or (resname POPE and element name carbon)")
+    tree = analysed(fx, "aa", leaflets=True, heavy=heavy)
+    same_tokens(writers.tab_text(tree), golden("aa_order_different_hydrogen_numbers.tab"))
+    same_items(writers.csv_text(tree), golden("aa_order_different_hydrogen_numbers.csv"), sep=",")
+
+
+@pytest.mark.parametrize("leaflets,step,name", [(True, 1, "cg_order_leaflets_convergence.xvg"), (False, 5, "cg_order_convergence_s5.xvg")])
+def test_more_convergence_files(fixtures, leaflets, step, name):
+    # tests_cg.rs:1711-1780
+    fx = fixtures["cg"]
+    tables, labels, midx = cg_setup(fx, leaflets=METHODS["global"] if leaflets else None, timewise=True)
+    frames = fx.window(None, None, step)
+    eng = oracle.OracleEngine(tables, trig=oracle.TRIG_LIBM, n_threads=4)
+    eng.submit(np.ascontiguousarray(fx.xyz[frames][:, midx, :]), fx.boxes[frames], np.arange(len(frames)) * step)
+    eng.finish()
+    same_tokens(writers.convergence_text(eng.timewise(len(frames)), labels, "cg", leaflets, step=step), golden(name))

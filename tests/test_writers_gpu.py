@@ -9,7 +9,7 @@ from gorder_amd import HipEngine
 from gorder_amd import structure as st
 from gorder_amd import writers
 from golden_util import METHODS, Fixture, aa_setup, cg_setup, ua_setup
-from test_writers_cpu import CASES, golden, same_items, same_tokens
+from test_writers_cpu import CASES, MORE_TEXT, check_text, golden, same_items, same_tokens
 
 pytestmark = pytest.mark.gpu
 
@@ -68,3 +68,41 @@ def test_convergence_with_a_step_from_the_hip_path(fixtures):
     eng, _ = hip_run(tables, fx, midx, frames, frame_index=np.arange(len(frames)) * 5, batches=2)
     same_tokens(writers.convergence_text(eng.timewise(len(frames)), labels, "aa", False, step=5),
                 golden("aa_order_convergence_s5.xvg"))
+
+
+# ---- the remaining text twins (round 4), from the HIP path's accumulators -------------------------------------------------
+def hip_tree(fx, kind, leaflets=False, errors=False, min_samples=1, heavy=None):
+    setup = {"aa": aa_setup, "cg": cg_setup}[kind]
+    kw = dict(leaflets=METHODS["global"] if leaflets else None, timewise=errors)
+    if heavy is not None:
+        kw["heavy"] = heavy
+    tables, labels, midx = setup(fx, **kw)
+    frames = fx.window()
+    eng, res = hip_run(tables, fx, midx, frames)
+    tw = eng.timewise(len(frames)) if errors else None
+    return st.results_tree(res, labels, kind, leaflets=leaflets, timewise=tw, min_samples=min_samples)
+
+
+@pytest.mark.parametrize("kind,leaflets,errors,min_samples,files", MORE_TEXT, ids=[c[4][0] for c in MORE_TEXT])
+def test_more_text_outputs_from_the_hip_path(fixtures, kind, leaflets, errors, min_samples, files):
+    tree = hip_tree(fixtures[kind], kind, leaflets, errors, min_samples)
+    for name in files:
+        check_text(tree, name, kind)
+
+
+def test_molecule_types_with_different_numbers_of_hydrogens_from_the_hip_path(fixtures):
+    from gorder_amd.select import select
+    fx = fixtures["aa"]
+    heavy = select(fx.structure, "(resname POPC and name C29 C210) or (resname POPE and element name carbon)")
+    tree = hip_tree(fx, "aa", leaflets=True, heavy=heavy)
+    same_tokens(writers.tab_text(tree), golden("aa_order_different_hydrogen_numbers.tab"))
+    same_items(writers.csv_text(tree), golden("aa_order_different_hydrogen_numbers.csv"), sep=",")
+
+
+@pytest.mark.parametrize("leaflets,step,name", [(True, 1, "cg_order_leaflets_convergence.xvg"), (False, 5, "cg_order_convergence_s5.xvg")])
+def test_more_convergence_files_from_the_hip_path(fixtures, leaflets, step, name):
+    fx = fixtures["cg"]
+    tables, labels, midx = cg_setup(fx, leaflets=METHODS["global"] if leaflets else None, timewise=True)
+    frames = fx.window(None, None, step)
+    eng, _ = hip_run(tables, fx, midx, frames, frame_index=np.arange(len(frames)) * step, batches=2)
+    same_tokens(writers.convergence_text(eng.timewise(len(frames)), labels, "cg", leaflets, step=step), golden(name))
