@@ -522,8 +522,8 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
         e.inv_box = nullptr;
         if (ua_fast && a.pbc) {      // 1 / box edge per frame, once per frame instead of once per lane and frame
             int st3;
-            if ((st3 = ensure(h, &h->d_inv_box, &h->inv_box_cap, (size_t)a.n_frames * 3)) != GORDER_OK) return st3;
-            hipLaunchKernelGGL(k_inv_box, dim3((3u * a.n_frames + 255u) / 256u), dim3(256), 0, h->stream, a.box9, a.n_frames, h->d_inv_box);
+            if ((st3 = ensure(h, &h->d_inv_box, &h->inv_box_cap, (size_t)a.n_frames * 8)) != GORDER_OK) return st3;
+            hipLaunchKernelGGL(k_inv_box, dim3((4u * a.n_frames + 255u) / 256u), dim3(256), 0, h->stream, a.box9, a.n_frames, h->d_inv_box);
             e.inv_box = h->d_inv_box;
         }
         e.dyn = (h->dyn || h->manual_active) ? h->d_dyn_normals : nullptr;
@@ -951,6 +951,7 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
             }
             e.maps = 1; e.plane = om.plane; e.x0 = om.span_x[0]; e.y0 = om.span_y[0];
             e.binx = om.bin[0]; e.biny = om.bin[1]; e.nx = h->map_nx; e.ny = h->map_ny;
+            e.inv_binx = 1.0f / om.bin[0]; e.inv_biny = 1.0f / om.bin[1];
             e.bin_core = (om.bin[0] >= 0x1p-40f && om.bin[0] <= 0x1p+40f && om.bin[1] >= 0x1p-40f && om.bin[1] <= 0x1p+40f) ? 1 : 0;
             e.map_packed = h->d_map_packed;
         }

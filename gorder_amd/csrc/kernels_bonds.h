@@ -14,6 +14,14 @@ __device__ __forceinline__ int grid_index(float x, float lo, float bin, uint32_t
     if (!(k >= 0.0f) || !(k < (float)n)) return -1;
     return (int)k;
 }
+// GORDER_FLAG_UA_FAST_NORMALISE: the tile by one fma and a floor — floor((x - lo) * (1 / bin) + 0.5) — instead of the
+// rounded IEEE quotient: a sample within an ulp or two of the line between two tiles may land on the other side
+// (oracle: gridmap_index_fast; tools/ua_fast_fidelity.py counts them).
+__device__ __forceinline__ int grid_index_fast(float x, float lo, float inv_bin, uint32_t n) {
+    const float k = __builtin_floorf(__builtin_fmaf(x - lo, inv_bin, 0.5f));
+    if (!(k >= 0.0f) || !(k < (float)n)) return -1;
+    return (int)k;
+}
 // Ordermap samples out of the tiled kernel (k_bonds_tiled_maps, kernels_extras.h): the grid of the map and this
 // thread's words of the stage's kRecFrames frames.
 constexpr uint32_t kRecFrames = 4;               // frames per block of the bond tiles' staging layout = frames of a stage

@@ -123,10 +123,15 @@ __global__ void k_check_box(const float *__restrict__ box9, uint32_t n_frames, u
     if (f < n_frames) check_box_frame(box9, f, err);
 }
 
-// 1 / box edge per frame (GORDER_FLAG_UA_FAST_NORMALISE): inv[f][d] = 1.0f / box9[f][4 d], an IEEE division
+// The box edges and their reciprocals per frame (GORDER_FLAG_UA_FAST_NORMALISE), eight floats a frame so that one scalar
+// load fetches them: inv[f] = (Lx, Ly, Lz, -, 1 / Lx, 1 / Ly, 1 / Lz, -), the reciprocals IEEE divisions
 __global__ void k_inv_box(const float *__restrict__ box9, uint32_t n_frames, float *__restrict__ inv) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 3u * n_frames) inv[i] = 1.0f / box9[9u * (size_t)(i / 3u) + 4u * (i % 3u)];
+    if (i >= 4u * n_frames) return;
+    const uint32_t f = i >> 2, d = i & 3u;
+    const float L = d < 3u ? box9[9u * (size_t)f + 4u * d] : 1.0f;
+    inv[8u * (size_t)f + d] = L;
+    inv[8u * (size_t)f + 4u + d] = 1.0f / L;
 }
 
 // acc[i] += sum_r rep[r][i]; rep := 0   (i < 4 * n_acc)

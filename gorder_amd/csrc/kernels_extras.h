@@ -32,6 +32,7 @@ struct ExtraArgs {
     uint32_t rec_frame0, rec_stride; // rec_stride: words per lane = frames of the sub-range rounded up to 16
     const float4 *dyn;               // dynamic membrane normals [n_frames][n_mol_total] (nx, ny, nz, cloud size) or null
     int bin_core;                    // both bin widths in [2^-40, 2^40]: grid_index may use the division core
+    float inv_binx, inv_biny;        // 1 / bin (IEEE, from the host): GORDER_FLAG_UA_FAST_NORMALISE's tile index
     int axis;                        // the static normal is this coordinate axis (0..2), or -1
     int tw;                          // timewise on
     unsigned long long *tw_sums;     // [rows][3][n_acc]
@@ -43,7 +44,7 @@ struct ExtraArgs {
     int geom_kind, geom_invert, geom_orient;
     float geom_thr;                  // cylinder / sphere: local_radius_threshold(radius), d2 < geom_thr == sqrt(d2) < radius
     const float *shapes;
-    // GORDER_FLAG_UA_FAST_NORMALISE: 1 / box edge per frame [n_frames][3] (k_inv_box: IEEE divisions, once per frame instead
+    // GORDER_FLAG_UA_FAST_NORMALISE: box edges and 1 / box edge per frame [n_frames][8] (k_inv_box: IEEE divisions, once per frame instead
     // of once per lane and frame), or null
     const float *inv_box;
 };
@@ -87,13 +88,20 @@ template <bool STAGED_ONLY = false, bool NO_MAPS = false>
 __device__ __forceinline__ void extras_add(const FrameArgs &a, const ExtraArgs &e, uint32_t gslot, uint32_t lslot,
                                            int tick, float px, float py, float pz, int leaflet /* -1 none */,
                                            int *l_tw, uint32_t *l_twn, uint32_t lstride,
-                                           unsigned long long *rec = nullptr, bool skip_tw = false) {
+                                           unsigned long long *rec = nullptr, bool skip_tw = false, bool fast_bin = false) {
     if (!NO_MAPS && (STAGED_ONLY || e.maps)) {
         float x, y;
         if (e.plane == 0) { x = px; y = py; }
         else if (e.plane == 1) { x = px; y = pz; }
         else { x = pz; y = py; }
-        const int ix = grid_index(x, e.x0, e.binx, e.nx, e.bin_core != 0), iy = grid_index(y, e.y0, e.biny, e.ny, e.bin_core != 0);
+        int ix, iy;
+        if (fast_bin) {     // (united atoms with GORDER_FLAG_UA_FAST_NORMALISE, carbons the fast construction kept)
+            ix = grid_index_fast(x, e.x0, e.inv_binx, e.nx);
+            iy = grid_index_fast(y, e.y0, e.inv_biny, e.ny);
+        } else {
+            ix = grid_index(x, e.x0, e.binx, e.nx, e.bin_core != 0);
+            iy = grid_index(y, e.y0, e.biny, e.ny, e.bin_core != 0);
+        }
         if (ix >= 0 && iy >= 0) {
             // ONE atomic per sample: count and tick sum share a 64-bit word, and with leaflets only the
             // sample's own leaflet plane is touched (total = upper + lower, bond.rs:199-213); k_fold_maps
@@ -905,9 +913,13 @@ __device__ __forceinline__ UaBonds ua_carbon_fast(uint32_t kind, UaCarbon c, UaC
     UaBonds r;
     r.v0 = r.v1 = r.v2 = r.b0 = r.b1 = r.b2 = zero;
     r.bad = 0;
-    auto bond = [&](V3 target, V3 hu, V3 &v, V3 &b) {          // C -> H from the unwrapped hydrogen; position = wrapped H + v / 2
-        v = {hu.x - target.x, hu.y - target.y, hu.z - target.z};
-        if (POS && need_pos) { const V3 h = ps.wrap(hu); b = {h.x + v.x / 2.0f, h.y + v.y / 2.0f, h.z + v.z / 2.0f}; }
+    // C -> H from the unwrapped hydrogen; position = wrapped H + v / 2.  (Values in, values out: with `V3 &` parameters the
+    // results of the branches below met as a phi of POINTERS and stayed in scratch.)
+    auto bond_v = [&](V3 target, V3 hu) { return V3{hu.x - target.x, hu.y - target.y, hu.z - target.z}; };
+    auto bond_b = [&](V3 hu, V3 v) {
+        if (!(POS && need_pos)) return zero;
+        const V3 h = ps.wrap(hu);
+        return V3{h.x + v.x / 2.0f, h.y + v.y / 2.0f, h.z + v.z / 2.0f};
     };
     if (kind == GORDER_UA_CH2 || kind == GORDER_UA_CH3) {
         const V3 target = c.p1;
@@ -924,20 +936,25 @@ __device__ __forceinline__ UaBonds ua_carbon_fast(uint32_t kind, UaCarbon c, UaC
             const V3 th1 = v3p_lane0(th), th2 = v3p_lane1(th);
             const V3 ua = ps.unit(v3_cross(th2, th1));                                     // perpendicular to th1
             const V3 hv1 = v3_rotate_perp(ua, e.sin_tet, e.cos_tet, th1);
-            bond(target, ps.shift(target, hv1), r.v0, r.b0);
+            const V3 h0 = ps.shift(target, hv1);
+            r.v0 = bond_v(target, h0);
+            r.b0 = bond_b(h0, r.v0);
             const V3 n1 = ps.unit(th1);
             hu = pp.shift(target, v3p_rotate_rod_pm(n1, e.sin_ch3, e.cos_ch3, hv1));
         }
         const V3P v = {hu.x - f2_splat(target.x), hu.y - f2_splat(target.y), hu.z - f2_splat(target.z)};
         V3P b = {f2_splat(0.0f), f2_splat(0.0f), f2_splat(0.0f)};
         if (POS && need_pos) { const V3P h = pp.wrap(hu); b = {h.x + v.x / 2.0f, h.y + v.y / 2.0f, h.z + v.z / 2.0f}; }
-        if (kind == GORDER_UA_CH2) {
-            r.v0 = v3p_lane0(v); r.b0 = v3p_lane0(b);
-            r.v1 = v3p_lane1(v); r.b1 = v3p_lane1(b);
-        } else {
-            r.v1 = v3p_lane0(v); r.b1 = v3p_lane0(b);
-            r.v2 = v3p_lane1(v); r.b2 = v3p_lane1(b);
-        }
+        // The pair is hydrogens (0, 1) of a methylene and (1, 2) of a methyl carbon.  As selects of VALUES: assigning
+        // `r.v0, r.v1` in one branch and `r.v1, r.v2` in the other made the compiler keep the result in scratch and index
+        // it by the kind (two scratch stores and loads per frame, and a wait for every load in flight behind them).
+        const bool ch2 = kind == GORDER_UA_CH2;
+        const V3 v_lo = v3p_lane0(v), v_hi = v3p_lane1(v), b_lo = v3p_lane0(b), b_hi = v3p_lane1(b);
+        r.v0 = V3{ch2 ? v_lo.x : r.v0.x, ch2 ? v_lo.y : r.v0.y, ch2 ? v_lo.z : r.v0.z};
+        r.b0 = V3{ch2 ? b_lo.x : r.b0.x, ch2 ? b_lo.y : r.b0.y, ch2 ? b_lo.z : r.b0.z};
+        r.v1 = V3{ch2 ? v_hi.x : v_lo.x, ch2 ? v_hi.y : v_lo.y, ch2 ? v_hi.z : v_lo.z};
+        r.b1 = V3{ch2 ? b_hi.x : b_lo.x, ch2 ? b_hi.y : b_lo.y, ch2 ? b_hi.z : b_lo.z};
+        r.v2 = v_hi; r.b2 = b_hi;                  // (a methylene carbon has no third hydrogen: never read)
     } else {
         V3 target = c.p1, hu;
         if (kind == GORDER_UA_CH1_UNSAT) {      // uaorder.rs:1024-1045
@@ -959,7 +976,8 @@ __device__ __forceinline__ UaBonds ua_carbon_fast(uint32_t kind, UaCarbon c, UaC
             const V3 t1 = ps.unit(ps.to(target, c.p0)), t2 = ps.unit(ps.to(target, c.p1)), t3 = ps.unit(ps.to(target, c.p2));
             hu = ps.shift(target, V3{-((t1.x + t2.x) + t3.x), -((t1.y + t2.y) + t3.y), -((t1.z + t2.z) + t3.z)});
         }
-        bond(target, hu, r.v0, r.b0);
+        r.v0 = bond_v(target, hu);
+        r.b0 = bond_b(hu, r.v0);
     }
     slow = ps.slow || pp.slow();
     return r;
@@ -1086,25 +1104,69 @@ __device__ __forceinline__ void ua_extras_body(FrameArgs a_in, ExtraArgs e, cons
         c.p3 = {src[3][o], src[3][o + 1], src[3][o + 2]};
         return c;
     };
+    // PREFETCH: the next frame's four atoms are asked for before this frame's arithmetic, by EVERY lane (idle lanes point
+    // at the tile's first atom) and without a branch (the last frame asks for itself again): inside `if (active)` or
+    // behind `f + 1 < f_end` the loaded registers are copied into the loop-carried ones at the end of the conditional
+    // block, and the wait for the loads lands right behind them — a prefetch that hides nothing.
+    // The frame's box lengths (and their reciprocals) come the same way: scalar loads, a frame ahead.
+    auto fetch_box = [&](uint32_t f, V3 &bx, V3 &inv) {
+        bx = {1.0f, 1.0f, 1.0f};
+        inv = {1.0f, 1.0f, 1.0f};
+        if (pbc) {
+            if (FAST) {         // (k_inv_box's record of the frame: one scalar load)
+                const float4 *ib = reinterpret_cast<const float4 *>(inv_box) + 2 * (size_t)f;
+                const float4 lo = ib[0], hi = ib[1];
+                bx = {lo.x, lo.y, lo.z};
+                inv = {hi.x, hi.y, hi.z};
+            } else {
+                const float *b = a.box9 + 9 * (size_t)f;
+                bx = {b[0], b[4], b[8]};
+            }
+        }
+    };
+    auto fetch_flag = [&](uint32_t f) { return a.aflags[(size_t)a.arow[f] * a.n_mol_total + (active ? it.mol : 0u)]; };
     UaCarbon c_next{};
-    if (PREFETCH && active && f_begin < f_end) c_next = fetch(f_begin);
+    V3 bx_next{1.0f, 1.0f, 1.0f}, inv_next{1.0f, 1.0f, 1.0f};
+    uint8_t lf_next = 0;
+    if (PREFETCH && f_begin < f_end) {
+        c_next = fetch(f_begin);
+        fetch_box(f_begin, bx_next, inv_next);
+        if (a.leaflets) lf_next = fetch_flag(f_begin);
+    }
     for (uint32_t f = f_begin; f < f_end; f++) {
         int tw_s[3] = {0, 0, 0}, tw_sl[3] = {0, 0, 0}, tw_n[3] = {0, 0, 0};      // tw_waves: this lane's ticks, lower-leaflet ticks, counts (all | lower << 16)
+        UaCarbon c_now{};
+        V3 bx3{1.0f, 1.0f, 1.0f}, inv3{1.0f, 1.0f, 1.0f};
+        if (PREFETCH) {
+            c_now = c_next; bx3 = bx_next; inv3 = inv_next;
+            const uint32_t fn = f + 1 < f_end ? f + 1 : f;
+            c_next = fetch(fn);
+            fetch_box(fn, bx_next, inv_next);
+        } else {
+            fetch_box(f, bx3, inv3);
+        }
+        // (the molecule's leaflet flag: a frame ahead with the atoms — its load is waited for where the flag is first
+        // looked at, which the compiler puts right behind the load —, or up here)
+        uint8_t lf_raw = 0;
+        if (PREFETCH) {
+            lf_raw = lf_next;
+            if (a.leaflets) lf_next = fetch_flag(f + 1 < f_end ? f + 1 : f);
+        } else if (a.leaflets) {
+            lf_raw = fetch_flag(f);
+        }
         if (active) {
-            const UaCarbon c = PREFETCH ? c_next : fetch(f);
-            if (PREFETCH && f + 1 < f_end) c_next = fetch(f + 1);
-            V3 bx3{1.0f, 1.0f, 1.0f};
-            if (pbc) { const float *b = a.box9 + 9 * (size_t)f; bx3 = {b[0], b[4], b[8]}; }
+            const UaCarbon c = PREFETCH ? c_now : fetch(f);
             // the atoms are checked in index order (uaorder.rs:400-437 via get_position of each helper); the smallest key wins
-            if (c.p0.x != c.p0.x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, f, kStageTypes, gslot0, 1, it.mol, 0);
-            else if (c.p1.x != c.p1.x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, f, kStageTypes, gslot0, 1, it.mol, 1);
-            else if (c.p2.x != c.p2.x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, f, kStageTypes, gslot0, 1, it.mol, 2);
-            else if (c.p3.x != c.p3.x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, f, kStageTypes, gslot0, 1, it.mol, 3);
+            // (one test for the four first — two unordered compares —, the chain only where it fires)
+            if (__builtin_expect((int)__builtin_isunordered(c.p0.x, c.p1.x) | (int)__builtin_isunordered(c.p2.x, c.p3.x), 0)) {
+                if (c.p0.x != c.p0.x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, f, kStageTypes, gslot0, 1, it.mol, 0);
+                else if (c.p1.x != c.p1.x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, f, kStageTypes, gslot0, 1, it.mol, 1);
+                else if (c.p2.x != c.p2.x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, f, kStageTypes, gslot0, 1, it.mol, 2);
+                else if (c.p3.x != c.p3.x) raise_error(a.err, GORDER_ERR_UNDEFINED_POSITION, f, kStageTypes, gslot0, 1, it.mol, 3);
+            }
             bool slow = false;
             UaBonds ub;
             if (FAST) {
-                V3 inv3{1.0f, 1.0f, 1.0f};
-                if (pbc) { const float *ib = inv_box + 3 * (size_t)f; inv3 = {ib[0], ib[1], ib[2]}; }
                 ub = ua_carbon_fast<MAPS_POSSIBLE>(kind, c, uc, bx3, inv3, pbc, e.maps != 0 || e.geom_kind != 0, slow);
             } else if (kind == GORDER_UA_CH2 || kind == GORDER_UA_CH3) {       // the two common kinds: paired arithmetic
                 ub = ua_carbon_pairs(kind, c, uc, bx3, pbc, slow);
@@ -1118,7 +1180,7 @@ __device__ __forceinline__ void ua_extras_body(FrameArgs a_in, ExtraArgs e, cons
                 bad |= ub.bad;
             }
             int leaflet = -1;
-            if (a.leaflets) leaflet = a.aflags[(size_t)a.arow[f] * a.n_mol_total + it.mol] ? 1 : 0;
+            if (a.leaflets) leaflet = lf_raw ? 1 : 0;
             float nrx = a.nx, nry = a.ny, nrz = a.nz, nr2 = a.n2, nr2sq = a.n2sq;
             if (FULL && e.dyn) {   // fetched for every molecule, before the geometry test (uaorder.rs:412-413)
                 const float4 n = e.dyn[(size_t)f * a.n_mol_total + it.mol];
@@ -1155,7 +1217,8 @@ __device__ __forceinline__ void ua_extras_body(FrameArgs a_in, ExtraArgs e, cons
                 }
                 if (EXTRAS)
                     extras_add<!GENERAL, !MAPS_POSSIBLE>(a, e, gslot0 + (uint32_t)k, it.lslot0 + (uint32_t)k, tick, b.x, b.y, b.z, leaflet, l_tw,
-                                                         l_twn, LS, (MAPS_POSSIBLE && (!GENERAL || e.map_rec)) ? &recs[k] : nullptr, tw_waves);
+                                                         l_twn, LS, (MAPS_POSSIBLE && (!GENERAL || e.map_rec)) ? &recs[k] : nullptr, tw_waves,
+                                                         FAST && !slow);
             };
             sample(0, ub.v0, ub.b0);
             sample(1, ub.v1, ub.b1);
@@ -1229,6 +1292,9 @@ __device__ __forceinline__ void ua_extras_body(FrameArgs a_in, ExtraArgs e, cons
     }
 }
 
+#ifndef GORDER_UA_PREFETCH
+#define GORDER_UA_PREFETCH 0        // the exact kernel is bound by VALU issue: a frame ahead buys nothing there (measured, round 4)
+#endif
 #define GORDER_UA_KERNEL_ARGS                                                                                              \
     FrameArgs a_in, ExtraArgs e, const float *__restrict__ xyz, const float *__restrict__ box9,                               \
         const uint8_t *__restrict__ aflags, const uint32_t *__restrict__ arow, const Tile *__restrict__ tiles,                \
@@ -1236,7 +1302,7 @@ __device__ __forceinline__ void ua_extras_body(FrameArgs a_in, ExtraArgs e, cons
         const float *__restrict__ inv_box
 template <bool ACOS_COS, int MODE>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ua_extras(GORDER_UA_KERNEL_ARGS) {
-    ua_extras_body<ACOS_COS, MODE, false, false>(a_in, e, xyz, box9, aflags, arow, tiles, items, tile_slots, n_tiles, inv_box);
+    ua_extras_body<ACOS_COS, MODE, false, GORDER_UA_PREFETCH != 0>(a_in, e, xyz, box9, aflags, arow, tiles, items, tile_slots, n_tiles, inv_box);
 }
 // GORDER_FLAG_UA_FAST_NORMALISE (the default cosine only)
 #ifndef GORDER_UA_FAST_WAVES

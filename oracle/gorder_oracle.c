@@ -831,6 +831,14 @@ static inline int gridmap_index(float x, float lo, float bin, uint32_t n) {
     return (int)k;
 }
 
+/* The device's tile index under GORDER_FLAG_UA_FAST_NORMALISE (gorder_amd/csrc/kernels_bonds.h: grid_index_fast), operation
+ * for operation: one fma with the reciprocal of the bin and a floor.  Not the reference's arithmetic. */
+static inline int gridmap_index_fast(float x, float lo, float inv_bin, uint32_t n) {
+    const float k = floorf(fmaf(x - lo, inv_bin, 0.5f));
+    if (!(k >= 0.0f) || !(k < (float)n)) return -1;
+    return (int)k;
+}
+
 uint32_t gorder_oracle_n_accumulators(const gorder_oracle_handle *h) { return h->n_acc; }
 uint32_t gorder_oracle_ordermap_dims(const gorder_oracle_handle *h, uint32_t *nx, uint32_t *ny) {
     if (nx) *nx = h->nx;
@@ -1031,7 +1039,7 @@ static int assign_leaflets(gorder_oracle_handle *h, const float *xyz, const floa
 
 /* ---- one sample: BondLike::add_order, bond.rs:184-215 (+ Map::add_order, ordermap.rs:100-113) */
 static inline void add_order(const gorder_oracle_handle *h, o_acc *a, int64_t *tw_s, uint64_t *tw_n,
-                             uint32_t slot, float sch, const float *pos, int leaflet /* -1 none */) {
+                             uint32_t slot, float sch, const float *pos, int leaflet /* -1 none */, int fast_bin) {
     const int64_t tick = gorder_oracle_tick(sch);
     const uint32_t n_acc = h->n_acc;
     int tile = -1;
@@ -1042,8 +1050,10 @@ static inline void add_order(const gorder_oracle_handle *h, o_acc *a, int64_t *t
             case 1: x = pos[0]; y = pos[2]; break;
             default: x = pos[2]; y = pos[1]; break;
         }
-        const int ix = gridmap_index(x, h->om.span_x[0], h->om.bin[0], h->nx);
-        const int iy = gridmap_index(y, h->om.span_y[0], h->om.bin[1], h->ny);
+        const int ix = fast_bin ? gridmap_index_fast(x, h->om.span_x[0], 1.0f / h->om.bin[0], h->nx)
+                                : gridmap_index(x, h->om.span_x[0], h->om.bin[0], h->nx);
+        const int iy = fast_bin ? gridmap_index_fast(y, h->om.span_y[0], 1.0f / h->om.bin[1], h->ny)
+                                : gridmap_index(y, h->om.span_y[0], h->om.bin[1], h->ny);
         if (ix >= 0 && iy >= 0) tile = ix * (int)h->ny + iy;
     }
     for (int pass = 0; pass < 2; pass++) {
@@ -1121,7 +1131,7 @@ static int analyze_frame_orders(const gorder_oracle_handle *h, o_acc *a, int64_t
                     if (normal[3] < 3.0f) { *err_index = (uint64_t)normal[3]; return GORDER_ERR_DYNAMIC_NORMAL; }
                 }
                 const float sch = calc_sch(v, normal, h->trig);
-                add_order(h, a, tw_s, tw_n, mt->slot0 + bt, sch, mid, lf ? flags[mt->mol0 + i] : -1);
+                add_order(h, a, tw_s, tw_n, mt->slot0 + bt, sch, mid, lf ? flags[mt->mol0 + i] : -1, 0);
             }
         }
         for (uint32_t ua = 0; ua < mt->n_ua_atoms; ua++) {
@@ -1159,7 +1169,7 @@ static int analyze_frame_orders(const gorder_oracle_handle *h, o_acc *a, int64_t
                     if (geom && !inside_shape(&h->geom, &shape, bp, box, h->pbc, &bad)) continue; /* uaorder.rs:388-390 */
                     const float sch = calc_sch(v, normal, h->trig);
                     add_order(h, a, tw_s, tw_n, mt->ua_slot0[ua] + (uint32_t)k, sch, bp,
-                              lf ? flags[mt->mol0 + i] : -1);
+                              lf ? flags[mt->mol0 + i] : -1, fast_ok);
                 }
             }
         }
@@ -1230,8 +1240,11 @@ int gorder_oracle_ua_fast_fidelity(const gorder_oracle_handle *h, const float *x
                                     case 1: px = p[0]; py = p[2]; break;
                                     default: px = p[2]; py = p[1]; break;
                                 }
-                                const int gx = gridmap_index(px, h->om.span_x[0], h->om.bin[0], h->nx);
-                                const int gy = gridmap_index(py, h->om.span_y[0], h->om.bin[1], h->ny);
+                                /* (w = 1: the fast construction's position AND its tile index) */
+                                const int gx = w ? gridmap_index_fast(px, h->om.span_x[0], 1.0f / h->om.bin[0], h->nx)
+                                                 : gridmap_index(px, h->om.span_x[0], h->om.bin[0], h->nx);
+                                const int gy = w ? gridmap_index_fast(py, h->om.span_y[0], 1.0f / h->om.bin[1], h->ny)
+                                                 : gridmap_index(py, h->om.span_y[0], h->om.bin[1], h->ny);
                                 tile[w] = (gx >= 0 && gy >= 0) ? gx * (int)h->ny + gy : -1;
                             }
                             if (tile[0] != tile[1]) out[2]++;
