@@ -924,7 +924,17 @@ __global__ __launch_bounds__(1024) void k_local_build(LocalArgs a) {
     auto cell_ab = [&](float xa, float xb) -> uint32_t {
         in_halo = false;
         if (!a.pbc) return 0u;
-        const float wa = gm_wrap(xa, box[da], bad), wb = gm_wrap(xb, box[db], bad);
+        // gm_wrap's first steps as selects — the same subtraction and addition —; a coordinate more than a box length
+        // outside (rare) takes the loops.  (Four data-dependent loops per atom, forty atoms per thread, were most of this
+        // kernel's branches: a taken branch costs a wave far more than the arithmetic it skips.)
+        const float La = box[da], Lb = box[db];
+        float wa = xa > La ? xa - La : xa, wb = xb > Lb ? xb - Lb : xb;
+        wa = wa < 0.0f ? wa + La : wa;
+        wb = wb < 0.0f ? wb + Lb : wb;
+        if (__builtin_expect(!(wa >= 0.0f && wa <= La && wb >= 0.0f && wb <= Lb), 0)) {      // (NaN comes here too, and stays NaN)
+            wa = gm_wrap(xa, La, bad);
+            wb = gm_wrap(xb, Lb, bad);
+        }
         const uint32_t ca = (uint32_t)fminf(fmaxf(floorf(wa * inv_a), 0.0f), (float)(nca - 1u));
         const uint32_t cb = (uint32_t)fminf(fmaxf(floorf(wb * inv_b), 0.0f), (float)(ncb - 1u));
         in_halo = cb < n_halo;
