@@ -1084,6 +1084,7 @@ __device__ __forceinline__ void ua_extras_body(FrameArgs a_in, ExtraArgs e, cons
     int bad = 0;
     const bool pbc = a.pbc != 0;
     const UaConsts uc{e.sin_tet, e.cos_tet, e.sin_ch3, e.cos_ch3, e.sin_half, e.cos_half};
+    const float axis_x = e.axis == 0 ? 1.0f : 0.0f, axis_y = e.axis == 1 ? 1.0f : 0.0f, axis_z = e.axis == 2 ? 1.0f : 0.0f;
     unsigned long long *rec_row = nullptr;
     uint32_t rec_n = 0;
     const size_t rec_plane = (size_t)kBlock * e.rec_stride;      // hydrogen k of the same lanes: k planes further
@@ -1108,7 +1109,7 @@ __device__ __forceinline__ void ua_extras_body(FrameArgs a_in, ExtraArgs e, cons
     // at the tile's first atom) and without a branch (the last frame asks for itself again): inside `if (active)` or
     // behind `f + 1 < f_end` the loaded registers are copied into the loop-carried ones at the end of the conditional
     // block, and the wait for the loads lands right behind them — a prefetch that hides nothing.
-    // The frame's box lengths (and their reciprocals) come the same way: scalar loads, a frame ahead.
+    // The frame's box lengths (and their reciprocals): scalar loads at the top of the frame.
     auto fetch_box = [&](uint32_t f, V3 &bx, V3 &inv) {
         bx = {1.0f, 1.0f, 1.0f};
         inv = {1.0f, 1.0f, 1.0f};
@@ -1126,11 +1127,9 @@ __device__ __forceinline__ void ua_extras_body(FrameArgs a_in, ExtraArgs e, cons
     };
     auto fetch_flag = [&](uint32_t f) { return a.aflags[(size_t)a.arow[f] * a.n_mol_total + (active ? it.mol : 0u)]; };
     UaCarbon c_next{};
-    V3 bx_next{1.0f, 1.0f, 1.0f}, inv_next{1.0f, 1.0f, 1.0f};
     uint8_t lf_next = 0;
     if (PREFETCH && f_begin < f_end) {
         c_next = fetch(f_begin);
-        fetch_box(f_begin, bx_next, inv_next);
         if (a.leaflets) lf_next = fetch_flag(f_begin);
     }
     for (uint32_t f = f_begin; f < f_end; f++) {
@@ -1138,10 +1137,10 @@ __device__ __forceinline__ void ua_extras_body(FrameArgs a_in, ExtraArgs e, cons
         UaCarbon c_now{};
         V3 bx3{1.0f, 1.0f, 1.0f}, inv3{1.0f, 1.0f, 1.0f};
         if (PREFETCH) {
-            c_now = c_next; bx3 = bx_next; inv3 = inv_next;
+            c_now = c_next;
             const uint32_t fn = f + 1 < f_end ? f + 1 : f;
             c_next = fetch(fn);
-            fetch_box(fn, bx_next, inv_next);
+            fetch_box(f, bx3, inv3);        // (scalar loads; a frame ahead they bought nothing and cost six scalar registers)
         } else {
             fetch_box(f, bx3, inv3);
         }
@@ -1197,7 +1196,11 @@ __device__ __forceinline__ void ua_extras_body(FrameArgs a_in, ExtraArgs e, cons
                 if (!ACOS_COS && e.axis >= 0 && !(FULL && e.dyn) && s2 >= 0x1p-40f && s2 <= 0x1p+40f) {
                     // static normal along an axis, |v|^2 in the guarded range: the squared cosine by the division core,
                     // no clamp (gm_sch_axis has the argument); anything else takes the general routine
-                    const float prod = e.axis == 0 ? v.x : (e.axis == 1 ? v.y : v.z);
+                    // the axis component by a unit vector in scalar registers — x * 1 + y * 0 + z * 0, exact for the finite
+                    // components this branch holds (|v|^2 <= 2^40), the sign of a zero aside, which the square drops —:
+                    // as selects the two lane masks `axis == 0`, `axis == 1` lived in spilled scalar registers and were
+                    // read back (v_readlane) for every hydrogen
+                    const float prod = __builtin_fmaf(v.z, axis_z, __builtin_fmaf(v.y, axis_y, v.x * axis_x));
                     sch = (1.5f * gm_div_core(prod * prod, s2)) - 0.5f;
                 } else {
                     sch = gm_calc_sch<ACOS_COS>(v.x, v.y, v.z, nrx, nry, nrz, nr2, nr2sq);
