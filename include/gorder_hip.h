@@ -183,8 +183,10 @@ typedef struct {
  *   (uaorder.rs:947-1104) with tolerance-bounded arithmetic instead of the reference's operation sequence — a / |a| as
  *   a * rsqrt(|a|^2) (integer seed + three Newton steps, relative error ~1e-7 where the reference's two roundings leave
  *   6e-8), no second normalisation of the CH2 rotation axis (uaorder.rs:990-1003), minimum image / wrap as
- *   d - L rint(d / L) and x - L floor(x / L).  Every operation is an IEEE mul / add / fma, restated by the oracle's
- *   FAST mode: device and oracle sums stay EQUAL.  Against the reference-faithful (libm) oracle every order parameter
+ *   d - L rint(d / L) and x - L floor(x / L), the ordermap tile of a virtual C-H bond as floor((x - x0) * (1 / bin) + 1/2)
+ *   by one fma instead of the rounded IEEE quotient (a position within an ulp or two of the line between two tiles may
+ *   land on the other side: 0 of 522 036 on the reference's membrane, 5 of 1 015 808 on the synthetic one).  Every
+ *   operation is an IEEE mul / add / fma, restated by the oracle's FAST mode: device and oracle sums stay EQUAL.  Against the reference-faithful (libm) oracle every order parameter
  *   stays within one 1e-6 tick; single samples move more often than with the default (a hydrogen position is
  *   target + 0.109 nm * unit vector rounded to the grid of the target's coordinates, so an ulp in the unit vector
  *   flips that rounding in ~1 % of the components): measured in profiles/r04_ua_fast_fidelity.json.  Not with
