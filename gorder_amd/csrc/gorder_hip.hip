@@ -82,6 +82,7 @@ struct gorder_hip_handle {
     uint32_t *d_ua_item_run = nullptr, *d_item_run = nullptr;
     uint4 *d_lgrid = nullptr;       // per slab frame: the cell grid of the local-leaflet kernels
     LocalRowPre *d_lrowpre = nullptr;   // per slab frame: prefix sums along the rows of cells (k_local_rowprefix)
+    LocalEdge *d_ledge = nullptr;       // the same cells' 16-byte entries for the bound of k_local_flags_rows
     float4 *d_lfinfo = nullptr;     // per slab frame: extrema of the membrane's normal coordinate, finite flag
     uint2 *d_ltodo = nullptr;       // {count}, then the (slab frame, head) pairs left to the general passes
     size_t map_lds_bytes = 0;
@@ -1122,6 +1123,7 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
             HIP_TRY(h, hipMalloc((void **)&h->d_lgrid, sl * sizeof(uint4)));
             if (h->local_halo) {    // (GORDER_HIP_LOCAL_ATOMS_ONLY, an A/B switch: every candidate atom by atom, the general passes)
                 HIP_TRY(h, hipMalloc((void **)&h->d_lrowpre, sl * (size_t)kLocalMaxCells1D * (kLocalMaxCells1D + 1u) * sizeof(LocalRowPre)));
+                HIP_TRY(h, hipMalloc((void **)&h->d_ledge, sl * (size_t)kLocalMaxCells1D * (kLocalMaxCells1D + 1u) * sizeof(LocalEdge)));
                 HIP_TRY(h, hipMalloc((void **)&h->d_lfinfo, sl * sizeof(float4)));
                 HIP_TRY(h, hipMalloc((void **)&h->d_ltodo, (1 + sl * (size_t)(p.n_mol_total ? p.n_mol_total : 1)) * sizeof(uint2)));
             }
@@ -1148,7 +1150,7 @@ void gorder_hip_destroy(gorder_hip_handle *h) {
     (void)hipFree(h->d_geom_group); (void)hipFree(h->d_shapes); (void)hipFree(h->d_inv_box);
     (void)hipFree(h->d_map_rec); (void)hipFree(h->d_ua_runs); (void)hipFree(h->d_ua_run_begin);
     (void)hipFree(h->d_runs); (void)hipFree(h->d_run_begin); (void)hipFree(h->d_items_by_slot);
-    (void)hipFree(h->d_ua_item_run); (void)hipFree(h->d_item_run); (void)hipFree(h->d_lgrid); (void)hipFree(h->d_lrowpre); (void)hipFree(h->d_lfinfo); (void)hipFree(h->d_ltodo);
+    (void)hipFree(h->d_ua_item_run); (void)hipFree(h->d_item_run); (void)hipFree(h->d_lgrid); (void)hipFree(h->d_lrowpre); (void)hipFree(h->d_ledge); (void)hipFree(h->d_lfinfo); (void)hipFree(h->d_ltodo);
     (void)hipFree(h->d_dyn_cloud); (void)hipFree(h->d_dyn_heads); (void)hipFree(h->d_dyn_cell_of); (void)hipFree(h->d_dyn_count);
     (void)hipFree(h->d_dyn_rec); (void)hipFree(h->d_dyn_normals); (void)hipFree(h->d_dyn_cov);
     if (!h->acc_external) (void)hipFree(h->d_acc);
@@ -1254,8 +1256,10 @@ static int run_leaflets(gorder_hip_handle *h, const float *d_xyz, const float *d
         lo.cell_fill = h->d_lcell_fill; lo.err = h->d_err;
         lo.grid = h->d_lgrid;
         lo.halo = h->local_halo ? 1 : 0;
+        lo.prune = env_flag("GORDER_HIP_LOCAL_NO_PRUNE") ? 0 : 1;
         lo.rec_stride = (uint32_t)h->local_rec_stride;
         lo.rowpre = h->d_lrowpre;
+        lo.edge = h->d_ledge;
         lo.finfo = h->d_lfinfo;
         lo.todo = h->d_ltodo;
         for (size_t done = 0; done < aframes.size(); done += h->local_slab) {

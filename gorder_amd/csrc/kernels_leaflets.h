@@ -482,7 +482,22 @@ inline uint32_t local_slab_frames(size_t n_membrane) {
     return (uint32_t)(n < 4 ? 4 : (n > kLocalSlabMax ? kLocalSlabMax : n));
 }
 
-struct LocalRowPre { float sc, ss; double sz; };   // sum cos, sum sin, sum of the normal coordinate: cells before this one in its row
+// Two tables of running sums along each row of cells (k_local_rowprefix), an entry per cell = the cells before it in its row:
+// LocalRowPre for the exact centre (sum cos, sum sin of the normal angle in f32; the normal coordinate itself in f64), and
+// LocalEdge, 16 bytes = ONE load, for the bound that decides most heads without their ring (k_local_flags_rows): the cell's
+// first record, sum of (z - half the box) and of its square in f32 (they only feed a bound that carries its own slack), and
+// the cos / sin sums again as two 16-bit fixed-point numbers (1/16 units, modulo 2^16: a DIFFERENCE of two entries is
+// exact to 1/16 as long as it is below 2048 in magnitude, i.e. the span holds fewer than 2048 records).
+struct LocalRowPre { float sc, ss; double sz; };
+struct alignas(16) LocalEdge { uint32_t q; float zm, sq; uint32_t cs; };
+constexpr uint32_t kEdgeSpanMax = 2000;        // records in a span whose 16-bit cos / sin differences are still exact
+__device__ __forceinline__ uint32_t local_edge_trig(float sc, float ss) {
+    return ((uint32_t)(int)__builtin_rintf(sc * 16.0f) & 0xffffu) | ((uint32_t)(int)__builtin_rintf(ss * 16.0f) << 16);
+}
+__device__ __forceinline__ void local_edge_trig_diff(uint32_t hi, uint32_t lo, float &dc, float &ds) {
+    dc = (float)(int16_t)((hi & 0xffffu) - (lo & 0xffffu)) * 0.0625f;
+    ds = (float)(int16_t)((hi >> 16) - (lo >> 16)) * 0.0625f;
+}
 // a membrane atom in cell order: (in-plane a, in-plane b, normal coordinate), 12 bytes.  (Round 2 kept cos and sin of the
 // normal angle next to it, 20 bytes an atom: the kernels that walk the records are bound by the bytes they pull through
 // L2, and the two hardware transcendentals that make the pair again from the coordinate cost less than the 8 bytes.)
@@ -520,8 +535,10 @@ struct LocalArgs {
     // copies of its first 2 kb cells (records included), so that the (2 kb + 1) cells a head looks at in a row are one
     // contiguous run of cells — and of records — wherever the head stands; rows are `ncb + 2 kb` cells apart
     int halo;
+    int prune;                  // k_local_flags_rows: decide a head from bounds on its ring where they suffice (0: GORDER_HIP_LOCAL_NO_PRUNE)
     uint32_t rows_groups;       // k_local_flags_rows: workgroups per frame (16 heads each)
     uint32_t rec_stride;        // records per slab frame the record arrays have room for (>= n_membrane; 2 x with halo)
+    LocalEdge *edge;            // [n_slab][kLocalMaxCells1D * (kLocalMaxCells1D + 1)], see LocalEdge
     LocalRowPre *rowpre;        // [n_slab][kLocalMaxCells1D * (kLocalMaxCells1D + 1)] prefix sums along each row of cells
                                 // (k_local_rowprefix) for k_local_flags_rows, or null
     float4 *finfo;              // [n_slab] (min, max of the membrane's normal coordinate, 1 if every coordinate is finite, -)
@@ -760,8 +777,10 @@ __device__ __forceinline__ uint32_t row_add_u32(uint32_t v) {
 // wave's PIECE + 1 parking places in LDS.  zlo / zhi / nf collect the frame's extrema and non-finite flag.
 template <uint32_t PIECE>
 __device__ __forceinline__ void local_row_prefix(const uint32_t *__restrict__ cstart, const LocalRec *__restrict__ rec,
-                                                 LocalRowPre *__restrict__ out, uint32_t ra, uint32_t ncs, float inv_Ln,
-                                                 float *pc, float *ps, double *pz, float &zlo, float &zhi, uint32_t &nf) {
+                                                 LocalRowPre *__restrict__ out, LocalEdge *__restrict__ out_edge, uint32_t ra,
+                                                 uint32_t ncs, float inv_Ln,
+                                                 float z_mid, float *pc, float *ps, double *pz, float *pq, float &zlo, float &zhi,
+                                                 uint32_t &nf) {
     constexpr uint32_t T = PIECE / 64u;
     const uint32_t lane = threadIdx.x & 63u;
     // the row's cell starts first, all of them at once (cell j = lane + 64 i; entry ncs = the end of the row): the record
@@ -775,7 +794,7 @@ __device__ __forceinline__ void local_row_prefix(const uint32_t *__restrict__ cs
 #pragma unroll
     for (uint32_t i = 0; i < CQ; i++)
         if ((ncs >> 6) == i) qb = (uint32_t)__shfl((int)cq[i], (int)(ncs & 63u), 64);       // (uniform)
-    float carry_c = 0.0f, carry_s = 0.0f;
+    float carry_c = 0.0f, carry_s = 0.0f, carry_q = 0.0f;
     double carry_z = 0.0;
     for (uint32_t base = qa; base < qb || base == qa; base += PIECE) {
         const uint32_t n_here = min(PIECE, qb - base);
@@ -794,34 +813,37 @@ __device__ __forceinline__ void local_row_prefix(const uint32_t *__restrict__ cs
             local_trig(r[t].z, inv_Ln, &sn_t, &cs_t);
             const float vc = valid ? cs_t : 0.0f, vs = valid ? sn_t : 0.0f;
             const double vz = valid ? (double)r[t].z : 0.0;
+            const float dq = r[t].z - z_mid, vq = valid ? dq * dq : 0.0f;
             if (valid) {
                 zlo = fminf(zlo, r[t].z);
                 zhi = fmaxf(zhi, r[t].z);
                 nf |= ((r[t].x - r[t].x) + (r[t].y - r[t].y)) + (r[t].z - r[t].z) == 0.0f ? 0u : 1u;
             }
-            float ic = vc, is = vs;
+            float ic = vc, is = vs, iq = vq;
             double iz = vz;
-            ic = row_add<0x111>(ic); is = row_add<0x111>(is); iz = row_add_f64<0x111>(iz);
-            ic = row_add<0x112>(ic); is = row_add<0x112>(is); iz = row_add_f64<0x112>(iz);
-            ic = row_add<0x114>(ic); is = row_add<0x114>(is); iz = row_add_f64<0x114>(iz);
-            ic = row_add<0x118>(ic); is = row_add<0x118>(is); iz = row_add_f64<0x118>(iz);
-            float bc = 0.0f, bs = 0.0f;
+            ic = row_add<0x111>(ic); is = row_add<0x111>(is); iz = row_add_f64<0x111>(iz); iq = row_add<0x111>(iq);
+            ic = row_add<0x112>(ic); is = row_add<0x112>(is); iz = row_add_f64<0x112>(iz); iq = row_add<0x112>(iq);
+            ic = row_add<0x114>(ic); is = row_add<0x114>(is); iz = row_add_f64<0x114>(iz); iq = row_add<0x114>(iq);
+            ic = row_add<0x118>(ic); is = row_add<0x118>(is); iz = row_add_f64<0x118>(iz); iq = row_add<0x118>(iq);
+            float bc = 0.0f, bs = 0.0f, bq = 0.0f;
             double bz = 0.0;
 #pragma unroll
             for (int r4 = 0; r4 < 3; r4++) {
-                const float tc = __shfl(ic, 16 * r4 + 15, 64), ts = __shfl(is, 16 * r4 + 15, 64);
+                const float tc = __shfl(ic, 16 * r4 + 15, 64), ts = __shfl(is, 16 * r4 + 15, 64), tq = __shfl(iq, 16 * r4 + 15, 64);
                 const double tz = __shfl(iz, 16 * r4 + 15, 64);
-                if ((int)(lane >> 4) > r4) { bc += tc; bs += ts; bz += tz; }
+                if ((int)(lane >> 4) > r4) { bc += tc; bs += ts; bz += tz; bq += tq; }
             }
-            ic += bc; is += bs; iz += bz;                                   // inclusive over the 64 lanes
+            ic += bc; is += bs; iz += bz; iq += bq;                         // inclusive over the 64 lanes
             pc[64u * t + lane] = carry_c + (ic - vc);                       // records of the row before this one
             ps[64u * t + lane] = carry_s + (is - vs);
             pz[64u * t + lane] = carry_z + (iz - vz);
+            pq[64u * t + lane] = carry_q + (iq - vq);
             carry_c += __shfl(ic, 63, 64);
             carry_s += __shfl(is, 63, 64);
             carry_z += __shfl(iz, 63, 64);
+            carry_q += __shfl(iq, 63, 64);
         }
-        if (lane == 0u) { pc[n_here] = carry_c; ps[n_here] = carry_s; pz[n_here] = carry_z; }   // behind the piece's last record
+        if (lane == 0u) { pc[n_here] = carry_c; ps[n_here] = carry_s; pz[n_here] = carry_z; pq[n_here] = carry_q; }   // behind the piece's last record
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -835,6 +857,12 @@ __device__ __forceinline__ void local_row_prefix(const uint32_t *__restrict__ cs
                 LocalRowPre o;
                 o.sc = pc[q0 - base]; o.ss = ps[q0 - base]; o.sz = pz[q0 - base];
                 out[j] = o;
+                LocalEdge e;
+                e.q = q0;
+                e.zm = (float)(o.sz - (double)(q0 - qa) * (double)z_mid);
+                e.sq = pq[q0 - base];
+                e.cs = local_edge_trig(o.sc, o.ss);
+                out_edge[j] = e;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -862,7 +890,7 @@ __device__ __forceinline__ void local_finfo_merge(const LocalArgs &a, uint32_t s
 // membrane: neither the waves in flight nor the round trips per row bound this kernel; 256 keeps the LDS small)
 constexpr uint32_t kRowPrefixPiece = 256;
 __global__ __launch_bounds__(256) void k_local_rowprefix(LocalArgs a) {
-    __shared__ float l_c[4][kRowPrefixPiece + 1], l_s[4][kRowPrefixPiece + 1];
+    __shared__ float l_c[4][kRowPrefixPiece + 1], l_s[4][kRowPrefixPiece + 1], l_q[4][kRowPrefixPiece + 1];
     __shared__ double l_z[4][kRowPrefixPiece + 1];
     const uint32_t s = blockIdx.y, wave = threadIdx.x >> 6, ra = blockIdx.x * 4u + wave;
     const uint4 g = a.grid[s];
@@ -875,9 +903,11 @@ __global__ __launch_bounds__(256) void k_local_rowprefix(LocalArgs a) {
     float box[3];
     frame_box(a, a.aframes ? a.aframes[s] : a.frame0 + s, box);
     LocalRowPre *out = a.rowpre + (size_t)s * (kLocalMaxCells1D * (kLocalMaxCells1D + 1u)) + (size_t)ra * (ncs + 1u);
+    LocalEdge *out_edge = a.edge + (size_t)s * (kLocalMaxCells1D * (kLocalMaxCells1D + 1u)) + (size_t)ra * (ncs + 1u);
     float zlo = 3.0e38f, zhi = -3.0e38f;
     uint32_t nf = 0;
-    local_row_prefix<kRowPrefixPiece>(cstart, rec, out, ra, ncs, 1.0f / box[a.dim], l_c[wave], l_s[wave], l_z[wave], zlo, zhi, nf);
+    local_row_prefix<kRowPrefixPiece>(cstart, rec, out, out_edge, ra, ncs, 1.0f / box[a.dim], 0.5f * box[a.dim], l_c[wave], l_s[wave], l_z[wave],
+                                      l_q[wave], zlo, zhi, nf);
     if (merge) local_finfo_merge(a, s, zlo, zhi, nf);
 }
 
@@ -1442,9 +1472,9 @@ __global__ __launch_bounds__(256) void k_local_flags_rows(LocalArgs a) {
     const float halfn = Ln / 2.0f;
     const float thr = a.radius_thr;
     const uint32_t n_rows = 2u * ka + 1u;
-    const uint32_t *cstart = a.cell_count + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u);
     const LocalRec *rec = reinterpret_cast<const LocalRec *>(a.trig) + (size_t)s * a.rec_stride;
     const LocalRowPre *pre = a.rowpre + (size_t)s * (kLocalMaxCells1D * (kLocalMaxCells1D + 1u));
+    const LocalEdge *edge = a.edge + (size_t)s * (kLocalMaxCells1D * (kLocalMaxCells1D + 1u));
     // (uniform) grids the rows do not handle, frames with a non-finite coordinate
     const bool fail = !(ka >= 1u && kb >= 1u && n_rows <= 16u && fk.z == 0u && fk.x <= fk.y);
 
@@ -1474,6 +1504,12 @@ __global__ __launch_bounds__(256) void k_local_flags_rows(LocalArgs a) {
     float sc = 0.0f, ss = 0.0f, su = 0.0f;            // (sc, ss: over the cells wholly inside only, see the end)
     double inner_z = 0.0;
     uint32_t cnt = 0, n_inner = 0, n_ring = 0;
+    // for the bound that may decide the head without its ring (below): this row's candidates — every record of the cells the
+    // circle touches —, their number, the sum of their normal coordinates and of the squares, relative to the middle of the box
+    const float z_mid = 0.5f * Ln;
+    uint32_t c_n = 0, r_n = 0, j_lo = 0, j_hi = 0, row_e0 = 0;
+    float c_z = 0.0f, r_z = 0.0f, r_q = 0.0f, c_c = 0.0f, c_s = 0.0f;
+    bool span_ok = true;
     uint2 *ring = l_ring[wave * 4u + row];
     uint32_t run_q0[2] = {0u, 0u}, run_q1[2] = {0u, 0u};
     if (!fail && sub < n_rows) {
@@ -1506,23 +1542,89 @@ __global__ __launch_bounds__(256) void k_local_flags_rows(LocalArgs a) {
             }
             uint32_t ra = a0 + sub;
             ra -= ra >= nca ? nca : 0u;
-            const uint32_t c0 = ra * ncs + b0;
             const bool inner = ji_lo <= ji_hi;
-            const uint32_t qa0 = cstart[c0 + jo_lo], qb1 = cstart[c0 + jo_hi + 1u];
-            const uint32_t qa1 = inner ? cstart[c0 + ji_lo] : qb1;
-            const uint32_t qb0 = inner ? cstart[c0 + ji_hi + 1u] : qb1;
-            if (inner) {
-                const LocalRowPre p_lo = pre[ra * (ncs + 1u) + b0 + ji_lo], p_hi = pre[ra * (ncs + 1u) + b0 + ji_hi + 1u];
-                const uint32_t n_in = qb0 - qa1;
-                cnt += n_in;
-                n_inner = n_in;
-                sc += p_hi.sc - p_lo.sc;
-                ss += p_hi.ss - p_lo.ss;
-                inner_z = p_hi.sz - p_lo.sz;
-            }
+            // the four cell edges of the row in ONE round trip: the outer span's two, the inner span's two (a row without an
+            // inner cell takes the outer span's end for both: empty differences); an entry holds the cell's first record too
+            const LocalEdge *row_edge = edge + ra * (ncs + 1u) + b0;
+            const uint32_t j_d = jo_hi + 1u;
+            j_lo = inner ? ji_lo : j_d;
+            j_hi = inner ? ji_hi + 1u : j_d;
+            row_e0 = ra * (ncs + 1u) + b0;
+            const LocalEdge e_a = row_edge[jo_lo], e_d = row_edge[j_d], e_lo = row_edge[j_lo], e_hi = row_edge[j_hi];
+            const uint32_t qa0 = e_a.q, qb1 = e_d.q, qa1 = e_lo.q, qb0 = e_hi.q;
+            n_inner = qb0 - qa1;
+            cnt += n_inner;
+            c_n = qb1 - qa0;
+            c_z = e_d.zm - e_a.zm;
+            r_n = c_n - n_inner;
+            r_z = c_z - (e_hi.zm - e_lo.zm);
+            r_q = (e_d.sq - e_a.sq) - (e_hi.sq - e_lo.sq);
+            local_edge_trig_diff(e_d.cs, e_a.cs, c_c, c_s);
+            span_ok = c_n < kEdgeSpanMax;
             run_q0[0] = qa0; run_q1[0] = qa1;
             run_q0[1] = qb0; run_q1[1] = qb1;
         }
+    }
+    // ---- a head its ring cannot change.  The leaflet is the SIGN of  z_head - centre,  centre = the mean normal coordinate of
+    // the members (of their periodic images next to the circular-mean estimate).  Write u = z - z_head (plain differences) and
+    // S = sum over the members of u: the sign wanted is minus the sign of S wherever (i) the reference's image choice moves
+    // every member by the SAME number of box lengths and (ii) |S / n| < L / 2.
+    // The members are the candidates (every record of the cells the circle touches: n_c of them, T = sum of their u, from the
+    // prefix sums) without the non-members, which are SOME of the ring candidates (N of them, A = sum of u, B = sum of u^2,
+    // prefix sums again).  For any subset K of the ring  sum_K u = (A + sum_j e_j u_j) / 2  with signs e_j = +-1, and
+    // |sum_j e_j u_j| <= sqrt(N B) (Cauchy-Schwarz), so
+    //     S  lies in  [T - A / 2 - sqrt(N B) / 2,  T - A / 2 + sqrt(N B) / 2] .
+    // If that interval keeps clear of zero — by more than the rounding of the reference's f32 mean and of the f32 arithmetic
+    // here can move it (`slack`) — the head's side is known without looking at a single ring atom.  That is the case for
+    // every head whose local centre is not within a few hundredths of a nanometre of the head itself (measured: all heads of
+    // the reference's own coarse-grained membrane and of the synthetic ones, flat or undulating by 2 nm;
+    // tools/local_prune_probe.py).
+    // (i): the circular mean of the CANDIDATES stands in for the reference's estimate (of the members) the way the inner
+    // cells' does further down: the resultants differ by at most N unit vectors, the directions by asin(N / |R_c|) <=
+    // (pi / 2) N / |R_c|, a length of (N / |R_c|) L / 4; every coordinate of the frame must keep that distance, and a margin,
+    // from the far side of the box as seen from the stand-in.  (ii): (|T - A / 2| + sqrt(N B) / 2) / n_inner < L / 2.
+    // A wave whose four heads are all decided skips the lists, the ring loop and the centre; any other wave does everything
+    // as before (and finds the same sides).
+    if (a.prune) {          // (uniform)
+        c_n = row_add_u32<0x111>(c_n); r_n = row_add_u32<0x111>(r_n); c_z = row_add<0x111>(c_z); r_z = row_add<0x111>(r_z); r_q = row_add<0x111>(r_q);
+        c_n = row_add_u32<0x112>(c_n); r_n = row_add_u32<0x112>(r_n); c_z = row_add<0x112>(c_z); r_z = row_add<0x112>(r_z); r_q = row_add<0x112>(r_q);
+        c_n = row_add_u32<0x114>(c_n); r_n = row_add_u32<0x114>(r_n); c_z = row_add<0x114>(c_z); r_z = row_add<0x114>(r_z); r_q = row_add<0x114>(r_q);
+        c_n = row_add_u32<0x118>(c_n); r_n = row_add_u32<0x118>(r_n); c_z = row_add<0x118>(c_z); r_z = row_add<0x118>(r_z); r_q = row_add<0x118>(r_q);
+        c_c = row_add<0x111>(c_c); c_s = row_add<0x111>(c_s);
+        c_c = row_add<0x112>(c_c); c_s = row_add<0x112>(c_s);
+        c_c = row_add<0x114>(c_c); c_s = row_add<0x114>(c_s);
+        c_c = row_add<0x118>(c_c); c_s = row_add<0x118>(c_s);
+        const float hm = hn_pos - z_mid, fn = (float)c_n, fr = (float)r_n, fi = (float)(c_n - r_n);
+        const float T = c_z - fn * hm, A = r_z - fr * hm;
+        const float B = __builtin_fmaxf((r_q - 2.0f * hm * r_z) + fr * hm * hm, 0.0f) * 1.02f + 1e-3f * fr;
+        const float mid = T - 0.5f * A, rad = 0.5005f * __builtin_amdgcn_sqrtf(fr * B);
+        const float slack = 0.1f + fn * (1e-3f + 1e-6f * fn * Ln);
+        // (i)
+        const float r_c = __builtin_amdgcn_sqrtf(c_c * c_c + c_s * c_s);
+        const float est_c = (local_atan2_fast(-c_s, -c_c) + 3.1415927f) * (Ln * 0.15915494f);
+        const float shift_c = gm_min_image(hn_pos - est_c, Ln, bad);
+        const float emargin = 1e-4f * Ln + (fr + 1.0f) * __builtin_amdgcn_rcpf(r_c) * (0.2501f * Ln);
+        const bool same_image = fr + 1.0f < r_c && ulo_g + shift_c > -halfn + emargin && uhi_g + shift_c < halfn - emargin;
+        // (ii)
+        const bool head_near = __builtin_fabsf(mid) + rad < (halfn - 1e-3f * Ln) * fi;
+        const uint64_t wide = __ballot(!span_ok);        // a span too long for the 16-bit cos / sin differences: its head is not decided here
+        const bool spans_ok = ((wide >> (16u * row)) & 0xffffull) == 0ull;
+        const bool decided = !fail && !redo && spans_ok && c_n > r_n && same_image && head_near && (int)s != a.write_dist_frame &&
+                             __builtin_fabsf(mid) > rad + slack;             // (NaN anywhere: not decided)
+        const uint64_t dm = __ballot(sub != 15u || decided || !head_ok);
+        if (dm == ~0ull) {
+            if (sub == 15u && head_ok)       // S > 0: the centre lies above the head, d = z_head - centre < 0
+                a.aflags[(size_t)(a.row0 + s) * a.n_mol_total + m] = (uint8_t)((mid > 0.0f ? 1 : 0) ^ (a.flip ? 1 : 0));
+            if (bad) raise_box_range(a.err, f);
+            return;
+        }
+    }
+    // ---- the exact path from here: the inner span's sums for the centre
+    if (!fail && sub < n_rows && j_lo != j_hi) {
+        const LocalRowPre p_lo = pre[row_e0 + j_lo], p_hi = pre[row_e0 + j_hi];
+        sc += p_hi.sc - p_lo.sc;
+        ss += p_hi.ss - p_lo.ss;
+        inner_z = p_hi.sz - p_lo.sz;
     }
     // ---- the ring runs go to the row's list in pieces of <= 8 records: every lane's share of the list starts where
     // the lanes before it in the row end (exclusive scan of the piece counts by row shifts)
