@@ -1475,6 +1475,7 @@ __global__ __launch_bounds__(256) void k_local_flags_rows(LocalArgs a) {
     const LocalRec *rec = reinterpret_cast<const LocalRec *>(a.trig) + (size_t)s * a.rec_stride;
     const LocalRowPre *pre = a.rowpre + (size_t)s * (kLocalMaxCells1D * (kLocalMaxCells1D + 1u));
     const LocalEdge *edge = a.edge + (size_t)s * (kLocalMaxCells1D * (kLocalMaxCells1D + 1u));
+    const uint32_t *cstart = a.cell_count + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u);
     // (uniform) grids the rows do not handle, frames with a non-finite coordinate
     const bool fail = !(ka >= 1u && kb >= 1u && n_rows <= 16u && fk.z == 0u && fk.x <= fk.y);
 
@@ -1507,6 +1508,9 @@ __global__ __launch_bounds__(256) void k_local_flags_rows(LocalArgs a) {
     // for the bound that may decide the head without its ring (below): this row's candidates — every record of the cells the
     // circle touches —, their number, the sum of their normal coordinates and of the squares, relative to the middle of the box
     const float z_mid = 0.5f * Ln;
+    // (a frame whose atoms span more than three quarters of the box along the normal cannot pass condition (i) below with a
+    // ring of the usual size: its heads do not try — a shortcut about speed, not about correctness)
+    const bool try_prune = a.prune != 0 && z_max - z_min < 0.75f * Ln;       // (uniform)
     uint32_t c_n = 0, r_n = 0, j_lo = 0, j_hi = 0, row_e0 = 0;
     float c_z = 0.0f, r_z = 0.0f, r_q = 0.0f, c_c = 0.0f, c_s = 0.0f;
     bool span_ok = true;
@@ -1545,22 +1549,34 @@ __global__ __launch_bounds__(256) void k_local_flags_rows(LocalArgs a) {
             const bool inner = ji_lo <= ji_hi;
             // the four cell edges of the row in ONE round trip: the outer span's two, the inner span's two (a row without an
             // inner cell takes the outer span's end for both: empty differences); an entry holds the cell's first record too
-            const LocalEdge *row_edge = edge + ra * (ncs + 1u) + b0;
             const uint32_t j_d = jo_hi + 1u;
             j_lo = inner ? ji_lo : j_d;
             j_hi = inner ? ji_hi + 1u : j_d;
             row_e0 = ra * (ncs + 1u) + b0;
-            const LocalEdge e_a = row_edge[jo_lo], e_d = row_edge[j_d], e_lo = row_edge[j_lo], e_hi = row_edge[j_hi];
-            const uint32_t qa0 = e_a.q, qb1 = e_d.q, qa1 = e_lo.q, qb0 = e_hi.q;
+            uint32_t qa0, qb1, qa1, qb0;
+            if (try_prune) {
+                const LocalEdge *row_edge = edge + row_e0;
+                const LocalEdge e_a = row_edge[jo_lo], e_d = row_edge[j_d], e_lo = row_edge[j_lo], e_hi = row_edge[j_hi];
+                qa0 = e_a.q; qb1 = e_d.q; qa1 = e_lo.q; qb0 = e_hi.q;
+                c_n = qb1 - qa0;
+                c_z = e_d.zm - e_a.zm;
+                r_n = c_n - (qb0 - qa1);
+                r_z = c_z - (e_hi.zm - e_lo.zm);
+                r_q = (e_d.sq - e_a.sq) - (e_hi.sq - e_lo.sq);
+                local_edge_trig_diff(e_d.cs, e_a.cs, c_c, c_s);
+                span_ok = c_n < kEdgeSpanMax;
+            } else {                            // the exact path for certain: the cell list's own starts (4 bytes an edge) and its sums
+                const uint32_t c0 = ra * ncs + b0;
+                qa0 = cstart[c0 + jo_lo]; qb1 = cstart[c0 + j_d]; qa1 = cstart[c0 + j_lo]; qb0 = cstart[c0 + j_hi];
+                if (inner) {
+                    const LocalRowPre p_lo = pre[row_e0 + j_lo], p_hi = pre[row_e0 + j_hi];
+                    sc += p_hi.sc - p_lo.sc;
+                    ss += p_hi.ss - p_lo.ss;
+                    inner_z = p_hi.sz - p_lo.sz;
+                }
+            }
             n_inner = qb0 - qa1;
             cnt += n_inner;
-            c_n = qb1 - qa0;
-            c_z = e_d.zm - e_a.zm;
-            r_n = c_n - n_inner;
-            r_z = c_z - (e_hi.zm - e_lo.zm);
-            r_q = (e_d.sq - e_a.sq) - (e_hi.sq - e_lo.sq);
-            local_edge_trig_diff(e_d.cs, e_a.cs, c_c, c_s);
-            span_ok = c_n < kEdgeSpanMax;
             run_q0[0] = qa0; run_q1[0] = qa1;
             run_q0[1] = qb0; run_q1[1] = qb1;
         }
@@ -1580,12 +1596,13 @@ __global__ __launch_bounds__(256) void k_local_flags_rows(LocalArgs a) {
     // the reference's own coarse-grained membrane and of the synthetic ones, flat or undulating by 2 nm;
     // tools/local_prune_probe.py).
     // (i): the circular mean of the CANDIDATES stands in for the reference's estimate (of the members) the way the inner
-    // cells' does further down: the resultants differ by at most N unit vectors, the directions by asin(N / |R_c|) <=
-    // (pi / 2) N / |R_c|, a length of (N / |R_c|) L / 4; every coordinate of the frame must keep that distance, and a margin,
-    // from the far side of the box as seen from the stand-in.  (ii): (|T - A / 2| + sqrt(N B) / 2) / n_inner < L / 2.
+    // cells' does further down: the resultants differ by at most N unit vectors, the directions by asin(N / |R_c|), a length
+    // of asin(N / |R_c|) L / (2 pi); every coordinate of the frame must keep that distance, and a margin, from the far side of
+    // the box as seen from the stand-in.  (This is the condition that fails first: a membrane that undulates by a nanometre
+    // in a 10-nm box leaves too little water for it, and its heads take the exact path, as before.)  (ii): (|T - A / 2| + sqrt(N B) / 2) / n_inner < L / 2.
     // A wave whose four heads are all decided skips the lists, the ring loop and the centre; any other wave does everything
     // as before (and finds the same sides).
-    if (a.prune) {          // (uniform)
+    if (try_prune) {
         c_n = row_add_u32<0x111>(c_n); r_n = row_add_u32<0x111>(r_n); c_z = row_add<0x111>(c_z); r_z = row_add<0x111>(r_z); r_q = row_add<0x111>(r_q);
         c_n = row_add_u32<0x112>(c_n); r_n = row_add_u32<0x112>(r_n); c_z = row_add<0x112>(c_z); r_z = row_add<0x112>(r_z); r_q = row_add<0x112>(r_q);
         c_n = row_add_u32<0x114>(c_n); r_n = row_add_u32<0x114>(r_n); c_z = row_add<0x114>(c_z); r_z = row_add<0x114>(r_z); r_q = row_add<0x114>(r_q);
@@ -1603,7 +1620,8 @@ __global__ __launch_bounds__(256) void k_local_flags_rows(LocalArgs a) {
         const float r_c = __builtin_amdgcn_sqrtf(c_c * c_c + c_s * c_s);
         const float est_c = (local_atan2_fast(-c_s, -c_c) + 3.1415927f) * (Ln * 0.15915494f);
         const float shift_c = gm_min_image(hn_pos - est_c, Ln, bad);
-        const float emargin = 1e-4f * Ln + (fr + 1.0f) * __builtin_amdgcn_rcpf(r_c) * (0.2501f * Ln);
+        const float xr = (fr + 1.0f) * __builtin_amdgcn_rcpf(r_c);          // asin(x) <= x + (pi / 2 - 1) x^3 on [0, 1]
+        const float emargin = 1e-4f * Ln + (xr + 0.5708f * xr * xr * xr) * (0.15916f * Ln);
         const bool same_image = fr + 1.0f < r_c && ulo_g + shift_c > -halfn + emargin && uhi_g + shift_c < halfn - emargin;
         // (ii)
         const bool head_near = __builtin_fabsf(mid) + rad < (halfn - 1e-3f * Ln) * fi;
@@ -1620,7 +1638,7 @@ __global__ __launch_bounds__(256) void k_local_flags_rows(LocalArgs a) {
         }
     }
     // ---- the exact path from here: the inner span's sums for the centre
-    if (!fail && sub < n_rows && j_lo != j_hi) {
+    if (try_prune && !fail && sub < n_rows && j_lo != j_hi) {
         const LocalRowPre p_lo = pre[row_e0 + j_lo], p_hi = pre[row_e0 + j_hi];
         sc += p_hi.sc - p_lo.sc;
         ss += p_hi.ss - p_lo.ss;

@@ -841,3 +841,82 @@ def test_wide_windows_fit_the_default_lds_budget(built):
     plan = eng.plan()
     assert plan["max_window_atoms"] > 700 and plan["n_direct_items"] == 0
     assert plan["frames_per_stage"] == 4 and plan["lds_bytes"] <= 64 * 1024
+
+
+# ---- k_local_flags_rows decides most heads from a bound on their ring (round 4): the decision and the exact path agree ----
+def _sums_equal(a, b):
+    np.testing.assert_array_equal(a.sums, b.sums)
+    np.testing.assert_array_equal(a.counts, b.counts)
+
+
+@pytest.mark.parametrize("shape", ["flat", "undulating", "tight box"])
+def test_local_leaflets_decided_from_the_bound_are_the_exact_paths(built, monkeypatch, shape):
+    """The rows kernel skips a head's ring when prefix sums alone bound the members' mean normal coordinate away from the
+    head (kernels_leaflets.h, "a head its ring cannot change"); GORDER_HIP_LOCAL_NO_PRUNE=1 sends every head through the
+    lists, the ring loop and the centre.  Upper / lower sums of every frame — all frames but a batch's last take the bound —
+    must be EQUAL between the two, and to the oracle's."""
+    box = {"flat": None, "undulating": (16.0, 16.0, 12.0), "tight box": (14.0, 14.0, 7.4)}[shape]
+    system = synthetic.cg_membrane(900 if shape == "flat" else 500, leaflets=LEAFLETS_LOCAL, radius=2.5, n_types=2, box=box)
+    n = 12
+    xyz = system.frames(n, seed=53)
+    if shape == "undulating":
+        wave = 1.5 * np.sin(2 * np.pi * xyz[:, :, 0] / 16.0) * np.cos(2 * np.pi * xyz[:, :, 1] / 16.0)
+        xyz[:, :, 2] = (xyz[:, :, 2] + wave).astype(np.float32)
+    _, pruned = run_gpu(system, xyz, system.box9(n), batches=2)
+    monkeypatch.setenv("GORDER_HIP_LOCAL_NO_PRUNE", "1")
+    _, exact = run_gpu(system, xyz, system.box9(n), batches=2)
+    monkeypatch.delenv("GORDER_HIP_LOCAL_NO_PRUNE")
+    _sums_equal(pruned, exact)
+    assert pruned.counts[1].sum() > 0 and pruned.counts[2].sum() > 0
+    _, want = run_oracle(system, xyz, system.box9(n))
+    _sums_equal(pruned, want)
+
+
+def test_local_leaflets_with_heads_on_the_local_mid_plane(built, monkeypatch):
+    """Heads a millimicron from the centre of their own neighbourhood: the bound cannot decide them (its slack is a few
+    thousandths of a nanometre), their waves take the exact path while the others are decided from the sums — and every
+    flag is still the oracle's."""
+    system = synthetic.cg_membrane(800, leaflets=LEAFLETS_LOCAL, radius=2.5, n_types=2)
+    n = 6
+    xyz = system.frames(n, seed=59).astype(np.float32)
+    box = np.asarray(system.box, dtype=np.float64)
+    heads = np.concatenate([np.asarray(m.heads) for m in system.tables.molecule_types])
+    rng = np.random.default_rng(61)
+    moved = rng.choice(heads, 40, replace=False)
+    offs = rng.uniform(4e-4, 2e-3, len(moved)) * rng.choice([-1.0, 1.0], len(moved))
+    for f in range(n):
+        for _ in range(4):                      # a head moves its own neighbourhood's mean a little: iterate
+            p = xyz[f].astype(np.float64)
+            for h, off in zip(moved, offs):
+                d = p[:, :2] - p[h, :2]
+                d -= box[:2] * np.round(d / box[:2])
+                members = (d ** 2).sum(1) < 2.5 ** 2
+                xyz[f, h, 2] = np.float32(p[members, 2].mean() + off)
+    eng, got = run_gpu(system, xyz, system.box9(n), batches=2)
+    o, want = run_oracle(system, xyz, system.box9(n))
+    flags, _ = eng.leaflets()
+    oflags, odist, _ = o.leaflets()
+    diff = flags != oflags
+    assert not diff.any() or np.abs(odist[diff]).max() < 1e-4
+    assert_sums_given_device_flags(system.tables, xyz, system.box9(n), got, max_flag_diffs=8)
+    monkeypatch.setenv("GORDER_HIP_LOCAL_NO_PRUNE", "1")
+    _, exact = run_gpu(system, xyz, system.box9(n), batches=2)
+    _sums_equal(got, exact)
+
+
+def test_local_leaflets_with_spans_too_long_for_the_16_bit_sums(built, monkeypatch):
+    """The edge entries keep the cos / sin sums in 16 bits (differences exact below 2048 records a span): 2 600 atoms on one
+    spot make spans longer than that, the heads that see them are not decided from the bound, and nothing shows."""
+    system = synthetic.cg_membrane(600, leaflets=LEAFLETS_LOCAL, radius=2.0, n_types=2, box=(16.0, 16.0, 10.0))
+    n = 4
+    xyz = system.frames(n, seed=67)
+    rng = np.random.default_rng(7)
+    crowd = rng.choice(xyz.shape[1], 2600, replace=False)
+    xyz[:, crowd, 0] = (5.03 + rng.normal(0, 0.01, (n, 2600))).astype(np.float32)
+    xyz[:, crowd, 1] = (9.41 + rng.normal(0, 0.01, (n, 2600))).astype(np.float32)
+    _, got = run_gpu(system, xyz, system.box9(n), batches=1)
+    monkeypatch.setenv("GORDER_HIP_LOCAL_NO_PRUNE", "1")
+    _, exact = run_gpu(system, xyz, system.box9(n), batches=1)
+    monkeypatch.delenv("GORDER_HIP_LOCAL_NO_PRUNE")
+    _sums_equal(got, exact)
+    assert_sums_given_device_flags(system.tables, xyz, system.box9(n), got, max_flag_diffs=8)
