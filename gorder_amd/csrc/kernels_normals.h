@@ -103,10 +103,11 @@ __global__ __launch_bounds__(256) void k_dyn_cov(LocalArgs a, DynCov *__restrict
         float dx = r.x - hx, dy = r.y - hy, dz = r.z - hz;
         if (pbc) { dx = gm_min_image(dx, box[0], bad); dy = gm_min_image(dy, box[1], bad); dz = gm_min_image(dz, box[2], bad); }
         if (valid && (dx * dx + dy * dy) + dz * dz < thr) {          // == sqrt(..) < radius (local_radius_threshold)
+            const double ex = (double)dx, ey = (double)dy, ez = (double)dz;       // (products and sums as f64 fmas: 9 + 3 instead of 6 + 6 + 9)
             cnt += 1;
-            sx += (double)dx; sy += (double)dy; sz += (double)dz;
-            sxx += (double)dx * dx; sxy += (double)dx * dy; sxz += (double)dx * dz;
-            syy += (double)dy * dy; syz += (double)dy * dz; szz += (double)dz * dz;
+            sx += ex; sy += ey; sz += ez;
+            sxx = __builtin_fma(ex, ex, sxx); sxy = __builtin_fma(ex, ey, sxy); sxz = __builtin_fma(ex, ez, sxz);
+            syy = __builtin_fma(ey, ey, syy); syz = __builtin_fma(ey, ez, syz); szz = __builtin_fma(ez, ez, szz);
         }
     };
     auto walk = [&](uint32_t q0, uint32_t q1, uint32_t first, uint32_t step) {      // records q0 + first, + step, ... below q1
