@@ -471,15 +471,18 @@ __global__ __launch_bounds__(256) void k_leaflets_individual(LeafletArgs a) {
 //   k_local_scatter : per (slab frame, membrane atom): cell-ordered record (coordinates + cos/sin)
 //   k_local_flags   : one wave per (slab frame, head): two passes over the 3x3 neighbour cells
 constexpr uint32_t kLocalMaxCells1D = 128;
-// assignment frames processed per launch group: as many as fit 512 MiB of cell-list scratch, at most 256 (one block of
-// k_local_build per frame then fills the 256 CUs)
-constexpr uint32_t kLocalSlabMax = 256;
+// assignment frames processed per launch group: as many as fit 1 GiB of cell-list scratch, at most 512 (two rounds of
+// k_local_build's one block per frame and CU; 256 measured 4 % slower end to end — eight launches a group instead of
+// four per 512 frames —, 128 20 % slower)
+constexpr uint32_t kLocalSlabMax = 512;
 inline uint32_t local_slab_frames(size_t n_membrane) {
     // (the heads' to-do list, 8 bytes per head and frame, is on top: heads are a fraction of the membrane atoms)
-    // (records twice — the halo copies —, the cell of every atom, two tables of cell counts, the rows' prefix sums)
-    const size_t per_frame = n_membrane * (2u * 12u + 4u) + (size_t)(2 * 4u + 16u) * kLocalMaxCells1D * (kLocalMaxCells1D + 1u) + 32u;
-    const size_t n = ((size_t)512 << 20) / per_frame;
-    return (uint32_t)(n < 4 ? 4 : (n > kLocalSlabMax ? kLocalSlabMax : n));
+    // (records twice — the halo copies —, the cell of every atom, two tables of cell counts, the rows' two tables of sums)
+    const size_t per_frame = n_membrane * (2u * 12u + 4u) + (size_t)(2 * 4u + 16u + 16u) * kLocalMaxCells1D * (kLocalMaxCells1D + 1u) + 32u;
+    const size_t n = ((size_t)1024 << 20) / per_frame;
+    uint32_t cap = kLocalSlabMax;
+    if (const char *ev = getenv("GORDER_HIP_LOCAL_SLAB")) cap = (uint32_t)std::max(4, atoi(ev));      // (A/B: frames per launch group)
+    return (uint32_t)(n < 4 ? 4 : (n > cap ? cap : n));
 }
 
 // Two tables of running sums along each row of cells (k_local_rowprefix), an entry per cell = the cells before it in its row:
