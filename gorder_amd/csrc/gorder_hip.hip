@@ -138,6 +138,24 @@ struct gorder_hip_handle {
     size_t arow_cap = 0, aframes_cap = 0;
     bool have_assignment = false;
     uint64_t assignment_frame = 0;
+    // one read for global leaflets + order parameters (Plan::spec_ok; k_bonds_tiled<..., MOM> + k_spec_*)
+    bool spec_enabled = false;         // the plan allows it and GORDER_HIP_NO_SPECULATE is not set
+    bool spec_now = false;             // this batch's order kernel is the MOM variant
+    uint2 *d_own = nullptr;
+    float4 *d_mom = nullptr;
+    size_t mom_cap = 0;
+    float *d_spec_center = nullptr;
+    uint8_t *d_spec_ok = nullptr;
+    size_t spec_frames_cap = 0;
+    uint2 *d_spec_fix = nullptr;
+    size_t spec_fix_cap = 0;
+    uint32_t *d_spec_counters = nullptr;           // [0] mispredicted (frame, molecule) pairs, [1] frames left to the exact kernel
+    uint32_t *h_spec_counters = nullptr;           // pinned copy of the last speculative batch's counters, read one batch later
+    hipEvent_t spec_counters_copied = nullptr;
+    uint64_t spec_prev_frames = 0;                 // frames of that batch (0: nothing to look at)
+    uint32_t *d_spec_mol_begin = nullptr;
+    SpecSample *d_spec_samples = nullptr;
+    uint64_t spec_batches = 0, spec_fixed = 0, spec_exact_frames = 0;   // statistics (gorder_hip_speculation_stats)
     // host staging for submit_host: two device buffers, filled on a copy stream while the kernels of the other one run
     float *d_stage_xyz[2] = {nullptr, nullptr}, *d_stage_box[2] = {nullptr, nullptr};
     size_t stage_xyz_cap[2] = {0, 0}, stage_box_cap[2] = {0, 0};
@@ -458,9 +476,15 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
         const bool ac = (h->tables.flags & GORDER_FLAG_TRIG_ACOS_COS) != 0;
         const dim3 g((uint32_t)grid), b(kBlock);
 #define GORDER_LAUNCH_TILED_A(G_, NPF_, AC_, PBC_, LF_, AX_)                                               \
-        hipLaunchKernelGGL((k_bonds_tiled<G_, NPF_, AC_, PBC_, LF_, AX_>), g, b, h->lds_bytes, h->stream, a,     \
-                           a.xyz, a.box9, a.aflags, a.arow, h->d_tiles, h->d_items, h->d_tile_slots, n_tiles,   \
-                           h->lw)
+        do {                                                                                                \
+            if (LF_ && h->spec_now)                                                                         \
+                hipLaunchKernelGGL((k_bonds_tiled<G_, NPF_, AC_, PBC_, LF_, AX_, LF_>), g, b, h->lds_bytes, h->stream, a, \
+                                   a.xyz, a.box9, a.aflags, a.arow, h->d_tiles, h->d_items, h->d_tile_slots, n_tiles, h->lw); \
+            else                                                                                            \
+                hipLaunchKernelGGL((k_bonds_tiled<G_, NPF_, AC_, PBC_, LF_, AX_>), g, b, h->lds_bytes, h->stream, a,     \
+                                   a.xyz, a.box9, a.aflags, a.arow, h->d_tiles, h->d_items, h->d_tile_slots, n_tiles,   \
+                                   h->lw);                                                                  \
+        } while (0)
 #define GORDER_LAUNCH_TILED_V(G_, NPF_, AC_, PBC_, LF_)                                                    \
         do {                                                                                                \
             if (h->axis == 2) GORDER_LAUNCH_TILED_A(G_, NPF_, AC_, PBC_, LF_, 2);                           \
@@ -1106,6 +1130,27 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
             h->membrane_is_frame = lf.n_membrane == t->n_atoms && !env_flag("GORDER_HIP_LEAFLETS_GENERIC");
             for (uint32_t i = 0; i < lf.n_membrane && h->membrane_is_frame; i++) h->membrane_is_frame = mem[i] == i;
         }
+        // one read for global leaflets + order parameters: the tables of k_bonds_tiled<..., MOM> and k_spec_fixup
+        if (lf.method == GORDER_LEAFLETS_GLOBAL && p.spec_ok && !env_flag("GORDER_HIP_NO_SPECULATE")) {
+            std::vector<uint2> own(p.tiles.size());
+            for (size_t i = 0; i < own.size(); i++) own[i] = make_uint2(p.own[2 * i], p.own[2 * i + 1]);
+            if ((st = upload(h, &h->d_own, own)) != GORDER_OK) return st;
+            std::vector<std::vector<SpecSample>> per_mol(p.n_mol_total);
+            for (const Tile &tile : p.tiles)
+                for (uint32_t q = 0; q < tile.n_items; q++) {
+                    const Item &it = p.items[tile.item0 + q];
+                    per_mol[it.mol].push_back({tile.atom0 + it.li, tile.atom0 + it.lj, p.tile_slots[tile.slot0 + it.lslot]});
+                }
+            std::vector<uint32_t> mbeg(1, 0);
+            std::vector<SpecSample> all;
+            for (const auto &v : per_mol) { all.insert(all.end(), v.begin(), v.end()); mbeg.push_back((uint32_t)all.size()); }
+            if ((st = upload(h, &h->d_spec_mol_begin, mbeg)) != GORDER_OK) return st;
+            if ((st = upload(h, &h->d_spec_samples, all)) != GORDER_OK) return st;
+            HIP_TRY(h, hipMalloc((void **)&h->d_spec_counters, 2 * sizeof(uint32_t)));
+            HIP_TRY(h, hipHostMalloc((void **)&h->h_spec_counters, 2 * sizeof(uint32_t)));
+            HIP_TRY(h, hipEventCreateWithFlags(&h->spec_counters_copied, hipEventDisableTiming));
+            h->spec_enabled = true;
+        }
         if (lf.method == GORDER_LEAFLETS_LOCAL) {
             const size_t nm = lf.n_membrane, ncell = (size_t)kLocalMaxCells1D * kLocalMaxCells1D;
             const size_t sl = h->local_slab = local_slab_frames(nm);
@@ -1150,7 +1195,11 @@ void gorder_hip_destroy(gorder_hip_handle *h) {
     (void)hipFree(h->d_geom_group); (void)hipFree(h->d_shapes); (void)hipFree(h->d_inv_box);
     (void)hipFree(h->d_map_rec); (void)hipFree(h->d_ua_runs); (void)hipFree(h->d_ua_run_begin);
     (void)hipFree(h->d_runs); (void)hipFree(h->d_run_begin); (void)hipFree(h->d_items_by_slot);
-    (void)hipFree(h->d_ua_item_run); (void)hipFree(h->d_item_run); (void)hipFree(h->d_lgrid); (void)hipFree(h->d_lrowpre); (void)hipFree(h->d_ledge); (void)hipFree(h->d_lfinfo); (void)hipFree(h->d_ltodo);
+    (void)hipFree(h->d_ua_item_run); (void)hipFree(h->d_item_run); (void)hipFree(h->d_lgrid); (void)hipFree(h->d_lrowpre); (void)hipFree(h->d_ledge);
+    (void)hipFree(h->d_own); (void)hipFree(h->d_mom); (void)hipFree(h->d_spec_center); (void)hipFree(h->d_spec_ok);
+    (void)hipFree(h->d_spec_fix); (void)hipFree(h->d_spec_counters); (void)hipFree(h->d_spec_mol_begin); (void)hipFree(h->d_spec_samples);
+    if (h->h_spec_counters) (void)hipHostFree(h->h_spec_counters);
+    if (h->spec_counters_copied) (void)hipEventDestroy(h->spec_counters_copied); (void)hipFree(h->d_lfinfo); (void)hipFree(h->d_ltodo);
     (void)hipFree(h->d_dyn_cloud); (void)hipFree(h->d_dyn_heads); (void)hipFree(h->d_dyn_cell_of); (void)hipFree(h->d_dyn_count);
     (void)hipFree(h->d_dyn_rec); (void)hipFree(h->d_dyn_normals); (void)hipFree(h->d_dyn_cov);
     if (!h->acc_external) (void)hipFree(h->d_acc);
@@ -1200,7 +1249,7 @@ int gorder_hip_plan(const gorder_hip_handle *h, gorder_hip_plan_t *plan) {
 
 // ---- leaflet assignment rows for a batch (host part of leaflets.rs:435-441, 1437-1472) --------
 static int run_leaflets(gorder_hip_handle *h, const float *d_xyz, const float *d_box,
-                        const std::vector<uint32_t> &aframes, uint32_t row0) {
+                        const std::vector<uint32_t> &aframes, uint32_t row0, const uint8_t *skip = nullptr) {
     if (aframes.empty()) return GORDER_OK;
     int st;
     const size_t cap_before = h->aframes_cap;
@@ -1221,6 +1270,7 @@ static int run_leaflets(gorder_hip_handle *h, const float *d_xyz, const float *d
     la.methyl_begin = h->d_methyl_begin; la.methyl_atoms = h->d_methyl_atoms;
     la.dim = lf.normal_dim; la.flip = lf.flip ? 1 : 0; la.pbc = h->tables.handle_pbc ? 1 : 0;
     la.err = h->d_err;
+    la.skip = skip;
     if (lf.method == GORDER_LEAFLETS_GLOBAL) {
         const dim3 g((uint32_t)aframes.size()), b(1024);
         TIMING_MARK(h, h->membrane_is_frame ? "k_leaflets_global_contig" : "k_leaflets_global");
@@ -1312,6 +1362,8 @@ int gorder_hip_submit_device(gorder_hip_handle *h, const float *d_xyz, const flo
     // batches (AssignedLeaflets::local, leaflets.rs:1371-1380), rows 1.. = assignment frames here
     const bool leaflets = lf.method != GORDER_LEAFLETS_NONE;
     size_t n_new_rows = 0;
+    bool spec = false;
+    std::vector<uint32_t> spec_aframes;
     // argument errors come before the first kernel of the batch is queued (a batch that fails later leaves through
     // abort_batch below, so that a key its kernels raised is not committed under the next batch's ordinal)
     if (h->manual_frames) {
@@ -1339,7 +1391,24 @@ int gorder_hip_submit_device(gorder_hip_handle *h, const float *d_xyz, const flo
             if (!have) return fail(h, GORDER_ERR_LEAFLETS_NOT_PRIMED, "no leaflet assignment for the first frame");
             arow[f] = cur;
         }
-        const size_t rows = aframes.size() + 1;
+        // One read for global leaflets + order parameters: every frame of the batch is an assignment frame, an earlier
+        // assignment exists (row 0), nothing but the plain order kernel runs.  The order kernel then routes by row 0.
+        spec = h->spec_enabled && lf.method == GORDER_LEAFLETS_GLOBAL && h->have_assignment && aframes.size() == n_frames &&
+               n_frames <= 65535u && !h->extra.maps && !h->extra.tw && !h->extra.geom_kind && !h->dyn && !h->manual_frames &&
+               !h->use_gather && !p.tiles.empty();
+        if (spec && h->spec_prev_frames && hipEventQuery(h->spec_counters_copied) == hipSuccess) {
+            // what the last speculative batch cost: many frames whose centre the sums could not vouch for, or many
+            // mispredicted molecules (a membrane across the periodic boundary; lipids that keep changing sides) — then
+            // the two-kernel path is the cheaper one for this trajectory
+            h->spec_fixed += h->h_spec_counters[0];
+            h->spec_exact_frames += h->h_spec_counters[1];
+            if ((uint64_t)h->h_spec_counters[1] * 8u > h->spec_prev_frames ||
+                (uint64_t)h->h_spec_counters[0] * 16u > h->spec_prev_frames * p.n_mol_total)
+                h->spec_enabled = spec = false;
+            h->spec_prev_frames = 0;
+        }
+        if (spec) std::fill(arow.begin(), arow.end(), 0u);
+        const size_t rows = spec ? (size_t)n_frames + 2 : aframes.size() + 1;
         if (rows > h->aflags_rows) {
             uint8_t *nb = nullptr;
             const size_t nrows = rows + rows / 4;
@@ -1362,10 +1431,11 @@ int gorder_hip_submit_device(gorder_hip_handle *h, const float *d_xyz, const flo
             h->up_arow = arow;
             h->up_arow_at = h->d_arow;
         }
-        if ((st = run_leaflets(h, d_xyz, d_box, aframes, 1)) != GORDER_OK) return abort_batch(st);
+        if (spec) spec_aframes = aframes;
+        else if ((st = run_leaflets(h, d_xyz, d_box, aframes, 1)) != GORDER_OK) return abort_batch(st);
         h->have_assignment = true;
         h->assignment_frame = last_assign_frame;
-        n_new_rows = aframes.size();
+        n_new_rows = spec ? 0 : aframes.size();
     }
     // (check_box: k_batch_end, at the end of the batch)
     if (h->extra.tw && h->n_frames + n_frames > h->tw_cap) {   // grow the per-frame rows (timewise.rs:183-186)
@@ -1403,10 +1473,51 @@ int gorder_hip_submit_device(gorder_hip_handle *h, const float *d_xyz, const flo
         h->manual_active = true;
         h->manual_frames = 0;
     }
+    const uint32_t n_tiles_all = (uint32_t)p.tiles.size();
+    if (spec) {
+        if ((st = ensure(h, &h->d_mom, &h->mom_cap, (size_t)n_frames * n_tiles_all)) != GORDER_OK) return abort_batch(st);
+        a.own = h->d_own; a.mom = h->d_mom; a.mom_dim = (int)lf.normal_dim;
+        h->spec_now = true;
+    }
     st = launch_orders(h, a);
+    h->spec_now = false;
     h->manual_active = false;
     if (st != GORDER_OK) return abort_batch(st);
     h->rep_dirty = true;
+    if (spec) {
+        // the exact centres from the order kernel's sums, the exact kernel for the frames they cannot vouch for, the sides
+        // of every (frame, molecule) against the prediction, the mispredicted ones moved
+        const size_t pairs = (size_t)n_frames * p.n_mol_total;
+        size_t cap_c = h->spec_frames_cap, cap_o = h->spec_frames_cap;
+        if ((st = ensure(h, &h->d_spec_center, &cap_c, n_frames)) != GORDER_OK) return abort_batch(st);
+        if ((st = ensure(h, &h->d_spec_ok, &cap_o, n_frames)) != GORDER_OK) return abort_batch(st);
+        h->spec_frames_cap = std::min(cap_c, cap_o);
+        if ((st = ensure(h, &h->d_spec_fix, &h->spec_fix_cap, pairs)) != GORDER_OK) return abort_batch(st);
+        HIP_TRY(h, hipMemsetAsync(h->d_spec_counters, 0, 2 * sizeof(uint32_t), h->stream));
+        SpecArgs sa{};
+        sa.xyz = d_xyz; sa.box9 = d_box; sa.n_atoms = p.n_atoms; sa.n_frames = n_frames; sa.n_tiles = n_tiles_all;
+        sa.n_mol_total = p.n_mol_total; sa.n_membrane = lf.n_membrane; sa.dim = lf.normal_dim; sa.flip = lf.flip ? 1 : 0;
+        sa.pbc = pbc ? 1 : 0; sa.mom = h->d_mom; sa.center = h->d_spec_center; sa.ok = h->d_spec_ok; sa.heads = h->d_heads;
+        sa.aflags = h->d_aflags; sa.adist = h->d_adist; sa.fix = h->d_spec_fix; sa.counters = h->d_spec_counters; sa.err = h->d_err;
+        (void)timing_mark(h, "k_spec_resolve + k_spec_check + k_spec_fixup");
+        hipLaunchKernelGGL(k_spec_resolve, dim3((n_frames + 255u) / 256u), dim3(256), 0, h->stream, sa);
+        if ((st = run_leaflets(h, d_xyz, d_box, spec_aframes, 1, h->d_spec_ok)) != GORDER_OK) return abort_batch(st);
+        (void)timing_mark(h, "k_spec_resolve + k_spec_check + k_spec_fixup");
+        hipLaunchKernelGGL(k_spec_check, dim3((p.n_mol_total + 255u) / 256u, n_frames), dim3(256), 0, h->stream, sa);
+        if (h->tables.flags & GORDER_FLAG_TRIG_ACOS_COS)
+            hipLaunchKernelGGL(k_spec_fixup<true>, dim3(1024), dim3(64), 0, h->stream, a, h->d_spec_fix, h->d_spec_counters,
+                               h->d_spec_mol_begin, h->d_spec_samples);
+        else
+            hipLaunchKernelGGL(k_spec_fixup<false>, dim3(1024), dim3(64), 0, h->stream, a, h->d_spec_fix, h->d_spec_counters,
+                               h->d_spec_mol_begin, h->d_spec_samples);
+        HIP_TRY(h, hipGetLastError());
+        HIP_TRY(h, hipMemcpyAsync(h->d_aflags, h->d_aflags + ((size_t)n_frames + 1) * p.n_mol_total, p.n_mol_total,
+                                  hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->h_spec_counters, h->d_spec_counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipEventRecord(h->spec_counters_copied, h->stream));
+        h->spec_prev_frames = n_frames;
+        h->spec_batches++;
+    }
     if (n_new_rows) {   // newest assignment becomes the carry row of the next batch
         HIP_TRY(h, hipMemcpyAsync(h->d_aflags, h->d_aflags + n_new_rows * (size_t)p.n_mol_total, p.n_mol_total,
                                   hipMemcpyDeviceToDevice, h->stream));

@@ -135,22 +135,40 @@ struct TiledStage {
         }
     }
     // registers (and, for windows wider than NPF * TPF float4, late loads) -> LDS
-    template <bool TAIL>
-    static __device__ __forceinline__ void store(const FrameArgs &a, const Tile &t, uint32_t f0, uint32_t f_end,
+    // (FINITE: also says whether every float this thread staged is finite — MOM's stand-in for the reference's check of the
+    // membrane atoms' coordinates; the 16-byte granules may hold a neighbour's float or two: a NaN there only sends the
+    // frame to the exact kernel)
+    template <bool TAIL, bool FINITE = false>
+    static __device__ __forceinline__ bool store(const FrameArgs &a, const Tile &t, uint32_t f0, uint32_t f_end,
                                                  uint32_t sk, uint32_t si, const v4f (&pre)[NPF], float *lds,
                                                  uint32_t lw) {
         const uint32_t f = f0 + sk;
-        if (TAIL && f >= f_end) return;
+        if (TAIL && f >= f_end) return true;
         const size_t base = ((size_t)f * a.n_atoms + t.atom0) * 3u;
         const uint32_t n4 = ((uint32_t)(base & 3u) + 3u * t.n_window + 3u) >> 2;
         const v4f *src = reinterpret_cast<const v4f *>(a.xyz + (base & ~(size_t)3));
         v4f *dst = reinterpret_cast<v4f *>(lds + (size_t)sk * lw);
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        v2f poison = {0.0f, 0.0f};                  // stays 0 while everything is finite: 0 * x is 0, or NaN for an infinity or a NaN
+        const v2f zero2 = {0.0f, 0.0f};
 #pragma unroll
         for (int j = 0; j < NPF; j++) {
             const uint32_t i = si + (uint32_t)j * TPF;
             if (i < n4) dst[i] = pre[j];
+            if (FINITE) {
+                poison = __builtin_elementwise_fma(pre[j].xy, zero2, poison);
+                poison = __builtin_elementwise_fma(pre[j].zw, zero2, poison);
+            }
         }
-        for (uint32_t i = si + (uint32_t)NPF * TPF; i < n4; i += TPF) dst[i] = __builtin_nontemporal_load(src + i);
+        for (uint32_t i = si + (uint32_t)NPF * TPF; i < n4; i += TPF) {
+            const v4f v = __builtin_nontemporal_load(src + i);
+            dst[i] = v;
+            if (FINITE) {
+                poison = __builtin_elementwise_fma(v.xy, zero2, poison);
+                poison = __builtin_elementwise_fma(v.zw, zero2, poison);
+            }
+        }
+        return poison.x + poison.y == 0.0f;
     }
     // My sample in each of the G frames of a stage; P[k] = {p1x,p1y,p1z,p2x,p2y,p2z} of frame f0 + k.
     // The common path is straight-line code (selects only) so that the G independent dependency chains
@@ -313,7 +331,50 @@ struct TiledStage {
 #ifndef GORDER_TILED_MIN_WAVES
 #define GORDER_TILED_MIN_WAVES 4   // waves per SIMD the register allocation must allow (8 => <= 64 VGPRs)
 #endif
-template <int G, int NPF, bool ACOS_COS, bool PBC, bool LEAF, int AXIS>
+// MOM (one read for global leaflets + order parameters): the wave that stands for frame slot k of the stage sums the
+// normal coordinate of the atoms this tile OWNS (FrameArgs::own) out of the window that is in LDS anyway — relative to the
+// middle of the box, with its square and the extrema; a NaN coordinate poisons the sums — and leaves them for
+// k_spec_resolve: mom[frame][tile].  Five instructions an atom, no sine or cosine.
+// a wave reduction by DPP alone: four shifts inside the rows of 16, then the rows' results passed on (row_bcast:15 into
+// rows 1 and 3, row_bcast:31 into the upper half): the total ends up in lane 63
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float mom_dpp(float v, float old) {   // the value the control names, `old` where there is none
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ void tiled_moments(const FrameArgs &a, const Tile &t, uint2 own, uint32_t tile_id, uint32_t n_tiles,
+                                              uint32_t f, const float *slot, bool finite) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t sh = (uint32_t)((((size_t)f * a.n_atoms + t.atom0) * 3u) & 3u);
+    const float *w = slot + sh + a.mom_dim + 3u * (own.x - t.atom0);
+    const uint32_t n_own = own.y - own.x;
+    float s = 0.0f, q = 0.0f, mn = 3.0e38f, mx = -3.0e38f;
+    // eight atoms a lane and trip, their LDS reads in flight together (one trip for up to 512 owned atoms: the moments sit
+    // between a stage's loads and its arithmetic, and what they wait for the stage waits for); plain sums of z and z^2 —
+    // k_spec_resolve adds the tiles' in f64 and allows for the f32 rounding here
+    for (uint32_t i0 = 0; i0 < n_own; i0 += 512u) {
+        float z[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; u++) z[u] = w[3u * min(i0 + 64u * u + lane, n_own - 1u)];
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; u++) {
+            const bool valid = i0 + 64u * u + lane < n_own;
+            const float d = valid ? z[u] : 0.0f;
+            s += d;
+            q = __builtin_fmaf(d, d, q);
+            mn = __builtin_fminf(mn, valid ? z[u] : mn);
+            mx = __builtin_fmaxf(mx, valid ? z[u] : mx);
+        }
+    }
+#define GORDER_MOM_STEP(CTRL, MASK)                                                             \
+    s += mom_dpp<CTRL, MASK>(s, 0.0f); q += mom_dpp<CTRL, MASK>(q, 0.0f);                       \
+    mn = __builtin_fminf(mn, mom_dpp<CTRL, MASK>(mn, mn)); mx = __builtin_fmaxf(mx, mom_dpp<CTRL, MASK>(mx, mx));
+    GORDER_MOM_STEP(0x111, 0xf) GORDER_MOM_STEP(0x112, 0xf) GORDER_MOM_STEP(0x114, 0xf) GORDER_MOM_STEP(0x118, 0xf)
+    GORDER_MOM_STEP(0x142, 0xa) GORDER_MOM_STEP(0x143, 0xc)
+#undef GORDER_MOM_STEP
+    const bool all_finite = __all(finite);
+    if (lane == 63u) a.mom[(size_t)f * n_tiles + tile_id] = make_float4(all_finite ? s : __builtin_nanf(""), q, mn, mx);
+}
+template <int G, int NPF, bool ACOS_COS, bool PBC, bool LEAF, int AXIS, bool MOM = false>
 __global__ __launch_bounds__(kBlock, GORDER_TILED_MIN_WAVES) void k_bonds_tiled(FrameArgs a_in, const float *__restrict__ xyz,
                                                       const float *__restrict__ box9,
                                                       const uint8_t *__restrict__ aflags,
@@ -345,19 +406,26 @@ __global__ __launch_bounds__(kBlock, GORDER_TILED_MIN_WAVES) void k_bonds_tiled(
     int bad = 0;
     uint32_t nan_which = 0, nan_frame = kNoNan;
     v4f pre[NPF];
+    uint2 own = make_uint2(0u, 0u);
+    if (MOM) own = a.own[tile_id];
 
     if (f_begin < f_full) S::template load<false>(a, t, f_begin, f_end, sk, si, pre);
     for (uint32_t f0 = f_begin; f0 < f_full; f0 += G) {
-        S::template store<false>(a, t, f0, f_end, sk, si, pre, lds, lw);
+        const bool finite = S::template store<false, MOM>(a, t, f0, f_end, sk, si, pre, lds, lw);
         __syncthreads();
         if (f0 + G < f_full) S::template load<false>(a, t, f0 + G, f_end, sk, si, pre);   // next stage in flight
+        if (MOM) {          // (the wave that staged frame slot k sums it: TPF = 64)
+            static_assert(!MOM || (uint32_t)G * 64u == kBlock, "a wave per frame slot");
+            tiled_moments(a, t, own, tile_id, n_tiles, f0 + sk, lds + (size_t)sk * lw, finite);
+        }
         if (active) S::compute(a, t, it, f0, lds, lw, acc, bad, nan_which, nan_frame);
         __syncthreads();
     }
     if (f_full < f_end) {   // last, partial stage of the batch
         S::template load<true>(a, t, f_full, f_end, sk, si, pre);
-        S::template store<true>(a, t, f_full, f_end, sk, si, pre, lds, lw);
+        const bool finite = S::template store<true, MOM>(a, t, f_full, f_end, sk, si, pre, lds, lw);
         __syncthreads();
+        if (MOM && f_full + sk < f_end) tiled_moments(a, t, own, tile_id, n_tiles, f_full + sk, lds + (size_t)sk * lw, finite);
         if (active) S::compute_tail(a, t, it, f_full, f_end, lds, lw, acc, bad, nan_which, nan_frame);
         __syncthreads();
     }

@@ -27,6 +27,10 @@ struct FrameArgs {
     uint32_t n_rep;
     uint32_t n_acc;
     uint32_t *err;
+    // k_bonds_tiled<..., MOM> only (one read for global leaflets + order parameters):
+    const uint2 *own;        // [n_tiles] the atoms of the membrane group each tile sums: [x, y)
+    float4 *mom;             // [n_frames][n_tiles] (sum z, sum z^2, min z, max z) of the owned atoms
+    int mom_dim;             // which coordinate z is (the leaflets' normal)
 };
 
 // ---- device error record --------------------------------------------------------------------------

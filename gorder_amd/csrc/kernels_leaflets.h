@@ -23,6 +23,7 @@ struct LeafletArgs {
     uint32_t dim;
     int flip, pbc;
     uint32_t *err;
+    const uint8_t *skip;       // Global, after a speculative batch: [n_frames] 1 = this frame's centre is known already, leave
 };
 
 // cos / sin of 2*pi*u by the hardware v_cos_f32 / v_sin_f32 (argument in revolutions, ~1e-6 absolute
@@ -166,6 +167,7 @@ __global__ __launch_bounds__(1024) void k_leaflets_global(LeafletArgs a) {
     __shared__ double scratch[16];
     __shared__ float s_center;
     const uint32_t f = a.aframes[blockIdx.x];
+    if (a.skip && a.skip[f]) return;                                  // (uniform over the workgroup)
     const float *x = a.xyz + (size_t)f * a.n_atoms * 3u;
     const uint32_t dn = a.dim;
     float L = 1.0f;
@@ -288,6 +290,7 @@ __global__ __launch_bounds__(256) void k_leaflets_global_contig(LeafletArgs a) {
     __shared__ float fscratch[32];
     __shared__ float s_center;
     const uint32_t f = a.aframes[blockIdx.x];
+    if (a.skip && a.skip[f]) return;                                  // (uniform over the workgroup)
     const uint32_t dn = a.dim;
     float L = 1.0f;
     if (a.pbc) L = a.box9[9 * (size_t)f + 4 * dn];
@@ -434,6 +437,119 @@ __global__ __launch_bounds__(256) void k_leaflets_global_contig(LeafletArgs a) {
         if (last && a.adist) a.adist[m] = d;
     }
     if (bad) raise_box_range(a.err, f);
+}
+
+// ---- one read for global leaflets + order parameters: what follows k_bonds_tiled<..., MOM> ------------------------------
+// The order kernel of a speculative batch routed every molecule by the side it had at the last assignment before the batch
+// (row 0 of aflags) and left, per frame and tile, the sums of the membrane atoms' normal coordinates (FrameArgs::mom).
+//   k_spec_resolve : per frame, the plain mean c of the membrane's normal coordinate and whether it IS the reference's centre:
+//                    the reference takes the circular mean as an estimate, the image of every atom next to it, and their mean
+//                    (GlobalClassification, leaflets.rs:586-640 -> pbc.rs).  With angles d_j = 2 pi (z_j - c) / L about the
+//                    mean (sum d_j = 0):  |sum sin d_j| = |sum (sin d_j - d_j)| <= d_max sum d_j^2 / 6  and
+//                    sum cos d_j >= n - sum d_j^2 / 2,  so the estimate lies within  atan(d_max S2 / 6 / (n - S2 / 2)) L / 2 pi
+//                    of c;  if every atom of the group keeps that distance, and a margin, from the far side of the box as
+//                    seen from c, every image is the atom's own coordinate moved by the same number of box lengths and the
+//                    centre is c (modulo L).  Frames where that cannot be shown (a membrane across the periodic boundary,
+//                    a NaN) are left to k_leaflets_global_contig (`skip`).
+//   k_spec_check   : per (frame, molecule): the side by the exact centre against the side the order kernel used; the pairs
+//                    that differ go on a list; the last frame's sides become the next batch's row 0 (through a spare row).
+//   k_spec_fixup   : per listed pair: the molecule's samples of that frame again, their ticks moved from one leaflet's sums to
+//                    the other's.  Lipids do not change leaflet from one frame to the next: the list is short.
+struct SpecArgs {
+    const float *xyz;
+    const float *box9;
+    uint32_t n_atoms, n_frames, n_tiles, n_mol_total, n_membrane;
+    uint32_t dim;
+    int flip, pbc;
+    const float4 *mom;         // [n_frames][n_tiles]
+    float *center;             // [n_frames]
+    uint8_t *ok;               // [n_frames] 1 = `center` is the reference's centre
+    const uint32_t *heads;
+    uint8_t *aflags;           // row 0: the sides the order kernel used; rows 1 + f: exact sides of the frames that were not ok;
+                               // row n_frames + 1: the last frame's exact sides (copied to row 0 afterwards)
+    float *adist;
+    uint2 *fix;                // (frame, molecule | exact side << 31)
+    uint32_t *counters;        // [0] listed pairs, [1] frames that were not ok
+    uint32_t *err;
+};
+__global__ __launch_bounds__(256) void k_spec_resolve(SpecArgs a) {
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= a.n_frames) return;
+    double S = 0.0, Q = 0.0;
+    float mn = 3.0e38f, mx = -3.0e38f;
+    for (uint32_t t = 0; t < a.n_tiles; t++) {
+        const float4 m = a.mom[(size_t)f * a.n_tiles + t];
+        S += (double)m.x; Q += (double)m.y;
+        mn = fminf(mn, m.z); mx = fmaxf(mx, m.w);
+    }
+    const double n = (double)a.n_membrane;
+    const float L = a.pbc ? a.box9[9 * (size_t)f + 4 * a.dim] : 0.0f;
+    const double c = S / n;
+    bool ok = (S - S == 0.0) && (Q - Q == 0.0) && mn <= mx;             // finite sums, at least one atom
+    if (ok && a.pbc) {
+        const double k = 6.283185307179586 / (double)L;
+        // (the tiles' sums are f32: sum z^2 of a tile is good to ~1e-6 of itself, and the difference below is a few per
+        // cent of it in the worst case: 1e-4 of slack on the total covers it)
+        const double var = fmax(Q - S * S / n, 0.0) + 1e-4 * Q + 1e-6 * n;
+        const double dmax = k * fmax((double)mx - c, c - (double)mn), S2 = k * k * var, den = n - 0.5 * S2;
+        ok = den > 0.0 && L > 0.0f;
+        if (ok) {
+            const double dist = (dmax * S2 / 6.0 / den) / k;              // atan(x) <= x
+            const double room = 0.5 * (double)L - 1e-4 * (double)L - dist;
+            ok = (double)mx - c < room && c - (double)mn < room;
+        }
+    }
+    a.center[f] = (float)c;
+    a.ok[f] = ok ? 1 : 0;
+    if (!ok) atomicAdd(&a.counters[1], 1u);
+}
+__global__ __launch_bounds__(256) void k_spec_check(SpecArgs a) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
+    if (m >= a.n_mol_total) return;
+    const bool last = f + 1 == a.n_frames;
+    uint8_t exact;
+    int bad = 0;
+    if (a.ok[f]) {
+        const float zh = a.xyz[((size_t)f * a.n_atoms + a.heads[m]) * 3u + a.dim];
+        float d = zh - a.center[f];
+        if (a.pbc) d = gm_min_image(d, a.box9[9 * (size_t)f + 4 * a.dim], bad);
+        exact = (uint8_t)((d >= 0.0f ? 0 : 1) ^ (a.flip ? 1 : 0));
+        if (last && a.adist) a.adist[m] = d;
+    } else {
+        exact = a.aflags[(size_t)(1u + f) * a.n_mol_total + m];         // (k_leaflets_global_contig wrote it, and adist)
+    }
+    if (exact != a.aflags[m]) a.fix[atomicAdd(&a.counters[0], 1u)] = make_uint2(f, m | ((uint32_t)exact << 31));
+    if (last) a.aflags[(size_t)(a.n_frames + 1u) * a.n_mol_total + m] = exact;
+    if (bad) raise_box_range(a.err, f);
+}
+// the samples of every molecule, molecule by molecule (CSR), for k_spec_fixup
+struct SpecSample { uint32_t i, j, slot; };
+template <bool ACOS_COS>
+__global__ __launch_bounds__(64) void k_spec_fixup(FrameArgs a, const uint2 *__restrict__ fix, const uint32_t *__restrict__ counters,
+                                                   const uint32_t *__restrict__ mol_begin, const SpecSample *__restrict__ samples) {
+    const uint32_t n = counters[0];
+    for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
+        const uint2 w = fix[e];
+        const uint32_t f = w.x, m = w.y & 0x7fffffffu, exact = w.y >> 31;
+        const float *x = a.xyz + (size_t)f * a.n_atoms * 3u;
+        for (uint32_t q = mol_begin[m] + threadIdx.x; q < mol_begin[m + 1]; q += blockDim.x) {
+            const SpecSample sm = samples[q];
+            SampleAcc acc;
+            int bad = 0;
+            const float *p1 = x + 3u * (size_t)sm.i, *p2 = x + 3u * (size_t)sm.j;
+            bond_sample<ACOS_COS>(a, f, p1[0], p1[1], p1[2], p2[0], p2[1], p2[2], m, acc, bad);
+            if (!acc.n_tot) continue;                              // (an undefined position: the order kernel added nothing either)
+            // Leaflet::Upper = 0: a molecule that is in the upper leaflet after all gains the tick there, one that is not loses it
+            unsigned long long *rep = a.rep;                        // replica 0
+            if (exact == 0u) {
+                atomicAdd(&rep[(size_t)a.n_acc + sm.slot], (unsigned long long)acc.s_tot);
+                atomicAdd(&rep[3u * (size_t)a.n_acc + sm.slot], 1ull);
+            } else {
+                atomicAdd(&rep[(size_t)a.n_acc + sm.slot], (unsigned long long)(-acc.s_tot));
+                atomicAdd(&rep[3u * (size_t)a.n_acc + sm.slot], ~0ull);
+            }
+        }
+    }
 }
 
 // grid = (ceil(n_mol/256), n_assign).  IndividualClassification::identify_leaflet, leaflets.rs:777-801:

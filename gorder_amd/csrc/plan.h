@@ -73,6 +73,11 @@ struct Plan {
     std::vector<uint32_t> run_begin;
     std::vector<uint32_t> mol0;    // first global molecule id per molecule type
     std::vector<uint32_t> slot0;   // first accumulator slot per molecule type
+    // One read for global leaflets + order parameters (k_bonds_tiled<..., MOM>): when the membrane group is one
+    // contiguous range of atoms and the tiles' windows can be made to cover it, tile i OWNS the atoms [own[2i], own[2i+1])
+    // — the ranges partition the group — and sums their normal coordinates on the way.
+    bool spec_ok = false;
+    std::vector<uint32_t> own;
 };
 
 struct Sample {
@@ -352,6 +357,51 @@ inline int build_plan(const gorder_tables_t &t, bool force_direct, Plan &p, bool
         p.max_window = std::max(p.max_window, tile.n_window);
         spread_over_banks(p.items.data() + tile.item0, tile.n_items);
         p.tiles.push_back(tile);
+    }
+    // ---- ownership ranges of the membrane group's atoms (see Plan::own)
+    p.spec_ok = false;
+    p.own.clear();
+    if (t.leaflets.method == GORDER_LEAFLETS_GLOBAL && t.leaflets.n_membrane > 0 && t.leaflets.membrane && p.direct.empty() &&
+        !p.tiles.empty() && p.ua_tiles.empty()) {
+        const uint32_t *mb = t.leaflets.membrane;
+        const uint32_t nm = t.leaflets.n_membrane, m0 = mb[0], m1 = m0 + nm;
+        bool ok = m1 <= t.n_atoms && m1 > m0;
+        for (uint32_t i = 1; ok && i < nm; i++) ok = mb[i] == m0 + i;
+        for (size_t i = 1; ok && i < p.tiles.size(); i++) ok = p.tiles[i].atom0 >= p.tiles[i - 1].atom0;
+        if (ok) {
+            std::vector<Tile> nt = p.tiles;
+            std::vector<uint32_t> own(2 * nt.size());
+            uint32_t cur = m0, shift0 = 0, widest = 0;
+            for (size_t i = 0; ok && i < nt.size(); i++) {
+                const uint32_t lo = cur;
+                const uint32_t hi = i + 1 < nt.size() ? std::max(cur, std::min(nt[i + 1].atom0, m1)) : m1;
+                if (lo < hi) {
+                    if (lo < nt[i].atom0) {                     // (the first tile only: the group begins before its first sample)
+                        if (i != 0) { ok = false; break; }
+                        shift0 = nt[i].atom0 - lo;
+                        nt[i].atom0 = lo;
+                        nt[i].n_window += shift0;
+                    }
+                    if (hi > nt[i].atom0 + nt[i].n_window) nt[i].n_window = hi - nt[i].atom0;
+                    if (nt[i].n_window > kMaxWindow) ok = false;
+                }
+                own[2 * i] = lo;
+                own[2 * i + 1] = hi;
+                cur = hi;
+                widest = std::max(widest, nt[i].n_window);
+            }
+            if (ok && cur == m1) {
+                if (shift0)
+                    for (uint32_t q = 0; q < nt[0].n_items; q++) {
+                        p.items[nt[0].item0 + q].li = (uint16_t)(p.items[nt[0].item0 + q].li + shift0);
+                        p.items[nt[0].item0 + q].lj = (uint16_t)(p.items[nt[0].item0 + q].lj + shift0);
+                    }
+                p.tiles = nt;
+                p.max_window = std::max(p.max_window, widest);
+                p.own = own;
+                p.spec_ok = true;
+            }
+        }
     }
     {   // slot-ordered copy of the tile items + the runs of every slot (see MapRun)
         p.items_by_slot = p.items;
