@@ -1234,6 +1234,19 @@ int gorder_hip_set_stream(gorder_hip_handle *h, void *hip_stream) {
     return GORDER_OK;
 }
 
+int gorder_hip_speculation_stats(gorder_hip_handle *h, uint64_t out[4]) {
+    if (!h || !out) return GORDER_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->spec_prev_frames) {              // the last speculative batch's counters have not been looked at yet
+        h->spec_fixed += h->h_spec_counters[0];
+        h->spec_exact_frames += h->h_spec_counters[1];
+        h->spec_prev_frames = 0;
+    }
+    out[0] = h->spec_batches; out[1] = h->spec_fixed; out[2] = h->spec_exact_frames; out[3] = h->spec_enabled ? 1 : 0;
+    return GORDER_OK;
+}
+
 int gorder_hip_plan(const gorder_hip_handle *h, gorder_hip_plan_t *plan) {
     if (!h || !plan) return GORDER_ERR_INVALID_ARGUMENT;
     plan->n_tiles = (uint32_t)h->plan.tiles.size();

@@ -442,6 +442,17 @@ int gorder_hip_plan(const gorder_hip_handle *h, gorder_hip_plan_t *plan);
  * tables is covered exactly once by the plan. */
 int gorder_hip_plan_tables(const gorder_tables_t *tables, gorder_hip_plan_t *plan, int *selfcheck);
 
+/* Global leaflets assigned every frame, nothing but the order parameters asked for: from the second batch on the library
+ * reads every frame ONCE — the order kernel routes each molecule by the last assignment and sums the membrane group's
+ * normal coordinate on the way, the exact centres follow from the sums, and the few (frame, molecule) pairs whose side
+ * was mispredicted are moved afterwards (GORDER_HIP_NO_SPECULATE=1 keeps the two-kernel path; so does a
+ * membrane group that is not one range of atoms the tiles can cover).  Results are the two-kernel path's.
+ * out[0] = batches that ran this way, out[1] = mispredicted (frame, molecule) pairs moved, out[2] = frames whose centre
+ * the sums could not vouch for (they took the exact kernel), out[3] = 1 while the handle still speculates (it stops
+ * when a batch leaves more than 1/8 of its frames to the exact kernel or mispredicts more than 1/16 of its pairs).
+ * Waits for the handle's stream. */
+int gorder_hip_speculation_stats(gorder_hip_handle *h, uint64_t out[4]);
+
 /* Diagnostic: the kernels replace the IEEE division and square root by their Newton cores inside guarded operand
  * ranges (gm_div_core / gm_sqrt_core in gm_math.h; DESIGN.md, K1 arithmetic).  This runs both forms on `n` pseudo-random
  * operand sets on the device — divisors and radicands log-uniform over the guarded range [2^-40, 2^40], numerators of
