@@ -144,15 +144,21 @@ struct gorder_hip_handle {
     uint2 *d_own = nullptr;
     float4 *d_mom = nullptr;
     size_t mom_cap = 0;
+    float *d_head_z = nullptr;
+    size_t head_z_cap = 0;
+    uint32_t *d_own_head_begin = nullptr;
+    uint2 *d_own_heads = nullptr;
     float *d_spec_center = nullptr;
     uint8_t *d_spec_ok = nullptr;
     size_t spec_frames_cap = 0;
     uint2 *d_spec_fix = nullptr;
     size_t spec_fix_cap = 0;
-    uint32_t *d_spec_counters = nullptr;           // [0] mispredicted (frame, molecule) pairs, [1] frames left to the exact kernel
-    uint32_t *h_spec_counters = nullptr;           // pinned copy of the last speculative batch's counters, read one batch later
-    hipEvent_t spec_counters_copied = nullptr;
-    uint64_t spec_prev_frames = 0;                 // frames of that batch (0: nothing to look at)
+    uint32_t *d_spec_counters = nullptr;           // two pairs (batches alternate): [0] mispredicted (frame, molecule) pairs, [1] frames left to the exact kernel
+    // pinned copies of the last speculative batches' counters, looked at (without waiting) when a later batch is submitted
+    static constexpr uint32_t kSpecRing = 8;
+    uint32_t *h_spec_counters = nullptr;           // [kSpecRing][2]
+    hipEvent_t spec_counters_copied[kSpecRing] = {};
+    uint64_t spec_ring_frames[kSpecRing] = {};     // frames of the batch in that slot (0: nothing pending)
     uint32_t *d_spec_mol_begin = nullptr;
     SpecSample *d_spec_samples = nullptr;
     uint64_t spec_batches = 0, spec_fixed = 0, spec_exact_frames = 0;   // statistics (gorder_hip_speculation_stats)
@@ -1146,9 +1152,14 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
             for (const auto &v : per_mol) { all.insert(all.end(), v.begin(), v.end()); mbeg.push_back((uint32_t)all.size()); }
             if ((st = upload(h, &h->d_spec_mol_begin, mbeg)) != GORDER_OK) return st;
             if ((st = upload(h, &h->d_spec_samples, all)) != GORDER_OK) return st;
-            HIP_TRY(h, hipMalloc((void **)&h->d_spec_counters, 2 * sizeof(uint32_t)));
-            HIP_TRY(h, hipHostMalloc((void **)&h->h_spec_counters, 2 * sizeof(uint32_t)));
-            HIP_TRY(h, hipEventCreateWithFlags(&h->spec_counters_copied, hipEventDisableTiming));
+            std::vector<uint2> oh(p.own_heads.size() / 2);
+            for (size_t i = 0; i < oh.size(); i++) oh[i] = make_uint2(p.own_heads[2 * i], p.own_heads[2 * i + 1]);
+            if ((st = upload(h, &h->d_own_head_begin, p.own_head_begin)) != GORDER_OK) return st;
+            if ((st = upload(h, &h->d_own_heads, oh)) != GORDER_OK) return st;
+            HIP_TRY(h, hipMalloc((void **)&h->d_spec_counters, 4 * sizeof(uint32_t)));
+            HIP_TRY(h, hipMemset(h->d_spec_counters, 0, 4 * sizeof(uint32_t)));
+            HIP_TRY(h, hipHostMalloc((void **)&h->h_spec_counters, 2 * gorder_hip_handle::kSpecRing * sizeof(uint32_t)));
+            for (hipEvent_t &ev : h->spec_counters_copied) HIP_TRY(h, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
             h->spec_enabled = true;
         }
         if (lf.method == GORDER_LEAFLETS_LOCAL) {
@@ -1196,10 +1207,10 @@ void gorder_hip_destroy(gorder_hip_handle *h) {
     (void)hipFree(h->d_map_rec); (void)hipFree(h->d_ua_runs); (void)hipFree(h->d_ua_run_begin);
     (void)hipFree(h->d_runs); (void)hipFree(h->d_run_begin); (void)hipFree(h->d_items_by_slot);
     (void)hipFree(h->d_ua_item_run); (void)hipFree(h->d_item_run); (void)hipFree(h->d_lgrid); (void)hipFree(h->d_lrowpre); (void)hipFree(h->d_ledge);
-    (void)hipFree(h->d_own); (void)hipFree(h->d_mom); (void)hipFree(h->d_spec_center); (void)hipFree(h->d_spec_ok);
+    (void)hipFree(h->d_own); (void)hipFree(h->d_mom); (void)hipFree(h->d_head_z); (void)hipFree(h->d_own_head_begin); (void)hipFree(h->d_own_heads); (void)hipFree(h->d_spec_center); (void)hipFree(h->d_spec_ok);
     (void)hipFree(h->d_spec_fix); (void)hipFree(h->d_spec_counters); (void)hipFree(h->d_spec_mol_begin); (void)hipFree(h->d_spec_samples);
     if (h->h_spec_counters) (void)hipHostFree(h->h_spec_counters);
-    if (h->spec_counters_copied) (void)hipEventDestroy(h->spec_counters_copied); (void)hipFree(h->d_lfinfo); (void)hipFree(h->d_ltodo);
+    for (hipEvent_t ev : h->spec_counters_copied) if (ev) (void)hipEventDestroy(ev); (void)hipFree(h->d_lfinfo); (void)hipFree(h->d_ltodo);
     (void)hipFree(h->d_dyn_cloud); (void)hipFree(h->d_dyn_heads); (void)hipFree(h->d_dyn_cell_of); (void)hipFree(h->d_dyn_count);
     (void)hipFree(h->d_dyn_rec); (void)hipFree(h->d_dyn_normals); (void)hipFree(h->d_dyn_cov);
     if (!h->acc_external) (void)hipFree(h->d_acc);
@@ -1234,15 +1245,12 @@ int gorder_hip_set_stream(gorder_hip_handle *h, void *hip_stream) {
     return GORDER_OK;
 }
 
+static void spec_poll(gorder_hip_handle *h, bool wait);
 int gorder_hip_speculation_stats(gorder_hip_handle *h, uint64_t out[4]) {
     if (!h || !out) return GORDER_ERR_INVALID_ARGUMENT;
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    if (h->spec_prev_frames) {              // the last speculative batch's counters have not been looked at yet
-        h->spec_fixed += h->h_spec_counters[0];
-        h->spec_exact_frames += h->h_spec_counters[1];
-        h->spec_prev_frames = 0;
-    }
+    spec_poll(h, true);
     out[0] = h->spec_batches; out[1] = h->spec_fixed; out[2] = h->spec_exact_frames; out[3] = h->spec_enabled ? 1 : 0;
     return GORDER_OK;
 }
@@ -1258,6 +1266,25 @@ int gorder_hip_plan(const gorder_hip_handle *h, gorder_hip_plan_t *plan) {
     plan->map_staged = h->map_staged ? 1u : 0u;
     plan->map_lds_bytes = (uint32_t)h->map_lds_bytes;
     return GORDER_OK;
+}
+
+// What the speculative batches that have finished cost (never waits unless `wait`): their counters are added to the
+// handle's statistics, and a batch that left more than 1/8 of its frames to the exact kernel, or mispredicted more than
+// 1/16 of its (frame, molecule) pairs, ends the speculation for this handle — a membrane across the periodic boundary,
+// lipids that keep changing sides: the two-kernel path is the cheaper one for such a trajectory.
+static void spec_poll(gorder_hip_handle *h, bool wait) {
+    for (uint32_t i = 0; i < gorder_hip_handle::kSpecRing; i++) {
+        if (!h->spec_ring_frames[i]) continue;
+        if (wait) (void)hipEventSynchronize(h->spec_counters_copied[i]);
+        else if (hipEventQuery(h->spec_counters_copied[i]) != hipSuccess) continue;
+        const uint32_t moved = h->h_spec_counters[2 * i], exact = h->h_spec_counters[2 * i + 1];
+        h->spec_fixed += moved;
+        h->spec_exact_frames += exact;
+        if ((uint64_t)exact * 8u > h->spec_ring_frames[i] ||
+            (uint64_t)moved * 16u > h->spec_ring_frames[i] * h->plan.n_mol_total)
+            h->spec_enabled = false;
+        h->spec_ring_frames[i] = 0;
+    }
 }
 
 // ---- leaflet assignment rows for a batch (host part of leaflets.rs:435-441, 1437-1472) --------
@@ -1284,8 +1311,10 @@ static int run_leaflets(gorder_hip_handle *h, const float *d_xyz, const float *d
     la.dim = lf.normal_dim; la.flip = lf.flip ? 1 : 0; la.pbc = h->tables.handle_pbc ? 1 : 0;
     la.err = h->d_err;
     la.skip = skip;
+    la.n_assign = (uint32_t)aframes.size();
     if (lf.method == GORDER_LEAFLETS_GLOBAL) {
-        const dim3 g((uint32_t)aframes.size()), b(1024);
+        // (behind a speculative batch nearly every frame is skipped: a few hundred workgroups take the frames in turn)
+        const dim3 g(skip ? std::min<uint32_t>((uint32_t)aframes.size(), 512u) : (uint32_t)aframes.size()), b(1024);
         TIMING_MARK(h, h->membrane_is_frame ? "k_leaflets_global_contig" : "k_leaflets_global");
         if (h->membrane_is_frame) hipLaunchKernelGGL(k_leaflets_global_contig, g, dim3(256), 0, h->stream, la);
         else hipLaunchKernelGGL(k_leaflets_global, g, b, 0, h->stream, la);
@@ -1409,16 +1438,11 @@ int gorder_hip_submit_device(gorder_hip_handle *h, const float *d_xyz, const flo
         spec = h->spec_enabled && lf.method == GORDER_LEAFLETS_GLOBAL && h->have_assignment && aframes.size() == n_frames &&
                n_frames <= 65535u && !h->extra.maps && !h->extra.tw && !h->extra.geom_kind && !h->dyn && !h->manual_frames &&
                !h->use_gather && !p.tiles.empty();
-        if (spec && h->spec_prev_frames && hipEventQuery(h->spec_counters_copied) == hipSuccess) {
-            // what the last speculative batch cost: many frames whose centre the sums could not vouch for, or many
-            // mispredicted molecules (a membrane across the periodic boundary; lipids that keep changing sides) — then
-            // the two-kernel path is the cheaper one for this trajectory
-            h->spec_fixed += h->h_spec_counters[0];
-            h->spec_exact_frames += h->h_spec_counters[1];
-            if ((uint64_t)h->h_spec_counters[1] * 8u > h->spec_prev_frames ||
-                (uint64_t)h->h_spec_counters[0] * 16u > h->spec_prev_frames * p.n_mol_total)
-                h->spec_enabled = spec = false;
-            h->spec_prev_frames = 0;
+        if (spec) {
+            spec_poll(h, false);
+            const uint32_t slot = (uint32_t)(h->spec_batches % gorder_hip_handle::kSpecRing);
+            if (h->spec_ring_frames[slot]) (void)hipEventSynchronize(h->spec_counters_copied[slot]), spec_poll(h, false);
+            spec = h->spec_enabled;
         }
         if (spec) std::fill(arow.begin(), arow.end(), 0u);
         const size_t rows = spec ? (size_t)n_frames + 2 : aframes.size() + 1;
@@ -1489,7 +1513,9 @@ int gorder_hip_submit_device(gorder_hip_handle *h, const float *d_xyz, const flo
     const uint32_t n_tiles_all = (uint32_t)p.tiles.size();
     if (spec) {
         if ((st = ensure(h, &h->d_mom, &h->mom_cap, (size_t)n_frames * n_tiles_all)) != GORDER_OK) return abort_batch(st);
+        if ((st = ensure(h, &h->d_head_z, &h->head_z_cap, (size_t)n_frames * p.n_mol_total)) != GORDER_OK) return abort_batch(st);
         a.own = h->d_own; a.mom = h->d_mom; a.mom_dim = (int)lf.normal_dim;
+        a.own_head_begin = h->d_own_head_begin; a.own_heads = h->d_own_heads; a.head_z = h->d_head_z;
         h->spec_now = true;
     }
     st = launch_orders(h, a);
@@ -1506,29 +1532,27 @@ int gorder_hip_submit_device(gorder_hip_handle *h, const float *d_xyz, const flo
         if ((st = ensure(h, &h->d_spec_ok, &cap_o, n_frames)) != GORDER_OK) return abort_batch(st);
         h->spec_frames_cap = std::min(cap_c, cap_o);
         if ((st = ensure(h, &h->d_spec_fix, &h->spec_fix_cap, pairs)) != GORDER_OK) return abort_batch(st);
-        HIP_TRY(h, hipMemsetAsync(h->d_spec_counters, 0, 2 * sizeof(uint32_t), h->stream));
+        uint32_t *cnt = h->d_spec_counters + 2u * (uint32_t)(h->spec_batches & 1u);
+        uint32_t *cnt_next = h->d_spec_counters + 2u * (uint32_t)((h->spec_batches + 1u) & 1u);
         SpecArgs sa{};
         sa.xyz = d_xyz; sa.box9 = d_box; sa.n_atoms = p.n_atoms; sa.n_frames = n_frames; sa.n_tiles = n_tiles_all;
         sa.n_mol_total = p.n_mol_total; sa.n_membrane = lf.n_membrane; sa.dim = lf.normal_dim; sa.flip = lf.flip ? 1 : 0;
-        sa.pbc = pbc ? 1 : 0; sa.mom = h->d_mom; sa.center = h->d_spec_center; sa.ok = h->d_spec_ok; sa.heads = h->d_heads;
-        sa.aflags = h->d_aflags; sa.adist = h->d_adist; sa.fix = h->d_spec_fix; sa.counters = h->d_spec_counters; sa.err = h->d_err;
-        (void)timing_mark(h, "k_spec_resolve + k_spec_check + k_spec_fixup");
-        hipLaunchKernelGGL(k_spec_resolve, dim3((n_frames + 255u) / 256u), dim3(256), 0, h->stream, sa);
+        sa.pbc = pbc ? 1 : 0; sa.mom = h->d_mom; sa.head_z = h->d_head_z; sa.center = h->d_spec_center; sa.ok = h->d_spec_ok;
+        sa.aflags = h->d_aflags; sa.adist = h->d_adist; sa.fix = h->d_spec_fix; sa.counters = cnt; sa.counters_next = cnt_next;
+        const uint32_t ring_slot = (uint32_t)(h->spec_batches % gorder_hip_handle::kSpecRing);
+        sa.host_counters = h->h_spec_counters + 2u * ring_slot; sa.err = h->d_err;
+        (void)timing_mark(h, "k_spec_check + k_spec_fixup");
+        hipLaunchKernelGGL(k_spec_check, dim3(std::min<uint32_t>(n_frames, 2048u)), dim3(256), 0, h->stream, sa);
         if ((st = run_leaflets(h, d_xyz, d_box, spec_aframes, 1, h->d_spec_ok)) != GORDER_OK) return abort_batch(st);
-        (void)timing_mark(h, "k_spec_resolve + k_spec_check + k_spec_fixup");
-        hipLaunchKernelGGL(k_spec_check, dim3((p.n_mol_total + 255u) / 256u, n_frames), dim3(256), 0, h->stream, sa);
+        (void)timing_mark(h, "k_spec_check + k_spec_fixup");
+        hipLaunchKernelGGL(k_spec_check_exact, dim3(std::min<uint32_t>(n_frames, 256u)), dim3(256), 0, h->stream, sa);
         if (h->tables.flags & GORDER_FLAG_TRIG_ACOS_COS)
-            hipLaunchKernelGGL(k_spec_fixup<true>, dim3(1024), dim3(64), 0, h->stream, a, h->d_spec_fix, h->d_spec_counters,
-                               h->d_spec_mol_begin, h->d_spec_samples);
+            hipLaunchKernelGGL(k_spec_fixup<true>, dim3(1024), dim3(64), 0, h->stream, a, sa, h->d_spec_mol_begin, h->d_spec_samples);
         else
-            hipLaunchKernelGGL(k_spec_fixup<false>, dim3(1024), dim3(64), 0, h->stream, a, h->d_spec_fix, h->d_spec_counters,
-                               h->d_spec_mol_begin, h->d_spec_samples);
+            hipLaunchKernelGGL(k_spec_fixup<false>, dim3(1024), dim3(64), 0, h->stream, a, sa, h->d_spec_mol_begin, h->d_spec_samples);
         HIP_TRY(h, hipGetLastError());
-        HIP_TRY(h, hipMemcpyAsync(h->d_aflags, h->d_aflags + ((size_t)n_frames + 1) * p.n_mol_total, p.n_mol_total,
-                                  hipMemcpyDeviceToDevice, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(h->h_spec_counters, h->d_spec_counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipEventRecord(h->spec_counters_copied, h->stream));
-        h->spec_prev_frames = n_frames;
+        HIP_TRY(h, hipEventRecord(h->spec_counters_copied[ring_slot], h->stream));
+        h->spec_ring_frames[ring_slot] = n_frames;
         h->spec_batches++;
     }
     if (n_new_rows) {   // newest assignment becomes the carry row of the next batch

@@ -342,7 +342,7 @@ __device__ __forceinline__ float mom_dpp(float v, float old) {   // the value th
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
 }
 __device__ __forceinline__ void tiled_moments(const FrameArgs &a, const Tile &t, uint2 own, uint32_t tile_id, uint32_t n_tiles,
-                                              uint32_t f, const float *slot, bool finite) {
+                                              uint32_t f, const float *slot, bool finite, uint2 my_head) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t sh = (uint32_t)((((size_t)f * a.n_atoms + t.atom0) * 3u) & 3u);
     const float *w = slot + sh + a.mom_dim + 3u * (own.x - t.atom0);
@@ -373,6 +373,9 @@ __device__ __forceinline__ void tiled_moments(const FrameArgs &a, const Tile &t,
 #undef GORDER_MOM_STEP
     const bool all_finite = __all(finite);
     if (lane == 63u) a.mom[(size_t)f * n_tiles + tile_id] = make_float4(all_finite ? s : __builtin_nanf(""), q, mn, mx);
+    // the heads this tile owns (at most 64, one a lane, fetched once per workgroup): their normal coordinate out of LDS —
+    // k_spec_check would otherwise fetch a cache line per head
+    if (my_head.y != 0xffffffffu) a.head_z[(size_t)f * a.n_mol_total + my_head.y] = slot[sh + a.mom_dim + 3u * my_head.x];
 }
 template <int G, int NPF, bool ACOS_COS, bool PBC, bool LEAF, int AXIS, bool MOM = false>
 __global__ __launch_bounds__(kBlock, GORDER_TILED_MIN_WAVES) void k_bonds_tiled(FrameArgs a_in, const float *__restrict__ xyz,
@@ -406,8 +409,12 @@ __global__ __launch_bounds__(kBlock, GORDER_TILED_MIN_WAVES) void k_bonds_tiled(
     int bad = 0;
     uint32_t nan_which = 0, nan_frame = kNoNan;
     v4f pre[NPF];
-    uint2 own = make_uint2(0u, 0u);
-    if (MOM) own = a.own[tile_id];
+    uint2 own = make_uint2(0u, 0u), my_head = make_uint2(0u, 0xffffffffu);
+    if (MOM) {
+        own = a.own[tile_id];
+        const uint32_t hq = a.own_head_begin[tile_id] + (tid & 63u);           // (every wave holds the tile's heads, a lane each)
+        if (hq < a.own_head_begin[tile_id + 1u]) my_head = a.own_heads[hq];
+    }
 
     if (f_begin < f_full) S::template load<false>(a, t, f_begin, f_end, sk, si, pre);
     for (uint32_t f0 = f_begin; f0 < f_full; f0 += G) {
@@ -416,7 +423,7 @@ __global__ __launch_bounds__(kBlock, GORDER_TILED_MIN_WAVES) void k_bonds_tiled(
         if (f0 + G < f_full) S::template load<false>(a, t, f0 + G, f_end, sk, si, pre);   // next stage in flight
         if (MOM) {          // (the wave that staged frame slot k sums it: TPF = 64)
             static_assert(!MOM || (uint32_t)G * 64u == kBlock, "a wave per frame slot");
-            tiled_moments(a, t, own, tile_id, n_tiles, f0 + sk, lds + (size_t)sk * lw, finite);
+            tiled_moments(a, t, own, tile_id, n_tiles, f0 + sk, lds + (size_t)sk * lw, finite, my_head);
         }
         if (active) S::compute(a, t, it, f0, lds, lw, acc, bad, nan_which, nan_frame);
         __syncthreads();
@@ -425,7 +432,7 @@ __global__ __launch_bounds__(kBlock, GORDER_TILED_MIN_WAVES) void k_bonds_tiled(
         S::template load<true>(a, t, f_full, f_end, sk, si, pre);
         const bool finite = S::template store<true, MOM>(a, t, f_full, f_end, sk, si, pre, lds, lw);
         __syncthreads();
-        if (MOM && f_full + sk < f_end) tiled_moments(a, t, own, tile_id, n_tiles, f_full + sk, lds + (size_t)sk * lw, finite);
+        if (MOM && f_full + sk < f_end) tiled_moments(a, t, own, tile_id, n_tiles, f_full + sk, lds + (size_t)sk * lw, finite, my_head);
         if (active) S::compute_tail(a, t, it, f_full, f_end, lds, lw, acc, bad, nan_which, nan_frame);
         __syncthreads();
     }

@@ -31,6 +31,9 @@ struct FrameArgs {
     const uint2 *own;        // [n_tiles] the atoms of the membrane group each tile sums: [x, y)
     float4 *mom;             // [n_frames][n_tiles] (sum z, sum z^2, min z, max z) of the owned atoms
     int mom_dim;             // which coordinate z is (the leaflets' normal)
+    const uint32_t *own_head_begin;   // [n_tiles + 1] the molecules whose head atom the tile owns (Plan::own_heads)
+    const uint2 *own_heads;           // (window-relative atom, molecule)
+    float *head_z;                    // [n_frames][n_mol_total] their normal coordinate, handed on to k_spec_check
 };
 
 // ---- device error record --------------------------------------------------------------------------

@@ -24,6 +24,7 @@ struct LeafletArgs {
     int flip, pbc;
     uint32_t *err;
     const uint8_t *skip;       // Global, after a speculative batch: [n_frames] 1 = this frame's centre is known already, leave
+    uint32_t n_assign;         // Global: assignment frames of the launch (the grid may be smaller: workgroups take them in turn)
 };
 
 // cos / sin of 2*pi*u by the hardware v_cos_f32 / v_sin_f32 (argument in revolutions, ~1e-6 absolute
@@ -163,10 +164,10 @@ __global__ __launch_bounds__(256) void k_geom_shapes(GeomArgs g) {
 // (leaflets.rs:186-197 -> groan_rs group_get_center) followed by common_identify_leaflet
 // (leaflets.rs:711-732) for every molecule.  Per-thread f32 partial sums are combined in f64 (the
 // reference sums f32 sequentially; only the sign of head - centre is consumed).
-__global__ __launch_bounds__(1024) void k_leaflets_global(LeafletArgs a) {
+__device__ __forceinline__ void leaflets_global_frame(const LeafletArgs &a, uint32_t bi) {
     __shared__ double scratch[16];
     __shared__ float s_center;
-    const uint32_t f = a.aframes[blockIdx.x];
+    const uint32_t f = a.aframes[bi];
     if (a.skip && a.skip[f]) return;                                  // (uniform over the workgroup)
     const float *x = a.xyz + (size_t)f * a.n_atoms * 3u;
     const uint32_t dn = a.dim;
@@ -250,8 +251,8 @@ __global__ __launch_bounds__(1024) void k_leaflets_global(LeafletArgs a) {
     }
     __syncthreads();
     const float cdim = s_center;
-    uint8_t *row = a.aflags + (size_t)(a.row0 + blockIdx.x) * a.n_mol_total;
-    const bool last = blockIdx.x + 1 == gridDim.x;
+    uint8_t *row = a.aflags + (size_t)(a.row0 + bi) * a.n_mol_total;
+    const bool last = bi + 1 == a.n_assign;
     for (uint32_t m = threadIdx.x; m < a.n_mol_total; m += blockDim.x) {
         const float hp = x[3u * (size_t)a.heads[m] + dn];
         float d = hp - cdim;
@@ -260,6 +261,14 @@ __global__ __launch_bounds__(1024) void k_leaflets_global(LeafletArgs a) {
         if (last && a.adist) a.adist[m] = d;
     }
     if (bad) raise_box_range(a.err, f);
+}
+// grid = the assignment frames, or fewer workgroups that take them in turn (the launch behind a speculative batch, where
+// nearly every frame is skipped: a few hundred workgroups look at the flags instead of thousands being dispatched to leave)
+__global__ __launch_bounds__(1024) void k_leaflets_global(LeafletArgs a) {
+    for (uint32_t bi = blockIdx.x; bi < a.n_assign; bi += gridDim.x) {
+        leaflets_global_frame(a, bi);
+        __syncthreads();
+    }
 }
 
 // The same classifier for the usual case that the membrane group is EVERY atom of the frame, in order (all
@@ -285,11 +294,11 @@ __device__ __forceinline__ void block_minmax(float &lo, float &hi, float *scratc
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_leaflets_global_contig(LeafletArgs a) {
+__device__ __forceinline__ void leaflets_global_contig_frame(const LeafletArgs &a, uint32_t bi) {
     __shared__ double scratch[32];
     __shared__ float fscratch[32];
     __shared__ float s_center;
-    const uint32_t f = a.aframes[blockIdx.x];
+    const uint32_t f = a.aframes[bi];
     if (a.skip && a.skip[f]) return;                                  // (uniform over the workgroup)
     const uint32_t dn = a.dim;
     float L = 1.0f;
@@ -427,8 +436,8 @@ __global__ __launch_bounds__(256) void k_leaflets_global_contig(LeafletArgs a) {
     }
     __syncthreads();
     const float cdim = s_center;
-    uint8_t *row = a.aflags + (size_t)(a.row0 + blockIdx.x) * a.n_mol_total;
-    const bool last = blockIdx.x + 1 == gridDim.x;
+    uint8_t *row = a.aflags + (size_t)(a.row0 + bi) * a.n_mol_total;
+    const bool last = bi + 1 == a.n_assign;
     for (uint32_t m = threadIdx.x; m < a.n_mol_total; m += blockDim.x) {
         const float hp = x[3u * (size_t)a.heads[m] + dn];
         float d = hp - cdim;
@@ -438,11 +447,17 @@ __global__ __launch_bounds__(256) void k_leaflets_global_contig(LeafletArgs a) {
     }
     if (bad) raise_box_range(a.err, f);
 }
+__global__ __launch_bounds__(256) void k_leaflets_global_contig(LeafletArgs a) {
+    for (uint32_t bi = blockIdx.x; bi < a.n_assign; bi += gridDim.x) {
+        leaflets_global_contig_frame(a, bi);
+        __syncthreads();
+    }
+}
 
 // ---- one read for global leaflets + order parameters: what follows k_bonds_tiled<..., MOM> ------------------------------
 // The order kernel of a speculative batch routed every molecule by the side it had at the last assignment before the batch
 // (row 0 of aflags) and left, per frame and tile, the sums of the membrane atoms' normal coordinates (FrameArgs::mom).
-//   k_spec_resolve : per frame, the plain mean c of the membrane's normal coordinate and whether it IS the reference's centre:
+//   k_spec_check, first wave (k_spec_resolve's part): per frame, the plain mean c of the membrane's normal coordinate and whether it IS the reference's centre:
 //                    the reference takes the circular mean as an estimate, the image of every atom next to it, and their mean
 //                    (GlobalClassification, leaflets.rs:586-640 -> pbc.rs).  With angles d_j = 2 pi (z_j - c) / L about the
 //                    mean (sum d_j = 0):  |sum sin d_j| = |sum (sin d_j - d_j)| <= d_max sum d_j^2 / 6  and
@@ -451,7 +466,7 @@ __global__ __launch_bounds__(256) void k_leaflets_global_contig(LeafletArgs a) {
 //                    seen from c, every image is the atom's own coordinate moved by the same number of box lengths and the
 //                    centre is c (modulo L).  Frames where that cannot be shown (a membrane across the periodic boundary,
 //                    a NaN) are left to k_leaflets_global_contig (`skip`).
-//   k_spec_check   : per (frame, molecule): the side by the exact centre against the side the order kernel used; the pairs
+//   k_spec_check, then: per (frame, molecule): the side by the exact centre against the side the order kernel used; the pairs
 //                    that differ go on a list; the last frame's sides become the next batch's row 0 (through a spare row).
 //   k_spec_fixup   : per listed pair: the molecule's samples of that frame again, their ticks moved from one leaflet's sums to
 //                    the other's.  Lipids do not change leaflet from one frame to the next: the list is short.
@@ -462,74 +477,100 @@ struct SpecArgs {
     uint32_t dim;
     int flip, pbc;
     const float4 *mom;         // [n_frames][n_tiles]
+    const float *head_z;       // [n_frames][n_mol_total] the heads' normal coordinates, from the order kernel
     float *center;             // [n_frames]
     uint8_t *ok;               // [n_frames] 1 = `center` is the reference's centre
-    const uint32_t *heads;
     uint8_t *aflags;           // row 0: the sides the order kernel used; rows 1 + f: exact sides of the frames that were not ok;
-                               // row n_frames + 1: the last frame's exact sides (copied to row 0 afterwards)
+                               // row n_frames + 1: the last frame's exact sides (k_spec_fixup copies them to row 0)
     float *adist;
     uint2 *fix;                // (frame, molecule | exact side << 31)
-    uint32_t *counters;        // [0] listed pairs, [1] frames that were not ok
+    uint32_t *counters;        // this batch's pair: [0] listed pairs, [1] frames that were not ok
+    uint32_t *counters_next;   // the next batch's pair (k_spec_fixup zeroes it)
+    uint32_t *host_counters;   // pinned host copy of this batch's pair
     uint32_t *err;
 };
-__global__ __launch_bounds__(256) void k_spec_resolve(SpecArgs a) {
-    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= a.n_frames) return;
-    double S = 0.0, Q = 0.0;
-    float mn = 3.0e38f, mx = -3.0e38f;
-    for (uint32_t t = 0; t < a.n_tiles; t++) {
-        const float4 m = a.mom[(size_t)f * a.n_tiles + t];
-        S += (double)m.x; Q += (double)m.y;
-        mn = fminf(mn, m.z); mx = fmaxf(mx, m.w);
+// k_spec_check: a workgroup per frame (in turn).  Its first wave adds the frame's tiles — k_spec_resolve's part, see above —,
+// then every thread compares molecules.
+__global__ __launch_bounds__(256) void k_spec_check(SpecArgs a) {
+    __shared__ float s_center;
+    __shared__ int s_ok;
+    for (uint32_t f = blockIdx.x; f < a.n_frames; f += gridDim.x) {
+        const float L = a.pbc ? a.box9[9 * (size_t)f + 4 * a.dim] : 0.0f;
+        if (threadIdx.x < 64u) {
+            double S = 0.0, Q = 0.0;
+            float mn = 3.0e38f, mx = -3.0e38f;
+            for (uint32_t t = threadIdx.x; t < a.n_tiles; t += 64u) {
+                const float4 m = a.mom[(size_t)f * a.n_tiles + t];
+                S += (double)m.x; Q += (double)m.y;
+                mn = fminf(mn, m.z); mx = fmaxf(mx, m.w);
+            }
+            for (int off = 32; off >= 1; off >>= 1) {
+                S += __shfl_xor(S, off, 64); Q += __shfl_xor(Q, off, 64);
+                mn = fminf(mn, __shfl_xor(mn, off, 64)); mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+            }
+            if (threadIdx.x == 0u) {
+                const double n = (double)a.n_membrane, c = S / n;
+                bool ok = (S - S == 0.0) && (Q - Q == 0.0) && mn <= mx;             // finite sums, at least one atom
+                if (ok && a.pbc) {
+                    const double k = 6.283185307179586 / (double)L;
+                    // (the tiles' sums are f32: sum z^2 of a tile is good to ~1e-6 of itself, and the difference below is a
+                    // few per cent of it in the worst case: 1e-4 of slack on the total covers it)
+                    const double var = fmax(Q - S * S / n, 0.0) + 1e-4 * Q + 1e-6 * n;
+                    const double dmax = k * fmax((double)mx - c, c - (double)mn), S2 = k * k * var, den = n - 0.5 * S2;
+                    ok = den > 0.0 && L > 0.0f;
+                    if (ok) {
+                        const double dist = (dmax * S2 / 6.0 / den) / k;              // atan(x) <= x
+                        const double room = 0.5 * (double)L - 1e-4 * (double)L - dist;
+                        ok = (double)mx - c < room && c - (double)mn < room;
+                    }
+                }
+                a.center[f] = (float)c;
+                a.ok[f] = ok ? 1 : 0;
+                s_center = (float)c;
+                s_ok = ok ? 1 : 0;
+                if (!ok) atomicAdd(&a.counters[1], 1u);
+            }
+        }
+        __syncthreads();
+        if (s_ok) {
+            const float c = s_center;
+            const bool last = f + 1 == a.n_frames;
+            int bad = 0;
+            for (uint32_t m = threadIdx.x; m < a.n_mol_total; m += blockDim.x) {
+                float d = a.head_z[(size_t)f * a.n_mol_total + m] - c;
+                if (a.pbc) d = gm_min_image(d, L, bad);
+                const uint8_t exact = (uint8_t)((d >= 0.0f ? 0 : 1) ^ (a.flip ? 1 : 0));
+                if (exact != a.aflags[m]) a.fix[atomicAdd(&a.counters[0], 1u)] = make_uint2(f, m | ((uint32_t)exact << 31));
+                if (last) {
+                    a.aflags[(size_t)(a.n_frames + 1u) * a.n_mol_total + m] = exact;
+                    if (a.adist) a.adist[m] = d;
+                }
+            }
+            if (bad) raise_box_range(a.err, f);
+        }
+        __syncthreads();
     }
-    const double n = (double)a.n_membrane;
-    const float L = a.pbc ? a.box9[9 * (size_t)f + 4 * a.dim] : 0.0f;
-    const double c = S / n;
-    bool ok = (S - S == 0.0) && (Q - Q == 0.0) && mn <= mx;             // finite sums, at least one atom
-    if (ok && a.pbc) {
-        const double k = 6.283185307179586 / (double)L;
-        // (the tiles' sums are f32: sum z^2 of a tile is good to ~1e-6 of itself, and the difference below is a few per
-        // cent of it in the worst case: 1e-4 of slack on the total covers it)
-        const double var = fmax(Q - S * S / n, 0.0) + 1e-4 * Q + 1e-6 * n;
-        const double dmax = k * fmax((double)mx - c, c - (double)mn), S2 = k * k * var, den = n - 0.5 * S2;
-        ok = den > 0.0 && L > 0.0f;
-        if (ok) {
-            const double dist = (dmax * S2 / 6.0 / den) / k;              // atan(x) <= x
-            const double room = 0.5 * (double)L - 1e-4 * (double)L - dist;
-            ok = (double)mx - c < room && c - (double)mn < room;
+}
+// the frames k_leaflets_global[_contig] decided after all: their sides against the prediction
+__global__ __launch_bounds__(256) void k_spec_check_exact(SpecArgs a) {
+    for (uint32_t f = blockIdx.x; f < a.n_frames; f += gridDim.x) {
+        if (a.ok[f]) continue;
+        const bool last = f + 1 == a.n_frames;
+        for (uint32_t m = threadIdx.x; m < a.n_mol_total; m += blockDim.x) {
+            const uint8_t exact = a.aflags[(size_t)(1u + f) * a.n_mol_total + m];     // (the exact kernel wrote it, and adist)
+            if (exact != a.aflags[m]) a.fix[atomicAdd(&a.counters[0], 1u)] = make_uint2(f, m | ((uint32_t)exact << 31));
+            if (last) a.aflags[(size_t)(a.n_frames + 1u) * a.n_mol_total + m] = exact;
         }
     }
-    a.center[f] = (float)c;
-    a.ok[f] = ok ? 1 : 0;
-    if (!ok) atomicAdd(&a.counters[1], 1u);
-}
-__global__ __launch_bounds__(256) void k_spec_check(SpecArgs a) {
-    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
-    if (m >= a.n_mol_total) return;
-    const bool last = f + 1 == a.n_frames;
-    uint8_t exact;
-    int bad = 0;
-    if (a.ok[f]) {
-        const float zh = a.xyz[((size_t)f * a.n_atoms + a.heads[m]) * 3u + a.dim];
-        float d = zh - a.center[f];
-        if (a.pbc) d = gm_min_image(d, a.box9[9 * (size_t)f + 4 * a.dim], bad);
-        exact = (uint8_t)((d >= 0.0f ? 0 : 1) ^ (a.flip ? 1 : 0));
-        if (last && a.adist) a.adist[m] = d;
-    } else {
-        exact = a.aflags[(size_t)(1u + f) * a.n_mol_total + m];         // (k_leaflets_global_contig wrote it, and adist)
-    }
-    if (exact != a.aflags[m]) a.fix[atomicAdd(&a.counters[0], 1u)] = make_uint2(f, m | ((uint32_t)exact << 31));
-    if (last) a.aflags[(size_t)(a.n_frames + 1u) * a.n_mol_total + m] = exact;
-    if (bad) raise_box_range(a.err, f);
 }
 // the samples of every molecule, molecule by molecule (CSR), for k_spec_fixup
 struct SpecSample { uint32_t i, j, slot; };
 template <bool ACOS_COS>
-__global__ __launch_bounds__(64) void k_spec_fixup(FrameArgs a, const uint2 *__restrict__ fix, const uint32_t *__restrict__ counters,
-                                                   const uint32_t *__restrict__ mol_begin, const SpecSample *__restrict__ samples) {
-    const uint32_t n = counters[0];
+__global__ __launch_bounds__(64) void k_spec_fixup(FrameArgs a, SpecArgs sa, const uint32_t *__restrict__ mol_begin,
+                                                   const SpecSample *__restrict__ samples) {
+    const uint32_t n = sa.counters[0];
     for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
-        const uint2 w = fix[e];
+        const uint2 w = sa.fix[e];
         const uint32_t f = w.x, m = w.y & 0x7fffffffu, exact = w.y >> 31;
         const float *x = a.xyz + (size_t)f * a.n_atoms * 3u;
         for (uint32_t q = mol_begin[m] + threadIdx.x; q < mol_begin[m + 1]; q += blockDim.x) {
@@ -538,7 +579,6 @@ __global__ __launch_bounds__(64) void k_spec_fixup(FrameArgs a, const uint2 *__r
             int bad = 0;
             const float *p1 = x + 3u * (size_t)sm.i, *p2 = x + 3u * (size_t)sm.j;
             bond_sample<ACOS_COS>(a, f, p1[0], p1[1], p1[2], p2[0], p2[1], p2[2], m, acc, bad);
-            if (!acc.n_tot) continue;                              // (an undefined position: the order kernel added nothing either)
             // Leaflet::Upper = 0: a molecule that is in the upper leaflet after all gains the tick there, one that is not loses it
             unsigned long long *rep = a.rep;                        // replica 0
             if (exact == 0u) {
@@ -548,6 +588,18 @@ __global__ __launch_bounds__(64) void k_spec_fixup(FrameArgs a, const uint2 *__r
                 atomicAdd(&rep[(size_t)a.n_acc + sm.slot], (unsigned long long)(-acc.s_tot));
                 atomicAdd(&rep[3u * (size_t)a.n_acc + sm.slot], ~0ull);
             }
+        }
+    }
+    // housekeeping of the batch, by the first workgroup (every check is done by now): the last frame's sides become row 0,
+    // the counters go to the host's pinned copy, the next batch's counters start at zero
+    if (blockIdx.x == 0u) {
+        for (uint32_t m = threadIdx.x; m < sa.n_mol_total; m += blockDim.x)
+            sa.aflags[m] = sa.aflags[(size_t)(sa.n_frames + 1u) * sa.n_mol_total + m];
+        if (threadIdx.x == 0u) {
+            sa.host_counters[0] = n;
+            sa.host_counters[1] = sa.counters[1];
+            sa.counters_next[0] = 0u;
+            sa.counters_next[1] = 0u;
         }
     }
 }

@@ -78,6 +78,10 @@ struct Plan {
     // — the ranges partition the group — and sums their normal coordinates on the way.
     bool spec_ok = false;
     std::vector<uint32_t> own;
+    // the molecules whose HEAD atom a tile owns: (window-relative atom, molecule) per tile (CSR) — the order kernel hands
+    // their normal coordinates on, so that the sides can be checked without reading every head's cache line again
+    std::vector<uint32_t> own_head_begin;
+    std::vector<uint32_t> own_heads;      // pairs
 };
 
 struct Sample {
@@ -390,7 +394,38 @@ inline int build_plan(const gorder_tables_t &t, bool force_direct, Plan &p, bool
                 cur = hi;
                 widest = std::max(widest, nt[i].n_window);
             }
+            // every molecule's head must be an atom of the group (then exactly one tile owns it)
+            std::vector<uint32_t> head_begin, heads_flat;
             if (ok && cur == m1) {
+                std::vector<std::vector<uint32_t>> per_tile(nt.size());
+                uint32_t mol = 0;
+                for (uint32_t m = 0; ok && m < t.n_molecule_types; m++) {
+                    const gorder_moltype_t &mt = t.molecule_types[m];
+                    for (uint32_t k = 0; ok && k < mt.n_molecules; k++, mol++) {
+                        if (!mt.heads) { ok = false; break; }
+                        const uint32_t hd = mt.heads[k];
+                        if (hd < m0 || hd >= m1) { ok = false; break; }
+                        size_t lo_t = 0, hi_t = nt.size();          // the tile whose [own0, own1) holds hd (ranges ascend)
+                        while (hi_t - lo_t > 1) {
+                            const size_t mid = (lo_t + hi_t) / 2;
+                            if (own[2 * mid] <= hd) lo_t = mid; else hi_t = mid;
+                        }
+                        while (lo_t > 0 && !(own[2 * lo_t] <= hd && hd < own[2 * lo_t + 1])) lo_t--;    // (empty ranges share a start)
+                        if (!(own[2 * lo_t] <= hd && hd < own[2 * lo_t + 1])) { ok = false; break; }
+                        per_tile[lo_t].push_back(hd - nt[lo_t].atom0);
+                        per_tile[lo_t].push_back(mol);
+                    }
+                }
+                head_begin.push_back(0);
+                for (const auto &v : per_tile) {
+                    if (v.size() > 2 * 64) ok = false;             // (the order kernel holds a tile's heads one a lane)
+                    heads_flat.insert(heads_flat.end(), v.begin(), v.end());
+                    head_begin.push_back((uint32_t)(heads_flat.size() / 2));
+                }
+            }
+            if (ok && cur == m1) {
+                p.own_head_begin = head_begin;
+                p.own_heads = heads_flat;
                 if (shift0)
                     for (uint32_t q = 0; q < nt[0].n_items; q++) {
                         p.items[nt[0].item0 + q].li = (uint16_t)(p.items[nt[0].item0 + q].li + shift0);
