@@ -49,6 +49,8 @@ def make_system(name):
         return synthetic.aa_membrane(256, leaflets=LEAFLETS_GLOBAL), "AAOrder 256 lipids + global leaflets"
     if name == "cg3k":
         return synthetic.cg_membrane(3072), "CGOrder Martini bilayer 3072 lipids (36864 beads, 33792 bonds/frame)"
+    if name == "cg3k-leaflets":
+        return synthetic.cg_membrane(3072, leaflets=LEAFLETS_GLOBAL), "CGOrder Martini bilayer 3072 lipids + global leaflets"
     if name == "cg3k-local":     # BASELINE configs[2]
         from gorder_amd.abi import LEAFLETS_LOCAL
         return (synthetic.cg_membrane(3072, leaflets=LEAFLETS_LOCAL, radius=2.5),

@@ -1316,8 +1316,13 @@ static int run_leaflets(gorder_hip_handle *h, const float *d_xyz, const float *d
         // (behind a speculative batch nearly every frame is skipped: a few hundred workgroups take the frames in turn)
         const dim3 g(skip ? std::min<uint32_t>((uint32_t)aframes.size(), 512u) : (uint32_t)aframes.size()), b(1024);
         TIMING_MARK(h, h->membrane_is_frame ? "k_leaflets_global_contig" : "k_leaflets_global");
-        if (h->membrane_is_frame) hipLaunchKernelGGL(k_leaflets_global_contig, g, dim3(256), 0, h->stream, la);
-        else hipLaunchKernelGGL(k_leaflets_global, g, b, 0, h->stream, la);
+        if (h->membrane_is_frame) {
+            if (skip) hipLaunchKernelGGL(k_leaflets_global_contig<true>, g, dim3(256), 0, h->stream, la);
+            else hipLaunchKernelGGL(k_leaflets_global_contig<false>, g, dim3(256), 0, h->stream, la);
+        } else {
+            if (skip) hipLaunchKernelGGL(k_leaflets_global<true>, g, b, 0, h->stream, la);
+            else hipLaunchKernelGGL(k_leaflets_global<false>, g, b, 0, h->stream, la);
+        }
     } else if (lf.method == GORDER_LEAFLETS_INDIVIDUAL) {
         // gridDim.y <= 65535: launch in slabs
         TIMING_MARK(h, "k_leaflets_individual");

@@ -264,7 +264,14 @@ __device__ __forceinline__ void leaflets_global_frame(const LeafletArgs &a, uint
 }
 // grid = the assignment frames, or fewer workgroups that take them in turn (the launch behind a speculative batch, where
 // nearly every frame is skipped: a few hundred workgroups look at the flags instead of thousands being dispatched to leave)
+// (TURNS only for that launch: with the loop around it the frame's arithmetic spills — 67 registers —, and the ordinary
+// launch, a workgroup per frame, need not pay for that)
+template <bool TURNS>
 __global__ __launch_bounds__(1024) void k_leaflets_global(LeafletArgs a) {
+    if (!TURNS) {
+        leaflets_global_frame(a, blockIdx.x);
+        return;
+    }
     for (uint32_t bi = blockIdx.x; bi < a.n_assign; bi += gridDim.x) {
         leaflets_global_frame(a, bi);
         __syncthreads();
@@ -447,7 +454,12 @@ __device__ __forceinline__ void leaflets_global_contig_frame(const LeafletArgs &
     }
     if (bad) raise_box_range(a.err, f);
 }
+template <bool TURNS>
 __global__ __launch_bounds__(256) void k_leaflets_global_contig(LeafletArgs a) {
+    if (!TURNS) {
+        leaflets_global_contig_frame(a, blockIdx.x);
+        return;
+    }
     for (uint32_t bi = blockIdx.x; bi < a.n_assign; bi += gridDim.x) {
         leaflets_global_contig_frame(a, bi);
         __syncthreads();
