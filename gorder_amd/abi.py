@@ -111,7 +111,7 @@ class CPlan(C.Structure):
     _fields_ = [("n_tiles", C.c_uint32), ("block_threads", C.c_uint32),
                 ("max_window_atoms", C.c_uint32), ("n_direct_items", C.c_uint32),
                 ("frames_per_stage", C.c_uint32), ("lds_bytes", C.c_uint32),
-                ("map_staged", C.c_uint32), ("map_lds_bytes", C.c_uint32)]
+                ("map_staged", C.c_uint32), ("map_lds_bytes", C.c_uint32), ("leaflets_one_read", C.c_uint32)]
 
 
 # ---- python-side description of the tables ----------------------------------------------------

@@ -902,6 +902,7 @@ int gorder_hip_plan_tables(const gorder_tables_t *tables, gorder_hip_plan_t *out
     out->lds_bytes = (uint32_t)lds;
     out->map_staged = 0;         // decided at gorder_hip_create (device LDS size, GORDER_HIP_MAP_DIRECT)
     out->map_lds_bytes = 0;
+    out->leaflets_one_read = p.spec_ok ? 1u : 0u;
     if (selfcheck) *selfcheck = gorder::selfcheck_plan(*tables, p);
     return GORDER_OK;
 }
@@ -1265,6 +1266,7 @@ int gorder_hip_plan(const gorder_hip_handle *h, gorder_hip_plan_t *plan) {
     plan->lds_bytes = (uint32_t)h->lds_bytes;
     plan->map_staged = h->map_staged ? 1u : 0u;
     plan->map_lds_bytes = (uint32_t)h->map_lds_bytes;
+    plan->leaflets_one_read = h->plan.spec_ok ? 1u : 0u;
     return GORDER_OK;
 }
 

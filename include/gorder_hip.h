@@ -436,6 +436,8 @@ typedef struct {
     uint32_t lds_bytes;
     uint32_t map_staged;         /* 1: ordermap samples go through the staging buffer + k_map_accumulate (LDS) */
     uint32_t map_lds_bytes;      /* packed map of one accumulator slot (x2 with leaflets) = k_map_accumulate's LDS */
+    uint32_t leaflets_one_read;  /* 1: global leaflets can be assigned from the order kernel's own read of the frame (the
+                                  * membrane group is one range of atoms the tiles' windows cover, every head in it) */
 } gorder_hip_plan_t;
 int gorder_hip_plan(const gorder_hip_handle *h, gorder_hip_plan_t *plan);
 /* Same, without touching a device (host logic only); *selfcheck = 0 when every sample of the

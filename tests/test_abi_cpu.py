@@ -100,3 +100,32 @@ def test_force_direct_env(built, monkeypatch):
     monkeypatch.setenv("GORDER_HIP_FORCE_DIRECT", "1")
     plan = abi.plan_tables(system.tables)
     assert plan["n_tiles"] == 0 and plan["n_direct_items"] == 64 * 11 and plan["selfcheck"] == 0
+
+
+def test_plan_for_global_leaflets_in_one_read(built):
+    """Plan::spec_ok (plan.h): the order kernel can sum the membrane group on the way when the group is one range of atoms
+    the tiles' windows cover — extended where needed, the first tile backwards too — and every head lies in it."""
+    # the usual case: the group is every atom of the lipids
+    assert abi.plan_tables(synthetic.aa_membrane(40, leaflets=LEAFLETS_GLOBAL).tables)["leaflets_one_read"] == 1
+    assert abi.plan_tables(synthetic.cg_membrane(300, leaflets=LEAFLETS_GLOBAL, n_types=3).tables)["leaflets_one_read"] == 1
+    assert abi.plan_tables(synthetic.cg_membrane(300).tables)["leaflets_one_read"] == 0          # no leaflets
+    # the first bead of every lipid in no bond: the first tile's window is moved back to the group's first atom, the
+    # others reach forward over the beads between them — and the plan still covers every sample exactly once
+    s = synthetic.cg_membrane(200, leaflets=LEAFLETS_GLOBAL)
+    mt = s.tables.molecule_types[0]
+    mt.bonds = mt.bonds[1:]
+    plan = abi.plan_tables(s.tables)
+    assert plan["leaflets_one_read"] == 1 and plan["selfcheck"] == 0
+    # an index list that is not a range: the two-kernel path
+    s = synthetic.cg_membrane(100, leaflets=LEAFLETS_GLOBAL)
+    s.tables.leaflets.membrane = np.arange(0, s.n_atoms, 2, dtype=np.uint32)
+    assert abi.plan_tables(s.tables)["leaflets_one_read"] == 0
+    # a head outside the group
+    s = synthetic.cg_membrane(100, leaflets=LEAFLETS_GLOBAL)
+    s.tables.leaflets.membrane = np.arange(24, s.n_atoms, dtype=np.uint32)
+    assert abi.plan_tables(s.tables)["leaflets_one_read"] == 0
+    # water behind the lipids: the group ends before the frame does
+    s = synthetic.cg_membrane(100, leaflets=LEAFLETS_GLOBAL)
+    s.tables.n_atoms += 500
+    plan = abi.plan_tables(s.tables)
+    assert plan["leaflets_one_read"] == 1 and plan["selfcheck"] == 0
