@@ -1837,6 +1837,14 @@ int gorder_hip_reset(gorder_hip_handle *h) {
     h->manual_frames = 0;
     h->err_index = 0;
     h->err_msg.clear();
+    // a new run speculates again (and starts its statistics anew); the batches still in flight are waited for first —
+    // their counters would otherwise be booked on the new run
+    if (h->d_own) {
+        spec_poll(h, true);
+        h->spec_enabled = true;
+        h->spec_batches = h->spec_fixed = h->spec_exact_frames = 0;
+        HIP_TRY(h, hipMemsetAsync(h->d_spec_counters, 0, 4 * sizeof(uint32_t), h->stream));
+    }
     return GORDER_OK;
 }
 
