@@ -336,11 +336,24 @@ struct TiledStage {
 // middle of the box, with its square and the extrema; a NaN coordinate poisons the sums — and leaves them for
 // k_spec_resolve: mom[frame][tile].  Five instructions an atom, no sine or cosine.
 // a wave reduction by DPP alone: four shifts inside the rows of 16, then the rows' results passed on (row_bcast:15 into
-// rows 1 and 3, row_bcast:31 into the upper half): the total ends up in lane 63
-template <int CTRL, int ROW_MASK = 0xf>
-__device__ __forceinline__ float mom_dpp(float v, float old) {   // the value the control names, `old` where there is none
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+// rows 1 and 3, row_bcast:31 into the upper half): the total ends up in lane 63.  Sums take 0 where the control names no
+// lane (bound_ctrl: the shift folds into the add), extrema their own value.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float mom_dpp0(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
 }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float mom_dpp_self(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+// v_min_f32 / v_max_f32 as the hardware has them: `fminf` makes the compiler canonicalise both operands first (a v_max x, x, x
+// each — over a hundred extra instructions in the moments), and a NaN does not matter here: the finiteness of the staged
+// floats is checked on its own.  The DPP forms write only the lanes whose source lane exists (the others keep their value);
+// the s_nop covers the two wait states a DPP read needs behind a VALU write, which inline assembly has to provide itself.
+__device__ __forceinline__ float mom_min(float x, float y) { float r; __asm__("v_min_f32_e32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
+__device__ __forceinline__ float mom_max(float x, float y) { float r; __asm__("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
+#define GORDER_MOM_MINMAX_DPP(CTRL_TEXT)                                                                    \
+    __asm__("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 " CTRL_TEXT "\n\tv_max_f32_dpp %1, %1, %1 " CTRL_TEXT : "+v"(mn), "+v"(mx))
 __device__ __forceinline__ void tiled_moments(const FrameArgs &a, const Tile &t, uint2 own, uint32_t tile_id, uint32_t n_tiles,
                                               uint32_t f, const float *slot, bool finite, uint2 my_head) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -350,26 +363,32 @@ __device__ __forceinline__ void tiled_moments(const FrameArgs &a, const Tile &t,
     float s = 0.0f, q = 0.0f, mn = 3.0e38f, mx = -3.0e38f;
     // eight atoms a lane and trip, their LDS reads in flight together (one trip for up to 512 owned atoms: the moments sit
     // between a stage's loads and its arithmetic, and what they wait for the stage waits for); plain sums of z and z^2 —
-    // k_spec_resolve adds the tiles' in f64 and allows for the f32 rounding here
+    // k_spec_check adds the tiles' in f64 and allows for the f32 rounding here.  A lane past the range reads the range's
+    // last atom again: that leaves the extrema alone, and only the one group of 64 that is not full masks its sums.
     for (uint32_t i0 = 0; i0 < n_own; i0 += 512u) {
         float z[8];
 #pragma unroll
         for (uint32_t u = 0; u < 8u; u++) z[u] = w[3u * min(i0 + 64u * u + lane, n_own - 1u)];
 #pragma unroll
         for (uint32_t u = 0; u < 8u; u++) {
-            const bool valid = i0 + 64u * u + lane < n_own;
-            const float d = valid ? z[u] : 0.0f;
+            if (i0 + 64u * u >= n_own) break;                              // (uniform)
+            float d = z[u];
+            if (i0 + 64u * u + 64u > n_own) d = i0 + 64u * u + lane < n_own ? d : 0.0f;     // (uniform condition: the partial group)
             s += d;
             q = __builtin_fmaf(d, d, q);
-            mn = __builtin_fminf(mn, valid ? z[u] : mn);
-            mx = __builtin_fmaxf(mx, valid ? z[u] : mx);
+            mn = mom_min(mn, z[u]);
+            mx = mom_max(mx, z[u]);
         }
     }
-#define GORDER_MOM_STEP(CTRL, MASK)                                                             \
-    s += mom_dpp<CTRL, MASK>(s, 0.0f); q += mom_dpp<CTRL, MASK>(q, 0.0f);                       \
-    mn = __builtin_fminf(mn, mom_dpp<CTRL, MASK>(mn, mn)); mx = __builtin_fmaxf(mx, mom_dpp<CTRL, MASK>(mx, mx));
-    GORDER_MOM_STEP(0x111, 0xf) GORDER_MOM_STEP(0x112, 0xf) GORDER_MOM_STEP(0x114, 0xf) GORDER_MOM_STEP(0x118, 0xf)
-    GORDER_MOM_STEP(0x142, 0xa) GORDER_MOM_STEP(0x143, 0xc)
+#define GORDER_MOM_STEP(CTRL, MASK, CTRL_TEXT)                                                  \
+    s += mom_dpp0<CTRL, MASK>(s); q += mom_dpp0<CTRL, MASK>(q);                                 \
+    GORDER_MOM_MINMAX_DPP(CTRL_TEXT);
+    GORDER_MOM_STEP(0x111, 0xf, "row_shr:1 row_mask:0xf bank_mask:0xf")
+    GORDER_MOM_STEP(0x112, 0xf, "row_shr:2 row_mask:0xf bank_mask:0xf")
+    GORDER_MOM_STEP(0x114, 0xf, "row_shr:4 row_mask:0xf bank_mask:0xf")
+    GORDER_MOM_STEP(0x118, 0xf, "row_shr:8 row_mask:0xf bank_mask:0xf")
+    GORDER_MOM_STEP(0x142, 0xa, "row_bcast:15 row_mask:0xa bank_mask:0xf")
+    GORDER_MOM_STEP(0x143, 0xc, "row_bcast:31 row_mask:0xc bank_mask:0xf")
 #undef GORDER_MOM_STEP
     const bool all_finite = __all(finite);
     if (lane == 63u) a.mom[(size_t)f * n_tiles + tile_id] = make_float4(all_finite ? s : __builtin_nanf(""), q, mn, mx);
@@ -421,7 +440,7 @@ __global__ __launch_bounds__(kBlock, GORDER_TILED_MIN_WAVES) void k_bonds_tiled(
         const bool finite = S::template store<false, MOM>(a, t, f0, f_end, sk, si, pre, lds, lw);
         __syncthreads();
         if (f0 + G < f_full) S::template load<false>(a, t, f0 + G, f_end, sk, si, pre);   // next stage in flight
-        if (MOM) {          // (the wave that staged frame slot k sums it: TPF = 64)
+        if (MOM) {          // (the wave that staged frame slot k sums it: TPF = 64; before or behind the loads: measured equal)
             static_assert(!MOM || (uint32_t)G * 64u == kBlock, "a wave per frame slot");
             tiled_moments(a, t, own, tile_id, n_tiles, f0 + sk, lds + (size_t)sk * lw, finite, my_head);
         }
