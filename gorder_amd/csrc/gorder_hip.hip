@@ -151,8 +151,6 @@ struct gorder_hip_handle {
     float *d_spec_center = nullptr;
     uint8_t *d_spec_ok = nullptr;
     size_t spec_frames_cap = 0;
-    uint2 *d_spec_fix = nullptr;
-    size_t spec_fix_cap = 0;
     uint32_t *d_spec_counters = nullptr;           // two pairs (batches alternate): [0] mispredicted (frame, molecule) pairs, [1] frames left to the exact kernel
     // pinned copies of the last speculative batches' counters, looked at (without waiting) when a later batch is submitted
     static constexpr uint32_t kSpecRing = 8;
@@ -1209,7 +1207,7 @@ void gorder_hip_destroy(gorder_hip_handle *h) {
     (void)hipFree(h->d_runs); (void)hipFree(h->d_run_begin); (void)hipFree(h->d_items_by_slot);
     (void)hipFree(h->d_ua_item_run); (void)hipFree(h->d_item_run); (void)hipFree(h->d_lgrid); (void)hipFree(h->d_lrowpre); (void)hipFree(h->d_ledge);
     (void)hipFree(h->d_own); (void)hipFree(h->d_mom); (void)hipFree(h->d_head_z); (void)hipFree(h->d_own_head_begin); (void)hipFree(h->d_own_heads); (void)hipFree(h->d_spec_center); (void)hipFree(h->d_spec_ok);
-    (void)hipFree(h->d_spec_fix); (void)hipFree(h->d_spec_counters); (void)hipFree(h->d_spec_mol_begin); (void)hipFree(h->d_spec_samples);
+    (void)hipFree(h->d_spec_counters); (void)hipFree(h->d_spec_mol_begin); (void)hipFree(h->d_spec_samples);
     if (h->h_spec_counters) (void)hipHostFree(h->h_spec_counters);
     for (hipEvent_t ev : h->spec_counters_copied) if (ev) (void)hipEventDestroy(ev); (void)hipFree(h->d_lfinfo); (void)hipFree(h->d_ltodo);
     (void)hipFree(h->d_dyn_cloud); (void)hipFree(h->d_dyn_heads); (void)hipFree(h->d_dyn_cell_of); (void)hipFree(h->d_dyn_count);
@@ -1443,7 +1441,7 @@ int gorder_hip_submit_device(gorder_hip_handle *h, const float *d_xyz, const flo
         // One read for global leaflets + order parameters: every frame of the batch is an assignment frame, an earlier
         // assignment exists (row 0), nothing but the plain order kernel runs.  The order kernel then routes by row 0.
         spec = h->spec_enabled && lf.method == GORDER_LEAFLETS_GLOBAL && h->have_assignment && aframes.size() == n_frames &&
-               n_frames <= 65535u && !h->extra.maps && !h->extra.tw && !h->extra.geom_kind && !h->dyn && !h->manual_frames &&
+               !h->extra.maps && !h->extra.tw && !h->extra.geom_kind && !h->dyn && !h->manual_frames &&
                !h->use_gather && !p.tiles.empty();
         if (spec) {
             spec_poll(h, false);
@@ -1452,7 +1450,7 @@ int gorder_hip_submit_device(gorder_hip_handle *h, const float *d_xyz, const flo
             spec = h->spec_enabled;
         }
         if (spec) std::fill(arow.begin(), arow.end(), 0u);
-        const size_t rows = spec ? (size_t)n_frames + 2 : aframes.size() + 1;
+        const size_t rows = aframes.size() + 1;            // (a speculative batch: row 0 and every frame's exact sides)
         if (rows > h->aflags_rows) {
             uint8_t *nb = nullptr;
             const size_t nrows = rows + rows / 4;
@@ -1533,30 +1531,29 @@ int gorder_hip_submit_device(gorder_hip_handle *h, const float *d_xyz, const flo
     if (spec) {
         // the exact centres from the order kernel's sums, the exact kernel for the frames they cannot vouch for, the sides
         // of every (frame, molecule) against the prediction, the mispredicted ones moved
-        const size_t pairs = (size_t)n_frames * p.n_mol_total;
         size_t cap_c = h->spec_frames_cap, cap_o = h->spec_frames_cap;
         if ((st = ensure(h, &h->d_spec_center, &cap_c, n_frames)) != GORDER_OK) return abort_batch(st);
         if ((st = ensure(h, &h->d_spec_ok, &cap_o, n_frames)) != GORDER_OK) return abort_batch(st);
         h->spec_frames_cap = std::min(cap_c, cap_o);
-        if ((st = ensure(h, &h->d_spec_fix, &h->spec_fix_cap, pairs)) != GORDER_OK) return abort_batch(st);
         uint32_t *cnt = h->d_spec_counters + 2u * (uint32_t)(h->spec_batches & 1u);
         uint32_t *cnt_next = h->d_spec_counters + 2u * (uint32_t)((h->spec_batches + 1u) & 1u);
         SpecArgs sa{};
         sa.xyz = d_xyz; sa.box9 = d_box; sa.n_atoms = p.n_atoms; sa.n_frames = n_frames; sa.n_tiles = n_tiles_all;
         sa.n_mol_total = p.n_mol_total; sa.n_membrane = lf.n_membrane; sa.dim = lf.normal_dim; sa.flip = lf.flip ? 1 : 0;
         sa.pbc = pbc ? 1 : 0; sa.mom = h->d_mom; sa.head_z = h->d_head_z; sa.center = h->d_spec_center; sa.ok = h->d_spec_ok;
-        sa.aflags = h->d_aflags; sa.adist = h->d_adist; sa.fix = h->d_spec_fix; sa.counters = cnt; sa.counters_next = cnt_next;
+        sa.aflags = h->d_aflags; sa.adist = h->d_adist; sa.counters = cnt; sa.counters_next = cnt_next;
         const uint32_t ring_slot = (uint32_t)(h->spec_batches % gorder_hip_handle::kSpecRing);
         sa.host_counters = h->h_spec_counters + 2u * ring_slot; sa.err = h->d_err;
         (void)timing_mark(h, "k_spec_check + k_spec_fixup");
         hipLaunchKernelGGL(k_spec_check, dim3(std::min<uint32_t>(n_frames, 2048u)), dim3(256), 0, h->stream, sa);
         if ((st = run_leaflets(h, d_xyz, d_box, spec_aframes, 1, h->d_spec_ok)) != GORDER_OK) return abort_batch(st);
         (void)timing_mark(h, "k_spec_check + k_spec_fixup");
-        hipLaunchKernelGGL(k_spec_check_exact, dim3(std::min<uint32_t>(n_frames, 256u)), dim3(256), 0, h->stream, sa);
+        const uint32_t fix_grid = (uint32_t)std::min<uint64_t>(((uint64_t)n_frames * p.n_mol_total + 63u) / 64u, 4096u);
         if (h->tables.flags & GORDER_FLAG_TRIG_ACOS_COS)
-            hipLaunchKernelGGL(k_spec_fixup<true>, dim3(1024), dim3(64), 0, h->stream, a, sa, h->d_spec_mol_begin, h->d_spec_samples);
+            hipLaunchKernelGGL(k_spec_fixup<true>, dim3(fix_grid), dim3(64), 0, h->stream, a, sa, h->d_spec_mol_begin, h->d_spec_samples);
         else
-            hipLaunchKernelGGL(k_spec_fixup<false>, dim3(1024), dim3(64), 0, h->stream, a, sa, h->d_spec_mol_begin, h->d_spec_samples);
+            hipLaunchKernelGGL(k_spec_fixup<false>, dim3(fix_grid), dim3(64), 0, h->stream, a, sa, h->d_spec_mol_begin, h->d_spec_samples);
+        hipLaunchKernelGGL(k_spec_finish, dim3(1), dim3(256), 0, h->stream, sa);
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipEventRecord(h->spec_counters_copied[ring_slot], h->stream));
         h->spec_ring_frames[ring_slot] = n_frames;

@@ -479,9 +479,10 @@ __global__ __launch_bounds__(256) void k_leaflets_global_contig(LeafletArgs a) {
 //                    centre is c (modulo L).  Frames where that cannot be shown (a membrane across the periodic boundary,
 //                    a NaN) are left to k_leaflets_global_contig (`skip`).
 //   k_spec_check, then: per (frame, molecule): the side by the exact centre against the side the order kernel used; the pairs
-//                    that differ go on a list; the last frame's sides become the next batch's row 0 (through a spare row).
-//   k_spec_fixup   : per listed pair: the molecule's samples of that frame again, their ticks moved from one leaflet's sums to
-//                    the other's.  Lipids do not change leaflet from one frame to the next: the list is short.
+//                    (rows 1 + f of the flag table).
+//   k_spec_fixup   : per pair whose exact side is not row 0's: the molecule's samples of that frame again, their ticks moved
+//                    from one leaflet's sums to the other's.  Lipids do not change leaflet from one frame to the next:
+//                    there are few.  k_spec_finish: the last frame's sides become the next batch's row 0.
 struct SpecArgs {
     const float *xyz;
     const float *box9;
@@ -492,11 +493,10 @@ struct SpecArgs {
     const float *head_z;       // [n_frames][n_mol_total] the heads' normal coordinates, from the order kernel
     float *center;             // [n_frames]
     uint8_t *ok;               // [n_frames] 1 = `center` is the reference's centre
-    uint8_t *aflags;           // row 0: the sides the order kernel used; rows 1 + f: exact sides of the frames that were not ok;
-                               // row n_frames + 1: the last frame's exact sides (k_spec_fixup copies them to row 0)
+    uint8_t *aflags;           // row 0: the sides the order kernel used; rows 1 + f: every frame's exact sides (k_spec_check's,
+                               // or the exact kernel's for the frames that were not ok); k_spec_finish copies the last to row 0
     float *adist;
-    uint2 *fix;                // (frame, molecule | exact side << 31)
-    uint32_t *counters;        // this batch's pair: [0] listed pairs, [1] frames that were not ok
+    uint32_t *counters;        // this batch's pair: [0] mispredicted pairs, [1] frames that were not ok
     uint32_t *counters_next;   // the next batch's pair (k_spec_fixup zeroes it)
     uint32_t *host_counters;   // pinned host copy of this batch's pair
     uint32_t *err;
@@ -551,68 +551,73 @@ __global__ __launch_bounds__(256) void k_spec_check(SpecArgs a) {
             for (uint32_t m = threadIdx.x; m < a.n_mol_total; m += blockDim.x) {
                 float d = a.head_z[(size_t)f * a.n_mol_total + m] - c;
                 if (a.pbc) d = gm_min_image(d, L, bad);
-                const uint8_t exact = (uint8_t)((d >= 0.0f ? 0 : 1) ^ (a.flip ? 1 : 0));
-                if (exact != a.aflags[m]) a.fix[atomicAdd(&a.counters[0], 1u)] = make_uint2(f, m | ((uint32_t)exact << 31));
-                if (last) {
-                    a.aflags[(size_t)(a.n_frames + 1u) * a.n_mol_total + m] = exact;
-                    if (a.adist) a.adist[m] = d;
-                }
+                // (row 1 + f: the frame's exact sides, as the exact kernel leaves them for the frames it decides)
+                a.aflags[(size_t)(1u + f) * a.n_mol_total + m] = (uint8_t)((d >= 0.0f ? 0 : 1) ^ (a.flip ? 1 : 0));
+                if (last && a.adist) a.adist[m] = d;
             }
             if (bad) raise_box_range(a.err, f);
         }
         __syncthreads();
     }
 }
-// the frames k_leaflets_global[_contig] decided after all: their sides against the prediction
-__global__ __launch_bounds__(256) void k_spec_check_exact(SpecArgs a) {
-    for (uint32_t f = blockIdx.x; f < a.n_frames; f += gridDim.x) {
-        if (a.ok[f]) continue;
-        const bool last = f + 1 == a.n_frames;
-        for (uint32_t m = threadIdx.x; m < a.n_mol_total; m += blockDim.x) {
-            const uint8_t exact = a.aflags[(size_t)(1u + f) * a.n_mol_total + m];     // (the exact kernel wrote it, and adist)
-            if (exact != a.aflags[m]) a.fix[atomicAdd(&a.counters[0], 1u)] = make_uint2(f, m | ((uint32_t)exact << 31));
-            if (last) a.aflags[(size_t)(a.n_frames + 1u) * a.n_mol_total + m] = exact;
-        }
-    }
-}
 // the samples of every molecule, molecule by molecule (CSR), for k_spec_fixup
 struct SpecSample { uint32_t i, j, slot; };
+// k_spec_fixup: a wave looks at 64 (frame, molecule) pairs at a time — rows 1 + f hold every frame's exact sides by now,
+// k_spec_check's or the exact kernel's —, and for each pair whose side differs from row 0 all its lanes go over that
+// molecule's samples.  No list: nothing to overflow when a batch mispredicts wholesale.
 template <bool ACOS_COS>
 __global__ __launch_bounds__(64) void k_spec_fixup(FrameArgs a, SpecArgs sa, const uint32_t *__restrict__ mol_begin,
                                                    const SpecSample *__restrict__ samples) {
-    const uint32_t n = sa.counters[0];
-    for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
-        const uint2 w = sa.fix[e];
-        const uint32_t f = w.x, m = w.y & 0x7fffffffu, exact = w.y >> 31;
-        const float *x = a.xyz + (size_t)f * a.n_atoms * 3u;
-        for (uint32_t q = mol_begin[m] + threadIdx.x; q < mol_begin[m + 1]; q += blockDim.x) {
-            const SpecSample sm = samples[q];
-            SampleAcc acc;
-            int bad = 0;
-            const float *p1 = x + 3u * (size_t)sm.i, *p2 = x + 3u * (size_t)sm.j;
-            bond_sample<ACOS_COS>(a, f, p1[0], p1[1], p1[2], p2[0], p2[1], p2[2], m, acc, bad);
-            // Leaflet::Upper = 0: a molecule that is in the upper leaflet after all gains the tick there, one that is not loses it
-            unsigned long long *rep = a.rep;                        // replica 0
-            if (exact == 0u) {
-                atomicAdd(&rep[(size_t)a.n_acc + sm.slot], (unsigned long long)acc.s_tot);
-                atomicAdd(&rep[3u * (size_t)a.n_acc + sm.slot], 1ull);
-            } else {
-                atomicAdd(&rep[(size_t)a.n_acc + sm.slot], (unsigned long long)(-acc.s_tot));
-                atomicAdd(&rep[3u * (size_t)a.n_acc + sm.slot], ~0ull);
+    const uint64_t n_pairs = (uint64_t)sa.n_frames * sa.n_mol_total;
+    uint32_t moved = 0;
+    for (uint64_t p0 = (uint64_t)blockIdx.x * 64u; p0 < n_pairs; p0 += (uint64_t)gridDim.x * 64u) {
+        const uint64_t pi = p0 + threadIdx.x;
+        bool differs = false;
+        uint32_t exact_l = 0;
+        if (pi < n_pairs) {
+            exact_l = sa.aflags[(size_t)sa.n_mol_total + pi];               // row 1 + f, molecule m: offset n_mol + f n_mol + m
+            differs = exact_l != sa.aflags[pi % sa.n_mol_total];
+        }
+        unsigned long long todo = __ballot(differs);
+        moved += (uint32_t)__popcll(todo);
+        while (todo) {
+            const int l = __ffsll((long long)todo) - 1;
+            todo &= todo - 1ull;
+            const uint64_t pj = p0 + (uint64_t)l;
+            const uint32_t f = (uint32_t)(pj / sa.n_mol_total), m = (uint32_t)(pj - (uint64_t)f * sa.n_mol_total);
+            const uint32_t exact = (uint32_t)__shfl((int)exact_l, l, 64);
+            const float *x = a.xyz + (size_t)f * a.n_atoms * 3u;
+            for (uint32_t q = mol_begin[m] + threadIdx.x; q < mol_begin[m + 1]; q += 64u) {
+                const SpecSample sm = samples[q];
+                SampleAcc acc;
+                int bad = 0;
+                const float *p1 = x + 3u * (size_t)sm.i, *p2 = x + 3u * (size_t)sm.j;
+                bond_sample<ACOS_COS>(a, f, p1[0], p1[1], p1[2], p2[0], p2[1], p2[2], m, acc, bad);
+                // Leaflet::Upper = 0: a molecule that is in the upper leaflet after all gains the tick there, one that is not
+                // loses it
+                unsigned long long *rep = a.rep;                        // replica 0
+                if (exact == 0u) {
+                    atomicAdd(&rep[(size_t)a.n_acc + sm.slot], (unsigned long long)acc.s_tot);
+                    atomicAdd(&rep[3u * (size_t)a.n_acc + sm.slot], 1ull);
+                } else {
+                    atomicAdd(&rep[(size_t)a.n_acc + sm.slot], (unsigned long long)(-acc.s_tot));
+                    atomicAdd(&rep[3u * (size_t)a.n_acc + sm.slot], ~0ull);
+                }
             }
         }
     }
-    // housekeeping of the batch, by the first workgroup (every check is done by now): the last frame's sides become row 0,
-    // the counters go to the host's pinned copy, the next batch's counters start at zero
-    if (blockIdx.x == 0u) {
-        for (uint32_t m = threadIdx.x; m < sa.n_mol_total; m += blockDim.x)
-            sa.aflags[m] = sa.aflags[(size_t)(sa.n_frames + 1u) * sa.n_mol_total + m];
-        if (threadIdx.x == 0u) {
-            sa.host_counters[0] = n;
-            sa.host_counters[1] = sa.counters[1];
-            sa.counters_next[0] = 0u;
-            sa.counters_next[1] = 0u;
-        }
+    if (threadIdx.x == 0u && moved) atomicAdd(&sa.counters[0], moved);
+}
+// the batch's housekeeping, behind the fix-up: the last frame's sides become row 0, the counters go to the host's pinned
+// words, the next batch's counters start at zero
+__global__ __launch_bounds__(256) void k_spec_finish(SpecArgs sa) {
+    for (uint32_t m = threadIdx.x; m < sa.n_mol_total; m += blockDim.x)
+        sa.aflags[m] = sa.aflags[(size_t)sa.n_frames * sa.n_mol_total + m];          // row 1 + (n_frames - 1)
+    if (threadIdx.x == 0u) {
+        sa.host_counters[0] = sa.counters[0];
+        sa.host_counters[1] = sa.counters[1];
+        sa.counters_next[0] = 0u;
+        sa.counters_next[1] = 0u;
     }
 }
 
