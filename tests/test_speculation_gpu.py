@@ -162,3 +162,43 @@ def test_a_non_finite_coordinate_of_a_membrane_atom_outside_every_bond(built, mo
             eng, _ = run(system, xyz, box, 3, monkeypatch, speculate)
         codes.append((e.value.status, e.value.frame if hasattr(e.value, "frame") else None))
     assert codes[0][0] == codes[1][0] == abi.ERR_INVALID_GLOBAL_MEMBRANE_CENTER
+
+
+def test_a_batch_that_mispredicts_every_molecule(built, monkeypatch):
+    """The membrane mirrored about its mid-plane from the second batch on: every molecule of every later frame is on the
+    other side than the last assignment says.  The fix-up moves them all (nothing overflows: it keeps no list), the handle
+    stops speculating after that batch, and the sums are the two-kernel path's."""
+    system = synthetic.cg_membrane(120, leaflets=LEAFLETS_GLOBAL, n_types=2)
+    n = 36
+    xyz = system.frames(n, seed=101).astype(np.float32)
+    zc = float(system.box[2]) / 2
+    xyz[9:, :, 2] = (2 * zc - xyz[9:, :, 2]).astype(np.float32)
+    box = system.box9(n)
+    e1, _ = run(system, xyz, box, 4, monkeypatch, True)
+    assert e1.stats["moved"] >= 9 * 120 and not e1.stats["enabled"]
+    got = both(system, xyz, box, 4, monkeypatch)
+    want = oracle_sums(system, xyz, box)
+    np.testing.assert_array_equal(got.sums, want.sums)
+    np.testing.assert_array_equal(got.counts, want.counts)
+
+
+def test_a_first_batch_of_one_frame_and_reset(built, monkeypatch):
+    system = synthetic.aa_membrane(24, leaflets=LEAFLETS_GLOBAL)
+    n = 21
+    xyz = system.frames(n, seed=103)
+    box = system.box9(n)
+    eng = HipEngine(system.tables)
+    for a, b in ((0, 1), (1, 14), (14, 21)):
+        eng.submit_host(xyz[a:b], box[a:b], np.arange(a, b))
+    first = eng.finish()
+    assert eng.speculation_stats()["batches"] == 2
+    want = oracle_sums(system, xyz, box)
+    np.testing.assert_array_equal(first.sums, want.sums)
+    eng.reset()                                   # a new run on the same handle: the first batch assigns exactly again
+    assert eng.speculation_stats() == {"batches": 0, "moved": 0, "exact_frames": 0, "enabled": True}
+    for a, b in ((0, 8), (8, 21)):
+        eng.submit_host(xyz[a:b], box[a:b], np.arange(a, b))
+    again = eng.finish()
+    np.testing.assert_array_equal(again.sums, want.sums)
+    np.testing.assert_array_equal(again.counts, want.counts)
+    assert eng.speculation_stats()["batches"] == 1
