@@ -47,6 +47,9 @@ def make_system(name):
         return synthetic.aa_membrane(256), "AAOrder 256-lipid all-atom membrane (25088 atoms, 16384 C-H bonds/frame)"
     if name == "aa256-leaflets":
         return synthetic.aa_membrane(256, leaflets=LEAFLETS_GLOBAL), "AAOrder 256 lipids + global leaflets"
+    if name == "aa256-leaflets-timewise":
+        return (synthetic.aa_membrane(256, leaflets=LEAFLETS_GLOBAL, timewise=True),
+                "AAOrder 256 lipids + global leaflets + per-frame rows (error estimation)")
     if name == "cg3k":
         return synthetic.cg_membrane(3072), "CGOrder Martini bilayer 3072 lipids (36864 beads, 33792 bonds/frame)"
     if name == "cg3k-leaflets":

@@ -612,7 +612,10 @@ int launch_orders(gorder_hip_handle *h, FrameArgs &a) {
                                             !env_flag("GORDER_HIP_MAPS_GATHER");
 #define GORDER_LAUNCH_TM_A(NPF_, PBC_, LF_, AX_)                                                                   \
     do {                                                                                                            \
-        if (tiled_tw && staged)                                                                                     \
+        if (tiled_tw && !staged && LF_ && h->spec_now)                                                              \
+            hipLaunchKernelGGL((k_bonds_tiled_tw<NPF_, PBC_, LF_, AX_, false, LF_>), g, blk, h->lds_bytes, h->stream, b, e, b.xyz, \
+                               b.box9, b.aflags, b.arow, h->d_tiles, items, h->d_tile_slots, nt, h->lw);               \
+        else if (tiled_tw && staged)                                                                                \
             hipLaunchKernelGGL((k_bonds_tiled_tw<NPF_, PBC_, LF_, AX_, true>), g, blk, h->lds_bytes, h->stream, b, e, b.xyz, \
                                b.box9, b.aflags, b.arow, h->d_tiles, items, h->d_tile_slots, nt, h->lw);               \
         else if (tiled_tw)                                                                                          \
@@ -1440,8 +1443,11 @@ int gorder_hip_submit_device(gorder_hip_handle *h, const float *d_xyz, const flo
         }
         // One read for global leaflets + order parameters: every frame of the batch is an assignment frame, an earlier
         // assignment exists (row 0), nothing but the plain order kernel runs.  The order kernel then routes by row 0.
+        // (per-frame rows too where they come out of the tiled kernel: k_bonds_tiled_tw, the default cosine)
+        const bool tw_tiled = h->extra.tw && !(h->tables.flags & GORDER_FLAG_TRIG_ACOS_COS) && h->d_item_run &&
+                              h->frames_per_stage == (int)kRecFrames && !env_flag("GORDER_HIP_TW_GATHER");
         spec = h->spec_enabled && lf.method == GORDER_LEAFLETS_GLOBAL && h->have_assignment && aframes.size() == n_frames &&
-               !h->extra.maps && !h->extra.tw && !h->extra.geom_kind && !h->dyn && !h->manual_frames &&
+               !h->extra.maps && (!h->extra.tw || tw_tiled) && !h->extra.geom_kind && !h->dyn && !h->manual_frames &&
                !h->use_gather && !p.tiles.empty();
         if (spec) {
             spec_poll(h, false);
@@ -1549,10 +1555,15 @@ int gorder_hip_submit_device(gorder_hip_handle *h, const float *d_xyz, const flo
         if ((st = run_leaflets(h, d_xyz, d_box, spec_aframes, 1, h->d_spec_ok)) != GORDER_OK) return abort_batch(st);
         (void)timing_mark(h, "k_spec_check + k_spec_fixup");
         const uint32_t fix_grid = (uint32_t)std::min<uint64_t>(((uint64_t)n_frames * p.n_mol_total + 63u) / 64u, 4096u);
-        if (h->tables.flags & GORDER_FLAG_TRIG_ACOS_COS)
-            hipLaunchKernelGGL(k_spec_fixup<true>, dim3(fix_grid), dim3(64), 0, h->stream, a, sa, h->d_spec_mol_begin, h->d_spec_samples);
+        if (h->extra.tw)
+            hipLaunchKernelGGL((k_spec_fixup<false, true>), dim3(fix_grid), dim3(64), 0, h->stream, a, sa, h->d_spec_mol_begin,
+                               h->d_spec_samples, h->d_tw_sums, h->d_tw_cnts, (uint64_t)h->n_frames);
+        else if (h->tables.flags & GORDER_FLAG_TRIG_ACOS_COS)
+            hipLaunchKernelGGL((k_spec_fixup<true, false>), dim3(fix_grid), dim3(64), 0, h->stream, a, sa, h->d_spec_mol_begin,
+                               h->d_spec_samples, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (uint64_t)0);
         else
-            hipLaunchKernelGGL(k_spec_fixup<false>, dim3(fix_grid), dim3(64), 0, h->stream, a, sa, h->d_spec_mol_begin, h->d_spec_samples);
+            hipLaunchKernelGGL((k_spec_fixup<false, false>), dim3(fix_grid), dim3(64), 0, h->stream, a, sa, h->d_spec_mol_begin,
+                               h->d_spec_samples, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (uint64_t)0);
         hipLaunchKernelGGL(k_spec_finish, dim3(1), dim3(256), 0, h->stream, sa);
         HIP_TRY(h, hipGetLastError());
         HIP_TRY(h, hipEventRecord(h->spec_counters_copied[ring_slot], h->stream));

@@ -388,7 +388,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_bonds_tiled_maps(FrameArgs a_in, 
 // to the rows with the same global atomics as extras_flush_tw.  No barrier of its own: the ticks are written before the
 // barrier that ends a stage and read behind it, next to the staging of the next stage.
 // grid = n_tiles * n_chunks; items = the slot-ordered copy, e.item_run its runs.
-template <int NPF, bool PBC, bool LEAF, int AXIS, bool MAPS>
+// MOM: as in k_bonds_tiled — the tile's share of the membrane group's normal coordinates summed on the way, for a batch whose
+// leaflets are assigned from this kernel's own read of the frames.
+template <int NPF, bool PBC, bool LEAF, int AXIS, bool MAPS, bool MOM = false>
 __global__ __launch_bounds__(kBlock, 4) void k_bonds_tiled_tw(FrameArgs a_in, ExtraArgs e, const float *__restrict__ xyz,
                                                              const float *__restrict__ box9, const uint8_t *__restrict__ aflags,
                                                              const uint32_t *__restrict__ arow, const Tile *__restrict__ tiles,
@@ -431,17 +433,28 @@ __global__ __launch_bounds__(kBlock, 4) void k_bonds_tiled_tw(FrameArgs a_in, Ex
     v4f pre[NPF];
     const uint32_t my_slot = tid < t.n_slots ? tile_slots[t.slot0 + tid] : 0u;
     l_slot_id[tid] = my_slot;
+    uint2 own = make_uint2(0u, 0u), my_head = make_uint2(0u, 0xffffffffu);
+    if (MOM) {
+        own = a.own[tile_id];
+        const uint32_t hq = a.own_head_begin[tile_id] + (tid & 63u);
+        if (hq < a.own_head_begin[tile_id + 1u]) my_head = a.own_heads[hq];
+    }
     if (f_begin + G <= f_end) S::template load<false>(a, t, f_begin, f_end, sk, si, pre);
     for (uint32_t fs = f_begin; fs < f_end; fs += G) {
         const bool full = fs + G <= f_end;
+        bool finite;
         if (full) {
-            S::template store<false>(a, t, fs, f_end, sk, si, pre, lds, lw);
+            finite = S::template store<false, MOM>(a, t, fs, f_end, sk, si, pre, lds, lw);
         } else {
             S::template load<true>(a, t, fs, f_end, sk, si, pre);
-            S::template store<true>(a, t, fs, f_end, sk, si, pre, lds, lw);
+            finite = S::template store<true, MOM>(a, t, fs, f_end, sk, si, pre, lds, lw);
         }
         __syncthreads();
         if (full && fs + 2u * G <= f_end) S::template load<false>(a, t, fs + G, f_end, sk, si, pre);     // next stage in flight
+        if (MOM && fs + sk < f_end) {
+            static_assert(!MOM || (uint32_t)G * 64u == kBlock, "a wave per frame slot");
+            tiled_moments(a, t, own, tile_id, n_tiles, fs + sk, lds + (size_t)sk * lw, finite, my_head);
+        }
 #pragma unroll
         for (uint32_t k = 0; k < kRecFrames; k++) { words[k] = kMapNoSample; if (MAPS) mwords[k] = kMapNoSample; }
         if (active) {

@@ -565,9 +565,11 @@ struct SpecSample { uint32_t i, j, slot; };
 // k_spec_fixup: a wave looks at 64 (frame, molecule) pairs at a time — rows 1 + f hold every frame's exact sides by now,
 // k_spec_check's or the exact kernel's —, and for each pair whose side differs from row 0 all its lanes go over that
 // molecule's samples.  No list: nothing to overflow when a batch mispredicts wholesale.
-template <bool ACOS_COS>
+// TW: the per-frame rows (timewise.rs:130-186) hold the tick under its leaflet as well: moved there too.
+template <bool ACOS_COS, bool TW>
 __global__ __launch_bounds__(64) void k_spec_fixup(FrameArgs a, SpecArgs sa, const uint32_t *__restrict__ mol_begin,
-                                                   const SpecSample *__restrict__ samples) {
+                                                   const SpecSample *__restrict__ samples, unsigned long long *tw_sums,
+                                                   unsigned long long *tw_cnts, uint64_t tw_row0) {
     const uint64_t n_pairs = (uint64_t)sa.n_frames * sa.n_mol_total;
     uint32_t moved = 0;
     for (uint64_t p0 = (uint64_t)blockIdx.x * 64u; p0 < n_pairs; p0 += (uint64_t)gridDim.x * 64u) {
@@ -602,6 +604,15 @@ __global__ __launch_bounds__(64) void k_spec_fixup(FrameArgs a, SpecArgs sa, con
                 } else {
                     atomicAdd(&rep[(size_t)a.n_acc + sm.slot], (unsigned long long)(-acc.s_tot));
                     atomicAdd(&rep[3u * (size_t)a.n_acc + sm.slot], ~0ull);
+                }
+                if (TW) {           // rows [frame][total, upper, lower][slot]: out of the side it was counted under, into the other
+                    const size_t row = (size_t)(tw_row0 + f) * 3u * a.n_acc;
+                    const size_t to = row + (exact == 0u ? 1u : 2u) * (size_t)a.n_acc + sm.slot;
+                    const size_t from = row + (exact == 0u ? 2u : 1u) * (size_t)a.n_acc + sm.slot;
+                    atomicAdd(&tw_sums[to], (unsigned long long)acc.s_tot);
+                    atomicAdd(&tw_cnts[to], 1ull);
+                    atomicAdd(&tw_sums[from], (unsigned long long)(-acc.s_tot));
+                    atomicAdd(&tw_cnts[from], ~0ull);
                 }
             }
         }

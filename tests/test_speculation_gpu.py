@@ -202,3 +202,36 @@ def test_a_first_batch_of_one_frame_and_reset(built, monkeypatch):
     np.testing.assert_array_equal(again.sums, want.sums)
     np.testing.assert_array_equal(again.counts, want.counts)
     assert eng.speculation_stats()["batches"] == 1
+
+
+@pytest.mark.parametrize("kind", ["aa", "cg movers"])
+def test_per_frame_rows_in_a_speculative_batch(built, monkeypatch, kind):
+    """Error estimation on (timewise.rs:130-186): the rows hold every frame's ticks under total / upper / lower; the tiled
+    kernel that writes them sums the membrane as well, and the fix-up moves a mispredicted molecule's ticks in the rows too."""
+    if kind == "aa":
+        system = synthetic.aa_membrane(40, leaflets=LEAFLETS_GLOBAL, timewise=True)
+        n = 30
+        xyz = system.frames(n, seed=107)
+    else:
+        system = synthetic.cg_membrane(150, leaflets=LEAFLETS_GLOBAL, n_types=2, timewise=True)
+        n = 40
+        xyz = system.frames(n, seed=109).astype(np.float32)
+        zc = float(system.box[2]) / 2
+        for f in range(n):
+            for k, m in enumerate((3, 17, 58, 101, 140)):
+                if (f // (2 + k)) % 2:
+                    a = slice(m * 12, m * 12 + 12)
+                    xyz[f, a, 2] = (2 * zc - xyz[f, a, 2]).astype(np.float32)
+    box = system.box9(n)
+    e1, spec = run(system, xyz, box, 3, monkeypatch, True)
+    assert e1.stats["batches"] == 2 and (kind == "aa" or e1.stats["moved"] > 10)
+    tw1 = e1.timewise(n)
+    e2, plain = run(system, xyz, box, 3, monkeypatch, False)
+    tw2 = e2.timewise(n)
+    np.testing.assert_array_equal(spec.sums, plain.sums)
+    np.testing.assert_array_equal(spec.counts, plain.counts)
+    np.testing.assert_array_equal(tw1[0], tw2[0])
+    np.testing.assert_array_equal(tw1[1], tw2[1])
+    # and the rows add up to the totals, leaflet by leaflet
+    np.testing.assert_array_equal(np.asarray(tw1[0]).sum(axis=0), spec.sums)
+    np.testing.assert_array_equal(np.asarray(tw1[1]).sum(axis=0), spec.counts)

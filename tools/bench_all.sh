@@ -10,6 +10,8 @@ run aa256 10000 100 40 --trig acos
 run aa256-leaflets 4000 50 40
 GORDER_HIP_NO_SPECULATE=1 run aa256-leaflets 4000 50 40          # the two-kernel path (the frame read twice)
 run cg3k-leaflets 4000 50 40
+run aa256-leaflets-timewise 3000 50 40
+GORDER_HIP_NO_SPECULATE=1 run aa256-leaflets-timewise 3000 50 40
 run aa256-maps 3000 50 40
 run cg3k 4000 100 60
 run cg3k-local 512 10 4
