@@ -1754,6 +1754,15 @@ int gorder_hip_timewise(gorder_hip_handle *h, int64_t *tw_sums, uint64_t *tw_cou
     if (n) {
         HIP_TRY(h, hipMemcpy(tw_sums, h->d_tw_sums, n * sizeof(int64_t), hipMemcpyDeviceToHost));
         HIP_TRY(h, hipMemcpy(tw_counts, h->d_tw_cnts, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        // the kernels keep total and upper only (a third fewer atomics): the lower leaflet's rows are their difference
+        if (h->tables.leaflets.method != GORDER_LEAFLETS_NONE) {
+            const size_t na = h->plan.n_acc;
+            for (uint64_t f = 0; f < h->n_frames; f++) {
+                int64_t *s = tw_sums + f * 3 * na;
+                uint64_t *c = tw_counts + f * 3 * na;
+                for (size_t k = 0; k < na; k++) { s[2 * na + k] = s[k] - s[na + k]; c[2 * na + k] = c[k] - c[na + k]; }
+            }
+        }
     }
     return GORDER_OK;
 }

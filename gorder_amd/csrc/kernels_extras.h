@@ -119,9 +119,9 @@ __device__ __forceinline__ void extras_add(const FrameArgs &a, const ExtraArgs &
     if (!STAGED_ONLY && e.tw && !skip_tw) {
         atomicAdd(&l_tw[lslot], tick);
         atomicAdd(&l_twn[lslot], 1u);
-        if (leaflet >= 0) {
-            atomicAdd(&l_tw[(1 + leaflet) * lstride + lslot], tick);
-            atomicAdd(&l_twn[(1 + leaflet) * lstride + lslot], 1u);
+        if (leaflet == 0) {         // (the lower leaflet's row is total - upper: gorder_hip_timewise takes the difference)
+            atomicAdd(&l_tw[lstride + lslot], tick);
+            atomicAdd(&l_twn[lstride + lslot], 1u);
         }
     }
 }
@@ -132,7 +132,7 @@ __device__ __forceinline__ void extras_flush_tw(const FrameArgs &a, const ExtraA
                                                 uint32_t lstride) {
     for (uint32_t ls = threadIdx.x; ls < n_slots; ls += blockDim.x) {
         const size_t row = ((size_t)e.tw_row0 + f) * 3u * a.n_acc;
-        for (uint32_t w = 0; w < 3; w++) {
+        for (uint32_t w = 0; w < 2; w++) {          // total, upper (the lower leaflet's row is their difference)
             const uint32_t n = l_twn[w * lstride + ls];
             if (n) {
                 atomicAdd(&e.tw_sums[row + (size_t)w * a.n_acc + slots[ls]],
@@ -494,10 +494,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_bonds_tiled_tw(FrameArgs a_in, Ex
                     atomicAdd(&e.tw_sums[row + (size_t)a.n_acc + slot], (unsigned long long)(long long)(s_all - s_low));
                     atomicAdd(&e.tw_cnts[row + (size_t)a.n_acc + slot], (unsigned long long)n_up);
                 }
-                if (n_low) {
-                    atomicAdd(&e.tw_sums[row + 2u * (size_t)a.n_acc + slot], (unsigned long long)(long long)s_low);
-                    atomicAdd(&e.tw_cnts[row + 2u * (size_t)a.n_acc + slot], (unsigned long long)n_low);
-                }
+                // (no atomics for the lower leaflet: its row is total - upper, taken by gorder_hip_timewise — a third of this
+                // kernel's row traffic)
             }
         }
     }
@@ -1268,10 +1266,7 @@ __device__ __forceinline__ void ua_extras_body(FrameArgs a_in, ExtraArgs e, cons
                             atomicAdd(&e.tw_sums[row + (size_t)a.n_acc + slot], (unsigned long long)(long long)(s_all - s_low));
                             atomicAdd(&e.tw_cnts[row + (size_t)a.n_acc + slot], (unsigned long long)n_up_w);
                         }
-                        if (n_low) {
-                            atomicAdd(&e.tw_sums[row + 2u * (size_t)a.n_acc + slot], (unsigned long long)(long long)s_low);
-                            atomicAdd(&e.tw_cnts[row + 2u * (size_t)a.n_acc + slot], (unsigned long long)n_low);
-                        }
+                        // (the lower leaflet's row: total - upper, gorder_hip_timewise)
                     }
                 }
             }

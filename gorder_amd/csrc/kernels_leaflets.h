@@ -605,14 +605,10 @@ __global__ __launch_bounds__(64) void k_spec_fixup(FrameArgs a, SpecArgs sa, con
                     atomicAdd(&rep[(size_t)a.n_acc + sm.slot], (unsigned long long)(-acc.s_tot));
                     atomicAdd(&rep[3u * (size_t)a.n_acc + sm.slot], ~0ull);
                 }
-                if (TW) {           // rows [frame][total, upper, lower][slot]: out of the side it was counted under, into the other
-                    const size_t row = (size_t)(tw_row0 + f) * 3u * a.n_acc;
-                    const size_t to = row + (exact == 0u ? 1u : 2u) * (size_t)a.n_acc + sm.slot;
-                    const size_t from = row + (exact == 0u ? 2u : 1u) * (size_t)a.n_acc + sm.slot;
-                    atomicAdd(&tw_sums[to], (unsigned long long)acc.s_tot);
-                    atomicAdd(&tw_cnts[to], 1ull);
-                    atomicAdd(&tw_sums[from], (unsigned long long)(-acc.s_tot));
-                    atomicAdd(&tw_cnts[from], ~0ull);
+                if (TW) {           // rows [frame][total, upper, (lower = total - upper)][slot]: the upper row gains or loses the tick
+                    const size_t up = (size_t)(tw_row0 + f) * 3u * a.n_acc + (size_t)a.n_acc + sm.slot;
+                    atomicAdd(&tw_sums[up], (unsigned long long)(exact == 0u ? acc.s_tot : -acc.s_tot));
+                    atomicAdd(&tw_cnts[up], exact == 0u ? 1ull : ~0ull);
                 }
             }
         }
