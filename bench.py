@@ -47,6 +47,11 @@ def make_system(name):
         return synthetic.aa_membrane(256), "AAOrder 256-lipid all-atom membrane (25088 atoms, 16384 C-H bonds/frame)"
     if name == "aa256-leaflets":
         return synthetic.aa_membrane(256, leaflets=LEAFLETS_GLOBAL), "AAOrder 256 lipids + global leaflets"
+    if name == "aa256-leaflets-maps":
+        from gorder_amd.abi import OrderMap
+        om = OrderMap(enabled=True, plane=0, span_x=(0.0, 9.0), span_y=(0.0, 9.0), bin=(0.1, 0.1))
+        return (synthetic.aa_membrane(256, leaflets=LEAFLETS_GLOBAL, ordermap=om),
+                "AAOrder 256 lipids + global leaflets + 91x91 ordermaps per leaflet")
     if name == "aa256-leaflets-timewise":
         return (synthetic.aa_membrane(256, leaflets=LEAFLETS_GLOBAL, timewise=True),
                 "AAOrder 256 lipids + global leaflets + per-frame rows (error estimation)")
