@@ -956,6 +956,11 @@ template <int CTRL>
 __device__ __forceinline__ uint32_t row_add_u32(uint32_t v) {
     return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
 }
+// the value one lane holds, for every lane (lane index known at compile time: v_readlane, no LDS)
+__device__ __forceinline__ float lane_value(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ double lane_value(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
 // Per row of cells: running sums along the row (the halo cells continue it), so that k_local_flags_rows takes the
 // cells of a row that lie wholly inside a head's cylinder — always one span of consecutive cells — as the difference
 // of two entries:  rowpre[ra (ncs + 1) + j] = sums over the cells 0 .. j-1 of row ra (cos and sin of the normal angle
@@ -988,7 +993,7 @@ __device__ __forceinline__ void local_row_prefix(const uint32_t *__restrict__ cs
     uint32_t qb = 0;
 #pragma unroll
     for (uint32_t i = 0; i < CQ; i++)
-        if ((ncs >> 6) == i) qb = (uint32_t)__shfl((int)cq[i], (int)(ncs & 63u), 64);       // (uniform)
+        if ((ncs >> 6) == i) qb = (uint32_t)__builtin_amdgcn_readlane((int)cq[i], (int)(ncs & 63u));       // (uniform)
     float carry_c = 0.0f, carry_s = 0.0f, carry_q = 0.0f;
     double carry_z = 0.0;
     for (uint32_t base = qa; base < qb || base == qa; base += PIECE) {
@@ -1023,9 +1028,9 @@ __device__ __forceinline__ void local_row_prefix(const uint32_t *__restrict__ cs
             float bc = 0.0f, bs = 0.0f, bq = 0.0f;
             double bz = 0.0;
 #pragma unroll
-            for (int r4 = 0; r4 < 3; r4++) {
-                const float tc = __shfl(ic, 16 * r4 + 15, 64), ts = __shfl(is, 16 * r4 + 15, 64), tq = __shfl(iq, 16 * r4 + 15, 64);
-                const double tz = __shfl(iz, 16 * r4 + 15, 64);
+            for (int r4 = 0; r4 < 3; r4++) {              // (the rows' totals by v_readlane: a __shfl is a trip through the LDS each)
+                const float tc = lane_value(ic, 16 * r4 + 15), ts = lane_value(is, 16 * r4 + 15), tq = lane_value(iq, 16 * r4 + 15);
+                const double tz = lane_value(iz, 16 * r4 + 15);
                 if ((int)(lane >> 4) > r4) { bc += tc; bs += ts; bz += tz; bq += tq; }
             }
             ic += bc; is += bs; iz += bz; iq += bq;                         // inclusive over the 64 lanes
@@ -1033,10 +1038,10 @@ __device__ __forceinline__ void local_row_prefix(const uint32_t *__restrict__ cs
             ps[64u * t + lane] = carry_s + (is - vs);
             pz[64u * t + lane] = carry_z + (iz - vz);
             pq[64u * t + lane] = carry_q + (iq - vq);
-            carry_c += __shfl(ic, 63, 64);
-            carry_s += __shfl(is, 63, 64);
-            carry_z += __shfl(iz, 63, 64);
-            carry_q += __shfl(iq, 63, 64);
+            carry_c += lane_value(ic, 63);
+            carry_s += lane_value(is, 63);
+            carry_z += lane_value(iz, 63);
+            carry_q += lane_value(iq, 63);
         }
         if (lane == 0u) { pc[n_here] = carry_c; ps[n_here] = carry_s; pz[n_here] = carry_z; pq[n_here] = carry_q; }   // behind the piece's last record
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
