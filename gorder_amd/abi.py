@@ -311,7 +311,7 @@ _EXPORTS = [
     "gorder_hip_last_error_message", "gorder_hip_strerror", "gorder_hip_kernel_time", "gorder_hip_kernel_time_group", "gorder_hip_plan",
     "gorder_hip_plan_tables", "gorder_hip_selftest_arithmetic", "gorder_hip_selftest_trig", "gorder_hip_run_trajectory",
     "gorder_hip_comm_unique_id", "gorder_hip_comm_create", "gorder_hip_comm_destroy", "gorder_hip_allreduce",
-    "gorder_hip_reset", "gorder_hip_xtc_decode", "gorder_hip_release_staging", "gorder_hip_speculation_stats",
+    "gorder_hip_reset", "gorder_hip_xtc_decode", "gorder_hip_release_staging", "gorder_hip_speculation_stats", "gorder_hip_local_decide_stats",
 ]
 
 _lib = None
@@ -381,6 +381,7 @@ def load_library() -> C.CDLL:
     lib.gorder_hip_kernel_time_group.argtypes = [vp, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(u64)]
     lib.gorder_hip_plan.argtypes = [vp, C.POINTER(CPlan)]
     lib.gorder_hip_speculation_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
+    lib.gorder_hip_local_decide_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.gorder_hip_plan_tables.argtypes = [C.POINTER(CTables), C.POINTER(CPlan), C.POINTER(i32)]
     lib.gorder_hip_selftest_arithmetic.argtypes = [i32, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
     lib.gorder_hip_selftest_trig.argtypes = [i32, i32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
@@ -722,6 +723,13 @@ class HipEngine:
         out = (C.c_uint64 * 4)()
         self._check(self.lib.gorder_hip_speculation_stats(self._h, out))
         return {"batches": int(out[0]), "moved": int(out[1]), "exact_frames": int(out[2]), "enabled": bool(out[3])}
+
+    def local_decide_stats(self) -> dict:
+        """Local leaflets (gorder_hip_local_decide_stats): submits that ran the bound kernel, submits that paused it, and the
+        last report read back (frames left open, frames seen)."""
+        out = (C.c_uint64 * 4)()
+        self._check(self.lib.gorder_hip_local_decide_stats(self._h, out))
+        return {"submits": int(out[0]), "paused": int(out[1]), "open_frames": int(out[2]), "frames": int(out[3])}
 
     def plan(self) -> dict:
         p = CPlan()

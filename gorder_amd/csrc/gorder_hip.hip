@@ -84,6 +84,17 @@ struct gorder_hip_handle {
     LocalRowPre *d_lrowpre = nullptr;   // per slab frame: prefix sums along the rows of cells (k_local_rowprefix)
     LocalEdge *d_ledge = nullptr;       // the same cells' 16-byte entries for the bound of k_local_flags_rows
     float4 *d_lfinfo = nullptr;     // per slab frame: extrema of the membrane's normal coordinate, finite flag
+    // k_local_decide pays when it decides whole frames; a membrane whose heads it leaves open (one that undulates by more than
+    // the water around it allows) is better off without it: every submit that runs it reports {frames left open, frames}
+    // to pinned memory, and a submit that finds the majority open sends the next kDecidePause submits down the rows kernel
+    // alone.  (Either way the sides are the reference's: the choice is about time only.)
+    static constexpr uint32_t kDecidePause = 16;
+    uint32_t *d_lsummary = nullptr, *h_lsummary = nullptr;
+    hipEvent_t lsummary_written = nullptr;
+    bool lsummary_pending = false;
+    uint32_t decide_pause = 0;
+    uint64_t decide_submits = 0, decide_paused_submits = 0;
+    uint32_t *d_lneed = nullptr;    // [local_slab] heads of each slab frame k_local_decide left to k_local_flags_rows
     uint2 *d_ltodo = nullptr;       // {count}, then the (slab frame, head) pairs left to the general passes
     size_t map_lds_bytes = 0;
     bool map_staged = false;       // the packed map of one slot fits LDS: stage + accumulate instead of one atomic per sample
@@ -1183,6 +1194,14 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
                 HIP_TRY(h, hipMalloc((void **)&h->d_lrowpre, sl * (size_t)kLocalMaxCells1D * (kLocalMaxCells1D + 1u) * sizeof(LocalRowPre)));
                 HIP_TRY(h, hipMalloc((void **)&h->d_ledge, sl * (size_t)kLocalMaxCells1D * (kLocalMaxCells1D + 1u) * sizeof(LocalEdge)));
                 HIP_TRY(h, hipMalloc((void **)&h->d_lfinfo, sl * sizeof(float4)));
+                HIP_TRY(h, hipMalloc((void **)&h->d_lneed, sl * sizeof(uint32_t)));
+                HIP_TRY(h, hipMalloc((void **)&h->d_lsummary, 2 * sizeof(uint32_t)));
+                HIP_TRY(h, hipMemset(h->d_lsummary, 0, 2 * sizeof(uint32_t)));
+                HIP_TRY(h, hipHostMalloc((void **)&h->h_lsummary, 2 * sizeof(uint32_t)));
+                h->h_lsummary[0] = h->h_lsummary[1] = 0u;
+                HIP_TRY(h, hipEventCreateWithFlags(&h->lsummary_written, hipEventDisableTiming));
+                HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_local_decide), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)kDecideLds));
                 HIP_TRY(h, hipMalloc((void **)&h->d_ltodo, (1 + sl * (size_t)(p.n_mol_total ? p.n_mol_total : 1)) * sizeof(uint2)));
             }
         }
@@ -1212,7 +1231,8 @@ void gorder_hip_destroy(gorder_hip_handle *h) {
     (void)hipFree(h->d_own); (void)hipFree(h->d_mom); (void)hipFree(h->d_head_z); (void)hipFree(h->d_own_head_begin); (void)hipFree(h->d_own_heads); (void)hipFree(h->d_spec_center); (void)hipFree(h->d_spec_ok);
     (void)hipFree(h->d_spec_counters); (void)hipFree(h->d_spec_mol_begin); (void)hipFree(h->d_spec_samples);
     if (h->h_spec_counters) (void)hipHostFree(h->h_spec_counters);
-    for (hipEvent_t ev : h->spec_counters_copied) if (ev) (void)hipEventDestroy(ev); (void)hipFree(h->d_lfinfo); (void)hipFree(h->d_ltodo);
+    for (hipEvent_t ev : h->spec_counters_copied) if (ev) (void)hipEventDestroy(ev); (void)hipFree(h->d_lfinfo); (void)hipFree(h->d_ltodo); (void)hipFree(h->d_lneed);
+    (void)hipFree(h->d_lsummary); if (h->h_lsummary) (void)hipHostFree(h->h_lsummary); if (h->lsummary_written) (void)hipEventDestroy(h->lsummary_written);
     (void)hipFree(h->d_dyn_cloud); (void)hipFree(h->d_dyn_heads); (void)hipFree(h->d_dyn_cell_of); (void)hipFree(h->d_dyn_count);
     (void)hipFree(h->d_dyn_rec); (void)hipFree(h->d_dyn_normals); (void)hipFree(h->d_dyn_cov);
     if (!h->acc_external) (void)hipFree(h->d_acc);
@@ -1254,6 +1274,15 @@ int gorder_hip_speculation_stats(gorder_hip_handle *h, uint64_t out[4]) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     spec_poll(h, true);
     out[0] = h->spec_batches; out[1] = h->spec_fixed; out[2] = h->spec_exact_frames; out[3] = h->spec_enabled ? 1 : 0;
+    return GORDER_OK;
+}
+
+int gorder_hip_local_decide_stats(gorder_hip_handle *h, uint64_t out[4]) {
+    if (!h || !out) return GORDER_ERR_INVALID_ARGUMENT;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    out[0] = h->decide_submits; out[1] = h->decide_paused_submits;
+    out[2] = h->h_lsummary ? h->h_lsummary[0] : 0; out[3] = h->h_lsummary ? h->h_lsummary[1] : 0;
     return GORDER_OK;
 }
 
@@ -1356,18 +1385,32 @@ static int run_leaflets(gorder_hip_handle *h, const float *d_xyz, const float *d
         lo.cell_fill = h->d_lcell_fill; lo.err = h->d_err;
         lo.grid = h->d_lgrid;
         lo.halo = h->local_halo ? 1 : 0;
-        lo.prune = env_flag("GORDER_HIP_LOCAL_NO_PRUNE") ? 0 : 1;
+        lo.prune = env_flag("GORDER_HIP_LOCAL_NO_PRUNE") ? 0 : (env_flag("GORDER_HIP_LOCAL_DECIDE_NOTHING") ? 2 : 1);
         lo.rec_stride = (uint32_t)h->local_rec_stride;
         lo.rowpre = h->d_lrowpre;
         lo.edge = h->d_ledge;
         lo.finfo = h->d_lfinfo;
         lo.todo = h->d_ltodo;
+        // the bound first, a lane per head (k_local_decide); the rows kernel then only for the frames with a head left open
+        bool decide = lo.halo && lo.prune && lo.n_mol_total && !env_flag("GORDER_HIP_LOCAL_NO_DECIDE");
+        if (decide) {
+            if (h->lsummary_pending && hipEventQuery(h->lsummary_written) == hipSuccess) {
+                h->lsummary_pending = false;
+                if (2u * h->h_lsummary[0] > h->h_lsummary[1]) h->decide_pause = gorder_hip_handle::kDecidePause;
+            }
+            if (h->decide_pause) { h->decide_pause--; h->decide_paused_submits++; decide = false; }
+            else h->decide_submits++;
+        }
+        lo.need = decide ? h->d_lneed : nullptr;
+        const bool report = decide && !h->lsummary_pending;      // (one report in flight)
+        lo.summary = report ? h->d_lsummary : nullptr;
         for (size_t done = 0; done < aframes.size(); done += h->local_slab) {
             const uint32_t ns = (uint32_t)std::min<size_t>(aframes.size() - done, h->local_slab);
             lo.aframes = h->d_aframes + done;
             lo.n_slab = ns;
             lo.row0 = row0 + (uint32_t)done;
             lo.write_dist_frame = (done + ns == aframes.size()) ? (int)ns - 1 : -1;
+            lo.summary_host = report && done + ns == aframes.size() ? h->h_lsummary : nullptr;
             if (lf.n_membrane > kLocalBuildMax || env_flag("GORDER_HIP_LOCAL_THREE_KERNELS"))
                 HIP_TRY(h, hipMemsetAsync(h->d_lcell_fill, 0, ns * ncell * sizeof(uint32_t), h->stream));
             const int cst = launch_cell_list(h, lo, ns, lf.n_membrane, h->d_lcell_count, ns * (ncell + 1) * sizeof(uint32_t));
@@ -1376,8 +1419,13 @@ static int run_leaflets(gorder_hip_handle *h, const float *d_xyz, const float *d
                 TIMING_MARK(h, "k_local_rowprefix");
                 hipLaunchKernelGGL(k_local_rowprefix, dim3(kLocalMaxCells1D / 4u, ns), dim3(256), 0, h->stream, lo);
                 lo.rows_groups = (lo.n_mol_total + 15u) / 16u;
+                if (lo.need) {
+                    TIMING_MARK(h, "k_local_decide");
+                    hipLaunchKernelGGL(k_local_decide, dim3(ns), dim3(1024), kDecideLds, h->stream, lo);
+                }
                 TIMING_MARK(h, "k_local_flags_rows");
-                hipLaunchKernelGGL(k_local_flags_rows, dim3(lo.rows_groups * ((ns + 7u) / 8u * 8u)), dim3(256), 0, h->stream, lo);
+                if (lo.need) hipLaunchKernelGGL(k_local_flags_rows_open, dim3(lo.rows_groups * 8u * kRowsSlots), dim3(256), 0, h->stream, lo);
+                else hipLaunchKernelGGL(k_local_flags_rows, dim3(lo.rows_groups * ((ns + 7u) / 8u * 8u)), dim3(256), 0, h->stream, lo);
                 // the heads the rows left over (normally none: the grid finds an empty list and leaves)
                 TIMING_MARK(h, "k_local_flags_todo");
                 hipLaunchKernelGGL(k_local_flags_todo, dim3(512), dim3(256), 0, h->stream, lo);
@@ -1385,6 +1433,10 @@ static int run_leaflets(gorder_hip_handle *h, const float *d_xyz, const float *d
                 TIMING_MARK(h, "k_local_flags");
                 hipLaunchKernelGGL(k_local_flags, dim3((lo.n_mol_total + 3) / 4, ns), dim3(256), 0, h->stream, lo);
             }
+        }
+        if (report && !aframes.empty()) {
+            HIP_TRY(h, hipEventRecord(h->lsummary_written, h->stream));
+            h->lsummary_pending = true;
         }
     }
     HIP_TRY(h, hipGetLastError());

@@ -739,6 +739,10 @@ struct LocalArgs {
     float4 *finfo;              // [n_slab] (min, max of the membrane's normal coordinate, 1 if every coordinate is finite, -)
     uint2 *todo;                // [1 + n_slab * n_mol_total] with agg: {count, -} then the (slab frame, head) pairs
                                 // k_local_flags_rows leaves to k_local_flags_todo
+    uint32_t *summary;          // {frames k_local_decide left open, frames it saw} summed over the slabs of a submit (k_local_flags_todo), or null
+    uint32_t *summary_host;     // the last slab of a submit: where (pinned host memory) the two sums go, or null
+    uint32_t *need;             // [n_slab] heads of the frame k_local_decide left open (zeroed by k_local_rowprefix); k_local_flags_rows
+                                // then works on the frames with a count only.  null: no k_local_decide, every frame
     uint32_t *err;
 };
 
@@ -1096,6 +1100,7 @@ __global__ __launch_bounds__(256) void k_local_rowprefix(LocalArgs a) {
     const uint4 g = a.grid[s];
     const uint32_t nca = g.x, ncs = local_row_stride(a, g.y, g.w);
     if (blockIdx.x == 0 && s == 0 && threadIdx.x == 0) a.todo[0] = make_uint2(0u, 0u);        // this slab's list starts empty
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.need) a.need[s] = 0u;                          // nothing of this frame left open yet
     if (ra >= nca) return;                                                                       // (uniform per wave; no workgroup barrier below)
     const bool merge = reinterpret_cast<const uint4 *>(a.finfo)[s].w != 2u;                     // 2: k_local_build made the frame's record
     const uint32_t *cstart = a.cell_count + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u);
@@ -1644,18 +1649,11 @@ __device__ __forceinline__ float local_atan2_fast(float y, float x) {
 #endif
 constexpr uint32_t kRowFlight = GORDER_ROW_FLIGHT;            // iterations of the ring loop whose records are fetched together
 constexpr uint32_t kRowRing = 96;              // ring pieces (<= 8 records each) a head may list (typically ~45)
-__global__ __launch_bounds__(256) void k_local_flags_rows(LocalArgs a) {
-    __shared__ uint2 l_ring[16][kRowRing + 2u * kRowFlight];      // (the loop below reads past a list's end, and masks)
+typedef uint2 LocalRingLists[kRowRing + 2u * kRowFlight];          // (the ring loop reads past a list's end, and masks)
+// the 16 heads of workgroup `bx` of slab frame `s`
+__device__ __forceinline__ void local_rows_group(const LocalArgs &a, uint32_t s, uint32_t bx, LocalRingLists *l_ring) {
     const uint32_t lane = threadIdx.x & 63u, row = lane >> 4, sub = lane & 15u;
     const uint32_t wave = threadIdx.x >> 6;
-    // Workgroups go to the 8 XCDs round-robin in launch order, and every XCD has an L2 of its own: the heads of ONE frame
-    // share that frame's records (a head reads ~330 ring records, neighbouring heads mostly the same ones), so all the
-    // workgroups of a frame are given to one XCD — launch index L -> XCD L mod 8 takes frames (L / 8) / groups * 8 + L mod 8 —
-    // and a frame's records come from HBM once instead of once per XCD (measured: 2.1 GB -> see DESIGN, K6).
-    const uint32_t n_groups = a.rows_groups, linear = blockIdx.x;
-    const uint32_t xcd = linear & 7u, k = linear >> 3;
-    const uint32_t s = (k / n_groups) * 8u + xcd, bx = k - (k / n_groups) * n_groups;
-    if (s >= a.n_slab) return;                                              // (the slab's frame count rounded up to 8)
     const uint32_t m_raw = (bx * 4u + wave) * 4u + row;
     if ((bx * 4u + wave) * 4u >= a.n_mol_total) return;                   // the whole wave is past the last head
     const bool head_ok = m_raw < a.n_mol_total;
@@ -1710,7 +1708,7 @@ __global__ __launch_bounds__(256) void k_local_flags_rows(LocalArgs a) {
     const float z_mid = 0.5f * Ln;
     // (a frame whose atoms span more than three quarters of the box along the normal cannot pass condition (i) below with a
     // ring of the usual size: its heads do not try — a shortcut about speed, not about correctness)
-    const bool try_prune = a.prune != 0 && z_max - z_min < 0.75f * Ln;       // (uniform)
+    const bool try_prune = a.prune == 1 && z_max - z_min < 0.75f * Ln;       // (uniform; prune == 2: see k_local_decide)
     uint32_t c_n = 0, r_n = 0, j_lo = 0, j_hi = 0, row_e0 = 0;
     float c_z = 0.0f, r_z = 0.0f, r_q = 0.0f, c_c = 0.0f, c_s = 0.0f;
     bool span_ok = true;
@@ -1965,9 +1963,219 @@ __global__ __launch_bounds__(256) void k_local_flags_rows(LocalArgs a) {
         a.todo[1u + at] = make_uint2(s, m);
     }
 }
+// Workgroups go to the 8 XCDs round-robin in launch order, and every XCD has an L2 of its own: the heads of ONE frame
+// share that frame's records (a head reads ~330 ring records, neighbouring heads mostly the same ones), so all the
+// workgroups of a frame are given to one XCD — launch index L -> XCD L mod 8 takes frames (L / 8) / groups * 8 + L mod 8 —
+// and a frame's records come from HBM once instead of once per XCD (measured: 2.1 GB -> see DESIGN, K6).
+// k_local_flags_rows: grid = rows_groups * (n_slab rounded up to 8), a workgroup per (frame, 16 heads).
+// k_local_flags_rows_open, behind k_local_decide: grid = rows_groups * 8 * kRowsSlots, and the workgroups of XCD x walk the frames x, x + 8, ...
+// that have a head left open (need[s] != 0) — slot j of kRowsSlots takes every kRowsSlots-th of them —: none, normally, and
+// the launch costs what 1 536 workgroups cost that read one word each (a workgroup per frame and 16 heads that leaves at
+// once: 40 us per 512 frames; 6 144 workgroups: 17 us); with every frame open a workgroup makes 64 trips, all of the chip's.
+constexpr uint32_t kRowsSlots = 1;
+__global__ __launch_bounds__(256) void k_local_flags_rows(LocalArgs a) {
+    __shared__ LocalRingLists l_ring[16];
+    const uint32_t n_groups = a.rows_groups, linear = blockIdx.x;
+    const uint32_t xcd = linear & 7u, k = linear >> 3;
+    const uint32_t s = (k / n_groups) * 8u + xcd, bx = k - (k / n_groups) * n_groups;
+    if (s < a.n_slab) local_rows_group(a, s, bx, l_ring);                   // (the slab's frame count rounded up to 8)
+}
+__global__ __launch_bounds__(256) void k_local_flags_rows_open(LocalArgs a) {
+    __shared__ LocalRingLists l_ring[16];
+    const uint32_t n_groups = a.rows_groups, linear = blockIdx.x;
+    const uint32_t xcd = linear & 7u, k = linear >> 3;
+    const uint32_t slot = k / n_groups, bx = k - slot * n_groups, lane = threadIdx.x & 63u;
+    uint32_t seen = 0;
+    for (uint32_t base = xcd; base < a.n_slab; base += 8u * 64u) {          // 64 of this XCD's frames at a time, a lane each
+        const uint32_t sl = base + 8u * lane;
+        uint64_t open = __ballot(sl < a.n_slab && a.need[sl] != 0u);
+        while (open != 0ull) {                                              // (uniform)
+            const uint32_t bit = (uint32_t)__builtin_ctzll(open);
+            open &= open - 1ull;
+            if (seen++ % kRowsSlots == slot) local_rows_group(a, (uint32_t)__builtin_amdgcn_readfirstlane((int)(base + 8u * bit)), bx, l_ring);
+        }
+    }
+}
+
+// The bound of k_local_flags_rows ("a head its ring cannot change") on its own, a LANE per head, the frame's table of cell
+// edges in the LDS.  In the rows kernel a head is the business of 16 lanes — one per row of cells, which is what its ring
+// loop wants —, and everything that is per head (its cell, the centre's estimate, the decision: two thirds of the ~390
+// instructions a wave spends on four heads) is done 16 times over: 152 M instructions per 512 frames, all the SIMDs' cycles
+// (PMC).  A lane that walks the 15 rows of its own head spends ~2 000 instructions on 64 heads instead of 16 x 390 — and
+// then waits for the loads: a head's 60 entries are 60 addresses of their own, a wave's load instruction 64 cache lines, and
+// the texture path looks up one line a cycle (1.57 M such instructions per 512 frames = 164 us whichever way the lanes are
+// dealt: the lane-per-head kernel took 192 us reading the table from memory, the rows kernel 238).  The table of ONE frame,
+// though, is 84 x 99 entries of 16 bytes for the 3 072-lipid membrane — 133 KB, and a CU has 160 KB of LDS: a workgroup per
+// frame copies it in once, coalesced, and the heads' lookups are LDS reads.
+// A frame this kernel decides completely costs k_local_flags_rows_open nothing; a frame with a head left open
+// (need[s] != 0) is done there as before, every head of it (the sides agree: both are the reference's).  A frame whose
+// table does not fit is read from memory.
+// block = 1024 threads, a lane per head, as many trips as the frame has heads; grid = n_slab; dynamic LDS = kDecideLds.
+constexpr uint32_t kDecideEntries = 10000;                                  // table entries the LDS copy has room for
+constexpr uint32_t kDecideLds = kDecideEntries * (uint32_t)sizeof(LocalEdge);
+struct DecideFrame {
+    uint32_t nca, ncb, ka, kb, ncs, n_rows;
+    int da, db, dn;
+    float La, Lb, Ln, z_min, z_max;
+};
+// one head; `edge` = the frame's table (LDS or memory).  true: decided, `upper_side` = its flag before the flip
+template <typename EdgePtr>
+__device__ __forceinline__ bool local_decide_head(const LocalArgs &a, const DecideFrame &F, uint32_t f, uint32_t m, EdgePtr edge,
+                                                  bool &centre_above, int &bad) {
+    const uint32_t nca = F.nca, ncb = F.ncb, ka = F.ka, kb = F.kb, ncs = F.ncs, n_rows = F.n_rows;
+    const float La = F.La, Lb = F.Lb, Ln = F.Ln;
+    const float halfn = Ln / 2.0f, z_mid = 0.5f * Ln;
+    const float thr = a.radius_thr;
+    // ---- the head (as in k_local_flags_rows)
+    const float *hp = a.xyz + ((size_t)f * a.n_atoms + a.heads[m]) * 3u;
+    const float ha_pos = hp[F.da], hb_pos = hp[F.db], hn_pos = hp[F.dn];
+    const float wa = ha_pos < 0.0f ? ha_pos + La : (ha_pos > La ? ha_pos - La : ha_pos);
+    const float wb = hb_pos < 0.0f ? hb_pos + Lb : (hb_pos > Lb ? hb_pos - Lb : hb_pos);
+    const float ca = La * __builtin_amdgcn_rcpf((float)nca), cb = Lb * __builtin_amdgcn_rcpf((float)ncb);
+    const uint32_t ha = (uint32_t)fminf(fmaxf(floorf(wa * __builtin_amdgcn_rcpf(ca)), 0.0f), (float)(nca - 1u));
+    const uint32_t hb = (uint32_t)fminf(fmaxf(floorf(wb * __builtin_amdgcn_rcpf(cb)), 0.0f), (float)(ncb - 1u));
+    const float fa = wa - (float)ha * ca, fb = wb - (float)hb * cb;
+    uint32_t a0 = ha + nca - ka, b0 = hb + ncb - kb;
+    a0 -= a0 >= nca ? nca : 0u;
+    b0 -= b0 >= ncb ? ncb : 0u;
+    const float ulo_g = F.z_min - hn_pos, uhi_g = F.z_max - hn_pos;
+    const bool redo = !(fa >= -1e-4f * ca && fa <= ca * 1.0001f && fb >= -1e-4f * cb && fb <= cb * 1.0001f) ||
+                      !(wa >= 0.0f && wa <= La && wb >= 0.0f && wb <= Lb);
+    // ---- the rows of cells around the head, four at a time
+    const float r_in = thr * (1.0f - 4e-4f), r_out = thr * (1.0f + 4e-4f);
+    const float inv_cb = __builtin_amdgcn_rcpf(cb), t0 = fb * inv_cb + (float)kb, two_kb = (float)(2u * kb);
+    uint32_t c_n = 0, r_n = 0;
+    float c_z = 0.0f, r_z = 0.0f, r_q = 0.0f, c_c = 0.0f, c_s = 0.0f;
+    bool spans_ok = true;
+    for (uint32_t sub0 = 0; sub0 < n_rows; sub0 += 4u) {                   // (uniform)
+        LocalEdge e_a[4], e_d[4], e_lo[4], e_hi[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; u++) {
+            const uint32_t sub = sub0 + u;
+            const float a_lo = ((float)sub - (float)ka) * ca - fa, a_hi = a_lo + ca;      // the row's strip relative to the head
+            const float a_far = fmaxf(fabsf(a_lo), fabsf(a_hi));
+            const float a_near = (a_lo <= 0.0f && a_hi >= 0.0f) ? 0.0f : fminf(fabsf(a_lo), fabsf(a_hi));
+            const float w_out2 = r_out - a_near * a_near, w_in2 = r_in - a_far * a_far;
+            const bool touch = sub < n_rows && w_out2 > 0.0f;
+            // (the spans as in k_local_flags_rows; a row the circle does not touch reads entry 0 four times: empty differences)
+            const float w_out = __builtin_amdgcn_sqrtf(fmaxf(w_out2, 0.0f)) * inv_cb;
+            const float jo_lo_f = floorf(t0 - w_out - 1e-3f), jo_hi_f = floorf(t0 + w_out + 1e-3f);
+            const uint32_t jo_lo = (uint32_t)fminf(fmaxf(jo_lo_f, 0.0f), two_kb);
+            const uint32_t jo_hi = (uint32_t)fminf(fmaxf(jo_hi_f, 0.0f), two_kb);
+            const float w_in = __builtin_amdgcn_sqrtf(fmaxf(w_in2, 0.0f)) * inv_cb;
+            const float lo_f = ceilf(t0 - w_in + 1e-3f), hi_f = floorf(t0 + w_in - 1e-3f) - 1.0f;
+            const bool inner = w_in2 > 0.0f && hi_f >= lo_f;
+            const uint32_t ji_lo = (uint32_t)fmaxf(lo_f, (float)jo_lo), ji_hi = (uint32_t)fmaxf(fminf(hi_f, (float)jo_hi), 0.0f);
+            const bool has_inner = inner && ji_lo <= ji_hi;
+            const uint32_t j_d = jo_hi + 1u;
+            const uint32_t j_lo = has_inner ? ji_lo : j_d, j_hi = has_inner ? ji_hi + 1u : j_d;
+            uint32_t ra = a0 + (sub < n_rows ? sub : 0u);
+            ra -= ra >= nca ? nca : 0u;
+            EdgePtr row_edge = edge + (ra * (ncs + 1u) + b0);
+            e_a[u] = row_edge[touch ? jo_lo : 0u];
+            e_d[u] = row_edge[touch ? j_d : 0u];
+            e_lo[u] = row_edge[touch ? j_lo : 0u];
+            e_hi[u] = row_edge[touch ? j_hi : 0u];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; u++) {
+            const uint32_t n_c = e_d[u].q - e_a[u].q;
+            const float z_c = e_d[u].zm - e_a[u].zm;
+            c_n += n_c;
+            c_z += z_c;
+            r_n += n_c - (e_hi[u].q - e_lo[u].q);
+            r_z += z_c - (e_hi[u].zm - e_lo[u].zm);
+            r_q += (e_d[u].sq - e_a[u].sq) - (e_hi[u].sq - e_lo[u].sq);
+            float dc, ds;
+            local_edge_trig_diff(e_d[u].cs, e_a[u].cs, dc, ds);
+            c_c += dc;
+            c_s += ds;
+            spans_ok &= n_c < kEdgeSpanMax;
+        }
+    }
+    // ---- the decision (k_local_flags_rows: S in [T - A / 2 -+ sqrt(N B) / 2], conditions (i) and (ii))
+    const float hm = hn_pos - z_mid, fn = (float)c_n, fr = (float)r_n, fi = (float)(c_n - r_n);
+    const float T = c_z - fn * hm, A = r_z - fr * hm;
+    const float B = __builtin_fmaxf((r_q - 2.0f * hm * r_z) + fr * hm * hm, 0.0f) * 1.02f + 1e-3f * fr;
+    const float mid = T - 0.5f * A, rad = 0.5005f * __builtin_amdgcn_sqrtf(fr * B);
+    const float slack = 0.1f + fn * (1e-3f + 1e-6f * fn * Ln);
+    const float r_c = __builtin_amdgcn_sqrtf(c_c * c_c + c_s * c_s);
+    const float est_c = (local_atan2_fast(-c_s, -c_c) + 3.1415927f) * (Ln * 0.15915494f);
+    const float shift_c = gm_min_image(hn_pos - est_c, Ln, bad);
+    const float xr = (fr + 1.0f) * __builtin_amdgcn_rcpf(r_c);              // asin(x) <= x + (pi / 2 - 1) x^3 on [0, 1]
+    const float emargin = 1e-4f * Ln + (xr + 0.5708f * xr * xr * xr) * (0.15916f * Ln);
+    const bool same_image = fr + 1.0f < r_c && ulo_g + shift_c > -halfn + emargin && uhi_g + shift_c < halfn - emargin;
+    const bool head_near = __builtin_fabsf(mid) + rad < (halfn - 1e-3f * Ln) * fi;
+    centre_above = mid > 0.0f;         // S > 0: the centre lies above the head, d = z_head - centre < 0
+    // (prune == 2, GORDER_HIP_LOCAL_DECIDE_NOTHING: a measuring aid — what a membrane costs whose heads the bound cannot decide)
+    return !redo && spans_ok && c_n > r_n && same_image && head_near && a.prune != 2 &&
+           __builtin_fabsf(mid) > rad + slack;                              // (NaN anywhere: not decided)
+}
+template <typename EdgePtr>
+__device__ __forceinline__ void local_decide_frame(const LocalArgs &a, const DecideFrame &F, uint32_t s, uint32_t f, EdgePtr edge) {
+    int bad = 0;
+    uint32_t n_open = 0;
+    for (uint32_t m0 = threadIdx.x & ~63u; m0 < a.n_mol_total; m0 += 1024u) {         // (uniform per wave)
+        const uint32_t m_raw = m0 + (threadIdx.x & 63u);
+        const bool head_ok = m_raw < a.n_mol_total;
+        const uint32_t m = head_ok ? m_raw : a.n_mol_total - 1u;          // idle lanes shadow the last head, write nothing
+        bool centre_above;
+        const bool decided = local_decide_head(a, F, f, m, edge, centre_above, bad);
+        if (decided && head_ok)
+            a.aflags[(size_t)(a.row0 + s) * a.n_mol_total + m] = (uint8_t)((centre_above ? 1 : 0) ^ (a.flip ? 1 : 0));
+        n_open += (uint32_t)__popcll(__ballot(!decided && head_ok));
+    }
+    if (n_open != 0u && (threadIdx.x & 63u) == 0u) atomicAdd(&a.need[s], n_open);
+    if (bad) raise_box_range(a.err, f);
+}
+__global__ __launch_bounds__(1024) void k_local_decide(LocalArgs a) {
+    extern __shared__ LocalEdge l_edge[];
+    const uint32_t s = blockIdx.x;
+    const uint32_t f = a.aframes ? a.aframes[s] : a.frame0 + s;
+    float box[3];
+    frame_box(a, f, box);
+    const uint4 g = a.grid[s];
+    const uint4 fk = reinterpret_cast<const uint4 *>(a.finfo)[s];
+    DecideFrame F;
+    F.nca = g.x; F.ncb = g.y; F.ka = g.z; F.kb = g.w; F.ncs = g.y + 2u * g.w; F.n_rows = 2u * g.z + 1u;
+    F.da = (int)((a.dim + 1u) % 3u); F.db = (int)((a.dim + 2u) % 3u); F.dn = (int)a.dim;
+    F.La = box[F.da]; F.Lb = box[F.db]; F.Ln = box[F.dn];
+    F.z_min = local_key_float(fk.x); F.z_max = local_key_float(fk.y);
+    // (uniform) frames the bound does not apply to — the conditions of k_local_flags_rows — and the frame whose distances are wanted
+    const bool fail = !(F.ka >= 1u && F.kb >= 1u && F.n_rows <= 16u && fk.z == 0u && fk.x <= fk.y);
+    if (fail || !(F.z_max - F.z_min < 0.75f * F.Ln) || (int)s == a.write_dist_frame) {
+        if (threadIdx.x == 0u) atomicAdd(&a.need[s], 1u);
+        return;
+    }
+    const LocalEdge *edge = a.edge + (size_t)s * (kLocalMaxCells1D * (kLocalMaxCells1D + 1u));
+    const uint32_t n_entries = F.nca * (F.ncs + 1u);
+    if (n_entries <= kDecideEntries) {                                      // (uniform)
+        const uint4 *src = reinterpret_cast<const uint4 *>(edge);
+        uint4 *dst = reinterpret_cast<uint4 *>(l_edge);
+        for (uint32_t i = threadIdx.x; i < n_entries; i += 1024u) dst[i] = src[i];
+        __syncthreads();
+        local_decide_frame<const LocalEdge *>(a, F, s, f, l_edge);
+    } else {
+        local_decide_frame<const LocalEdge *>(a, F, s, f, edge);
+    }
+}
 
 // The general passes for the heads k_local_flags_rows listed; one wave per head, a fixed grid walks the list.
 __global__ __launch_bounds__(256) void k_local_flags_todo(LocalArgs a) {
+    // how k_local_decide fared, for the host to choose the next submit's kernels by (see run_leaflets)
+    if (a.need && a.summary && blockIdx.x == 0u && threadIdx.x < 64u) {
+        uint32_t c = 0;
+        for (uint32_t s = threadIdx.x; s < a.n_slab; s += 64u) c += a.need[s] != 0u ? 1u : 0u;
+        c = wave_total_u32(c);
+        if (threadIdx.x == 0u) {
+            const uint32_t open = atomicAdd(&a.summary[0], c) + c, seen = atomicAdd(&a.summary[1], a.n_slab) + a.n_slab;
+            if (a.summary_host) {
+                a.summary_host[0] = open;
+                a.summary_host[1] = seen;
+                a.summary[0] = a.summary[1] = 0u;
+            }
+        }
+    }
     const uint32_t n = a.todo[0].x;
     for (uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6); i < n; i += gridDim.x * 4u) {
         const uint2 e = a.todo[1u + i];

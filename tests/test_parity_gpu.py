@@ -920,3 +920,51 @@ def test_local_leaflets_with_spans_too_long_for_the_16_bit_sums(built, monkeypat
     monkeypatch.delenv("GORDER_HIP_LOCAL_NO_PRUNE")
     _sums_equal(got, exact)
     assert_sums_given_device_flags(system.tables, xyz, system.box9(n), got, max_flag_diffs=8)
+
+
+# ---- k_local_decide: the bound on its own, a lane per head, before the rows kernel (round 4) ----
+def _submit_in_batches(system, xyz, box, batches):
+    torch = torch_cuda()
+    eng = HipEngine(system.tables)
+    eng.use_torch_stream()
+    edges = np.linspace(0, xyz.shape[0], batches + 1).astype(int)
+    keep = []
+    for a, b in zip(edges[:-1], edges[1:]):
+        dx, db = torch.from_numpy(xyz[a:b]).cuda(), torch.from_numpy(box[a:b]).cuda()
+        keep += [dx, db]
+        eng.submit_device(dx, db, np.arange(a, b))
+        eng.synchronize()                   # (the report of a submit is read at the next one if it has arrived)
+    return eng, eng.finish()
+
+
+def test_local_decide_runs_every_submit_on_a_flat_membrane(built):
+    """Every frame but a submit's last (whose distances are wanted) is decided by k_local_decide; it keeps running."""
+    system = synthetic.cg_membrane(900, leaflets=LEAFLETS_LOCAL, radius=2.5, n_types=2)
+    n = 24
+    xyz = system.frames(n, seed=71)
+    eng, got = _submit_in_batches(system, xyz, system.box9(n), 4)
+    st = eng.local_decide_stats()
+    assert st["submits"] == 4 and st["paused"] == 0
+    assert st["frames"] == 6 and st["open_frames"] == 1
+    _, want = run_oracle(system, xyz, system.box9(n))
+    _sums_equal(got, want)
+
+
+def test_local_decide_pauses_when_it_leaves_the_frames_open(built, monkeypatch):
+    """GORDER_HIP_LOCAL_DECIDE_NOTHING=1 makes the kernel leave every head open — what a strongly undulating membrane does —:
+    the first report sends the following submits down the rows kernel alone, and the sums stay the oracle's throughout."""
+    system = synthetic.cg_membrane(700, leaflets=LEAFLETS_LOCAL, radius=2.5, n_types=2)
+    n = 20
+    xyz = system.frames(n, seed=73)
+    monkeypatch.setenv("GORDER_HIP_LOCAL_DECIDE_NOTHING", "1")
+    eng, got = _submit_in_batches(system, xyz, system.box9(n), 5)
+    monkeypatch.delenv("GORDER_HIP_LOCAL_DECIDE_NOTHING")
+    st = eng.local_decide_stats()
+    assert st["submits"] == 1 and st["paused"] == 4
+    assert st["open_frames"] == st["frames"] == 4
+    _, want = run_oracle(system, xyz, system.box9(n))
+    _sums_equal(got, want)
+    monkeypatch.setenv("GORDER_HIP_LOCAL_NO_DECIDE", "1")
+    eng2, got2 = _submit_in_batches(system, xyz, system.box9(n), 5)
+    assert eng2.local_decide_stats()["submits"] == 0
+    _sums_equal(got, got2)
