@@ -94,7 +94,7 @@ struct gorder_hip_handle {
     bool lsummary_pending = false;
     uint32_t decide_pause = 0;
     uint64_t decide_submits = 0, decide_paused_submits = 0;
-    uint32_t *d_lneed = nullptr;    // [local_slab] heads of each slab frame k_local_decide left to k_local_flags_rows
+    uint32_t *d_lneed = nullptr;    // [local_slab + 1] heads of each slab frame k_local_decide left to k_local_flags_rows; any of the slab
     uint2 *d_ltodo = nullptr;       // {count}, then the (slab frame, head) pairs left to the general passes
     size_t map_lds_bytes = 0;
     bool map_staged = false;       // the packed map of one slot fits LDS: stage + accumulate instead of one atomic per sample
@@ -1194,7 +1194,7 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
                 HIP_TRY(h, hipMalloc((void **)&h->d_lrowpre, sl * (size_t)kLocalMaxCells1D * (kLocalMaxCells1D + 1u) * sizeof(LocalRowPre)));
                 HIP_TRY(h, hipMalloc((void **)&h->d_ledge, sl * (size_t)kLocalMaxCells1D * (kLocalMaxCells1D + 1u) * sizeof(LocalEdge)));
                 HIP_TRY(h, hipMalloc((void **)&h->d_lfinfo, sl * sizeof(float4)));
-                HIP_TRY(h, hipMalloc((void **)&h->d_lneed, sl * sizeof(uint32_t)));
+                HIP_TRY(h, hipMalloc((void **)&h->d_lneed, (sl + 1) * sizeof(uint32_t)));
                 HIP_TRY(h, hipMalloc((void **)&h->d_lsummary, 2 * sizeof(uint32_t)));
                 HIP_TRY(h, hipMemset(h->d_lsummary, 0, 2 * sizeof(uint32_t)));
                 HIP_TRY(h, hipHostMalloc((void **)&h->h_lsummary, 2 * sizeof(uint32_t)));

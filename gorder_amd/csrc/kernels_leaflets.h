@@ -741,7 +741,7 @@ struct LocalArgs {
                                 // k_local_flags_rows leaves to k_local_flags_todo
     uint32_t *summary;          // {frames k_local_decide left open, frames it saw} summed over the slabs of a submit (k_local_flags_todo), or null
     uint32_t *summary_host;     // the last slab of a submit: where (pinned host memory) the two sums go, or null
-    uint32_t *need;             // [n_slab] heads of the frame k_local_decide left open (zeroed by k_local_rowprefix); k_local_flags_rows
+    uint32_t *need;             // [n_slab + 1] heads of the frame k_local_decide left open (zeroed by k_local_rowprefix; the last word: any of the slab); k_local_flags_rows
                                 // then works on the frames with a count only.  null: no k_local_decide, every frame
     uint32_t *err;
 };
@@ -1100,7 +1100,10 @@ __global__ __launch_bounds__(256) void k_local_rowprefix(LocalArgs a) {
     const uint4 g = a.grid[s];
     const uint32_t nca = g.x, ncs = local_row_stride(a, g.y, g.w);
     if (blockIdx.x == 0 && s == 0 && threadIdx.x == 0) a.todo[0] = make_uint2(0u, 0u);        // this slab's list starts empty
-    if (blockIdx.x == 0 && threadIdx.x == 0 && a.need) a.need[s] = 0u;                          // nothing of this frame left open yet
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.need) {                                        // nothing of this frame left open yet
+        a.need[s] = 0u;
+        if (s == 0) a.need[a.n_slab] = 0u;                                                      // (nor of the slab: the word behind the frames')
+    }
     if (ra >= nca) return;                                                                       // (uniform per wave; no workgroup barrier below)
     const bool merge = reinterpret_cast<const uint4 *>(a.finfo)[s].w != 2u;                     // 2: k_local_build made the frame's record
     const uint32_t *cstart = a.cell_count + (size_t)s * (kLocalMaxCells1D * kLocalMaxCells1D + 1u);
@@ -1984,6 +1987,7 @@ __global__ __launch_bounds__(256) void k_local_flags_rows_open(LocalArgs a) {
     __shared__ LocalRingLists l_ring[16];
     const uint32_t n_groups = a.rows_groups, linear = blockIdx.x;
     const uint32_t xcd = linear & 7u, k = linear >> 3;
+    if (a.need[a.n_slab] == 0u) return;                                     // no frame of the slab has a head left open (one scalar load)
     const uint32_t slot = k / n_groups, bx = k - slot * n_groups, lane = threadIdx.x & 63u;
     uint32_t seen = 0;
     for (uint32_t base = xcd; base < a.n_slab; base += 8u * 64u) {          // 64 of this XCD's frames at a time, a lane each
@@ -2125,7 +2129,7 @@ __device__ __forceinline__ void local_decide_frame(const LocalArgs &a, const Dec
             a.aflags[(size_t)(a.row0 + s) * a.n_mol_total + m] = (uint8_t)((centre_above ? 1 : 0) ^ (a.flip ? 1 : 0));
         n_open += (uint32_t)__popcll(__ballot(!decided && head_ok));
     }
-    if (n_open != 0u && (threadIdx.x & 63u) == 0u) atomicAdd(&a.need[s], n_open);
+    if (n_open != 0u && (threadIdx.x & 63u) == 0u) { atomicAdd(&a.need[s], n_open); a.need[a.n_slab] = 1u; }
     if (bad) raise_box_range(a.err, f);
 }
 __global__ __launch_bounds__(1024) void k_local_decide(LocalArgs a) {
@@ -2144,7 +2148,7 @@ __global__ __launch_bounds__(1024) void k_local_decide(LocalArgs a) {
     // (uniform) frames the bound does not apply to — the conditions of k_local_flags_rows — and the frame whose distances are wanted
     const bool fail = !(F.ka >= 1u && F.kb >= 1u && F.n_rows <= 16u && fk.z == 0u && fk.x <= fk.y);
     if (fail || !(F.z_max - F.z_min < 0.75f * F.Ln) || (int)s == a.write_dist_frame) {
-        if (threadIdx.x == 0u) atomicAdd(&a.need[s], 1u);
+        if (threadIdx.x == 0u) { atomicAdd(&a.need[s], 1u); a.need[a.n_slab] = 1u; }
         return;
     }
     const LocalEdge *edge = a.edge + (size_t)s * (kLocalMaxCells1D * (kLocalMaxCells1D + 1u));
