@@ -985,7 +985,6 @@ __device__ __forceinline__ void local_row_prefix(const uint32_t *__restrict__ cs
                                                  uint32_t ncs, float inv_Ln,
                                                  float z_mid, float *pc, float *ps, double *pz, float *pq, float &zlo, float &zhi,
                                                  uint32_t &nf) {
-    constexpr uint32_t T = PIECE / 64u;
     const uint32_t lane = threadIdx.x & 63u;
     // the row's cell starts first, all of them at once (cell j = lane + 64 i; entry ncs = the end of the row): the record
     // loads below then depend on ONE round trip, and the cells' read-out at the end of a piece on none
@@ -1000,53 +999,68 @@ __device__ __forceinline__ void local_row_prefix(const uint32_t *__restrict__ cs
         if ((ncs >> 6) == i) qb = (uint32_t)__builtin_amdgcn_readlane((int)cq[i], (int)(ncs & 63u));       // (uniform)
     float carry_c = 0.0f, carry_s = 0.0f, carry_q = 0.0f;
     double carry_z = 0.0;
+    static_assert(PIECE == 256u, "a lane takes four consecutive records of a piece");
     for (uint32_t base = qa; base < qb || base == qa; base += PIECE) {
         const uint32_t n_here = min(PIECE, qb - base);
-        LocalRec r[T];
+        // FOUR CONSECUTIVE records per lane (the wave's four loads walk the same cache lines): the running sums inside a
+        // lane are three adds per quantity, and the scan over the 64 lanes — row shifts, the rows' totals by v_readlane —
+        // runs once per piece on the lanes' totals instead of once per 64 records (the scan was 60 % of this kernel's
+        // instructions: 128 -> see DESIGN K6)
+        LocalRec r[4];
 #pragma unroll
-        for (uint32_t t = 0; t < T; t++) {
-            const uint32_t q = base + 64u * t + lane;
-            const uint32_t qc = q < qb ? q : (qb ? qb - 1u : 0u);
-            r[t] = rec[qc];
+        for (uint32_t k = 0; k < 4u; k++) {
+            const uint32_t q = base + 4u * lane + k;
+            r[k] = rec[q < qb ? q : (qb ? qb - 1u : 0u)];
         }
+        float vc[4], vs[4], vq[4];
+        double vz[4];
 #pragma unroll
-        for (uint32_t t = 0; t < T; t++) {
-            if (64u * t >= n_here) break;                                   // (uniform)
-            const bool valid = base + 64u * t + lane < qb;
+        for (uint32_t k = 0; k < 4u; k++) {
+            const bool valid = base + 4u * lane + k < qb;
             float sn_t, cs_t;
-            local_trig(r[t].z, inv_Ln, &sn_t, &cs_t);
-            const float vc = valid ? cs_t : 0.0f, vs = valid ? sn_t : 0.0f;
-            const double vz = valid ? (double)r[t].z : 0.0;
-            const float dq = r[t].z - z_mid, vq = valid ? dq * dq : 0.0f;
+            local_trig(r[k].z, inv_Ln, &sn_t, &cs_t);
+            vc[k] = valid ? cs_t : 0.0f;
+            vs[k] = valid ? sn_t : 0.0f;
+            vz[k] = valid ? (double)r[k].z : 0.0;
+            const float dq = r[k].z - z_mid;
+            vq[k] = valid ? dq * dq : 0.0f;
             if (valid) {
-                zlo = fminf(zlo, r[t].z);
-                zhi = fmaxf(zhi, r[t].z);
-                nf |= ((r[t].x - r[t].x) + (r[t].y - r[t].y)) + (r[t].z - r[t].z) == 0.0f ? 0u : 1u;
+                zlo = fminf(zlo, r[k].z);
+                zhi = fmaxf(zhi, r[k].z);
+                nf |= ((r[k].x - r[k].x) + (r[k].y - r[k].y)) + (r[k].z - r[k].z) == 0.0f ? 0u : 1u;
             }
-            float ic = vc, is = vs, iq = vq;
-            double iz = vz;
-            ic = row_add<0x111>(ic); is = row_add<0x111>(is); iz = row_add_f64<0x111>(iz); iq = row_add<0x111>(iq);
-            ic = row_add<0x112>(ic); is = row_add<0x112>(is); iz = row_add_f64<0x112>(iz); iq = row_add<0x112>(iq);
-            ic = row_add<0x114>(ic); is = row_add<0x114>(is); iz = row_add_f64<0x114>(iz); iq = row_add<0x114>(iq);
-            ic = row_add<0x118>(ic); is = row_add<0x118>(is); iz = row_add_f64<0x118>(iz); iq = row_add<0x118>(iq);
-            float bc = 0.0f, bs = 0.0f, bq = 0.0f;
-            double bz = 0.0;
-#pragma unroll
-            for (int r4 = 0; r4 < 3; r4++) {              // (the rows' totals by v_readlane: a __shfl is a trip through the LDS each)
-                const float tc = lane_value(ic, 16 * r4 + 15), ts = lane_value(is, 16 * r4 + 15), tq = lane_value(iq, 16 * r4 + 15);
-                const double tz = lane_value(iz, 16 * r4 + 15);
-                if ((int)(lane >> 4) > r4) { bc += tc; bs += ts; bz += tz; bq += tq; }
-            }
-            ic += bc; is += bs; iz += bz; iq += bq;                         // inclusive over the 64 lanes
-            pc[64u * t + lane] = carry_c + (ic - vc);                       // records of the row before this one
-            ps[64u * t + lane] = carry_s + (is - vs);
-            pz[64u * t + lane] = carry_z + (iz - vz);
-            pq[64u * t + lane] = carry_q + (iq - vq);
-            carry_c += lane_value(ic, 63);
-            carry_s += lane_value(is, 63);
-            carry_z += lane_value(iz, 63);
-            carry_q += lane_value(iq, 63);
         }
+        // the lane's own running sums: x1 = v0, x2 = v0 + v1, x3 = (v0 + v1) + v2, total = x3 + v3
+        const float c1 = vc[0], c2 = c1 + vc[1], c3 = c2 + vc[2], tc = c3 + vc[3];
+        const float s1 = vs[0], s2 = s1 + vs[1], s3 = s2 + vs[2], ts = s3 + vs[3];
+        const float q1 = vq[0], q2 = q1 + vq[1], q3 = q2 + vq[2], tq = q3 + vq[3];
+        const double z1 = vz[0], z2 = z1 + vz[1], z3 = z2 + vz[2], tz = z3 + vz[3];
+        float ic = tc, is = ts, iq = tq;
+        double iz = tz;
+        ic = row_add<0x111>(ic); is = row_add<0x111>(is); iz = row_add_f64<0x111>(iz); iq = row_add<0x111>(iq);
+        ic = row_add<0x112>(ic); is = row_add<0x112>(is); iz = row_add_f64<0x112>(iz); iq = row_add<0x112>(iq);
+        ic = row_add<0x114>(ic); is = row_add<0x114>(is); iz = row_add_f64<0x114>(iz); iq = row_add<0x114>(iq);
+        ic = row_add<0x118>(ic); is = row_add<0x118>(is); iz = row_add_f64<0x118>(iz); iq = row_add<0x118>(iq);
+        float bc = 0.0f, bs = 0.0f, bq = 0.0f;
+        double bz = 0.0;
+#pragma unroll
+        for (int r4 = 0; r4 < 3; r4++) {              // (the rows' totals by v_readlane: a __shfl is a trip through the LDS each)
+            const float rc = lane_value(ic, 16 * r4 + 15), rs = lane_value(is, 16 * r4 + 15), rq = lane_value(iq, 16 * r4 + 15);
+            const double rz = lane_value(iz, 16 * r4 + 15);
+            if ((int)(lane >> 4) > r4) { bc += rc; bs += rs; bz += rz; bq += rq; }
+        }
+        ic += bc; is += bs; iz += bz; iq += bq;                             // inclusive over the 64 lanes' totals
+        const float ec = carry_c + (ic - tc), es = carry_s + (is - ts), eq = carry_q + (iq - tq);   // records of the row before this lane's
+        const double ez = carry_z + (iz - tz);
+        *reinterpret_cast<float4 *>(pc + 4u * lane) = make_float4(ec, ec + c1, ec + c2, ec + c3);
+        *reinterpret_cast<float4 *>(ps + 4u * lane) = make_float4(es, es + s1, es + s2, es + s3);
+        *reinterpret_cast<float4 *>(pq + 4u * lane) = make_float4(eq, eq + q1, eq + q2, eq + q3);
+        *reinterpret_cast<double2 *>(pz + 4u * lane) = make_double2(ez, ez + z1);
+        *reinterpret_cast<double2 *>(pz + 4u * lane + 2u) = make_double2(ez + z2, ez + z3);
+        carry_c += lane_value(ic, 63);
+        carry_s += lane_value(is, 63);
+        carry_z += lane_value(iz, 63);
+        carry_q += lane_value(iq, 63);
         if (lane == 0u) { pc[n_here] = carry_c; ps[n_here] = carry_s; pz[n_here] = carry_z; pq[n_here] = carry_q; }   // behind the piece's last record
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1094,8 +1108,9 @@ __device__ __forceinline__ void local_finfo_merge(const LocalArgs &a, uint32_t s
 // membrane: neither the waves in flight nor the round trips per row bound this kernel; 256 keeps the LDS small)
 constexpr uint32_t kRowPrefixPiece = 256;
 __global__ __launch_bounds__(256) void k_local_rowprefix(LocalArgs a) {
-    __shared__ float l_c[4][kRowPrefixPiece + 1], l_s[4][kRowPrefixPiece + 1], l_q[4][kRowPrefixPiece + 1];
-    __shared__ double l_z[4][kRowPrefixPiece + 1];
+    // (+ 1 for the sums behind a full piece's last record; rows 16 bytes apart in size: the lanes store four values at once)
+    __shared__ alignas(16) float l_c[4][kRowPrefixPiece + 4], l_s[4][kRowPrefixPiece + 4], l_q[4][kRowPrefixPiece + 4];
+    __shared__ alignas(16) double l_z[4][kRowPrefixPiece + 2];
     const uint32_t s = blockIdx.y, wave = threadIdx.x >> 6, ra = blockIdx.x * 4u + wave;
     const uint4 g = a.grid[s];
     const uint32_t nca = g.x, ncs = local_row_stride(a, g.y, g.w);
