@@ -1914,6 +1914,14 @@ int gorder_hip_reset(gorder_hip_handle *h) {
         h->spec_batches = h->spec_fixed = h->spec_exact_frames = 0;
         HIP_TRY(h, hipMemsetAsync(h->d_spec_counters, 0, 4 * sizeof(uint32_t), h->stream));
     }
+    // likewise k_local_decide: a new run tries the bound again (a report still in flight is read, and dropped)
+    if (h->d_lsummary) {
+        if (h->lsummary_pending) { (void)hipEventSynchronize(h->lsummary_written); h->lsummary_pending = false; }
+        h->decide_pause = 0;
+        h->decide_submits = h->decide_paused_submits = 0;
+        h->h_lsummary[0] = h->h_lsummary[1] = 0u;
+        HIP_TRY(h, hipMemsetAsync(h->d_lsummary, 0, 2 * sizeof(uint32_t), h->stream));
+    }
     return GORDER_OK;
 }
 

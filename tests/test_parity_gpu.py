@@ -962,6 +962,8 @@ def test_local_decide_pauses_when_it_leaves_the_frames_open(built, monkeypatch):
     st = eng.local_decide_stats()
     assert st["submits"] == 1 and st["paused"] == 4
     assert st["open_frames"] == st["frames"] == 4
+    eng.reset()                                 # a new run tries the bound again
+    assert eng.local_decide_stats() == {"submits": 0, "paused": 0, "open_frames": 0, "frames": 0}
     _, want = run_oracle(system, xyz, system.box9(n))
     _sums_equal(got, want)
     monkeypatch.setenv("GORDER_HIP_LOCAL_NO_DECIDE", "1")
