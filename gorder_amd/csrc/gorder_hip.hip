@@ -11,7 +11,7 @@
 //   SystemLeafletClassification::run   leaflets.rs:171-205           -> k_leaflets_global
 //   common_identify_leaflet            leaflets.rs:711-732              (same kernel)
 //   IndividualClassification           leaflets.rs:777-801           -> k_leaflets_individual
-//   LocalClassification + local centres leaflets.rs:661-675, pbc.rs:273-318 -> k_local_{bin,scan,scatter,flags}
+//   LocalClassification + local centres leaflets.rs:661-675, pbc.rs:273-318 -> k_local_{build,rowprefix,decide,flags_rows,flags_todo} (k_local_{bin,scan,scatter,flags}: very large membranes, no box)
 //   should_assign / get_assigned       leaflets.rs:435-441, 1437-1472   (host: assignment-row table)
 //   SystemTopology::add / reduce       topology/mod.rs:236-272          (integer sums: order-free)
 //
