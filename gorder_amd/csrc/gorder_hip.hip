@@ -1394,9 +1394,13 @@ static int run_leaflets(gorder_hip_handle *h, const float *d_xyz, const float *d
         // the bound first, a lane per head (k_local_decide); the rows kernel then only for the frames with a head left open
         bool decide = lo.halo && lo.prune && lo.n_mol_total && !env_flag("GORDER_HIP_LOCAL_NO_DECIDE");
         if (decide) {
-            if (h->lsummary_pending && hipEventQuery(h->lsummary_written) == hipSuccess) {
-                h->lsummary_pending = false;
-                if (2u * h->h_lsummary[0] > h->h_lsummary[1]) h->decide_pause = gorder_hip_handle::kDecidePause;
+            if (h->lsummary_pending) {
+                if (hipEventQuery(h->lsummary_written) == hipSuccess) {
+                    h->lsummary_pending = false;
+                    if (2u * h->h_lsummary[0] > h->h_lsummary[1]) h->decide_pause = gorder_hip_handle::kDecidePause;
+                } else {
+                    (void)hipGetLastError();        // (hipErrorNotReady is an answer, not a failure of this submit)
+                }
             }
             if (h->decide_pause) { h->decide_pause--; h->decide_paused_submits++; decide = false; }
             else h->decide_submits++;

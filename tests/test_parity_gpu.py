@@ -970,3 +970,18 @@ def test_local_decide_pauses_when_it_leaves_the_frames_open(built, monkeypatch):
     eng2, got2 = _submit_in_batches(system, xyz, system.box9(n), 5)
     assert eng2.local_decide_stats()["submits"] == 0
     _sums_equal(got, got2)
+
+
+def test_local_decide_reports_arrive_whenever_they_arrive(built, monkeypatch):
+    """Submits queued back to back (no wait in between): the report of one is read by whichever later submit finds it
+    there; when that is only changes which kernels run, never the sums."""
+    system = synthetic.cg_membrane(700, leaflets=LEAFLETS_LOCAL, radius=2.5, n_types=2)
+    n = 32
+    xyz = system.frames(n, seed=79)
+    monkeypatch.setenv("GORDER_HIP_LOCAL_DECIDE_NOTHING", "1")
+    eng, got = run_gpu(system, xyz, system.box9(n), batches=8)
+    monkeypatch.delenv("GORDER_HIP_LOCAL_DECIDE_NOTHING")
+    st = eng.local_decide_stats()
+    assert st["submits"] >= 1 and st["submits"] + st["paused"] == 8
+    _, want = run_oracle(system, xyz, system.box9(n))
+    _sums_equal(got, want)
