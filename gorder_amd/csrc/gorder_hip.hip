@@ -1202,6 +1202,8 @@ int gorder_hip_create(const gorder_tables_t *t, gorder_hip_handle **out) {
                 HIP_TRY(h, hipEventCreateWithFlags(&h->lsummary_written, hipEventDisableTiming));
                 HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_local_decide), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)kDecideLds));
+                HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_local_sums), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)kSumsLds));
                 HIP_TRY(h, hipMalloc((void **)&h->d_ltodo, (1 + sl * (size_t)(p.n_mol_total ? p.n_mol_total : 1)) * sizeof(uint2)));
             }
         }
@@ -1406,6 +1408,9 @@ static int run_leaflets(gorder_hip_handle *h, const float *d_xyz, const float *d
             else h->decide_submits++;
         }
         lo.need = decide ? h->d_lneed : nullptr;
+        // ... and the table that kernel reads made from per-cell sums first (k_local_sums): the cell list only for the frames left open
+        lo.sums = decide && lf.n_membrane <= kLocalBuildMax && !env_flag("GORDER_HIP_LOCAL_THREE_KERNELS") &&
+                  !env_flag("GORDER_HIP_LOCAL_NO_SUMS") ? 1 : 0;
         const bool report = decide && !h->lsummary_pending;      // (one report in flight)
         lo.summary = report ? h->d_lsummary : nullptr;
         for (size_t done = 0; done < aframes.size(); done += h->local_slab) {
@@ -1417,13 +1422,20 @@ static int run_leaflets(gorder_hip_handle *h, const float *d_xyz, const float *d
             lo.summary_host = report && done + ns == aframes.size() ? h->h_lsummary : nullptr;
             if (lf.n_membrane > kLocalBuildMax || env_flag("GORDER_HIP_LOCAL_THREE_KERNELS"))
                 HIP_TRY(h, hipMemsetAsync(h->d_lcell_fill, 0, ns * ncell * sizeof(uint32_t), h->stream));
+            if (lo.sums) {
+                HIP_TRY(h, hipMemsetAsync(h->d_lneed, 0, (ns + 1) * sizeof(uint32_t), h->stream));
+                TIMING_MARK(h, "k_local_sums");
+                hipLaunchKernelGGL(k_local_sums, dim3(ns), dim3(1024), kSumsLds, h->stream, lo);
+                TIMING_MARK(h, "k_local_decide");
+                hipLaunchKernelGGL(k_local_decide, dim3(ns), dim3(1024), kDecideLds, h->stream, lo);
+            }
             const int cst = launch_cell_list(h, lo, ns, lf.n_membrane, h->d_lcell_count, ns * (ncell + 1) * sizeof(uint32_t));
             if (cst != GORDER_OK) return cst;
             if (lo.halo) {
                 TIMING_MARK(h, "k_local_rowprefix");
                 hipLaunchKernelGGL(k_local_rowprefix, dim3(kLocalMaxCells1D / 4u, ns), dim3(256), 0, h->stream, lo);
                 lo.rows_groups = (lo.n_mol_total + 15u) / 16u;
-                if (lo.need) {
+                if (lo.need && !lo.sums) {
                     TIMING_MARK(h, "k_local_decide");
                     hipLaunchKernelGGL(k_local_decide, dim3(ns), dim3(1024), kDecideLds, h->stream, lo);
                 }

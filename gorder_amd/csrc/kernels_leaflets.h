@@ -746,6 +746,7 @@ struct LocalArgs {
     float4 *finfo;              // [n_slab] (min, max of the membrane's normal coordinate, 1 if every coordinate is finite, -)
     uint2 *todo;                // [1 + n_slab * n_mol_total] with agg: {count, -} then the (slab frame, head) pairs
                                 // k_local_flags_rows leaves to k_local_flags_todo
+    int sums;                   // the slab starts with k_local_sums: k_local_build / k_local_rowprefix then only do the frames with need[s] != 0
     uint32_t *summary;          // {frames k_local_decide left open, frames it saw} summed over the slabs of a submit (k_local_flags_todo), or null
     uint32_t *summary_host;     // the last slab of a submit: where (pinned host memory) the two sums go, or null
     uint32_t *need;             // [n_slab + 1] heads of the frame k_local_decide left open (zeroed by k_local_rowprefix; the last word: any of the slab); k_local_flags_rows
@@ -1121,8 +1122,10 @@ __global__ __launch_bounds__(256) void k_local_rowprefix(LocalArgs a) {
     const uint32_t s = blockIdx.y, wave = threadIdx.x >> 6, ra = blockIdx.x * 4u + wave;
     const uint4 g = a.grid[s];
     const uint32_t nca = g.x, ncs = local_row_stride(a, g.y, g.w);
-    if (blockIdx.x == 0 && s == 0 && threadIdx.x == 0) a.todo[0] = make_uint2(0u, 0u);        // this slab's list starts empty
-    if (blockIdx.x == 0 && threadIdx.x == 0 && a.need) {                                        // nothing of this frame left open yet
+    if (a.sums) {                                   // behind k_local_sums + k_local_decide: the frames with a head left open only
+        if (a.need[a.n_slab] == 0u || a.need[s] == 0u) return;
+    } else if (blockIdx.x == 0 && s == 0 && threadIdx.x == 0) a.todo[0] = make_uint2(0u, 0u);   // this slab's list starts empty
+    if (!a.sums && blockIdx.x == 0 && threadIdx.x == 0 && a.need) {                              // nothing of this frame left open yet
         a.need[s] = 0u;
         if (s == 0) a.need[a.n_slab] = 0u;                                                      // (nor of the slab: the word behind the frames')
     }
@@ -1162,6 +1165,7 @@ __global__ __launch_bounds__(1024) void k_local_build(LocalArgs a) {
     __shared__ uint32_t l_over;
     uint32_t *l_start = l_build, *l_fill = l_build + kLocalMaxCells1D * kLocalMaxCells1D;
     const uint32_t s = blockIdx.x, tid = threadIdx.x;
+    if (a.sums && (a.need[a.n_slab] == 0u || a.need[s] == 0u)) return;      // behind k_local_sums + k_local_decide: open frames only
     const uint32_t f = a.aframes ? a.aframes[s] : a.frame0 + s;
     float box[3];
     frame_box(a, f, box);
@@ -2023,6 +2027,152 @@ __global__ __launch_bounds__(256) void k_local_flags_rows_open(LocalArgs a) {
     }
 }
 
+// The table of cell edges WITHOUT the cell list.  k_local_decide reads nothing else, and where it decides every head of a
+// frame (the usual case) the sorted records, the cell starts and the f64 row sums of k_local_build / k_local_rowprefix —
+// 60 % of the step — are made for nobody.  The edge entries are sums over cells, and sums do not need the atoms in order:
+// a workgroup per frame adds every membrane atom into its cell's two 64-bit words in LDS (fixed point; one pass, two LDS
+// atomics an atom, nothing kept per atom), then a wave per row of cells scans the row's cells — integers, so the order of the
+// atomics does not show — and writes the entries, halo columns included.  Frames that keep a head open (need[s] != 0 after
+// k_local_decide; the frame whose distances are exported is one) get their cell list and row sums from k_local_build and
+// k_local_rowprefix as before — those kernels leave at once for the other frames — and k_local_rowprefix overwrites the
+// frame's entries with its own.
+//   word A = sum of rint((z - L/2 + 8) 2^15) << 32 | sum of rint((z - L/2)^2 2^13)          (|z - L/2| < 8 nm, or the frame is left open)
+//   word B = count << 42 | sum of rint((cos + 1) 2^8) << 21 | sum of rint((sin + 1) 2^8)    (4 095 atoms a cell, or the frame is left open)
+// block = 1024 threads; grid = n_slab; dynamic LDS = kSumsLds (frames with more than kSumsCells cells are left open).
+constexpr uint32_t kSumsCells = 9000;
+constexpr uint32_t kSumsLds = kSumsCells * 2u * (uint32_t)sizeof(unsigned long long);
+__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v, uint32_t lane) {         // inclusive, over the 64 lanes
+    v = row_add_u32<0x111>(v); v = row_add_u32<0x112>(v); v = row_add_u32<0x114>(v); v = row_add_u32<0x118>(v);
+    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 15), t1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 31),
+                   t2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 47);
+    const uint32_t r = lane >> 4;
+    return v + (r > 0u ? t0 : 0u) + (r > 1u ? t1 : 0u) + (r > 2u ? t2 : 0u);
+}
+__device__ __forceinline__ double wave_scan_f64(double v, uint32_t lane) {             // (exact: the values are integers below 2^53)
+    v = row_add_f64<0x111>(v); v = row_add_f64<0x112>(v); v = row_add_f64<0x114>(v); v = row_add_f64<0x118>(v);
+    const double t0 = lane_value(v, 15), t1 = lane_value(v, 31), t2 = lane_value(v, 47);
+    const uint32_t r = lane >> 4;
+    return v + (r > 0u ? t0 : 0.0) + (r > 1u ? t1 : 0.0) + (r > 2u ? t2 : 0.0);
+}
+__global__ __launch_bounds__(1024) void k_local_sums(LocalArgs a) {
+    extern __shared__ unsigned long long l_sums[];
+    __shared__ float l_zlo[16], l_zhi[16];
+    __shared__ uint32_t l_flag[16];
+    const uint32_t s = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t f = a.aframes ? a.aframes[s] : a.frame0 + s;
+    float box[3];
+    frame_box(a, f, box);
+    uint32_t nca, ncb, ka, kb;
+    int da, db;
+    local_grid(a, box, nca, ncb, da, db, ka, kb);
+    const uint32_t ncs = local_row_stride(a, ncb, kb), n_base = nca * ncb;
+    const int dn = (int)a.dim;
+    if (tid == 0u) a.grid[s] = make_uint4(nca, ncb, ka, kb);
+    if (!(a.pbc && ka >= 1u && kb >= 1u && n_base <= kSumsCells)) {          // (uniform) not a grid for this kernel: the frame is left open
+        if (tid == 0u) { local_finfo_init(a, s); a.need[s] = 1u; a.need[a.n_slab] = 1u; }
+        return;
+    }
+    unsigned long long *l_a = l_sums, *l_b = l_sums + n_base;
+    for (uint32_t k = tid; k < 2u * n_base; k += 1024u) l_sums[k] = 0ull;
+    __syncthreads();
+    const float *x = a.xyz + (size_t)f * a.n_atoms * 3u;
+    const float La = box[da], Lb = box[db], Ln = box[dn];
+    const float inv_a = (float)nca / La, inv_b = (float)ncb / Lb, inv_Ln = 1.0f / Ln, z_mid = 0.5f * Ln;
+    int bad = 0;
+    float zlo = 3.0e38f, zhi = -3.0e38f;
+    uint32_t flag = 0;                                  // 1: a coordinate is not finite; 2: an atom the fixed point has no room for
+    constexpr uint32_t U = 8;
+    for (uint32_t i0 = tid; i0 < a.n_membrane; i0 += U * 1024u) {           // (uniform trip count up to the last trip's tail)
+        uint32_t at[U];
+        float pa[U], pb[U], pn[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) { const uint32_t i = min(i0 + u * 1024u, a.n_membrane - 1u); at[u] = a.membrane ? a.membrane[i] : i; }
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) {
+            pa[u] = x[3u * (size_t)at[u] + da]; pb[u] = x[3u * (size_t)at[u] + db]; pn[u] = x[3u * (size_t)at[u] + dn];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) {
+            if (i0 + u * 1024u >= a.n_membrane) continue;
+            // the atom's cell: k_local_build's arithmetic (cell_ab)
+            float wa = pa[u] > La ? pa[u] - La : pa[u], wb = pb[u] > Lb ? pb[u] - Lb : pb[u];
+            wa = wa < 0.0f ? wa + La : wa;
+            wb = wb < 0.0f ? wb + Lb : wb;
+            if (__builtin_expect(!(wa >= 0.0f && wa <= La && wb >= 0.0f && wb <= Lb), 0)) {
+                wa = gm_wrap(pa[u], La, bad);
+                wb = gm_wrap(pb[u], Lb, bad);
+            }
+            const uint32_t ca = (uint32_t)fminf(fmaxf(floorf(wa * inv_a), 0.0f), (float)(nca - 1u));
+            const uint32_t cb = (uint32_t)fminf(fmaxf(floorf(wb * inv_b), 0.0f), (float)(ncb - 1u));
+            const float z = pn[u], zm = z - z_mid;
+            float sn, cs;
+            local_trig(z, inv_Ln, &sn, &cs);
+            const bool finite = ((pa[u] - pa[u]) + (pb[u] - pb[u])) + (z - z) == 0.0f;
+            const bool room = zm > -8.0f && zm < 8.0f;
+            flag |= (finite ? 0u : 1u) | (room ? 0u : 2u);
+            zlo = fminf(zlo, z);
+            zhi = fmaxf(zhi, z);
+            if (finite && room) {
+                const unsigned long long wa64 = ((unsigned long long)(uint32_t)__builtin_rintf((zm + 8.0f) * 32768.0f) << 32) |
+                                                (unsigned long long)(uint32_t)__builtin_rintf(zm * zm * 8192.0f);
+                const unsigned long long wb64 = (1ull << 42) | ((unsigned long long)(uint32_t)__builtin_rintf((cs + 1.0f) * 256.0f) << 21) |
+                                                (unsigned long long)(uint32_t)__builtin_rintf((sn + 1.0f) * 256.0f);
+                atomicAdd(&l_a[ca * ncb + cb], wa64);
+                atomicAdd(&l_b[ca * ncb + cb], wb64);
+            }
+        }
+    }
+    if (bad) raise_box_range(a.err, f);
+    __syncthreads();
+    // ---- a wave per row of cells: the entries = exclusive sums along the row, the first 2 kb cells again behind the last
+    LocalEdge *out = a.edge + (size_t)s * (kLocalMaxCells1D * (kLocalMaxCells1D + 1u));
+    for (uint32_t ra = wave; ra < nca; ra += 16u) {
+        uint32_t c_n = 0, c_c = 0, c_s = 0;             // the sums of the chunks before (64 cells a chunk)
+        double c_z = 0.0, c_q = 0.0;
+        for (uint32_t j0 = 0; j0 <= ncs; j0 += 64u) {
+            const uint32_t j = j0 + lane, jb = j < ncb ? j : j - ncb;
+            unsigned long long va = 0ull, vb = 0ull;
+            if (j < ncs) { va = l_a[ra * ncb + jb]; vb = l_b[ra * ncb + jb]; }
+            const uint32_t n = (uint32_t)(vb >> 42), ci = (uint32_t)(vb >> 21) & 0x1fffffu, si = (uint32_t)vb & 0x1fffffu;
+            const double zi = (double)(uint32_t)(va >> 32), qi = (double)(uint32_t)va;
+            flag |= n > 4095u ? 2u : 0u;
+            const uint32_t i_n = wave_scan_u32(n, lane), i_c = wave_scan_u32(ci, lane), i_s = wave_scan_u32(si, lane);
+            const double i_z = wave_scan_f64(zi, lane), i_q = wave_scan_f64(qi, lane);
+            if (j <= ncs) {
+                const uint32_t e_n = c_n + (i_n - n);
+                const double e_z = c_z + (i_z - zi), e_q = c_q + (i_q - qi);
+                const float e_c = (float)(c_c + (i_c - ci)) * (1.0f / 256.0f) - (float)e_n;
+                const float e_s = (float)(c_s + (i_s - si)) * (1.0f / 256.0f) - (float)e_n;
+                LocalEdge e;
+                e.q = e_n;              // (relative to the row's first cell: k_local_decide takes differences inside a row only)
+                e.zm = (float)(e_z * (1.0 / 32768.0) - 8.0 * (double)e_n);
+                e.sq = (float)(e_q * (1.0 / 8192.0));
+                e.cs = local_edge_trig(e_c, e_s);
+                out[(size_t)ra * (ncs + 1u) + j] = e;
+            }
+            c_n += (uint32_t)__builtin_amdgcn_readlane((int)i_n, 63);
+            c_c += (uint32_t)__builtin_amdgcn_readlane((int)i_c, 63);
+            c_s += (uint32_t)__builtin_amdgcn_readlane((int)i_s, 63);
+            c_z += lane_value(i_z, 63);
+            c_q += lane_value(i_q, 63);
+        }
+    }
+    // ---- the frame's record: extrema of the normal coordinate, and whether the frame is for this kernel at all
+    for (int off = 32; off >= 1; off >>= 1) {
+        zlo = fminf(zlo, __shfl_xor(zlo, off, 64));
+        zhi = fmaxf(zhi, __shfl_xor(zhi, off, 64));
+        flag |= (uint32_t)__shfl_xor((int)flag, off, 64);
+    }
+    if (lane == 0u) { l_zlo[wave] = zlo; l_zhi[wave] = zhi; l_flag[wave] = flag; }
+    __syncthreads();
+    if (tid == 0u) {
+        for (uint32_t w = 1; w < 16u; w++) { zlo = fminf(zlo, l_zlo[w]); zhi = fmaxf(zhi, l_zhi[w]); flag |= l_flag[w]; }
+        reinterpret_cast<uint4 *>(a.finfo)[s] = zlo <= zhi ? make_uint4(local_float_key(zlo), local_float_key(zhi), flag & 1u, 2u)
+                                                            : make_uint4(0xffffffffu, 0u, flag & 1u, 2u);
+        if (flag) { a.need[s] = 1u; a.need[a.n_slab] = 1u; }          // (k_local_build makes the frame's record again, and everything else)
+    }
+}
+
 // The bound of k_local_flags_rows ("a head its ring cannot change") on its own, a LANE per head, the frame's table of cell
 // edges in the LDS.  In the rows kernel a head is the business of 16 lanes — one per row of cells, which is what its ring
 // loop wants —, and everything that is per head (its cell, the centre's estimate, the decision: two thirds of the ~390
@@ -2124,13 +2274,17 @@ __device__ __forceinline__ bool local_decide_head(const LocalArgs &a, const Deci
     const float T = c_z - fn * hm, A = r_z - fr * hm;
     const float B = __builtin_fmaxf((r_q - 2.0f * hm * r_z) + fr * hm * hm, 0.0f) * 1.02f + 1e-3f * fr;
     const float mid = T - 0.5f * A, rad = 0.5005f * __builtin_amdgcn_sqrtf(fr * B);
-    const float slack = 0.1f + fn * (1e-3f + 1e-6f * fn * Ln);
+    // (behind k_local_sums the table holds fixed-point sums: a candidate's z - L/2 rounded to 2^-16, its square to 2^-14, cos and
+    // sin to 2^-9 — 5e-5 n_c on T, taken from the slack; 1e-4 N on B, inside its 1e-3 N; 2e-3 n_c < 0.004 n_c on the resultant,
+    // counted among the unit vectors the two resultants may differ by)
+    const float slack = 0.1f + fn * (1.05e-3f + 1e-6f * fn * Ln);
     const float r_c = __builtin_amdgcn_sqrtf(c_c * c_c + c_s * c_s);
     const float est_c = (local_atan2_fast(-c_s, -c_c) + 3.1415927f) * (Ln * 0.15915494f);
     const float shift_c = gm_min_image(hn_pos - est_c, Ln, bad);
-    const float xr = (fr + 1.0f) * __builtin_amdgcn_rcpf(r_c);              // asin(x) <= x + (pi / 2 - 1) x^3 on [0, 1]
+    const float e_c = fr + 1.0f + 0.004f * fn;
+    const float xr = e_c * __builtin_amdgcn_rcpf(r_c);                      // asin(x) <= x + (pi / 2 - 1) x^3 on [0, 1]
     const float emargin = 1e-4f * Ln + (xr + 0.5708f * xr * xr * xr) * (0.15916f * Ln);
-    const bool same_image = fr + 1.0f < r_c && ulo_g + shift_c > -halfn + emargin && uhi_g + shift_c < halfn - emargin;
+    const bool same_image = e_c < r_c && ulo_g + shift_c > -halfn + emargin && uhi_g + shift_c < halfn - emargin;
     const bool head_near = __builtin_fabsf(mid) + rad < (halfn - 1e-3f * Ln) * fi;
     centre_above = mid > 0.0f;         // S > 0: the centre lies above the head, d = z_head - centre < 0
     // (prune == 2, GORDER_HIP_LOCAL_DECIDE_NOTHING: a measuring aid — what a membrane costs whose heads the bound cannot decide)
@@ -2169,7 +2323,8 @@ __global__ __launch_bounds__(1024) void k_local_decide(LocalArgs a) {
     F.z_min = local_key_float(fk.x); F.z_max = local_key_float(fk.y);
     // (uniform) frames the bound does not apply to — the conditions of k_local_flags_rows — and the frame whose distances are wanted
     const bool fail = !(F.ka >= 1u && F.kb >= 1u && F.n_rows <= 16u && fk.z == 0u && fk.x <= fk.y);
-    if (fail || !(F.z_max - F.z_min < 0.75f * F.Ln) || (int)s == a.write_dist_frame) {
+    if (a.sums && s == 0u && threadIdx.x == 0u) a.todo[0] = make_uint2(0u, 0u);                 // this slab's list starts empty
+    if (fail || !(F.z_max - F.z_min < 0.75f * F.Ln) || (int)s == a.write_dist_frame || (a.sums && a.need[s] != 0u)) {
         if (threadIdx.x == 0u) { atomicAdd(&a.need[s], 1u); a.need[a.n_slab] = 1u; }
         return;
     }
