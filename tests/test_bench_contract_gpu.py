@@ -54,7 +54,7 @@ def test_single_gpu_line(built):
 
 
 @pytest.mark.parametrize("workload,dominant,others", [
-    ("cg3k-local", "k_local_build", {"k_local_rowprefix", "k_local_decide", "k_local_flags_rows", "k_local_flags_todo", "k_bonds_tiled", "k_batch_end"}),
+    ("cg3k-local", "k_local_sums", {"k_local_build", "k_local_rowprefix", "k_local_decide", "k_local_flags_rows", "k_local_flags_todo", "k_bonds_tiled", "k_batch_end"}),
     ("aa256-leaflets", None, {"k_leaflets_global_contig", "k_bonds_tiled", "k_batch_end"}),
     ("ua256-maps", "k_ua_extras", {"k_map_accumulate", "k_batch_end"})])
 def test_the_roofline_names_the_longest_kernel_group(built, workload, dominant, others):

@@ -985,3 +985,39 @@ def test_local_decide_reports_arrive_whenever_they_arrive(built, monkeypatch):
     assert st["submits"] >= 1 and st["submits"] + st["paused"] == 8
     _, want = run_oracle(system, xyz, system.box9(n))
     _sums_equal(got, want)
+
+
+# ---- k_local_sums: the table of cell edges from per-cell fixed-point sums, the cell list only for frames left open ----
+@pytest.mark.parametrize("case", ["plain", "tall box", "crowded cell", "unwrapped z"])
+def test_local_sums_and_the_cell_list_agree(built, monkeypatch, case):
+    """k_local_sums + k_local_decide against the same frames through k_local_build + k_local_rowprefix for every frame
+    (GORDER_HIP_LOCAL_NO_SUMS=1), and the oracle.  'tall box': atoms more than 8 nm from the middle of the box (the fixed
+    point's range) — 'crowded cell': more than 4 095 atoms in one cell (its count's) —: such frames are left open and take
+    the cell list; 'unwrapped z': lipids whole boxes away along the normal."""
+    box = {"plain": None, "tall box": (16.0, 16.0, 24.0), "crowded cell": (16.0, 16.0, 10.0), "unwrapped z": None}[case]
+    system = synthetic.cg_membrane(900 if case == "plain" else 600, leaflets=LEAFLETS_LOCAL, radius=2.0 if case == "crowded cell" else 2.5,
+                                   n_types=2, box=box)
+    n = 10
+    xyz = system.frames(n, seed=83)
+    rng = np.random.default_rng(9)
+    if case == "tall box":
+        xyz[4:, 12 * 5:12 * 6, 2] += 9.5                    # one lipid far up, from frame 4 on (still inside the box)
+    if case == "crowded cell":
+        crowd = rng.choice(xyz.shape[1], 5000, replace=False)
+        xyz[2:7, crowd, 0] = (5.03 + rng.normal(0, 0.004, (5, 5000))).astype(np.float32)
+        xyz[2:7, crowd, 1] = (9.41 + rng.normal(0, 0.004, (5, 5000))).astype(np.float32)
+    if case == "unwrapped z":
+        xyz[3:, 12 * 7:12 * 9, 2] += 2 * system.box[2]
+        xyz[6:, 12 * 40:12 * 41, 2] -= 3 * system.box[2]
+    eng, got = run_gpu(system, xyz, system.box9(n), batches=2)
+    assert eng.local_decide_stats()["submits"] == 2
+    monkeypatch.setenv("GORDER_HIP_LOCAL_NO_SUMS", "1")
+    _, lists = run_gpu(system, xyz, system.box9(n), batches=2)
+    monkeypatch.delenv("GORDER_HIP_LOCAL_NO_SUMS")
+    _sums_equal(got, lists)
+    assert got.counts[1].sum() > 0 and got.counts[2].sum() > 0
+    if case != "crowded cell":              # (5 000 atoms on one spot: the oracle's f32 sums and the device's f64 ones may part)
+        _, want = run_oracle(system, xyz, system.box9(n))
+        _sums_equal(got, want)
+    else:
+        assert_sums_given_device_flags(system.tables, xyz, system.box9(n), got, max_flag_diffs=8)
