@@ -663,9 +663,11 @@ __global__ __launch_bounds__(256) void k_leaflets_individual(LeafletArgs a) {
 //   k_local_scatter : per (slab frame, membrane atom): cell-ordered record (coordinates + cos/sin)
 //   k_local_flags   : one wave per (slab frame, head): two passes over the 3x3 neighbour cells
 // In a periodic box (the usual case; "halo" below) the pipeline is, per slab of up to 512 assignment frames:
-//   k_local_build           : bin + scan + scatter in one kernel, a workgroup per frame (membranes of up to 65 536 atoms)
-//   k_local_rowprefix       : running sums along every row of cells: LocalRowPre (exact centres), LocalEdge (the bound)
+//   k_local_sums            : per-cell fixed-point sums by LDS atomics -> the LocalEdge table, no cell list
 //   k_local_decide          : a lane per head: the side from a bound on what the ring of cut cells can change, where it holds
+//   -- for the frames with a head left open only (their workgroups leave at once otherwise):
+//   k_local_build           : bin + scan + scatter in one kernel, a workgroup per frame (membranes of up to 65 536 atoms)
+//   k_local_rowprefix       : running sums along every row of cells: LocalRowPre (exact centres), LocalEdge again
 //   k_local_flags_rows_open : the frames with a head left open, every head of them: 16 lanes per head, inner cells from the
 //                             sums, ring atoms one by one (k_local_flags_rows: the same for every frame, without k_local_decide)
 //   k_local_flags_todo      : the general passes (k_local_flags' code) for heads the rows cannot do

@@ -456,8 +456,9 @@ int gorder_hip_plan_tables(const gorder_tables_t *tables, gorder_hip_plan_t *pla
 int gorder_hip_speculation_stats(gorder_hip_handle *h, uint64_t out[4]);
 
 /* Local leaflets in a periodic box: a kernel of its own (k_local_decide) first tries every head against a bound on what the
- * atoms in the ring of cells the cylinder cuts can change about its side, and a frame whose heads it all decides skips the
- * pass that looks at those atoms.  A submit that finds the majority of its frames left open — a membrane
+ * atoms in the ring of cells the cylinder cuts can change about its side — from per-cell sums made without sorting the
+ * atoms (k_local_sums) —, and a frame whose heads it all decides skips the cell list and the pass that looks at those
+ * atoms.  A submit that finds the majority of its frames left open — a membrane
  * that undulates by more than the water around it allows — sends the next 16 submits down the atom-by-atom pass alone.
  * The sides are the reference's either way.  out[0] = submits that ran the bound kernel, out[1] = submits that paused it,
  * out[2] / out[3] = frames left open / frames seen in the last report read back.  (GORDER_HIP_LOCAL_NO_DECIDE=1: never.)
