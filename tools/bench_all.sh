@@ -15,6 +15,7 @@ GORDER_HIP_NO_SPECULATE=1 run aa256-leaflets-timewise 3000 50 40
 run aa256-maps 3000 50 40
 run cg3k 4000 100 60
 run cg3k-local 512 10 4
+run cg3k-local 10000 40 5             # 20 slabs a submit: the frame whose distances are exported is one in 10 000
 run ua256 3000 50 40
 run ua256-maps 3000 50 30
 run ua256-fast 3000 50 40
