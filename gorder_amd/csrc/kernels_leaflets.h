@@ -2043,6 +2043,15 @@ __global__ __launch_bounds__(256) void k_local_flags_rows_open(LocalArgs a) {
 // block = 1024 threads; grid = n_slab; dynamic LDS = kSumsLds (frames with more than kSumsCells cells are left open).
 constexpr uint32_t kSumsCells = 9000;
 constexpr uint32_t kSumsLds = kSumsCells * 2u * (uint32_t)sizeof(unsigned long long);
+// an atom more than a box length outside the box in the plane (rare): gm_wrap's loops, once for the whole kernel
+struct LocalWrapped { float a, b; int bad; };
+__device__ __attribute__((noinline)) LocalWrapped local_wrap_far(float xa, float xb, float La, float Lb) {
+    LocalWrapped w;
+    w.bad = 0;
+    w.a = gm_wrap(xa, La, w.bad);
+    w.b = gm_wrap(xb, Lb, w.bad);
+    return w;
+}
 __device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v, uint32_t lane) {         // inclusive, over the 64 lanes
     v = row_add_u32<0x111>(v); v = row_add_u32<0x112>(v); v = row_add_u32<0x114>(v); v = row_add_u32<0x118>(v);
     const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 15), t1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 31),
@@ -2101,8 +2110,8 @@ __global__ __launch_bounds__(1024) void k_local_sums(LocalArgs a) {
             wa = wa < 0.0f ? wa + La : wa;
             wb = wb < 0.0f ? wb + Lb : wb;
             if (__builtin_expect(!(wa >= 0.0f && wa <= La && wb >= 0.0f && wb <= Lb), 0)) {
-                wa = gm_wrap(pa[u], La, bad);
-                wb = gm_wrap(pb[u], Lb, bad);
+                const LocalWrapped w = local_wrap_far(pa[u], pb[u], La, Lb);           // (out of line: eight inlined copies of
+                wa = w.a; wb = w.b; bad |= w.bad;                                        //  gm_wrap's loops were 70 % of this kernel's code)
             }
             const uint32_t ca = (uint32_t)fminf(fmaxf(floorf(wa * inv_a), 0.0f), (float)(nca - 1u));
             const uint32_t cb = (uint32_t)fminf(fmaxf(floorf(wb * inv_b), 0.0f), (float)(ncb - 1u));
