@@ -672,15 +672,16 @@ __global__ __launch_bounds__(256) void k_leaflets_individual(LeafletArgs a) {
 //                             sums, ring atoms one by one (k_local_flags_rows: the same for every frame, without k_local_decide)
 //   k_local_flags_todo      : the general passes (k_local_flags' code) for heads the rows cannot do
 constexpr uint32_t kLocalMaxCells1D = 128;
-// assignment frames processed per launch group: as many as fit 1 GiB of cell-list scratch, at most 512 (two rounds of
-// k_local_build's one block per frame and CU; 256 measured 4 % slower end to end — eight launches a group instead of
-// four per 512 frames —, 128 20 % slower)
-constexpr uint32_t kLocalSlabMax = 512;
+// assignment frames processed per launch group: as many as fit 4 GiB of cell-list scratch, at most 2048.  (A group costs
+// seven launches and ~36 us of kernels that find nothing to do whatever its size: 512 frames a group — 1 GiB — gave 1.85 M
+// frames/s on the 3 072-lipid membrane, 1 024 gave 1.97 M, 2 048 2.07 M; 256 had measured 4 % slower than 512, 128 20 %.
+// The scratch is sized for every frame of a group being left open; where k_local_decide decides the frames it stays untouched.)
+constexpr uint32_t kLocalSlabMax = 2048;
 inline uint32_t local_slab_frames(size_t n_membrane) {
     // (the heads' to-do list, 8 bytes per head and frame, is on top: heads are a fraction of the membrane atoms)
     // (records twice — the halo copies —, the cell of every atom, two tables of cell counts, the rows' two tables of sums)
     const size_t per_frame = n_membrane * (2u * 12u + 4u) + (size_t)(2 * 4u + 16u + 16u) * kLocalMaxCells1D * (kLocalMaxCells1D + 1u) + 32u;
-    const size_t n = ((size_t)1024 << 20) / per_frame;
+    const size_t n = ((size_t)4096 << 20) / per_frame;
     uint32_t cap = kLocalSlabMax;
     if (const char *ev = getenv("GORDER_HIP_LOCAL_SLAB")) cap = (uint32_t)std::max(4, atoi(ev));      // (A/B: frames per launch group)
     return (uint32_t)(n < 4 ? 4 : (n > cap ? cap : n));

@@ -460,7 +460,9 @@ int gorder_hip_speculation_stats(gorder_hip_handle *h, uint64_t out[4]);
  * atoms (k_local_sums) —, and a frame whose heads it all decides skips the cell list and the pass that looks at those
  * atoms.  A submit that finds the majority of its frames left open — a membrane
  * that undulates by more than the water around it allows — sends the next 16 submits down the atom-by-atom pass alone.
- * The sides are the reference's either way.  out[0] = submits that ran the bound kernel, out[1] = submits that paused it,
+ * The sides are the reference's either way.  (Device memory: a handle with local leaflets holds up to 4 GiB of cell-list
+ * scratch — 2 048 assignment frames a launch group, fewer for membranes that need more than 2 MB a frame;
+ * GORDER_HIP_LOCAL_SLAB=n caps the frames.)  out[0] = submits that ran the bound kernel, out[1] = submits that paused it,
  * out[2] / out[3] = frames left open / frames seen in the last report read back.  (GORDER_HIP_LOCAL_NO_DECIDE=1: never.)
  * Waits for the handle's stream. */
 int gorder_hip_local_decide_stats(gorder_hip_handle *h, uint64_t out[4]);
